@@ -1,0 +1,361 @@
+"""CPU oracle for the ContextFlow coupling-layer density path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-torch (CPU, fp32 or fp64) *restatement* of the reference's
+forward / inverse flow arithmetic.  It is NOT part of the product: only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it.
+The product path (`contextflow_amd/`) never does and fails loudly without its HIP
+library.
+
+Parity status: PINNED.  The reference holds no golden vectors of its own
+(SURVEY.md §4), so the pins are outputs of the reference itself, run in the build
+container by `tests/golden/make_golden.py` and committed as `tests/golden/*.npz`;
+`tests/test_oracle_golden.py` checks every function here against them.
+
+Every function cites the reference lines (relative to /root/reference/contextflow)
+whose arithmetic it restates.  The model is described by a flat *program* — a list
+of op tuples produced by `program()` — and a flat dict of tensors keyed with the
+reference's `state_dict` names, so no nn.Module is involved.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+LOG_2PI = math.log(2.0 * math.pi)
+ALPHA = 1e-4          # model.py:96
+K_COMPONENTS = 8      # model.py:115
+
+
+# --------------------------------------------------------------------------------------
+# topology  (model.py:95-163 restated as data)
+# --------------------------------------------------------------------------------------
+CONFIGS = {
+    # name: (data_size, mixtures, num_blocks, block_size, split_prior, coupling)   model.py:173-220
+    "mnist": ((1, 32, 32), 10, 2, 2, False, "conv"),
+    "cifar10": ((3, 32, 32), 10, 3, 4, True, "conv"),
+    "smap": ((25, 8, 1), 1, 2, 4, False, "trans"),
+}
+
+
+def program(dataset, data_size=None, mixtures=None, num_blocks=None, block_size=None,
+            split_prior=None, coupling=None):
+    """Layer list of `create_model` (model.py:95-163) for the generalist / context-free case.
+
+    Returns (ops, prior_size, mixtures).  Each op is a tuple whose 2nd element is the index
+    of the layer inside the reference's FlowSequential (= its state_dict key prefix).
+    """
+    d = CONFIGS[dataset]
+    data_size = data_size or d[0]
+    mixtures = mixtures or d[1]
+    num_blocks = num_blocks or d[2]
+    block_size = block_size or d[3]
+    split_prior = d[4] if split_prior is None else split_prior
+    coupling = coupling or d[5]
+    ts = dataset in ("atm", "msl", "smd", "smap")            # model.py:113
+    patch, krn, pad = ((2, 1), (3, 1), (1, 0)) if ts else ((2, 2), (3, 3), (1, 1))  # model.py:114
+    ops = []
+    if dataset in ("mnist", "cifar10"):                       # model.py:97-100
+        ops += [("dequant", 0), ("affine", 1, 0.0, 256.0),
+                ("affine", 2, ALPHA, 1.0 / (1.0 - 2.0 * ALPHA)), ("logit", 3)]
+    sz = tuple(data_size)
+    for blk in range(num_blocks):
+        if sz[0] % 2:                                         # model.py:121-123
+            ops.append(("augment", len(ops), 1)); sz = (sz[0] + 1, sz[1], sz[2])
+        if dataset not in ("msl", "smd", "smap"):             # model.py:125-127
+            ops.append(("squeeze", len(ops), patch))
+            sz = (sz[0] * patch[0] * patch[1], sz[1] // patch[0], sz[2] // patch[1])
+        for _ in range(block_size):
+            ops.append(("conv1x1", len(ops), sz))
+            ops.append(("actnorm", len(ops), sz))
+            if coupling == "trans" and sz[1] % patch[0] == 0 and sz[2] % patch[1] == 0:  # model.py:139
+                ops.append(("transcoupling", len(ops), sz, patch))
+            elif coupling == "conv":
+                ops.append(("coupling", len(ops), sz, krn, pad))
+        if split_prior and blk < num_blocks - 1:              # model.py:153-158
+            sz = (sz[0] // 2, sz[1], sz[2])
+            ops.append(("split", len(ops), sz))
+    return ops, sz, mixtures
+
+
+# --------------------------------------------------------------------------------------
+# index-only ops
+# --------------------------------------------------------------------------------------
+def squeeze_fwd(x, p):
+    """squeeze.py:10-11  'b c (h p1) (w p2) -> b (c p1 p2) h w'."""
+    B, C, H, W = x.shape
+    v = x.reshape(B, C, H // p[0], p[0], W // p[1], p[1])
+    return v.permute(0, 1, 3, 5, 2, 4).reshape(B, C * p[0] * p[1], H // p[0], W // p[1])
+
+
+def squeeze_inv(z, p):
+    """squeeze.py:13-14."""
+    B, C, H, W = z.shape
+    c = C // (p[0] * p[1])
+    v = z.reshape(B, c, p[0], p[1], H, W)
+    return v.permute(0, 1, 4, 2, 5, 3).reshape(B, c, H * p[0], W * p[1])
+
+
+# --------------------------------------------------------------------------------------
+# pre-processing (ldj is part of bits/dim)
+# --------------------------------------------------------------------------------------
+def affine_fwd(x, translation, scale):
+    """normalize.py:27-34,42-49 with scalar scale: out = x/scale + translation,
+    ldj = -C*(H*W)*log(scale) for every sample."""
+    s = torch.tensor([scale], dtype=torch.float32).to(x.dtype)      # torch.Tensor([scale]) is fp32
+    t = torch.tensor([translation], dtype=torch.float32).to(x.dtype)
+    B, C = x.shape[:2]
+    n = x.numel() / B / C
+    ldj = C * (-1.0 * n * torch.log(s).sum())
+    return x / s + t, ldj.expand(B)
+
+
+def affine_inv(y, translation, scale):
+    """normalize.py:36-40."""
+    s = torch.tensor([scale], dtype=torch.float32).to(y.dtype)
+    t = torch.tensor([translation], dtype=torch.float32).to(y.dtype)
+    return (y - t) * s
+
+
+def logit_fwd(x):
+    """transforms.py:11-18."""
+    l0, l1 = torch.log(x), torch.log(1 - x)
+    return l0 - l1, (-l0 - l1).flatten(1).sum(-1)
+
+
+def std_normal_neg_logq(eps):
+    """augment.py:14-18 + gaussian.py:50-54: ldj of Augment = -log N(eps;0,1), shape (B,1)."""
+    lp = (-0.5 * LOG_2PI - 0.5 * eps ** 2).flatten(1).sum(-1)
+    return -lp.unsqueeze(-1)
+
+
+# --------------------------------------------------------------------------------------
+# flow layers
+# --------------------------------------------------------------------------------------
+def conv1x1_fwd(x, W):
+    """conv1x1.py:52-57 (context-free): z = W x per pixel, ldj = slogdet(W)*H*W."""
+    B, C, H, Wd = x.shape
+    z = torch.einsum("oi,bihw->bohw", W, x)
+    ldj = torch.linalg.slogdet(W)[1] * H * Wd
+    return z, ldj.expand(B)
+
+
+def conv1x1_inv(z, W):
+    """conv1x1.py:72."""
+    return torch.einsum("oi,bihw->bohw", torch.inverse(W), z)
+
+
+def actnorm_stats(x):
+    """actnorm.py:28-35: data-dependent init, unbiased std over (B,H,W), log(std + 1e-8)."""
+    dims = [0, 2, 3]
+    return torch.mean(x, dim=dims), torch.log(torch.std(x, dim=dims) + 1e-8)
+
+
+def actnorm_fwd(x, t, logs):
+    """actnorm.py:53-60: z = (x-t)*exp(-logs); ldj = +sum_c logs (no H*W factor — reference quirk)."""
+    z = (x - t.view(1, -1, 1, 1)) * torch.exp(-logs.view(1, -1, 1, 1))
+    return z, logs.sum().expand(x.shape[0])
+
+
+def actnorm_inv(z, t, logs):
+    """actnorm.py:78."""
+    return z * torch.exp(logs.view(1, -1, 1, 1)) + t.view(1, -1, 1, 1)
+
+
+def coupling_net(x0, p, prefix, pad):
+    """coupling.py:26-29: 1x1 -> ReLU -> k x k (reflect pad) -> ReLU -> 1x1."""
+    h = F.relu(F.conv2d(x0, p[prefix + "NN.0.weight"], p[prefix + "NN.0.bias"]))
+    if pad[0] or pad[1]:
+        h = F.pad(h, (pad[1], pad[1], pad[0], pad[0]), mode="reflect")
+    h = F.relu(F.conv2d(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
+    return F.conv2d(h, p[prefix + "NN.4.weight"], p[prefix + "NN.4.bias"])
+
+
+def affine_from_net(h):
+    """coupling.py:52-57: t = first half of h, log_s = 2*tanh(second half / 2)."""
+    c = h.shape[1] // 2
+    return h[:, :c], 2.0 * torch.tanh(h[:, c:] / 2.0)
+
+
+def coupling_apply_fwd(x, h):
+    """coupling.py:60-66: second channel half transformed, first half is the conditioner."""
+    c = x.shape[1] // 2
+    t, log_s = affine_from_net(h)
+    z1 = x[:, c:] * torch.exp(log_s) + t
+    return torch.cat([x[:, :c], z1], 1), log_s.flatten(1).sum(-1)
+
+
+def coupling_apply_inv(z, h):
+    """coupling.py:68-73."""
+    c = z.shape[1] // 2
+    t, log_s = affine_from_net(h)
+    return torch.cat([z[:, :c], (z[:, c:] - t) / torch.exp(log_s)], 1)
+
+
+def coupling_fwd(x, p, prefix, pad):
+    return coupling_apply_fwd(x, coupling_net(x[:, : x.shape[1] // 2], p, prefix, pad))
+
+
+def coupling_inv(z, p, prefix, pad):
+    return coupling_apply_inv(z, coupling_net(z[:, : z.shape[1] // 2], p, prefix, pad))
+
+
+# ---- SimpleViT inner net of TransCoupling ------------------------------------------------
+def posemb_sincos_2d(h, w, dim, temperature=10000.0):
+    """simple_vit.py:18-27 (note omega = arange(dim/4)/(dim/4 - 1))."""
+    y, x = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    omega = torch.arange(dim // 4) / (dim // 4 - 1)
+    omega = 1.0 / (temperature ** omega)
+    y = y.flatten()[:, None] * omega[None, :]
+    x = x.flatten()[:, None] * omega[None, :]
+    return torch.cat((x.sin(), x.cos(), y.sin(), y.cos()), dim=1).float()
+
+
+def vit_dims(sz, patch):
+    """coupling.py:103-114: dim = O*p1*p2, heads 1, dim_head 64, depth 6, mlp_dim = dim."""
+    C, H, W = sz
+    return dict(cin=C // 2, dim=C * patch[0] * patch[1], gh=H // patch[0], gw=W // patch[1],
+                depth=6, dim_head=64, patch_dim=(C // 2) * patch[0] * patch[1])
+
+
+def vit_net(x0, p, prefix, sz, patch):
+    """simple_vit.py:117-127 with Attention (:56-68), FeedForward (:30-40), Transformer (:71-88)."""
+    d = vit_dims(sz, patch)
+    B = x0.shape[0]
+    p1, p2, gh, gw, dim = patch[0], patch[1], d["gh"], d["gw"], d["dim"]
+    q = prefix + "NN.0."
+    # 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)'
+    tok = x0.reshape(B, d["cin"], gh, p1, gw, p2).permute(0, 2, 4, 3, 5, 1).reshape(B, gh * gw, d["patch_dim"])
+    tok = F.layer_norm(tok, (d["patch_dim"],), p[q + "to_patch_embedding.1.weight"], p[q + "to_patch_embedding.1.bias"])
+    tok = F.linear(tok, p[q + "to_patch_embedding.2.weight"], p[q + "to_patch_embedding.2.bias"])
+    tok = F.layer_norm(tok, (dim,), p[q + "to_patch_embedding.3.weight"], p[q + "to_patch_embedding.3.bias"])
+    tok = tok + posemb_sincos_2d(gh, gw, dim).to(tok.dtype)
+    for l in range(d["depth"]):
+        a = q + "transformer.layers.%d.0." % l
+        f = q + "transformer.layers.%d.1.net." % l
+        y = F.layer_norm(tok, (dim,), p[a + "norm.weight"], p[a + "norm.bias"])
+        qkv = F.linear(y, p[a + "to_qkv.weight"])
+        qq, kk, vv = qkv.chunk(3, dim=-1)
+        att = torch.softmax(torch.matmul(qq, kk.transpose(-1, -2)) * d["dim_head"] ** -0.5, dim=-1)
+        tok = F.linear(torch.matmul(att, vv), p[a + "to_out.weight"]) + tok
+        y = F.layer_norm(tok, (dim,), p[f + "0.weight"], p[f + "0.bias"])
+        y = F.linear(F.gelu(F.linear(y, p[f + "1.weight"], p[f + "1.bias"])), p[f + "3.weight"], p[f + "3.bias"])
+        tok = y + tok
+    tok = F.layer_norm(tok, (dim,), p[q + "transformer.norm.weight"], p[q + "transformer.norm.bias"])
+    # 'b (h w) (p1 p2 c) -> b c (h p1) (w p2)'  with c = dim/(p1 p2) = full channel count
+    cout = dim // (p1 * p2)
+    return tok.reshape(B, gh, gw, p1, p2, cout).permute(0, 5, 1, 3, 2, 4).reshape(B, cout, gh * p1, gw * p2)
+
+
+def transcoupling_fwd(x, p, prefix, sz, patch):
+    """coupling.py:123-147."""
+    return coupling_apply_fwd(x, vit_net(x[:, : x.shape[1] // 2], p, prefix, sz, patch))
+
+
+def transcoupling_inv(z, p, prefix, sz, patch):
+    """coupling.py:149-155."""
+    return coupling_apply_inv(z, vit_net(z[:, : z.shape[1] // 2], p, prefix, sz, patch))
+
+
+# ---- prior ------------------------------------------------------------------------------
+def gmm_logprob(x, mG, sG, wG, chunk=64):
+    """gaussian.py:138-161 (context-free): for each class-mixture m, logsumexp over K diagonal
+    components of log_softmax(wG[m]) + sum_d N(x; mG, softplus(sG)).  Returns (B, M)."""
+    B = x.shape[0]
+    M, K = wG.shape
+    mu = mG.reshape(1, M * K, -1)
+    sig = F.softplus(sG).reshape(1, M * K, -1)
+    cst = (-torch.log(sig) - 0.5 * LOG_2PI)
+    logw = torch.log_softmax(wG, dim=-1)
+    out = []
+    for b0 in range(0, B, chunk):
+        xv = x[b0:b0 + chunk].reshape(-1, 1, mu.shape[-1])
+        lp = (-0.5 * ((xv - mu) / sig) ** 2 + cst).sum(-1).reshape(-1, M, K)
+        out.append(torch.logsumexp(lp + logw, dim=-1))
+    return torch.cat(out, 0)
+
+
+# --------------------------------------------------------------------------------------
+# whole flow  (flowsequential.py:18-30)
+# --------------------------------------------------------------------------------------
+def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None):
+    """log p(x) for every class-mixture: returns (z, logp (B,M)).
+
+    `u` is the dequantisation noise (uniform.py:31-34) and `eps` the list of Augment noises
+    (gaussian.py:68-72), passed in so that runs are reproducible.  With `init_actnorm` the
+    ActNorm parameters are (re)computed from this batch as on the reference's first call and
+    written into `params`.  `trace`, if a list, receives (op_name, index, z, ldj) per layer.
+    """
+    B = x.shape[0]
+    M = params["dist.wG"].shape[0]
+    logdet = torch.zeros((B, M), dtype=x.dtype)
+    eps = list(eps)
+    for op in ops:
+        kind, idx = op[0], op[1]
+        pre = "%d." % idx
+        if kind == "dequant":
+            x, ldj = x + u, torch.zeros(B, dtype=x.dtype)      # dequantize.py:14-17, log q = 0
+        elif kind == "affine":
+            x, ldj = affine_fwd(x, op[2], op[3])
+        elif kind == "logit":
+            x, ldj = logit_fwd(x)
+        elif kind == "augment":
+            e = eps.pop(0)
+            x, ldj = torch.cat([x, e], 1), std_normal_neg_logq(e)
+        elif kind == "squeeze":
+            x, ldj = squeeze_fwd(x, op[2]), torch.zeros(B, dtype=x.dtype)
+        elif kind == "conv1x1":
+            x, ldj = conv1x1_fwd(x, params[pre + "NN"])
+        elif kind == "actnorm":
+            if init_actnorm:
+                t, logs = actnorm_stats(x)
+                params[pre + "NN_t"], params[pre + "NN_logs"] = t, logs
+                params[pre + "initialized"] = torch.tensor(1)
+            x, ldj = actnorm_fwd(x, params[pre + "NN_t"], params[pre + "NN_logs"])
+        elif kind == "coupling":
+            x, ldj = coupling_fwd(x, params, pre, op[4])
+        elif kind == "transcoupling":
+            x, ldj = transcoupling_fwd(x, params, pre, op[2], op[3])
+        elif kind == "split":                                     # splitprior.py:12-15
+            c = x.shape[1] // 2
+            ldj = gmm_logprob(x[:, c:], params[pre + "dist.mG"], params[pre + "dist.sG"], params[pre + "dist.wG"])
+            x = x[:, :c]
+        else:
+            raise ValueError(kind)
+        logdet = logdet + (ldj if ldj.dim() == 2 else ldj.unsqueeze(-1))   # flowsequential.py:23
+        if trace is not None:
+            trace.append((kind, idx, x, ldj))
+    logp = gmm_logprob(x, params["dist.mG"], params["dist.sG"], params["dist.wG"])
+    return x, logp + logdet
+
+
+def flow_inverse_layers(ops, params, z, upto=None):
+    """Per-layer `reverse` chain (flowsequential.py:32-39) over the invertible, context-free layers.
+    Stops at SplitPrior/Augment boundaries being handled by the caller (the reference's own
+    `SplitPrior.reverse` is broken), so `ops` must not contain them."""
+    for op in reversed(ops[:upto]):
+        kind, idx = op[0], op[1]
+        pre = "%d." % idx
+        if kind == "squeeze":
+            z = squeeze_inv(z, op[2])
+        elif kind == "conv1x1":
+            z = conv1x1_inv(z, params[pre + "NN"])
+        elif kind == "actnorm":
+            z = actnorm_inv(z, params[pre + "NN_t"], params[pre + "NN_logs"])
+        elif kind == "coupling":
+            z = coupling_inv(z, params, pre, op[4])
+        elif kind == "transcoupling":
+            z = transcoupling_inv(z, params, pre, op[2], op[3])
+        elif kind == "affine":
+            z = affine_inv(z, op[2], op[3])
+        elif kind == "logit":
+            z = torch.sigmoid(z)                                  # transforms.py:14-15
+        elif kind == "dequant":
+            z = z.floor()                                         # dequantize.py:19-20
+        else:
+            raise ValueError("no inverse for %s" % kind)
+    return z
+
+
+def bits_per_dim(logp, dims):
+    """-logsumexp_m logp / (D ln 2), D = prod of the un-augmented data size."""
+    return -torch.logsumexp(logp, dim=-1) / (dims * math.log(2.0))

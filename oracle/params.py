@@ -1,0 +1,129 @@
+"""Parameter specification + deterministic parameter generation for the oracle and the tests.
+
+TEST INFRASTRUCTURE ONLY (see oracle/flow_oracle.py header).
+
+`param_spec` lists the reference's `state_dict` entries (names, shapes, dtypes) for a program from
+`flow_oracle.program` — SURVEY.md Appendix B; `tests/golden/make_golden.py` asserts it equals the
+real reference `state_dict` key for key.  `gen_params` fills it from `numpy.random.RandomState`
+streams (frozen by NumPy's compatibility policy, so the same bits on every box), which keeps the
+committed fixtures small: big tensors are regenerated from the seed instead of being stored.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .flow_oracle import K_COMPONENTS, vit_dims
+
+
+def _gmm(prefix, size, M, spec):
+    D, H, W = size
+    spec[prefix + "mG"] = ((M, K_COMPONENTS, D, H, W), "normal")
+    spec[prefix + "sG"] = ((M, K_COMPONENTS, D, H, W), "scale")
+    spec[prefix + "wG"] = ((M, K_COMPONENTS), "normal")
+
+
+def param_spec(ops, prior_size, mixtures):
+    """OrderedDict name -> (shape, kind) in the reference's state_dict order
+    (flowsequential.py:8-12: `dist` is registered before the numbered layers)."""
+    spec = OrderedDict()
+    _gmm("dist.", prior_size, mixtures, spec)
+    for op in ops:
+        kind, idx = op[0], op[1]
+        pre = "%d." % idx
+        if kind == "dequant":
+            spec[pre + "dist.empty"] = ((1,), "zeros")                       # uniform.py:15
+        elif kind == "affine":
+            spec[pre + "translation"] = ((1,), ("const", op[2]))             # normalize.py:24-25
+            spec[pre + "scale"] = ((1,), ("const", op[3]))
+        elif kind == "augment":
+            spec[pre + "distribution.buffer"] = ((1,), "zeros")              # gaussian.py:19
+        elif kind == "conv1x1":
+            C = op[2][0]
+            spec[pre + "NN"] = ((C, C), "orthogonal")                         # conv1x1.py:16-17
+        elif kind == "actnorm":
+            C = op[2][0]
+            spec[pre + "NN_t"] = ((C,), "zeros")                              # actnorm.py:14-16
+            spec[pre + "NN_logs"] = ((C,), "zeros")
+            spec[pre + "initialized"] = ((), "flag")
+        elif kind == "coupling":
+            C = op[2][0]
+            kh, kw = op[3]
+            D, Hd, O = C // 2, C * 2, C                                        # coupling.py:17-19
+            for name, shp in (("NN.0", (Hd, D, 1, 1)), ("NN.2", (Hd, Hd, kh, kw)), ("NN.4", (O, Hd, 1, 1))):
+                fan_in = shp[1] * shp[2] * shp[3]
+                spec[pre + name + ".weight"] = (shp, ("uniform", fan_in))
+                spec[pre + name + ".bias"] = ((shp[0],), ("uniform", fan_in))
+        elif kind == "transcoupling":
+            d = vit_dims(op[2], op[3])
+            dim, pd, inner = d["dim"], d["patch_dim"], d["dim_head"]
+            q = pre + "NN.0."
+            spec[q + "to_patch_embedding.1.weight"] = ((pd,), "ln_w")
+            spec[q + "to_patch_embedding.1.bias"] = ((pd,), "ln_b")
+            spec[q + "to_patch_embedding.2.weight"] = ((dim, pd), ("uniform", pd))
+            spec[q + "to_patch_embedding.2.bias"] = ((dim,), ("uniform", pd))
+            spec[q + "to_patch_embedding.3.weight"] = ((dim,), "ln_w")
+            spec[q + "to_patch_embedding.3.bias"] = ((dim,), "ln_b")
+            spec[q + "transformer.norm.weight"] = ((dim,), "ln_w")
+            spec[q + "transformer.norm.bias"] = ((dim,), "ln_b")
+            for l in range(d["depth"]):
+                a = q + "transformer.layers.%d.0." % l
+                f = q + "transformer.layers.%d.1.net." % l
+                spec[a + "norm.weight"] = ((dim,), "ln_w")
+                spec[a + "norm.bias"] = ((dim,), "ln_b")
+                spec[a + "to_qkv.weight"] = ((3 * inner, dim), ("uniform", dim))
+                spec[a + "to_out.weight"] = ((dim, inner), ("uniform", inner))
+                spec[f + "0.weight"] = ((dim,), "ln_w")
+                spec[f + "0.bias"] = ((dim,), "ln_b")
+                spec[f + "1.weight"] = ((dim, dim), ("uniform", dim))
+                spec[f + "1.bias"] = ((dim,), ("uniform", dim))
+                spec[f + "3.weight"] = ((dim, dim), ("uniform", dim))
+                spec[f + "3.bias"] = ((dim,), ("uniform", dim))
+        elif kind == "split":
+            _gmm(pre + "dist.", op[2], mixtures, spec)
+    return spec
+
+
+def gen_params(spec, seed=0, dtype=torch.float32):
+    """Deterministic parameters.  Each entry has its own RandomState stream keyed by its name."""
+    out = OrderedDict()
+    for name, (shape, kind) in spec.items():
+        rs = np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 32))
+        if kind == "zeros":
+            v = np.zeros(shape)
+        elif kind == "flag":
+            out[name] = torch.tensor(0); continue
+        elif kind == "normal":
+            v = rs.standard_normal(shape)
+        elif kind == "scale":          # pre-softplus scale, perturbed so that softplus is exercised
+            v = 1.0 + 0.2 * rs.standard_normal(shape)
+        elif kind == "ln_w":
+            v = 1.0 + 0.1 * rs.standard_normal(shape)
+        elif kind == "ln_b":
+            v = 0.1 * rs.standard_normal(shape)
+        elif kind == "orthogonal":     # LAPACK-dependent in the last bits -> fixtures store these
+            q, r = np.linalg.qr(rs.standard_normal(shape))
+            v = q * np.sign(np.diag(r))[None, :]
+        elif kind[0] == "const":
+            v = np.full(shape, np.float32(kind[1]))
+        elif kind[0] == "uniform":
+            b = 1.0 / np.sqrt(kind[1])
+            v = rs.uniform(-b, b, size=shape)
+        else:
+            raise ValueError(kind)
+        out[name] = torch.from_numpy(np.asarray(v, dtype=np.float64)).to(dtype)
+    return out
+
+
+LAPACK_DEPENDENT = ("orthogonal",)
+
+
+def stored_keys(spec):
+    """Entries a fixture must store explicitly (not bit-reproducible from the seed everywhere,
+    or produced by the reference's data-dependent ActNorm init)."""
+    keys = []
+    for name, (shape, kind) in spec.items():
+        if kind in LAPACK_DEPENDENT or name.endswith(("NN_t", "NN_logs", "initialized")):
+            keys.append(name)
+    return keys

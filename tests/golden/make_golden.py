@@ -1,0 +1,299 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE (build container only).
+
+    python tests/golden/make_golden.py
+
+The reference (/root/reference) cannot travel to the GPU box, so its outputs are committed here
+as data: inputs, captured noise, the few parameters that are not bit-reproducible from a seed,
+and the reference's outputs.  Large parameters are regenerated at test time from
+`oracle.params.gen_params` (NumPy RandomState streams) and are loaded INTO the reference here
+with `load_state_dict(strict=True)`, which also proves that `oracle.params.param_spec` names every
+reference `state_dict` entry with the right shape.
+
+Import recipe: SURVEY.md Appendix C (stub the dataset / reporting modules that need absent
+third-party packages; they are not on the density path).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference/contextflow"
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+
+    class InputDropout(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    stub("datasets")
+    stub("datasets.ts", InputDropout=InputDropout, load_data_ts=None)
+    stub("datasets.mnist", load_data=None)
+    stub("datasets.cifar10", load_data=None)
+    stub("datasets.mtad_dataloader", mtad_entities={})
+    stub("torchinfo", summary=None)
+    stub("ood_metrics", auroc=None, aupr=None, fpr_at_95_tpr=None)
+    import model as ref_model
+    import layers as ref_layers
+    sys.path.remove(REF)
+    for k in [k for k in sys.modules if k == "datasets" or k.startswith("datasets.")]:
+        del sys.modules[k]
+    return ref_model, ref_layers
+
+
+REF_MODEL, REF_LAYERS = _import_reference()
+
+from oracle import flow_oracle as fo          # noqa: E402
+from oracle import params as op               # noqa: E402
+
+REF_CFG = {
+    "mnist": dict(dataset="mnist", num_blocks=2, block_size=2, split_prior=False, coupling="conv", contexts=[-1]),
+    "cifar10": dict(dataset="cifar10", num_blocks=3, block_size=4, split_prior=True, coupling="conv", contexts=[-1, -1]),
+    "smap": dict(dataset="smap", num_blocks=2, block_size=4, split_prior=False, coupling="trans", contexts=[55]),
+}
+
+
+def build_reference(name):
+    data_size, mixtures = fo.CONFIGS[name][0], fo.CONFIGS[name][1]
+    c = REF_CFG[name]
+    REF_MODEL.c = types.SimpleNamespace(dataset=name)
+    cfg = dict(dataset=name, contextflow=False, generalist=True, enc_emb="onehot", enc_type="uniform",
+               num_blocks=c["num_blocks"], block_size=c["block_size"], actnorm=True, coupling=c["coupling"],
+               split_prior=c["split_prior"], dist="gauss")
+    flow = REF_MODEL.create_model(cfg, data_size=data_size, mixtures=mixtures, contexts=c["contexts"]).eval()
+    return flow, len(c["contexts"])
+
+
+def synth_input(name, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    C, H, W = fo.CONFIGS[name][0]
+    if name == "smap":
+        return torch.rand(B, C, H, W, generator=g)
+    return torch.randint(0, 256, (B, C, H, W), generator=g).float()
+
+
+def end_to_end(name, B=4, seed=0):
+    flow, nctx = build_reference(name)
+    ops, prior_size, M = fo.program(name)
+    spec = op.param_spec(ops, prior_size, M)
+    sd = flow.state_dict()
+    assert list(sd.keys()) == list(spec.keys()), (name, set(sd) ^ set(spec))
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(spec[k][0]), (k, v.shape, spec[k][0])
+    params = op.gen_params(spec, seed)
+    flow.load_state_dict(params, strict=True)
+
+    x = synth_input(name, B, seed)
+    ctx = torch.zeros(B, nctx, dtype=torch.long)
+    with torch.no_grad():
+        torch.manual_seed(1234 + seed)
+        z_first, logp_first = flow(x, ctx)            # first call: runs the ActNorm data-dependent init
+        post = {k: v.clone() for k, v in flow.state_dict().items()}
+        # second pass, layer by layer with the same RNG stream, to capture noise and a trace
+        torch.manual_seed(1234 + seed)
+        h = x
+        logdet = torch.zeros(B, M)
+        trace, noise_u, noise_eps = [], None, []
+        for i, m in enumerate(flow.sequence_modules):
+            out, ldj = m(h, ctx)
+            kind = ops[i][0]
+            if kind == "dequant":
+                noise_u = out - h                      # exact (Sterbenz): h + noise_u == out bitwise
+                assert torch.equal(h + noise_u, out)
+            if kind == "augment":
+                noise_eps.append(out[:, h.shape[1]:].clone())
+            logdet += ldj if ldj.dim() == 2 else ldj.unsqueeze(-1)
+            trace.append((kind, out.clone(), ldj.clone()))
+            h = out
+        logp = flow.dist.log_prob(h, ctx) + logdet
+    assert torch.equal(logp, logp_first) and torch.equal(h, z_first), name
+
+    fx = dict(x=x.numpy().astype(np.uint8) if name != "smap" else x.numpy(), logp=logp.numpy(), z=h.numpy(),
+              seed=np.int64(seed))
+    if noise_u is not None:
+        fx["u"] = noise_u.numpy()
+    for j, e in enumerate(noise_eps):
+        fx["eps%d" % j] = e.numpy()
+    for k in op.stored_keys(spec):
+        fx["param:" + k] = post[k].numpy()
+    keep = set()
+    first_of = {}
+    for i, (kind, _, _) in enumerate(trace):
+        first_of.setdefault(kind, i)
+    keep.update(first_of.values())
+    # first and last flow step of every resolution level + everything around split/squeeze
+    for i, (kind, _, _) in enumerate(trace):
+        if kind in ("squeeze", "split", "augment", "logit"):
+            keep.update({i, min(i + 1, len(trace) - 1), min(i + 2, len(trace) - 1), min(i + 3, len(trace) - 1)})
+    keep.update({len(trace) - 1, len(trace) - 2, len(trace) - 3})
+    for i, (kind, out, ldj) in enumerate(trace):
+        fx["ldj%d" % i] = ldj.numpy()
+        if i in keep:
+            fx["z%d" % i] = out.numpy()
+    # fp64 evaluation of the same function (noise floor reference): run the reference itself in double
+    flow64 = flow.double()
+    with torch.no_grad():
+        h = x.double()
+        logdet = torch.zeros(B, M, dtype=torch.float64)
+        eps_iter = iter(noise_eps)
+        for i, m in enumerate(flow64.sequence_modules):
+            kind = ops[i][0]
+            if kind == "dequant":
+                out, ldj = h + noise_u.double(), torch.zeros(B, dtype=torch.float64)
+            elif kind == "augment":
+                e = next(eps_iter).double()
+                out = torch.cat([h, e], 1)
+                ldj = -m.distribution.log_prob(e)
+            else:
+                out, ldj = m(h, ctx)
+            logdet += ldj if ldj.dim() == 2 else ldj.unsqueeze(-1)
+            h = out
+        logp64 = flow64.dist.log_prob(h, ctx) + logdet
+    fx["logp_f64"] = logp64.numpy()
+    np.savez(os.path.join(HERE, "e2e_%s.npz" % name), **fx)
+    D = int(np.prod(fo.CONFIGS[name][0]))
+    bpd = fo.bits_per_dim(logp, D)
+    bpd64 = fo.bits_per_dim(logp64, D)
+    print("%-8s logp[0,:3]=%s  bpd=%s  fp32-vs-fp64 max|dbpd|=%.3e  (%d layers, %d kept z)" % (
+        name, logp[0, :3].tolist(), bpd.tolist(), (bpd.double() - bpd64).abs().max().item(), len(trace), len(keep)))
+    return flow.float(), ops, post
+
+
+def sample_inverse_mnist(seed=0):
+    """FlowSequential.sample (flowsequential.py:32-39) only works for the mnist topology
+    (SURVEY §3.3).  Capture z -> x through every layer's `reverse`."""
+    flow, _ = build_reference("mnist")
+    ops, prior_size, M = fo.program("mnist")
+    spec = op.param_spec(ops, prior_size, M)
+    flow.load_state_dict(op.gen_params(spec, seed), strict=True)
+    x = synth_input("mnist", 4, seed)
+    with torch.no_grad():
+        torch.manual_seed(7)
+        flow(x, torch.zeros(4, 1, dtype=torch.long))
+        post = {k: v.clone() for k, v in flow.state_dict().items()}
+        torch.manual_seed(11)
+        z, _ = flow.dist.sample(3)
+        h = z
+        for m in reversed(flow.sequence_modules):
+            h = m.reverse(h, None)
+        torch.manual_seed(11)
+        assert torch.equal(flow.sample(3), h)
+    fx = dict(z=z.numpy(), x=h.numpy(), seed=np.int64(seed))
+    for k in op.stored_keys(spec):
+        fx["param:" + k] = post[k].numpy()
+    np.savez(os.path.join(HERE, "inverse_mnist.npz"), **fx)
+    print("inverse_mnist: x range", h.min().item(), h.max().item())
+
+
+def unit_layers():
+    """Per-layer vectors at awkward shapes (odd sizes, (3,1) kernels, C=26 ...)."""
+    L = REF_LAYERS
+    fx = {}
+
+    def put(tag, **kw):
+        for k, v in kw.items():
+            fx["%s/%s" % (tag, k)] = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+    def sd(tag, module):
+        for k, v in module.state_dict().items():
+            fx["%s/sd:%s" % (tag, k)] = v.numpy()
+
+    torch.manual_seed(42)
+    with torch.no_grad():
+        # Coupling, 3x3 reflect, non-square odd image
+        for tag, C, krn, pad, shape in (("coupling_3x3", 12, (3, 3), (1, 1), (3, 12, 6, 10)),
+                                        ("coupling_3x1", 8, (3, 1), (1, 0), (2, 8, 9, 1)),
+                                        ("coupling_c16", 16, (3, 3), (1, 1), (2, 16, 16, 16))):
+            m = L.Coupling(C, kernel_size=krn, padding=pad)
+            x = torch.randn(*shape)
+            z, ldj = m(x)
+            put(tag, x=x, z=z, ldj=ldj, h=m.NN(x[:, :C // 2]), xrec=m.reverse(z), krn=krn, pad=pad)
+            sd(tag, m)
+        # Conv1x1
+        for tag, size, shape in (("conv1x1_c26", (26, 8, 1), (3, 26, 8, 1)), ("conv1x1_c64", (64, 4, 4), (2, 64, 4, 4))):
+            m = L.Conv1x1(size)
+            m.NN.add_(0.05 * torch.randn_like(m.NN))       # leave exact orthogonality: |det| != 1
+            x = torch.randn(*shape)
+            z, ldj = m(x)
+            put(tag, x=x, z=z, ldj=ldj, xrec=m.reverse(z))
+            sd(tag, m)
+        # ActNorm: data-dependent init on first call, then a second batch
+        m = L.ActNorm((7, 3, 4))
+        x = 3.0 * torch.randn(5, 7, 3, 4) + torch.arange(7.0).view(1, 7, 1, 1)
+        z, ldj = m(x)
+        x2 = torch.randn(2, 7, 3, 4)
+        z2, ldj2 = m(x2)
+        put("actnorm", x=x, z=z, ldj=ldj, x2=x2, z2=z2, ldj2=ldj2, x2rec=m.reverse(z2))
+        sd("actnorm", m)
+        # Squeeze
+        x = torch.randn(2, 3, 4, 6)
+        put("squeeze22", x=x, z=L.Squeeze((2, 2))(x)[0], xrec=L.Squeeze((2, 2)).reverse(L.Squeeze((2, 2))(x)[0]))
+        x = torch.randn(2, 5, 6, 1)
+        put("squeeze21", x=x, z=L.Squeeze((2, 1))(x)[0])
+        # GMM prior and SplitPrior
+        m = L.GaussianMixtureDistribution(size=(5, 3, 2), mixtures=3, components=8)
+        m.sG.add_(0.3 * torch.randn_like(m.sG))
+        x = torch.randn(6, 5, 3, 2)
+        put("gmm", x=x, logp=m.log_prob(x))
+        sd("gmm", m)
+        sp = L.SplitPrior(L.GaussianMixtureDistribution(size=(5, 3, 2), mixtures=2, components=8))
+        x = torch.randn(4, 10, 3, 2)
+        z, ldj = sp(x)
+        put("split", x=x, z=z, ldj=ldj)
+        sd("split", sp)
+        # pre-processing
+        n = L.Normalization(translation=1e-4, scale=1 / (1 - 2e-4))
+        x = torch.rand(3, 2, 4, 4)
+        z, ldj = n(x)
+        put("normalize", x=x, z=z, ldj=ldj, xrec=n.reverse(z))
+        n = L.Normalization(translation=0.0, scale=256.0)
+        x = torch.randint(0, 256, (3, 2, 4, 4)).float() + torch.rand(3, 2, 4, 4)
+        z, ldj = n(x)
+        put("normalize256", x=x, z=z, ldj=ldj)
+        lt = L.LogitTransform()
+        x = torch.rand(3, 2, 4, 4) * 0.98 + 0.01
+        z, ldj = lt(x)
+        put("logit", x=x, z=z, ldj=ldj, xrec=lt.reverse(z))
+        sn = L.StandardNormal((1, 4, 4))
+        e = torch.randn(3, 1, 4, 4)
+        put("stdnormal", x=e, logp=sn.log_prob(e))
+        # TransCoupling (time-series geometry of smap and a small image geometry)
+        for tag, in_sz, p, B in (("trans_ts", (26, 8, 1), (2, 1), 3), ("trans_img", (8, 4, 4), (2, 2), 2)):
+            m = L.TransCoupling(in_sz, p)
+            for prm in m.parameters():                       # LayerNorm affine away from (1, 0)
+                if prm.dim() == 1:
+                    prm.add_(0.1 * torch.randn_like(prm))
+            x = torch.randn(B, *in_sz)
+            z, ldj = m(x)
+            put(tag, x=x, z=z, ldj=ldj, h=m.NN(x[:, :in_sz[0] // 2]), xrec=m.reverse(z), in_sz=in_sz, p=p)
+            sd(tag, m)
+    np.savez(os.path.join(HERE, "unit_layers.npz"), **fx)
+    print("unit_layers: %d arrays" % len(fx))
+
+
+if __name__ == "__main__":
+    for name in ("mnist", "cifar10", "smap"):
+        end_to_end(name)
+    sample_inverse_mnist()
+    unit_layers()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("%-24s %8.1f KB" % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

@@ -1,0 +1,59 @@
+"""Shared helpers for the tests: fixture loading and parameter reconstruction."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from oracle import flow_oracle as fo
+from oracle import params as op
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_e2e(name):
+    """Returns (ops, prior_size, M, params(post ActNorm init), fixture dict)."""
+    fx = dict(np.load(os.path.join(GOLDEN, "e2e_%s.npz" % name)))
+    ops, prior_size, M = fo.program(name)
+    spec = op.param_spec(ops, prior_size, M)
+    params = op.gen_params(spec, int(fx["seed"]))
+    for k, v in fx.items():
+        if k.startswith("param:"):
+            params[k[6:]] = torch.from_numpy(v)
+    return ops, prior_size, M, params, fx
+
+
+def pre_init_params(name, fx):
+    """Same parameters but with ActNorm still un-initialised (as before the first call)."""
+    ops, prior_size, M = fo.program(name)
+    spec = op.param_spec(ops, prior_size, M)
+    params = op.gen_params(spec, int(fx["seed"]))
+    for k, v in fx.items():
+        if k.startswith("param:") and spec[k[6:]][1] == "orthogonal":
+            params[k[6:]] = torch.from_numpy(v)
+    return params
+
+
+def e2e_inputs(name, fx):
+    x = torch.from_numpy(fx["x"].astype(np.float32))
+    u = torch.from_numpy(fx["u"]) if "u" in fx else None
+    eps = [torch.from_numpy(fx["eps%d" % j]) for j in range(8) if "eps%d" % j in fx]
+    return x, u, eps
+
+
+def unit(tag):
+    fx = np.load(os.path.join(GOLDEN, "unit_layers.npz"))
+    out, sd = {}, {}
+    for k in fx.files:
+        if k.startswith(tag + "/"):
+            key = k[len(tag) + 1:]
+            if key.startswith("sd:"):
+                sd[key[3:]] = torch.from_numpy(fx[k])
+            else:
+                out[key] = torch.from_numpy(fx[k]) if fx[k].dtype.kind == "f" else fx[k]
+    return out, sd
+
+
+def bpd(logp, name):
+    D = int(np.prod(fo.CONFIGS[name][0]))
+    return -torch.logsumexp(logp.double(), dim=-1) / (D * math.log(2.0))

@@ -1,0 +1,157 @@
+"""CPU: the oracle (oracle/flow_oracle.py) against the reference's own outputs (tests/golden)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as fo
+from tests.helpers import load_e2e, pre_init_params, e2e_inputs, unit, bpd
+
+BPD_TOL = 1e-5     # BASELINE.json: bits/dim within 1e-5 of the reference
+Z_TOL = 1e-5
+
+
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+def test_e2e_logp_and_trace(name):
+    ops, _, M, params, fx = load_e2e(name)
+    x, u, eps = e2e_inputs(name, fx)
+    trace = []
+    z, logp = fo.flow_forward(ops, params, x, u, eps, trace=trace)
+    ref = torch.from_numpy(fx["logp"])
+    assert logp.shape == ref.shape == (x.shape[0], M)
+    assert (bpd(logp, name) - bpd(ref, name)).abs().max() < BPD_TOL
+    # per-mixture logp, expressed in bits/dim units
+    D = np.prod(fo.CONFIGS[name][0])
+    assert ((logp - ref).abs().max() / (D * np.log(2))) < BPD_TOL
+    assert (z - torch.from_numpy(fx["z"])).abs().max() < 2e-4
+    for i, (kind, idx, zi, ldj) in enumerate(trace):
+        r = torch.from_numpy(fx["ldj%d" % i])
+        assert ldj.shape == r.shape, (i, kind)
+        assert torch.allclose(ldj, r, rtol=2e-6, atol=2e-3), (i, kind, (ldj - r).abs().max())
+        if "z%d" % i in fx:
+            zr = torch.from_numpy(fx["z%d" % i])
+            assert (zi - zr).abs().max() <= 1e-4 * max(1.0, zr.abs().max().item()), (i, kind)
+
+
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+def test_e2e_actnorm_init(name):
+    """First call: data-dependent ActNorm init must reproduce the reference's post-init state."""
+    ops, _, M, post, fx = load_e2e(name)
+    params = pre_init_params(name, fx)
+    x, u, eps = e2e_inputs(name, fx)
+    _, logp = fo.flow_forward(ops, params, x, u, eps, init_actnorm=True)
+    for k in post:
+        if k.endswith(("NN_t", "NN_logs")):
+            assert torch.allclose(params[k], post[k], rtol=1e-4, atol=2e-5), k
+    assert (bpd(logp, name) - bpd(torch.from_numpy(fx["logp"]), name)).abs().max() < BPD_TOL
+
+
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+def test_fp64_noise_floor(name):
+    """The oracle in fp64 against the reference in fp64: restatement is exact up to fp64 rounding."""
+    ops, _, M, params, fx = load_e2e(name)
+    x, u, eps = e2e_inputs(name, fx)
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
+    _, logp = fo.flow_forward(ops, p64, x.double(), None if u is None else u.double(), [e.double() for e in eps])
+    ref = torch.from_numpy(fx["logp_f64"])
+    assert (logp - ref).abs().max() < 1e-7 * ref.abs().max()
+
+
+def test_inverse_mnist():
+    import os
+    from tests.helpers import GOLDEN
+    from oracle import params as op
+    fx = dict(np.load(os.path.join(GOLDEN, "inverse_mnist.npz")))
+    ops, prior_size, M = fo.program("mnist")
+    params = op.gen_params(op.param_spec(ops, prior_size, M), int(fx["seed"]))
+    for k, v in fx.items():
+        if k.startswith("param:"):
+            params[k[6:]] = torch.from_numpy(v)
+    z = torch.from_numpy(fx["z"])
+    # layers after the Augment (index 4): reverse chain; Augment.reverse drops the noise channel
+    h = fo.flow_inverse_layers(ops[5:], params, z)
+    h = h[:, :1]
+    h = fo.flow_inverse_layers(ops[:4], params, h)
+    ref = torch.from_numpy(fx["x"])
+    # floor() of the dequantisation makes this integer-valued: allow a flip only at exact boundaries
+    assert (h - ref).abs().max() <= 1.0 and (h != ref).float().mean() < 2e-3
+
+
+@pytest.mark.parametrize("tag", ["coupling_3x3", "coupling_3x1", "coupling_c16"])
+def test_unit_coupling(tag):
+    t, sd = unit(tag)
+    pad = tuple(int(v) for v in t["pad"])
+    p = {"0." + k: v for k, v in sd.items()}
+    h = fo.coupling_net(t["x"][:, : t["x"].shape[1] // 2], p, "0.", pad)
+    assert torch.allclose(h, t["h"], rtol=1e-5, atol=1e-5)
+    z, ldj = fo.coupling_fwd(t["x"], p, "0.", pad)
+    assert torch.allclose(z, t["z"], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ldj, t["ldj"], rtol=1e-5, atol=1e-4)
+    assert torch.allclose(fo.coupling_inv(t["z"], p, "0.", pad), t["xrec"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["conv1x1_c26", "conv1x1_c64"])
+def test_unit_conv1x1(tag):
+    t, sd = unit(tag)
+    z, ldj = fo.conv1x1_fwd(t["x"], sd["NN"])
+    assert torch.allclose(z, t["z"], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ldj, t["ldj"].expand_as(ldj), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(fo.conv1x1_inv(t["z"], sd["NN"]), t["xrec"], rtol=1e-4, atol=1e-4)
+
+
+def test_unit_actnorm():
+    t, sd = unit("actnorm")
+    mean, logs = fo.actnorm_stats(t["x"])
+    assert torch.allclose(mean, sd["NN_t"], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(logs, sd["NN_logs"], rtol=1e-6, atol=1e-6)
+    z, ldj = fo.actnorm_fwd(t["x2"], sd["NN_t"], sd["NN_logs"])
+    assert torch.allclose(z, t["z2"], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(ldj, t["ldj2"], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(fo.actnorm_inv(t["z2"], sd["NN_t"], sd["NN_logs"]), t["x2rec"], rtol=1e-6, atol=1e-6)
+
+
+def test_unit_squeeze():
+    t, _ = unit("squeeze22")
+    assert torch.equal(fo.squeeze_fwd(t["x"], (2, 2)), t["z"])
+    assert torch.equal(fo.squeeze_inv(t["z"], (2, 2)), t["xrec"])
+    t, _ = unit("squeeze21")
+    assert torch.equal(fo.squeeze_fwd(t["x"], (2, 1)), t["z"])
+
+
+def test_unit_gmm_and_split():
+    t, sd = unit("gmm")
+    lp = fo.gmm_logprob(t["x"], sd["mG"], sd["sG"], sd["wG"])
+    assert torch.allclose(lp, t["logp"], rtol=1e-5, atol=1e-4)
+    t, sd = unit("split")
+    c = t["x"].shape[1] // 2
+    assert torch.equal(t["x"][:, :c], t["z"])
+    lp = fo.gmm_logprob(t["x"][:, c:], sd["dist.mG"], sd["dist.sG"], sd["dist.wG"])
+    assert torch.allclose(lp, t["ldj"], rtol=1e-5, atol=1e-4)
+
+
+def test_unit_preprocessing():
+    t, _ = unit("normalize")
+    z, ldj = fo.affine_fwd(t["x"], 1e-4, 1 / (1 - 2e-4))
+    assert torch.equal(z, t["z"]) and torch.allclose(ldj, t["ldj"], rtol=1e-6)
+    assert torch.allclose(fo.affine_inv(t["z"], 1e-4, 1 / (1 - 2e-4)), t["xrec"], rtol=1e-6, atol=1e-7)
+    t, _ = unit("normalize256")
+    z, ldj = fo.affine_fwd(t["x"], 0.0, 256.0)
+    assert torch.equal(z, t["z"]) and torch.allclose(ldj, t["ldj"], rtol=1e-6)
+    t, _ = unit("logit")
+    z, ldj = fo.logit_fwd(t["x"])
+    assert torch.allclose(z, t["z"], rtol=1e-6, atol=1e-6) and torch.allclose(ldj, t["ldj"], rtol=1e-6)
+    t, _ = unit("stdnormal")
+    assert torch.allclose(-fo.std_normal_neg_logq(t["x"]), t["logp"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["trans_ts", "trans_img"])
+def test_unit_transcoupling(tag):
+    t, sd = unit(tag)
+    sz = tuple(int(v) for v in t["in_sz"])
+    patch = tuple(int(v) for v in t["p"])
+    p = {"0." + k: v for k, v in sd.items()}
+    h = fo.vit_net(t["x"][:, : sz[0] // 2], p, "0.", sz, patch)
+    assert torch.allclose(h, t["h"], rtol=1e-4, atol=1e-5)
+    z, ldj = fo.transcoupling_fwd(t["x"], p, "0.", sz, patch)
+    assert torch.allclose(z, t["z"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(ldj, t["ldj"], rtol=1e-5, atol=1e-4)
+    assert torch.allclose(fo.transcoupling_inv(t["z"], p, "0.", sz, patch), t["xrec"], rtol=1e-4, atol=1e-4)
