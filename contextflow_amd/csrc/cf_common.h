@@ -1,0 +1,60 @@
+// Shared helpers for the gfx950 kernels of libcontextflow_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/contextflow_hip.h"
+
+#define CF_WAVE 64
+
+void cf_set_error(const char* fmt, ...);
+
+#define CF_REQUIRE(cond)                                                        \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            cf_set_error("%s: requirement failed: %s", __func__, #cond);        \
+            return CF_ERR_ARG;                                                  \
+        }                                                                       \
+    } while (0)
+
+#define CF_LAUNCH_CHECK()                                                       \
+    do {                                                                        \
+        hipError_t e_ = hipGetLastError();                                      \
+        if (e_ != hipSuccess) {                                                 \
+            cf_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return (int)e_;                                                     \
+        }                                                                       \
+    } while (0)
+
+static inline hipStream_t cf_s(cf_stream_t s) { return (hipStream_t)s; }
+
+// ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------
+__device__ __forceinline__ float cf_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double cf_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float cf_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Sum over a block of NW waves; result valid in every thread.  `scratch` holds >= NW floats.
+template <int NW>
+__device__ __forceinline__ float cf_block_sum(float v, float* scratch) {
+    v = cf_wave_sum(v);
+    if (NW == 1) return v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += scratch[i];
+    return s;
+}

@@ -1,0 +1,287 @@
+// GaussianMixtureDistribution.log_prob (layers/distributions/gaussian.py:138-161) without the
+// (B, M, K, D) broadcast the reference materialises.
+//
+//   out[b,m] = logsumexp_k( cst[m,k] - 1/2 * sum_d ((x[b,d] - mu[mk,d]) / sigma[mk,d])^2 )
+//
+// Work shape: a "GEMM with a square in the inner product" — (B samples) x (M*K components) x D.
+// VALU-bound (2 FMA per term) when operands are reused from registers, so the kernel is register
+// tiled: a 256-thread workgroup owns 128 samples x 80 components, each thread an 8 x 5 micro-tile;
+// x and the (a, bm) = (1/sigma, -mu/sigma) rows stream through LDS in 32-wide d-chunks with
+// 36-float row stride (every ds_read_b128 lane group hits distinct 4-bank groups), the next
+// chunk's global loads are issued before the current chunk's FMAs.  D can be split over
+// blockIdx.z (partials in a caller workspace + a small finishing kernel) to fill 256 CUs when
+// B/128 is small.
+#include "cf_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr float kLog2Pi = 1.8378770664093453f;
+constexpr int TB = 128;        // samples per workgroup
+constexpr int DC = 32;         // d-chunk
+constexpr int LD = DC + 4;     // LDS row stride (floats)
+constexpr int SPT = 8;         // samples per thread (strided by 16)
+
+__device__ __forceinline__ float softplus_ref(float v) {      // torch softplus, beta=1, threshold=20
+    return v > 20.f ? v : log1pf(expf(v));
+}
+
+// one block per component row mk
+__global__ __launch_bounds__(256) void k_gmm_prepare(const float* __restrict__ mG, const float* __restrict__ sG,
+                                                     const float* __restrict__ wG, float* __restrict__ a,
+                                                     float* __restrict__ bm, float* __restrict__ cst, int K, int D) {
+    __shared__ float red[4];
+    const int mk = blockIdx.x;
+    const float* mu = mG + (int64_t)mk * D;
+    const float* sg = sG + (int64_t)mk * D;
+    float acc = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float s = softplus_ref(sg[d]);
+        const float inv = 1.0f / s;
+        a[(int64_t)mk * D + d] = inv;
+        bm[(int64_t)mk * D + d] = -mu[d] * inv;
+        acc += logf(s);
+    }
+    acc = cf_block_sum<4>(acc, red);
+    if (threadIdx.x == 0) {
+        const int m = mk / K;
+        const float* wr = wG + m * K;
+        float mx = wr[0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, wr[k]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(wr[k] - mx);
+        const float logw = wG[mk] - mx - logf(s);                       // log_softmax(wG[m])[k]
+        cst[mk] = logw - acc - 0.5f * (float)D * kLog2Pi;
+    }
+}
+
+// guarded 4-float load for ragged tails: elements at d >= dend read as 0 (a = bm = 0 makes the term vanish)
+template <bool VEC>
+__device__ __forceinline__ float4 ld4_tail(const float* row, int d, int dend) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (VEC) {
+        if (d < dend) v = *reinterpret_cast<const float4*>(row + d);
+    } else {
+        if (d + 0 < dend) v.x = row[d + 0];
+        if (d + 1 < dend) v.y = row[d + 1];
+        if (d + 2 < dend) v.z = row[d + 2];
+        if (d + 3 < dend) v.w = row[d + 3];
+    }
+    return v;
+}
+
+// MKT = components per thread; the workgroup covers MKB = 16*MKT components starting at blockIdx.y*MKB.
+// Partial sums q[b, mk] over d in [dlo, dhi) go to qout (workspace, [nsplit][B][MKtot]) when SPLIT,
+// otherwise the logsumexp epilogue runs here.
+template <int MKT, bool VEC, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict__ x, const float* __restrict__ a,
+                                                     const float* __restrict__ bm, const float* __restrict__ cst,
+                                                     float* __restrict__ out, float* __restrict__ qout,
+                                                     int B, int MKtot, int K, int D, int dsplit,
+                                                     int64_t xbs, int accumulate, int Mtot) {
+    constexpr int MKB = 16 * MKT;
+    constexpr int XITEMS = TB * (DC / 4) / 256;                    // float4 per thread for the x chunk (4)
+    constexpr int PITEMS = (MKB * (DC / 4) + 255) / 256;           // float4 per thread per parameter array
+    constexpr int LDS_MAIN = (TB + 2 * MKB) * LD;
+    constexpr int LDS_EPI = TB * (MKB + 1);
+    constexpr int LDS_FLOATS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+    __shared__ __align__(16) float lds[LDS_FLOATS];
+    float* xs = lds;                   // [TB][LD]
+    float* as_ = lds + TB * LD;        // [MKB][LD]
+    float* bs = as_ + MKB * LD;        // [MKB][LD]
+
+    const int tid = threadIdx.x;
+    const int tm = tid & 15, ts = tid >> 4;
+    const int b0 = blockIdx.x * TB;
+    const int mk0 = blockIdx.y * MKB;
+    const int dlo = blockIdx.z * dsplit;
+    const int dhi = min(D, dlo + dsplit);
+
+    float acc[SPT][MKT];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i)
+#pragma unroll
+        for (int j = 0; j < MKT; ++j) acc[i][j] = 0.f;
+
+    float4 px[XITEMS], pa[PITEMS], pb[PITEMS];
+    // rows past B / past the last component are clamped to a valid row: their results are never written
+    auto gload = [&](int d0) {
+        const bool full = VEC && (d0 + DC <= dhi);                 // wave-uniform: unguarded 16-B loads
+#pragma unroll
+        for (int q = 0; q < XITEMS; ++q) {
+            const int e = q * 256 + tid, row = e >> 3, c4 = (e & 7) * 4;
+            const float* rp = x + (int64_t)min(b0 + row, B - 1) * xbs;
+            px[q] = full ? *reinterpret_cast<const float4*>(rp + d0 + c4) : ld4_tail<VEC>(rp, d0 + c4, dhi);
+        }
+#pragma unroll
+        for (int q = 0; q < PITEMS; ++q) {
+            const int e = q * 256 + tid, row = e >> 3, c4 = (e & 7) * 4;
+            const int64_t off = (int64_t)min(mk0 + row, MKtot - 1) * D;
+            pa[q] = full ? *reinterpret_cast<const float4*>(a + off + d0 + c4) : ld4_tail<VEC>(a + off, d0 + c4, dhi);
+            pb[q] = full ? *reinterpret_cast<const float4*>(bm + off + d0 + c4) : ld4_tail<VEC>(bm + off, d0 + c4, dhi);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < XITEMS; ++q) {
+            const int e = q * 256 + tid, row = e >> 3, c4 = (e & 7) * 4;
+            *reinterpret_cast<float4*>(&xs[row * LD + c4]) = px[q];
+        }
+#pragma unroll
+        for (int q = 0; q < PITEMS; ++q) {
+            const int e = q * 256 + tid, row = e >> 3, c4 = (e & 7) * 4;
+            if (row < MKB) {
+                *reinterpret_cast<float4*>(&as_[row * LD + c4]) = pa[q];
+                *reinterpret_cast<float4*>(&bs[row * LD + c4]) = pb[q];
+            }
+        }
+    };
+
+    gload(dlo);
+    for (int d0 = dlo; d0 < dhi; d0 += DC) {
+        __syncthreads();                      // previous chunk fully consumed
+        lstore();
+        __syncthreads();
+        if (d0 + DC < dhi) gload(d0 + DC);    // prefetch the next chunk behind the FMAs
+#pragma unroll 2
+        for (int dd = 0; dd < DC; dd += 2) {
+            // 8-byte LDS reads: same bytes per LDS cycle as 16-byte ones, half the operand registers
+            float2 xv[SPT], av[MKT], bv[MKT];
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) xv[i] = *reinterpret_cast<const float2*>(&xs[(ts + 16 * i) * LD + dd]);
+#pragma unroll
+            for (int j = 0; j < MKT; ++j) {
+                av[j] = *reinterpret_cast<const float2*>(&as_[(tm + 16 * j) * LD + dd]);
+                bv[j] = *reinterpret_cast<const float2*>(&bs[(tm + 16 * j) * LD + dd]);
+            }
+#pragma unroll
+            for (int i = 0; i < SPT; ++i)
+#pragma unroll
+                for (int j = 0; j < MKT; ++j) {
+                    float t;
+                    t = fmaf(xv[i].x, av[j].x, bv[j].x); acc[i][j] = fmaf(t, t, acc[i][j]);
+                    t = fmaf(xv[i].y, av[j].y, bv[j].y); acc[i][j] = fmaf(t, t, acc[i][j]);
+                }
+        }
+    }
+
+    if (SPLIT) {
+        float* qb = qout + (int64_t)blockIdx.z * B * MKtot;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int b = b0 + ts + 16 * i;
+#pragma unroll
+            for (int j = 0; j < MKT; ++j) {
+                const int mk = mk0 + tm + 16 * j;
+                if (b < B && mk < MKtot) qb[(int64_t)b * MKtot + mk] = acc[i][j];
+            }
+        }
+        return;
+    }
+
+    // epilogue: q -> LDS, then logsumexp over the K components of every (sample, mixture)
+    __syncthreads();
+    float* qs = lds;                                  // [TB][MKB+1]
+#pragma unroll
+    for (int i = 0; i < SPT; ++i)
+#pragma unroll
+        for (int j = 0; j < MKT; ++j) qs[(ts + 16 * i) * (MKB + 1) + tm + 16 * j] = acc[i][j];
+    __syncthreads();
+    const int mloc = MKB / K;                         // mixtures fully inside this component block
+    for (int e = tid; e < TB * mloc; e += 256) {
+        const int s = e / mloc, ml = e - s * mloc;
+        const int b = b0 + s, mk = mk0 + ml * K;
+        if (b >= B || mk >= MKtot) continue;
+        const float* qrow = &qs[s * (MKB + 1) + ml * K];
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, cst[mk + k] - 0.5f * qrow[k]);
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += expf(cst[mk + k] - 0.5f * qrow[k] - mx);
+        const float r = mx + logf(sum);
+        float* o = out + (int64_t)b * Mtot + (mk / K);
+        *o = accumulate ? *o + r : r;
+    }
+}
+
+// finishing kernel for the D-split form: sum partials, logsumexp.  one thread per (b, m)
+__global__ __launch_bounds__(256) void k_gmm_finish(const float* __restrict__ q, const float* __restrict__ cst,
+                                                    float* __restrict__ out, int B, int M, int K, int nsplit,
+                                                    int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * M) return;
+    const int b = (int)(e / M), m = (int)(e - (int64_t)b * M);
+    const int MK = M * K;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += q[((int64_t)z * B + b) * MK + m * K + k];
+        mx = fmaxf(mx, cst[m * K + k] - 0.5f * s);
+    }
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (int z = 0; z < nsplit; ++z) s += q[((int64_t)z * B + b) * MK + m * K + k];
+        sum += expf(cst[m * K + k] - 0.5f * s - mx);
+    }
+    const float r = mx + logf(sum);
+    out[e] = accumulate ? out[e] + r : r;
+}
+
+// D-split heuristic: enough workgroups to cover the chip (~2 per CU), chunks stay multiples of DC
+int choose_nsplit(int B, int MK, int D) {
+    const int mkb = MK <= 16 ? 16 : 80;
+    const int64_t base = (int64_t)((B + TB - 1) / TB) * ((MK + mkb - 1) / mkb);
+    int ns = 1;
+    while (base * ns < 512 && ns < 16 && D / (ns * 2) >= 4 * DC) ns *= 2;
+    return ns;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, float* bm, float* cst, int M, int K,
+                   int D, cf_stream_t stream) {
+    CF_REQUIRE(mG && sG && wG && a && bm && cst && M > 0 && K > 0 && D > 0);
+    k_gmm_prepare<<<dim3(M * K), dim3(256), 0, cf_s(stream)>>>(mG, sG, wG, a, bm, cst, K, D);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int64_t cf_gmm_ws_bytes(int B, int M, int K, int D) {
+    const int ns = choose_nsplit(B, M * K, D);
+    return ns > 1 ? (int64_t)ns * B * M * K * sizeof(float) : 0;
+}
+
+int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float* cst, float* out, void* ws,
+                   int B, int M, int K, int D, int64_t x_bstride, int accumulate, cf_stream_t stream) {
+    CF_REQUIRE(x && a && bm && cst && out && B >= 0 && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
+    if (B == 0) return 0;
+    const int MK = M * K;
+    const bool small = MK <= 16;
+    CF_REQUIRE(small ? (16 % K == 0 || M == 1) : (80 % K == 0));
+    int ns = ws ? choose_nsplit(B, MK, D) : 1;
+    int dsplit = D;
+    if (ns > 1) { dsplit = ((D + ns - 1) / ns + DC - 1) / DC * DC; ns = (D + dsplit - 1) / dsplit; }
+    const bool vec = (D % 4 == 0) && (x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(bm) & 15) == 0) &&
+                     (dsplit % 4 == 0);
+    const int mkb = small ? 16 : 80;
+    dim3 grid((B + TB - 1) / TB, (MK + mkb - 1) / mkb, ns);
+    float* q = (float*)ws;
+#define CF_GO(MKT, V, S) k_gmm_logprob<MKT, V, S><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, bm, cst, out, q, B, MK, K, D, dsplit, x_bstride, accumulate, M)
+    if (ns > 1) {
+        if (small) { if (vec) CF_GO(1, true, true); else CF_GO(1, false, true); }
+        else       { if (vec) CF_GO(5, true, true); else CF_GO(5, false, true); }
+        const int64_t n = (int64_t)B * M;
+        k_gmm_finish<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cf_s(stream)>>>(q, cst, out, B, M, K, ns, accumulate);
+    } else {
+        if (small) { if (vec) CF_GO(1, true, false); else CF_GO(1, false, false); }
+        else       { if (vec) CF_GO(5, true, false); else CF_GO(5, false, false); }
+    }
+#undef CF_GO
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,491 @@
+// One flow step — Conv1x1 -> ActNorm -> Coupling(1x1, ReLU, 3x3 reflect, ReLU, 1x1; affine map;
+// log-det) — as ONE gfx950 kernel.  Reference: contextflow/model.py:129-147 (the per-step triple),
+// layers/conv1x1.py:52-57, layers/actnorm.py:53-60, layers/coupling.py:26-29,52-66.
+//
+// Design (MI355X):
+//  * every contraction runs on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32): the weights
+//    are the A operand (row = output channel), the activations the B operand (column = pixel), so
+//    a result tile has the PIXEL on the lane and the CHANNELS in the 16 accumulator registers.
+//    That makes every LDS access of the activation planes [channel][pixel] a run of 32 consecutive
+//    floats per half-wave (bank-conflict free, also under the 3x3 tap shifts with reflection), and
+//    puts t, log_s and x1 of one (channel, pixel) in the SAME lane for the affine epilogue;
+//  * a workgroup (4 waves) owns PIX = 128/256 pixels = SPW whole samples; activations never leave
+//    the CU between the five contractions: x -> [MFMA] y=W'x+b' (ActNorm folded into the 1x1
+//    matrix) -> LDS -> h1 -> LDS -> 3x3 implicit GEMM over 9 taps -> LDS -> h -> epilogue.
+//    HBM traffic per step = read x once + write z once;
+//  * weights are pre-packed per call by cf_flow_step_prepare into MFMA-fragment order (one 16-byte
+//    load per lane = A fragments of 4 k-steps, 1 KiB per wave-instruction, L2-resident) and
+//    software-prefetched one group ahead of the MFMAs that use them;
+//  * log-det: lane-local sum over channels, shuffle-reduce over the lanes of one sample, one LDS
+//    hop across waves, then a plain read-modify-write of ldj_acc[b] by the single owner of sample
+//    b — no float atomics, bitwise reproducible.
+#include "cf_common.h"
+#include <math.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;
+
+// ---- compile-time geometry of one supported shape ------------------------------------------------
+template <int C_, int H_, int W_, int SPW_>
+struct Geo {
+    static constexpr int C = C_, H = H_, W = W_, SPW = SPW_;
+    static constexpr int HW = H * W;
+    static constexpr int PIX = SPW * HW;              // pixels per workgroup
+    static constexpr int HALF = C / 2;                // conditioner channels
+    static constexpr int HID = 2 * C;                 // hidden width of the coupling net
+    static constexpr int NPT = PIX / 32;              // 32-pixel tiles per workgroup
+    static constexpr int PTW = NPT / kWaves;          // pixel tiles per wave
+    static constexpr int HP = HALF <= 16 ? 16 : 32;   // packed rows per channel half
+    static constexpr int R03 = 2 * HP;                // packed rows of the C-channel results (y, h)
+    static constexpr int RT03 = R03 / 32;
+    static constexpr int RT1 = (HID + 31) / 32;       // row tiles of the hidden planes
+    static constexpr int R1 = RT1 * 32;
+    // k-steps (2 k per MFMA) and 4-step groups of every contraction
+    static constexpr int KS0 = C / 2, KS1 = HALF / 2, KS3 = HID / 2;
+    static constexpr int NG0 = (KS0 + 3) / 4, NG1 = (KS1 + 3) / 4, NG3 = (KS3 + 3) / 4;
+    static constexpr int NCG = HID / 8;               // groups per 3x3 tap
+    static constexpr int NG2 = 9 * NCG;
+    // workspace layout (floats)
+    static constexpr int OFF_B0 = 4, OFF_B1 = OFF_B0 + R03, OFF_B2 = OFF_B1 + R1, OFF_B3 = OFF_B2 + R1;
+    static constexpr int OFF_A0 = OFF_B3 + R03;
+    static constexpr int OFF_A1 = OFF_A0 + NG0 * RT03 * 256;
+    static constexpr int OFF_A2 = OFF_A1 + NG1 * RT1 * 256;
+    static constexpr int OFF_A3 = OFF_A2 + NG2 * RT1 * 256;
+    static constexpr int WS_FLOATS = OFF_A3 + NG3 * RT03 * 256;
+    static constexpr int LDS_FLOATS = (HALF + HID) * PIX;
+    static_assert(PIX % 128 == 0 && PTW >= 1, "workgroup must own a multiple of 128 pixels");
+    static_assert(HID % 8 == 0 && C % 4 == 0, "channel counts must fill whole k-steps");
+    static_assert((HW & (HW - 1)) == 0 && (W & (W - 1)) == 0, "power-of-two images");
+};
+
+// packed row p of a C-channel result -> channel, or -1 for a padding row.  First-half channels sit
+// in rows [0, HALF), second-half channels in rows [HP, HP + HALF): t / log_s / x1 of one channel
+// then share a lane and differ by a fixed register offset.
+template <class G> __host__ __device__ constexpr int chan_of_row(int p) {
+    return ((p % G::HP) < G::HALF) ? (p / G::HP) * G::HALF + (p % G::HP) : -1;
+}
+
+// ---- weight packing (cf_flow_step_prepare) ---------------------------------------------------------
+// A fragment of k-step s, row tile rt, lane l: A[row = rt*32 + (l&31)][k = 2s + (l>>5)]; 4 k-steps
+// per float4: element ((g*RT + rt)*64 + l)*4 + e holds k-step 4g+e.
+template <class G>
+__global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm, const float* __restrict__ t,
+                                                   const float* __restrict__ logs, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2,
+                                                   const float* __restrict__ b2, const float* __restrict__ w3,
+                                                   const float* __restrict__ b3, float* __restrict__ ws) {
+    const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    if (gtid == 0) {       // ldj_const = H*W*log|det Wm| + sum_c logs  (ws[1] holds log|det| from k_slogdet)
+        float s = 0.f;
+        for (int c = 0; c < G::C; ++c) s += logs[c];
+        ws[0] = (float)G::HW * ws[1] + s;                    // conv1x1.py:53 + actnorm.py:58
+    }
+    for (int p = gtid; p < G::R03; p += gsz) {
+        const int ch = chan_of_row<G>(p);
+        ws[G::OFF_B0 + p] = ch >= 0 ? -t[ch] * expf(-logs[ch]) : 0.f;     // (x - t) e^{-logs} = e^{-logs} x - t e^{-logs}
+        ws[G::OFF_B3 + p] = ch >= 0 ? b3[ch] : 0.f;
+    }
+    for (int p = gtid; p < G::R1; p += gsz) {
+        ws[G::OFF_B1 + p] = p < G::HID ? b1[p] : 0.f;
+        ws[G::OFF_B2 + p] = p < G::HID ? b2[p] : 0.f;
+    }
+    auto split = [](int e, int RT, int& g, int& rt, int& lane, int& j) {
+        j = e & 3; lane = (e >> 2) & 63; const int q = e >> 8; rt = q % RT; g = q / RT;
+    };
+    int g, rt, lane, j;
+    for (int e = gtid; e < G::NG0 * G::RT03 * 256; e += gsz) {            // phase 0: e^{-logs} Wm
+        split(e, G::RT03, g, rt, lane, j);
+        const int ch = chan_of_row<G>(rt * 32 + (lane & 31)), k = 2 * (4 * g + j) + (lane >> 5);
+        ws[G::OFF_A0 + e] = (ch >= 0 && k < G::C) ? expf(-logs[ch]) * Wm[ch * G::C + k] : 0.f;
+    }
+    for (int e = gtid; e < G::NG1 * G::RT1 * 256; e += gsz) {             // phase 1: NN.0 (HID x HALF)
+        split(e, G::RT1, g, rt, lane, j);
+        const int row = rt * 32 + (lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+        ws[G::OFF_A1 + e] = (row < G::HID && k < G::HALF) ? w1[row * G::HALF + k] : 0.f;
+    }
+    for (int e = gtid; e < G::NG2 * G::RT1 * 256; e += gsz) {             // phase 2: NN.2, k = tap*HID + ci
+        split(e, G::RT1, g, rt, lane, j);
+        const int row = rt * 32 + (lane & 31);
+        const int tap = g / G::NCG, ci = 8 * (g % G::NCG) + 2 * j + (lane >> 5);
+        ws[G::OFF_A2 + e] = (row < G::HID) ? w2[(row * G::HID + ci) * 9 + tap] : 0.f;
+    }
+    for (int e = gtid; e < G::NG3 * G::RT03 * 256; e += gsz) {            // phase 3: NN.4 (C x HID), packed rows
+        split(e, G::RT03, g, rt, lane, j);
+        const int ch = chan_of_row<G>(rt * 32 + (lane & 31)), k = 2 * (4 * g + j) + (lane >> 5);
+        ws[G::OFF_A3 + e] = (ch >= 0 && k < G::HID) ? w3[ch * G::HID + k] : 0.f;
+    }
+}
+
+// ---- helpers -----------------------------------------------------------------------------------------
+// accumulator tile initialised with the per-row bias: row(r, lk) = (r&3) + 8*(r>>2) + 4*lk
+__device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ bias32, int lk) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(bias32 + 8 * q + 4 * lk);
+        a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+    return a;
+}
+__device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+__device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// One dense phase whose B operand is an LDS plane [k][PIX]:  acc[rt][q] += A_frag * plane
+//   KS   real k-steps, NG groups of 4, RT row tiles, frags = packed A of this phase
+template <class G, int KS, int NG, int RT>
+__device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const float4* __restrict__ frags,
+                                            const float* __restrict__ plane, const int (&pix)[G::PTW], int lane) {
+    const int lk = lane >> 5;
+    float4 a_cur[RT], a_nxt[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a_nxt[rt] = frags[((g + 1) * RT + rt) * 64 + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (4 * g + e < KS) {
+                const int k = 2 * (4 * g + e) + lk;
+#pragma unroll
+                for (int q = 0; q < G::PTW; ++q) {
+                    const float b = plane[k * G::PIX + pix[q]];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), b, acc[rt][q], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a_cur[rt] = a_nxt[rt];
+    }
+}
+
+// ---- the step kernel ---------------------------------------------------------------------------------
+// dbg (optional, tests only): [4][C_or_HID rows][gridDim*PIX] dumps of y, h1, h2, h.
+template <class G>
+__global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
+                                                   float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                   int64_t xbs, float* __restrict__ dbg) {
+    constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
+    constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
+    extern __shared__ __align__(16) float lds[];      // G::LDS_FLOATS floats (up to 80 KiB: dynamic)
+    float* Y0 = lds;                    // [HALF][PIX]   conditioner input y0 (phase 0 -> 1); later the ldj scratch
+    float* H1 = lds + HALF * PIX;       // [HID][PIX]    h1, then h2 in place
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    const int b0 = blockIdx.x * G::SPW;
+    const int64_t dbg_cols = (int64_t)gridDim.x * PIX;
+
+    int pix[PTW];                       // this lane's pixel column inside the workgroup, per owned tile
+    int smp[PTW], pin[PTW];             // sample (global) and pixel-in-sample
+    bool live[PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) {
+        pix[q] = (wave * PTW + q) * 32 + li;
+        smp[q] = b0 + pix[q] / HW;
+        pin[q] = pix[q] % HW;
+        live[q] = smp[q] < B;
+    }
+
+    // ================= phase 0: y = (e^{-logs} Wm) x - t e^{-logs}        (conv1x1.py:54 + actnorm.py:59)
+    f32x16 acc0[RT03][PTW];
+#pragma unroll
+    for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) acc0[rt][q] = bias_tile(ws + G::OFF_B0 + rt * 32, lk);
+    {
+        const float4* frags = reinterpret_cast<const float4*>(ws + G::OFF_A0);
+        const float* xp[PTW];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) xp[q] = x + (int64_t)min(smp[q], B - 1) * xbs + pin[q] + (int64_t)lk * HW;
+#pragma unroll
+        for (int g = 0; g < G::NG0; ++g) {
+            float4 a[RT03];
+#pragma unroll
+            for (int rt = 0; rt < RT03; ++rt) a[rt] = frags[(g * RT03 + rt) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (4 * g + e < G::KS0) {
+#pragma unroll
+                    for (int q = 0; q < PTW; ++q) {
+                        const float b = xp[q][(int64_t)(2 * (4 * g + e)) * HW];      // B[k][pixel] = x[ch k][pixel]
+#pragma unroll
+                        for (int rt = 0; rt < RT03; ++rt)
+                            acc0[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[rt], e), b, acc0[rt][q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // first half: conditioner input -> LDS, and it is also the first half of the output (coupling.py:65)
+    // second half (x1 after Conv1x1+ActNorm) stays in registers until the epilogue
+    float y1[PTW][HALF <= 16 ? 8 : 16];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) {
+        float* zq = z + (int64_t)smp[q] * C * HW + pin[q];
+#pragma unroll
+        for (int r = 0; r < (HALF <= 16 ? 8 : 16); ++r) {
+            const int idx = tile_row(r, lk);                 // channel index inside its half
+            const float v0 = acc0[0][q][r];
+            if (idx < HALF) {
+                Y0[idx * PIX + pix[q]] = v0;
+                if (live[q]) zq[(int64_t)idx * HW] = v0;
+            }
+            y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
+        }
+    }
+    __syncthreads();
+    if (dbg) {
+        for (int e = tid; e < HALF * PIX; e += 256) dbg[(int64_t)(e / PIX) * dbg_cols + blockIdx.x * PIX + (e % PIX)] = Y0[e];
+    }
+
+    // ================= phase 1: h1 = relu(NN.0 y0 + b)                      (coupling.py:26)
+    {
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B1 + rt * 32, lk);
+        dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(ws + G::OFF_A1), Y0, pix, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + tile_row(r, lk);
+                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                }
+    }
+    __syncthreads();
+    if (dbg) {
+        float* d = dbg + (int64_t)C * dbg_cols;
+        for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + blockIdx.x * PIX + (e % PIX)] = H1[e];
+    }
+
+    // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
+    {
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B2 + rt * 32, lk);
+        const float4* frags = reinterpret_cast<const float4*>(ws + G::OFF_A2);
+        float4 a_cur[RT1], a_nxt[RT1];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const float* src[PTW];
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
+                yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);       // reflect (padding_mode='reflect')
+                xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+                src[q] = H1 + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
+            }
+#pragma unroll
+            for (int cg = 0; cg < G::NCG; ++cg) {
+                const int g = tap * G::NCG + cg;
+                const int gn = min(g + 1, G::NG2 - 1);
+#pragma unroll
+                for (int rt = 0; rt < RT1; ++rt) a_nxt[rt] = frags[(gn * RT1 + rt) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int q = 0; q < PTW; ++q) {
+                        const float b = src[q][(8 * cg + 2 * e) * PIX];
+#pragma unroll
+                        for (int rt = 0; rt < RT1; ++rt)
+                            acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), b, acc[rt][q], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
+            }
+        }
+        __syncthreads();                 // every wave has finished reading h1 (taps cross pixel tiles)
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + tile_row(r, lk);
+                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                }
+    }
+    __syncthreads();
+    if (dbg) {
+        float* d = dbg + (int64_t)(C + HID) * dbg_cols;
+        for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + blockIdx.x * PIX + (e % PIX)] = H1[e];
+    }
+
+    // ================= phase 3: h = NN.4 h2 + b ; affine map ; log-det        (coupling.py:28,52-66)
+    f32x16 acc3[RT03][PTW];
+#pragma unroll
+    for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(ws + G::OFF_B3 + rt * 32, lk);
+    dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(ws + G::OFF_A3), H1, pix, lane);
+
+    float lsum[PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) {
+        lsum[q] = 0.f;
+        float* zq = z + (int64_t)smp[q] * C * HW + (int64_t)HALF * HW + pin[q];
+#pragma unroll
+        for (int r = 0; r < (HALF <= 16 ? 8 : 16); ++r) {
+            const int idx = tile_row(r, lk);
+            if (idx < HALF) {
+                const float tt = acc3[0][q][r];
+                const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
+                const float ls = 2.0f * tanhf(raw * 0.5f);                    // coupling.py:55-56
+                const float z1 = y1[q][r] * expf(ls) + tt;                     // coupling.py:63
+                lsum[q] += ls;
+                if (live[q]) zq[(int64_t)idx * HW] = z1;
+                if (dbg) {
+                    float* d = dbg + (int64_t)(C + 2 * HID) * dbg_cols + blockIdx.x * PIX + pix[q];
+                    d[(int64_t)idx * dbg_cols] = tt;
+                    d[(int64_t)(HALF + idx) * dbg_cols] = raw;
+                }
+            }
+        }
+    }
+    // per-sample reduction of log_s: lanes of one sample inside a 32-pixel tile, then across tiles via LDS
+    constexpr int SEG = HW < 32 ? HW : 32;            // lanes (pixels) of one sample inside a tile
+    constexpr int SPT = 32 / SEG;                      // samples per tile
+    __syncthreads();                                   // Y0 is dead: reuse it as scratch [NPT*SPT]
+    float* red = Y0;
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) {
+        float v = lsum[q];
+#pragma unroll
+        for (int o = 1; o < SEG; o <<= 1) v += __shfl_xor(v, o, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lk == 0 && (li % SEG) == 0) red[(wave * PTW + q) * SPT + li / SEG] = v;
+    }
+    __syncthreads();
+    if (tid < G::SPW && b0 + tid < B) {
+        constexpr int EPS = HW >= 32 ? HW / 32 : 1;                  // scratch entries per sample
+        float s = 0.f;
+        if (HW >= 32) {
+#pragma unroll
+            for (int i = 0; i < EPS; ++i) s += red[tid * EPS + i];
+        } else {
+            s = red[tid];
+        }
+        ldj_acc[b0 + tid] += ws[0] + s;
+    }
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------------
+using G8 = Geo<8, 16, 16, 1>;
+using G16 = Geo<16, 16, 16, 1>;
+using G32 = Geo<32, 8, 8, 4>;
+using G64 = Geo<64, 4, 4, 8>;
+
+template <class G>
+int launch_prepare(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
+                   const float* w2, const float* b2, const float* w3, const float* b3, float* ws, hipStream_t s) {
+    int rc = cf_slogdet_inverse(Wm, G::C, ws + 1, nullptr, (cf_stream_t)s);
+    if (rc) return rc;
+    int blocks = (G::WS_FLOATS + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    k_step_pack<G><<<dim3(blocks), dim3(256), 0, s>>>(Wm, t, logs, w1, b1, w2, b2, w3, b3, ws);
+    return 0;
+}
+
+template <class G>
+int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
+    if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds_bytes);
+            if (e != hipSuccess) { cf_set_error("cf_flow_step_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
+    k_flow_step<G><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg);
+    return 0;
+}
+
+int shape_id(int C, int H, int W) {
+    if (C == 8 && H == 16 && W == 16) return 0;
+    if (C == 16 && H == 16 && W == 16) return 1;
+    if (C == 32 && H == 8 && W == 8) return 2;
+    if (C == 64 && H == 4 && W == 4) return 3;
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cf_flow_step_supported(int C, int H, int W, int kh, int kw) {
+    return (kh == 3 && kw == 3 && shape_id(C, H, W) >= 0) ? 1 : 0;
+}
+
+int64_t cf_flow_step_ws_bytes(int C, int H, int W) {
+    switch (shape_id(C, H, W)) {
+        case 0: return (int64_t)G8::WS_FLOATS * 4;
+        case 1: return (int64_t)G16::WS_FLOATS * 4;
+        case 2: return (int64_t)G32::WS_FLOATS * 4;
+        case 3: return (int64_t)G64::WS_FLOATS * 4;
+    }
+    return 0;
+}
+
+int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
+                         const float* w2, const float* b2, const float* w3, const float* b3, void* ws, int C, int H,
+                         int W, cf_stream_t stream) {
+    CF_REQUIRE(Wm && t && logs && w1 && b1 && w2 && b2 && w3 && b3 && ws);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+    int rc;
+    float* w = (float*)ws;
+    switch (shape_id(C, H, W)) {
+        case 0: rc = launch_prepare<G8>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
+        case 1: rc = launch_prepare<G16>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
+        case 2: rc = launch_prepare<G32>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
+        case 3: rc = launch_prepare<G64>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
+        default: cf_set_error("cf_flow_step_prepare: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// test hook (not part of the public header): same as cf_flow_step_fwd plus per-phase dumps
+int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
+                           int64_t x_bstride, float* dbg, cf_stream_t stream) {
+    CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);
+    if (B == 0) return 0;
+    const float* w = (const float*)ws;
+    int rc = 0;
+    switch (shape_id(C, H, W)) {
+        case 0: rc = launch_step<G8>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)); break;
+        case 1: rc = launch_step<G16>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)); break;
+        case 2: rc = launch_step<G32>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)); break;
+        case 3: rc = launch_step<G64>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)); break;
+        default: cf_set_error("cf_flow_step_fwd: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
+                     int64_t x_bstride, cf_stream_t stream) {
+    return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, nullptr, stream);
+}
+
+}  // extern "C"

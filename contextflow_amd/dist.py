@@ -1,0 +1,66 @@
+"""Data-parallel evaluation of the flow: one process per GPU, batch sharded, ONE collective.
+
+The reference is single-device (contextflow/model.py:168-170).  Every sample's log-density depends
+only on that sample and the replicated parameters, so ranks never exchange
+activations; the only exchange is an all-reduce (RCCL over xGMI on MI355X, `backend="nccl"`; gloo
+in the CPU tests) of two fp64 scalars [sum_b logsumexp_m logp[b, :], number of samples] from which
+the global mean NLL / bits-per-dim follows.  The message is 16 bytes: latency-bound, not link-bound.
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_bounds(total, rank, world):
+    """Contiguous, balanced shard [lo, hi) of `total` samples for `rank` (first `total % world` ranks get one more)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_nll(local_sum_logp, local_count):
+    """All-reduce [sum of per-sample log p, sample count] (fp64).  `local_sum_logp` may be a 0-dim/1-elem
+    tensor on the compute device.  Returns the reduced (sum, count) as a 2-element fp64 tensor."""
+    dev = local_sum_logp.device if torch.is_tensor(local_sum_logp) else torch.device("cpu")
+    buf = torch.zeros(2, dtype=torch.float64, device=dev)
+    buf[0] = local_sum_logp.reshape(-1)[0].double() if torch.is_tensor(local_sum_logp) else float(local_sum_logp)
+    buf[1] = float(local_count)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
+
+
+def mean_bits_per_dim(reduced, dims):
+    """bits/dim = -(sum log p / count) / (D ln 2)."""
+    return float(-(reduced[0] / reduced[1]) / (dims * math.log(2.0)))
+
+
+def broadcast_parameters(module, src=0):
+    """Replicate parameters and buffers from `src` (after rank `src` ran the ActNorm data-dependent init)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src)
+    for m in module.modules():
+        if hasattr(m, "_init_done") and hasattr(m, "initialized"):
+            m._init_done = bool(int(m.initialized.item()))

@@ -1,0 +1,120 @@
+"""ctypes binding of libcontextflow_hip.so (C ABI: include/contextflow_hip.h).
+
+This is the only place the product touches native code.  There is NO CPU fallback: if the shared
+library is missing, or a tensor is not on a ROCm device, the call raises.  (The CPU oracle lives in
+`oracle/` and is test infrastructure only.)
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libcontextflow_hip.so")
+ABI_VERSION = 1
+
+_c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/contextflow_hip.h declares
+SIGNATURES = {
+    "cf_abi_version": (_c_int, []),
+    "cf_last_error": (ctypes.c_char_p, []),
+    "cf_dequant_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p]),
+    "cf_affine": (_c_int, [_c_p, _c_p, _c_i64, _c_f, _c_f, _c_int, _c_p]),
+    "cf_logit_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
+    "cf_sigmoid": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
+    "cf_floor": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
+    "cf_preprocess_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
+    "cf_std_normal_nll": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_i64, _c_p]),
+    "cf_squeeze": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_int, _c_p]),
+    "cf_conv1x1_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_p]),
+    "cf_slogdet_inverse": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p]),
+    "cf_actnorm_stats_ws_bytes": (_c_i64, [_c_int]),
+    "cf_actnorm_stats": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_p]),
+    "cf_actnorm": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "cf_conv2d_reflect": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_i64, _c_p]),
+    "cf_coupling_apply": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
+    "cf_gmm_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_p]),
+    "cf_gmm_ws_bytes": (_c_i64, [_c_int] * 4),
+    "cf_gmm_logprob": (_c_int, [_c_p] * 6 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
+    "cf_flow_step_supported": (_c_int, [_c_int] * 5),
+    "cf_flow_step_ws_bytes": (_c_i64, [_c_int] * 3),
+    "cf_flow_step_prepare": (_c_int, [_c_p] * 10 + [_c_int] * 3 + [_c_p]),
+    "cf_flow_step_fwd": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_p]),
+    "cf_linear": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),
+    "cf_layernorm": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_f, _c_p]),
+    "cf_attention": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
+    "cf_patchify": (_c_int, [_c_p, _c_p] + [_c_int] * 6 + [_c_i64, _c_int, _c_p]),
+    "cf_logdet_combine": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
+    "cf_nll_sum": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "contextflow_amd: %s not found. Build it first: "
+                "python -c 'import __graft_entry__ as g; g.build()' (needs hipcc, gfx950)." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        got = handle.cf_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError("contextflow_amd: ABI version %d != expected %d" % (got, ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().cf_last_error().decode(errors="replace")
+        raise RuntimeError("libcontextflow_hip %s failed (code %d): %s" % (what, rc, msg))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def stream():
+    return _c_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "contextflow_amd layers run on a ROCm device only (got a %s tensor); there is no CPU path" % t.device)
+
+
+def f32(t):
+    """fp32 + fully contiguous view/copy of a parameter or activation."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def bview(t):
+    """(tensor, batch_stride) with everything but the batch dim dense (so channel slices pass un-copied)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    inner = 1
+    ok = True
+    for d in range(t.dim() - 1, 0, -1):
+        if t.shape[d] != 1 and t.stride(d) != inner:
+            ok = False
+            break
+        inner *= t.shape[d]
+    if not ok or (t.shape[0] > 1 and t.stride(0) < inner):
+        t = t.contiguous()
+    bs = t.stride(0) if t.shape[0] > 1 else inner
+    return t, int(bs)
+
+
+def p(t):
+    return _c_p(0) if t is None else _c_p(t.data_ptr())

@@ -1,0 +1,85 @@
+"""ActNorm (reference: contextflow/layers/actnorm.py:7-101), context-free branch.
+
+Reference quirks kept on purpose: the data-dependent init runs on the
+first forward in any mode, uses the unbiased std and log(std + 1e-8); ldj = +sum_c logs."""
+import torch
+import torch.nn as nn
+
+from . import _hip
+from .flowlayer import FlowLayer, no_context
+
+
+class ActNorm(FlowLayer):
+    def __init__(self, data_size, context_net=None, contextflow=False):
+        super().__init__()
+        no_context("ActNorm", context_net)
+        D, H, W = data_size if len(data_size) == 3 else (data_size[0], 1, 1)
+        self.D, self.H, self.W = D, H, W
+        self.NN_t = nn.Parameter(torch.zeros(D))
+        self.NN_logs = nn.Parameter(torch.zeros(D))
+        self.register_buffer("initialized", torch.tensor(0))
+        self.context_net = context_net
+        self.contextflow = contextflow
+        self._init_done = False          # host mirror of the flag: no device sync per call
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._init_done = bool(int(self.initialized.item()))
+
+    def is_initialized(self):
+        return self._init_done
+
+    def initialize(self, x):
+        """actnorm.py:28-35 on the device: two-stage fp64 reduction of sum x and sum x^2 per channel."""
+        x, xbs = _hip.bview(x)
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        ws = torch.empty(_hip.lib().cf_actnorm_stats_ws_bytes(C), device=x.device, dtype=torch.uint8)
+        t = torch.empty(C, device=x.device, dtype=torch.float32)
+        logs = torch.empty(C, device=x.device, dtype=torch.float32)
+        _hip.call("cf_actnorm_stats", _hip.p(x), _hip.p(t), _hip.p(logs), _hip.p(ws), B, C, HW, xbs, _hip.stream())
+        with torch.no_grad():
+            self.NN_t.data.copy_(t)
+            self.NN_logs.data.copy_(logs)
+            self.initialized.fill_(1)
+        self._init_done = True
+
+    def _run(self, x, inverse):
+        _hip.require_device(x, self.NN_t)
+        x = _hip.f32(x)
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // max(B * C, 1) if B else 1
+        out = torch.empty_like(x)
+        s = None if inverse else torch.empty(1, device=x.device, dtype=torch.float32)
+        _hip.call("cf_actnorm", _hip.p(x), _hip.p(_hip.f32(self.NN_t.detach())), _hip.p(_hip.f32(self.NN_logs.detach())),
+                  _hip.p(out), _hip.p(s), B, C, HW, int(inverse), _hip.stream())
+        return out, s
+
+    def forward(self, x, context=None):
+        _hip.require_device(x)
+        if not self._init_done:
+            self.initialize(x)
+        z, s = self._run(x, False)
+        return z, s.expand(x.shape[0])
+
+    def reverse(self, z, context=None):
+        assert self._init_done
+        return self._run(z, True)[0]
+
+    def logdet(self, x, context=None):
+        return self.forward(x, context)[1]
+
+
+class ActNormFC(ActNorm):
+    def __init__(self, data_size):
+        super().__init__(data_size)
+
+    def forward(self, x, context=None):
+        out, ldj = super().forward(x.view(-1, self.D, 1, 1), context)
+        return out.view(-1, self.D), ldj
+
+    def reverse(self, x, context=None):
+        return super().reverse(x.view(-1, self.D, 1, 1), context).view(-1, self.D)
+
+    def logdet(self, x, context=None):
+        return super().logdet(x.view(-1, self.D, 1, 1))

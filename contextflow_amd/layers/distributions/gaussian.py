@@ -1,0 +1,102 @@
+"""Base densities on the hot path (reference: contextflow/layers/distributions/gaussian.py).
+
+StandardNormal (:10-72) is the Augment noise model; GaussianMixtureDistribution (:118-169) is the
+class-conditional prior used by SplitPrior and as the final base density.  The reference broadcasts
+(B, M, K, D, H, W); here one register-tiled kernel streams x once per 80 components."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..flowlayer import no_context
+
+
+class StandardNormal(nn.Module):
+    def __init__(self, size, mixtures=1, context_net=None, contextflow=False):
+        super().__init__()
+        assert mixtures == 1, "mixtures should be 1 in StandardNormal"
+        no_context("StandardNormal", context_net)
+        self.size = torch.Size(size)
+        self.M = mixtures
+        self.K = 8
+        self.register_buffer("buffer", torch.zeros(1))
+        self.context_net = context_net
+        self.contextflow = contextflow
+        self.fixed_noise = None      # tests inject the reference's captured noise here
+
+    def forward(self, input, context=None):
+        return self.log_prob(input, context)
+
+    def log_prob(self, input, context=None):
+        """(B,1): sum(-0.5 log 2pi - 0.5 x^2)   gaussian.py:50-54."""
+        _hip.require_device(input)
+        x, xbs = _hip.bview(input)
+        B = x.shape[0]
+        N = x.numel() // max(B, 1) if B else 1
+        nll = torch.empty(B, device=x.device, dtype=torch.float32)
+        _hip.call("cf_std_normal_nll", _hip.p(x), _hip.p(nll), B, N, xbs, _hip.stream())
+        return -nll.unsqueeze(-1)
+
+    def sample(self, n_samples, context=None):
+        dev = self.buffer.device
+        if self.fixed_noise is not None:
+            x = self.fixed_noise.to(dev)
+        else:
+            x = torch.randn(n_samples, *self.size, device=dev, dtype=self.buffer.dtype)
+        return x, self.log_prob(x, context)
+
+
+def gmm_prepare(mG, sG, wG):
+    """Per-call parameter transform on the device: a = 1/softplus(sG), bm = -mG*a, cst (M,K)."""
+    M, K = wG.shape
+    D = mG.numel() // (M * K)
+    dev = mG.device
+    a = torch.empty(M * K, D, device=dev, dtype=torch.float32)
+    bm = torch.empty(M * K, D, device=dev, dtype=torch.float32)
+    cst = torch.empty(M * K, device=dev, dtype=torch.float32)
+    _hip.call("cf_gmm_prepare", _hip.p(_hip.f32(mG)), _hip.p(_hip.f32(sG)), _hip.p(_hip.f32(wG)),
+              _hip.p(a), _hip.p(bm), _hip.p(cst), M, K, D, _hip.stream())
+    return a, bm, cst, M, K, D
+
+
+def gmm_logprob(x, prepared, out=None, accumulate=False):
+    a, bm, cst, M, K, D = prepared
+    x, xbs = _hip.bview(x)
+    B = x.shape[0]
+    assert x.numel() // max(B, 1) == D or B == 0
+    if out is None:
+        out = torch.empty(B, M, device=x.device, dtype=torch.float32)
+        accumulate = False
+    nbytes = _hip.lib().cf_gmm_ws_bytes(B, M, K, D)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    _hip.call("cf_gmm_logprob", _hip.p(x), _hip.p(a), _hip.p(bm), _hip.p(cst), _hip.p(out), _hip.p(ws),
+              B, M, K, D, xbs, int(accumulate), _hip.stream())
+    return out
+
+
+class GaussianMixtureDistribution(nn.Module):
+    def __init__(self, size, mixtures=2, components=8, context_net=None, contextflow=False):
+        super().__init__()
+        no_context("GaussianMixtureDistribution", context_net)
+        self.size = size
+        D, H, W = size
+        self.D = D
+        self.M = M = mixtures
+        self.K = K = components
+        self.mG = nn.Parameter(torch.randn(M, K, D, H, W))
+        self.sG = nn.Parameter(torch.ones(M, K, D, H, W))
+        self.wG = nn.Parameter(torch.randn(M, K))
+        self.context_net = context_net
+        self.contextflow = contextflow
+
+    def prepared(self):
+        return gmm_prepare(self.mG.detach(), self.sG.detach(), self.wG.detach())
+
+    def log_prob(self, input, context=None):
+        """(B, M) class-mixture log-densities   gaussian.py:142-161."""
+        _hip.require_device(input, self.mG)
+        return gmm_logprob(input, self.prepared())
+
+    def sample(self, n_samples, context=None):
+        raise NotImplementedError("sampling from the prior is a later scope row (SURVEY.md §8(f) rank 3)")

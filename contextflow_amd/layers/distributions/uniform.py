@@ -1,0 +1,31 @@
+"""UniformDistribution (reference: contextflow/layers/distributions/uniform.py:6-34)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class UniformDistribution(nn.Module):
+    def __init__(self, size, scale=1.0):
+        super().__init__()
+        self.size = size
+        self.scale = scale
+        self.dim = int(np.prod(size))
+        self.register_buffer("empty", torch.zeros(1))
+        self.fixed_noise = None      # tests inject the reference's captured noise here
+
+    def forward(self, input, context=None):
+        return self.log_prob(input, context)
+
+    def log_prob(self, input, context=None):
+        inside = (input >= 0) & (input <= 1.0)
+        log_px = torch.where(inside, torch.zeros_like(input), torch.full_like(input, -1e30))
+        return log_px.view(log_px.size(0), self.dim).sum(-1)
+
+    def sample(self, n_samples, context=None):
+        dev = self.empty.device
+        if self.fixed_noise is not None:
+            x = self.fixed_noise.to(dev)
+        else:
+            # drawn on the device (the reference draws on the CPU and copies: uniform.py:32)
+            x = torch.rand((n_samples, *self.size), device=dev) / self.scale
+        return x, torch.zeros(x.shape[0], device=dev)

@@ -1,0 +1,36 @@
+"""FlowLayer contract of the reference (contextflow/layers/flowlayer.py:7-51):
+forward(input, context=None) -> (output, ldj); reverse(input, context=None) -> input; logdet(...) -> ldj.
+`ldj` is (B,) or (B, M)."""
+from abc import ABCMeta, abstractmethod
+
+import torch.nn as nn
+
+
+class FlowLayer(nn.Module, metaclass=ABCMeta):
+    @abstractmethod
+    def forward(self, input, context=None):
+        ...
+
+    @abstractmethod
+    def reverse(self, input, context=None):
+        ...
+
+    @abstractmethod
+    def logdet(self, input, context=None):
+        ...
+
+
+class PreprocessingFlowLayer(FlowLayer):
+    pass
+
+
+class ModifiedGradFlowLayer(FlowLayer):
+    pass
+
+
+def no_context(module_name, context_net):
+    """The generalist (context-free) path is implemented natively; specialist variants are the next
+    scope row."""
+    if context_net:
+        raise NotImplementedError(
+            "%s: context-conditioned (specialist) variant is not implemented in contextflow_amd yet" % module_name)

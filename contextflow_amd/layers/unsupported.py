@@ -1,0 +1,26 @@
+"""Names the reference's `from layers import *` exposes that are outside the density hot path
+(§8(f)).  They exist so that model-assembly code importing them keeps
+working; constructing one raises."""
+import torch.nn as nn
+
+
+def _stub(name, why):
+    def __init__(self, *a, **k):
+        raise NotImplementedError("%s is not implemented in contextflow_amd (%s)" % (name, why))
+    return type(name, (nn.Module,), {"__init__": __init__})
+
+
+MaskedCoupling = _stub("MaskedCoupling", "--coupling maf; not in the benchmark configs, inverse is a stub upstream")
+PermuteAxes = _stub("PermuteAxes", "ATM topology only")
+StudentMixtureDistribution = _stub("StudentMixtureDistribution", "--dist tdist; non-default prior")
+ConditionalGaussianDistribution = _stub("ConditionalGaussianDistribution", "specialist context encoders")
+GaussianDistribution = _stub("GaussianDistribution", "unused by create_model")
+MultivariateGaussianMixtureDistribution = _stub("MultivariateGaussianMixtureDistribution", "unused by create_model")
+UniformCatDequantization = _stub("UniformCatDequantization", "specialist context encoders")
+VariationalCatDequantization = _stub("VariationalCatDequantization", "specialist context encoders")
+ArgmaxCatDequantization = _stub("ArgmaxCatDequantization", "specialist context encoders")
+EyeSampling = _stub("EyeSampling", "specialist context encoders")
+ProbSampling = _stub("ProbSampling", "specialist context encoders")
+SplineActivation = _stub("SplineActivation", "activation layers are disabled in every config (model.py:137)")
+SmoothLeakyRelu = _stub("SmoothLeakyRelu", "activation layers are disabled in every config")
+LearnableLeakyRelu = _stub("LearnableLeakyRelu", "activation layers are disabled in every config")

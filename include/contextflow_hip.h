@@ -1,0 +1,142 @@
+/*
+ * contextflow_hip.h — C ABI of libcontextflow_hip.so (MI355X / gfx950).
+ *
+ * The reference (gudovskiy/contextflow) has no FFI: its "plugin API" is the Python package
+ * `layers` (contextflow/layers/__init__.py:1-14) whose classes implement
+ * FlowLayer.forward/reverse/logdet (contextflow/layers/flowlayer.py:7-24).  This library is the
+ * seam *underneath* those classes: each entry point below replaces the torch arithmetic of the
+ * reference lines it cites.  the modules in `contextflow_amd/layers/` bind it with ctypes
+ * (contextflow_amd/_lib.py); INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to contiguous fp32 (NCHW for activations) unless noted;
+ *     `*_bstride` arguments are batch strides in elements, so a channel slice of a larger tensor
+ *     (SplitPrior halves, Augment concat target) can be passed without a copy;
+ *   - the caller allocates every output and workspace; the library never allocates, frees or
+ *     retains caller memory; work is enqueued asynchronously on `stream` (a hipStream_t);
+ *   - return 0 on success, a positive hipError_t or a negative CF_ERR_* otherwise; the message
+ *     is in cf_last_error() (thread-local).  No exceptions cross the ABI, no global state.
+ */
+#ifndef CONTEXTFLOW_HIP_H
+#define CONTEXTFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_ABI_VERSION 1
+#define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
+#define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
+
+typedef void* cf_stream_t;       /* hipStream_t */
+
+int cf_abi_version(void);
+const char* cf_last_error(void);
+
+/* ---- pre-processing (layers/dequantize.py:14-17, normalize.py:27-49, transforms.py:11-18) ---- */
+/* y = x + u                                                     Dequantization.forward           */
+int cf_dequant_fwd(const float* x, const float* u, float* y, int64_t n, cf_stream_t stream);
+/* inverse=0: y = x/scale + translation ; inverse=1: y = (x - translation)*scale   Normalization   */
+int cf_affine(const float* x, float* y, int64_t n, float translation, float scale, int inverse, cf_stream_t stream);
+/* y = log x - log(1-x), ldj[b] = sum(-log x - log(1-x))         LogitTransform.forward/logdet    */
+int cf_logit_fwd(const float* x, float* y, float* ldj, int B, int N, cf_stream_t stream);
+/* y = sigmoid(x)                                                LogitTransform.reverse           */
+int cf_sigmoid(const float* x, float* y, int64_t n, cf_stream_t stream);
+/* y = floor(x)                                                  Dequantization.reverse           */
+int cf_floor(const float* x, float* y, int64_t n, cf_stream_t stream);
+/* Fused layers 0-3 of the image flows (model.py:97-100): v = ((x+u)/s1 + t1)/s2 + t2,
+ * y = logit(v) written with batch stride y_bstride, ldj[b] = ldj_const + sum(-log v - log(1-v)).   */
+int cf_preprocess_fwd(const float* x, const float* u, float* y, float* ldj, int B, int N, int64_t y_bstride,
+                      float t1, float s1, float t2, float s2, float ldj_const, cf_stream_t stream);
+/* out[b] = 0.5*sum(eps^2) + 0.5*N*log(2 pi)  = -log N(eps;0,I)  Augment ldj (augment.py:14-18,
+ * distributions/gaussian.py:50-54); eps rows have stride eps_bstride.                              */
+int cf_std_normal_nll(const float* eps, float* out, int B, int N, int64_t eps_bstride, cf_stream_t stream);
+
+/* ---- index-only layers (layers/squeeze.py:10-14) ---------------------------------------------- */
+/* inverse=0: 'b c (h p1)(w p2) -> b (c p1 p2) h w' with x = (B,C,H,W); inverse=1: the opposite map,
+ * x = (B, C*p1*p2, H/p1, W/p2) -> y = (B,C,H,W).  C,H,W always describe the UNsqueezed tensor.     */
+int cf_squeeze(const float* x, float* y, int B, int C, int H, int W, int p1, int p2,
+               int64_t x_bstride, int64_t y_bstride, int inverse, cf_stream_t stream);
+
+/* ---- Conv1x1 (layers/conv1x1.py:52-57,72) ------------------------------------------------------ */
+/* z[b,o,p] = sum_i Wm[o,i] x[b,i,p] (+ bias[o] if bias != NULL); C <= 128.                         */
+int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z, int B, int C, int HW,
+                   int64_t x_bstride, int64_t z_bstride, cf_stream_t stream);
+/* logabsdet[0] = log|det Wm| (LU with partial pivoting in fp64); if inv != NULL also Wm^-1 (C x C). */
+int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_stream_t stream);
+
+/* ---- ActNorm (layers/actnorm.py:28-35,53-60,78) ------------------------------------------------- */
+/* data-dependent init: t[c] = mean, logs[c] = log(unbiased_std + 1e-8) over (B,H,W).
+ * ws: caller workspace of cf_actnorm_stats_ws_bytes(C) bytes.                                       */
+int64_t cf_actnorm_stats_ws_bytes(int C);
+int cf_actnorm_stats(const float* x, float* t, float* logs, void* ws, int B, int C, int HW, int64_t x_bstride,
+                     cf_stream_t stream);
+/* inverse=0: z = (x - t)*exp(-logs), ldj_scalar[0] = sum_c logs (reference quirk: no H*W factor);
+ * inverse=1: z = x*exp(logs) + t (ldj_scalar may be NULL).                                          */
+int cf_actnorm(const float* x, const float* t, const float* logs, float* z, float* ldj_scalar,
+               int B, int C, int HW, int inverse, cf_stream_t stream);
+
+/* ---- Coupling (layers/coupling.py:26-29,39-73) -------------------------------------------------- */
+/* generic k x k convolution, stride 1, reflect padding (ph,pw), optional ReLU; fp32 direct form.     */
+int cf_conv2d_reflect(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout,
+                      int H, int W, int kh, int kw, int ph, int pw, int relu, int64_t x_bstride, cf_stream_t stream);
+/* affine map from the net output h (B,C,HW): t = h[:, :C/2], log_s = 2 tanh(h[:, C/2:]/2).
+ * inverse=0: z = [x0 | x1*exp(log_s)+t], ldj[b] = sum log_s ;  inverse=1: z = [x0 | (x1-t)/exp(log_s)] */
+int cf_coupling_apply(const float* x, const float* h, float* z, float* ldj, int B, int C, int HW, int inverse,
+                      cf_stream_t stream);
+
+/* ---- GaussianMixtureDistribution.log_prob (layers/distributions/gaussian.py:138-161) ------------ */
+/* parameter transform, once per call: a = 1/softplus(sG), bm = -mG*a (both (M*K, D)),
+ * cst[m,k] = log_softmax(wG[m])[k] - sum_d log softplus(sG) - D/2 log(2 pi).                         */
+int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, float* bm, float* cst,
+                   int M, int K, int D, cf_stream_t stream);
+/* out[b,m] (+)= logsumexp_k( cst[m,k] - 0.5 * sum_d (x[b,d]*a + bm)^2 );  K <= 16.
+ * accumulate != 0 adds into out (used to fold SplitPrior's ldj into the running (B,M) log-det).
+ * ws: optional workspace of cf_gmm_ws_bytes(B,M,K,D) bytes; when given (and non-zero sized) the
+ * D axis is split over workgroups to fill the chip at small B; NULL = single pass.                  */
+int64_t cf_gmm_ws_bytes(int B, int M, int K, int D);
+int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float* cst, float* out, void* ws,
+                   int B, int M, int K, int D, int64_t x_bstride, int accumulate, cf_stream_t stream);
+
+/* ---- fused flow step: Conv1x1 -> ActNorm -> Coupling(conv net) in ONE kernel, fp32 MFMA ---------
+ * (model.py:129-147 per-step triple; coupling.py:26-29 net; conv1x1.py:52-57; actnorm.py:53-60)
+ * Supported (C,H,W): (8,16,16) (16,16,16) (32,8,8) (64,4,4) with 3x3 reflect conv; others return
+ * CF_ERR_UNSUPPORTED from cf_flow_step_supported().                                                  */
+int cf_flow_step_supported(int C, int H, int W, int kh, int kw);
+int64_t cf_flow_step_ws_bytes(int C, int H, int W);
+/* pack the step's parameters into MFMA-fragment order (device side, every call, no host sync):
+ * folds ActNorm into the 1x1 matrix, computes ldj_const[0] = H*W*log|det Wm| + sum_c logs.          */
+int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs,
+                         const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* w3, const float* b3, void* ws, int C, int H, int W, cf_stream_t stream);
+/* z = step(x); ldj_acc[b] += ldj_const + sum log_s   (ldj_acc is the running per-sample log-det).  */
+int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
+                     int64_t x_bstride, cf_stream_t stream);
+
+/* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
+/* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; K <= 128.
+ * act: 0 none, 1 exact (erf) GELU.   nn.Linear of patch embedding / to_qkv / to_out / FeedForward.   */
+int cf_linear(const float* x, const float* Wt, const float* bias, const float* res, float* y,
+              int rows, int K, int N, int act, cf_stream_t stream);
+/* y[r,:] = LayerNorm(x[r,:])*w + b (+ pos[r % ntok,:] if pos != NULL); biased variance, eps.          */
+int cf_layernorm(const float* x, const float* w, const float* b, const float* pos, float* y,
+                 int rows, int dim, int ntok, float eps, cf_stream_t stream);
+/* single-head attention over N tokens per sample; qkv rows = [q|k|v] (3*dh): out = softmax(qk^T*scale)v */
+int cf_attention(const float* qkv, float* out, int B, int N, int dh, float scale, cf_stream_t stream);
+/* inverse=0: tokens[b,(h w),(p1 p2 c)] <- image[b,c,(h p1),(w p2)] (image batch stride img_bstride);
+ * inverse=1: image <- tokens.  C,H,W describe the image.                                              */
+int cf_patchify(const float* src, float* dst, int B, int C, int H, int W, int p1, int p2,
+                int64_t img_bstride, int inverse, cf_stream_t stream);
+
+/* ---- log-det bookkeeping (layers/flowsequential.py:18-27) --------------------------------------- */
+/* out[b,m] = ldM[b,m] + ld1[b]                                                                      */
+int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream);
+/* acc[0] += sum_b logsumexp_m logp[b,m] (fp64 accumulator; the scalar each rank all-reduces)         */
+int cf_nll_sum(const float* logp, double* acc, int B, int M, cf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTEXTFLOW_HIP_H */

@@ -1,0 +1,153 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the host-side
+mirror of the reference API has the reference's state_dict layout, the product refuses to run on
+the CPU (no silent fallback), and the multi-rank NLL reduction is correct (gloo, world size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from contextflow_amd import build
+    return build.build()
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "contextflow_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    import ctypes
+    from contextflow_amd.layers import _hip
+    syms = header_symbols()
+    assert len(syms) >= 30
+    lib = ctypes.CDLL(built)
+    for s in syms:
+        assert hasattr(lib, s), "header declares %s but the library does not export it" % s
+    assert sorted(_hip.SIGNATURES) == syms, set(_hip.SIGNATURES) ^ set(syms)
+    assert _hip.lib().cf_abi_version() == 1
+    # pure host-side queries work without a GPU
+    assert _hip.lib().cf_flow_step_supported(64, 4, 4, 3, 3) == 1
+    assert _hip.lib().cf_flow_step_supported(26, 8, 1, 3, 1) == 0
+    assert _hip.lib().cf_flow_step_ws_bytes(16, 16, 16) > 4 * 10064
+    assert _hip.lib().cf_actnorm_stats_ws_bytes(16) == 16 * 64 * 2 * 8
+
+
+def test_gfx950_code_object(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built], capture_output=True, text=True)
+    blob = out.stdout + out.stderr
+    assert "gfx950" in blob, blob[:500]
+
+
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+def test_state_dict_matches_reference_layout(name):
+    """create_model reproduces the reference's state_dict names/shapes (oracle.params.param_spec is
+    itself asserted equal to the real reference state_dict in tests/golden/make_golden.py)."""
+    import contextflow_amd as cfa
+    from oracle import flow_oracle as fo, params as op
+    cfg, data_size, M = cfa.preset_config(name)
+    model = cfa.create_model(cfg, data_size, M)
+    ops, prior, M2 = fo.program(name)
+    spec = op.param_spec(ops, prior, M2)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(spec[k][0]), k
+    model.load_state_dict(op.gen_params(spec, 0), strict=True)
+    n = sum(p.numel() for p in model.parameters())
+    assert n == {"mnist": 415360, "cifar10": 1518896, "smap": 936008}[name]
+
+
+def test_layer_types_follow_program():
+    import contextflow_amd as cfa
+    from oracle import flow_oracle as fo
+    kinds = {"dequant": "Dequantization", "affine": "Normalization", "logit": "LogitTransform", "augment": "Augment",
+             "squeeze": "Squeeze", "conv1x1": "Conv1x1", "actnorm": "ActNorm", "coupling": "Coupling",
+             "transcoupling": "TransCoupling", "split": "SplitPrior"}
+    for name in ("mnist", "cifar10", "smap"):
+        cfg, data_size, M = cfa.preset_config(name)
+        model = cfa.create_model(cfg, data_size, M)
+        ops, _, _ = fo.program(name)
+        assert [type(m).__name__ for m in model.sequence_modules] == [kinds[o[0]] for o in ops]
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-device; the oracle is never imported by the package."""
+    import contextflow_amd as cfa
+    cfg, data_size, M = cfa.preset_config("mnist")
+    model = cfa.create_model(cfg, data_size, M)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        model(torch.zeros(2, 1, 32, 32))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        cfa.layers.Coupling(8, (3, 3), (1, 1))(torch.zeros(1, 8, 4, 4))
+    for root, _, files in os.walk(os.path.join(ROOT, "contextflow_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_specialist_and_offpath_names_raise():
+    import contextflow_amd as cfa
+    L = cfa.layers
+    with pytest.raises(NotImplementedError):
+        L.Conv1x1((4, 2, 2), context_net=object())
+    with pytest.raises(NotImplementedError):
+        L.MaskedCoupling(4)
+    with pytest.raises(NotImplementedError):
+        cfa.create_model(dict(dataset="mnist", generalist=False, num_blocks=1, block_size=1), (1, 32, 32), 10)
+
+
+def test_shard_bounds():
+    from contextflow_amd.dist import shard_bounds
+    for total in (0, 1, 7, 64, 65536 + 3):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_bounds(total, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r'''
+import os, sys, math, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from contextflow_amd.dist import init_process_group, shard_bounds, allreduce_nll, mean_bits_per_dim
+from oracle import flow_oracle as fo
+from tests.helpers import load_e2e, e2e_inputs
+rank, _, world = init_process_group("gloo")
+ops, _, M, params, fx = load_e2e("mnist")
+x, u, eps = e2e_inputs("mnist", fx)
+lo, hi = shard_bounds(x.shape[0], rank, world)
+_, logp = fo.flow_forward(ops, params, x[lo:hi], u[lo:hi], [e[lo:hi] for e in eps])   # oracle stands in for the GPU kernels
+red = allreduce_nll(torch.logsumexp(logp.double(), -1).sum(), hi - lo)
+full = torch.logsumexp(torch.from_numpy(fx["logp"]).double(), -1)
+assert int(red[1]) == x.shape[0]
+assert abs(float(red[0]) - float(full.sum())) < 1e-2 * x.shape[0], (float(red[0]), float(full.sum()))
+bpd = mean_bits_per_dim(red, 1024)
+ref = float(-(full.mean()) / (1024 * math.log(2)))
+assert abs(bpd - ref) < 1e-5, (bpd, ref)
+dist.barrier()
+if rank == 0: print("OK", bpd)
+'''
+
+
+def test_two_rank_nll_allreduce_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0]
