@@ -47,15 +47,38 @@ def synth(name, n, dev, seed):
     return torch.randint(0, 256, (n, C, H, W), device=dev, generator=g).float()
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU
+    box exposes every core of the host to os.cpu_count() but grants a share of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    else:
+        n = min(n, 16)          # documented CPU share of a one-GPU box
+    return n
+
+
 def cpu_baseline(name, seconds):
     """The oracle (a CPU port of the reference path, pinned to the reference by tests/golden) timed on
     this box's host cores on a bounded sample of the same workload."""
     from oracle import flow_oracle as fo, params as op
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     ops, prior, M = fo.program(name)
     params = op.gen_params(op.param_spec(ops, prior, M), seed=0)

@@ -58,7 +58,7 @@ def test_conv1x1(L, tag, size):
     m = m.to(DEV)
     z, ldj = m(t["x"].to(DEV))
     close(z, t["z"])
-    close(ldj, t["ldj"].expand_as(ldj), tol=2e-6)
+    close(ldj, t["ldj"].expand_as(ldj), tol=1e-5)      # the reference LU is fp32, ours fp64
     close(m.reverse(t["z"].to(DEV)), t["xrec"], tol=1e-4)
     close(m.reverse(z), t["x"], tol=1e-4)
 
@@ -176,7 +176,7 @@ def test_fused_step_phases(L, C, H, W, B):
     z, ldj, d = fused_step_debug(x.to(DEV).contiguous(), conv, act, cpl)
     close(d["y0"], y[:, : C // 2]); close(d["h1"], h1); close(d["h2"], h2); close(d["h"], h)
     close(z, zref)
-    close(ldj, l0 + l1 + l2, tol=2e-6)
+    close(ldj, l0 + l1 + l2, tol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------ end to end
