@@ -238,11 +238,12 @@ __global__ __launch_bounds__(256) void k_logdet_combine(const float* __restrict_
         out[i] = ldM[i] + ld1[i / M];
 }
 
-// acc[0] += sum_b logsumexp_m logp[b,m]; one block, fp64 accumulation, deterministic order
+// acc[0] += sum_b logsumexp_m logp[b,m]: fp64 block partials, one fp64 atomic per block (a reported
+// scalar, not a parity output)
 __global__ __launch_bounds__(256) void k_nll_sum(const float* __restrict__ logp, double* __restrict__ acc, int B, int M) {
     __shared__ double red[4];
     double a = 0.0;
-    for (int b = threadIdx.x; b < B; b += 256) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
         const float* p = logp + (int64_t)b * M;
         float mx = p[0];
         for (int m = 1; m < M; ++m) mx = fmaxf(mx, p[m]);
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void k_nll_sum(const float* __restrict__ logp,
     a = cf_wave_sum_d(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) acc[0] += red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
 }
 
 }  // namespace
@@ -380,7 +381,10 @@ int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int
 
 int cf_nll_sum(const float* logp, double* acc, int B, int M, cf_stream_t stream) {
     CF_REQUIRE(logp && acc && B >= 0 && M > 0);
-    k_nll_sum<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(logp, acc, B, M);
+    if (B == 0) return 0;
+    int blocks = (B + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    k_nll_sum<<<dim3(blocks), dim3(256), 0, cf_s(stream)>>>(logp, acc, B, M);
     CF_LAUNCH_CHECK();
     return 0;
 }

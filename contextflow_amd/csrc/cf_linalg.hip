@@ -101,6 +101,38 @@ __global__ __launch_bounds__(256) void k_slogdet_inverse(const float* __restrict
     }
 }
 
+// log|det W| only (the per-call hot path of Conv1x1.forward): Gaussian elimination with IMPLICIT partial
+// pivoting in fp64.  The matrix sits column-major in LDS (lane = row: conflict-free), rows are never
+// swapped: the pivot row index r is wave-uniform, so its elements are read as LDS broadcasts.  Every
+// wave finds the pivot redundantly (6-shuffle argmax, no cross-wave traffic); the 4 waves split the
+// columns still to be updated; one barrier per step.  log|det| = sum log|pivot| (sign irrelevant).
+__global__ __launch_bounds__(256) void k_slogdet_lds(const float* __restrict__ Wm, int C, float* __restrict__ logabsdet) {
+    __shared__ double A[kMaxLU * kMaxLU];                       // A[j*64 + i] = W[i][j]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int e = tid; e < C * C; e += 256) { const int i = e / C, j = e - i * C; A[j * kMaxLU + i] = (double)Wm[e]; }
+    bool used = lane >= C;
+    double lsum = 0.0;
+    for (int k = 0; k < C; ++k) {
+        __syncthreads();                                        // column k is final, earlier updates visible
+        const double ak = A[k * kMaxLU + lane];
+        double best = used ? -1.0 : fabs(ak);
+        int bi = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        const int r = __builtin_amdgcn_readfirstlane(bi);       // pivot row, identical in every lane and wave
+        lsum += log(best);
+        const double piv = A[k * kMaxLU + r];
+        const double f = (used || lane == r) ? 0.0 : ak / piv;
+        for (int j = k + 1 + w; j < C; j += 4) A[j * kMaxLU + lane] -= f * A[j * kMaxLU + r];
+        if (lane == r) used = true;
+    }
+    if (tid == 0) logabsdet[0] = (float)lsum;
+}
+
 }  // namespace
 
 extern "C" {
@@ -121,7 +153,8 @@ int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z,
 int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_stream_t stream) {
     CF_REQUIRE(Wm && logabsdet && C > 0);
     if (C > kMaxLU) { cf_set_error("cf_slogdet_inverse: C=%d > %d unsupported", C, kMaxLU); return CF_ERR_UNSUPPORTED; }
-    k_slogdet_inverse<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet, inv);
+    if (inv == nullptr) k_slogdet_lds<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet);
+    else k_slogdet_inverse<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet, inv);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -168,7 +168,10 @@ __device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const flo
 
 // ---- the step kernel ---------------------------------------------------------------------------------
 // dbg (optional, tests only): [4][C_or_HID rows][gridDim*PIX] dumps of y, h1, h2, h.
-template <class G>
+// SQ: x is the UN-squeezed tensor (B, C/4, 2H, 2W) and Squeeze((2,2)) (squeeze.py:10-11) is folded into
+// the phase-0 operand addressing: channel k = 4c' + 2i1 + i2 of pixel (y,x) is in[c'][2y+i1][2x+i2]; with
+// k = 2s + (lane>>5) the two half-waves of one load read the interleaved even/odd columns of one row.
+template <class G, bool SQ>
 __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
                                                    float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
                                                    int64_t xbs, float* __restrict__ dbg) {
@@ -203,7 +206,10 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
         const float4* frags = reinterpret_cast<const float4*>(ws + G::OFF_A0);
         const float* xp[PTW];
 #pragma unroll
-        for (int q = 0; q < PTW; ++q) xp[q] = x + (int64_t)min(smp[q], B - 1) * xbs + pin[q] + (int64_t)lk * HW;
+        for (int q = 0; q < PTW; ++q) {
+            const float* xb = x + (int64_t)min(smp[q], B - 1) * xbs;
+            xp[q] = SQ ? xb + (2 * (pin[q] / W)) * (2 * W) + 2 * (pin[q] % W) + lk : xb + pin[q] + (int64_t)lk * HW;
+        }
 #pragma unroll
         for (int g = 0; g < G::NG0; ++g) {
             float4 a[RT03];
@@ -214,7 +220,9 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
                 if (4 * g + e < G::KS0) {
 #pragma unroll
                     for (int q = 0; q < PTW; ++q) {
-                        const float b = xp[q][(int64_t)(2 * (4 * g + e)) * HW];      // B[k][pixel] = x[ch k][pixel]
+                        const int ks = 4 * g + e;                                     // k-step: channels 2ks, 2ks+1
+                        const float b = SQ ? xp[q][(ks >> 1) * 4 * HW + (ks & 1) * 2 * W]
+                                           : xp[q][(int64_t)(2 * ks) * HW];           // B[k][pixel] = x[ch k][pixel]
 #pragma unroll
                         for (int rt = 0; rt < RT03; ++rt)
                             acc0[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[rt], e), b, acc0[rt][q], 0, 0, 0);
@@ -403,19 +411,19 @@ int launch_prepare(const float* Wm, const float* t, const float* logs, const flo
     return 0;
 }
 
-template <class G>
+template <class G, bool SQ>
 int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)lds_bytes);
             if (e != hipSuccess) { cf_set_error("cf_flow_step_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
             raised = true;
         }
     }
-    k_flow_step<G><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg);
+    k_flow_step<G, SQ><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg);
     return 0;
 }
 
@@ -466,26 +474,29 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, con
 
 // test hook (not part of the public header): same as cf_flow_step_fwd plus per-phase dumps
 int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
-                           int64_t x_bstride, float* dbg, cf_stream_t stream) {
+                           int64_t x_bstride, int in_squeeze, float* dbg, cf_stream_t stream) {
     CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);
     if (B == 0) return 0;
     const float* w = (const float*)ws;
     int rc = 0;
+#define CF_STEP(G) rc = in_squeeze ? launch_step<G, true>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)) \
+                                   : launch_step<G, false>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream))
     switch (shape_id(C, H, W)) {
-        case 0: rc = launch_step<G8>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)); break;
-        case 1: rc = launch_step<G16>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)); break;
-        case 2: rc = launch_step<G32>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)); break;
-        case 3: rc = launch_step<G64>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)); break;
+        case 0: CF_STEP(G8); break;
+        case 1: CF_STEP(G16); break;
+        case 2: CF_STEP(G32); break;
+        case 3: CF_STEP(G64); break;
         default: cf_set_error("cf_flow_step_fwd: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
+#undef CF_STEP
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
 }
 
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
-                     int64_t x_bstride, cf_stream_t stream) {
-    return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, nullptr, stream);
+                     int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
+    return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, stream);
 }
 
 }  // extern "C"

@@ -27,5 +27,7 @@ class UniformDistribution(nn.Module):
             x = self.fixed_noise.to(dev)
         else:
             # drawn on the device (the reference draws on the CPU and copies: uniform.py:32)
-            x = torch.rand((n_samples, *self.size), device=dev) / self.scale
+            x = torch.rand((n_samples, *self.size), device=dev)
+            if self.scale != 1.0:
+                x = x / self.scale
         return x, torch.zeros(x.shape[0], device=dev)

@@ -116,6 +116,14 @@ class FlowSequential(nn.Module):
                 x = self._fused_step(x, m, mods[i + 1], mods[i + 2], ld1, st, self.step_events)
                 i += 3
                 continue
+            # ---- Squeeze((2,2)) directly in front of a fused step: folded into the step's operand addressing
+            if (isinstance(m, Squeeze) and tuple(m.p) == (2, 2) and i + 3 < n and x.dim() == 4
+                    and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                    and self._step_supported(mods[i + 1], mods[i + 2], mods[i + 3],
+                                             (x.shape[1] * 4, x.shape[2] // 2, x.shape[3] // 2))):
+                x = self._fused_step(x, mods[i + 1], mods[i + 2], mods[i + 3], ld1, st, self.step_events, squeeze=True)
+                i += 4
+                continue
             if isinstance(m, Squeeze):
                 x = squeeze_op(x, m.p, False)
                 i += 1
@@ -139,9 +147,10 @@ class FlowSequential(nn.Module):
         return x, logp
 
     @staticmethod
-    def _fused_step(x, conv, act, cpl, ld1, st, events=None):
+    def _fused_step(x, conv, act, cpl, ld1, st, events=None, squeeze=False):
         x, xbs = _hip.bview(x)
-        B, C, H, W = x.shape
+        B = x.shape[0]
+        C, H, W = (x.shape[1] * 4, x.shape[2] // 2, x.shape[3] // 2) if squeeze else tuple(x.shape[1:])
         L = _hip.lib()
         ws = torch.empty(L.cf_flow_step_ws_bytes(C, H, W), device=x.device, dtype=torch.uint8)
         f, pp = _hip.f32, _hip.p
@@ -153,7 +162,7 @@ class FlowSequential(nn.Module):
         if events is not None:       # HIP events on the launch stream, bracketing exactly this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _hip.call("cf_flow_step_fwd", pp(x), pp(z), pp(ld1), pp(ws), B, C, H, W, xbs, st)
+        _hip.call("cf_flow_step_fwd", pp(x), pp(z), pp(ld1), pp(ws), B, C, H, W, xbs, int(squeeze), st)
         if events is not None:
             e1.record()
             events.append((e0, e1, B, C))

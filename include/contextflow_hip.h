@@ -111,9 +111,11 @@ int64_t cf_flow_step_ws_bytes(int C, int H, int W);
 int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs,
                          const float* w1, const float* b1, const float* w2, const float* b2,
                          const float* w3, const float* b3, void* ws, int C, int H, int W, cf_stream_t stream);
-/* z = step(x); ldj_acc[b] += ldj_const + sum log_s   (ldj_acc is the running per-sample log-det).  */
+/* z = step(x); ldj_acc[b] += ldj_const + sum log_s   (ldj_acc is the running per-sample log-det).
+ * in_squeeze != 0: x is the UN-squeezed (B, C/4, 2H, 2W) tensor and Squeeze((2,2)) (squeeze.py:10-11)
+ * is folded into the kernel's operand addressing (no separate index kernel, no extra HBM pass).      */
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
-                     int64_t x_bstride, cf_stream_t stream);
+                     int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; K <= 128.

@@ -27,13 +27,14 @@ def set_noise(model, u, eps, dev=DEV):
             m.distribution.fixed_noise = eps.pop(0).to(dev) if eps else None
 
 
-def fused_step_debug(x, conv, act, cpl):
+def fused_step_debug(x, conv, act, cpl, squeeze=False):
     """Run cf_flow_step_prepare + the debug variant of the step kernel; returns z, ldj, dumps."""
     L = _hip.lib()
     fn = L.cf_flow_step_fwd_debug
     fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
-    B, C, H, W = x.shape
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    B = x.shape[0]
+    C, H, W = (x.shape[1] * 4, x.shape[2] // 2, x.shape[3] // 2) if squeeze else tuple(x.shape[1:])
     ws = torch.empty(L.cf_flow_step_ws_bytes(C, H, W), device=x.device, dtype=torch.uint8)
     f, pp = _hip.f32, _hip.p
     c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
@@ -44,9 +45,10 @@ def fused_step_debug(x, conv, act, cpl):
     nwg = (B + spw - 1) // spw
     cols = nwg * spw * H * W
     dbg = torch.full((2 * C + 4 * C, cols), float("nan"), device=x.device)
-    z = torch.empty_like(x)
+    z = torch.empty(B, C, H, W, device=x.device)
     ldj = torch.zeros(B, device=x.device)
-    _hip.check(fn(pp(x), pp(z), pp(ldj), pp(ws), B, C, H, W, C * H * W, pp(dbg), _hip.stream()), "cf_flow_step_fwd_debug")
+    _hip.check(fn(pp(x), pp(z), pp(ldj), pp(ws), B, C, H, W, C * H * W, int(squeeze), pp(dbg), _hip.stream()),
+               "cf_flow_step_fwd_debug")
     torch.cuda.synchronize()
     HID, HALF = 2 * C, C // 2
 

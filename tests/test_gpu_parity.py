@@ -150,8 +150,9 @@ def test_transcoupling(L, tag):
 
 
 # ------------------------------------------------------------------------------------------ fused step kernel
+@pytest.mark.parametrize("squeeze", [False, True])
 @pytest.mark.parametrize("C,H,W,B", [(16, 16, 16, 3), (32, 8, 8, 5), (64, 4, 4, 11), (8, 16, 16, 2), (32, 8, 8, 8), (64, 4, 4, 16)])
-def test_fused_step_phases(L, C, H, W, B):
+def test_fused_step_phases(L, C, H, W, B, squeeze):
     """Conv1x1->ActNorm->Coupling in one MFMA kernel, every intermediate plane against the oracle
     (ragged batch sizes exercise the partially filled last workgroup)."""
     from tests.gpu_util import fused_step_debug
@@ -173,7 +174,8 @@ def test_fused_step_phases(L, C, H, W, B):
     zref, l2 = fo.coupling_apply_fwd(y, h)
     for m in (conv, act, cpl):
         m.to(DEV)
-    z, ldj, d = fused_step_debug(x.to(DEV).contiguous(), conv, act, cpl)
+    xin = fo.squeeze_inv(x, (2, 2)) if squeeze else x          # feed the un-squeezed tensor: Squeeze is folded in
+    z, ldj, d = fused_step_debug(xin.to(DEV).contiguous(), conv, act, cpl, squeeze=squeeze)
     close(d["y0"], y[:, : C // 2]); close(d["h1"], h1); close(d["h2"], h2); close(d["h"], h)
     close(z, zref)
     close(ldj, l0 + l1 + l2, tol=1e-5)
