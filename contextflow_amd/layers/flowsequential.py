@@ -6,9 +6,12 @@ Two execution modes produce the same numbers:
   * layer-by-layer (any layer list, and always the first call, because ActNorm's data-dependent
     init needs the materialised intermediates);
   * the fused plan used afterwards: pre-processing (Dequantization..LogitTransform[..Augment]) in
-    one kernel, each Conv1x1->ActNorm->Coupling triple in ONE fp32-MFMA kernel that accumulates its
-    log-det straight into a running per-sample buffer, SplitPrior/prior GMMs accumulated into a
-    running (B, M) buffer, channel splits passed by stride (no copies).
+    one kernel, each [Squeeze ->] Conv1x1 -> ActNorm -> Coupling group in ONE fp32-MFMA kernel that
+    accumulates its log-det straight into a running per-sample buffer, SplitPrior / prior GMMs
+    accumulated into a running (B, M) buffer, channel splits passed by stride (no copies).
+    The per-call parameter transforms (log|det W|, ActNorm folding, MFMA-fragment packing, GMM
+    1/sigma tables) are tiny one-workgroup kernels: they are enqueued on a side HIP stream at the
+    start of the call and joined by events, so they overlap the main stream's kernels.
 Set `fused = False` on the instance to force the layer-by-layer mode."""
 import math
 
@@ -38,10 +41,17 @@ class FlowSequential(nn.Module):
             self.add_module(str(i), module)
         self.sequence_modules = modules
         self.fused = True
-        self.step_events = None      # bench.py: list collecting (start, end, batch) HIP events per step-kernel launch
+        self.step_events = None      # bench.py: list collecting (start, end, batch, C) HIP events per step-kernel launch
+        self._plans = {}             # input (C,H,W) -> op list
+        self._side = {}              # device index -> side stream for the parameter transforms
 
     def __iter__(self):
         yield from self.sequence_modules
+
+    def __getstate__(self):              # streams / cached plans are per-process runtime state
+        d = self.__dict__.copy()
+        d["_plans"], d["_side"], d["step_events"] = {}, {}, None
+        return d
 
     # ------------------------------------------------------------------ layer-by-layer mode
     def _forward_layers(self, input, context):
@@ -71,33 +81,114 @@ class FlowSequential(nn.Module):
             return False
         return bool(_hip.lib().cf_flow_step_supported(C, H, W, 3, 3))
 
-    def _forward_fused(self, x, context):
-        mods = self.sequence_modules
-        n = len(mods)
-        B, M, dev = x.shape[0], self.mixtures, x.device
-        ld1 = torch.zeros(B, device=dev, dtype=torch.float32)       # per-sample scalar log-dets
-        ldM = torch.zeros(B, M, device=dev, dtype=torch.float32)    # per-mixture terms (priors)
-        st = _hip.stream()
-        i = 0
+    def _build_plan(self, shape):
+        """Walk the layer list once per input shape and group it into kernels."""
+        mods, n = self.sequence_modules, len(self.sequence_modules)
+        ops, i = [], 0
+        shape = tuple(shape)
+
+        def is3(sh):
+            return sh is not None and len(sh) == 3
         while i < n:
             m = mods[i]
-            # ---- Dequantization -> Normalization -> Normalization -> LogitTransform [-> Augment]
             if (isinstance(m, Dequantization) and isinstance(m.dist, UniformDistribution) and i + 3 < n
                     and isinstance(mods[i + 1], Normalization) and isinstance(mods[i + 2], Normalization)
-                    and isinstance(mods[i + 3], LogitTransform)):
-                n1, n2 = mods[i + 1], mods[i + 2]
-                xin = _hip.f32(x)
-                C, H, W = xin.shape[1:]
-                N = C * H * W
-                u, _ = m.dist.sample(B, context=xin)
-                u = _hip.f32(u)
+                    and isinstance(mods[i + 3], LogitTransform) and is3(shape)):
                 aug = mods[i + 4] if (i + 4 < n and isinstance(mods[i + 4], Augment)
                                       and isinstance(mods[i + 4].distribution, StandardNormal)
                                       and mods[i + 4].split_dim == 1) else None
+                ops.append(("pre", m, mods[i + 1], mods[i + 2], aug))
+                if aug is not None:
+                    shape = (shape[0] + aug.aug_size,) + shape[1:]
+                i += 5 if aug is not None else 4
+                continue
+            if is3(shape) and i + 2 < n and self._step_supported(m, mods[i + 1], mods[i + 2], shape):
+                ops.append(("step", m, mods[i + 1], mods[i + 2], shape, False))
+                i += 3
+                continue
+            if isinstance(m, Squeeze) and is3(shape):
+                sq = (shape[0] * m.p[0] * m.p[1], shape[1] // m.p[0], shape[2] // m.p[1])
+                if (tuple(m.p) == (2, 2) and shape[1] % 2 == 0 and shape[2] % 2 == 0 and i + 3 < n
+                        and self._step_supported(mods[i + 1], mods[i + 2], mods[i + 3], sq)):
+                    ops.append(("step", mods[i + 1], mods[i + 2], mods[i + 3], sq, True))   # Squeeze folded in
+                    i += 4
+                else:
+                    ops.append(("squeeze", m))
+                    i += 1
+                shape = sq
+                continue
+            if isinstance(m, SplitPrior) and isinstance(m.dist, GaussianMixtureDistribution) and is3(shape):
+                ops.append(("split", m))
+                shape = (shape[0] // 2,) + shape[1:]
+                i += 1
+                continue
+            if isinstance(m, Augment) and is3(shape) and m.split_dim == 1:
+                shape = (shape[0] + m.aug_size,) + shape[1:]
+            elif isinstance(m, (Squeeze, SplitPrior)):
+                shape = None            # unknown geometry from here on: everything else runs layer by layer
+            ops.append(("layer", m))
+            i += 1
+        return ops
+
+    def _side_stream(self, dev):
+        s = self._side.get(dev.index)
+        if s is None:
+            s = self._side[dev.index] = torch.cuda.Stream(device=dev)
+        return s
+
+    @staticmethod
+    def _prepare_step(conv, act, cpl, shape, dev):
+        C, H, W = shape
+        ws = torch.empty(_hip.lib().cf_flow_step_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+        f, pp = _hip.f32, _hip.p
+        c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
+        _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
+                  pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
+                  pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, _hip.stream())
+        return ws
+
+    def _forward_fused(self, x, context):
+        B, M, dev = x.shape[0], self.mixtures, x.device
+        key = tuple(x.shape[1:])
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._build_plan(key)
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev)
+
+        # ---- parameter transforms on the side stream (overlap the main stream's kernels)
+        side.wait_stream(main)
+        prepared = {}
+        with torch.cuda.stream(side):
+            for k, op in enumerate(plan):
+                if op[0] == "step":
+                    prepared[k] = self._prepare_step(op[1], op[2], op[3], op[4], dev)
+                elif op[0] == "split":
+                    prepared[k] = op[1].dist.prepared()
+                else:
+                    continue
+                ev = torch.cuda.Event()
+                ev.record(side)
+                prepared[k] = (prepared[k], ev)
+            prior = self.dist.prepared()
+            ev_prior = torch.cuda.Event()
+            ev_prior.record(side)
+
+        ld1 = torch.zeros(B, device=dev, dtype=torch.float32)       # per-sample scalar log-dets
+        ldM = torch.zeros(B, M, device=dev, dtype=torch.float32)    # per-mixture terms (priors)
+        st = _hip.stream()
+        for k, op in enumerate(plan):
+            kind = op[0]
+            if kind == "pre":
+                _, deq, n1, n2, aug = op
+                xin = _hip.f32(x)
+                C, H, W = xin.shape[1:]
+                N = C * H * W
+                u = _hip.f32(deq.dist.sample(B, context=xin)[0])
                 ca = aug.aug_size if aug is not None else 0
                 y = torch.empty(B, C + ca, H, W, device=dev, dtype=torch.float32)
                 cst = -N * math.log(n1._s) - N * math.log(n2._s)      # normalize.py:42-49, twice
-                ldp = ld1 if i == 0 else torch.empty_like(ld1)           # the kernel assigns its per-sample ldj
+                ldp = ld1 if k == 0 else torch.empty_like(ld1)         # the kernel assigns its per-sample ldj
                 _hip.call("cf_preprocess_fwd", _hip.p(xin), _hip.p(u), _hip.p(y), _hip.p(ldp), B, N, (C + ca) * H * W,
                           n1._t, n1._s, n2._t, n2._s, cst, st)
                 if ldp is not ld1:
@@ -106,67 +197,50 @@ class FlowSequential(nn.Module):
                     eps, logq = aug.distribution.sample(B)
                     y[:, C:].copy_(eps)
                     ld1 -= logq.squeeze(-1)                            # Augment ldj = -log q(eps)
-                    i += 5
-                else:
-                    i += 4
                 x = y
-                continue
-            # ---- Conv1x1 -> ActNorm -> Coupling in one MFMA kernel
-            if i + 2 < n and x.dim() == 4 and self._step_supported(m, mods[i + 1], mods[i + 2], tuple(x.shape[1:])):
-                x = self._fused_step(x, m, mods[i + 1], mods[i + 2], ld1, st, self.step_events)
-                i += 3
-                continue
-            # ---- Squeeze((2,2)) directly in front of a fused step: folded into the step's operand addressing
-            if (isinstance(m, Squeeze) and tuple(m.p) == (2, 2) and i + 3 < n and x.dim() == 4
-                    and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
-                    and self._step_supported(mods[i + 1], mods[i + 2], mods[i + 3],
-                                             (x.shape[1] * 4, x.shape[2] // 2, x.shape[3] // 2))):
-                x = self._fused_step(x, mods[i + 1], mods[i + 2], mods[i + 3], ld1, st, self.step_events, squeeze=True)
-                i += 4
-                continue
-            if isinstance(m, Squeeze):
-                x = squeeze_op(x, m.p, False)
-                i += 1
-                continue
-            if isinstance(m, SplitPrior) and isinstance(m.dist, GaussianMixtureDistribution):
+            elif kind == "step":
+                _, conv, act, cpl, (C, H, W), sq = op
+                ws, ev = prepared[k]
+                main.wait_event(ev)
+                x, xbs = _hip.bview(x)
+                z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+                events = self.step_events
+                if events is not None:       # HIP events on the launch stream, bracketing exactly this kernel
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                _hip.call("cf_flow_step_fwd", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), B, C, H, W, xbs, int(sq), st)
+                if events is not None:
+                    e1.record()
+                    events.append((e0, e1, B, C))
+                x = z
+            elif kind == "squeeze":
+                x = squeeze_op(x, op[1].p, False)
+            elif kind == "split":
+                prep, ev = prepared[k]
+                main.wait_event(ev)
                 c = x.shape[1] // 2
-                gmm_logprob(x[:, c:], m.dist.prepared(), out=ldM, accumulate=True)
+                gmm_logprob(x[:, c:], prep, out=ldM, accumulate=True)
                 x = x[:, :c]
-                i += 1
-                continue
-            # ---- anything else: the layer's own kernels
-            x, ldj = m(x, context)
-            if ldj.dim() == 2:
-                ldM += ldj
-            else:
-                ld1 += ldj
-            i += 1
-        gmm_logprob(x, self.dist.prepared(), out=ldM, accumulate=True)
+            else:                        # any other layer: its own kernels
+                x, ldj = op[1](x, context)
+                if ldj.dim() == 2:
+                    ldM += ldj
+                else:
+                    ld1 += ldj
+        main.wait_event(ev_prior)
+        gmm_logprob(x, prior, out=ldM, accumulate=True)
         logp = torch.empty(B, M, device=dev, dtype=torch.float32)
         _hip.call("cf_logdet_combine", _hip.p(ldM), _hip.p(ld1), _hip.p(logp), B, M, st)
+        # buffers written on the side stream are consumed on the main stream: keep the allocator informed
+        for v in prepared.values():
+            t = v[0]
+            for buf in (t if isinstance(t, tuple) else (t,)):
+                if torch.is_tensor(buf):
+                    buf.record_stream(main)
+        for buf in prior:
+            if torch.is_tensor(buf):
+                buf.record_stream(main)
         return x, logp
-
-    @staticmethod
-    def _fused_step(x, conv, act, cpl, ld1, st, events=None, squeeze=False):
-        x, xbs = _hip.bview(x)
-        B = x.shape[0]
-        C, H, W = (x.shape[1] * 4, x.shape[2] // 2, x.shape[3] // 2) if squeeze else tuple(x.shape[1:])
-        L = _hip.lib()
-        ws = torch.empty(L.cf_flow_step_ws_bytes(C, H, W), device=x.device, dtype=torch.uint8)
-        f, pp = _hip.f32, _hip.p
-        c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
-        _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
-                  pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
-                  pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, st)
-        z = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
-        if events is not None:       # HIP events on the launch stream, bracketing exactly this kernel
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _hip.call("cf_flow_step_fwd", pp(x), pp(z), pp(ld1), pp(ws), B, C, H, W, xbs, int(squeeze), st)
-        if events is not None:
-            e1.record()
-            events.append((e0, e1, B, C))
-        return z
 
     # ------------------------------------------------------------------ reference API
     def forward(self, input, context=None):
