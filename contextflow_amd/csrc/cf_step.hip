@@ -29,9 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWaves = 4;
 
 // ---- compile-time geometry of one supported shape ------------------------------------------------
-template <int C_, int H_, int W_, int SPW_>
+// PIPE_: phase-2 loop form (1 = explicit two-stage operand pipeline, 0 = compiler-scheduled per-tap loop)
+template <int C_, int H_, int W_, int SPW_, int PIPE_ = 1>
 struct Geo {
-    static constexpr int C = C_, H = H_, W = W_, SPW = SPW_;
+    static constexpr int C = C_, H = H_, W = W_, SPW = SPW_, PIPE = PIPE_;
     static constexpr int HW = H * W;
     static constexpr int PIX = SPW * HW;              // pixels per workgroup
     static constexpr int HALF = C / 2;                // conditioner channels
@@ -133,36 +134,52 @@ __device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ bias32, in
 __device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
+// Operands of one 4-k-step group: RT weight fragments (one 16-byte load each) and 4*PTW activation values.
+template <int RT, int PTW>
+struct GroupOps {
+    float4 a[RT];
+    float b[4][PTW];
+};
+
+template <int RT, int PTW>
+__device__ __forceinline__ void group_mma(f32x16 (&acc)[RT][PTW], const GroupOps<RT, PTW>& o, int nsteps) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (e < nsteps) {
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(o.a[rt], e), o.b[e][q], acc[rt][q], 0, 0, 0);
+        }
+    }
+}
+
 // One dense phase whose B operand is an LDS plane [k][PIX]:  acc[rt][q] += A_frag * plane
-//   KS   real k-steps, NG groups of 4, RT row tiles, frags = packed A of this phase
+//   KS real k-steps, NG groups of 4, RT row tiles, frags = packed A of this phase.
+// Software pipeline: the operands of group g+1 are requested BEFORE the MFMAs of group g are issued
+// (sched_barrier pins the loads there: left alone, hipcc sinks them next to their first use and every
+// group then stalls on an L2 round trip).
 template <class G, int KS, int NG, int RT>
 __device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const float4* __restrict__ frags,
                                             const float* __restrict__ plane, const int (&pix)[G::PTW], int lane) {
     const int lk = lane >> 5;
-    float4 a_cur[RT], a_nxt[RT];
+    GroupOps<RT, G::PTW> ops[2];
+    auto load = [&](int g, GroupOps<RT, G::PTW>& o) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+        for (int rt = 0; rt < RT; ++rt) o.a[rt] = frags[(g * RT + rt) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < G::PTW; ++q)
+                o.b[e][q] = (4 * g + e < KS) ? plane[(2 * (4 * g + e) + lk) * G::PIX + pix[q]] : 0.f;
+    };
+    load(0, ops[0]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a_nxt[rt] = frags[((g + 1) * RT + rt) * 64 + lane];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (4 * g + e < KS) {
-                const int k = 2 * (4 * g + e) + lk;
-#pragma unroll
-                for (int q = 0; q < G::PTW; ++q) {
-                    const float b = plane[k * G::PIX + pix[q]];
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt)
-                        acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), b, acc[rt][q], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) a_cur[rt] = a_nxt[rt];
+        if (g + 1 < NG) load(g + 1, ops[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        group_mma<RT, G::PTW>(acc, ops[g & 1], KS - 4 * g);
     }
 }
 
@@ -174,7 +191,7 @@ __device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const flo
 template <class G, bool SQ>
 __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
                                                    float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                   int64_t xbs, float* __restrict__ dbg) {
+                                                   int64_t xbs, float* __restrict__ dbg, int flags) {
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
     extern __shared__ __align__(16) float lds[];      // G::LDS_FLOATS floats (up to 80 KiB: dynamic)
@@ -183,6 +200,14 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
     const int b0 = blockIdx.x * G::SPW;
+    if (flags & 1) {
+        // de-phase the workgroups that share a CU: the first resident generation starts staggered (slot k of a CU
+        // waits k * stagger), later workgroups inherit the offset because they start when an earlier one retires.
+        const int slot = blockIdx.x / 256;                      // blocks are dealt round-robin over XCDs, then CUs
+        const int nslots = (flags >> 4) & 15, units = flags >> 8;
+        if (slot < nslots)
+            for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(64);
+    }
     const int64_t dbg_cols = (int64_t)gridDim.x * PIX;
 
     int pix[PTW];                       // this lane's pixel column inside the workgroup, per owned tile
@@ -248,8 +273,9 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
             y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
         }
     }
-    __syncthreads();
+    // no workgroup barrier here: phase 1 reads only the pixel columns of Y0 this wave has just written
     if (dbg) {
+        __syncthreads();
         for (int e = tid; e < HALF * PIX; e += 256) dbg[(int64_t)(e / PIX) * dbg_cols + blockIdx.x * PIX + (e % PIX)] = Y0[e];
     }
 
@@ -285,39 +311,86 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
 #pragma unroll
             for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B2 + rt * 32, lk);
         const float4* frags = reinterpret_cast<const float4*>(ws + G::OFF_A2);
-        float4 a_cur[RT1], a_nxt[RT1];
+        if constexpr (G::PIPE == 0) {
+            // compiler-scheduled form: one tap per loop trip, all NCG groups of the tap unrolled
+            float4 a_cur[RT1], a_nxt[RT1];
 #pragma unroll
-        for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+            for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+            const int ntaps0 = (flags & 4) ? 1 : 9;
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const float* src[PTW];
+            for (int tap = 0; tap < ntaps0; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                int src[PTW];
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) {
+                    int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
+                    yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);   // reflect (padding_mode='reflect')
+                    xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+                    src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
+                }
+#pragma unroll
+                for (int cg = 0; cg < G::NCG; ++cg) {
+                    const int g = tap * G::NCG + cg;
+                    const int gn = min(g + 1, G::NG2 - 1);
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) a_nxt[rt] = frags[(gn * RT1 + rt) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int q = 0; q < PTW; ++q) {
+                            const float b = lds[src[q] + (8 * cg + 2 * e) * PIX];
+#pragma unroll
+                            for (int rt = 0; rt < RT1; ++rt)
+                                acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), b, acc[rt][q], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
+                }
+            }
+        } else {
+        // group g = tap*NCG + cg covers tap (dy,dx) and input channels 8cg .. 8cg+7.  The operands of group g+1
+        // are requested before the MFMAs of group g (two register sets, loads pinned by sched_barrier); the
+        // reflect-padded source pixel of a tap is computed once per tap, one tap ahead.
+        GroupOps<RT1, PTW> ops[2];
+        // (LDS offsets, not pointers: a pointer array loses the LDS address space and hipcc falls back to flat loads)
+        auto tap_src = [&](int tap, int (&src)[PTW]) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;              // wave-uniform
 #pragma unroll
             for (int q = 0; q < PTW; ++q) {
                 int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
                 yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);       // reflect (padding_mode='reflect')
                 xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-                src[q] = H1 + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
+                src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;   // index into lds[] (H1 plane)
+            }
+        };
+        auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * PIX];
+        };
+        int src_cur[PTW], src_nxt[PTW];
+        tap_src(0, src_cur);
+        load(frags, src_cur, 0, ops[0]);
+        const int ntaps = (flags & 4) ? 1 : 9;                          // flags&4: timing experiment
+#pragma unroll 1
+        for (int tap = 0; tap < ntaps; ++tap) {
+            tap_src(min(tap + 1, 8), src_nxt);
+            const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
+#pragma unroll
+            for (int cg = 0; cg < G::NCG; ++cg) {                       // NCG is even: static ping-pong
+                const float4* fn = fr + (cg + 1) * RT1 * 64;            // fragments of the next group
+                if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
+                else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);       // first group of the next tap
+                __builtin_amdgcn_sched_barrier(0);
+                group_mma<RT1, PTW>(acc, ops[cg & 1], 4);
             }
 #pragma unroll
-            for (int cg = 0; cg < G::NCG; ++cg) {
-                const int g = tap * G::NCG + cg;
-                const int gn = min(g + 1, G::NG2 - 1);
-#pragma unroll
-                for (int rt = 0; rt < RT1; ++rt) a_nxt[rt] = frags[(gn * RT1 + rt) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int q = 0; q < PTW; ++q) {
-                        const float b = src[q][(8 * cg + 2 * e) * PIX];
-#pragma unroll
-                        for (int rt = 0; rt < RT1; ++rt)
-                            acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), b, acc[rt][q], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
-            }
+            for (int q = 0; q < PTW; ++q) src_cur[q] = src_nxt[q];
+        }
         }
         __syncthreads();                 // every wave has finished reading h1 (taps cross pixel tiles)
 #pragma unroll
@@ -330,8 +403,9 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
                     if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
                 }
     }
-    __syncthreads();
+    // no barrier: phase 3 reads only this wave's own pixel columns of h2
     if (dbg) {
+        __syncthreads();
         float* d = dbg + (int64_t)(C + HID) * dbg_cols;
         for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + blockIdx.x * PIX + (e % PIX)] = H1[e];
     }
@@ -355,8 +429,12 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
             if (idx < HALF) {
                 const float tt = acc3[0][q][r];
                 const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
-                const float ls = 2.0f * tanhf(raw * 0.5f);                    // coupling.py:55-56
-                const float z1 = y1[q][r] * expf(ls) + tt;                     // coupling.py:63
+                float ls, z1;
+                if (flags & 8) { ls = raw; z1 = y1[q][r] * raw + tt; }       // timing experiment: no transcendental
+                else {
+                    ls = 2.0f * tanhf(raw * 0.5f);                             // coupling.py:55-56
+                    z1 = y1[q][r] * expf(ls) + tt;                             // coupling.py:63
+                }
                 lsum[q] += ls;
                 if (live[q]) zq[(int64_t)idx * HW] = z1;
                 if (dbg) {
@@ -367,38 +445,62 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
             }
         }
     }
-    // per-sample reduction of log_s: lanes of one sample inside a 32-pixel tile, then across tiles via LDS
+    // per-sample reduction of log_s: lanes of one sample inside a 32-pixel tile first (shuffles) ...
     constexpr int SEG = HW < 32 ? HW : 32;            // lanes (pixels) of one sample inside a tile
-    constexpr int SPT = 32 / SEG;                      // samples per tile
-    __syncthreads();                                   // Y0 is dead: reuse it as scratch [NPT*SPT]
-    float* red = Y0;
+    float v[PTW];
 #pragma unroll
     for (int q = 0; q < PTW; ++q) {
-        float v = lsum[q];
+        v[q] = lsum[q];
 #pragma unroll
-        for (int o = 1; o < SEG; o <<= 1) v += __shfl_xor(v, o, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (lk == 0 && (li % SEG) == 0) red[(wave * PTW + q) * SPT + li / SEG] = v;
+        for (int o = 1; o < SEG; o <<= 1) v[q] += __shfl_xor(v[q], o, 64);
+        v[q] += __shfl_xor(v[q], 32, 64);
     }
-    __syncthreads();
-    if (tid < G::SPW && b0 + tid < B) {
-        constexpr int EPS = HW >= 32 ? HW / 32 : 1;                  // scratch entries per sample
-        float s = 0.f;
-        if (HW >= 32) {
+    if constexpr (HW <= 32 * PTW) {
+        // ... whole samples live inside this wave: finish in registers, the first lane of a sample owns ldj_acc[b]
+        constexpr int TPS = HW >= 32 ? HW / 32 : 1;   // tiles per sample
 #pragma unroll
-            for (int i = 0; i < EPS; ++i) s += red[tid * EPS + i];
-        } else {
-            s = red[tid];
+        for (int q = 0; q < PTW; q += TPS) {
+            float sum = v[q];
+#pragma unroll
+            for (int i = 1; i < TPS; ++i) sum += v[q + i];
+            if (lk == 0 && (li % SEG) == 0 && live[q]) ldj_acc[smp[q]] += ws[0] + sum;
         }
-        ldj_acc[b0 + tid] += ws[0] + s;
+    } else {
+        // ... a sample spans several waves: one LDS hop (Y0 is dead since the barrier after phase 1)
+        constexpr int TPS = HW / 32;
+        float* red = Y0;
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+            if (lane == 0) red[wave * PTW + q] = v[q];
+        __syncthreads();
+        if (tid < G::SPW && b0 + tid < B) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TPS; ++i) sum += red[tid * TPS + i];
+            ldj_acc[b0 + tid] += ws[0] + sum;
+        }
     }
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------
-using G8 = Geo<8, 16, 16, 1>;
-using G16 = Geo<16, 16, 16, 1>;
-using G32 = Geo<32, 8, 8, 4>;
-using G64 = Geo<64, 4, 4, 8>;
+// Tile / loop form per shape, chosen by measurement on MI355X (tools/step_bench.py, B = 16384):
+//   C16: 1 sample (256 px, 40 KB LDS, 4 workgroups/CU), compiler-scheduled tap loop      108 TFLOP/s
+//   C32: 4 samples (256 px, 80 KB, 2/CU), explicit operand pipeline                        126 TFLOP/s
+//   C64: 16 samples (256 px, 160 KB = the whole LDS, 1/CU), explicit pipeline, 4x2 tiles   134 TFLOP/s
+using G8 = Geo<8, 16, 16, 1, 0>;
+using G16 = Geo<16, 16, 16, 1, 0>;
+using G32 = Geo<32, 8, 8, 4, 1>;
+using G64 = Geo<64, 4, 4, 16, 1>;
+// alternates kept for tools/step_bench.py, reachable only through cf_flow_step_fwd_debug (flags bits 16..19)
+using G16v1 = Geo<16, 16, 16, 1, 1>;
+using G16v2 = Geo<16, 16, 16, 4, 1>;
+using G16v3 = Geo<16, 16, 16, 4, 0>;
+using G32v1 = Geo<32, 8, 8, 4, 0>;
+using G32v2 = Geo<32, 8, 8, 8, 1>;
+using G32v3 = Geo<32, 8, 8, 8, 0>;
+using G64v1 = Geo<64, 4, 4, 8, 1>;
+using G64v2 = Geo<64, 4, 4, 8, 0>;
+using G64v3 = Geo<64, 4, 4, 16, 0>;
 
 template <class G>
 int launch_prepare(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
@@ -412,18 +514,20 @@ int launch_prepare(const float* Wm, const float* t, const float* logs, const flo
 }
 
 template <class G, bool SQ>
-int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, hipStream_t s) {
-    constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
+int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, int flags,
+                hipStream_t s) {
+    size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
+    if (flags & 2) lds_bytes = 160 * 1024;                      // experiment: force one workgroup per CU
     if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
         static bool raised = false;
         if (!raised) {
             hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lds_bytes);
+                                               160 * 1024);
             if (e != hipSuccess) { cf_set_error("cf_flow_step_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
             raised = true;
         }
     }
-    k_flow_step<G, SQ><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg);
+    k_flow_step<G, SQ><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags);
     return 0;
 }
 
@@ -474,19 +578,29 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, con
 
 // test hook (not part of the public header): same as cf_flow_step_fwd plus per-phase dumps
 int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
-                           int64_t x_bstride, int in_squeeze, float* dbg, cf_stream_t stream) {
+                           int64_t x_bstride, int in_squeeze, float* dbg, int flags, cf_stream_t stream) {
     CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);
     if (B == 0) return 0;
     const float* w = (const float*)ws;
     int rc = 0;
-#define CF_STEP(G) rc = in_squeeze ? launch_step<G, true>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream)) \
-                                   : launch_step<G, false>(x, z, ldj_acc, w, B, x_bstride, dbg, cf_s(stream))
-    switch (shape_id(C, H, W)) {
+#define CF_STEP(G) rc = in_squeeze ? launch_step<G, true>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream)) \
+                                   : launch_step<G, false>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream))
+    const int variant = (flags >> 16) & 15;
+    switch (shape_id(C, H, W) * 4 + variant) {
         case 0: CF_STEP(G8); break;
-        case 1: CF_STEP(G16); break;
-        case 2: CF_STEP(G32); break;
-        case 3: CF_STEP(G64); break;
-        default: cf_set_error("cf_flow_step_fwd: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+        case 4: CF_STEP(G16); break;
+        case 5: CF_STEP(G16v1); break;
+        case 6: CF_STEP(G16v2); break;
+        case 7: CF_STEP(G16v3); break;
+        case 8: CF_STEP(G32); break;
+        case 9: CF_STEP(G32v1); break;
+        case 10: CF_STEP(G32v2); break;
+        case 11: CF_STEP(G32v3); break;
+        case 12: CF_STEP(G64); break;
+        case 13: CF_STEP(G64v1); break;
+        case 14: CF_STEP(G64v2); break;
+        case 15: CF_STEP(G64v3); break;
+        default: cf_set_error("cf_flow_step_fwd: shape (%d,%d,%d) variant %d unsupported", C, H, W, variant); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEP
     if (rc) return rc;
@@ -496,7 +610,7 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
 
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                      int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
-    return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, stream);
+    return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -32,7 +32,7 @@ def fused_step_debug(x, conv, act, cpl, squeeze=False):
     L = _hip.lib()
     fn = L.cf_flow_step_fwd_debug
     fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     B = x.shape[0]
     C, H, W = (x.shape[1] * 4, x.shape[2] // 2, x.shape[3] // 2) if squeeze else tuple(x.shape[1:])
     ws = torch.empty(L.cf_flow_step_ws_bytes(C, H, W), device=x.device, dtype=torch.uint8)
@@ -41,13 +41,13 @@ def fused_step_debug(x, conv, act, cpl, squeeze=False):
     _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
               pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
               pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, _hip.stream())
-    spw = {256: 1, 64: 4, 16: 8}[H * W]
+    spw = {256: 1, 64: 4, 16: 16}[H * W]
     nwg = (B + spw - 1) // spw
     cols = nwg * spw * H * W
     dbg = torch.full((2 * C + 4 * C, cols), float("nan"), device=x.device)
     z = torch.empty(B, C, H, W, device=x.device)
     ldj = torch.zeros(B, device=x.device)
-    _hip.check(fn(pp(x), pp(z), pp(ldj), pp(ws), B, C, H, W, C * H * W, int(squeeze), pp(dbg), _hip.stream()),
+    _hip.check(fn(pp(x), pp(z), pp(ldj), pp(ws), B, C, H, W, C * H * W, int(squeeze), pp(dbg), 0, _hip.stream()),
                "cf_flow_step_fwd_debug")
     torch.cuda.synchronize()
     HID, HALF = 2 * C, C // 2
