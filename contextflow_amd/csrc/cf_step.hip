@@ -183,310 +183,341 @@ __device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const flo
     }
 }
 
+// ---- wave-local staging of activations with 16-byte global accesses ---------------------------------
+// A wave owns WPX = 32*PTW pixel columns.  Item n = i*64 + lane enumerates its C x WPX block of x.
+template <class G, bool SQ>
+__device__ __forceinline__ void x_load(float4 (&xr)[G::C * G::PTW / 8], const float* __restrict__ x, int64_t xbs,
+                                       int tile, int B, int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, W = G::W;
+    const int tb0 = tile * G::SPW;
+#pragma unroll
+    for (int i = 0; i < G::C * G::PTW / 8; ++i) {
+        const int n = i * 64 + lane;
+        if constexpr (!SQ) {
+            const int ch = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+            const int b = min(tb0 + col / HW, B - 1);
+            xr[i] = *reinterpret_cast<const float4*>(x + (int64_t)b * xbs + ch * HW + col % HW);
+        } else {
+            // un-squeezed row (2y+i1), 4 consecutive floats = channels (4c'+2i1, +1) of squeezed pixels (x, x+1)
+            const int cp = n / (WPX / 2), col = wave * WPX + 2 * (n % (WPX / 2));
+            const int b = min(tb0 + col / HW, B - 1);
+            const int p = col % HW, yy = p / W, xx = p % W;
+            xr[i] = *reinterpret_cast<const float4*>(x + (int64_t)b * xbs + (cp >> 1) * 4 * HW + (2 * yy + (cp & 1)) * 2 * W + 2 * xx);
+        }
+    }
+}
+
+template <class G, bool SQ>
+__device__ __forceinline__ void x_to_lds(const float4 (&xr)[G::C * G::PTW / 8], float* __restrict__ plane, int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, PIX = G::PIX;
+#pragma unroll
+    for (int i = 0; i < G::C * G::PTW / 8; ++i) {
+        const int n = i * 64 + lane;
+        if constexpr (!SQ) {
+            const int ch = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+            *reinterpret_cast<float4*>(&plane[ch * PIX + col]) = make_float4(xr[i].x, xr[i].y, xr[i].z, xr[i].w);
+        } else {
+            const int cp = n / (WPX / 2), col = wave * WPX + 2 * (n % (WPX / 2));
+            *reinterpret_cast<float2*>(&plane[(2 * cp) * PIX + col]) = make_float2(xr[i].x, xr[i].z);
+            *reinterpret_cast<float2*>(&plane[(2 * cp + 1) * PIX + col]) = make_float2(xr[i].y, xr[i].w);
+        }
+    }
+}
+
+// write one channel half of z from the LDS plane [HALF][PIX] (this wave's columns), 16 bytes per lane
+template <class G>
+__device__ __forceinline__ void z_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
+                                        int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, HALF = G::HALF, C = G::C;
+#pragma unroll
+    for (int i = 0; i < (HALF * G::PTW + 7) / 8; ++i) {
+        const int n = i * 64 + lane;
+        const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+        const int b = tb0 + col / HW;
+        if (idx < HALF && b < B)
+            *reinterpret_cast<float4*>(z + (int64_t)b * C * HW + (int64_t)(ch0 + idx) * HW + col % HW) =
+                *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
+    }
+}
+
 // ---- the step kernel ---------------------------------------------------------------------------------
-// dbg (optional, tests only): [4][C_or_HID rows][gridDim*PIX] dumps of y, h1, h2, h.
-// SQ: x is the UN-squeezed tensor (B, C/4, 2H, 2W) and Squeeze((2,2)) (squeeze.py:10-11) is folded into
-// the phase-0 operand addressing: channel k = 4c' + 2i1 + i2 of pixel (y,x) is in[c'][2y+i1][2x+i2]; with
-// k = 2s + (lane>>5) the two half-waves of one load read the interleaved even/odd columns of one row.
+// One workgroup per tile of SPW samples.  Per wave (all wave-local unless noted; a wave owns the pixel
+// columns of its PTW tiles):
+//   x (16-byte loads) -> registers -> LDS plane Xp[ch][pix]
+//   phase 0  y = W'x + b'        (MFMA, B operand from Xp)   -> y0 -> LDS Y0, y1 stays in registers
+//            z[:, :C/2] = y0     written from Y0 with 16-byte stores
+//   phase 1  h1 = relu(NN.0 y0)  -> LDS H1 ;  BARRIER (3x3 taps read neighbouring waves' columns)
+//   phase 2  3x3 reflect conv    ;  BARRIER (everyone done reading h1) ;  h2 -> LDS (in place)
+//   phase 3  h = NN.4 h2 ; affine map ; z[:, C/2:] via LDS with 16-byte stores ; per-sample log-det
+// SQ: x is the UN-squeezed tensor (B, C/4, 2H, 2W); Squeeze((2,2)) (squeeze.py:10-11) is folded into the x
+// staging: one 16-byte load along the un-squeezed row = channels (4c'+2i1, +1) of squeezed pixels (x, x+1).
+// dbg (optional, tests only): dumps of y0, h1, h2, h as [rows][tiles*PIX].
 template <class G, bool SQ>
 __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
                                                    float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
                                                    int64_t xbs, float* __restrict__ dbg, int flags) {
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
-    extern __shared__ __align__(16) float lds[];      // G::LDS_FLOATS floats (up to 80 KiB: dynamic)
-    float* Y0 = lds;                    // [HALF][PIX]   conditioner input y0 (phase 0 -> 1); later the ldj scratch
-    float* H1 = lds + HALF * PIX;       // [HID][PIX]    h1, then h2 in place
+    constexpr int WPX = 32 * PTW;                     // pixel columns owned by one wave
+    constexpr int XI = C * PTW / 8;                   // 16-byte x items per lane and tile
+    extern __shared__ __align__(16) float lds[];      // G::LDS_FLOATS floats (up to 160 KiB: dynamic)
+    float* Y0 = lds;                    // [HALF][PIX]   y0 (phase 0 -> 1), later the z1 staging plane
+    float* H1 = lds + HALF * PIX;       // [HID][PIX]    x plane (rows < C), then h1, then h2 in place
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
-    const int b0 = blockIdx.x * G::SPW;
-    if (flags & 1) {
-        // de-phase the workgroups that share a CU: the first resident generation starts staggered (slot k of a CU
-        // waits k * stagger), later workgroups inherit the offset because they start when an earlier one retires.
-        const int slot = blockIdx.x / 256;                      // blocks are dealt round-robin over XCDs, then CUs
-        const int nslots = (flags >> 4) & 15, units = flags >> 8;
-        if (slot < nslots)
-            for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(64);
-    }
-    const int64_t dbg_cols = (int64_t)gridDim.x * PIX;
+    const int ntiles = (B + G::SPW - 1) / G::SPW;
+    const int64_t dbg_cols = (int64_t)ntiles * PIX;
+    (void)flags;
 
-    int pix[PTW];                       // this lane's pixel column inside the workgroup, per owned tile
-    int smp[PTW], pin[PTW];             // sample (global) and pixel-in-sample
-    bool live[PTW];
+    int pix[PTW], pin[PTW];             // this lane's pixel column inside the workgroup / inside its sample
 #pragma unroll
     for (int q = 0; q < PTW; ++q) {
         pix[q] = (wave * PTW + q) * 32 + li;
-        smp[q] = b0 + pix[q] / HW;
         pin[q] = pix[q] % HW;
-        live[q] = smp[q] < B;
     }
 
-    // ================= phase 0: y = (e^{-logs} Wm) x - t e^{-logs}        (conv1x1.py:54 + actnorm.py:59)
-    f32x16 acc0[RT03][PTW];
-#pragma unroll
-    for (int rt = 0; rt < RT03; ++rt)
-#pragma unroll
-        for (int q = 0; q < PTW; ++q) acc0[rt][q] = bias_tile(ws + G::OFF_B0 + rt * 32, lk);
+    // One tile per workgroup (grid = ntiles).  A persistent tile loop with the next tile's x prefetched into
+    // registers was tried: hipcc then keeps 50-110 more VGPRs live across the loop (occupancy 4 -> 2 at C=16) and
+    // it measured slower; co-resident workgroups hide the x-load latency instead.
+    float4 xr[XI];
+    const int tile = blockIdx.x;
+    x_load<G, SQ>(xr, x, xbs, tile, B, wave, lane);
     {
-        const float4* frags = reinterpret_cast<const float4*>(ws + G::OFF_A0);
-        const float* xp[PTW];
+        const float* __restrict__ wsl = ws;
+        const int b0 = tile * G::SPW;
+        int smp[PTW];
+        bool live[PTW];
 #pragma unroll
-        for (int q = 0; q < PTW; ++q) {
-            const float* xb = x + (int64_t)min(smp[q], B - 1) * xbs;
-            xp[q] = SQ ? xb + (2 * (pin[q] / W)) * (2 * W) + 2 * (pin[q] % W) + lk : xb + pin[q] + (int64_t)lk * HW;
+        for (int q = 0; q < PTW; ++q) { smp[q] = b0 + pix[q] / HW; live[q] = smp[q] < B; }
+
+        x_to_lds<G, SQ>(xr, H1, wave, lane);
+
+        // ================= phase 0: y = (e^{-logs} Wm) x - t e^{-logs}        (conv1x1.py:54 + actnorm.py:59)
+        f32x16 acc0[RT03][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc0[rt][q] = bias_tile(wsl + G::OFF_B0 + rt * 32, lk);
+        dense_phase<G, G::KS0, G::NG0, RT03>(acc0, reinterpret_cast<const float4*>(wsl + G::OFF_A0), H1, pix, lane);
+        // first half: conditioner input -> LDS, and it is also the first half of the output (coupling.py:65);
+        // second half (x1 after Conv1x1+ActNorm) stays in registers until the epilogue
+        float y1[PTW][HALF <= 16 ? 8 : 16];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+            for (int r = 0; r < (HALF <= 16 ? 8 : 16); ++r) {
+                const int idx = tile_row(r, lk);                 // channel index inside its half
+                if (idx < HALF) Y0[idx * PIX + pix[q]] = acc0[0][q][r];
+                y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
+            }
+        z_store<G>(z, Y0, b0, 0, B, wave, lane);
+        if (dbg) {
+            __syncthreads();
+            for (int e = tid; e < HALF * PIX; e += 256) dbg[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = Y0[e];
+            __syncthreads();
         }
+
+        // ================= phase 1: h1 = relu(NN.0 y0 + b)                      (coupling.py:26)
+        {
+            f32x16 acc[RT1][PTW];
 #pragma unroll
-        for (int g = 0; g < G::NG0; ++g) {
-            float4 a[RT03];
+            for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
-            for (int rt = 0; rt < RT03; ++rt) a[rt] = frags[(g * RT03 + rt) * 64 + lane];
+                for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B1 + rt * 32, lk);
+            dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(wsl + G::OFF_A1), Y0, pix, lane);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (4 * g + e < G::KS0) {
+            for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
-                    for (int q = 0; q < PTW; ++q) {
-                        const int ks = 4 * g + e;                                     // k-step: channels 2ks, 2ks+1
-                        const float b = SQ ? xp[q][(ks >> 1) * 4 * HW + (ks & 1) * 2 * W]
-                                           : xp[q][(int64_t)(2 * ks) * HW];           // B[k][pixel] = x[ch k][pixel]
+                for (int q = 0; q < PTW; ++q)
 #pragma unroll
-                        for (int rt = 0; rt < RT03; ++rt)
-                            acc0[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[rt], e), b, acc0[rt][q], 0, 0, 0);
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rt * 32 + tile_row(r, lk);
+                        if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
                     }
-                }
-            }
         }
-    }
-    // first half: conditioner input -> LDS, and it is also the first half of the output (coupling.py:65)
-    // second half (x1 after Conv1x1+ActNorm) stays in registers until the epilogue
-    float y1[PTW][HALF <= 16 ? 8 : 16];
-#pragma unroll
-    for (int q = 0; q < PTW; ++q) {
-        float* zq = z + (int64_t)smp[q] * C * HW + pin[q];
-#pragma unroll
-        for (int r = 0; r < (HALF <= 16 ? 8 : 16); ++r) {
-            const int idx = tile_row(r, lk);                 // channel index inside its half
-            const float v0 = acc0[0][q][r];
-            if (idx < HALF) {
-                Y0[idx * PIX + pix[q]] = v0;
-                if (live[q]) zq[(int64_t)idx * HW] = v0;
-            }
-            y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
+        __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' columns
+        if (dbg) {
+            float* d = dbg + (int64_t)C * dbg_cols;
+            for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
         }
-    }
-    // no workgroup barrier here: phase 1 reads only the pixel columns of Y0 this wave has just written
-    if (dbg) {
-        __syncthreads();
-        for (int e = tid; e < HALF * PIX; e += 256) dbg[(int64_t)(e / PIX) * dbg_cols + blockIdx.x * PIX + (e % PIX)] = Y0[e];
-    }
 
-    // ================= phase 1: h1 = relu(NN.0 y0 + b)                      (coupling.py:26)
-    {
-        f32x16 acc[RT1][PTW];
+        // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
+        {
+            f32x16 acc[RT1][PTW];
 #pragma unroll
-        for (int rt = 0; rt < RT1; ++rt)
+            for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
-            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B1 + rt * 32, lk);
-        dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(ws + G::OFF_A1), Y0, pix, lane);
-#pragma unroll
-        for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-            for (int q = 0; q < PTW; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rt * 32 + tile_row(r, lk);
-                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
-                }
-    }
-    __syncthreads();
-    if (dbg) {
-        float* d = dbg + (int64_t)C * dbg_cols;
-        for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + blockIdx.x * PIX + (e % PIX)] = H1[e];
-    }
-
-    // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
-    {
-        f32x16 acc[RT1][PTW];
-#pragma unroll
-        for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B2 + rt * 32, lk);
-        const float4* frags = reinterpret_cast<const float4*>(ws + G::OFF_A2);
-        if constexpr (G::PIPE == 0) {
-            // compiler-scheduled form: one tap per loop trip, all NCG groups of the tap unrolled
-            float4 a_cur[RT1], a_nxt[RT1];
-#pragma unroll
-            for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
-            const int ntaps0 = (flags & 4) ? 1 : 9;
-#pragma unroll 1
-            for (int tap = 0; tap < ntaps0; ++tap) {
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                int src[PTW];
+                for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B2 + rt * 32, lk);
+            const float4* frags = reinterpret_cast<const float4*>(wsl + G::OFF_A2);
+            // reflect-padded source pixel of a tap, as an index into lds[] (offsets, not pointers: a pointer array
+            // loses the LDS address space and hipcc falls back to flat loads)
+            auto tap_src = [&](int tap, int (&src)[PTW]) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;              // wave-uniform
 #pragma unroll
                 for (int q = 0; q < PTW; ++q) {
                     int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
-                    yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);   // reflect (padding_mode='reflect')
+                    yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);       // reflect (padding_mode='reflect')
                     xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
                     src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
                 }
+            };
+            if constexpr (G::PIPE == 0) {
+                // compiler-scheduled form: one tap per loop trip, all NCG groups of the tap unrolled
+                float4 a_cur[RT1], a_nxt[RT1];
 #pragma unroll
-                for (int cg = 0; cg < G::NCG; ++cg) {
-                    const int g = tap * G::NCG + cg;
-                    const int gn = min(g + 1, G::NG2 - 1);
+                for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+#pragma unroll 1
+                for (int tap = 0; tap < 9; ++tap) {
+                    int src[PTW];
+                    tap_src(tap, src);
 #pragma unroll
-                    for (int rt = 0; rt < RT1; ++rt) a_nxt[rt] = frags[(gn * RT1 + rt) * 64 + lane];
+                    for (int cg = 0; cg < G::NCG; ++cg) {
+                        const int g = tap * G::NCG + cg;
+                        const int gn = min(g + 1, G::NG2 - 1);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                        for (int rt = 0; rt < RT1; ++rt) a_nxt[rt] = frags[(gn * RT1 + rt) * 64 + lane];
 #pragma unroll
-                        for (int q = 0; q < PTW; ++q) {
-                            const float b = lds[src[q] + (8 * cg + 2 * e) * PIX];
+                        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                            for (int rt = 0; rt < RT1; ++rt)
-                                acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), b, acc[rt][q], 0, 0, 0);
+                            for (int q = 0; q < PTW; ++q) {
+                                const float bv = lds[src[q] + (8 * cg + 2 * e) * PIX];
+#pragma unroll
+                                for (int rt = 0; rt < RT1; ++rt)
+                                    acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), bv, acc[rt][q], 0, 0, 0);
+                            }
                         }
+#pragma unroll
+                        for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
+                    }
+                }
+            } else {
+                // group g = tap*NCG + cg covers tap (dy,dx) and input channels 8cg .. 8cg+7.  The operands of group
+                // g+1 are requested before the MFMAs of group g (two register sets, loads pinned by sched_barrier);
+                // the source pixel of a tap is computed once per tap, one tap ahead.
+                GroupOps<RT1, PTW> ops[2];
+                auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * PIX];
+                };
+                int src_cur[PTW], src_nxt[PTW];
+                tap_src(0, src_cur);
+                load(frags, src_cur, 0, ops[0]);
+#pragma unroll 1
+                for (int tap = 0; tap < 9; ++tap) {
+                    tap_src(min(tap + 1, 8), src_nxt);
+                    const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
+#pragma unroll
+                    for (int cg = 0; cg < G::NCG; ++cg) {                       // NCG is even: static ping-pong
+                        const float4* fn = fr + (cg + 1) * RT1 * 64;            // fragments of the next group
+                        if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
+                        else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);       // first group of the next tap
+                        __builtin_amdgcn_sched_barrier(0);
+                        group_mma<RT1, PTW>(acc, ops[cg & 1], 4);
                     }
 #pragma unroll
-                    for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
+                    for (int q = 0; q < PTW; ++q) src_cur[q] = src_nxt[q];
                 }
+            }
+            __syncthreads();                 // every wave has finished reading h1 (taps cross pixel tiles)
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+                for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rt * 32 + tile_row(r, lk);
+                        if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                    }
+        }
+        // no barrier: phase 3 reads only this wave's own pixel columns of h2
+        if (dbg) {
+            __syncthreads();
+            float* d = dbg + (int64_t)(C + HID) * dbg_cols;
+            for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
+        }
+
+        // ================= phase 3: h = NN.4 h2 + b ; affine map ; log-det        (coupling.py:28,52-66)
+        f32x16 acc3[RT03][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(wsl + G::OFF_B3 + rt * 32, lk);
+        dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(wsl + G::OFF_A3), H1, pix, lane);
+
+        float lsum[PTW];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) {
+            lsum[q] = 0.f;
+#pragma unroll
+            for (int r = 0; r < (HALF <= 16 ? 8 : 16); ++r) {
+                const int idx = tile_row(r, lk);
+                if (idx < HALF) {
+                    const float tt = acc3[0][q][r];
+                    const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
+                    const float ls = 2.0f * tanhf(raw * 0.5f);                    // coupling.py:55-56
+                    Y0[idx * PIX + pix[q]] = y1[q][r] * expf(ls) + tt;            // coupling.py:63 (z1, staged in LDS)
+                    lsum[q] += ls;
+                    if (dbg) {
+                        float* d = dbg + (int64_t)(C + 2 * HID) * dbg_cols + (int64_t)tile * PIX + pix[q];
+                        d[(int64_t)idx * dbg_cols] = tt;
+                        d[(int64_t)(HALF + idx) * dbg_cols] = raw;
+                    }
+                }
+            }
+        }
+        z_store<G>(z, Y0, b0, HALF, B, wave, lane);
+
+        // per-sample reduction of log_s: lanes of one sample inside a 32-pixel tile first (shuffles) ...
+        constexpr int SEG = HW < 32 ? HW : 32;            // lanes (pixels) of one sample inside a tile
+        float v[PTW];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) {
+            v[q] = lsum[q];
+#pragma unroll
+            for (int o = 1; o < SEG; o <<= 1) v[q] += __shfl_xor(v[q], o, 64);
+            v[q] += __shfl_xor(v[q], 32, 64);
+        }
+        if constexpr (HW <= 32 * PTW) {
+            // ... whole samples live inside this wave: finish in registers, the first lane of a sample owns ldj_acc[b]
+            constexpr int TPS = HW >= 32 ? HW / 32 : 1;   // tiles per sample
+#pragma unroll
+            for (int q = 0; q < PTW; q += TPS) {
+                float sum = v[q];
+#pragma unroll
+                for (int i = 1; i < TPS; ++i) sum += v[q + i];
+                if (lk == 0 && (li % SEG) == 0 && live[q]) ldj_acc[smp[q]] += wsl[0] + sum;
             }
         } else {
-        // group g = tap*NCG + cg covers tap (dy,dx) and input channels 8cg .. 8cg+7.  The operands of group g+1
-        // are requested before the MFMAs of group g (two register sets, loads pinned by sched_barrier); the
-        // reflect-padded source pixel of a tap is computed once per tap, one tap ahead.
-        GroupOps<RT1, PTW> ops[2];
-        // (LDS offsets, not pointers: a pointer array loses the LDS address space and hipcc falls back to flat loads)
-        auto tap_src = [&](int tap, int (&src)[PTW]) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;              // wave-uniform
-#pragma unroll
-            for (int q = 0; q < PTW; ++q) {
-                int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
-                yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);       // reflect (padding_mode='reflect')
-                xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-                src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;   // index into lds[] (H1 plane)
-            }
-        };
-        auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
-#pragma unroll
-            for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
+            // ... a sample spans several waves: one LDS hop through this wave's own columns of Y0 (its z1 values have
+            // been read back already); the second barrier keeps the next tile's y0 from overwriting the scratch
+            constexpr int TPS = HW / 32;
 #pragma unroll
             for (int q = 0; q < PTW; ++q)
+                if (lane == 0) Y0[wave * WPX + q] = v[q];
+            __syncthreads();
+            if (tid < G::SPW && b0 + tid < B) {
+                float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * PIX];
-        };
-        int src_cur[PTW], src_nxt[PTW];
-        tap_src(0, src_cur);
-        load(frags, src_cur, 0, ops[0]);
-        const int ntaps = (flags & 4) ? 1 : 9;                          // flags&4: timing experiment
-#pragma unroll 1
-        for (int tap = 0; tap < ntaps; ++tap) {
-            tap_src(min(tap + 1, 8), src_nxt);
-            const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
-#pragma unroll
-            for (int cg = 0; cg < G::NCG; ++cg) {                       // NCG is even: static ping-pong
-                const float4* fn = fr + (cg + 1) * RT1 * 64;            // fragments of the next group
-                if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
-                else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);       // first group of the next tap
-                __builtin_amdgcn_sched_barrier(0);
-                group_mma<RT1, PTW>(acc, ops[cg & 1], 4);
+                for (int i = 0; i < TPS; ++i) {
+                    const int t = tid * TPS + i;                       // tile index inside the workgroup
+                    sum += Y0[(t / PTW) * WPX + (t % PTW)];
+                }
+                ldj_acc[b0 + tid] += wsl[0] + sum;
             }
-#pragma unroll
-            for (int q = 0; q < PTW; ++q) src_cur[q] = src_nxt[q];
-        }
-        }
-        __syncthreads();                 // every wave has finished reading h1 (taps cross pixel tiles)
-#pragma unroll
-        for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-            for (int q = 0; q < PTW; ++q)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rt * 32 + tile_row(r, lk);
-                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
-                }
-    }
-    // no barrier: phase 3 reads only this wave's own pixel columns of h2
-    if (dbg) {
-        __syncthreads();
-        float* d = dbg + (int64_t)(C + HID) * dbg_cols;
-        for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + blockIdx.x * PIX + (e % PIX)] = H1[e];
-    }
-
-    // ================= phase 3: h = NN.4 h2 + b ; affine map ; log-det        (coupling.py:28,52-66)
-    f32x16 acc3[RT03][PTW];
-#pragma unroll
-    for (int rt = 0; rt < RT03; ++rt)
-#pragma unroll
-        for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(ws + G::OFF_B3 + rt * 32, lk);
-    dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(ws + G::OFF_A3), H1, pix, lane);
-
-    float lsum[PTW];
-#pragma unroll
-    for (int q = 0; q < PTW; ++q) {
-        lsum[q] = 0.f;
-        float* zq = z + (int64_t)smp[q] * C * HW + (int64_t)HALF * HW + pin[q];
-#pragma unroll
-        for (int r = 0; r < (HALF <= 16 ? 8 : 16); ++r) {
-            const int idx = tile_row(r, lk);
-            if (idx < HALF) {
-                const float tt = acc3[0][q][r];
-                const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
-                float ls, z1;
-                if (flags & 8) { ls = raw; z1 = y1[q][r] * raw + tt; }       // timing experiment: no transcendental
-                else {
-                    ls = 2.0f * tanhf(raw * 0.5f);                             // coupling.py:55-56
-                    z1 = y1[q][r] * expf(ls) + tt;                             // coupling.py:63
-                }
-                lsum[q] += ls;
-                if (live[q]) zq[(int64_t)idx * HW] = z1;
-                if (dbg) {
-                    float* d = dbg + (int64_t)(C + 2 * HID) * dbg_cols + blockIdx.x * PIX + pix[q];
-                    d[(int64_t)idx * dbg_cols] = tt;
-                    d[(int64_t)(HALF + idx) * dbg_cols] = raw;
-                }
-            }
-        }
-    }
-    // per-sample reduction of log_s: lanes of one sample inside a 32-pixel tile first (shuffles) ...
-    constexpr int SEG = HW < 32 ? HW : 32;            // lanes (pixels) of one sample inside a tile
-    float v[PTW];
-#pragma unroll
-    for (int q = 0; q < PTW; ++q) {
-        v[q] = lsum[q];
-#pragma unroll
-        for (int o = 1; o < SEG; o <<= 1) v[q] += __shfl_xor(v[q], o, 64);
-        v[q] += __shfl_xor(v[q], 32, 64);
-    }
-    if constexpr (HW <= 32 * PTW) {
-        // ... whole samples live inside this wave: finish in registers, the first lane of a sample owns ldj_acc[b]
-        constexpr int TPS = HW >= 32 ? HW / 32 : 1;   // tiles per sample
-#pragma unroll
-        for (int q = 0; q < PTW; q += TPS) {
-            float sum = v[q];
-#pragma unroll
-            for (int i = 1; i < TPS; ++i) sum += v[q + i];
-            if (lk == 0 && (li % SEG) == 0 && live[q]) ldj_acc[smp[q]] += ws[0] + sum;
-        }
-    } else {
-        // ... a sample spans several waves: one LDS hop (Y0 is dead since the barrier after phase 1)
-        constexpr int TPS = HW / 32;
-        float* red = Y0;
-#pragma unroll
-        for (int q = 0; q < PTW; ++q)
-            if (lane == 0) red[wave * PTW + q] = v[q];
-        __syncthreads();
-        if (tid < G::SPW && b0 + tid < B) {
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < TPS; ++i) sum += red[tid * TPS + i];
-            ldj_acc[b0 + tid] += ws[0] + sum;
+            __syncthreads();
         }
     }
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------
 // Tile / loop form per shape, chosen by measurement on MI355X (tools/step_bench.py, B = 16384):
-//   C16: 1 sample (256 px, 40 KB LDS, 4 workgroups/CU), compiler-scheduled tap loop      108 TFLOP/s
-//   C32: 4 samples (256 px, 80 KB, 2/CU), explicit operand pipeline                        126 TFLOP/s
-//   C64: 16 samples (256 px, 160 KB = the whole LDS, 1/CU), explicit pipeline, 4x2 tiles   134 TFLOP/s
+//   C16: 1 sample (256 px, 40 KB LDS, 3-4 workgroups/CU), compiler-scheduled tap loop    113 TFLOP/s
+//   C32: 4 samples (256 px, 80 KB, 2/CU), explicit operand pipeline                        130 TFLOP/s
+//   C64: 16 samples (256 px, 160 KB = the whole LDS, 1/CU), explicit pipeline, 4x2 tiles   136 TFLOP/s
 using G8 = Geo<8, 16, 16, 1, 0>;
 using G16 = Geo<16, 16, 16, 1, 0>;
 using G32 = Geo<32, 8, 8, 4, 1>;
@@ -516,8 +547,7 @@ int launch_prepare(const float* Wm, const float* t, const float* logs, const flo
 template <class G, bool SQ>
 int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, int flags,
                 hipStream_t s) {
-    size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
-    if (flags & 2) lds_bytes = 160 * 1024;                      // experiment: force one workgroup per CU
+    constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
         static bool raised = false;
         if (!raised) {
@@ -527,7 +557,8 @@ int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, in
             raised = true;
         }
     }
-    k_flow_step<G, SQ><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags);
+    const int grid = (B + G::SPW - 1) / G::SPW;
+    k_flow_step<G, SQ><<<dim3(grid), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags);
     return 0;
 }
 
@@ -580,6 +611,7 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, con
 int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                            int64_t x_bstride, int in_squeeze, float* dbg, int flags, cf_stream_t stream) {
     CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && x_bstride % 4 == 0);
     if (B == 0) return 0;
     const float* w = (const float*)ws;
     int rc = 0;
