@@ -184,7 +184,8 @@ def main():
                 "kernel_time_share": round(ms * 1e-3 / dt, 3)}
 
     if rank == 0:
-        out = {"metric": "samples/s fwd+logdet (log p(x) (B,M)), %s conv flow" % ("CIFAR-10C" if name == "cifar10" else name),
+        label = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap": "SMAP trans flow"}[name]
+        out = {"metric": "samples/s fwd+logdet (log p(x) (B,M)), %s" % label,
                "value": round(G * a.steps / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

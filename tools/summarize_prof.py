@@ -58,3 +58,42 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
         n = max(cnt[k].values())
         print("| `%s` | %d | " % (k, n) + " | ".join("%.4g" % (acc[k][c] / max(cnt[k][c], 1)) for c in names) + " |")
     print()
+
+# ---- HBM traffic of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950:
+# FETCH_SIZE counts 64 B per 128-B request on 16-B/lane streaming reads -> x2; WRITE_SIZE is exact; both in KiB.
+import json
+
+
+def pmc_avg(counter):
+    for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) if os.path.isdir(d) else []
+        if not files:
+            continue
+        acc, cnt = defaultdict(float), defaultdict(int)
+        for r in csv.DictReader(open(files[0])):
+            if r["Counter_Name"] == counter:
+                k = short(r["Kernel_Name"])
+                acc[k] += float(r["Counter_Value"]); cnt[k] += 1
+        if acc:
+            return {k: acc[k] / cnt[k] for k in acc}, cnt
+    return {}, {}
+
+
+fetch, nf = pmc_avg("FETCH_SIZE")
+write, nw = pmc_avg("WRITE_SIZE")
+levels, tot_b, tot_n = {}, 0.0, 0
+for k in fetch:
+    if k.startswith("k_flow_step") and k in write:
+        m = re.search(r"Geo<(\d+), (\d+), (\d+)", k)
+        C, H, W = (int(v) for v in m.groups())
+        byt = (2.0 * fetch[k] + write[k]) * 1024.0
+        alg = 16384 * 2 * C * H * W * 4
+        levels[k] = {"hbm_bytes_per_launch": round(byt), "algorithmic_bytes_per_launch": alg, "launches": nf[k]}
+        tot_b += byt * nf[k]; tot_n += nf[k]
+if tot_n:
+    tj = {"k_flow_step_bytes_per_launch": round(tot_b / tot_n), "batch_per_launch": 16384,
+          "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes (gfx950: FETCH_SIZE reads 1/2 on 16-B/lane streams)",
+          "algorithmic_bytes_per_launch_avg": round(sum(v["algorithmic_bytes_per_launch"] * v["launches"] for v in levels.values()) / tot_n),
+          "per_kernel": levels}
+    json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print("## HBM traffic of k_flow_step\n\n```json\n" + json.dumps(tj, indent=1) + "\n```")
