@@ -45,6 +45,11 @@ SIGNATURES = {
     "cf_layernorm": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_f, _c_p]),
     "cf_attention": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
     "cf_patchify": (_c_int, [_c_p, _c_p] + [_c_int] * 6 + [_c_i64, _c_int, _c_p]),
+    "cf_vit_supported": (_c_int, [_c_int] * 8),
+    "cf_vit_ws_bytes": (_c_i64, [_c_int] * 3),
+    "cf_vit_flat_params": (_c_i64, [_c_int] * 3),
+    "cf_vit_prepare": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
+    "cf_vit_coupling": (_c_int, [_c_p] * 5 + [_c_int] * 8 + [_c_i64, _c_int, _c_p]),
     "cf_logdet_combine": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     "cf_nll_sum": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
 }

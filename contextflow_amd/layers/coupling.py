@@ -98,8 +98,64 @@ class TransCoupling(_AffineCoupling):
         T = O * p_sz[0] * p_sz[1]                       # transformer width (coupling.py:108)
         self.context_net = context_net
         self.contextflow = contextflow
+        self.in_sz, self.p_sz = tuple(in_sz), tuple(p_sz)
         self.NN = nn.Sequential(SimpleViT(image_size=(in_sz[1], in_sz[2]), patch_size=p_sz, dim=T, depth=6, heads=1,
                                           mlp_dim=T, channels=D))
+        self.fused = True                                # one-kernel path when the geometry allows it
 
     def net(self, x0):
+        """Conditioner output h (layer-by-layer kernels; also the fallback for unsupported geometries)."""
         return self.NN[0](x0)
+
+    # ---- fused path: patchify -> ViT -> un-patchify -> affine map -> log-det in one kernel
+    def _fused_ok(self, x):
+        if not self.fused or x.dim() != 4:
+            return False
+        vit = self.NN[0]
+        C, H, W = x.shape[1:]
+        att = vit.transformer.layers[0][0] if len(vit.transformer.layers) else None
+        if att is None or (C, H, W) != self.in_sz:
+            return False
+        return bool(_hip.lib().cf_vit_supported(C, H, W, self.p_sz[0], self.p_sz[1], vit.dim, att.dim_head, att.heads))
+
+    def _flat_params(self):
+        vit = self.NN[0]
+        tpe = vit.to_patch_embedding
+        parts = [tpe[1].weight, tpe[1].bias, tpe[2].weight, tpe[2].bias, tpe[3].weight, tpe[3].bias]
+        for attn, ff in vit.transformer.layers:
+            parts += [attn.norm.weight, attn.norm.bias, attn.to_qkv.weight, attn.to_out.weight,
+                      ff.net[0].weight, ff.net[0].bias, ff.net[1].weight, ff.net[1].bias, ff.net[3].weight, ff.net[3].bias]
+        parts += [vit.transformer.norm.weight, vit.transformer.norm.bias]
+        return torch.cat([t.detach().reshape(-1).float() for t in parts])
+
+    def _fused(self, x, inverse):
+        vit = self.NN[0]
+        x, xbs = _hip.bview(x)
+        B, C, H, W = x.shape
+        p1, p2 = self.p_sz
+        pd, dim, depth = (C // 2) * p1 * p2, vit.dim, len(vit.transformer.layers)
+        L = _hip.lib()
+        flat = self._flat_params()
+        assert flat.numel() == L.cf_vit_flat_params(pd, dim, depth)
+        ws = torch.empty(L.cf_vit_ws_bytes(pd, dim, depth), device=x.device, dtype=torch.uint8)
+        st = _hip.stream()
+        _hip.call("cf_vit_prepare", _hip.p(flat), _hip.p(ws), pd, dim, depth, st)
+        if vit.pos_embedding.device != x.device:
+            vit.pos_embedding = vit.pos_embedding.to(x.device).contiguous()
+        z = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+        ldj = None if inverse else torch.empty(B, device=x.device, dtype=torch.float32)
+        _hip.call("cf_vit_coupling", _hip.p(x), _hip.p(z), _hip.p(ldj), _hip.p(ws), _hip.p(vit.pos_embedding),
+                  B, C, H, W, p1, p2, dim, depth, xbs, int(inverse), st)
+        return z, ldj
+
+    def forward(self, x, context=None):
+        _hip.require_device(x)
+        if self._fused_ok(x):
+            return self._fused(x, False)
+        return super().forward(x, context)
+
+    def reverse(self, z, context=None):
+        _hip.require_device(z)
+        if self._fused_ok(z):
+            return self._fused(z, True)[0]
+        return super().reverse(z, context)

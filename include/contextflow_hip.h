@@ -132,6 +132,23 @@ int cf_attention(const float* qkv, float* out, int B, int N, int dh, float scale
 int cf_patchify(const float* src, float* dst, int B, int C, int H, int W, int p1, int p2,
                 int64_t img_bstride, int inverse, cf_stream_t stream);
 
+/* ---- fused TransCoupling: patchify -> SimpleViT -> un-patchify -> affine map -> log-det in ONE kernel ---
+ * (layers/coupling.py:100-159 + layers/simple_vit.py:18-127).  Limits: heads 1, dim_head 64,
+ * dim = C*p1*p2 <= 64, patch_dim = (C/2)*p1*p2 <= 64, tokens per sample a power of two <= 32.        */
+int cf_vit_supported(int C, int H, int W, int p1, int p2, int dim, int dim_head, int heads);
+int64_t cf_vit_ws_bytes(int patch_dim, int dim, int depth);
+/* number of floats of the flat parameter vector cf_vit_prepare expects, in this order:
+ *   patch LN w,b | patch Linear W (dim x patch_dim), b | embed LN w,b |
+ *   depth x [attn LN w,b | to_qkv W (192 x dim) | to_out W (dim x 64) | ff LN w,b | ff W1 (dim x dim), b1 | W2, b2] |
+ *   final LN w,b                                                                                      */
+int64_t cf_vit_flat_params(int patch_dim, int dim, int depth);
+/* pack the flat parameters into MFMA-fragment order (device side, every call).                        */
+int cf_vit_prepare(const float* flat_params, void* ws, int patch_dim, int dim, int depth, cf_stream_t stream);
+/* x: (B,C,H,W) batch stride x_bstride; z: (B,C,H,W) dense; pos: (tokens, dim) sin/cos table.
+ * inverse=0: z = [x0 | x1*exp(log_s)+t], ldj[b] = sum log_s (assigned); inverse=1: z = [x0 | (x1-t)/exp(log_s)] */
+int cf_vit_coupling(const float* x, float* z, float* ldj, const void* ws, const float* pos, int B, int C, int H, int W,
+                    int p1, int p2, int dim, int depth, int64_t x_bstride, int inverse, cf_stream_t stream);
+
 /* ---- log-det bookkeeping (layers/flowsequential.py:18-27) --------------------------------------- */
 /* out[b,m] = ldM[b,m] + ld1[b]                                                                      */
 int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream);

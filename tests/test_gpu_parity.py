@@ -135,14 +135,17 @@ def test_preprocessing(L):
     close(L.StandardNormal((1, 4, 4)).to(DEV).log_prob(t["x"].to(DEV)), t["logp"], tol=1e-6)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("tag", ["trans_ts", "trans_img"])
-def test_transcoupling(L, tag):
+def test_transcoupling(L, tag, fused):
     t, sd = unit(tag)
     sz = tuple(int(v) for v in t["in_sz"]); patch = tuple(int(v) for v in t["p"])
     m = L.TransCoupling(sz, patch)
     m.load_state_dict(sd)
     m = m.to(DEV)
+    m.fused = fused
     x = t["x"].to(DEV)
+    assert m._fused_ok(x) == fused
     close(m.net(x[:, : sz[0] // 2]), t["h"], tol=2e-5)
     z, ldj = m(x)
     close(z, t["z"], tol=2e-5); close(ldj, t["ldj"], tol=2e-5)
