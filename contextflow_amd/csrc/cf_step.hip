@@ -30,9 +30,10 @@ constexpr int kWaves = 4;
 
 // ---- compile-time geometry of one supported shape ------------------------------------------------
 // PIPE_: phase-2 loop form (1 = explicit two-stage operand pipeline, 0 = compiler-scheduled per-tap loop)
-template <int C_, int H_, int W_, int SPW_, int PIPE_ = 1>
+// ABL_: timing-only ablations for tools/step_bench.py (1 = phase-2 operands are constants: no LDS / L2 loads there)
+template <int C_, int H_, int W_, int SPW_, int PIPE_ = 1, int ABL_ = 0>
 struct Geo {
-    static constexpr int C = C_, H = H_, W = W_, SPW = SPW_, PIPE = PIPE_;
+    static constexpr int C = C_, H = H_, W = W_, SPW = SPW_, PIPE = PIPE_, ABL = ABL_;
     static constexpr int HW = H * W;
     static constexpr int PIX = SPW * HW;              // pixels per workgroup
     static constexpr int HALF = C / 2;                // conditioner channels
@@ -375,12 +376,13 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
                         const int g = tap * G::NCG + cg;
                         const int gn = min(g + 1, G::NG2 - 1);
 #pragma unroll
-                        for (int rt = 0; rt < RT1; ++rt) a_nxt[rt] = frags[(gn * RT1 + rt) * 64 + lane];
+                        for (int rt = 0; rt < RT1; ++rt)
+                            a_nxt[rt] = G::ABL == 1 ? make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg) : frags[(gn * RT1 + rt) * 64 + lane];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
 #pragma unroll
                             for (int q = 0; q < PTW; ++q) {
-                                const float bv = lds[src[q] + (8 * cg + 2 * e) * PIX];
+                                const float bv = G::ABL == 1 ? 0.001f * (src[q] + e) : lds[src[q] + (8 * cg + 2 * e) * PIX];
 #pragma unroll
                                 for (int rt = 0; rt < RT1; ++rt)
                                     acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), bv, acc[rt][q], 0, 0, 0);
@@ -396,6 +398,15 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
                 // the source pixel of a tap is computed once per tap, one tap ahead.
                 GroupOps<RT1, PTW> ops[2];
                 auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+                    if constexpr (G::ABL == 1) {                      // timing ablation: operands from registers only
+#pragma unroll
+                        for (int rt = 0; rt < RT1; ++rt) o.a[rt] = make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg);
+#pragma unroll
+                        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o.b[e][q] = 0.001f * (src[q] + e);
+                        return;
+                    }
 #pragma unroll
                     for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
 #pragma unroll
@@ -458,8 +469,10 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
                 if (idx < HALF) {
                     const float tt = acc3[0][q][r];
                     const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
-                    const float ls = 2.0f * tanhf(raw * 0.5f);                    // coupling.py:55-56
-                    Y0[idx * PIX + pix[q]] = y1[q][r] * expf(ls) + tt;            // coupling.py:63 (z1, staged in LDS)
+                    // log_s = 2 tanh(raw/2) = 2 - 4/(e^raw + 1)  (coupling.py:55-56) on the hardware exp/rcp path:
+                    // |abs err| ~1e-7 per element, i.e. ~1e-8 bits/dim after the per-sample sum (tolerance 1e-5)
+                    const float ls = 2.0f - __fdividef(4.0f, __expf(raw) + 1.0f);
+                    Y0[idx * PIX + pix[q]] = fmaf(y1[q][r], __expf(ls), tt);      // coupling.py:63 (z1, staged in LDS)
                     lsum[q] += ls;
                     if (dbg) {
                         float* d = dbg + (int64_t)(C + 2 * HID) * dbg_cols + (int64_t)tile * PIX + pix[q];
@@ -523,13 +536,13 @@ using G16 = Geo<16, 16, 16, 1, 0>;
 using G32 = Geo<32, 8, 8, 4, 1>;
 using G64 = Geo<64, 4, 4, 16, 1>;
 // alternates kept for tools/step_bench.py, reachable only through cf_flow_step_fwd_debug (flags bits 16..19)
-using G16v1 = Geo<16, 16, 16, 1, 1>;
+using G16v1 = Geo<16, 16, 16, 1, 0, 1>;
 using G16v2 = Geo<16, 16, 16, 4, 1>;
 using G16v3 = Geo<16, 16, 16, 4, 0>;
-using G32v1 = Geo<32, 8, 8, 4, 0>;
+using G32v1 = Geo<32, 8, 8, 4, 1, 1>;
 using G32v2 = Geo<32, 8, 8, 8, 1>;
 using G32v3 = Geo<32, 8, 8, 8, 0>;
-using G64v1 = Geo<64, 4, 4, 8, 1>;
+using G64v1 = Geo<64, 4, 4, 16, 1, 1>;
 using G64v2 = Geo<64, 4, 4, 8, 0>;
 using G64v3 = Geo<64, 4, 4, 16, 0>;
 
