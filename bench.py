@@ -32,19 +32,25 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cifar10", choices=["cifar10", "mnist", "smap"])
-    ap.add_argument("--global-batch", type=int, default=65536)
-    ap.add_argument("--chunk", type=int, default=16384, help="samples per kernel launch sequence on one rank")
+    ap.add_argument("--global-batch", type=int, default=524288)
+    ap.add_argument("--chunk", type=int, default=65536, help="samples per kernel launch sequence on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
 def synth(name, n, dev, seed):
+    """Synthetic input resident in HBM: uint8-valued fp32 images (what Dequantization receives) or [0,1) series."""
     g = torch.Generator(device=dev).manual_seed(seed)
     C, H, W = {"cifar10": (3, 32, 32), "mnist": (1, 32, 32), "smap": (25, 8, 1)}[name]
-    if name == "smap":
-        return torch.rand(n, C, H, W, device=dev, generator=g)
-    return torch.randint(0, 256, (n, C, H, W), device=dev, generator=g).float()
+    out = torch.empty(n, C, H, W, device=dev, dtype=torch.float32)
+    for i in range(0, n, 65536):                      # piecewise: randint materialises int64
+        m = min(65536, n - i)
+        if name == "smap":
+            out[i:i + m] = torch.rand(m, C, H, W, device=dev, generator=g)
+        else:
+            out[i:i + m] = torch.randint(0, 256, (m, C, H, W), device=dev, generator=g).float()
+    return out
 
 
 def host_cores():
@@ -174,8 +180,10 @@ def main():
             per[k][0] += e0.elapsed_time(e1); per[k][1] += b * FLOP_PER_SAMPLE_STEP[name]
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get("k_flow_step_bytes_per_launch")
+        if os.path.exists(tp):          # PMC-measured HBM bytes (profiles/, tools/profile.sh), scaled to this run's launch size
+            tj = json.load(open(tp))
+            avg_b = sum(b for _, _, b, _ in events) / len(events)
+            traffic = int(tj["k_flow_step_bytes_per_launch"] / tj["batch_per_launch"] * avg_b)
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "kernel": "k_flow_step (Conv1x1+ActNorm+Coupling fused, v_mfma_f32_32x32x2_f32)",
