@@ -227,6 +227,18 @@ __global__ __launch_bounds__(256) void k_gmm_finish(const float* __restrict__ q,
     out[e] = accumulate ? out[e] + r : r;
 }
 
+// prior sampling (gaussian.py:163-169): x[n,:] = mG[row_n,:] + softplus(sG[row_n,:]) * eps[n,:], row_n = m*K + k_n
+__global__ __launch_bounds__(256) void k_gmm_sample(const float* __restrict__ mG, const float* __restrict__ sG,
+                                                    const int64_t* __restrict__ rows, const float* __restrict__ eps,
+                                                    float* __restrict__ out, int D, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / D;
+        const int d = (int)(i - n * D);
+        const int64_t r = rows[n] * D + d;
+        out[i] = fmaf(softplus_ref(sG[r]), eps[i], mG[r]);
+    }
+}
+
 // D-split heuristic: enough workgroups to cover the chip (~2 per CU), chunks stay multiples of DC
 int choose_nsplit(int B, int MK, int D) {
     const int mkb = MK <= 16 ? 16 : 80;
@@ -244,6 +256,18 @@ int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, 
                    int D, cf_stream_t stream) {
     CF_REQUIRE(mG && sG && wG && a && bm && cst && M > 0 && K > 0 && D > 0);
     k_gmm_prepare<<<dim3(M * K), dim3(256), 0, cf_s(stream)>>>(mG, sG, wG, a, bm, cst, K, D);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_sample(const float* mG, const float* sG, const int64_t* rows, const float* eps, float* out, int N, int D,
+                  cf_stream_t stream) {
+    CF_REQUIRE(mG && sG && rows && eps && out && N >= 0 && D > 0);
+    const int64_t total = (int64_t)N * D;
+    if (total == 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    k_gmm_sample<<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(mG, sG, rows, eps, out, D, total);
     CF_LAUNCH_CHECK();
     return 0;
 }

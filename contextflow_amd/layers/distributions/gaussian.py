@@ -99,4 +99,17 @@ class GaussianMixtureDistribution(nn.Module):
         return gmm_logprob(input, self.prepared())
 
     def sample(self, n_samples, context=None):
-        raise NotImplementedError("sampling from the prior is a later scope row (SURVEY.md §8(f) rank 3)")
+        """gaussian.py:163-169: draw from the mixture of class-mixture index 1 (the reference hard-codes `x[:, 1]`;
+        with a single mixture, where the reference raises, index 0 is used) and return (x, log_prob(x))."""
+        _hip.require_device(self.mG)
+        dev = self.mG.device
+        m = 1 if self.M > 1 else 0
+        w = torch.softmax(self.wG.detach()[m].float(), dim=-1)
+        k = torch.multinomial(w, n_samples, replacement=True)              # component per sample (RNG: plumbing)
+        rows = (m * self.K + k).to(torch.int64).contiguous()
+        D = self.mG[0, 0].numel()
+        eps = torch.randn(n_samples, D, device=dev, dtype=torch.float32)
+        x = torch.empty(n_samples, *self.mG.shape[2:], device=dev, dtype=torch.float32)
+        _hip.call("cf_gmm_sample", _hip.p(_hip.f32(self.mG.detach())), _hip.p(_hip.f32(self.sG.detach())), _hip.p(rows),
+                  _hip.p(eps), _hip.p(x), n_samples, D, _hip.stream())
+        return x, self.log_prob(x, context)

@@ -1,5 +1,7 @@
 """SplitPrior (reference: contextflow/layers/splitprior.py:7-25): second channel half is scored by a
 prior and leaves the flow; its log-density is returned as the layer's ldj (B, M)."""
+import torch
+
 from .flowlayer import FlowLayer
 
 
@@ -14,8 +16,11 @@ class SplitPrior(FlowLayer):
         return x[:, :c], self.dist.log_prob(x[:, c:], context)
 
     def reverse(self, z, context=None):
-        raise NotImplementedError("SplitPrior.reverse is broken in the reference (splitprior.py:18); "
-                                  "sampling is a later scope row (SURVEY.md §8(f) rank 3)")
+        """Inverse by specification: the reference's own line (splitprior.py:18, `self.dist.sample(self.C, ...)`)
+        reads an attribute that is never set; the evident intent — resample the split-off half from its prior, one
+        draw per batch element, and concatenate — is what runs here."""
+        z2, _ = self.dist.sample(z.shape[0], context)
+        return torch.cat([z, z2], dim=1)
 
     def logdet(self, input, context=None):
         return self.forward(input, context)[1]

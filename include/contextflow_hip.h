@@ -100,6 +100,11 @@ int64_t cf_gmm_ws_bytes(int B, int M, int K, int D);
 int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float* cst, float* out, void* ws,
                    int B, int M, int K, int D, int64_t x_bstride, int accumulate, cf_stream_t stream);
 
+/* prior sampling (gaussian.py:163-169): out[n,:] = mG[rows[n],:] + softplus(sG[rows[n],:]) * eps[n,:];
+ * rows[n] = m*K + k_n (int64, component drawn by the caller), eps ~ N(0,1) supplied by the caller.      */
+int cf_gmm_sample(const float* mG, const float* sG, const int64_t* rows, const float* eps, float* out, int N, int D,
+                  cf_stream_t stream);
+
 /* ---- fused flow step: Conv1x1 -> ActNorm -> Coupling(conv net) in ONE kernel, fp32 MFMA ---------
  * (model.py:129-147 per-step triple; coupling.py:26-29 net; conv1x1.py:52-57; actnorm.py:53-60)
  * Supported (C,H,W): (8,16,16) (16,16,16) (32,8,8) (64,4,4) with 3x3 reflect conv; others return
