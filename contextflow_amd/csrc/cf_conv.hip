@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k_conv2d_reflect(const float* __restrict_
 extern "C" int cf_conv2d_reflect(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout,
                                  int H, int W, int kh, int kw, int ph, int pw, int relu, int64_t x_bstride,
                                  cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && w && y && B >= 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && kh > 0 && kw > 0);
     CF_REQUIRE(ph >= 0 && pw >= 0 && ph < H && pw < W && kh == 2 * ph + 1 && kw == 2 * pw + 1);
     const int64_t total = (int64_t)B * Cout * H * W;

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void k_nll_sum(const float* __restrict__ logp,
 extern "C" {
 
 int cf_dequant_fwd(const float* x, const float* u, float* y, int64_t n, cf_stream_t stream) {
+    if (n == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && u && y && n >= 0);
     launch_flat<OP_ADD2>(x, u, y, n, 0.f, 0.f, cf_s(stream));
     CF_LAUNCH_CHECK();
@@ -272,6 +273,7 @@ int cf_dequant_fwd(const float* x, const float* u, float* y, int64_t n, cf_strea
 }
 
 int cf_affine(const float* x, float* y, int64_t n, float translation, float scale, int inverse, cf_stream_t stream) {
+    if (n == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && y && n >= 0);
     if (inverse) launch_flat<OP_AFFINE_INV>(x, nullptr, y, n, translation, scale, cf_s(stream));
     else launch_flat<OP_AFFINE_FWD>(x, nullptr, y, n, translation, scale, cf_s(stream));
@@ -280,6 +282,7 @@ int cf_affine(const float* x, float* y, int64_t n, float translation, float scal
 }
 
 int cf_sigmoid(const float* x, float* y, int64_t n, cf_stream_t stream) {
+    if (n == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && y && n >= 0);
     launch_flat<OP_SIGMOID>(x, nullptr, y, n, 0.f, 0.f, cf_s(stream));
     CF_LAUNCH_CHECK();
@@ -287,6 +290,7 @@ int cf_sigmoid(const float* x, float* y, int64_t n, cf_stream_t stream) {
 }
 
 int cf_floor(const float* x, float* y, int64_t n, cf_stream_t stream) {
+    if (n == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && y && n >= 0);
     launch_flat<OP_FLOOR>(x, nullptr, y, n, 0.f, 0.f, cf_s(stream));
     CF_LAUNCH_CHECK();
@@ -294,6 +298,7 @@ int cf_floor(const float* x, float* y, int64_t n, cf_stream_t stream) {
 }
 
 int cf_logit_fwd(const float* x, float* y, float* ldj, int B, int N, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && y && ldj && B >= 0 && N > 0);
     launch_sample<0>(x, nullptr, y, ldj, B, N, N, N, 0, 1, 0, 1, 0.f, cf_s(stream));
     CF_LAUNCH_CHECK();
@@ -302,6 +307,7 @@ int cf_logit_fwd(const float* x, float* y, float* ldj, int B, int N, cf_stream_t
 
 int cf_preprocess_fwd(const float* x, const float* u, float* y, float* ldj, int B, int N, int64_t y_bstride,
                       float t1, float s1, float t2, float s2, float ldj_const, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && u && y && ldj && B >= 0 && N > 0 && y_bstride >= N);
     launch_sample<1>(x, u, y, ldj, B, N, N, y_bstride, t1, s1, t2, s2, ldj_const, cf_s(stream));
     CF_LAUNCH_CHECK();
@@ -309,6 +315,7 @@ int cf_preprocess_fwd(const float* x, const float* u, float* y, float* ldj, int 
 }
 
 int cf_std_normal_nll(const float* eps, float* out, int B, int N, int64_t eps_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(eps && out && B >= 0 && N > 0 && eps_bstride >= N);
     launch_sample<2>(eps, nullptr, nullptr, out, B, N, eps_bstride, 0, 0, 1, 0, 1, 0.5f * N * kLog2Pi, cf_s(stream));
     CF_LAUNCH_CHECK();
@@ -317,6 +324,7 @@ int cf_std_normal_nll(const float* eps, float* out, int B, int N, int64_t eps_bs
 
 int cf_squeeze(const float* x, float* y, int B, int C, int H, int W, int p1, int p2, int64_t x_bstride,
                int64_t y_bstride, int inverse, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && y && B >= 0 && C > 0 && H > 0 && W > 0 && p1 > 0 && p2 > 0 && H % p1 == 0 && W % p2 == 0);
     const int64_t total = (int64_t)B * C * H * W;
     if (total == 0) return 0;
@@ -341,6 +349,7 @@ int cf_actnorm_stats(const float* x, float* t, float* logs, void* ws, int B, int
 
 int cf_actnorm(const float* x, const float* t, const float* logs, float* z, float* ldj_scalar, int B, int C, int HW,
                int inverse, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && t && logs && z && B >= 0 && C > 0 && HW > 0);
     const int64_t total = (int64_t)B * C * HW;
     int64_t blocks = (total + 255) / 256;
@@ -354,6 +363,7 @@ int cf_actnorm(const float* x, const float* t, const float* logs, float* z, floa
 
 int cf_coupling_apply(const float* x, const float* h, float* z, float* ldj, int B, int C, int HW, int inverse,
                       cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && h && z && B >= 0 && C > 0 && C % 2 == 0 && HW > 0 && (inverse || ldj));
     if (B == 0) return 0;
     const int half_n = (C / 2) * HW;
@@ -369,6 +379,7 @@ int cf_coupling_apply(const float* x, const float* h, float* z, float* ldj, int 
 }
 
 int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(ldM && ld1 && out && B >= 0 && M > 0);
     const int64_t total = (int64_t)B * M;
     if (total == 0) return 0;
@@ -380,6 +391,7 @@ int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int
 }
 
 int cf_nll_sum(const float* logp, double* acc, int B, int M, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(logp && acc && B >= 0 && M > 0);
     if (B == 0) return 0;
     int blocks = (B + 255) / 256;

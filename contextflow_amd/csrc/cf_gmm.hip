@@ -262,6 +262,7 @@ int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, 
 
 int cf_gmm_sample(const float* mG, const float* sG, const int64_t* rows, const float* eps, float* out, int N, int D,
                   cf_stream_t stream) {
+    if (N == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(mG && sG && rows && eps && out && N >= 0 && D > 0);
     const int64_t total = (int64_t)N * D;
     if (total == 0) return 0;
@@ -279,6 +280,7 @@ int64_t cf_gmm_ws_bytes(int B, int M, int K, int D) {
 
 int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float* cst, float* out, void* ws,
                    int B, int M, int K, int D, int64_t x_bstride, int accumulate, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && a && bm && cst && out && B >= 0 && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
     if (B == 0) return 0;
     const int MK = M * K;

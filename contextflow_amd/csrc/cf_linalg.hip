@@ -139,6 +139,7 @@ extern "C" {
 
 int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z, int B, int C, int HW,
                    int64_t x_bstride, int64_t z_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && Wm && z && B >= 0 && C > 0 && C <= 128 && HW > 0);
     const int64_t npix = (int64_t)B * HW;
     if (npix == 0) return 0;

@@ -623,6 +623,7 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, con
 // test hook (not part of the public header): same as cf_flow_step_fwd plus per-phase dumps
 int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                            int64_t x_bstride, int in_squeeze, float* dbg, int flags, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);
     CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && x_bstride % 4 == 0);
     if (B == 0) return 0;

@@ -161,6 +161,7 @@ extern "C" {
 
 int cf_linear(const float* x, const float* Wt, const float* bias, const float* res, float* y, int rows, int K, int N,
               int act, cf_stream_t stream) {
+    if (rows == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && Wt && y && rows >= 0 && K > 0 && N > 0 && (act == 0 || act == 1));
     if (K > 128) { cf_set_error("cf_linear: K=%d > 128 unsupported", K); return CF_ERR_UNSUPPORTED; }
     if (rows == 0) return 0;
@@ -184,6 +185,7 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
 
 int cf_layernorm(const float* x, const float* w, const float* b, const float* pos, float* y, int rows, int dim,
                  int ntok, float eps, cf_stream_t stream) {
+    if (rows == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && w && b && y && rows >= 0 && dim > 0 && (pos == nullptr || ntok > 0));
     if (rows == 0) return 0;
     k_layernorm<<<dim3((rows + 15) / 16), dim3(256), 0, cf_s(stream)>>>(x, w, b, pos, y, rows, dim, ntok > 0 ? ntok : 1, eps);
@@ -192,6 +194,7 @@ int cf_layernorm(const float* x, const float* w, const float* b, const float* po
 }
 
 int cf_attention(const float* qkv, float* out, int B, int N, int dh, float scale, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(qkv && out && B >= 0 && N > 0 && dh > 0);
     const size_t lds = (size_t)(N * 3 * dh + N * N) * sizeof(float);
     if (lds > 64 * 1024) { cf_set_error("cf_attention: N=%d dh=%d needs %zu B of LDS", N, dh, lds); return CF_ERR_UNSUPPORTED; }
@@ -203,6 +206,7 @@ int cf_attention(const float* qkv, float* out, int B, int N, int dh, float scale
 
 int cf_patchify(const float* src, float* dst, int B, int C, int H, int W, int p1, int p2, int64_t img_bstride,
                 int inverse, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(src && dst && B >= 0 && C > 0 && H > 0 && W > 0 && p1 > 0 && p2 > 0 && H % p1 == 0 && W % p2 == 0);
     const int64_t total = (int64_t)B * C * H * W;
     if (total == 0) return 0;

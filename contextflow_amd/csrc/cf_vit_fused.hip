@@ -340,6 +340,7 @@ int cf_vit_prepare(const float* flat_params, void* ws, int patch_dim, int dim, i
 
 int cf_vit_coupling(const float* x, float* z, float* ldj, const void* ws, const float* pos, int B, int C, int H, int W,
                     int p1, int p2, int dim, int depth, int64_t x_bstride, int inverse, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && z && ws && pos && B >= 0 && (inverse || ldj) && x_bstride >= (int64_t)C * H * W);
     if (!vit_ok(C, H, W, p1, p2, dim, 64, 1)) {
         cf_set_error("cf_vit_coupling: geometry C=%d H=%d W=%d p=(%d,%d) dim=%d unsupported", C, H, W, p1, p2, dim);

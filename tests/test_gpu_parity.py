@@ -343,3 +343,32 @@ def test_sample_shapes_and_prior_consistency(L, name):
     close(model.dist.log_prob(z), lp, tol=1e-6)
     # mixture 1 must explain its own samples better than the other class-mixtures do, on average
     assert int(lp.mean(0).argmax()) == 1
+
+
+# ------------------------------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("name", ["cifar10", "mnist", "smap"])
+def test_edge_batches_and_layouts(L, name):
+    """Empty batch, single sample, ragged sizes, non-contiguous and fp64 inputs — fused plan vs the oracle."""
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e(name)
+    model = build_model(name, params)
+    C, H, W = fo.CONFIGS[name][0]
+    g = torch.Generator().manual_seed(9)
+    # empty batch: shape-correct, no launch failures
+    set_noise(model, None, [])
+    z, logp = model(torch.zeros(0, C, H, W, device=DEV))
+    assert tuple(logp.shape) == (0, M) and z.shape[0] == 0
+    for B in (1, 3, 17):
+        x = torch.rand(B, C, H, W, generator=g) if name == "smap" else torch.randint(0, 256, (B, C, H, W), generator=g).float()
+        u = torch.rand(B, C, H, W, generator=g) if name != "smap" else None
+        eps = [torch.randn(B, 1, H, W, generator=g)]
+        _, ref = fo.flow_forward(ops, params, x, u, eps)
+        set_noise(model, u, eps)
+        _, logp = model(x.to(DEV))
+        assert (bpd(logp.cpu(), name) - bpd(ref, name)).abs().max() < BPD_TOL, B
+        # same values through a non-contiguous fp64 view
+        xx = x.double().to(DEV).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        assert not xx.is_contiguous() or B == 1 or C == 1
+        set_noise(model, u, eps)
+        _, logp2 = model(xx)
+        assert (logp2 - logp).abs().max().item() == 0.0
