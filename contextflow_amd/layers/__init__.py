@@ -17,6 +17,7 @@ from .distributions import StandardNormal, GaussianMixtureDistribution, UniformD
 from .splitprior import SplitPrior
 from .flowsequential import FlowSequential, FlowInvSequential
 from .conv1x1 import Conv1x1, FC
+from .activations import FlowActivationLayer, SplineActivation
 from .actnorm import ActNorm, ActNormFC
 from .squeeze import Squeeze, UnSqueeze
 from .transforms import LogitTransform

@@ -21,6 +21,5 @@ VariationalCatDequantization = _stub("VariationalCatDequantization", "specialist
 ArgmaxCatDequantization = _stub("ArgmaxCatDequantization", "specialist context encoders")
 EyeSampling = _stub("EyeSampling", "specialist context encoders")
 ProbSampling = _stub("ProbSampling", "specialist context encoders")
-SplineActivation = _stub("SplineActivation", "activation layers are disabled in every config (model.py:137)")
 SmoothLeakyRelu = _stub("SmoothLeakyRelu", "activation layers are disabled in every config")
 LearnableLeakyRelu = _stub("LearnableLeakyRelu", "activation layers are disabled in every config")

@@ -154,6 +154,17 @@ int cf_vit_prepare(const float* flat_params, void* ws, int patch_dim, int dim, i
 int cf_vit_coupling(const float* x, float* z, float* ldj, const void* ws, const float* pos, int B, int C, int H, int W,
                     int p1, int p2, int dim, int depth, int64_t x_bstride, int inverse, cf_stream_t stream);
 
+/* ---- SplineActivation: monotone rational-quadratic spline, linear tails (layers/activations.py:120-211,
+ * layers/splines/rational_quadratic.py:21-176) ----------------------------------------------------- */
+/* knot tables: P parameter sets (1 = shared weights, C*H*W = individual_weights) of K bins;
+ * uw, uh: (P,K), ud: (P,K-1); table: cf_spline_table_floats(P,K) floats.                               */
+int64_t cf_spline_table_floats(int P, int K);
+int cf_spline_prepare(const float* uw, const float* uh, const float* ud, float* table, int P, int K, float tail_bound,
+                      cf_stream_t stream);
+/* inverse=0: y = spline(x), ldj[b] = sum log|dy/dx| ; inverse=1: y = spline^-1(x).  x,y: (B,N) dense.  */
+int cf_spline(const float* x, const float* table, float* y, float* ldj, int B, int N, int P, int K, float tail_bound,
+              int inverse, cf_stream_t stream);
+
 /* ---- log-det bookkeeping (layers/flowsequential.py:18-27) --------------------------------------- */
 /* out[b,m] = ldM[b,m] + ld1[b]                                                                      */
 int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream);

@@ -256,6 +256,69 @@ def transcoupling_inv(z, p, prefix, sz, patch):
     return coupling_apply_inv(z, vit_net(z[:, : z.shape[1] // 2], p, prefix, sz, patch))
 
 
+# ---- rational-quadratic spline activation (activations.py:120-211, splines/rational_quadratic.py) ----
+def rq_spline_tables(uw, uh, ud, tail_bound, min_w=1e-3, min_h=1e-3, min_d=1e-3):
+    """Knot tables (cumwidths, cumheights, derivatives), each (..., K+1).  rational_quadratic.py:36-48,98-118:
+    the (K-1) inner derivative parameters are zero-padded to K+1 and the constant log(exp(1-min_d)-1) is added
+    to ALL of them, so the two boundary derivatives are exactly 1 (linear tails)."""
+    K = uw.shape[-1]
+    const = math.log(math.exp(1 - min_d) - 1)
+    ud = F.pad(ud, (1, 1)) + const
+
+    def knots(u, lo, hi, m):
+        v = m + (1 - m * K) * torch.softmax(u, dim=-1)
+        c = F.pad(torch.cumsum(v, dim=-1), (1, 0))
+        c = (hi - lo) * c + lo
+        c[..., 0], c[..., -1] = lo, hi
+        return c
+
+    return knots(uw, -tail_bound, tail_bound, min_w), knots(uh, -tail_bound, tail_bound, min_h), min_d + F.softplus(ud)
+
+
+def rq_spline(x, uw, uh, ud, tail_bound=10.0, inverse=False):
+    """Elementwise spline with linear tails; parameters broadcast against x with a trailing knot axis.
+    Returns (y, logabsdet) with logabsdet = 0 and y = x outside [-tail_bound, tail_bound]."""
+    cw, ch, dv = rq_spline_tables(uw, uh, ud, tail_bound)
+    cw, ch, dv = (t.expand(x.shape + (t.shape[-1],)) for t in (cw, ch, dv))
+    K = cw.shape[-1] - 1
+    inside = (x >= -tail_bound) & (x <= tail_bound)
+    loc = (ch if inverse else cw).clone()
+    loc[..., -1] += 1e-6                                               # searchsorted eps (rational_quadratic.py:13-18)
+    idx = ((x[..., None] >= loc).sum(-1) - 1).clamp(0, K - 1)[..., None]
+    g = lambda t: t.gather(-1, idx)[..., 0]
+    w0, h0 = g(cw), g(ch)
+    w = g(cw[..., 1:]) - w0
+    h = g(ch[..., 1:]) - h0
+    d0, d1 = g(dv), g(dv[..., 1:])
+    delta = h / w
+    if inverse:
+        a = (x - h0) * (d0 + d1 - 2 * delta) + h * (delta - d0)
+        b = h * d0 - (x - h0) * (d0 + d1 - 2 * delta)
+        c = -delta * (x - h0)
+        root = (2 * c) / (-b - torch.sqrt(b * b - 4 * a * c))
+        y = root * w + w0
+        th = root
+    else:
+        th = (x - w0) / w
+        y = h0 + h * (delta * th * th + d0 * th * (1 - th)) / (delta + (d0 + d1 - 2 * delta) * th * (1 - th))
+    den = delta + (d0 + d1 - 2 * delta) * th * (1 - th)
+    lad = torch.log(delta * delta * (d1 * th * th + 2 * delta * th * (1 - th) + d0 * (1 - th) ** 2)) - 2 * torch.log(den)
+    if inverse:
+        lad = -lad
+    return torch.where(inside, y, x), torch.where(inside, lad, torch.zeros_like(lad))
+
+
+def spline_activation_fwd(x, uw, uh, ud, tail_bound=10.0):
+    """SplineActivation.forward (activations.py:166-180): (act, ldj (B,)).  uw/uh: (K,) or (1,C,H,W,K)."""
+    y, lad = rq_spline(x, uw, uh, ud, tail_bound, False)
+    return y, lad.flatten(1).sum(-1)
+
+
+def spline_activation_inv(y, uw, uh, ud, tail_bound=10.0):
+    """SplineActivation.reverse (activations.py:182-194)."""
+    return rq_spline(y, uw, uh, ud, tail_bound, True)[0]
+
+
 # ---- prior ------------------------------------------------------------------------------
 def gmm_logprob(x, mG, sG, wG, chunk=64):
     """gaussian.py:138-161 (context-free): for each class-mixture m, logsumexp over K diagonal

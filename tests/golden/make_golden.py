@@ -285,6 +285,16 @@ def unit_layers():
             z, ldj = m(x)
             put(tag, x=x, z=z, ldj=ldj, h=m.NN(x[:, :in_sz[0] // 2]), xrec=m.reverse(z), in_sz=in_sz, p=p)
             sd(tag, m)
+        # SplineActivation (RQ spline, linear tails at +-10): shared and per-position knots, inputs inside and outside
+        for tag, indiv in (("spline_shared", False), ("spline_indiv", True)):
+            m = L.SplineActivation((3, 4, 5), n_bins=5, tail_bound=10., individual_weights=indiv)
+            for prm in m.parameters():
+                prm.mul_(60.0)                                 # default init (0.01 * randn) is almost the identity
+            x = 6.0 * torch.randn(4, 3, 4, 5)
+            x[0, 0, 0, :3] = torch.tensor([-10.0, 10.0, 0.0])  # exact knots / bounds
+            z, ldj = m(x)
+            put(tag, x=x, z=z, ldj=ldj, xrec=m.reverse(z))
+            sd(tag, m)
     np.savez(os.path.join(HERE, "unit_layers.npz"), **fx)
     print("unit_layers: %d arrays" % len(fx))
 

@@ -303,6 +303,26 @@ def test_abi_errors(L):
         L.Squeeze((2, 2))(torch.zeros(1, 1, 2, 2))           # CPU tensor: no fallback
 
 
+@pytest.mark.parametrize("tag,indiv", [("spline_shared", False), ("spline_indiv", True)])
+def test_spline_activation(L, tag, indiv):
+    t, sd = unit(tag)
+    m = L.SplineActivation((3, 4, 5), n_bins=5, tail_bound=10., individual_weights=indiv)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    z, ldj = m(t["x"].to(DEV))
+    close(z, t["z"]); close(ldj, t["ldj"])
+    close(m.reverse(t["z"].to(DEV)), t["xrec"])
+    close(m.reverse(z), t["x"], tol=2e-5)
+    close(m.logdet(t["x"].to(DEV)), t["ldj"])
+    # full size, size-independent properties: round trip, monotone, identity outside the tails
+    g = torch.Generator().manual_seed(2)
+    x = (8.0 * torch.randn(4096, 3, 4, 5, generator=g)).to(DEV)
+    z, ldj = m(x)
+    close(m.reverse(z), x, tol=5e-5)
+    out = x.abs() > 10.0
+    assert out.any() and torch.equal(z[out], x[out]) and torch.isfinite(ldj).all()
+
+
 # ------------------------------------------------------------------------------------------ sampling direction
 def test_inverse_chain_mnist_golden(L):
     """FlowSequential.sample's layer chain (flowsequential.py:32-39) on the reference's own z -> x vectors."""

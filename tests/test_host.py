@@ -103,6 +103,8 @@ def test_specialist_and_offpath_names_raise():
         L.Conv1x1((4, 2, 2), context_net=object())
     with pytest.raises(NotImplementedError):
         L.MaskedCoupling(4)
+    assert set(L.SplineActivation((2, 2, 2), individual_weights=True).state_dict()) == {
+        "unnormalized_widths", "unnormalized_heights", "unnormalized_derivatives"}
     with pytest.raises(NotImplementedError):
         cfa.create_model(dict(dataset="mnist", generalist=False, num_blocks=1, block_size=1), (1, 32, 32), 10)
 

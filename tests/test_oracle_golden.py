@@ -155,3 +155,15 @@ def test_unit_transcoupling(tag):
     assert torch.allclose(z, t["z"], rtol=1e-4, atol=1e-5)
     assert torch.allclose(ldj, t["ldj"], rtol=1e-5, atol=1e-4)
     assert torch.allclose(fo.transcoupling_inv(t["z"], p, "0.", sz, patch), t["xrec"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["spline_shared", "spline_indiv"])
+def test_unit_spline_activation(tag):
+    t, sd = unit(tag)
+    uw, uh, ud = sd["unnormalized_widths"], sd["unnormalized_heights"], sd["unnormalized_derivatives"]
+    z, ldj = fo.spline_activation_fwd(t["x"], uw, uh, ud, 10.0)
+    assert torch.allclose(z, t["z"], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ldj, t["ldj"], rtol=1e-5, atol=1e-4)
+    assert torch.allclose(fo.spline_activation_inv(t["z"], uw, uh, ud, 10.0), t["xrec"], rtol=1e-5, atol=1e-5)
+    outside = t["x"].abs() > 10.0
+    assert outside.any() and torch.equal(z[outside], t["x"][outside])
