@@ -225,20 +225,180 @@ __device__ __forceinline__ void x_to_lds(const float4 (&xr)[G::C * G::PTW / 8], 
     }
 }
 
-// write one channel half of z from the LDS plane [HALF][PIX] (this wave's columns), 16 bytes per lane
-template <class G>
-__device__ __forceinline__ void z_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
-                                        int wave, int lane) {
-    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, HALF = G::HALF, C = G::C;
+// write NROWS channel rows (channels ch0 .. ch0+NROWS-1 of a (B,C,H,W) tensor) from an LDS plane [row][PIX]
+// (this wave's columns), 16 bytes per lane
+template <class G, int NROWS>
+__device__ __forceinline__ void rows_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
+                                           int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, C = G::C;
 #pragma unroll
-    for (int i = 0; i < (HALF * G::PTW + 7) / 8; ++i) {
+    for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
         const int n = i * 64 + lane;
         const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
         const int b = tb0 + col / HW;
-        if (idx < HALF && b < B)
+        if (idx < NROWS && b < B)
             *reinterpret_cast<float4*>(z + (int64_t)b * C * HW + (int64_t)(ch0 + idx) * HW + col % HW) =
                 *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
     }
+}
+template <class G>
+__device__ __forceinline__ void z_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
+                                        int wave, int lane) {
+    rows_store<G, G::HALF>(z, plane, tb0, ch0, B, wave, lane);
+}
+
+// ---- the conditioner: phases 1-3 of a step (shared by the forward and the inverse kernel) --------------
+// In: Y0 = y0 plane (this wave's columns).  Out: acc3 = NN.4 output tiles (t rows / raw rows, packed-row
+// layout of chan_of_row).  Uses the H region of LDS for h1 / h2; two workgroup barriers.
+template <class G>
+__device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW], float* __restrict__ lds,
+                                                const float* __restrict__ wsl, const int (&pix)[G::PTW],
+                                                const int (&pin)[G::PTW], int lane, int tid, float* __restrict__ dbg,
+                                                int64_t dbg_cols, int tile) {
+    constexpr int C = G::C, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
+    constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
+    float* Y0 = lds;
+    float* H1 = lds + HALF * PIX;
+    const int lk = lane >> 5;
+    // ================= phase 1: h1 = relu(NN.0 y0 + b)                      (coupling.py:26)
+    {
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B1 + rt * 32, lk);
+        dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(wsl + G::OFF_A1), Y0, pix, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + tile_row(r, lk);
+                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                }
+    }
+    __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' columns
+    if (dbg) {
+        float* d = dbg + (int64_t)C * dbg_cols;
+        for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
+    }
+
+    // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
+    {
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B2 + rt * 32, lk);
+        const float4* frags = reinterpret_cast<const float4*>(wsl + G::OFF_A2);
+        // reflect-padded source pixel of a tap, as an index into lds[] (offsets, not pointers: a pointer array
+        // loses the LDS address space and hipcc falls back to flat loads)
+        auto tap_src = [&](int tap, int (&src)[PTW]) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;              // wave-uniform
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
+                yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);       // reflect (padding_mode='reflect')
+                xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+                src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
+            }
+        };
+        if constexpr (G::PIPE == 0) {
+            // compiler-scheduled form: one tap per loop trip, all NCG groups of the tap unrolled
+            float4 a_cur[RT1], a_nxt[RT1];
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                int src[PTW];
+                tap_src(tap, src);
+#pragma unroll
+                for (int cg = 0; cg < G::NCG; ++cg) {
+                    const int g = tap * G::NCG + cg;
+                    const int gn = min(g + 1, G::NG2 - 1);
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt)
+                        a_nxt[rt] = G::ABL == 1 ? make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg) : frags[(gn * RT1 + rt) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int q = 0; q < PTW; ++q) {
+                            const float bv = G::ABL == 1 ? 0.001f * (src[q] + e) : lds[src[q] + (8 * cg + 2 * e) * PIX];
+#pragma unroll
+                            for (int rt = 0; rt < RT1; ++rt)
+                                acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), bv, acc[rt][q], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
+                }
+            }
+        } else {
+            // group g = tap*NCG + cg covers tap (dy,dx) and input channels 8cg .. 8cg+7.  The operands of group
+            // g+1 are requested before the MFMAs of group g (two register sets, loads pinned by sched_barrier);
+            // the source pixel of a tap is computed once per tap, one tap ahead.
+            GroupOps<RT1, PTW> ops[2];
+            auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+                if constexpr (G::ABL == 1) {                      // timing ablation: operands from registers only
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) o.a[rt] = make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg);
+#pragma unroll
+                    for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.b[e][q] = 0.001f * (src[q] + e);
+                    return;
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * PIX];
+            };
+            int src_cur[PTW], src_nxt[PTW];
+            tap_src(0, src_cur);
+            load(frags, src_cur, 0, ops[0]);
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                tap_src(min(tap + 1, 8), src_nxt);
+                const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
+#pragma unroll
+                for (int cg = 0; cg < G::NCG; ++cg) {                       // NCG is even: static ping-pong
+                    const float4* fn = fr + (cg + 1) * RT1 * 64;            // fragments of the next group
+                    if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
+                    else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);       // first group of the next tap
+                    __builtin_amdgcn_sched_barrier(0);
+                    group_mma<RT1, PTW>(acc, ops[cg & 1], 4);
+                }
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) src_cur[q] = src_nxt[q];
+            }
+        }
+        __syncthreads();                 // every wave has finished reading h1 (taps cross pixel tiles)
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + tile_row(r, lk);
+                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                }
+    }
+    // no barrier: phase 3 reads only this wave's own pixel columns of h2
+    if (dbg) {
+        __syncthreads();
+        float* d = dbg + (int64_t)(C + HID) * dbg_cols;
+        for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
+    }
+
+    // ================= phase 3: h = NN.4 h2 + b ; affine map ; log-det        (coupling.py:28,52-66)
+#pragma unroll
+    for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(wsl + G::OFF_B3 + rt * 32, lk);
+    dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(wsl + G::OFF_A3), H1, pix, lane);
 }
 
 // ---- the step kernel ---------------------------------------------------------------------------------
@@ -318,146 +478,8 @@ __global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, 
             __syncthreads();
         }
 
-        // ================= phase 1: h1 = relu(NN.0 y0 + b)                      (coupling.py:26)
-        {
-            f32x16 acc[RT1][PTW];
-#pragma unroll
-            for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-                for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B1 + rt * 32, lk);
-            dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(wsl + G::OFF_A1), Y0, pix, lane);
-#pragma unroll
-            for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-                for (int q = 0; q < PTW; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rt * 32 + tile_row(r, lk);
-                        if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
-                    }
-        }
-        __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' columns
-        if (dbg) {
-            float* d = dbg + (int64_t)C * dbg_cols;
-            for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
-        }
-
-        // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
-        {
-            f32x16 acc[RT1][PTW];
-#pragma unroll
-            for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-                for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B2 + rt * 32, lk);
-            const float4* frags = reinterpret_cast<const float4*>(wsl + G::OFF_A2);
-            // reflect-padded source pixel of a tap, as an index into lds[] (offsets, not pointers: a pointer array
-            // loses the LDS address space and hipcc falls back to flat loads)
-            auto tap_src = [&](int tap, int (&src)[PTW]) {
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;              // wave-uniform
-#pragma unroll
-                for (int q = 0; q < PTW; ++q) {
-                    int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
-                    yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);       // reflect (padding_mode='reflect')
-                    xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-                    src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
-                }
-            };
-            if constexpr (G::PIPE == 0) {
-                // compiler-scheduled form: one tap per loop trip, all NCG groups of the tap unrolled
-                float4 a_cur[RT1], a_nxt[RT1];
-#pragma unroll
-                for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
-#pragma unroll 1
-                for (int tap = 0; tap < 9; ++tap) {
-                    int src[PTW];
-                    tap_src(tap, src);
-#pragma unroll
-                    for (int cg = 0; cg < G::NCG; ++cg) {
-                        const int g = tap * G::NCG + cg;
-                        const int gn = min(g + 1, G::NG2 - 1);
-#pragma unroll
-                        for (int rt = 0; rt < RT1; ++rt)
-                            a_nxt[rt] = G::ABL == 1 ? make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg) : frags[(gn * RT1 + rt) * 64 + lane];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                            for (int q = 0; q < PTW; ++q) {
-                                const float bv = G::ABL == 1 ? 0.001f * (src[q] + e) : lds[src[q] + (8 * cg + 2 * e) * PIX];
-#pragma unroll
-                                for (int rt = 0; rt < RT1; ++rt)
-                                    acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), bv, acc[rt][q], 0, 0, 0);
-                            }
-                        }
-#pragma unroll
-                        for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
-                    }
-                }
-            } else {
-                // group g = tap*NCG + cg covers tap (dy,dx) and input channels 8cg .. 8cg+7.  The operands of group
-                // g+1 are requested before the MFMAs of group g (two register sets, loads pinned by sched_barrier);
-                // the source pixel of a tap is computed once per tap, one tap ahead.
-                GroupOps<RT1, PTW> ops[2];
-                auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
-                    if constexpr (G::ABL == 1) {                      // timing ablation: operands from registers only
-#pragma unroll
-                        for (int rt = 0; rt < RT1; ++rt) o.a[rt] = make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg);
-#pragma unroll
-                        for (int q = 0; q < PTW; ++q)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o.b[e][q] = 0.001f * (src[q] + e);
-                        return;
-                    }
-#pragma unroll
-                    for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
-#pragma unroll
-                    for (int q = 0; q < PTW; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * PIX];
-                };
-                int src_cur[PTW], src_nxt[PTW];
-                tap_src(0, src_cur);
-                load(frags, src_cur, 0, ops[0]);
-#pragma unroll 1
-                for (int tap = 0; tap < 9; ++tap) {
-                    tap_src(min(tap + 1, 8), src_nxt);
-                    const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
-#pragma unroll
-                    for (int cg = 0; cg < G::NCG; ++cg) {                       // NCG is even: static ping-pong
-                        const float4* fn = fr + (cg + 1) * RT1 * 64;            // fragments of the next group
-                        if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
-                        else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);       // first group of the next tap
-                        __builtin_amdgcn_sched_barrier(0);
-                        group_mma<RT1, PTW>(acc, ops[cg & 1], 4);
-                    }
-#pragma unroll
-                    for (int q = 0; q < PTW; ++q) src_cur[q] = src_nxt[q];
-                }
-            }
-            __syncthreads();                 // every wave has finished reading h1 (taps cross pixel tiles)
-#pragma unroll
-            for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-                for (int q = 0; q < PTW; ++q)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rt * 32 + tile_row(r, lk);
-                        if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
-                    }
-        }
-        // no barrier: phase 3 reads only this wave's own pixel columns of h2
-        if (dbg) {
-            __syncthreads();
-            float* d = dbg + (int64_t)(C + HID) * dbg_cols;
-            for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
-        }
-
-        // ================= phase 3: h = NN.4 h2 + b ; affine map ; log-det        (coupling.py:28,52-66)
         f32x16 acc3[RT03][PTW];
-#pragma unroll
-        for (int rt = 0; rt < RT03; ++rt)
-#pragma unroll
-            for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(wsl + G::OFF_B3 + rt * 32, lk);
-        dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(wsl + G::OFF_A3), H1, pix, lane);
+        conditioner_net<G>(acc3, lds, wsl, pix, pin, lane, tid, dbg, dbg_cols, tile);
 
         float lsum[PTW];
 #pragma unroll
@@ -575,6 +597,127 @@ int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, in
     return 0;
 }
 
+// ---- inverse step: x = Conv1x1^-1(ActNorm^-1(Coupling^-1(z)))   (coupling.py:68-73, actnorm.py:78, conv1x1.py:72)
+// z0 conditions the same three contractions as in the forward direction; y1 = (z1 - t) e^{-log_s}; then
+// x = (Wm^-1 diag(e^{logs})) [z0 | y1] + Wm^-1 t  as one more MFMA phase with natural channel rows.
+template <class G> struct GeoInv {
+    static constexpr int RTI = (G::C + 31) / 32;                 // row tiles of the natural-order output
+    static constexpr int OFF_WINV = 0;                           // C*C floats: Wm^-1 (scratch of the prepare step)
+    static constexpr int OFF_BI = ((G::C * G::C + 3) / 4) * 4;
+    static constexpr int OFF_AI = OFF_BI + RTI * 32;
+    static constexpr int WS_FLOATS = OFF_AI + G::NG0 * RTI * 256;
+};
+
+template <class G>
+__global__ __launch_bounds__(256) void k_step_pack_inv(const float* __restrict__ t, const float* __restrict__ logs,
+                                                       float* __restrict__ wsi) {
+    using I = GeoInv<G>;
+    const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    const float* Winv = wsi + I::OFF_WINV;
+    for (int c = gtid; c < I::RTI * 32; c += gsz) {
+        float s = 0.f;
+        if (c < G::C)
+            for (int k = 0; k < G::C; ++k) s = fmaf(Winv[c * G::C + k], t[k], s);
+        wsi[I::OFF_BI + c] = s;
+    }
+    for (int e = gtid; e < G::NG0 * I::RTI * 256; e += gsz) {
+        const int j = e & 3, lane = (e >> 2) & 63, q = e >> 8, rt = q % I::RTI, g = q / I::RTI;
+        const int row = rt * 32 + (lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+        wsi[I::OFF_AI + e] = (row < G::C && k < G::C) ? Winv[row * G::C + k] * expf(logs[k]) : 0.f;
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__ z, float* __restrict__ x,
+                                                       const float* __restrict__ ws, const float* __restrict__ wsi, int B,
+                                                       int64_t zbs) {
+    using I = GeoInv<G>;
+    constexpr int C = G::C, HW = G::HW, PIX = G::PIX, HALF = G::HALF;
+    constexpr int PTW = G::PTW, RT03 = G::RT03, NR = (HALF <= 16 ? 8 : 16);
+    constexpr int XI = C * PTW / 8;
+    extern __shared__ __align__(16) float lds[];
+    float* Y0 = lds;
+    float* H1 = lds + HALF * PIX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    const int tile = blockIdx.x, b0 = tile * G::SPW;
+    int pix[PTW], pin[PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q] % HW; }
+
+    float4 zr[XI];
+    x_load<G, false>(zr, z, zbs, tile, B, wave, lane);
+    x_to_lds<G, false>(zr, H1, wave, lane);                      // z plane: rows [0,HALF) = z0, [HALF,C) = z1
+    float z0[PTW][NR], z1[PTW][NR];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int idx = tile_row(r, lk);
+            const bool ok = idx < HALF;
+            z0[q][r] = ok ? H1[idx * PIX + pix[q]] : 0.f;
+            z1[q][r] = ok ? H1[(HALF + idx) * PIX + pix[q]] : 0.f;
+            if (ok) Y0[idx * PIX + pix[q]] = z0[q][r];           // conditioner input
+        }
+    f32x16 acc3[RT03][PTW];
+    conditioner_net<G>(acc3, lds, ws, pix, pin, lane, tid, nullptr, 0, tile);
+    // y = [z0 | (z1 - t) e^{-log_s}] as the operand plane of the last phase (this wave's columns of the H region)
+#pragma unroll
+    for (int q = 0; q < PTW; ++q)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int idx = tile_row(r, lk);
+            if (idx < HALF) {
+                const float tt = acc3[0][q][r];
+                const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
+                const float ls = 2.0f - __fdividef(4.0f, __expf(raw) + 1.0f);
+                H1[idx * PIX + pix[q]] = z0[q][r];
+                H1[(HALF + idx) * PIX + pix[q]] = (z1[q][r] - tt) * __expf(-ls);
+            }
+        }
+    f32x16 acc[I::RTI][PTW];
+#pragma unroll
+    for (int rt = 0; rt < I::RTI; ++rt)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsi + I::OFF_BI + rt * 32, lk);
+    dense_phase<G, G::KS0, G::NG0, I::RTI>(acc, reinterpret_cast<const float4*>(wsi + I::OFF_AI), H1, pix, lane);
+    // x tiles -> LDS rows [C, 2C) of the H region (own columns) -> 16-byte stores
+    float* Xp = H1 + C * PIX;
+#pragma unroll
+    for (int rt = 0; rt < I::RTI; ++rt)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 32 + tile_row(r, lk);
+                if (row < C) Xp[row * PIX + pix[q]] = acc[rt][q][r];
+            }
+    rows_store<G, C>(x, Xp, b0, 0, B, wave, lane);
+}
+
+template <class G>
+int launch_prepare_inv(const float* Wm, const float* t, const float* logs, float* wsi, hipStream_t s) {
+    using I = GeoInv<G>;
+    int rc = cf_slogdet_inverse(Wm, G::C, wsi + I::WS_FLOATS, wsi + I::OFF_WINV, (cf_stream_t)s);   // log|det| lands past the tables
+    if (rc) return rc;
+    k_step_pack_inv<G><<<dim3(16), dim3(256), 0, s>>>(t, logs, wsi);
+    return 0;
+}
+
+template <class G>
+int launch_step_inv(const float* z, float* x, const float* ws, const float* wsi, int B, int64_t zbs, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
+    if (lds_bytes > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step_inv<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("cf_flow_step_inv: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
+    k_flow_step_inv<G><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(z, x, ws, wsi, B, zbs);
+    return 0;
+}
+
 int shape_id(int C, int H, int W) {
     if (C == 8 && H == 16 && W == 16) return 0;
     if (C == 16 && H == 16 && W == 16) return 1;
@@ -614,6 +757,53 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, con
         case 2: rc = launch_prepare<G32>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
         case 3: rc = launch_prepare<G64>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
         default: cf_set_error("cf_flow_step_prepare: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int64_t cf_flow_step_inv_ws_bytes(int C, int H, int W) {
+    switch (shape_id(C, H, W)) {
+        case 0: return (int64_t)(GeoInv<G8>::WS_FLOATS + 4) * 4;
+        case 1: return (int64_t)(GeoInv<G16>::WS_FLOATS + 4) * 4;
+        case 2: return (int64_t)(GeoInv<G32>::WS_FLOATS + 4) * 4;
+        case 3: return (int64_t)(GeoInv<G64>::WS_FLOATS + 4) * 4;
+    }
+    return 0;
+}
+
+int cf_flow_step_inv_prepare(const float* Wm, const float* t, const float* logs, void* wsi, int C, int H, int W,
+                             cf_stream_t stream) {
+    CF_REQUIRE(Wm && t && logs && wsi && (reinterpret_cast<uintptr_t>(wsi) & 15) == 0);
+    int rc;
+    float* w = (float*)wsi;
+    switch (shape_id(C, H, W)) {
+        case 0: rc = launch_prepare_inv<G8>(Wm, t, logs, w, cf_s(stream)); break;
+        case 1: rc = launch_prepare_inv<G16>(Wm, t, logs, w, cf_s(stream)); break;
+        case 2: rc = launch_prepare_inv<G32>(Wm, t, logs, w, cf_s(stream)); break;
+        case 3: rc = launch_prepare_inv<G64>(Wm, t, logs, w, cf_s(stream)); break;
+        default: cf_set_error("cf_flow_step_inv_prepare: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, int B, int C, int H, int W,
+                     int64_t z_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
+    CF_REQUIRE(z && x && ws && wsi && B >= 0 && z_bstride >= (int64_t)C * H * W && z_bstride % 4 == 0);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(z) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    int rc;
+    const float* w = (const float*)ws;
+    const float* wi = (const float*)wsi;
+    switch (shape_id(C, H, W)) {
+        case 0: rc = launch_step_inv<G8>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        case 1: rc = launch_step_inv<G16>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        case 2: rc = launch_step_inv<G32>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        case 3: rc = launch_step_inv<G64>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        default: cf_set_error("cf_flow_step_inv: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
     CF_LAUNCH_CHECK();

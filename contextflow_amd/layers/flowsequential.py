@@ -253,11 +253,42 @@ class FlowSequential(nn.Module):
     def log_prob(self, input, context=None):
         return self.forward(input, context)[1]
 
+    def _inverse_step(self, z, conv, act, cpl):
+        """Conv1x1^-1 o ActNorm^-1 o Coupling^-1 in one MFMA kernel (cf_flow_step_inv)."""
+        z, zbs = _hip.bview(z)
+        B, C, H, W = z.shape
+        dev = z.device
+        ws = self._prepare_step(conv, act, cpl, (C, H, W), dev)
+        wsi = torch.empty(_hip.lib().cf_flow_step_inv_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+        f, pp, st = _hip.f32, _hip.p, _hip.stream()
+        _hip.call("cf_flow_step_inv_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
+                  pp(wsi), C, H, W, st)
+        x = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+        _hip.call("cf_flow_step_inv", pp(z), pp(x), pp(ws), pp(wsi), B, C, H, W, zbs, st)
+        return x
+
+    def inverse(self, z, context=None):
+        """Run every layer's `reverse` from the last to the first (the loop of flowsequential.py:35-37); groups
+        Coupling <- ActNorm <- Conv1x1 of a supported shape run as one fused kernel."""
+        _hip.require_device(z)
+        mods = self.sequence_modules
+        i = len(mods) - 1
+        with torch.no_grad():
+            while i >= 0:
+                m = mods[i]
+                if (self.fused and i >= 2 and z.dim() == 4 and isinstance(mods[i - 1], ActNorm)
+                        and mods[i - 1].is_initialized()
+                        and self._step_supported(mods[i - 2], mods[i - 1], m, tuple(z.shape[1:]))):
+                    z = self._inverse_step(z, mods[i - 2], mods[i - 1], m)
+                    i -= 3
+                else:
+                    z = m.reverse(z, context)
+                    i -= 1
+        return z
+
     def sample(self, n_samples, context=None):
         z, _ = self.dist.sample(n_samples, context)
-        for module in reversed(self.sequence_modules):
-            z = module.reverse(z, context)
-        return z
+        return self.inverse(z, context)
 
 
 class FlowInvSequential(nn.Module):

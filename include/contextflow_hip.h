@@ -122,6 +122,15 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs,
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                      int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 
+/* inverse of the fused step (coupling.py:68-73, actnorm.py:78, conv1x1.py:72): x = step^-1(z) in ONE kernel.
+ * `ws` is the forward table of cf_flow_step_prepare (the conditioner is the same); `wsi` holds
+ * Wm^-1 diag(e^{logs}) in fragment order and Wm^-1 t, built by cf_flow_step_inv_prepare.               */
+int64_t cf_flow_step_inv_ws_bytes(int C, int H, int W);
+int cf_flow_step_inv_prepare(const float* Wm, const float* t, const float* logs, void* wsi, int C, int H, int W,
+                             cf_stream_t stream);
+int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, int B, int C, int H, int W,
+                     int64_t z_bstride, cf_stream_t stream);
+
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; K <= 128.
  * act: 0 none, 1 exact (erf) GELU.   nn.Linear of patch embedding / to_qkv / to_out / FeedForward.   */

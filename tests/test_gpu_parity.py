@@ -323,6 +323,33 @@ def test_spline_activation(L, tag, indiv):
     assert out.any() and torch.equal(z[out], x[out]) and torch.isfinite(ldj).all()
 
 
+@pytest.mark.parametrize("C,H,W,B", [(16, 16, 16, 3), (32, 8, 8, 5), (64, 4, 4, 21), (8, 16, 16, 2)])
+def test_fused_inverse_step(L, C, H, W, B):
+    """cf_flow_step_inv against the oracle's layer inverses, and forward(inverse(z)) == z through the fused pair."""
+    import contextflow_amd as cfa
+    torch.manual_seed(C + B)
+    conv, act, cpl = L.Conv1x1((C, H, W)), L.ActNorm((C, H, W)), L.Coupling(C, kernel_size=(3, 3), padding=(1, 1))
+    with torch.no_grad():
+        conv.NN.add_(0.1 * torch.randn(C, C))
+        act.NN_t.copy_(0.3 * torch.randn(C)); act.NN_logs.copy_(0.2 * torch.randn(C)); act.initialized.fill_(1)
+    act._init_done = True
+    z = torch.randn(B, C, H, W)
+    p = {"0." + k: v.detach() for k, v in cpl.state_dict().items()}
+    ref = fo.coupling_inv(z, p, "0.", (1, 1))
+    ref = fo.actnorm_inv(ref, act.NN_t.detach(), act.NN_logs.detach())
+    ref = fo.conv1x1_inv(ref, conv.NN.detach())
+    flow = cfa.layers.FlowSequential(L.GaussianMixtureDistribution(size=(C, H, W), mixtures=2, components=8), conv, act, cpl).to(DEV)
+    x = flow.inverse(z.to(DEV))
+    close(x, ref, tol=3e-5)
+    flow.fused = False
+    close(flow.inverse(z.to(DEV)), ref, tol=3e-5)           # layer-by-layer inverse agrees too
+    flow.fused = True
+    zz = x
+    for m in flow.sequence_modules:
+        zz, _ = m(zz)
+    close(zz, z, tol=5e-5)
+
+
 # ------------------------------------------------------------------------------------------ sampling direction
 def test_inverse_chain_mnist_golden(L):
     """FlowSequential.sample's layer chain (flowsequential.py:32-39) on the reference's own z -> x vectors."""
@@ -337,12 +364,12 @@ def test_inverse_chain_mnist_golden(L):
         if k.startswith("param:"):
             params[k[6:]] = torch.from_numpy(v)
     model = build_model("mnist", params)
-    h = torch.from_numpy(fx["z"]).to(DEV)
-    for m in reversed(model.sequence_modules):
-        h = m.reverse(h, None)
     ref = torch.from_numpy(fx["x"])
-    # the final floor() makes the output integer valued: only exact-boundary cases may flip by one
-    assert (h.cpu() - ref).abs().max() <= 1.0 and (h.cpu() != ref).float().mean() < 2e-3
+    for fused in (False, True):                       # per-layer reverse kernels, then the fused inverse steps
+        model.fused = fused
+        h = model.inverse(torch.from_numpy(fx["z"]).to(DEV))
+        # the final floor() makes the output integer valued: only exact-boundary cases may flip by one
+        assert (h.cpu() - ref).abs().max() <= 1.0 and (h.cpu() != ref).float().mean() < 2e-3, fused
 
 
 @pytest.mark.parametrize("name", ["mnist", "cifar10"])
