@@ -260,6 +260,26 @@ int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, 
     return 0;
 }
 
+// q[b, mk] = sum_d (x[b,d]*a[mk,d] + bm[mk,d])^2 — the quadratic forms alone (used by the backward pass to rebuild
+// the component responsibilities)
+int cf_gmm_quad(const float* x, const float* a, const float* bm, float* q, int B, int M, int K, int D, int64_t x_bstride,
+                cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
+    CF_REQUIRE(x && a && bm && q && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
+    const int MK = M * K;
+    const bool small = MK <= 16;
+    const bool vec = (D % 4 == 0) && (x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(bm) & 15) == 0);
+    const int mkb = small ? 16 : 80;
+    dim3 grid((B + TB - 1) / TB, (MK + mkb - 1) / mkb, 1);
+#define CF_GO(MKT, V) k_gmm_logprob<MKT, V, true><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, bm, nullptr, nullptr, q, B, MK, K, D, D, x_bstride, 0, M)
+    if (small) { if (vec) CF_GO(1, true); else CF_GO(1, false); }
+    else       { if (vec) CF_GO(5, true); else CF_GO(5, false); }
+#undef CF_GO
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
 int cf_gmm_sample(const float* mG, const float* sG, const int64_t* rows, const float* eps, float* out, int N, int D,
                   cf_stream_t stream) {
     if (N == 0) return 0;                       // empty batch: nothing to do (pointers may be null)

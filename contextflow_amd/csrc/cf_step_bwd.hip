@@ -1,0 +1,474 @@
+// Backward of one flow step (Conv1x1 -> ActNorm -> Coupling) for the training step that follows the density
+// path (contextflow/experiment_cl.py:130-136 `cost.backward()`), as ONE gfx950 kernel per step.
+//
+// Per tile the kernel re-runs the forward in LDS (same code as cf_step.hip: invertible flows make storing the
+// conv intermediates unnecessary), then walks the data-gradient chain on the fp32 matrix cores with
+// TRANSPOSED weight fragments:
+//     g_h   = [ g_z1 ,  (g_z1 * y1 * e^{ls} + g_ld) * (1 - (ls/2)^2) ]           affine map + log-det
+//     g_h2  = (NN.4^T g_h)            * [h2 > 0]
+//     g_h1  = (NN.2^T (*) g_h2)       * [h1 > 0]     3x3 transposed conv = adjoint of the reflect-padded gather
+//     g_y0  =  NN.0^T g_h1 + g_z0 ;   g_y1 = g_z1 * e^{ls}
+//     g_x   = (e^{-logs} Wm)^T g_y
+// and writes, next to g_x, the operand planes the weight gradients contract over (y0, h1, h2, g_h, g_h2, g_h1,
+// g_y).  The weight gradients themselves are plain GEMMs over (batch x pixels) and are left to rocBLAS through
+// torch (contextflow_amd/layers/autograd.py).  ReLU masks are 16-bit lane masks in registers.
+#include "cf_step_common.h"
+
+namespace {
+
+template <class G> struct GeoBwd {
+    static constexpr int RTI = (G::C + 31) / 32;                  // natural-order C rows
+    static constexpr int OFF_A3T = 0;                             // rows HID, K = C        g_h2 = NN.4^T g_h
+    static constexpr int OFF_A2T = OFF_A3T + G::NG0 * G::RT1 * 256;   // per tap: rows ci, K = co
+    static constexpr int OFF_A1T = OFF_A2T + G::NG2 * G::RT1 * 256;   // rows HALF (1 tile), K = HID
+    static constexpr int OFF_A0T = OFF_A1T + G::NG3 * 1 * 256;        // rows C, K = C          g_x = W'^T g_y
+    static constexpr int WS_FLOATS = OFF_A0T + G::NG0 * RTI * 256;
+};
+
+template <class G>
+__global__ __launch_bounds__(256) void k_step_pack_bwd(const float* __restrict__ Wm, const float* __restrict__ logs,
+                                                       const float* __restrict__ w1, const float* __restrict__ w2,
+                                                       const float* __restrict__ w3, float* __restrict__ wsb) {
+    using Bw = GeoBwd<G>;
+    const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    auto split = [](int e, int RT, int& g, int& rt, int& lane, int& j) {
+        j = e & 3; lane = (e >> 2) & 63; const int q = e >> 8; rt = q % RT; g = q / RT;
+    };
+    int g, rt, lane, j;
+    for (int e = gtid; e < G::NG0 * G::RT1 * 256; e += gsz) {               // A3T[j_hid][ch] = w3[ch][j_hid]
+        split(e, G::RT1, g, rt, lane, j);
+        const int row = rt * 32 + (lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+        wsb[Bw::OFF_A3T + e] = (row < G::HID && k < G::C) ? w3[k * G::HID + row] : 0.f;
+    }
+    for (int e = gtid; e < G::NG2 * G::RT1 * 256; e += gsz) {               // A2T[tap][ci][co] = w2[co][ci][tap]
+        split(e, G::RT1, g, rt, lane, j);
+        const int row = rt * 32 + (lane & 31);
+        const int tap = g / G::NCG, co = 8 * (g % G::NCG) + 2 * j + (lane >> 5);
+        wsb[Bw::OFF_A2T + e] = (row < G::HID) ? w2[(co * G::HID + row) * 9 + tap] : 0.f;
+    }
+    for (int e = gtid; e < G::NG3 * 256; e += gsz) {                         // A1T[c][j_hid] = w1[j_hid][c]
+        split(e, 1, g, rt, lane, j);
+        const int row = lane & 31, k = 2 * (4 * g + j) + (lane >> 5);
+        wsb[Bw::OFF_A1T + e] = (row < G::HALF && k < G::HID) ? w1[k * G::HALF + row] : 0.f;
+    }
+    for (int e = gtid; e < G::NG0 * Bw::RTI * 256; e += gsz) {               // A0T[k_in][c] = e^{-logs[c]} Wm[c][k_in]
+        split(e, Bw::RTI, g, rt, lane, j);
+        const int row = rt * 32 + (lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+        wsb[Bw::OFF_A0T + e] = (row < G::C && k < G::C) ? expf(-logs[k]) * Wm[k * G::C + row] : 0.f;
+    }
+}
+
+// rows_store for a target tensor with CT channels per sample
+template <class G, int NROWS, int CT>
+__device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const float* __restrict__ plane, int tb0, int B,
+                                             int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX;
+#pragma unroll
+    for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
+        const int n = i * 64 + lane;
+        const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+        const int b = tb0 + col / HW;
+        if (idx < NROWS && b < B)
+            *reinterpret_cast<float4*>(dst + (int64_t)b * CT * HW + (int64_t)idx * HW + col % HW) =
+                *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
+    }
+}
+
+template <class G, int RT>
+__device__ __forceinline__ void tiles_to_plane(const f32x16 (&acc)[RT][G::PTW], float* __restrict__ plane, int nrows,
+                                               const int (&pix)[G::PTW], int lk) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < G::PTW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 32 + tile_row(r, lk);
+                if (row < nrows) plane[row * G::PIX + pix[q]] = acc[rt][q][r];
+            }
+}
+
+template <class G, bool SQ>
+__global__ __launch_bounds__(256) void k_flow_step_bwd(
+    const float* __restrict__ x, const float* __restrict__ gz, const float* __restrict__ gld,
+    const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ gx,
+    float* __restrict__ s_y0, float* __restrict__ s_h1, float* __restrict__ s_h2, float* __restrict__ s_gh,
+    float* __restrict__ s_gh2, float* __restrict__ s_gh1, float* __restrict__ s_gy, int B, int64_t xbs) {
+    using Bw = GeoBwd<G>;
+    constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
+    constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1, NR = (HALF <= 16 ? 8 : 16);
+    constexpr int XI = C * PTW / 8;
+    extern __shared__ __align__(16) float lds[];
+    float* Y0 = lds;                    // [HALF][PIX]
+    float* H1 = lds + HALF * PIX;       // [HID][PIX]  (HID = 2C rows)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    const int tile = blockIdx.x, b0 = tile * G::SPW;
+    int pix[PTW], pin[PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q] % HW; }
+
+    // ---------------------------------------------------------------- forward recompute
+    float y1[PTW][NR];
+    {
+        float4 xr[XI];
+        x_load<G, SQ>(xr, x, xbs, tile, B, wave, lane);
+        x_to_lds<G, SQ>(xr, H1, wave, lane);
+        f32x16 acc0[RT03][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc0[rt][q] = bias_tile(ws + G::OFF_B0 + rt * 32, lk);
+        dense_phase<G, G::KS0, G::NG0, RT03>(acc0, reinterpret_cast<const float4*>(ws + G::OFF_A0), H1, pix, lane);
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int idx = tile_row(r, lk);
+                if (idx < HALF) Y0[idx * PIX + pix[q]] = acc0[0][q][r];
+                y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
+            }
+        rows_store_t<G, HALF, HALF>(s_y0, Y0, b0, B, wave, lane);
+    }
+    unsigned m1[RT1][PTW], m2[RT1][PTW];       // ReLU masks of h1 / h2, one bit per accumulator register
+    {   // phase 1
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B1 + rt * 32, lk);
+        dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(ws + G::OFF_A1), Y0, pix, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                unsigned m = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaxf(acc[rt][q][r], 0.f);
+                    m |= (acc[rt][q][r] > 0.f ? 1u : 0u) << r;
+                    acc[rt][q][r] = v;
+                }
+                m1[rt][q] = m;
+            }
+        tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);
+        rows_store_t<G, HID, HID>(s_h1, H1, b0, B, wave, lane);
+    }
+    __syncthreads();                     // h1 complete (taps cross waves)
+    {   // phase 2 (compiler-scheduled form; the backward is not yet tuned per shape)
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B2 + rt * 32, lk);
+        const float4* frags = reinterpret_cast<const float4*>(ws + G::OFF_A2);
+        GroupOps<RT1, PTW> ops[2];
+        auto tap_src = [&](int tap, int (&src)[PTW]) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
+                yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+                xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+                src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
+            }
+        };
+        auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * PIX];
+        };
+        int src_cur[PTW], src_nxt[PTW];
+        tap_src(0, src_cur);
+        load(frags, src_cur, 0, ops[0]);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            tap_src(min(tap + 1, 8), src_nxt);
+            const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
+#pragma unroll
+            for (int cg = 0; cg < G::NCG; ++cg) {
+                const float4* fn = fr + (cg + 1) * RT1 * 64;
+                if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
+                else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                group_mma<RT1, PTW>(acc, ops[cg & 1], 4);
+            }
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) src_cur[q] = src_nxt[q];
+        }
+        __syncthreads();                 // everyone done reading h1
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                unsigned m = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    m |= (acc[rt][q][r] > 0.f ? 1u : 0u) << r;
+                    acc[rt][q][r] = fmaxf(acc[rt][q][r], 0.f);
+                }
+                m2[rt][q] = m;
+            }
+        tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);
+        rows_store_t<G, HID, HID>(s_h2, H1, b0, B, wave, lane);
+    }
+    // phase 3 -> t, raw
+    float ls[PTW][NR];
+    {
+        f32x16 acc3[RT03][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(ws + G::OFF_B3 + rt * 32, lk);
+        dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(ws + G::OFF_A3), H1, pix, lane);
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
+                ls[q][r] = 2.0f - __fdividef(4.0f, __expf(raw) + 1.0f);
+            }
+    }
+
+    // ---------------------------------------------------------------- backward
+    // upstream gradient g_z -> LDS plane (H rows [0,C), own columns: h2 there is dead for this wave)
+    float gz0[PTW][NR], gy1[PTW][NR];
+    {
+        float4 gr[XI];
+        x_load<G, false>(gr, gz, (int64_t)C * HW, tile, B, wave, lane);
+        x_to_lds<G, false>(gr, H1, wave, lane);
+        float* GH = H1 + C * PIX;                     // g_h plane: rows [0,HALF) = g_t, [HALF,C) = g_raw
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) {
+            const float gl = gld[min(b0 + pix[q] / HW, B - 1)];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int idx = tile_row(r, lk);
+                if (idx < HALF) {
+                    const float g0 = H1[idx * PIX + pix[q]], g1 = H1[(HALF + idx) * PIX + pix[q]];
+                    const float e = __expf(ls[q][r]);
+                    gz0[q][r] = g0;
+                    gy1[q][r] = g1 * e;                                              // d z1 / d y1
+                    const float gls = g1 * y1[q][r] * e + gl;                        // d/d log_s (+ the log-det path)
+                    GH[idx * PIX + pix[q]] = g1;                                     // d z1 / d t
+                    GH[(HALF + idx) * PIX + pix[q]] = gls * (1.0f - 0.25f * ls[q][r] * ls[q][r]);   // d log_s / d raw
+                } else { gz0[q][r] = 0.f; gy1[q][r] = 0.f; }
+            }
+        }
+        rows_store_t<G, C, C>(s_gh, GH, b0, B, wave, lane);
+        // g_h2 = (NN.4^T g_h) * [h2 > 0]
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][q][r] = 0.f;
+        dense_phase<G, G::KS0, G::NG0, RT1>(acc, reinterpret_cast<const float4*>(wsb + Bw::OFF_A3T), GH, pix, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!((m2[rt][q] >> r) & 1u)) acc[rt][q][r] = 0.f;
+        tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);       // g_h2 plane over the whole H region (own columns)
+        rows_store_t<G, HID, HID>(s_gh2, H1, b0, B, wave, lane);
+    }
+    __syncthreads();                     // g_h2 complete: the transposed 3x3 reads neighbouring waves' columns
+    {   // g_h1 = (NN.2^T (*) g_h2) * [h1 > 0]: adjoint of the reflect-padded gather.  Output pixel p of tap (dy,dx)
+        // collects every o with reflect(o + d) = p: o = p - d, plus the border pixel whose reflection lands on p.
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][q][r] = 0.f;
+        const float4* frags = reinterpret_cast<const float4*>(wsb + Bw::OFF_A2T);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int off[PTW][4];
+            float wgt[PTW][4];
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                const int py = pin[q] / W, px = pin[q] % W;
+                const int ym = py - dy, xm = px - dx;                       // main source
+                const bool ymv = ym >= 0 && ym < H, xmv = xm >= 0 && xm < W;
+                const int ye = (dy == -1 && py == 1) ? 0 : ((dy == 1 && py == H - 2) ? H - 1 : -1);   // reflected border source
+                const int xe = (dx == -1 && px == 1) ? 0 : ((dx == 1 && px == W - 2) ? W - 1 : -1);
+                const int base = HALF * PIX + (pix[q] - pin[q]) + lk * PIX;
+                const int ys[2] = {ymv ? ym : 0, ye >= 0 ? ye : 0}, xs[2] = {xmv ? xm : 0, xe >= 0 ? xe : 0};
+                const bool yv[2] = {ymv, ye >= 0}, xv[2] = {xmv, xe >= 0};
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        off[q][2 * a + b] = base + ys[a] * W + xs[b];
+                        wgt[q][2 * a + b] = (yv[a] && xv[b]) ? 1.f : 0.f;
+                    }
+            }
+            const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
+#pragma unroll
+            for (int cg = 0; cg < G::NCG; ++cg) {
+                GroupOps<RT1, PTW> o;
+#pragma unroll
+                for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[(cg * RT1 + rt) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ko = (8 * cg + 2 * e) * PIX;
+                        float v = wgt[q][0] * lds[off[q][0] + ko];
+                        v = fmaf(wgt[q][1], lds[off[q][1] + ko], v);
+                        v = fmaf(wgt[q][2], lds[off[q][2] + ko], v);
+                        v = fmaf(wgt[q][3], lds[off[q][3] + ko], v);
+                        o.b[e][q] = v;
+                    }
+                group_mma<RT1, PTW>(acc, o, 4);
+            }
+        }
+        __syncthreads();                 // everyone done reading g_h2
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!((m1[rt][q] >> r) & 1u)) acc[rt][q][r] = 0.f;
+        tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);       // g_h1 plane
+        rows_store_t<G, HID, HID>(s_gh1, H1, b0, B, wave, lane);
+    }
+    {   // g_y0 = NN.0^T g_h1 + g_z0 ;  g_y plane = [g_y0 | g_y1] -> Y0 (HALF rows) + ... stored as C rows in the H region
+        f32x16 acc[1][PTW];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][q][r] = 0.f;
+        dense_phase<G, G::KS3, G::NG3, 1>(acc, reinterpret_cast<const float4*>(wsb + Bw::OFF_A1T), H1, pix, lane);
+        // rows of this single tile are channels 0..31 in natural order: row = tile_row(r, lk) for r = 0..15
+        float* GY = H1;                                   // g_y plane rows [0,C) (g_h1 is dead for this wave now)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tile_row(r, lk);
+                if (row < HALF) {
+                    // g_z0 lives in the packed-tile register layout: its register for channel `row` is r itself when
+                    // HALF <= 16 (rows 0..15 <-> regs 0..7) and r when HALF == 32 (regs 0..15)
+                    GY[row * PIX + pix[q]] = acc[0][q][r] + gz0[q][HALF <= 16 ? (r & 7) : r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int idx = tile_row(r, lk);
+                if (idx < HALF) GY[(HALF + idx) * PIX + pix[q]] = gy1[q][r];
+            }
+        }
+        rows_store_t<G, C, C>(s_gy, GY, b0, B, wave, lane);
+        // g_x = (e^{-logs} Wm)^T g_y
+        f32x16 ax[Bw::RTI][PTW];
+#pragma unroll
+        for (int rt = 0; rt < Bw::RTI; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ax[rt][q][r] = 0.f;
+        dense_phase<G, G::KS0, G::NG0, Bw::RTI>(ax, reinterpret_cast<const float4*>(wsb + Bw::OFF_A0T), GY, pix, lane);
+        float* GX = H1 + C * PIX;
+        tiles_to_plane<G, Bw::RTI>(ax, GX, C, pix, lk);
+        rows_store_t<G, C, C>(gx, GX, b0, B, wave, lane);
+    }
+}
+
+template <class G>
+int launch_prepare_bwd(const float* Wm, const float* logs, const float* w1, const float* w2, const float* w3, float* wsb,
+                       hipStream_t s) {
+    int blocks = (GeoBwd<G>::WS_FLOATS + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    k_step_pack_bwd<G><<<dim3(blocks), dim3(256), 0, s>>>(Wm, logs, w1, w2, w3, wsb);
+    return 0;
+}
+
+template <class G, bool SQ>
+int launch_step_bwd(const float* x, const float* gz, const float* gld, const float* ws, const float* wsb, float* gx,
+                    float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy, int B,
+                    int64_t xbs, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
+    if (lds_bytes > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step_bwd<G, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("cf_flow_step_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
+    k_flow_step_bwd<G, SQ><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(
+        x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs);
+    return 0;
+}
+
+// the backward uses the smaller tiles (2 workgroups/CU at C = 64): its register footprint is larger than the forward's
+using B8 = Geo<8, 16, 16, 1, 1>;
+using B16 = Geo<16, 16, 16, 1, 1>;
+using B32 = Geo<32, 8, 8, 4, 1>;
+using B64 = Geo<64, 4, 4, 8, 1>;
+
+}  // namespace
+
+extern "C" {
+
+int64_t cf_flow_step_bwd_ws_bytes(int C, int H, int W) {
+    switch (shape_id(C, H, W)) {
+        case 0: return (int64_t)GeoBwd<B8>::WS_FLOATS * 4;
+        case 1: return (int64_t)GeoBwd<B16>::WS_FLOATS * 4;
+        case 2: return (int64_t)GeoBwd<B32>::WS_FLOATS * 4;
+        case 3: return (int64_t)GeoBwd<B64>::WS_FLOATS * 4;
+    }
+    return 0;
+}
+
+int cf_flow_step_bwd_prepare(const float* Wm, const float* logs, const float* w1, const float* w2, const float* w3,
+                             void* wsb, int C, int H, int W, cf_stream_t stream) {
+    CF_REQUIRE(Wm && logs && w1 && w2 && w3 && wsb && (reinterpret_cast<uintptr_t>(wsb) & 15) == 0);
+    float* w = (float*)wsb;
+    switch (shape_id(C, H, W)) {
+        case 0: launch_prepare_bwd<B8>(Wm, logs, w1, w2, w3, w, cf_s(stream)); break;
+        case 1: launch_prepare_bwd<B16>(Wm, logs, w1, w2, w3, w, cf_s(stream)); break;
+        case 2: launch_prepare_bwd<B32>(Wm, logs, w1, w2, w3, w, cf_s(stream)); break;
+        case 3: launch_prepare_bwd<B64>(Wm, logs, w1, w2, w3, w, cf_s(stream)); break;
+        default: cf_set_error("cf_flow_step_bwd_prepare: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
+                     float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy,
+                     int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
+    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
+    CF_REQUIRE(x && gz && gld && ws && wsb && gx && s_y0 && s_h1 && s_h2 && s_gh && s_gh2 && s_gh1 && s_gy);
+    CF_REQUIRE(x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(gz) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0);
+    const float* w = (const float*)ws;
+    const float* wb = (const float*)wsb;
+    int rc = 0;
+#define CF_BWD(G) rc = in_squeeze ? launch_step_bwd<G, true>(x, gz, gld, w, wb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream)) \
+                                  : launch_step_bwd<G, false>(x, gz, gld, w, wb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream))
+    switch (shape_id(C, H, W)) {
+        case 0: CF_BWD(B8); break;
+        case 1: CF_BWD(B16); break;
+        case 2: CF_BWD(B32); break;
+        case 3: CF_BWD(B64); break;
+        default: cf_set_error("cf_flow_step_bwd: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+#undef CF_BWD
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

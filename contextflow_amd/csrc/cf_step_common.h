@@ -1,0 +1,366 @@
+// Shared device code of the fused flow-step kernels (forward, inverse, backward): compile-time geometry,
+// MFMA operand pipeline, wave-local staging, the conditioner (phases 1-3).  Included by cf_step.hip and
+// cf_step_bwd.hip; everything lives in an anonymous namespace of the including translation unit.
+#pragma once
+#include "cf_common.h"
+#include <math.h>
+
+namespace {
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaves = 4;
+
+// ---- compile-time geometry of one supported shape ------------------------------------------------
+// PIPE_: phase-2 loop form (1 = explicit two-stage operand pipeline, 0 = compiler-scheduled per-tap loop)
+// ABL_: timing-only ablations for tools/step_bench.py (1 = phase-2 operands are constants: no LDS / L2 loads there)
+template <int C_, int H_, int W_, int SPW_, int PIPE_ = 1, int ABL_ = 0>
+struct Geo {
+    static constexpr int C = C_, H = H_, W = W_, SPW = SPW_, PIPE = PIPE_, ABL = ABL_;
+    static constexpr int HW = H * W;
+    static constexpr int PIX = SPW * HW;              // pixels per workgroup
+    static constexpr int HALF = C / 2;                // conditioner channels
+    static constexpr int HID = 2 * C;                 // hidden width of the coupling net
+    static constexpr int NPT = PIX / 32;              // 32-pixel tiles per workgroup
+    static constexpr int PTW = NPT / kWaves;          // pixel tiles per wave
+    static constexpr int HP = HALF <= 16 ? 16 : 32;   // packed rows per channel half
+    static constexpr int R03 = 2 * HP;                // packed rows of the C-channel results (y, h)
+    static constexpr int RT03 = R03 / 32;
+    static constexpr int RT1 = (HID + 31) / 32;       // row tiles of the hidden planes
+    static constexpr int R1 = RT1 * 32;
+    // k-steps (2 k per MFMA) and 4-step groups of every contraction
+    static constexpr int KS0 = C / 2, KS1 = HALF / 2, KS3 = HID / 2;
+    static constexpr int NG0 = (KS0 + 3) / 4, NG1 = (KS1 + 3) / 4, NG3 = (KS3 + 3) / 4;
+    static constexpr int NCG = HID / 8;               // groups per 3x3 tap
+    static constexpr int NG2 = 9 * NCG;
+    // workspace layout (floats)
+    static constexpr int OFF_B0 = 4, OFF_B1 = OFF_B0 + R03, OFF_B2 = OFF_B1 + R1, OFF_B3 = OFF_B2 + R1;
+    static constexpr int OFF_A0 = OFF_B3 + R03;
+    static constexpr int OFF_A1 = OFF_A0 + NG0 * RT03 * 256;
+    static constexpr int OFF_A2 = OFF_A1 + NG1 * RT1 * 256;
+    static constexpr int OFF_A3 = OFF_A2 + NG2 * RT1 * 256;
+    static constexpr int WS_FLOATS = OFF_A3 + NG3 * RT03 * 256;
+    static constexpr int LDS_FLOATS = (HALF + HID) * PIX;
+    static_assert(PIX % 128 == 0 && PTW >= 1, "workgroup must own a multiple of 128 pixels");
+    static_assert(HID % 8 == 0 && C % 4 == 0, "channel counts must fill whole k-steps");
+    static_assert((HW & (HW - 1)) == 0 && (W & (W - 1)) == 0, "power-of-two images");
+};
+
+// packed row p of a C-channel result -> channel, or -1 for a padding row.  First-half channels sit
+// in rows [0, HALF), second-half channels in rows [HP, HP + HALF): t / log_s / x1 of one channel
+// then share a lane and differ by a fixed register offset.
+template <class G> __host__ __device__ constexpr int chan_of_row(int p) {
+    return ((p % G::HP) < G::HALF) ? (p / G::HP) * G::HALF + (p % G::HP) : -1;
+}
+
+// ---- helpers -----------------------------------------------------------------------------------------
+// accumulator tile initialised with the per-row bias: row(r, lk) = (r&3) + 8*(r>>2) + 4*lk
+__device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ bias32, int lk) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(bias32 + 8 * q + 4 * lk);
+        a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+    return a;
+}
+__device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+__device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// Operands of one 4-k-step group: RT weight fragments (one 16-byte load each) and 4*PTW activation values.
+template <int RT, int PTW>
+struct GroupOps {
+    float4 a[RT];
+    float b[4][PTW];
+};
+
+template <int RT, int PTW>
+__device__ __forceinline__ void group_mma(f32x16 (&acc)[RT][PTW], const GroupOps<RT, PTW>& o, int nsteps) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (e < nsteps) {
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(o.a[rt], e), o.b[e][q], acc[rt][q], 0, 0, 0);
+        }
+    }
+}
+
+// One dense phase whose B operand is an LDS plane [k][PIX]:  acc[rt][q] += A_frag * plane
+//   KS real k-steps, NG groups of 4, RT row tiles, frags = packed A of this phase.
+// Software pipeline: the operands of group g+1 are requested BEFORE the MFMAs of group g are issued
+// (sched_barrier pins the loads there: left alone, hipcc sinks them next to their first use and every
+// group then stalls on an L2 round trip).
+template <class G, int KS, int NG, int RT>
+__device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const float4* __restrict__ frags,
+                                            const float* __restrict__ plane, const int (&pix)[G::PTW], int lane) {
+    const int lk = lane >> 5;
+    GroupOps<RT, G::PTW> ops[2];
+    auto load = [&](int g, GroupOps<RT, G::PTW>& o) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) o.a[rt] = frags[(g * RT + rt) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < G::PTW; ++q)
+                o.b[e][q] = (4 * g + e < KS) ? plane[(2 * (4 * g + e) + lk) * G::PIX + pix[q]] : 0.f;
+    };
+    load(0, ops[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) load(g + 1, ops[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        group_mma<RT, G::PTW>(acc, ops[g & 1], KS - 4 * g);
+    }
+}
+
+// ---- wave-local staging of activations with 16-byte global accesses ---------------------------------
+// A wave owns WPX = 32*PTW pixel columns.  Item n = i*64 + lane enumerates its C x WPX block of x.
+template <class G, bool SQ>
+__device__ __forceinline__ void x_load(float4 (&xr)[G::C * G::PTW / 8], const float* __restrict__ x, int64_t xbs,
+                                       int tile, int B, int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, W = G::W;
+    const int tb0 = tile * G::SPW;
+#pragma unroll
+    for (int i = 0; i < G::C * G::PTW / 8; ++i) {
+        const int n = i * 64 + lane;
+        if constexpr (!SQ) {
+            const int ch = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+            const int b = min(tb0 + col / HW, B - 1);
+            xr[i] = *reinterpret_cast<const float4*>(x + (int64_t)b * xbs + ch * HW + col % HW);
+        } else {
+            // un-squeezed row (2y+i1), 4 consecutive floats = channels (4c'+2i1, +1) of squeezed pixels (x, x+1)
+            const int cp = n / (WPX / 2), col = wave * WPX + 2 * (n % (WPX / 2));
+            const int b = min(tb0 + col / HW, B - 1);
+            const int p = col % HW, yy = p / W, xx = p % W;
+            xr[i] = *reinterpret_cast<const float4*>(x + (int64_t)b * xbs + (cp >> 1) * 4 * HW + (2 * yy + (cp & 1)) * 2 * W + 2 * xx);
+        }
+    }
+}
+
+template <class G, bool SQ>
+__device__ __forceinline__ void x_to_lds(const float4 (&xr)[G::C * G::PTW / 8], float* __restrict__ plane, int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, PIX = G::PIX;
+#pragma unroll
+    for (int i = 0; i < G::C * G::PTW / 8; ++i) {
+        const int n = i * 64 + lane;
+        if constexpr (!SQ) {
+            const int ch = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+            *reinterpret_cast<float4*>(&plane[ch * PIX + col]) = make_float4(xr[i].x, xr[i].y, xr[i].z, xr[i].w);
+        } else {
+            const int cp = n / (WPX / 2), col = wave * WPX + 2 * (n % (WPX / 2));
+            *reinterpret_cast<float2*>(&plane[(2 * cp) * PIX + col]) = make_float2(xr[i].x, xr[i].z);
+            *reinterpret_cast<float2*>(&plane[(2 * cp + 1) * PIX + col]) = make_float2(xr[i].y, xr[i].w);
+        }
+    }
+}
+
+// write NROWS channel rows (channels ch0 .. ch0+NROWS-1 of a (B,C,H,W) tensor) from an LDS plane [row][PIX]
+// (this wave's columns), 16 bytes per lane
+template <class G, int NROWS>
+__device__ __forceinline__ void rows_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
+                                           int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, C = G::C;
+#pragma unroll
+    for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
+        const int n = i * 64 + lane;
+        const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+        const int b = tb0 + col / HW;
+        if (idx < NROWS && b < B)
+            *reinterpret_cast<float4*>(z + (int64_t)b * C * HW + (int64_t)(ch0 + idx) * HW + col % HW) =
+                *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
+    }
+}
+template <class G>
+__device__ __forceinline__ void z_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
+                                        int wave, int lane) {
+    rows_store<G, G::HALF>(z, plane, tb0, ch0, B, wave, lane);
+}
+
+// ---- the conditioner: phases 1-3 of a step (shared by the forward and the inverse kernel) --------------
+// In: Y0 = y0 plane (this wave's columns).  Out: acc3 = NN.4 output tiles (t rows / raw rows, packed-row
+// layout of chan_of_row).  Uses the H region of LDS for h1 / h2; two workgroup barriers.
+template <class G>
+__device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW], float* __restrict__ lds,
+                                                const float* __restrict__ wsl, const int (&pix)[G::PTW],
+                                                const int (&pin)[G::PTW], int lane, int tid, float* __restrict__ dbg,
+                                                int64_t dbg_cols, int tile) {
+    constexpr int C = G::C, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
+    constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
+    float* Y0 = lds;
+    float* H1 = lds + HALF * PIX;
+    const int lk = lane >> 5;
+    // ================= phase 1: h1 = relu(NN.0 y0 + b)                      (coupling.py:26)
+    {
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B1 + rt * 32, lk);
+        dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(wsl + G::OFF_A1), Y0, pix, lane);
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + tile_row(r, lk);
+                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                }
+    }
+    __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' columns
+    if (dbg) {
+        float* d = dbg + (int64_t)C * dbg_cols;
+        for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
+    }
+
+    // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
+    {
+        f32x16 acc[RT1][PTW];
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B2 + rt * 32, lk);
+        const float4* frags = reinterpret_cast<const float4*>(wsl + G::OFF_A2);
+        // reflect-padded source pixel of a tap, as an index into lds[] (offsets, not pointers: a pointer array
+        // loses the LDS address space and hipcc falls back to flat loads)
+        auto tap_src = [&](int tap, int (&src)[PTW]) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;              // wave-uniform
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
+                yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);       // reflect (padding_mode='reflect')
+                xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+                src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
+            }
+        };
+        if constexpr (G::PIPE == 0) {
+            // compiler-scheduled form: one tap per loop trip, all NCG groups of the tap unrolled
+            float4 a_cur[RT1], a_nxt[RT1];
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                int src[PTW];
+                tap_src(tap, src);
+#pragma unroll
+                for (int cg = 0; cg < G::NCG; ++cg) {
+                    const int g = tap * G::NCG + cg;
+                    const int gn = min(g + 1, G::NG2 - 1);
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt)
+                        a_nxt[rt] = G::ABL == 1 ? make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg) : frags[(gn * RT1 + rt) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int q = 0; q < PTW; ++q) {
+                            const float bv = G::ABL == 1 ? 0.001f * (src[q] + e) : lds[src[q] + (8 * cg + 2 * e) * PIX];
+#pragma unroll
+                            for (int rt = 0; rt < RT1; ++rt)
+                                acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), bv, acc[rt][q], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
+                }
+            }
+        } else {
+            // group g = tap*NCG + cg covers tap (dy,dx) and input channels 8cg .. 8cg+7.  The operands of group
+            // g+1 are requested before the MFMAs of group g (two register sets, loads pinned by sched_barrier);
+            // the source pixel of a tap is computed once per tap, one tap ahead.
+            GroupOps<RT1, PTW> ops[2];
+            auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+                if constexpr (G::ABL == 1) {                      // timing ablation: operands from registers only
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) o.a[rt] = make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg);
+#pragma unroll
+                    for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o.b[e][q] = 0.001f * (src[q] + e);
+                    return;
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * PIX];
+            };
+            int src_cur[PTW], src_nxt[PTW];
+            tap_src(0, src_cur);
+            load(frags, src_cur, 0, ops[0]);
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                tap_src(min(tap + 1, 8), src_nxt);
+                const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
+#pragma unroll
+                for (int cg = 0; cg < G::NCG; ++cg) {                       // NCG is even: static ping-pong
+                    const float4* fn = fr + (cg + 1) * RT1 * 64;            // fragments of the next group
+                    if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
+                    else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);       // first group of the next tap
+                    __builtin_amdgcn_sched_barrier(0);
+                    group_mma<RT1, PTW>(acc, ops[cg & 1], 4);
+                }
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) src_cur[q] = src_nxt[q];
+            }
+        }
+        __syncthreads();                 // every wave has finished reading h1 (taps cross pixel tiles)
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + tile_row(r, lk);
+                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                }
+    }
+    // no barrier: phase 3 reads only this wave's own pixel columns of h2
+    if (dbg) {
+        __syncthreads();
+        float* d = dbg + (int64_t)(C + HID) * dbg_cols;
+        for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
+    }
+
+    // ================= phase 3: h = NN.4 h2 + b ; affine map ; log-det        (coupling.py:28,52-66)
+#pragma unroll
+    for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(wsl + G::OFF_B3 + rt * 32, lk);
+    dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(wsl + G::OFF_A3), H1, pix, lane);
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------------
+// Tile / loop form per shape, chosen by measurement on MI355X (tools/step_bench.py, B = 16384):
+//   C16: 1 sample (256 px, 40 KB LDS, 3-4 workgroups/CU), compiler-scheduled tap loop    113 TFLOP/s
+//   C32: 4 samples (256 px, 80 KB, 2/CU), explicit operand pipeline                        130 TFLOP/s
+//   C64: 16 samples (256 px, 160 KB = the whole LDS, 1/CU), explicit pipeline, 4x2 tiles   136 TFLOP/s
+using G8 = Geo<8, 16, 16, 1, 0>;
+using G16 = Geo<16, 16, 16, 1, 0>;
+using G32 = Geo<32, 8, 8, 4, 1>;
+using G64 = Geo<64, 4, 4, 16, 1>;
+// alternates kept for tools/step_bench.py, reachable only through cf_flow_step_fwd_debug (flags bits 16..19)
+using G16v1 = Geo<16, 16, 16, 1, 0, 1>;
+using G16v2 = Geo<16, 16, 16, 4, 1>;
+using G16v3 = Geo<16, 16, 16, 4, 0>;
+using G32v1 = Geo<32, 8, 8, 4, 1, 1>;
+using G32v2 = Geo<32, 8, 8, 8, 1>;
+using G32v3 = Geo<32, 8, 8, 8, 0>;
+using G64v1 = Geo<64, 4, 4, 16, 1, 1>;
+using G64v2 = Geo<64, 4, 4, 8, 0>;
+using G64v3 = Geo<64, 4, 4, 16, 0>;
+
+
+int shape_id(int C, int H, int W) {
+    if (C == 8 && H == 16 && W == 16) return 0;
+    if (C == 16 && H == 16 && W == 16) return 1;
+    if (C == 32 && H == 8 && W == 8) return 2;
+    if (C == 64 && H == 4 && W == 4) return 3;
+    return -1;
+}
+
+}  // namespace

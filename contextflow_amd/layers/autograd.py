@@ -1,0 +1,154 @@
+"""Backward of the fused density path: d log p(x)(B,M) / d parameters, for the training step that follows
+`model.log_prob` in the reference (contextflow/experiment_cl.py:127-136: loss(logp).backward(); optimizer.step()).
+
+Forward = the fused plan of FlowSequential (same kernels, same numbers) with a tape of each group's input.
+Backward walks the tape in reverse:
+  * flow step  : ONE kernel (cf_flow_step_bwd) recomputes the step in LDS and runs the data-gradient chain on the
+                 fp32 matrix cores; it also writes the operand planes of the weight gradients, which are plain
+                 GEMMs over (batch x pixels) -> rocBLAS through torch.einsum (a library GEMM, not a fallback of the
+                 hot path: the convolution arithmetic of the chain itself is in the HIP kernel);
+  * GMM priors : component responsibilities from the HIP quadratic-form kernel (cf_gmm_quad), the remaining
+                 contractions are (B x 80) x (80 x D) library GEMMs + small elementwise terms;
+  * Squeeze / SplitPrior / Augment : index maps (squeeze kernel with `inverse`, concatenation).
+Reference quirks carried into the gradients: ActNorm's ldj = +sum(logs) (d/dlogs gets sum_b g_ld), Conv1x1's
+ldj = H*W*log|det W| (d/dW gets sum_b g_ld * H*W * W^-T).  Covers the conv-coupling topologies (mnist, cifar10);
+TransCoupling has no backward yet.  Weight-gradient sums run in fp32 and are not bitwise reproducible."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _hip
+from .distributions.gaussian import gmm_logprob
+from .squeeze import squeeze_op
+
+
+# ------------------------------------------------------------------------------------------------ GMM prior
+def gmm_backward(x, dist, prepared, g):
+    """x: (B, D...) possibly a channel slice; g: (B, M) upstream.  Returns (gx like x, {param: grad})."""
+    a, bm, cst, M, K, D = prepared
+    xv, xbs = _hip.bview(x)
+    B = xv.shape[0]
+    q = torch.empty(B, M * K, device=xv.device, dtype=torch.float32)
+    _hip.call("cf_gmm_quad", _hip.p(xv), _hip.p(a), _hip.p(bm), _hip.p(q), B, M, K, D, xbs, _hip.stream())
+    lp = (cst.unsqueeze(0) - 0.5 * q).view(B, M, K)
+    r = (torch.softmax(lp, dim=-1) * g.unsqueeze(-1)).reshape(B, M * K)      # responsibilities x upstream
+    xf = xv.reshape(B, -1) if xv.is_contiguous() else xv.contiguous().reshape(B, -1)
+    # d/dx = -sum_mk r a (x a + bm)
+    gx = -(xf * (r @ (a * a)) + r @ (a * bm))
+    # parameter sums over the batch: plain GEMMs (80 x B) x (B x D)
+    S0 = r.sum(0).unsqueeze(-1)                      # (MK, 1)
+    S1 = r.t() @ xf                                  # (MK, D)
+    S2 = r.t() @ (xf * xf)
+    rt = a * S1 + bm * S0                            # sum_b r t
+    rt2 = a * a * S2 + 2 * a * bm * S1 + bm * bm * S0
+    g_mu = a * rt
+    g_sigma = a * (rt2 - S0)
+    sG = dist.sG.detach().reshape(M * K, D)
+    grads = {
+        dist.mG: g_mu.view_as(dist.mG),
+        dist.sG: (g_sigma * torch.sigmoid(sG)).view_as(dist.sG),        # softplus' = sigmoid
+        dist.wG: r.sum(0).view(M, K) - g.sum(0).unsqueeze(-1) * torch.softmax(dist.wG.detach(), dim=-1),
+    }
+    return gx.view(xv.shape), grads
+
+
+# ------------------------------------------------------------------------------------------------ flow step
+def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld):
+    """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
+    Returns (dL/dx in the layout of x, {param: grad})."""
+    C, H, W = shape
+    HW, HALF, HID = H * W, C // 2, 2 * C
+    xv, xbs = _hip.bview(x)
+    B, dev = xv.shape[0], xv.device
+    L = _hip.lib()
+    f, pp, st = _hip.f32, _hip.p, _hip.stream()
+    c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
+    Wm, t, logs = f(conv.NN.detach()), f(act.NN_t.detach()), f(act.NN_logs.detach())
+    wsb = torch.empty(L.cf_flow_step_bwd_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+    _hip.call("cf_flow_step_bwd_prepare", pp(Wm), pp(logs), pp(f(c1.weight.detach())), pp(f(c2.weight.detach())),
+              pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
+    new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
+    gx = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+    s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy = new(HALF), new(HID), new(HID), new(C), new(HID), new(HID), new(C)
+    gzc = f(gz)
+    _hip.call("cf_flow_step_bwd", pp(xv), pp(gzc), pp(f(gld)), pp(ws), pp(wsb), pp(gx), pp(s_y0), pp(s_h1), pp(s_h2),
+              pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, int(squeeze), st)
+    # ---- weight gradients: contractions over (batch, pixel) = library GEMMs
+    gw3 = torch.einsum("bcp,bjp->cj", s_gh, s_h2)
+    h1pad = F.pad(s_h1.view(B, HID, H, W), (1, 1, 1, 1), mode="reflect")
+    gw2 = torch.empty(HID, HID, 3, 3, device=dev, dtype=torch.float32)
+    for ky in range(3):
+        for kx in range(3):
+            gw2[:, :, ky, kx] = torch.einsum("bop,bip->oi", s_gh2, h1pad[:, :, ky:ky + H, kx:kx + W].reshape(B, HID, HW))
+    gw1 = torch.einsum("bjp,bcp->jc", s_gh1, s_y0)
+    xs = squeeze_op(xv, (2, 2), False) if squeeze else xv
+    gWp = torch.einsum("bcp,bkp->ck", s_gy, xs.reshape(B, C, HW))
+    gbp = s_gy.sum((0, 2))
+    # ---- chain to Conv1x1 / ActNorm parameters:  W' = diag(s) Wm, b' = -t s, s = exp(-logs)
+    s = torch.exp(-logs)
+    G = gld.sum()
+    lad = torch.empty(1, device=dev, dtype=torch.float32)
+    winv = torch.empty(C, C, device=dev, dtype=torch.float32)
+    _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
+    grads = {
+        conv.NN: s.unsqueeze(1) * gWp + (G * HW) * winv.t(),                  # + d(H W log|det W|)/dW
+        act.NN_t: -s * gbp,
+        act.NN_logs: -(gWp * (s.unsqueeze(1) * Wm)).sum(1) + gbp * t * s + G,   # quirk: ldj = +sum(logs)
+        c1.weight: gw1.view_as(c1.weight), c1.bias: s_gh1.sum((0, 2)),
+        c2.weight: gw2, c2.bias: s_gh2.sum((0, 2)),
+        c3.weight: gw3.view_as(c3.weight), c3.bias: s_gh.sum((0, 2)),
+    }
+    if squeeze:
+        gx = squeeze_op(gx, (2, 2), True)
+    return gx, grads
+
+
+# ------------------------------------------------------------------------------------------------ the Function
+class FlowLogProb(torch.autograd.Function):
+    """logp (B,M) of a FlowSequential with parameter gradients.  `params` are passed positionally only so that autograd
+    tracks them; the arithmetic reads them from the modules."""
+
+    @staticmethod
+    def forward(ctx, flow, x, *params):
+        tape = []
+        z, logp = flow._forward_fused(x, None, tape=tape)
+        ctx.flow, ctx.tape, ctx.params = flow, tape, params
+        ctx.mark_non_differentiable(z)
+        return z, logp
+
+    @staticmethod
+    def backward(ctx, _gz_unused, glogp):
+        flow, tape, params = ctx.flow, ctx.tape, ctx.params
+        glogp = _hip.f32(glogp)
+        gld = glogp.sum(1).contiguous()                     # d/d ld1[b]: logp = ldM + ld1[:, None]
+        acc = {}
+
+        def add(d):
+            for p, g in d.items():
+                acc[p] = g if p not in acc else acc[p] + g
+
+        gz = None
+        for rec in reversed(tape):
+            kind = rec[0]
+            if kind == "prior":
+                _, xin, dist, prep = rec
+                gz, gp = gmm_backward(xin, dist, prep, glogp)
+                add(gp)
+            elif kind == "split":
+                _, xin, dist, prep = rec                      # xin: full tensor before the split
+                c = xin.shape[1] // 2
+                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp)
+                add(gp)
+                gz = torch.cat([gz, g2], dim=1)
+            elif kind == "step":
+                _, xin, sq, conv, act, cpl, shape, ws = rec
+                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld)
+                add(gp)
+            elif kind == "squeeze":
+                gz = squeeze_op(gz, rec[1], True)
+            elif kind == "pre":
+                break                                        # nothing trainable upstream of the pre-processing
+            else:
+                raise NotImplementedError("no backward for layer %s in the fused plan" % type(rec[1]).__name__)
+        return (None, None) + tuple(acc.get(p) for p in params)

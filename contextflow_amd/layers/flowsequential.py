@@ -147,7 +147,7 @@ class FlowSequential(nn.Module):
                   pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, _hip.stream())
         return ws
 
-    def _forward_fused(self, x, context):
+    def _forward_fused(self, x, context, tape=None):
         B, M, dev = x.shape[0], self.mixtures, x.device
         key = tuple(x.shape[1:])
         plan = self._plans.get(key)
@@ -180,6 +180,8 @@ class FlowSequential(nn.Module):
         for k, op in enumerate(plan):
             kind = op[0]
             if kind == "pre":
+                if tape is not None:
+                    tape.append(("pre",))
                 _, deq, n1, n2, aug = op
                 xin = _hip.f32(x)
                 C, H, W = xin.shape[1:]
@@ -202,6 +204,8 @@ class FlowSequential(nn.Module):
                 _, conv, act, cpl, (C, H, W), sq = op
                 ws, ev = prepared[k]
                 main.wait_event(ev)
+                if tape is not None:
+                    tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws))
                 x, xbs = _hip.bview(x)
                 z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
                 events = self.step_events
@@ -214,20 +218,28 @@ class FlowSequential(nn.Module):
                     events.append((e0, e1, B, C))
                 x = z
             elif kind == "squeeze":
+                if tape is not None:
+                    tape.append(("squeeze", tuple(op[1].p)))
                 x = squeeze_op(x, op[1].p, False)
             elif kind == "split":
                 prep, ev = prepared[k]
                 main.wait_event(ev)
+                if tape is not None:
+                    tape.append(("split", x, op[1].dist, prep))
                 c = x.shape[1] // 2
                 gmm_logprob(x[:, c:], prep, out=ldM, accumulate=True)
                 x = x[:, :c]
             else:                        # any other layer: its own kernels
+                if tape is not None:
+                    tape.append(("layer", op[1]))
                 x, ldj = op[1](x, context)
                 if ldj.dim() == 2:
                     ldM += ldj
                 else:
                     ld1 += ldj
         main.wait_event(ev_prior)
+        if tape is not None:
+            tape.append(("prior", x, self.dist, prior))
         gmm_logprob(x, prior, out=ldM, accumulate=True)
         logp = torch.empty(B, M, device=dev, dtype=torch.float32)
         _hip.call("cf_logdet_combine", _hip.p(ldM), _hip.p(ld1), _hip.p(logp), B, M, st)
@@ -245,6 +257,11 @@ class FlowSequential(nn.Module):
     # ------------------------------------------------------------------ reference API
     def forward(self, input, context=None):
         _hip.require_device(input)
+        if torch.is_grad_enabled() and self._fusable():
+            params = [p for p in self.parameters() if p.requires_grad]
+            if params:                       # training: same kernels + a tape, hand-written backward (autograd.py)
+                from .autograd import FlowLogProb
+                return FlowLogProb.apply(self, input, *params)
         with torch.no_grad():
             if self._fusable():
                 return self._forward_fused(input, context)

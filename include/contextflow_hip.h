@@ -100,6 +100,10 @@ int64_t cf_gmm_ws_bytes(int B, int M, int K, int D);
 int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float* cst, float* out, void* ws,
                    int B, int M, int K, int D, int64_t x_bstride, int accumulate, cf_stream_t stream);
 
+/* q[b, m*K+k] = sum_d (x[b,d]*a + bm)^2 only (B x M*K, dense): the backward pass rebuilds the responsibilities
+ * softmax_k(cst - q/2) from it.                                                                        */
+int cf_gmm_quad(const float* x, const float* a, const float* bm, float* q, int B, int M, int K, int D,
+                int64_t x_bstride, cf_stream_t stream);
 /* prior sampling (gaussian.py:163-169): out[n,:] = mG[rows[n],:] + softplus(sG[rows[n],:]) * eps[n,:];
  * rows[n] = m*K + k_n (int64, component drawn by the caller), eps ~ N(0,1) supplied by the caller.      */
 int cf_gmm_sample(const float* mG, const float* sG, const int64_t* rows, const float* eps, float* out, int N, int D,
@@ -130,6 +134,19 @@ int cf_flow_step_inv_prepare(const float* Wm, const float* t, const float* logs,
                              cf_stream_t stream);
 int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, int B, int C, int H, int W,
                      int64_t z_bstride, cf_stream_t stream);
+
+/* ---- backward of the fused step (training: experiment_cl.py:130-136) ------------------------------
+ * One kernel per step: recomputes the forward in LDS, then the data-gradient chain on fp32 MFMA with
+ * transposed weight fragments (cf_flow_step_bwd_prepare), writes g_x (B,C,H,W; squeezed layout when
+ * in_squeeze) and the operand planes the weight gradients contract over, each (B, rows, H*W) dense:
+ * s_y0 (C/2), s_h1, s_h2, s_gh2, s_gh1 (2C), s_gh, s_gy (C).  gz: dL/dz (B,C,H,W) dense; gld: dL/d(log-det) (B,).
+ * The weight gradients are plain GEMMs over (batch x pixels) left to the caller (rocBLAS).              */
+int64_t cf_flow_step_bwd_ws_bytes(int C, int H, int W);
+int cf_flow_step_bwd_prepare(const float* Wm, const float* logs, const float* w1, const float* w2, const float* w3,
+                             void* wsb, int C, int H, int W, cf_stream_t stream);
+int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
+                     float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy,
+                     int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; K <= 128.
