@@ -4,9 +4,8 @@
 Forward = the fused plan of FlowSequential (same kernels, same numbers) with a tape of each group's input.
 Backward walks the tape in reverse:
   * flow step  : ONE kernel (cf_flow_step_bwd) recomputes the step in LDS and runs the data-gradient chain on the
-                 fp32 matrix cores; it also writes the operand planes of the weight gradients, which are plain
-                 GEMMs over (batch x pixels) -> rocBLAS through torch.einsum (a library GEMM, not a fallback of the
-                 hot path: the convolution arithmetic of the chain itself is in the HIP kernel);
+                 fp32 matrix cores; it also writes the operand planes of the weight gradients, which are split-K
+                 MFMA GEMMs over (batch x pixels) with the 3x3 tap shifts (cf_wgrad);
   * GMM priors : component responsibilities from the HIP quadratic-form kernel (cf_gmm_quad), the remaining
                  contractions are (B x 80) x (80 x D) library GEMMs + small elementwise terms;
   * Squeeze / SplitPrior / Augment : index maps (squeeze kernel with `inverse`, concatenation).
@@ -16,7 +15,6 @@ TransCoupling has no backward yet.  Weight-gradient sums run in fp32 and are not
 import math
 
 import torch
-import torch.nn.functional as F
 
 from . import _hip
 from .distributions.gaussian import gmm_logprob
@@ -74,16 +72,17 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld):
     gzc = f(gz)
     _hip.call("cf_flow_step_bwd", pp(xv), pp(gzc), pp(f(gld)), pp(ws), pp(wsb), pp(gx), pp(s_y0), pp(s_h1), pp(s_h2),
               pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, int(squeeze), st)
-    # ---- weight gradients: contractions over (batch, pixel) = library GEMMs
-    gw3 = torch.einsum("bcp,bjp->cj", s_gh, s_h2)
-    h1pad = F.pad(s_h1.view(B, HID, H, W), (1, 1, 1, 1), mode="reflect")
-    gw2 = torch.empty(HID, HID, 3, 3, device=dev, dtype=torch.float32)
-    for ky in range(3):
-        for kx in range(3):
-            gw2[:, :, ky, kx] = torch.einsum("bop,bip->oi", s_gh2, h1pad[:, :, ky:ky + H, kx:kx + W].reshape(B, HID, HW))
-    gw1 = torch.einsum("bjp,bcp->jc", s_gh1, s_y0)
-    xs = squeeze_op(xv, (2, 2), False) if squeeze else xv
-    gWp = torch.einsum("bcp,bkp->ck", s_gy, xs.reshape(B, C, HW))
+    # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts (cf_wgrad)
+    def wgrad(A, Bm, taps):
+        out = torch.zeros(taps, A.shape[1], Bm.shape[1], device=dev, dtype=torch.float32)
+        _hip.call("cf_wgrad", pp(A), pp(Bm), pp(out), B, A.shape[1], Bm.shape[1], H, W, taps, st)
+        return out
+
+    gw3 = wgrad(s_gh, s_h2, 1)[0]
+    gw2 = wgrad(s_gh2, s_h1, 9).permute(1, 2, 0).reshape(HID, HID, 3, 3)
+    gw1 = wgrad(s_gh1, s_y0, 1)[0]
+    xs = squeeze_op(xv, (2, 2), False) if squeeze else xv.contiguous()
+    gWp = wgrad(s_gy, xs.reshape(B, C, HW), 1)[0]
     gbp = s_gy.sum((0, 2))
     # ---- chain to Conv1x1 / ActNorm parameters:  W' = diag(s) Wm, b' = -t s, s = exp(-logs)
     s = torch.exp(-logs)
