@@ -22,12 +22,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // NT = 32-column tiles of Bm (1, 2 or 4); the 4 waves split (column tile) x (K quarter): KW = 4 / NT
 template <int H, int W, int TAPS, int NT>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, const float* __restrict__ Bm,
-                                               float* __restrict__ gw, int B, int MR, int NR) {
+                                               float* __restrict__ gw, float* __restrict__ gbias, int B, int MR, int NR) {
     constexpr int HW = H * W;
     constexpr int KC = HW >= 64 ? HW : 64;            // pixels per chunk (whole samples)
     constexpr int SPC = KC / HW;                      // samples per chunk
     constexpr int KW = 4 / NT;
     constexpr int SA = 33, SB = NT * 32 + 1;          // odd LDS row strides
+    constexpr int IA = 32 * KC / 256, IB = NT * 32 * KC / 256;    // staged elements per thread
     extern __shared__ __align__(16) float lds[];
     float* TA = lds;                                  // [KC][SA]   A tile, transposed
     float* TB = lds + KC * SA;                        // [KC][SB]   B tile, transposed
@@ -51,27 +52,41 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;                                 // row sum of A (= the bias gradient), lanes of column tile 0
 
-    const int nchunks = (B + SPC - 1) / SPC;
-    for (int c = blockIdx.y; c < nchunks; c += gridDim.y) {
-        __syncthreads();                              // previous chunk consumed (and tab written)
+    // global -> registers (lanes along pixels: coalesced); one chunk ahead of the MFMAs
+    float ra[IA], rb[IB];
+    auto gload = [&](int c) {
         const int s0 = c * SPC;
-        // stage: lanes along pixels (coalesced global reads, conflict-free transposed LDS writes)
-        for (int e = tid; e < 32 * KC; e += 256) {
-            const int ch = e / KC, pix = e - ch * KC, b = s0 + pix / HW;
-            const int m = m0 + ch;
-            TA[pix * SA + ch] = (m < MR && b < B) ? A[((int64_t)b * MR + m) * HW + pix % HW] : 0.f;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int e = i * 256 + tid, ch = e / KC, pix = e - ch * KC, b = s0 + pix / HW, m = m0 + ch;
+            ra[i] = (m < MR && b < B) ? A[((int64_t)b * MR + m) * HW + pix % HW] : 0.f;
         }
-        for (int e = tid; e < NT * 32 * KC; e += 256) {
-            const int ch = e / KC, pix = e - ch * KC, b = s0 + pix / HW;
-            TB[pix * SB + ch] = (ch < NR && b < B) ? Bm[((int64_t)b * NR + ch) * HW + pix % HW] : 0.f;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int e = i * 256 + tid, ch = e / KC, pix = e - ch * KC, b = s0 + pix / HW;
+            rb[i] = (ch < NR && b < B) ? Bm[((int64_t)b * NR + ch) * HW + pix % HW] : 0.f;
         }
+    };
+    const int nchunks = (B + SPC - 1) / SPC;
+    int c = blockIdx.y;
+    if (c < nchunks) gload(c);
+    for (; c < nchunks; c += gridDim.y) {
+        __syncthreads();                              // previous chunk consumed (and tab written)
+        // registers -> LDS, transposed (lanes = consecutive pixels, odd stride: conflict-free)
+#pragma unroll
+        for (int i = 0; i < IA; ++i) { const int e = i * 256 + tid, ch = e / KC, pix = e - ch * KC; TA[pix * SA + ch] = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) { const int e = i * 256 + tid, ch = e / KC, pix = e - ch * KC; TB[pix * SB + ch] = rb[i]; }
         __syncthreads();
+        if (c + (int)gridDim.y < nchunks) gload(c + gridDim.y);       // next chunk in flight behind the MFMAs
         // K loop: k-step s covers pixels 2s, 2s+1; this wave takes the steps s = kq (mod KW)
 #pragma unroll 2
         for (int s = kq; s < KC / 2; s += KW) {
             const int pix = 2 * s + lk;
             const float a = TA[pix * SA + li];                       // A[i = m][k = pixel]
+            bsum += a;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const float b = TB[tab[t * KC + pix] * SB + nt * 32 + li];   // B[k = pixel][j = n], tap-shifted
@@ -90,10 +105,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
                 if (m < MR) atomicAdd(gw + ((int64_t)t * MR + m) * NR + n, acc[t][r]);
             }
     }
+    if (gbias != nullptr && nt == 0) {                // every A element is seen once by the waves of column tile 0
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lk == 0 && m0 + li < MR) atomicAdd(gbias + m0 + li, bsum);
+    }
 }
 
 template <int H, int W, int TAPS, int NT>
-int launch_wgrad(const float* A, const float* Bm, float* gw, int B, int MR, int NR, hipStream_t s) {
+int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, int B, int MR, int NR, hipStream_t s) {
     constexpr int HW = H * W, KC = HW >= 64 ? HW : 64, SPC = KC / HW;
     constexpr size_t lds = (size_t)(KC * 33 + KC * (NT * 32 + 1) + TAPS * KC) * 4;
     if (lds > 64 * 1024) {
@@ -109,26 +128,26 @@ int launch_wgrad(const float* A, const float* Bm, float* gw, int B, int MR, int 
     int splits = 768 / mtiles;                        // ~3 workgroups per CU in flight
     if (splits > nchunks) splits = nchunks;
     if (splits < 1) splits = 1;
-    k_wgrad<H, W, TAPS, NT><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, gw, B, MR, NR);
+    k_wgrad<H, W, TAPS, NT><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, gw, gbias, B, MR, NR);
     return 0;
 }
 
 template <int H, int W, int TAPS>
-int dispatch_nt(const float* A, const float* Bm, float* gw, int B, int MR, int NR, hipStream_t s) {
-    if (NR <= 32) return launch_wgrad<H, W, TAPS, 1>(A, Bm, gw, B, MR, NR, s);
-    if (NR <= 64) return launch_wgrad<H, W, TAPS, 2>(A, Bm, gw, B, MR, NR, s);
-    return launch_wgrad<H, W, TAPS, 4>(A, Bm, gw, B, MR, NR, s);
+int dispatch_nt(const float* A, const float* Bm, float* gw, float* gbias, int B, int MR, int NR, hipStream_t s) {
+    if (NR <= 32) return launch_wgrad<H, W, TAPS, 1>(A, Bm, gw, gbias, B, MR, NR, s);
+    if (NR <= 64) return launch_wgrad<H, W, TAPS, 2>(A, Bm, gw, gbias, B, MR, NR, s);
+    return launch_wgrad<H, W, TAPS, 4>(A, Bm, gw, gbias, B, MR, NR, s);
 }
 
 }  // namespace
 
-extern "C" int cf_wgrad(const float* A, const float* Bm, float* gw, int B, int MR, int NR, int H, int W, int taps,
-                        cf_stream_t stream) {
+extern "C" int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, int B, int MR, int NR, int H, int W,
+                        int taps, cf_stream_t stream) {
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(A && Bm && gw && MR > 0 && NR > 0 && NR <= 128 && (taps == 1 || taps == 9));
     int rc;
     hipStream_t s = cf_s(stream);
-#define CF_W(HH, WW) rc = taps == 9 ? dispatch_nt<HH, WW, 9>(A, Bm, gw, B, MR, NR, s) : dispatch_nt<HH, WW, 1>(A, Bm, gw, B, MR, NR, s)
+#define CF_W(HH, WW) rc = taps == 9 ? dispatch_nt<HH, WW, 9>(A, Bm, gw, gbias, B, MR, NR, s) : dispatch_nt<HH, WW, 1>(A, Bm, gw, gbias, B, MR, NR, s)
     if (H == 16 && W == 16) CF_W(16, 16);
     else if (H == 8 && W == 8) CF_W(8, 8);
     else if (H == 4 && W == 4) CF_W(4, 4);

@@ -52,7 +52,7 @@ def gmm_backward(x, dist, prepared, g):
 
 
 # ------------------------------------------------------------------------------------------------ flow step
-def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld):
+def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
     Returns (dL/dx in the layout of x, {param: grad})."""
     C, H, W = shape
@@ -74,29 +74,33 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld):
               pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, int(squeeze), st)
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts (cf_wgrad)
     def wgrad(A, Bm, taps):
-        out = torch.zeros(taps, A.shape[1], Bm.shape[1], device=dev, dtype=torch.float32)
-        _hip.call("cf_wgrad", pp(A), pp(Bm), pp(out), B, A.shape[1], Bm.shape[1], H, W, taps, st)
-        return out
+        """(gw (taps, MR, NR), gbias (MR,) = row sums of A)"""
+        out = torch.zeros(taps * A.shape[1] * Bm.shape[1] + A.shape[1], device=dev, dtype=torch.float32)
+        gw, gb = out[:-A.shape[1]].view(taps, A.shape[1], Bm.shape[1]), out[-A.shape[1]:]
+        _hip.call("cf_wgrad", pp(A), pp(Bm), pp(gw), pp(gb), B, A.shape[1], Bm.shape[1], H, W, taps, st)
+        return gw, gb
 
-    gw3 = wgrad(s_gh, s_h2, 1)[0]
-    gw2 = wgrad(s_gh2, s_h1, 9).permute(1, 2, 0).reshape(HID, HID, 3, 3)
-    gw1 = wgrad(s_gh1, s_y0, 1)[0]
+    gw3, gb3 = wgrad(s_gh, s_h2, 1)
+    gw2, gb2 = wgrad(s_gh2, s_h1, 9)
+    gw1, gb1 = wgrad(s_gh1, s_y0, 1)
     xs = squeeze_op(xv, (2, 2), False) if squeeze else xv.contiguous()
-    gWp = wgrad(s_gy, xs.reshape(B, C, HW), 1)[0]
-    gbp = s_gy.sum((0, 2))
+    gWp, gbp = wgrad(s_gy, xs.reshape(B, C, HW), 1)
+    gw3, gw1, gWp = gw3[0], gw1[0], gWp[0]
+    gw2 = gw2.permute(1, 2, 0).reshape(HID, HID, 3, 3)
     # ---- chain to Conv1x1 / ActNorm parameters:  W' = diag(s) Wm, b' = -t s, s = exp(-logs)
     s = torch.exp(-logs)
     G = gld.sum()
-    lad = torch.empty(1, device=dev, dtype=torch.float32)
-    winv = torch.empty(C, C, device=dev, dtype=torch.float32)
-    _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
+    if winv is None:
+        lad = torch.empty(1, device=dev, dtype=torch.float32)
+        winv = torch.empty(C, C, device=dev, dtype=torch.float32)
+        _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
     grads = {
         conv.NN: s.unsqueeze(1) * gWp + (G * HW) * winv.t(),                  # + d(H W log|det W|)/dW
         act.NN_t: -s * gbp,
         act.NN_logs: -(gWp * (s.unsqueeze(1) * Wm)).sum(1) + gbp * t * s + G,   # quirk: ldj = +sum(logs)
-        c1.weight: gw1.view_as(c1.weight), c1.bias: s_gh1.sum((0, 2)),
-        c2.weight: gw2, c2.bias: s_gh2.sum((0, 2)),
-        c3.weight: gw3.view_as(c3.weight), c3.bias: s_gh.sum((0, 2)),
+        c1.weight: gw1.reshape(c1.weight.shape), c1.bias: gb1,
+        c2.weight: gw2, c2.bias: gb2,
+        c3.weight: gw3.reshape(c3.weight.shape), c3.bias: gb3,
     }
     if squeeze:
         gx = squeeze_op(gx, (2, 2), True)
@@ -141,8 +145,8 @@ class FlowLogProb(torch.autograd.Function):
                 add(gp)
                 gz = torch.cat([gz, g2], dim=1)
             elif kind == "step":
-                _, xin, sq, conv, act, cpl, shape, ws = rec
-                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld)
+                _, xin, sq, conv, act, cpl, shape, ws, winv = rec
+                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv)
                 add(gp)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)

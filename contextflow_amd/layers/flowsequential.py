@@ -163,6 +163,12 @@ class FlowSequential(nn.Module):
             for k, op in enumerate(plan):
                 if op[0] == "step":
                     prepared[k] = self._prepare_step(op[1], op[2], op[3], op[4], dev)
+                    if tape is not None:     # training: W^-1 for d(log|det W|)/dW, off the critical path
+                        Cc = op[4][0]
+                        winv = torch.empty(Cc, Cc, device=dev, dtype=torch.float32)
+                        lad = torch.empty(1, device=dev, dtype=torch.float32)
+                        _hip.call("cf_slogdet_inverse", _hip.p(_hip.f32(op[1].NN.detach())), Cc, _hip.p(lad), _hip.p(winv), _hip.stream())
+                        prepared[k] = (prepared[k], winv)
                 elif op[0] == "split":
                     prepared[k] = op[1].dist.prepared()
                 else:
@@ -205,7 +211,8 @@ class FlowSequential(nn.Module):
                 ws, ev = prepared[k]
                 main.wait_event(ev)
                 if tape is not None:
-                    tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws))
+                    ws, winv = ws
+                    tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws, winv))
                 x, xbs = _hip.bview(x)
                 z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
                 events = self.step_events
@@ -244,11 +251,16 @@ class FlowSequential(nn.Module):
         logp = torch.empty(B, M, device=dev, dtype=torch.float32)
         _hip.call("cf_logdet_combine", _hip.p(ldM), _hip.p(ld1), _hip.p(logp), B, M, st)
         # buffers written on the side stream are consumed on the main stream: keep the allocator informed
+        def _bufs(t):
+            if torch.is_tensor(t):
+                yield t
+            elif isinstance(t, tuple):
+                for u in t:
+                    yield from _bufs(u)
+
         for v in prepared.values():
-            t = v[0]
-            for buf in (t if isinstance(t, tuple) else (t,)):
-                if torch.is_tensor(buf):
-                    buf.record_stream(main)
+            for buf in _bufs(v[0]):
+                buf.record_stream(main)
         for buf in prior:
             if torch.is_tensor(buf):
                 buf.record_stream(main)

@@ -152,8 +152,8 @@ int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const vo
  *   gw[t][m][n] += sum_{b,p} A[b][m][p] * Bm[b][n][src_t(p)],  t < taps (1, or 9 = 3x3 reflect-shifted pixels)
  * A: (B, MR, H*W), Bm: (B, NR, H*W) dense (planes written by cf_flow_step_bwd); gw: (taps, MR, NR) fp32,
  * ACCUMULATED with atomics (zero it first).  H x W in {16x16, 8x8, 4x4}, NR <= 128.                    */
-int cf_wgrad(const float* A, const float* Bm, float* gw, int B, int MR, int NR, int H, int W, int taps,
-             cf_stream_t stream);
+int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, int B, int MR, int NR, int H, int W, int taps,
+             cf_stream_t stream);      /* gbias (optional, MR floats, zeroed by the caller) += sum_{b,p} A[b][m][p] */
 
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; K <= 128.
