@@ -64,3 +64,35 @@ def broadcast_parameters(module, src=0):
     for m in module.modules():
         if hasattr(m, "_init_done") and hasattr(m, "initialized"):
             m._init_done = bool(int(m.initialized.item()))
+
+
+def allreduce_gradients(module, bucket_bytes=32 << 20):
+    """Average parameter gradients over the ranks (data-parallel training step).  Gradients are packed into flat
+    fp32 buckets (default 32 MB; the whole cifar10 flow is 6 MB = one message) so that each RCCL all-reduce moves a
+    bandwidth-relevant payload over the point-to-point xGMI links instead of 135 tiny latency-bound ones."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    world = dist.get_world_size()
+    params = [p for p in module.parameters() if p.grad is not None]
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        o = 0
+        for p in bucket:
+            n = p.grad.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
+            o += n
+        bucket, size = [], 0
+
+    for p in params:
+        bucket.append(p)
+        size += p.grad.numel() * 4
+        if size >= bucket_bytes:
+            flush()
+    flush()

@@ -153,3 +153,32 @@ def test_two_rank_nll_allreduce_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+GRAD_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from contextflow_amd.dist import init_process_group, allreduce_gradients
+rank, _, world = init_process_group("gloo")
+torch.manual_seed(0)
+m = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+for i, p in enumerate(m.parameters()):
+    p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+allreduce_gradients(m, bucket_bytes=64)           # tiny buckets: several messages
+for i, p in enumerate(m.parameters()):
+    assert torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))), (rank, i, p.grad.flatten()[:3])
+dist.barrier()
+if rank == 0: print("OK")
+'''
+
+
+def test_two_rank_gradient_allreduce_gloo(tmp_path):
+    script = tmp_path / "gworker.py"
+    script.write_text(GRAD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0]
