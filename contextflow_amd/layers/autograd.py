@@ -11,7 +11,7 @@ Backward walks the tape in reverse:
   * Squeeze / SplitPrior / Augment : index maps (squeeze kernel with `inverse`, concatenation).
 Reference quirks carried into the gradients: ActNorm's ldj = +sum(logs) (d/dlogs gets sum_b g_ld), Conv1x1's
 ldj = H*W*log|det W| (d/dW gets sum_b g_ld * H*W * W^-T).  Covers the conv-coupling topologies (mnist, cifar10);
-TransCoupling has no backward yet.  Weight-gradient sums run in fp32 and are not bitwise reproducible."""
+TransCoupling has no backward yet.  Weight-gradient partial sums are combined in a fixed order (no float atomics)."""
 import math
 
 import torch
@@ -75,9 +75,11 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None):
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts (cf_wgrad)
     def wgrad(A, Bm, taps):
         """(gw (taps, MR, NR), gbias (MR,) = row sums of A)"""
-        out = torch.zeros(taps * A.shape[1] * Bm.shape[1] + A.shape[1], device=dev, dtype=torch.float32)
-        gw, gb = out[:-A.shape[1]].view(taps, A.shape[1], Bm.shape[1]), out[-A.shape[1]:]
-        _hip.call("cf_wgrad", pp(A), pp(Bm), pp(gw), pp(gb), B, A.shape[1], Bm.shape[1], H, W, taps, st)
+        MR, NR = A.shape[1], Bm.shape[1]
+        gw = torch.empty(taps, MR, NR, device=dev, dtype=torch.float32)
+        gb = torch.empty(MR, device=dev, dtype=torch.float32)
+        wsw = torch.empty(L.cf_wgrad_ws_bytes(B, MR, NR, H, W, taps), device=dev, dtype=torch.uint8)
+        _hip.call("cf_wgrad", pp(A), pp(Bm), pp(gw), pp(gb), pp(wsw), B, MR, NR, H, W, taps, st)
         return gw, gb
 
     gw3, gb3 = wgrad(s_gh, s_h2, 1)

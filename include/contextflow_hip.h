@@ -149,11 +149,14 @@ int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const vo
                      int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 
 /* weight gradient as a split-K MFMA GEMM over (sample, pixel):
- *   gw[t][m][n] += sum_{b,p} A[b][m][p] * Bm[b][n][src_t(p)],  t < taps (1, or 9 = 3x3 reflect-shifted pixels)
- * A: (B, MR, H*W), Bm: (B, NR, H*W) dense (planes written by cf_flow_step_bwd); gw: (taps, MR, NR) fp32,
- * ACCUMULATED with atomics (zero it first).  H x W in {16x16, 8x8, 4x4}, NR <= 128.                    */
-int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, int B, int MR, int NR, int H, int W, int taps,
-             cf_stream_t stream);      /* gbias (optional, MR floats, zeroed by the caller) += sum_{b,p} A[b][m][p] */
+ *   gw[t][m][n] = sum_{b,p} A[b][m][p] * Bm[b][n][src_t(p)],  t < taps (1, or 9 = 3x3 reflect-shifted pixels)
+ *   gbias[m]    = sum_{b,p} A[b][m][p]                         (optional)
+ * A: (B, MR, H*W), Bm: (B, NR, H*W) dense (planes written by cf_flow_step_bwd); gw: (taps, MR, NR) fp32.
+ * ws: cf_wgrad_ws_bytes(...) bytes for the split-K partials, summed in a fixed order (reproducible).
+ * H x W in {16x16, 8x8, 4x4}, NR <= 128.                                                               */
+int64_t cf_wgrad_ws_bytes(int B, int MR, int NR, int H, int W, int taps);
+int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws, int B, int MR, int NR, int H, int W,
+             int taps, cf_stream_t stream);
 
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; K <= 128.
