@@ -344,10 +344,10 @@ using G16 = Geo<16, 16, 16, 1, 0>;
 using G32 = Geo<32, 8, 8, 4, 1>;
 using G64 = Geo<64, 4, 4, 16, 1>;
 // alternates kept for tools/step_bench.py, reachable only through cf_flow_step_fwd_debug (flags bits 16..19)
-using G16v1 = Geo<16, 16, 16, 1, 0, 1>;
-using G16v2 = Geo<16, 16, 16, 4, 1>;
-using G16v3 = Geo<16, 16, 16, 4, 0>;
-using G32v1 = Geo<32, 8, 8, 4, 1, 1>;
+using G16v1 = Geo<16, 16, 16, 1, 1>;
+using G16v2 = Geo<16, 16, 16, 2, 1>;
+using G16v3 = Geo<16, 16, 16, 2, 0>;
+using G32v1 = Geo<32, 8, 8, 4, 0>;
 using G32v2 = Geo<32, 8, 8, 8, 1>;
 using G32v3 = Geo<32, 8, 8, 8, 0>;
 using G64v1 = Geo<64, 4, 4, 16, 1, 1>;
