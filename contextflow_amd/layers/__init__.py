@@ -15,7 +15,7 @@ from .normalize import Normalization
 from .augment import Augment
 from .distributions import StandardNormal, GaussianMixtureDistribution, UniformDistribution
 from .splitprior import SplitPrior
-from .flowsequential import FlowSequential, FlowInvSequential
+from .flowsequential import FlowSequential, FlowInvSequential, GraphedFlow
 from .conv1x1 import Conv1x1, FC
 from .activations import FlowActivationLayer, SplineActivation
 from .actnorm import ActNorm, ActNormFC

@@ -282,6 +282,11 @@ class FlowSequential(nn.Module):
     def log_prob(self, input, context=None):
         return self.forward(input, context)[1]
 
+    def capture(self, example_input):
+        """Capture the fused forward for inputs of this exact shape into a HIP graph; returns a callable
+        `g(x) -> (z, logp)` (static output buffers, overwritten by the next replay)."""
+        return GraphedFlow(self, example_input)
+
     def _inverse_step(self, z, conv, act, cpl):
         """Conv1x1^-1 o ActNorm^-1 o Coupling^-1 in one MFMA kernel (cf_flow_step_inv)."""
         z, zbs = _hip.bview(z)
@@ -318,6 +323,34 @@ class FlowSequential(nn.Module):
     def sample(self, n_samples, context=None):
         z, _ = self.dist.sample(n_samples, context)
         return self.inverse(z, context)
+
+
+class GraphedFlow:
+    """A FlowSequential forward captured once into a HIP graph (launch-bound regime: small batches, where the ~45
+    kernel launches + side-stream hand-offs of a call cost more than the kernels).  Replays write into static
+    output buffers; the noise layers keep drawing fresh noise (graph-safe Philox offsets)."""
+
+    def __init__(self, flow, example, warmup=2):
+        _hip.require_device(example)
+        if not flow._fusable():
+            raise RuntimeError("capture needs initialised ActNorms (run one forward first) and the fused plan")
+        self.flow = flow
+        self.static_in = example.detach().clone()
+        with torch.no_grad():
+            s = torch.cuda.Stream(device=example.device)
+            s.wait_stream(torch.cuda.current_stream(example.device))
+            with torch.cuda.stream(s):                 # warm-up off the default stream: first-use attribute calls,
+                for _ in range(warmup):               # allocator pools, plan construction
+                    flow._forward_fused(self.static_in, None)
+            torch.cuda.current_stream(example.device).wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_z, self.static_logp = flow._forward_fused(self.static_in, None)
+
+    def __call__(self, x):
+        self.static_in.copy_(x)
+        self.graph.replay()
+        return self.static_z, self.static_logp
 
 
 class FlowInvSequential(nn.Module):
