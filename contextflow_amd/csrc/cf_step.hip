@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm,
 // staging: one 16-byte load along the un-squeezed row = channels (4c'+2i1, +1) of squeezed pixels (x, x+1).
 // dbg (optional, tests only): dumps of y0, h1, h2, h as [rows][tiles*PIX].
 template <class G, bool SQ>
-__global__ __launch_bounds__(256) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
+__global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
                                                    float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
                                                    int64_t xbs, float* __restrict__ dbg, int flags) {
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;

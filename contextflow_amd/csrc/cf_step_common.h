@@ -42,6 +42,8 @@ struct Geo {
     static constexpr int OFF_A3 = OFF_A2 + NG2 * RT1 * 256;
     static constexpr int WS_FLOATS = OFF_A3 + NG3 * RT03 * 256;
     static constexpr int LDS_FLOATS = (HALF + HID) * PIX;
+    // waves per SIMD the register allocator must leave room for = workgroups per CU the LDS footprint admits
+    static constexpr int MINW = (160 * 1024) / (LDS_FLOATS * 4) >= 4 ? 4 : ((160 * 1024) / (LDS_FLOATS * 4) >= 2 ? 2 : 1);
     static_assert(PIX % 128 == 0 && PTW >= 1, "workgroup must own a multiple of 128 pixels");
     static_assert(HID % 8 == 0 && C % 4 == 0, "channel counts must fill whole k-steps");
     static_assert((HW & (HW - 1)) == 0 && (W & (W - 1)) == 0, "power-of-two images");
@@ -348,10 +350,10 @@ using G16v1 = Geo<16, 16, 16, 1, 1>;
 using G16v2 = Geo<16, 16, 16, 2, 1>;
 using G16v3 = Geo<16, 16, 16, 2, 0>;
 using G32v1 = Geo<32, 8, 8, 4, 0>;
-using G32v2 = Geo<32, 8, 8, 8, 1>;
+using G32v2 = Geo<32, 8, 8, 2, 1>;
 using G32v3 = Geo<32, 8, 8, 8, 0>;
 using G64v1 = Geo<64, 4, 4, 16, 1, 1>;
-using G64v2 = Geo<64, 4, 4, 8, 0>;
+using G64v2 = Geo<64, 4, 4, 8, 1>;
 using G64v3 = Geo<64, 4, 4, 16, 0>;
 
 
