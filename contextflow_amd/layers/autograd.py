@@ -12,12 +12,9 @@ Backward walks the tape in reverse:
 Reference quirks carried into the gradients: ActNorm's ldj = +sum(logs) (d/dlogs gets sum_b g_ld), Conv1x1's
 ldj = H*W*log|det W| (d/dW gets sum_b g_ld * H*W * W^-T).  Covers the conv-coupling topologies (mnist, cifar10);
 TransCoupling has no backward yet.  Weight-gradient partial sums are combined in a fixed order (no float atomics)."""
-import math
-
 import torch
 
 from . import _hip
-from .distributions.gaussian import gmm_logprob
 from .squeeze import squeeze_op
 
 

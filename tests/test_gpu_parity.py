@@ -486,3 +486,31 @@ def test_graph_capture_matches_eager(L, name):
         _, eager2 = model(x2.to(DEV))
     assert (lp2 - eager2).abs().max().item() == 0.0
     assert (lp2 - logp).abs().max().item() > 0.0          # it really is a different result (static buffer was overwritten)
+
+
+def test_training_steps_reduce_the_loss(L):
+    """A few AdamW steps with the reference's classification loss (experiment_cl.py:127-133) through the hand-written
+    backward: the loss must go down and stay finite (end-to-end use of the gradients, squeeze-folded steps included)."""
+    import contextflow_amd as cfa
+    torch.manual_seed(0)
+    cfg, ds, M = cfa.preset_config("mnist")
+    model = cfa.create_model(cfg, ds, M).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    B = 96
+    gt = torch.randint(0, M, (B,), generator=g)
+    x = (torch.randint(0, 200, (B, *ds), generator=g).float() + 5.0 * gt.view(B, 1, 1, 1).float()).clamp(0, 255)
+    x, gt = x.to(DEV), gt.to(DEV)
+    with torch.no_grad():
+        model(x)                                         # ActNorm data-dependent init
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    dim_inv = 1.0 / (ds[0] * ds[1] * ds[2])
+    losses = []
+    for _ in range(12):
+        opt.zero_grad(set_to_none=True)
+        logp = dim_inv * model.log_prob(x)
+        loss = torch.nn.functional.cross_entropy(logp, gt) + 1e-3 * (-torch.nn.functional.logsigmoid(torch.logsumexp(logp, -1))).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(math.isfinite(v) for v in losses), losses
+    assert losses[-1] < losses[0] - 1e-3, losses
