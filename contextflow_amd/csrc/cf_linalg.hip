@@ -44,93 +44,98 @@ __global__ __launch_bounds__(256) void k_conv1x1(const float* __restrict__ x, co
     }
 }
 
-// In-place Gauss-Jordan with partial pivoting in fp64: log|det| = sum log|pivot|, inverse optional.
-// One block; C <= 64 (32 KiB of LDS).
+// log|det W| and (optionally) W^-1 of one C x C matrix, C <= 64: the per-call parameter work of Conv1x1
+// (reference conv1x1.py:21-31: torch.slogdet / torch.inverse on every forward / reverse call).
+//
+// A latency problem, not a throughput one (64 dependent pivot steps), so the matrix lives in REGISTERS:
+// lane = row, wave w owns the columns j = 4 jj + w (NJ = CMAX/4 doubles per lane, statically indexed: the
+// pivot loop is unrolled by template recursion).  Gaussian elimination in fp64 with IMPLICIT partial
+// pivoting - rows are never swapped, the pivot row index r is wave-uniform:
+//   * column k is broadcast to the 4 waves through a double-buffered 64-double LDS line (1 barrier / step);
+//   * every wave finds the pivot redundantly: 6 xor-shuffles of one 32-bit key (fp32 magnitude, low 6 bits =
+//     63 - lane so that ties go to the lowest row; a near-maximal pivot is as stable as the maximal one);
+//   * pivot-row operands come from v_readlane (SGPR operands of the fp64 FMAs), no LDS traffic.
+// INV: Gauss-Jordan on [A | I] (rows that already served as pivots keep being eliminated), the pivot-row
+// scaling is deferred to the store: W^-1[k][:] = E[r_k][:] / pivot_k.  log|det| = sum_k log|pivot_k|.
 constexpr int kMaxLU = 64;
 
-__global__ __launch_bounds__(256) void k_slogdet_inverse(const float* __restrict__ Wm, int C,
-                                                         float* __restrict__ logabsdet, float* __restrict__ inv) {
-    __shared__ double A[kMaxLU * kMaxLU];
-    __shared__ double colk[kMaxLU];
-    __shared__ int perm[kMaxLU];
-    __shared__ int prow;
-    __shared__ double lsum;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < C * C; e += 256) A[e] = (double)Wm[e];
-    if (tid == 0) lsum = 0.0;
-    __syncthreads();
-    for (int k = 0; k < C; ++k) {
-        if (tid == 0) {
-            int r = k; double best = fabs(A[k * C + k]);
-            for (int i = k + 1; i < C; ++i) { const double v = fabs(A[i * C + k]); if (v > best) { best = v; r = i; } }
-            prow = r; perm[k] = r;
-            lsum += log(best);
-        }
-        __syncthreads();
-        const int r = prow;
-        if (r != k) {
-            for (int j = tid; j < C; j += 256) { const double tmp = A[k * C + j]; A[k * C + j] = A[r * C + j]; A[r * C + j] = tmp; }
-        }
-        __syncthreads();
-        const double piv = A[k * C + k];
-        if (tid < C) colk[tid] = A[tid * C + k];             // column k before it is overwritten
-        __syncthreads();
-        // row k: A[k][k] = 1, then scale by 1/piv
-        for (int j = tid; j < C; j += 256) A[k * C + j] = ((j == k) ? 1.0 : A[k * C + j]) / piv;
-        __syncthreads();
-        // other rows: A[i][k] = 0, then A[i][:] -= f_i * A[k][:]
-        for (int e = tid; e < C * C; e += 256) {
-            const int i = e / C, j = e - i * C;
-            if (i == k) continue;
-            const double f = colk[i];
-            const double cur = (j == k) ? 0.0 : A[e];
-            A[e] = cur - f * A[k * C + j];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) logabsdet[0] = (float)lsum;
-    if (inv != nullptr) {
-        for (int k = C - 1; k >= 0; --k) {                   // undo the row swaps as column swaps
-            const int r = perm[k];
-            if (r != k) {
-                for (int i = tid; i < C; i += 256) { const double tmp = A[i * C + k]; A[i * C + k] = A[i * C + r]; A[i * C + r] = tmp; }
-            }
+__device__ __forceinline__ double readlane_f64(double v, int r) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), r);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), r);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NJ> struct LuState {
+    double a[NJ];      // A[lane][4 jj + w]
+    double e[NJ];      // E[lane][4 jj + w]  (INV only)
+    double piv;        // pivot of the step this row served in
+    int col;           // that step
+    bool used;
+};
+
+template <int CMAX, bool INV, int K>
+__device__ __forceinline__ void lu_steps(LuState<CMAX / 4>& s, double* colbuf, int C, int lane, int w) {
+    if constexpr (K < CMAX) {
+        constexpr int NJ = CMAX / 4;
+        if (K < C) {                                              // uniform
+            double* line = colbuf + (K & 1) * kMaxLU;
+            if (w == (K & 3)) line[lane] = s.a[K >> 2];
             __syncthreads();
+            const double ak = line[lane];
+            unsigned key = s.used ? 0u : ((__float_as_uint((float)fabs(ak)) & ~63u) | (unsigned)(63 - lane));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned ok = (unsigned)__shfl_xor((int)key, o, 64); key = ok > key ? ok : key; }
+            const int r = __builtin_amdgcn_readfirstlane(63 - (int)(key & 63u));
+            const double piv = readlane_f64(ak, r);
+            const bool self = lane == r;
+            const double f = (self || (!INV && s.used)) ? 0.0 : ak / piv;
+#pragma unroll
+            for (int jj = K >> 2; jj < NJ; ++jj) s.a[jj] = fma(-f, readlane_f64(s.a[jj], r), s.a[jj]);
+            if constexpr (INV) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) s.e[jj] = fma(-f, readlane_f64(s.e[jj], r), s.e[jj]);
+            }
+            if (self) { s.used = true; s.piv = ak; s.col = K; }
         }
-        for (int e = tid; e < C * C; e += 256) inv[e] = (float)A[e];
+        lu_steps<CMAX, INV, K + 1>(s, colbuf, C, lane, w);
     }
 }
 
-// log|det W| only (the per-call hot path of Conv1x1.forward): Gaussian elimination with IMPLICIT partial
-// pivoting in fp64.  The matrix sits column-major in LDS (lane = row: conflict-free), rows are never
-// swapped: the pivot row index r is wave-uniform, so its elements are read as LDS broadcasts.  Every
-// wave finds the pivot redundantly (6-shuffle argmax, no cross-wave traffic); the 4 waves split the
-// columns still to be updated; one barrier per step.  log|det| = sum log|pivot| (sign irrelevant).
-__global__ __launch_bounds__(256) void k_slogdet_lds(const float* __restrict__ Wm, int C, float* __restrict__ logabsdet) {
-    __shared__ double A[kMaxLU * kMaxLU];                       // A[j*64 + i] = W[i][j]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid; e < C * C; e += 256) { const int i = e / C, j = e - i * C; A[j * kMaxLU + i] = (double)Wm[e]; }
-    bool used = lane >= C;
-    double lsum = 0.0;
-    for (int k = 0; k < C; ++k) {
-        __syncthreads();                                        // column k is final, earlier updates visible
-        const double ak = A[k * kMaxLU + lane];
-        double best = used ? -1.0 : fabs(ak);
-        int bi = lane;
+template <int CMAX, bool INV>
+__global__ __launch_bounds__(256) void k_slogdet(const float* __restrict__ Wm, int C, float* __restrict__ logabsdet,
+                                                 float* __restrict__ inv) {
+    constexpr int NJ = CMAX / 4;
+    __shared__ double colbuf[2 * kMaxLU];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    LuState<NJ> s;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        const int r = __builtin_amdgcn_readfirstlane(bi);       // pivot row, identical in every lane and wave
-        lsum += log(best);
-        const double piv = A[k * kMaxLU + r];
-        const double f = (used || lane == r) ? 0.0 : ak / piv;
-        for (int j = k + 1 + w; j < C; j += 4) A[j * kMaxLU + lane] -= f * A[j * kMaxLU + r];
-        if (lane == r) used = true;
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int j = 4 * jj + w;
+        s.a[jj] = (lane < C && j < C) ? (double)Wm[lane * C + j] : 0.0;
+        s.e[jj] = (lane == j) ? 1.0 : 0.0;
     }
-    if (tid == 0) logabsdet[0] = (float)lsum;
+    s.used = lane >= C; s.piv = 1.0; s.col = 0;
+    lu_steps<CMAX, INV, 0>(s, colbuf, C, lane, w);
+    if (w == 0) {
+        const double l = cf_wave_sum_d(lane < C ? log(fabs(s.piv)) : 0.0);
+        if (lane == 0) logabsdet[0] = (float)l;
+    }
+    if constexpr (INV) {
+        if (lane < C) {
+            const double rp = 1.0 / s.piv;
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = 4 * jj + w;
+                if (j < C) inv[s.col * C + j] = (float)(s.e[jj] * rp);
+            }
+        }
+    }
+}
+
+template <int CMAX>
+void launch_slogdet(const float* Wm, int C, float* lad, float* inv, hipStream_t st) {
+    if (inv == nullptr) k_slogdet<CMAX, false><<<dim3(1), dim3(256), 0, st>>>(Wm, C, lad, nullptr);
+    else k_slogdet<CMAX, true><<<dim3(1), dim3(256), 0, st>>>(Wm, C, lad, inv);
 }
 
 }  // namespace
@@ -154,8 +159,10 @@ int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z,
 int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_stream_t stream) {
     CF_REQUIRE(Wm && logabsdet && C > 0);
     if (C > kMaxLU) { cf_set_error("cf_slogdet_inverse: C=%d > %d unsupported", C, kMaxLU); return CF_ERR_UNSUPPORTED; }
-    if (inv == nullptr) k_slogdet_lds<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet);
-    else k_slogdet_inverse<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet, inv);
+    if (C <= 8) launch_slogdet<8>(Wm, C, logabsdet, inv, cf_s(stream));
+    else if (C <= 16) launch_slogdet<16>(Wm, C, logabsdet, inv, cf_s(stream));
+    else if (C <= 32) launch_slogdet<32>(Wm, C, logabsdet, inv, cf_s(stream));
+    else launch_slogdet<64>(Wm, C, logabsdet, inv, cf_s(stream));
     CF_LAUNCH_CHECK();
     return 0;
 }
