@@ -492,7 +492,12 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
 
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                      int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
-    return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, 0, stream);
+    // Small batches are latency-bound by the serial work of ONE workgroup (a launch of < 256 workgroups leaves CUs
+    // idle anyway): pick the geometry with half the samples per workgroup (same packed-weight workspace).
+    int flags = 0;
+    const int sid = shape_id(C, H, W);
+    if ((sid == 2 && B < 256 * G32::SPW) || (sid == 3 && B < 256 * G64::SPW)) flags = 2 << 16;
+    return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, flags, stream);
 }
 
 }  // extern "C"
