@@ -8,8 +8,8 @@
 // MI355X design: the contraction index (pixel) must sit on the MFMA k axis, so both operands are staged in LDS
 // TRANSPOSED — T[pixel][channel] with an odd row stride: the global reads stay coalesced along pixels, the LDS
 // writes (lanes = consecutive pixels, stride odd) and the operand reads (lanes = consecutive channels) are both
-// bank-conflict free.  The 3x3 taps are nine B-operand reads of the same staged tile through an LDS index table
-// (reflect padding resolved once per workgroup).  A workgroup owns one 32-row tile of A and ALL columns / taps and
+// bank-conflict free.  The 3x3 taps are nine B-operand reads of the same staged tile; the reflected source
+// rows are scalar arithmetic (the k-step index is wave-uniform), the three source columns three VALU ops.  A workgroup owns one 32-row tile of A and ALL columns / taps and
 // keeps its <= 9 accumulator tiles per wave in registers over its whole K range; it writes its partial once with
 // plain coalesced stores and a small second kernel sums the partials in a fixed order (no float atomics: the
 // outputs are tiny and shared by every workgroup, and the result stays bitwise reproducible).  Output layout
@@ -19,6 +19,117 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Operands of one k-step (pixels 2s, 2s+1) for all taps.  s is wave-uniform, so the sample base and the (reflected)
+// source rows of the 3 vertical taps are scalar; only the 3 horizontal sources depend on the lane half.
+template <int TAPS> struct WgOps { float a; float b[TAPS]; };
+
+// LDS float offsets of the operands of k-step s: ad[0] = A, ad[1 + t] = B of tap t
+template <int H, int W, int TAPS, int SA, int SB>
+__device__ __forceinline__ void wg_addr(int (&ad)[TAPS + 1], int offTB, int s, int li, int lk, int ncol) {
+    constexpr int HW = H * W;
+    const int pix0 = 2 * s;                                   // scalar; W >= 4 is even: pix0 and pix0 + 1 share a row
+    ad[0] = (pix0 + lk) * SA + li;
+    if constexpr (TAPS == 1) {
+        ad[1] = offTB + (pix0 + lk) * SB + ncol;
+    } else {
+        const int p = pix0 & (HW - 1), base = pix0 - p, y = p / W, x = (p & (W - 1)) + lk;
+        int rowoff[3], coloff[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            int yy = y + d - 1; yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+            int xx = x + d - 1; xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+            rowoff[d] = offTB + (base + yy * W) * SB;         // scalar
+            coloff[d] = xx * SB + ncol;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ad[1 + t] = rowoff[t / 3] + coloff[t % 3];
+    }
+}
+
+template <int TAPS>
+__device__ __forceinline__ void wg_load(WgOps<TAPS>& o, const float* __restrict__ lds, const int (&ad)[TAPS + 1]) {
+    o.a = lds[ad[0]];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) o.b[t] = lds[ad[1 + t]];
+}
+
+template <int TAPS>
+__device__ __forceinline__ void wg_mma(f32x16 (&acc)[TAPS], const WgOps<TAPS>& o, float& bsum) {
+    bsum += o.a;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a, o.b[t], acc[t], 0, 0, 0);
+}
+
+// ---- 3x3 path ---------------------------------------------------------------------------------------------
+// Measured on gfx950 (tools/micro/mfma_issue.hip): VALU instructions never overlap the MFMAs of their SIMD (the
+// first one after an MFMA costs ~16 cycles, each further one ~4.5; SALU and LDS instructions are free), so the K
+// loop is built to need almost none:
+//   * a wave owns whole image rows: the source rows of the three vertical taps are scalar (reflect on the SALU), the
+//     W/2 k-steps of a row are unrolled, so every operand is `row register + immediate`: 5 v_add per row;
+//   * the horizontal reflect costs nothing: at the left border the dx=-1 operand (columns 1,0) is the dx=0 operand
+//     with the two k-halves swapped, and swapping the halves of B equals swapping those of A - one extra A read
+//     (`as`) instead of lane selects; same at the right border for dx=+1;
+//   * operand reads of k-step j+1 are issued as one batch before the MFMAs of step j (one VALU<->MFMA switch a step).
+struct WgRow { int a, as, b[3]; };                    // LDS byte offsets of a row's operands, lane part included
+struct WgOps9 { float a, as, b[9]; };
+
+__device__ __forceinline__ float wg_ldf(const char* ldsb, int off) { return *reinterpret_cast<const float*>(ldsb + off); }
+
+template <int H, int W, int SA, int SB>
+__device__ __forceinline__ void wg_row_addr(WgRow& r, int g, int offTBb, int laneA, int laneAs, int laneB) {
+    const int smp = g / H, y = g - smp * H, base = smp * (H * W);     // scalar
+    r.a = (base + y * W) * (SA * 4) + laneA;
+    r.as = (base + y * W) * (SA * 4) + laneAs;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int yy = y + d - 1; yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+        r.b[d] = offTBb + (base + yy * W) * (SB * 4) + laneB;
+    }
+}
+
+template <int W, int XS> constexpr bool wg_swapped(int dx) { return (2 * XS == 0 && dx == -1) || (2 * XS == W - 2 && dx == 1); }
+
+template <int W, int SA, int SB, int XS>
+__device__ __forceinline__ void wg_row_load(WgOps9& o, const char* ldsb, const WgRow& r) {
+    constexpr int x0 = 2 * XS;
+    o.a = wg_ldf(ldsb, r.a + x0 * SA * 4);
+    if constexpr (x0 == 0 || x0 == W - 2) o.as = wg_ldf(ldsb, r.as + x0 * SA * 4);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx)
+            if (!wg_swapped<W, XS>(dx)) o.b[dy * 3 + dx + 1] = wg_ldf(ldsb, r.b[dy] + (x0 + dx) * SB * 4);
+}
+
+template <int W, int XS>
+__device__ __forceinline__ void wg_row_mma(f32x16 (&acc)[9], const WgOps9& o, float& bsum) {
+    bsum += o.a;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int t = dy * 3 + dx + 1;
+            if (wg_swapped<W, XS>(dx)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.as, o.b[dy * 3 + 1], acc[t], 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a, o.b[t], acc[t], 0, 0, 0);
+        }
+}
+
+// the W/2 k-steps of one row; operands alternate between o0 / o1 (W/2 is even), the last step prefetches the next row
+template <int W, int SA, int SB, int XS>
+__device__ __forceinline__ void wg_row_steps(f32x16 (&acc)[9], WgOps9& o0, WgOps9& o1, const char* ldsb, const WgRow& cur,
+                                             const WgRow& nxt, float& bsum) {
+    if constexpr (XS < W / 2) {
+        WgOps9& use = (XS & 1) ? o1 : o0;
+        WgOps9& fill = (XS & 1) ? o0 : o1;
+        if constexpr (XS + 1 < W / 2) wg_row_load<W, SA, SB, XS + 1>(fill, ldsb, cur);
+        else wg_row_load<W, SA, SB, 0>(fill, ldsb, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        wg_row_mma<W, XS>(acc, use, bsum);
+        __builtin_amdgcn_sched_barrier(0);
+        wg_row_steps<W, SA, SB, XS + 1>(acc, o0, o1, ldsb, cur, nxt, bsum);
+    }
+}
 
 // NT = 32-column tiles of Bm (1, 2 or 4); the 4 waves split (column tile) x (K quarter): KW = 4 / NT
 template <int H, int W, int TAPS, int NT>
@@ -33,21 +144,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     extern __shared__ __align__(16) float lds[];
     float* TA = lds;                                  // [KC][SA]   A tile, transposed
     float* TB = lds + KC * SA;                        // [KC][SB]   B tile, transposed
-    int* tab = reinterpret_cast<int*>(TB + KC * SB);  // [TAPS][KC] source pixel of every tap
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
-    const int nt = wave % NT, kq = wave / NT;
+    const int nt = wave % NT, kq = __builtin_amdgcn_readfirstlane(wave / NT);
     const int m0 = blockIdx.x * 32;
 
-    for (int e = tid; e < TAPS * KC; e += 256) {
-        const int t = e / KC, pix = e - t * KC, p = pix % HW;
-        int yy = p / W, xx = p % W;
-        if (TAPS == 9) {
-            yy += t / 3 - 1; xx += t % 3 - 1;
-            yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
-            xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-        }
-        tab[e] = (pix - p) + yy * W + xx;
-    }
     f32x16 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -55,44 +155,97 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;                                 // row sum of A (= the bias gradient), lanes of column tile 0
 
-    // global -> registers (lanes along pixels: coalesced); one chunk ahead of the MFMAs
+    // global -> registers (lanes along pixels: coalesced); one chunk ahead of the MFMAs.  Element i of thread tid is
+    // channel i*(256/KC) + tid/KC (wave-uniform), pixel tid % KC: a scalar row base + a lane offset that does not
+    // depend on the chunk - no vector address arithmetic per load.  Rows / columns past MR / NR are clamped (their
+    // products land in accumulator rows / columns that are never stored); samples past B are clamped and the A
+    // operand zeroed.
+    constexpr int CPI = 256 / KC;                     // channels per staging iteration (1 or 4)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int chw = CPI == 1 ? 0 : wv / (KC / 64);    // channel offset of this wave inside an iteration
+    const int pixl = tid % KC, sj = pixl / HW, pl = pixl % HW;
     float ra[IA], rb[IB];
     auto gload = [&](int c) {
         const int s0 = c * SPC;
+        int sjc = sj;
+        if constexpr (SPC > 1) sjc = min(sj, B - 1 - s0);
+        const int offA = sjc * MR * HW + pl, offB = sjc * NR * HW + pl;
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const int e = i * 256 + tid, ch = e / KC, pix = e - ch * KC, b = s0 + pix / HW, m = m0 + ch;
-            ra[i] = (m < MR && b < B) ? A[((int64_t)b * MR + m) * HW + pix % HW] : 0.f;
+            const int m = min(m0 + i * CPI + chw, MR - 1);
+            const float* rowp = A + ((int64_t)s0 * MR + m) * HW;
+            ra[i] = rowp[offA];
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            const int e = i * 256 + tid, ch = e / KC, pix = e - ch * KC, b = s0 + pix / HW;
-            rb[i] = (ch < NR && b < B) ? Bm[((int64_t)b * NR + ch) * HW + pix % HW] : 0.f;
+            const int n = min(i * CPI + chw, NR - 1);
+            const float* rowp = Bm + ((int64_t)s0 * NR + n) * HW;
+            rb[i] = rowp[offB];
+        }
+        if constexpr (SPC > 1) {
+            const float valid = (sj <= B - 1 - s0) ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) ra[i] *= valid;
         }
     };
     const int nchunks = (B + SPC - 1) / SPC;
     int c = blockIdx.y;
     if (c < nchunks) gload(c);
     for (; c < nchunks; c += gridDim.y) {
-        __syncthreads();                              // previous chunk consumed (and tab written)
+        __syncthreads();                              // previous chunk consumed
         // registers -> LDS, transposed (lanes = consecutive pixels, odd stride: conflict-free)
 #pragma unroll
-        for (int i = 0; i < IA; ++i) { const int e = i * 256 + tid, ch = e / KC, pix = e - ch * KC; TA[pix * SA + ch] = ra[i]; }
+        for (int i = 0; i < IA; ++i) TA[pixl * SA + chw + i * CPI] = ra[i];
 #pragma unroll
-        for (int i = 0; i < IB; ++i) { const int e = i * 256 + tid, ch = e / KC, pix = e - ch * KC; TB[pix * SB + ch] = rb[i]; }
+        for (int i = 0; i < IB; ++i) TB[pixl * SB + chw + i * CPI] = rb[i];
         __syncthreads();
         if (c + (int)gridDim.y < nchunks) gload(c + gridDim.y);       // next chunk in flight behind the MFMAs
-        // K loop: k-step s covers pixels 2s, 2s+1; this wave takes the steps s = kq (mod KW)
-#pragma unroll 2
-        for (int s = kq; s < KC / 2; s += KW) {
-            const int pix = 2 * s + lk;
-            const float a = TA[pix * SA + li];                       // A[i = m][k = pixel]
-            bsum += a;
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const float b = TB[tab[t * KC + pix] * SB + nt * 32 + li];   // B[k = pixel][j = n], tap-shifted
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        constexpr int offTB = KC * SA;
+        const int ncol = nt * 32 + li;
+        if constexpr (TAPS == 9) {
+            // this wave takes the image rows g = kq (mod KW) of the chunk's SPC samples
+            constexpr int ROWS = SPC * H;
+            static_assert(ROWS % KW == 0 && (W / 2) % 2 == 0, "rows split evenly; even number of k-steps per row");
+            const char* ldsb = reinterpret_cast<const char*>(lds);
+            const int laneA = (lk * SA + li) * 4, laneAs = ((1 - lk) * SA + li) * 4, laneB = (lk * SB + ncol) * 4;
+            WgOps9 o0, o1;
+            WgRow cur, nxt;
+            wg_row_addr<H, W, SA, SB>(cur, kq, offTB * 4, laneA, laneAs, laneB);
+            wg_row_load<W, SA, SB, 0>(o0, ldsb, cur);
+#pragma unroll 1
+            for (int g = kq; g < ROWS; g += KW) {
+                const int gn = g + KW < ROWS ? g + KW : kq;           // scalar select, no branch (see below)
+                wg_row_addr<H, W, SA, SB>(nxt, gn, offTB * 4, laneA, laneAs, laneB);
+                wg_row_steps<W, SA, SB, 0>(acc, o0, o1, ldsb, cur, nxt, bsum);
+                cur = nxt;
             }
+        } else {
+            // 1x1: bound by the staging.  k-step s covers pixels 2s, 2s+1; this wave takes s = kq (mod KW); two plain
+            // stages, no branch inside the loop (a join would force lgkmcnt(0)).
+            constexpr int NS = KC / 2 / KW;
+            static_assert(NS % 2 == 0, "even number of k-steps per wave");
+            WgOps<TAPS> o0, o1;
+            int ad[TAPS + 1];
+            wg_addr<H, W, TAPS, SA, SB>(ad, offTB, kq, li, lk, ncol);
+            wg_load<TAPS>(o0, lds, ad);
+            wg_addr<H, W, TAPS, SA, SB>(ad, offTB, kq + KW, li, lk, ncol);
+#pragma unroll 1
+            for (int i = 0; i < NS - 2; i += 2) {
+                wg_load<TAPS>(o1, lds, ad);
+                wg_addr<H, W, TAPS, SA, SB>(ad, offTB, kq + (i + 2) * KW, li, lk, ncol);
+                __builtin_amdgcn_sched_barrier(0);
+                wg_mma<TAPS>(acc, o0, bsum);
+                __builtin_amdgcn_sched_barrier(0);
+                wg_load<TAPS>(o0, lds, ad);
+                wg_addr<H, W, TAPS, SA, SB>(ad, offTB, kq + (i + 3) * KW, li, lk, ncol);
+                __builtin_amdgcn_sched_barrier(0);
+                wg_mma<TAPS>(acc, o1, bsum);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wg_load<TAPS>(o1, lds, ad);
+            __builtin_amdgcn_sched_barrier(0);
+            wg_mma<TAPS>(acc, o0, bsum);
+            wg_mma<TAPS>(acc, o1, bsum);
         }
     }
     // combine the KW K-quarters of this workgroup in LDS, in a fixed order (deterministic), into the kq == 0 waves
@@ -168,7 +321,7 @@ inline int wgrad_splits(int B, int MR, int HW) {
 template <int H, int W, int TAPS, int NT>
 int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s) {
     constexpr int HW = H * W, KC = HW >= 64 ? HW : 64, KW = 4 / NT;
-    constexpr size_t lds_main = (size_t)(KC * 33 + KC * (NT * 32 + 1) + TAPS * KC) * 4;
+    constexpr size_t lds_main = (size_t)(KC * 33 + KC * (NT * 32 + 1)) * 4;
     constexpr size_t lds_comb = KW > 1 ? (size_t)(NT * TAPS * 1024 + NT * 64) * 4 : 0;
     constexpr size_t lds = lds_main > lds_comb ? lds_main : lds_comb;
     if (lds > 64 * 1024) {

@@ -514,3 +514,28 @@ def test_training_steps_reduce_the_loss(L):
         losses.append(float(loss))
     assert all(math.isfinite(v) for v in losses), losses
     assert losses[-1] < losses[0] - 1e-3, losses
+
+
+@pytest.mark.parametrize("H,MR,NR,taps,B", [(16, 32, 32, 9, 5), (16, 16, 16, 9, 3), (8, 64, 64, 9, 7), (8, 32, 32, 9, 6),
+                                            (4, 128, 128, 9, 9), (4, 64, 64, 9, 6), (4, 64, 64, 9, 2), (16, 16, 32, 1, 4),
+                                            (8, 64, 16, 1, 5), (4, 128, 32, 1, 7), (4, 24, 40, 1, 3)])
+def test_wgrad_gemm_against_torch(L, H, MR, NR, taps, B):
+    """cf_wgrad: gw[t][m][n] = sum_{b,p} A[b][m][p] * Bm[b][n][reflect-shifted p] and gbias[m] = sum A, against the
+    weight / bias gradient of torch's conv2d over a reflect-padded input in fp64 (ragged tiles, tail chunks)."""
+    from contextflow_amd.layers import _hip
+    g = torch.Generator().manual_seed(H * 1000 + MR + NR + taps + B)
+    A = torch.randn(B, MR, H, H, generator=g)
+    Bm = torch.randn(B, NR, H, H, generator=g)
+    w = torch.zeros(MR, NR, 3 if taps == 9 else 1, 3 if taps == 9 else 1, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(MR, dtype=torch.float64, requires_grad=True)
+    xin = torch.nn.functional.pad(Bm.double(), (1, 1, 1, 1), mode="reflect") if taps == 9 else Bm.double()
+    (torch.nn.functional.conv2d(xin, w, bias) * A.double()).sum().backward()
+    ref_w = w.grad.permute(2, 3, 0, 1).reshape(taps, MR, NR)
+    Ad, Bd = A.reshape(B, MR, H * H).to(DEV), Bm.reshape(B, NR, H * H).to(DEV)
+    gw = torch.empty(taps, MR, NR, device=DEV)
+    gb = torch.empty(MR, device=DEV)
+    ws = torch.empty(_hip.lib().cf_wgrad_ws_bytes(B, MR, NR, H, H, taps), device=DEV, dtype=torch.uint8)
+    _hip.call("cf_wgrad", _hip.p(Ad), _hip.p(Bd), _hip.p(gw), _hip.p(gb), _hip.p(ws), B, MR, NR, H, H, taps, _hip.stream())
+    scale = ref_w.abs().max().item()
+    assert (gw.cpu().double() - ref_w).abs().max().item() < 1e-5 * scale + 1e-4
+    assert (gb.cpu().double() - bias.grad).abs().max().item() < 1e-4 * bias.grad.abs().max().item() + 1e-4
