@@ -164,23 +164,38 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int chw = CPI == 1 ? 0 : wv / (KC / 64);    // channel offset of this wave inside an iteration
     const int pixl = tid % KC, sj = pixl / HW, pl = pixl % HW;
+    const bool fullA = m0 + 32 <= MR, fullB = NT * 32 <= NR;
     float ra[IA], rb[IB];
     auto gload = [&](int c) {
         const int s0 = c * SPC;
         int sjc = sj;
         if constexpr (SPC > 1) sjc = min(sj, B - 1 - s0);
-        const int offA = sjc * MR * HW + pl, offB = sjc * NR * HW + pl;
+        const unsigned offA = sjc * MR * HW + pl, offB = sjc * NR * HW + pl;
+        if (fullA) {                                  // whole 32-row tile: one vector base, immediate row offsets
+            const float* pa = A + ((int64_t)s0 * MR + m0 + chw) * HW + offA;
 #pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const int m = min(m0 + i * CPI + chw, MR - 1);
-            const float* rowp = A + ((int64_t)s0 * MR + m) * HW;
-            ra[i] = rowp[offA];
+            for (int i = 0; i < IA; ++i) ra[i] = pa[i * CPI * HW];
+        } else {
+            int m0v = m0, mrv = MR;
+            asm volatile("" : "+s"(m0v), "+s"(mrv));  // keep the row bases out of LICM (live SGPRs spill to lanes)
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                const float* rowp = A + ((int64_t)s0 * MR + min(m0v + i * CPI + chw, mrv - 1)) * HW;
+                ra[i] = rowp[offA];
+            }
         }
+        if (fullB) {
+            const float* pb = Bm + ((int64_t)s0 * NR + chw) * HW + offB;
 #pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            const int n = min(i * CPI + chw, NR - 1);
-            const float* rowp = Bm + ((int64_t)s0 * NR + n) * HW;
-            rb[i] = rowp[offB];
+            for (int i = 0; i < IB; ++i) rb[i] = pb[i * CPI * HW];
+        } else {
+            int nrv = NR;
+            asm volatile("" : "+s"(nrv));
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const float* rowp = Bm + ((int64_t)s0 * NR + min(i * CPI + chw, nrv - 1)) * HW;
+                rb[i] = rowp[offB];
+            }
         }
         if constexpr (SPC > 1) {
             const float valid = (sj <= B - 1 - s0) ? 1.f : 0.f;
@@ -188,18 +203,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
             for (int i = 0; i < IA; ++i) ra[i] *= valid;
         }
     };
+    // Software pipeline over this workgroup's chunks: the loads of chunk k+1 are issued, then the MFMAs of chunk k
+    // (operands in LDS) run in front of them, then chunk k+1 goes registers -> LDS.  One gload / one MFMA site.
     const int nchunks = (B + SPC - 1) / SPC;
-    int c = blockIdx.y;
-    if (c < nchunks) gload(c);
-    for (; c < nchunks; c += gridDim.y) {
-        __syncthreads();                              // previous chunk consumed
-        // registers -> LDS, transposed (lanes = consecutive pixels, odd stride: conflict-free)
-#pragma unroll
-        for (int i = 0; i < IA; ++i) TA[pixl * SA + chw + i * CPI] = ra[i];
-#pragma unroll
-        for (int i = 0; i < IB; ++i) TB[pixl * SB + chw + i * CPI] = rb[i];
-        __syncthreads();
-        if (c + (int)gridDim.y < nchunks) gload(c + gridDim.y);       // next chunk in flight behind the MFMAs
+    bool have = false;                                // LDS holds a chunk
+    for (int cn = blockIdx.y;; cn += gridDim.y) {
+        const bool more = cn < nchunks;
+        if (more) gload(cn);
+        if (have) {
         constexpr int offTB = KC * SA;
         const int ncol = nt * 32 + li;
         if constexpr (TAPS == 9) {
@@ -247,6 +258,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
             wg_mma<TAPS>(acc, o0, bsum);
             wg_mma<TAPS>(acc, o1, bsum);
         }
+        }
+        if (!more) break;
+        __syncthreads();                              // previous chunk consumed
+        // registers -> LDS, transposed (lanes = consecutive pixels, odd stride: conflict-free)
+#pragma unroll
+        for (int i = 0; i < IA; ++i) TA[pixl * SA + chw + i * CPI] = ra[i];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) TB[pixl * SB + chw + i * CPI] = rb[i];
+        __syncthreads();
+        have = true;
     }
     // combine the KW K-quarters of this workgroup in LDS, in a fixed order (deterministic), into the kq == 0 waves
     if (KW > 1) {
