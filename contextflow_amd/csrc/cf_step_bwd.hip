@@ -88,6 +88,73 @@ __device__ __forceinline__ void tiles_to_plane(const f32x16 (&acc)[RT][G::PTW], 
             }
 }
 
+// ---- adjoint of the reflect-padded 3x3 gather (g_h2 -> g_h1) --------------------------------------------------
+// Output pixel p of tap d = (dy,dx) collects every source o with reflect(o + d) = p: the main source o = p - d (if
+// inside the image) plus, per axis, the border pixel whose reflection lands on p (row 0 for p in row 1 with dy = -1,
+// row H-1 for row H-2 with dy = +1; same for columns).  The number of candidate sources is a property of the tap:
+// 1 (centre), 2 (edge taps) or 4 (corner taps) - one code path per class (NS) instead of four masked reads for
+// every tap.  VALU work never overlaps the MFMAs of its SIMD (tools/micro/mfma_issue.hip), so the 0/1-weighted sums
+// run as ONE batch per 4-k-step group, and the LDS reads of group cg+1 are issued before the MFMAs of group cg.
+template <class G, int NS>
+__device__ __forceinline__ void adj_issue(float (&raw)[G::PTW][4][NS], float4 (&a)[G::RT1], const float4* __restrict__ fr,
+                                          const float* __restrict__ lds, const int (&off)[G::PTW][NS], int cg, int lane) {
+#pragma unroll
+    for (int rt = 0; rt < G::RT1; ++rt) a[rt] = fr[(cg * G::RT1 + rt) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < G::PTW; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) raw[q][e][j] = lds[off[q][j] + (8 * cg + 2 * e) * G::PIX];
+}
+
+template <class G, int NS>
+__device__ __forceinline__ void adj_combine(GroupOps<G::RT1, G::PTW>& o, const float (&raw)[G::PTW][4][NS],
+                                            const float4 (&a)[G::RT1], const float (&wgt)[G::PTW][NS]) {
+#pragma unroll
+    for (int rt = 0; rt < G::RT1; ++rt) o.a[rt] = a[rt];
+#pragma unroll
+    for (int q = 0; q < G::PTW; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (NS == 1) o.b[e][q] = raw[q][e][0];
+            else {
+                float v = wgt[q][0] * raw[q][e][0];
+#pragma unroll
+                for (int j = 1; j < NS; ++j) v = fmaf(wgt[q][j], raw[q][e][j], v);
+                o.b[e][q] = v;
+            }
+        }
+}
+
+template <class G, int NS>
+__device__ __forceinline__ void adj_tap(f32x16 (&acc)[G::RT1][G::PTW], const float4* __restrict__ fr,
+                                        const float* __restrict__ lds, const int (&off)[G::PTW][NS],
+                                        const float (&wgt)[G::PTW][NS], int lane) {
+    float raw[G::PTW][4][NS];
+    float4 a[2][G::RT1];
+    adj_issue<G, NS>(raw, a[0], fr, lds, off, 0, lane);
+#pragma unroll
+    for (int cg = 0; cg < G::NCG; ++cg) {
+        GroupOps<G::RT1, G::PTW> o;
+        adj_combine<G, NS>(o, raw, a[cg & 1], wgt);
+        if (cg + 1 < G::NCG) adj_issue<G, NS>(raw, a[(cg + 1) & 1], fr, lds, off, cg + 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        group_mma<G::RT1, G::PTW>(acc, o, 4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// candidate sources of output coordinate c along one axis of size N for tap shift d: [0] main, [1] reflected border
+__device__ __forceinline__ void adj_axis(int c, int d, int N, int (&src)[2], bool (&ok)[2]) {
+    const int m = c - d;
+    ok[0] = m >= 0 && m < N;
+    src[0] = ok[0] ? m : 0;
+    const int e = (d == -1 && c == 1) ? 0 : ((d == 1 && c == N - 2) ? N - 1 : -1);
+    ok[1] = e >= 0;
+    src[1] = ok[1] ? e : 0;
+}
+
 template <class G, bool SQ>
 __global__ __launch_bounds__(256) void k_flow_step_bwd(
     const float* __restrict__ x, const float* __restrict__ gz, const float* __restrict__ gld,
@@ -288,48 +355,56 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][q][r] = 0.f;
         const float4* frags = reinterpret_cast<const float4*>(wsb + Bw::OFF_A2T);
+        constexpr int TAPF = G::NCG * RT1 * 64;              // float4 fragments per tap
+        int py[PTW], px[PTW], base[PTW];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) { py[q] = pin[q] / W; px[q] = pin[q] % W; base[q] = HALF * PIX + (pix[q] - pin[q]) + lk * PIX; }
+        {   // centre tap: the pixel itself
+            int off[PTW][1];
+            float wgt[PTW][1];
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) { off[q][0] = base[q] + pin[q]; wgt[q][0] = 1.f; }
+            adj_tap<G, 1>(acc, frags + 4 * TAPF, lds, off, wgt, lane);
+        }
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        for (int k = 0; k < 4; ++k) {                        // edge taps 1, 3, 5, 7: main + one reflected source
+            const int tap = 2 * k + 1, dy = tap / 3 - 1, dx = tap % 3 - 1;
+            int off[PTW][2];
+            float wgt[PTW][2];
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                int ys[2], xs[2];
+                bool yv[2], xv[2];
+                adj_axis(py[q], dy, H, ys, yv);
+                adj_axis(px[q], dx, W, xs, xv);
+                const bool vert = dy != 0;                   // scalar
+                off[q][0] = base[q] + ys[0] * W + xs[0];
+                wgt[q][0] = (yv[0] && xv[0]) ? 1.f : 0.f;
+                off[q][1] = base[q] + (vert ? ys[1] : ys[0]) * W + (vert ? xs[0] : xs[1]);
+                wgt[q][1] = (vert ? (yv[1] && xv[0]) : (yv[0] && xv[1])) ? 1.f : 0.f;
+            }
+            adj_tap<G, 2>(acc, frags + tap * TAPF, lds, off, wgt, lane);
+        }
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {                        // corner taps 0, 2, 6, 8: up to four sources
+            const int tap = (k >> 1) * 6 + (k & 1) * 2, dy = tap / 3 - 1, dx = tap % 3 - 1;
             int off[PTW][4];
             float wgt[PTW][4];
 #pragma unroll
             for (int q = 0; q < PTW; ++q) {
-                const int py = pin[q] / W, px = pin[q] % W;
-                const int ym = py - dy, xm = px - dx;                       // main source
-                const bool ymv = ym >= 0 && ym < H, xmv = xm >= 0 && xm < W;
-                const int ye = (dy == -1 && py == 1) ? 0 : ((dy == 1 && py == H - 2) ? H - 1 : -1);   // reflected border source
-                const int xe = (dx == -1 && px == 1) ? 0 : ((dx == 1 && px == W - 2) ? W - 1 : -1);
-                const int base = HALF * PIX + (pix[q] - pin[q]) + lk * PIX;
-                const int ys[2] = {ymv ? ym : 0, ye >= 0 ? ye : 0}, xs[2] = {xmv ? xm : 0, xe >= 0 ? xe : 0};
-                const bool yv[2] = {ymv, ye >= 0}, xv[2] = {xmv, xe >= 0};
+                int ys[2], xs[2];
+                bool yv[2], xv[2];
+                adj_axis(py[q], dy, H, ys, yv);
+                adj_axis(px[q], dx, W, xs, xv);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        off[q][2 * a + b] = base + ys[a] * W + xs[b];
+                        off[q][2 * a + b] = base[q] + ys[a] * W + xs[b];
                         wgt[q][2 * a + b] = (yv[a] && xv[b]) ? 1.f : 0.f;
                     }
             }
-            const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
-#pragma unroll
-            for (int cg = 0; cg < G::NCG; ++cg) {
-                GroupOps<RT1, PTW> o;
-#pragma unroll
-                for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[(cg * RT1 + rt) * 64 + lane];
-#pragma unroll
-                for (int q = 0; q < PTW; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int ko = (8 * cg + 2 * e) * PIX;
-                        float v = wgt[q][0] * lds[off[q][0] + ko];
-                        v = fmaf(wgt[q][1], lds[off[q][1] + ko], v);
-                        v = fmaf(wgt[q][2], lds[off[q][2] + ko], v);
-                        v = fmaf(wgt[q][3], lds[off[q][3] + ko], v);
-                        o.b[e][q] = v;
-                    }
-                group_mma<RT1, PTW>(acc, o, 4);
-            }
+            adj_tap<G, 4>(acc, frags + tap * TAPF, lds, off, wgt, lane);
         }
         __syncthreads();                 // everyone done reading g_h2
 #pragma unroll
