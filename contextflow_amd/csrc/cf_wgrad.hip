@@ -134,7 +134,7 @@ __device__ __forceinline__ void wg_row_steps(f32x16 (&acc)[9], WgOps9& o0, WgOps
 // NT = 32-column tiles of Bm (1, 2 or 4); the 4 waves split (column tile) x (K quarter): KW = 4 / NT
 template <int H, int W, int TAPS, int NT>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, const float* __restrict__ Bm,
-                                               float* __restrict__ gw, float* __restrict__ gbias, int B, int MR, int NR) {
+                                               float* __restrict__ part, int B, int MR, int NR) {
     constexpr int HW = H * W;
     constexpr int KC = HW >= 64 ? HW : 64;            // pixels per chunk (whole samples)
     constexpr int SPC = KC / HW;                      // samples per chunk
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     // shared output would serialise at the memory side — and would not be reproducible).
     if (kq != 0) return;
     const int n = nt * 32 + li;
-    float* pw = gw + (int64_t)blockIdx.y * TAPS * MR * NR;
+    float* pw = part + (int64_t)blockIdx.y * (TAPS * MR * NR + MR);        // this split's partial: [TAPS][MR][NR] | [MR]
     if (n < NR) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
@@ -308,12 +308,14 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     }
     if (nt == 0) {                                    // every A element is seen once by the waves of column tile 0
         bsum += __shfl_xor(bsum, 32, 64);
-        if (lk == 0 && m0 + li < MR) gbias[(int64_t)blockIdx.y * MR + m0 + li] = bsum;
+        if (lk == 0 && m0 + li < MR) pw[TAPS * MR * NR + m0 + li] = bsum;
     }
 }
 
-// out[e] = sum_s part[s][e] in a fixed order: a wave covers 64 consecutive outputs, the 4 waves of a block split S
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ out, int n, int S) {
+// out[e] = sum_s part[s][e] in a fixed order: a wave covers 64 consecutive outputs, the 4 waves of a block split S.
+// The first n0 outputs go to out0 (weights), the rest to out1 (bias; may be null).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ out0,
+                                                      float* __restrict__ out1, int n0, int n, int S) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
@@ -328,7 +330,11 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     }
     red[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (w == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (w == 0 && e < n) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (e < n0) out0[e] = v;
+        else if (out1 != nullptr) out1[e - n0] = v;
+    }
 }
 
 inline int wgrad_splits(int B, int MR, int HW) {
@@ -356,11 +362,9 @@ int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float
     const int mtiles = (MR + 31) / 32;
     const int splits = wgrad_splits(B, MR, HW);
     const int S = splits, nw = TAPS * MR * NR;
-    float* pw = ws;                                   // [S][TAPS][MR][NR]
-    float* pb = ws + (int64_t)S * nw;                 // [S][MR]
-    k_wgrad<H, W, TAPS, NT><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, pw, pb, B, MR, NR);
-    k_wgrad_reduce<<<dim3((nw + 63) / 64), dim3(256), 0, s>>>(pw, gw, nw, S);
-    if (gbias) k_wgrad_reduce<<<dim3((MR + 63) / 64), dim3(256), 0, s>>>(pb, gbias, MR, S);
+    // partials: [S][TAPS*MR*NR + MR] (weights | bias of one split contiguous: ONE reduce launch)
+    k_wgrad<H, W, TAPS, NT><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, ws, B, MR, NR);
+    k_wgrad_reduce<<<dim3((nw + MR + 63) / 64), dim3(256), 0, s>>>(ws, gw, gbias, nw, nw + MR, S);
     return 0;
 }
 
