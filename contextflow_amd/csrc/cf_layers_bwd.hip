@@ -1,0 +1,246 @@
+// Backward kernels of the layer-by-layer path (TransCoupling's SimpleViT conditioner, generic ActNorm / affine map):
+// what the training step (experiment_ad.py:207-213: loss.backward()) needs besides the fused conv-flow backward.
+//
+// All of them are small HBM- / latency-bound VALU kernels over token-major (rows, dim) or NCHW tensors; the dense
+// contractions of the Linear layers' backward (gX = gY W, gW = gY^T X) are plain GEMMs and stay with the library
+// (torch.matmul -> hipBLASLt), as the scope rules allow.  Parameter gradients that are reductions over rows are
+// produced as per-workgroup partial sums in a fixed order (no float atomics: reproducible); the host sums the few
+// hundred partial rows.
+#include "cf_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kLnBlocks = 256;      // partial-sum rows of cf_layernorm_bwd
+constexpr int kLnMaxPer = 8;        // features per lane: dim <= 128
+
+// LayerNorm backward (biased variance, eps; forward: simple_vit.py:33,50,74,104-106).  16 lanes per row, 16 rows per
+// pass, grid-stride over row groups.  gx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat));
+// partial[blk][j] = sum_rows gy*xhat, partial[blk][dim + j] = sum_rows gy.
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ gy, float* __restrict__ gx,
+                                                       float* __restrict__ part, int rows, int dim, float eps) {
+    __shared__ float red[16][2 * 128];
+    const int g = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    float aw[kLnMaxPer], ab[kLnMaxPer];
+#pragma unroll
+    for (int i = 0; i < kLnMaxPer; ++i) { aw[i] = 0.f; ab[i] = 0.f; }
+    const float inv = 1.0f / (float)dim;
+    for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < rows; r0 += (int64_t)gridDim.x * 16) {
+        const int64_t row = r0 + rg;
+        const bool ok = row < rows;
+        const float* xr = x + (ok ? row : 0) * dim;
+        const float* gr = gy + (ok ? row : 0) * dim;
+        float s = 0.f;
+        for (int j = g; j < dim; j += 16) s += xr[j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * inv;
+        float v = 0.f;
+        for (int j = g; j < dim; j += 16) { const float d = xr[j] - mean; v = fmaf(d, d, v); }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        const float rstd = 1.0f / sqrtf(v * inv + eps);
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = g; j < dim; j += 16) {
+            const float gw = gr[j] * w[j], xh = (xr[j] - mean) * rstd;
+            s1 += gw; s2 = fmaf(gw, xh, s2);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 *= inv; s2 *= inv;
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < kLnMaxPer; ++i) {
+                const int j = g + 16 * i;
+                if (j < dim) {
+                    const float xh = (xr[j] - mean) * rstd, gv = gr[j];
+                    gx[row * dim + j] = rstd * (gv * w[j] - s1 - xh * s2);
+                    aw[i] = fmaf(gv, xh, aw[i]);
+                    ab[i] += gv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kLnMaxPer; ++i) {
+        const int j = g + 16 * i;
+        if (j < dim) { red[rg][j] = aw[i]; red[rg][128 + j] = ab[i]; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * dim; e += 256) {
+        const int j = e < dim ? e : 128 + (e - dim);
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][j];
+        part[(int64_t)blockIdx.x * 2 * dim + e] = t;
+    }
+}
+
+// single-head attention backward on N tokens per sample (forward: k_attention, simple_vit.py:56-68).
+// qkv rows [q | k | v], go = d/d out; gqkv rows [dq | dk | dv].  One 64-thread block per sample; the softmax is
+// recomputed.  dS = P o (dP - rowsum(P o dP)), dP = go V^T, dV = P^T go, dQ = scale dS K, dK = scale dS^T Q.
+__global__ __launch_bounds__(64) void k_attention_bwd(const float* __restrict__ qkv, const float* __restrict__ go,
+                                                      float* __restrict__ gqkv, int N, int dh, float scale) {
+    extern __shared__ __align__(16) float lds[];
+    float* s_qkv = lds;                     // [N][3 dh]
+    float* s_go = s_qkv + N * 3 * dh;       // [N][dh]
+    float* P = s_go + N * dh;               // [N][N]
+    float* dS = P + N * N;                  // [N][N]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* src = qkv + (int64_t)b * N * 3 * dh;
+    const float* gsrc = go + (int64_t)b * N * dh;
+    for (int e = tid; e < N * 3 * dh; e += 64) s_qkv[e] = src[e];
+    for (int e = tid; e < N * dh; e += 64) s_go[e] = gsrc[e];
+    __syncthreads();
+    for (int e = tid; e < N * N; e += 64) {
+        const int i = e / N, j = e - i * N;
+        const float* q = s_qkv + i * 3 * dh;
+        const float* k = s_qkv + j * 3 * dh + dh;
+        const float* v = s_qkv + j * 3 * dh + 2 * dh;
+        const float* g = s_go + i * dh;
+        float s = 0.f, d = 0.f;
+        for (int c = 0; c < dh; ++c) { s = fmaf(q[c], k[c], s); d = fmaf(g[c], v[c], d); }
+        P[e] = s * scale;
+        dS[e] = d;                          // dP for now
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 64) {     // row softmax, then dS = P o (dP - sum_j P dP)
+        float m = -INFINITY;
+        for (int j = 0; j < N; ++j) m = fmaxf(m, P[i * N + j]);
+        float z = 0.f;
+        for (int j = 0; j < N; ++j) { const float ev = expf(P[i * N + j] - m); P[i * N + j] = ev; z += ev; }
+        const float rz = 1.0f / z;
+        float dot = 0.f;
+        for (int j = 0; j < N; ++j) { P[i * N + j] *= rz; dot = fmaf(P[i * N + j], dS[i * N + j], dot); }
+        for (int j = 0; j < N; ++j) dS[i * N + j] = P[i * N + j] * (dS[i * N + j] - dot);
+    }
+    __syncthreads();
+    float* dst = gqkv + (int64_t)b * N * 3 * dh;
+    for (int e = tid; e < N * dh; e += 64) {
+        const int i = e / dh, c = e - i * dh;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < N; ++j) {
+            dq = fmaf(dS[i * N + j], s_qkv[j * 3 * dh + dh + c], dq);          // dS[i][j] K[j][c]
+            dk = fmaf(dS[j * N + i], s_qkv[j * 3 * dh + c], dk);               // dS[j][i] Q[j][c]
+            dv = fmaf(P[j * N + i], s_go[j * dh + c], dv);                     // P[j][i] go[j][c]
+        }
+        dst[i * 3 * dh + c] = dq * scale;
+        dst[i * 3 * dh + dh + c] = dk * scale;
+        dst[i * 3 * dh + 2 * dh + c] = dv;
+    }
+}
+
+// exact (erf) GELU, nn.GELU() default (simple_vit.py:36): y = x Phi(x); dy/dx = Phi(x) + x phi(x)
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_gelu(const float* __restrict__ x, const float* __restrict__ gy,
+                                              float* __restrict__ out, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float v = x[e];
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+        if (BWD) out[e] = gy[e] * (cdf + v * 0.39894228040143267794f * expf(-0.5f * v * v));
+        else out[e] = v * cdf;
+    }
+}
+
+// Backward of the affine coupling map (coupling.py:52-66): z = [x0 | x1 s + t], ldj = sum log_s,
+// log_s = 2 tanh(raw / 2), h = [t | raw].  gx = [gz0 | gz1 s]  (the conditioner's own gradient w.r.t. x0 is added by
+// the caller), gh = [gz1 | (gz1 x1 s + gld_b) (1 - (log_s/2)^2)].
+__global__ __launch_bounds__(256) void k_coupling_apply_bwd(const float* __restrict__ x, const float* __restrict__ h,
+                                                            const float* __restrict__ gz, const float* __restrict__ gld,
+                                                            float* __restrict__ gx, float* __restrict__ gh, int C,
+                                                            int HW, int64_t total_half, int64_t xbs, int64_t gzbs) {
+    const int half = C / 2;
+    const int64_t per = (int64_t)half * HW;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total_half; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / per, r = e - b * per;
+        const float x1 = x[b * xbs + per + r];
+        const float g0 = gz[b * gzbs + r], g1 = gz[b * gzbs + per + r];
+        const float raw = h[b * 2 * per + per + r];
+        const float th = tanhf(0.5f * raw), ls = 2.0f * th, s = expf(ls);
+        gx[b * 2 * per + r] = g0;
+        gx[b * 2 * per + per + r] = g1 * s;
+        gh[b * 2 * per + r] = g1;
+        gh[b * 2 * per + per + r] = (g1 * x1 * s + gld[b]) * (1.0f - th * th);
+    }
+}
+
+// out[c] = sum_{b,p} a[b][c][p], out[C + c] = sum_{b,p} a * b2   (per-channel reductions of the ActNorm backward).
+// One workgroup per channel, fixed summation order.
+__global__ __launch_bounds__(256) void k_channel_sums(const float* __restrict__ a, const float* __restrict__ b2,
+                                                      float* __restrict__ out, int B, int C, int HW, int64_t abs_,
+                                                      int64_t bbs) {
+    const int c = blockIdx.x;
+    const int64_t n = (int64_t)B * HW;
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t e = threadIdx.x; e < n; e += 256) {
+        const int64_t b = e / HW;
+        const int p = (int)(e - b * HW);
+        const float av = a[b * abs_ + (int64_t)c * HW + p];
+        s0 += av;
+        if (b2) s1 = fmaf(av, b2[b * bbs + (int64_t)c * HW + p], s1);
+    }
+    __shared__ float scr[4];
+    s0 = cf_block_sum<4>(s0, scr);
+    s1 = cf_block_sum<4>(s1, scr);
+    if (threadIdx.x == 0) { out[c] = s0; out[C + c] = s1; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cf_layernorm_bwd_parts(void) { return kLnBlocks; }
+
+int cf_layernorm_bwd(const float* x, const float* w, const float* gy, float* gx, float* partial, int rows, int dim,
+                     float eps, cf_stream_t stream) {
+    CF_REQUIRE(x && w && gy && gx && partial && rows >= 0 && dim > 0);
+    if (dim > 16 * kLnMaxPer) { cf_set_error("cf_layernorm_bwd: dim=%d > %d unsupported", dim, 16 * kLnMaxPer); return CF_ERR_UNSUPPORTED; }
+    k_layernorm_bwd<<<dim3(kLnBlocks), dim3(256), 0, cf_s(stream)>>>(x, w, gy, gx, partial, rows, dim, eps);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_attention_bwd(const float* qkv, const float* go, float* gqkv, int B, int N, int dh, float scale, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(qkv && go && gqkv && B >= 0 && N > 0 && dh > 0);
+    const size_t lds = (size_t)(N * 3 * dh + N * dh + 2 * N * N) * sizeof(float);
+    if (lds > 64 * 1024) { cf_set_error("cf_attention_bwd: N=%d dh=%d needs %zu B of LDS", N, dh, lds); return CF_ERR_UNSUPPORTED; }
+    k_attention_bwd<<<dim3(B), dim3(64), lds, cf_s(stream)>>>(qkv, go, gqkv, N, dh, scale);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gelu(const float* x, const float* gy, float* out, int64_t n, int backward, cf_stream_t stream) {
+    if (n == 0) return 0;
+    CF_REQUIRE(x && out && n >= 0 && (!backward || gy));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (backward) k_gelu<true><<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(x, gy, out, n);
+    else k_gelu<false><<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(x, nullptr, out, n);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_coupling_apply_bwd(const float* x, const float* h, const float* gz, const float* gld, float* gx, float* gh, int B,
+                          int C, int HW, int64_t x_bstride, int64_t gz_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && h && gz && gld && gx && gh && B >= 0 && C > 0 && C % 2 == 0 && HW > 0);
+    const int64_t total = (int64_t)B * (C / 2) * HW;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    k_coupling_apply_bwd<<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(x, h, gz, gld, gx, gh, C, HW, total,
+                                                                                x_bstride, gz_bstride);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_channel_sums(const float* a, const float* b2, float* out, int B, int C, int HW, int64_t a_bstride,
+                    int64_t b_bstride, cf_stream_t stream) {
+    CF_REQUIRE(a && out && B >= 0 && C > 0 && HW > 0);
+    k_channel_sums<<<dim3(C), dim3(256), 0, cf_s(stream)>>>(a, b2, out, B, C, HW, a_bstride, b_bstride);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

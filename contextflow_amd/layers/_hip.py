@@ -64,6 +64,12 @@ SIGNATURES = {
     "cf_spline_table_floats": (_c_i64, [_c_int, _c_int]),
     "cf_spline_prepare": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_f, _c_p]),
     "cf_spline": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_p]),
+    "cf_layernorm_bwd_parts": (_c_int, []),
+    "cf_layernorm_bwd": (_c_int, [_c_p] * 5 + [_c_int, _c_int, _c_f, _c_p]),
+    "cf_attention_bwd": (_c_int, [_c_p] * 3 + [_c_int] * 3 + [_c_f, _c_p]),
+    "cf_gelu": (_c_int, [_c_p] * 3 + [_c_i64, _c_int, _c_p]),
+    "cf_coupling_apply_bwd": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
+    "cf_channel_sums": (_c_int, [_c_p] * 3 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
     "cf_logdet_combine": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     "cf_nll_sum": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
 }

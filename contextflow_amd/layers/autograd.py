@@ -10,11 +10,12 @@ Backward walks the tape in reverse:
                  contractions are (B x 80) x (80 x D) library GEMMs + small elementwise terms;
   * Squeeze / SplitPrior / Augment : index maps (squeeze kernel with `inverse`, concatenation).
 Reference quirks carried into the gradients: ActNorm's ldj = +sum(logs) (d/dlogs gets sum_b g_ld), Conv1x1's
-ldj = H*W*log|det W| (d/dW gets sum_b g_ld * H*W * W^-T).  Covers the conv-coupling topologies (mnist, cifar10);
-TransCoupling has no backward yet.  Weight-gradient partial sums are combined in a fixed order (no float atomics)."""
+ldj = H*W*log|det W| (d/dW gets sum_b g_ld * H*W * W^-T).  Layers that run layer by layer in the plan (TransCoupling + its ViT,
+Conv1x1 / ActNorm of other shapes, Augment: the SMAP topology) go through autograd_layers.py.  Weight-gradient partial sums are combined in a fixed order (no float atomics)."""
 import torch
 
 from . import _hip
+from .autograd_layers import layer_backward
 from .squeeze import squeeze_op
 
 
@@ -151,6 +152,10 @@ class FlowLogProb(torch.autograd.Function):
                 gz = squeeze_op(gz, rec[1], True)
             elif kind == "pre":
                 break                                        # nothing trainable upstream of the pre-processing
+            elif kind == "layer":
+                _, mod, xin = rec
+                gz, gp = layer_backward(mod, xin, gz, gld)
+                add(gp)
             else:
-                raise NotImplementedError("no backward for layer %s in the fused plan" % type(rec[1]).__name__)
+                raise NotImplementedError("no backward for tape record %r" % (kind,))
         return (None, None) + tuple(acc.get(p) for p in params)

@@ -1,0 +1,179 @@
+"""Backward of the layers that run layer by layer inside the fused plan (everything that is not a fused conv flow
+step): TransCoupling with its SimpleViT conditioner, and Conv1x1 / ActNorm / Augment of shapes the step kernel does
+not cover (the SMAP topology: 26 channels, 8x1 windows; reference training step experiment_ad.py:204-213).
+
+Each `*_backward(module, x_in, gz, gld)` takes the layer's saved input, the gradient w.r.t. its output and the
+gradient w.r.t. the per-sample log-det (B,), and returns (gradient w.r.t. the input, {parameter: gradient}).
+Nothing but the layer input is kept from the forward: the conditioner is recomputed (token-major, with its
+intermediates) inside the backward.  Elementwise / normalisation / attention pieces are HIP kernels
+(csrc/cf_layers_bwd.hip); the Linear layers' two backward products are plain library GEMMs."""
+import torch
+
+from . import _hip
+from .simple_vit import _layernorm, _linear
+
+
+def _new(*shape, like):
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ small pieces
+def _linear_bwd(x_in, lin, gy, grads, need_gx=True):
+    """y = x W^T + b: gx = gy W, gW = gy^T x, gb = column sums."""
+    W = _hip.f32(lin.weight.detach())
+    grads[lin.weight] = gy.t() @ x_in
+    if lin.bias is not None:
+        grads[lin.bias] = gy.sum(0)
+    return gy @ W if need_gx else None
+
+
+def _layernorm_bwd(x_in, ln, gy, grads):
+    rows, dim = x_in.shape
+    gx = _new(rows, dim, like=x_in)
+    nparts = _hip.lib().cf_layernorm_bwd_parts()
+    part = _new(nparts, 2 * dim, like=x_in)
+    _hip.call("cf_layernorm_bwd", _hip.p(x_in), _hip.p(_hip.f32(ln.weight.detach())), _hip.p(gy), _hip.p(gx), _hip.p(part),
+              rows, dim, float(ln.eps), _hip.stream())
+    s = part.sum(0)
+    grads[ln.weight], grads[ln.bias] = s[:dim], s[dim:]
+    return gx
+
+
+def _gelu(x, gy=None):
+    out = torch.empty_like(x)
+    _hip.call("cf_gelu", _hip.p(x), _hip.p(gy), _hip.p(out), x.numel(), 0 if gy is None else 1, _hip.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ SimpleViT
+def vit_forward_taped(vit, x0):
+    """SimpleViT.forward (simple_vit.py:117-127) on x0 (B, C, H, W), keeping what the backward needs."""
+    x, xbs = _hip.bview(x0)
+    B, C, H, W = x.shape
+    ph, pw = vit.patch_size
+    ntok = vit.grid[0] * vit.grid[1]
+    if vit.pos_embedding.device != x.device:
+        vit.pos_embedding = vit.pos_embedding.to(x.device).contiguous()
+    tpe = vit.to_patch_embedding
+    tok = _new(B * ntok, C * ph * pw, like=x)
+    _hip.call("cf_patchify", _hip.p(x), _hip.p(tok), B, C, H, W, ph, pw, xbs, 0, _hip.stream())
+    a0 = _layernorm(tok, tpe[1])
+    e = _linear(a0, tpe[2])
+    t = _layernorm(e, tpe[3], pos=vit.pos_embedding, ntok=ntok)
+    layers = []
+    for attn, ff in vit.transformer.layers:
+        n1 = _layernorm(t, attn.norm)
+        qkv = _linear(n1, attn.to_qkv)
+        o = _new(t.shape[0], attn.dim_head, like=t)
+        _hip.call("cf_attention", _hip.p(qkv), _hip.p(o), B, ntok, attn.dim_head, float(attn.scale), _hip.stream())
+        u = _linear(o, attn.to_out, res=t)
+        n2 = _layernorm(u, ff.net[0])
+        hp = _linear(n2, ff.net[1])
+        hg = _gelu(hp)
+        t_next = _linear(hg, ff.net[3], res=u)
+        layers.append((t, n1, qkv, o, u, n2, hp, hg))
+        t = t_next
+    f = _layernorm(t, vit.transformer.norm)
+    cout = vit.dim // (ph * pw)
+    h = _new(B, cout, H, W, like=x)
+    _hip.call("cf_patchify", _hip.p(f), _hip.p(h), B, cout, H, W, ph, pw, cout * H * W, 1, _hip.stream())
+    return h, (tok, a0, e, layers, t, (B, C, H, W, ntok, cout))
+
+
+def vit_backward(vit, tape, gh, grads):
+    """gh: d/d h (B, cout, H, W) dense.  Returns d/d x0 (B, C, H, W) dense; parameter gradients go into `grads`."""
+    tok, a0, e, layers, t_last, (B, C, H, W, ntok, cout) = tape
+    ph, pw = vit.patch_size
+    tpe = vit.to_patch_embedding
+    st = _hip.stream()
+    gf = _new(B * ntok, vit.dim, like=gh)
+    _hip.call("cf_patchify", _hip.p(gh), _hip.p(gf), B, cout, H, W, ph, pw, cout * H * W, 0, st)
+    gt = _layernorm_bwd(t_last, vit.transformer.norm, gf, grads)
+    for (attn, ff), (t, n1, qkv, o, u, n2, hp, hg) in zip(reversed(list(vit.transformer.layers)), reversed(layers)):
+        # t_next = u + W2 gelu(W1 LN2(u) + b1) + b2
+        ghg = _linear_bwd(hg, ff.net[3], gt, grads)
+        ghp = _gelu(hp, ghg)
+        gn2 = _linear_bwd(n2, ff.net[1], ghp, grads)
+        gu = gt + _layernorm_bwd(u, ff.net[0], gn2, grads)
+        # u = t + Wo attn(Wqkv LN1(t))
+        go = _linear_bwd(o, attn.to_out, gu, grads)
+        gqkv = torch.empty_like(qkv)
+        _hip.call("cf_attention_bwd", _hip.p(qkv), _hip.p(go), _hip.p(gqkv), B, ntok, attn.dim_head, float(attn.scale), st)
+        gn1 = _linear_bwd(n1, attn.to_qkv, gqkv, grads)
+        gt = gu + _layernorm_bwd(t, attn.norm, gn1, grads)
+    # t0 = LN_b(e) + pos ; e = We LN_a(tok) + be
+    ge = _layernorm_bwd(e, tpe[3], gt, grads)
+    ga0 = _linear_bwd(a0, tpe[2], ge, grads)
+    gtok = _layernorm_bwd(tok, tpe[1], ga0, grads)
+    gx0 = _new(B, C, H, W, like=gh)
+    _hip.call("cf_patchify", _hip.p(gtok), _hip.p(gx0), B, C, H, W, ph, pw, C * H * W, 1, st)
+    return gx0
+
+
+# ------------------------------------------------------------------------------------------------ layers
+def transcoupling_backward(m, x_in, gz, gld):
+    """TransCoupling (coupling.py:123-155): z = [x0 | x1 exp(log_s) + t], ldj = sum log_s, [t | raw] = ViT(x0)."""
+    x, xbs = _hip.bview(x_in)
+    gzv, gzbs = _hip.bview(gz)
+    B, C, H, W = x.shape
+    half = C // 2
+    h, tape = vit_forward_taped(m.NN[0], x[:, :half])
+    gx = _new(B, C, H, W, like=x)
+    ghd = _new(B, C, H, W, like=x)
+    _hip.call("cf_coupling_apply_bwd", _hip.p(x), _hip.p(h), _hip.p(gzv), _hip.p(_hip.f32(gld)), _hip.p(gx), _hip.p(ghd),
+              B, C, H * W, xbs, gzbs, _hip.stream())
+    grads = {}
+    gx0 = vit_backward(m.NN[0], tape, ghd, grads)
+    gx[:, :half] += gx0
+    return gx, grads
+
+
+def conv1x1_backward(m, x_in, gz, gld):
+    """Conv1x1 (conv1x1.py:52-57): z = W x per pixel, ldj = H W log|det W|."""
+    x = _hip.f32(x_in)
+    B, C, H, W = x.shape
+    Wm = _hip.f32(m.NN.detach())
+    gzc = _hip.f32(gz).contiguous()
+    gx = torch.empty_like(gzc)
+    _hip.call("cf_conv1x1_fwd", _hip.p(gzc), _hip.p(Wm.t().contiguous()), None, _hip.p(gx), B, C, H * W, C * H * W, C * H * W,
+              _hip.stream())
+    lad = _new(1, like=gzc)
+    winv = _new(C, C, like=gzc)
+    _hip.call("cf_slogdet_inverse", _hip.p(Wm), C, _hip.p(lad), _hip.p(winv), _hip.stream())
+    xs = x.permute(1, 0, 2, 3).reshape(C, -1)
+    gs = gzc.permute(1, 0, 2, 3).reshape(C, -1)
+    gW = gs @ xs.t() + (gld.sum() * (H * W)) * winv.t()
+    return gx, {m.NN: gW}
+
+
+def actnorm_backward(m, x_in, gz, gld):
+    """ActNorm (actnorm.py:53-60): z = (x - t) exp(-logs), ldj = +sum(logs) (reference quirk: no H W factor)."""
+    x = _hip.f32(x_in).contiguous()
+    B, C, H, W = x.shape
+    t, logs = _hip.f32(m.NN_t.detach()), _hip.f32(m.NN_logs.detach())
+    gzc = _hip.f32(gz).contiguous()
+    st = _hip.stream()
+    z = _new(B, C, H, W, like=gzc)
+    _hip.call("cf_actnorm", _hip.p(x), _hip.p(t), _hip.p(logs), _hip.p(z), None, B, C, H * W, 0, st)
+    sums = _new(2 * C, like=gzc)
+    _hip.call("cf_channel_sums", _hip.p(gzc), _hip.p(z), _hip.p(sums), B, C, H * W, C * H * W, C * H * W, st)
+    s = torch.exp(-logs)
+    gx = gzc * s.view(1, C, 1, 1)
+    return gx, {m.NN_t: -s * sums[:C], m.NN_logs: gld.sum() - sums[C:]}
+
+
+def layer_backward(m, x_in, gz, gld):
+    """Dispatch on the layer type; raises for layers without a hand-written backward."""
+    from .actnorm import ActNorm
+    from .augment import Augment
+    from .conv1x1 import Conv1x1
+    from .coupling import TransCoupling
+    if isinstance(m, TransCoupling):
+        return transcoupling_backward(m, x_in, gz, gld)
+    if type(m) is Conv1x1:
+        return conv1x1_backward(m, x_in, gz, gld)
+    if type(m) is ActNorm:
+        return actnorm_backward(m, x_in, gz, gld)
+    if isinstance(m, Augment) and m.split_dim == 1:
+        return gz[:, : x_in.shape[1]], {}
+    raise NotImplementedError("no backward for layer %s in the fused plan" % type(m).__name__)

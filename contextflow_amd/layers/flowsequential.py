@@ -238,7 +238,7 @@ class FlowSequential(nn.Module):
                 x = x[:, :c]
             else:                        # any other layer: its own kernels
                 if tape is not None:
-                    tape.append(("layer", op[1]))
+                    tape.append(("layer", op[1], x))
                 x, ldj = op[1](x, context)
                 if ldj.dim() == 2:
                     ldM += ldj

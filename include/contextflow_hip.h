@@ -201,6 +201,28 @@ int cf_spline_prepare(const float* uw, const float* uh, const float* ud, float* 
 int cf_spline(const float* x, const float* table, float* y, float* ldj, int B, int N, int P, int K, float tail_bound,
               int inverse, cf_stream_t stream);
 
+/* ---- backward of the layer-by-layer path (training step, experiment_ad.py:207-213: loss.backward()) ---------
+ * SimpleViT conditioner of TransCoupling (simple_vit.py:30-127) and the generic ActNorm / affine coupling map.
+ * The Linear layers' backward GEMMs (gX = gY W, gW = gY^T X) are plain library GEMMs on the host side.        */
+/* LayerNorm backward: gx (rows,dim); partial[cf_layernorm_bwd_parts()][2*dim] = per-workgroup sums of
+ * (gy*xhat | gy) in a fixed order - the host adds the rows to get d/dweight, d/dbias.  dim <= 128.            */
+int cf_layernorm_bwd_parts(void);
+int cf_layernorm_bwd(const float* x, const float* w, const float* gy, float* gx, float* partial, int rows, int dim,
+                     float eps, cf_stream_t stream);
+/* single-head attention backward (simple_vit.py:56-68): qkv (B*N, 3*dh) rows [q|k|v], go (B*N, dh) -> gqkv   */
+int cf_attention_bwd(const float* qkv, const float* go, float* gqkv, int B, int N, int dh, float scale,
+                     cf_stream_t stream);
+/* exact GELU (nn.GELU default, simple_vit.py:36): backward=0: out = gelu(x); backward=1: out = gy * gelu'(x)  */
+int cf_gelu(const float* x, const float* gy, float* out, int64_t n, int backward, cf_stream_t stream);
+/* affine coupling map backward (coupling.py:52-66): x (B,C,HW) by stride, h = [t|raw] dense, gz by stride,
+ * gld (B) = d/d ldj -> gx = [gz0 | gz1*s] dense, gh = [d/dt | d/draw] dense                                   */
+int cf_coupling_apply_bwd(const float* x, const float* h, const float* gz, const float* gld, float* gx, float* gh, int B,
+                          int C, int HW, int64_t x_bstride, int64_t gz_bstride, cf_stream_t stream);
+/* out[c] = sum_{b,p} a[b,c,p]; out[C+c] = sum_{b,p} a*b2 (b2 may be null): ActNorm's d/dt, d/dlogs reductions
+ * (actnorm.py:53-60), one workgroup per channel, fixed order                                                  */
+int cf_channel_sums(const float* a, const float* b2, float* out, int B, int C, int HW, int64_t a_bstride,
+                    int64_t b_bstride, cf_stream_t stream);
+
 /* ---- log-det bookkeeping (layers/flowsequential.py:18-27) --------------------------------------- */
 /* out[b,m] = ldM[b,m] + ld1[b]                                                                      */
 int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream);

@@ -422,15 +422,16 @@ def test_edge_batches_and_layouts(L, name):
 
 
 # ------------------------------------------------------------------------------------------ training step (backward)
-@pytest.mark.parametrize("name,B", [("mnist", 6), ("cifar10", 5)])
+@pytest.mark.parametrize("name,B", [("mnist", 6), ("cifar10", 5), ("smap", 7)])
 def test_backward_against_autograd_oracle(L, name, B):
-    """d sum(w * logp) / d parameters: the hand-written backward (fused HIP step-backward kernel + library GEMMs)
-    against torch.autograd run through the CPU oracle in fp64 on the same inputs, noise and parameters."""
+    """d sum(w * logp) / d parameters: the hand-written backward (fused HIP step-backward kernel, the layer-by-layer
+    backward of TransCoupling / SimpleViT for smap, library GEMMs) against torch.autograd run through the CPU oracle
+    in fp64 on the same inputs, noise and parameters."""
     from tests.gpu_util import build_model, set_noise
     ops, _, M, params, fx = load_e2e(name)
     C, H, W = fo.CONFIGS[name][0]
     g = torch.Generator().manual_seed(21)
-    x = torch.randint(0, 256, (B, C, H, W), generator=g).float()
+    x = torch.rand(B, C, H, W, generator=g) if name == "smap" else torch.randint(0, 256, (B, C, H, W), generator=g).float()
     u = torch.rand(B, C, H, W, generator=g)
     eps = [torch.randn(B, 1, H, W, generator=g)]
     wts = torch.randn(B, M, generator=g)
@@ -539,3 +540,87 @@ def test_wgrad_gemm_against_torch(L, H, MR, NR, taps, B):
     scale = ref_w.abs().max().item()
     assert (gw.cpu().double() - ref_w).abs().max().item() < 1e-5 * scale + 1e-4
     assert (gb.cpu().double() - bias.grad).abs().max().item() < 1e-4 * bias.grad.abs().max().item() + 1e-4
+
+
+def test_layer_backward_kernels_against_torch(L):
+    """cf_layernorm_bwd / cf_attention_bwd / cf_gelu / cf_coupling_apply_bwd / cf_channel_sums against torch.autograd
+    in fp64 (ragged row counts, the SMAP ViT geometry: dim 52, 4 tokens, head 64)."""
+    from contextflow_amd.layers import _hip
+    g = torch.Generator().manual_seed(5)
+    st = _hip.stream
+    keep = []
+
+    def P(t):                                # device copies must outlive the (asynchronous) kernel launch
+        if t is None:
+            return None
+        t = t.to(DEV).contiguous()
+        keep.append(t)
+        return _hip.p(t)
+    # LayerNorm
+    rows, dim = 4 * 37 + 3, 52
+    x = torch.randn(rows, dim, generator=g); w = torch.randn(dim, generator=g); b = torch.randn(dim, generator=g); gy = torch.randn(rows, dim, generator=g)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    torch.nn.functional.layer_norm(x64, (dim,), w64, b64, 1e-5).backward(gy.double())
+    gx = torch.empty(rows, dim, device=DEV); nparts = _hip.lib().cf_layernorm_bwd_parts()
+    part = torch.empty(nparts, 2 * dim, device=DEV)
+    _hip.call("cf_layernorm_bwd", P(x.cpu()), P(w.cpu()), P(gy.cpu()), _hip.p(gx), _hip.p(part), rows, dim, 1e-5, st())
+    s = part.sum(0).cpu().double()
+    assert (gx.cpu().double() - x64.grad).abs().max() < 1e-4
+    assert (s[:dim] - w64.grad).abs().max() < 1e-3 and (s[dim:] - b64.grad).abs().max() < 1e-3
+    # attention
+    B, N, dh = 9, 4, 64
+    qkv = torch.randn(B * N, 3 * dh, generator=g); go = torch.randn(B * N, dh, generator=g)
+    q64 = qkv.double().requires_grad_(True)
+    q, k, v = q64.view(B, N, 3 * dh).split(dh, dim=-1)
+    out = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1) @ v
+    out.backward(go.double().view(B, N, dh))
+    gq = torch.empty(B * N, 3 * dh, device=DEV)
+    _hip.call("cf_attention_bwd", P(qkv.cpu()), P(go.cpu()), _hip.p(gq), B, N, dh, dh ** -0.5, st())
+    assert (gq.cpu().double() - q64.grad).abs().max() < 1e-4
+    # GELU
+    xg = torch.randn(1000, generator=g) * 2; gg = torch.randn(1000, generator=g)
+    x64 = xg.double().requires_grad_(True)
+    y64 = torch.nn.functional.gelu(x64); y64.backward(gg.double())
+    yo = torch.empty(1000, device=DEV); go2 = torch.empty(1000, device=DEV)
+    _hip.call("cf_gelu", P(xg.cpu()), None, _hip.p(yo), 1000, 0, st())
+    _hip.call("cf_gelu", P(xg.cpu()), P(gg.cpu()), _hip.p(go2), 1000, 1, st())
+    assert (yo.cpu().double() - y64.detach()).abs().max() < 1e-6 and (go2.cpu().double() - x64.grad).abs().max() < 1e-5
+    # affine coupling map
+    B, C, HW = 5, 26, 8
+    xc = torch.randn(B, C, HW, generator=g); h = torch.randn(B, C, HW, generator=g); gz = torch.randn(B, C, HW, generator=g); gl = torch.randn(B, generator=g)
+    x64, h64 = xc.double().requires_grad_(True), h.double().requires_grad_(True)
+    ls = 2 * torch.tanh(h64[:, C // 2:] / 2)
+    z = torch.cat([x64[:, :C // 2], x64[:, C // 2:] * torch.exp(ls) + h64[:, :C // 2]], 1)
+    ((z * gz.double()).sum() + (ls.flatten(1).sum(-1) * gl.double()).sum()).backward()
+    gxo, gho = torch.empty(B, C, HW, device=DEV), torch.empty(B, C, HW, device=DEV)
+    _hip.call("cf_coupling_apply_bwd", P(xc.cpu()), P(h.cpu()), P(gz.cpu()), P(gl.cpu()), _hip.p(gxo), _hip.p(gho), B, C, HW, C * HW, C * HW, st())
+    assert (gxo.cpu().double() - x64.grad).abs().max() < 1e-5 and (gho.cpu().double() - h64.grad).abs().max() < 1e-5
+    # channel sums
+    a, b2 = torch.randn(B, C, HW, generator=g), torch.randn(B, C, HW, generator=g)
+    out = torch.empty(2 * C, device=DEV)
+    _hip.call("cf_channel_sums", P(a.cpu()), P(b2.cpu()), _hip.p(out), B, C, HW, C * HW, C * HW, st())
+    assert (out[:C].cpu() - a.sum((0, 2))).abs().max() < 1e-4 and (out[C:].cpu() - (a * b2).sum((0, 2))).abs().max() < 1e-4
+
+
+def test_training_steps_reduce_the_loss_smap(L):
+    """AdamW steps on the SMAP transformer flow with the reference's anomaly-detection loss (experiment_ad.py:204-210:
+    negative mean log-likelihood per dimension) through the layer-by-layer backward: the loss must go down."""
+    import contextflow_amd as cfa
+    torch.manual_seed(0)
+    cfg, ds, M = cfa.preset_config("smap")
+    model = cfa.create_model(cfg, ds, M).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(128, *ds, generator=g).to(DEV)
+    with torch.no_grad():
+        model(x)                                         # ActNorm data-dependent init
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    dim_inv = 1.0 / (ds[0] * ds[1] * ds[2])
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        loss = -(dim_inv * model.log_prob(x)).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(math.isfinite(v) for v in losses), losses
+    assert losses[-1] < losses[0] - 1e-3, losses

@@ -13,7 +13,7 @@ dev = "cuda:0"
 torch.manual_seed(0)
 cfg, ds, M = cfa.preset_config(name)
 model = cfa.create_model(cfg, ds, M).to(dev)
-x = torch.randint(0, 256, (B, *ds), device=dev).float()
+x = torch.rand(B, *ds, device=dev) if name == "smap" else torch.randint(0, 256, (B, *ds), device=dev).float()
 gt = torch.randint(0, M, (B,), device=dev)
 with torch.no_grad():
     model(x[:256])                                   # ActNorm init
@@ -25,7 +25,10 @@ def step():
     opt.zero_grad(set_to_none=True)
     _, logp = model(x)
     logp = dim_inv * logp                              # experiment_cl.py:127
-    loss = torch.nn.functional.cross_entropy(logp, gt) + 1e-3 * (-torch.nn.functional.logsigmoid(torch.logsumexp(logp, -1))).mean()
+    if M == 1:
+        loss = -logp.mean()                            # experiment_ad.py:204-210 (anomaly detection: NLL)
+    else:
+        loss = torch.nn.functional.cross_entropy(logp, gt) + 1e-3 * (-torch.nn.functional.logsigmoid(torch.logsumexp(logp, -1))).mean()
     loss.backward()
     opt.step()
     return loss
