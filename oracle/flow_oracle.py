@@ -319,6 +319,99 @@ def spline_activation_inv(y, uw, uh, ud, tail_bound=10.0):
     return rq_spline(y, uw, uh, ud, tail_bound, True)[0]
 
 
+
+# --------------------------------------------------------------------------------------
+# specialist (context-conditioned) branches          SURVEY 8(f) rank 2
+# --------------------------------------------------------------------------------------
+# `ctx` = dict(contexts=[K_0, K_1, ...], enc_emb='eye'|'onehot', contextflow=bool) describes the reference's
+# `ContextEncoder(contexts, enc_emb, 'uniform', ...)` (model.py:30-90) that every Conv1x1 / ActNorm / Coupling owns in
+# the specialist mode (model.py:117,130-143), and the 'embed' + 'eyesample' lookup of the priors (model.py:157,162).
+def ctx_width(ctx):
+    """ContextEncoder.C (model.py:33,42,87): one-hot width or number of context variables."""
+    return sum(ctx["contexts"]) if ctx["enc_emb"] == "onehot" else len(ctx["contexts"])
+
+
+def ctx_encode(context, ctx, u):
+    """OneHotEncoder / EyeEncoder (rtdl/nn/_embeddings.py:76-150) followed by UniformCatDequantization
+    (dequantize.py:55-64): z = (x + u) / qbins, ldj = sum_d(-log(qbins_d) * n_dims) for every sample."""
+    K = ctx["contexts"]
+    if ctx["enc_emb"] == "onehot":
+        x = torch.cat([F.one_hot(context[:, i], K[i]) for i in range(len(K))], 1).to(u.dtype)
+        qbins = torch.ones(sum(K), dtype=torch.float32)
+    else:
+        x = context.to(u.dtype)
+        qbins = torch.tensor(K, dtype=torch.float32)
+    z = (x + u) / qbins.to(u.dtype)
+    ldj = ((-torch.log(qbins)) * x.shape[1]).sum(-1).to(u.dtype)
+    return z, ldj.repeat(x.shape[0])
+
+
+def conv1x1_ctx_fwd(x, W, cn_w, cn_b, c, logp_c, contextflow):
+    """conv1x1.py:34-50: per-sample triangular matrix from CN(c); log-det from its diagonal."""
+    B, D, H, Wd = x.shape
+    m = (c @ cn_w.t() + cn_b).reshape(B, D, D)
+    diag = torch.diagonal(torch.tril(m), dim1=-2, dim2=-1)
+    c_ldj = diag.sum(-1)
+    tri = torch.tril(m, diagonal=-1) + torch.diag_embed(torch.exp(diag))
+    if contextflow:
+        tri = tri - torch.eye(D, dtype=x.dtype) + W
+        ldj = H * Wd * (torch.linalg.slogdet(W)[1] + c_ldj)
+    else:
+        ldj = H * Wd * c_ldj
+    z = torch.einsum("boi,bihw->bohw", tri, x)
+    return z, ldj + logp_c * H * Wd
+
+
+def actnorm_ctx_fwd(x, t, logs, cn_w, cn_b, c, logp_c, contextflow):
+    """actnorm.py:40-60: per-sample shift / log-scale from CN(c), added to the shared ones under contextflow."""
+    B, D, H, Wd = x.shape
+    m = c @ cn_w.t() + cn_b
+    tb, lb = m[:, :D], m[:, D:]
+    if contextflow:
+        tb, lb = tb + t.view(1, -1), lb + logs.view(1, -1)
+    z = (x - tb.view(B, D, 1, 1)) * torch.exp(-lb.view(B, D, 1, 1))
+    return z, lb.sum(-1) + logp_c * H * Wd
+
+
+def coupling_cn(c, p, prefix):
+    """coupling.py:37: CN = Linear -> ReLU -> Linear -> ReLU -> Linear."""
+    h = F.relu(c @ p[prefix + "CN.0.weight"].t() + p[prefix + "CN.0.bias"])
+    h = F.relu(h @ p[prefix + "CN.2.weight"].t() + p[prefix + "CN.2.bias"])
+    return h @ p[prefix + "CN.4.weight"].t() + p[prefix + "CN.4.bias"]
+
+
+def coupling_ctx_fwd(x, p, prefix, pad, c, logp_c, contextflow):
+    """coupling.py:39-66 with a context net: additive CN(c) on the net output (contextflow) or CN(c) broadcast over
+    the image and concatenated to the conditioner input."""
+    B, C, H, Wd = x.shape
+    x0 = x[:, : C // 2]
+    cn = coupling_cn(c, p, prefix)
+    if contextflow:
+        h = coupling_net(x0, p, prefix, pad) + cn.view(B, -1, 1, 1)
+    else:
+        h = coupling_net(torch.cat([x0, cn.view(B, -1, 1, 1).expand(B, cn.shape[1], H, Wd)], 1), p, prefix, pad)
+    z, ldj = coupling_apply_fwd(x, h)
+    return z, ldj + logp_c * H * Wd
+
+
+def gmm_ctx_logprob(x, mG, sG, wG, emb, context, chunk=16):
+    """gaussian.py:142-158 with the 'embed' + 'eyesample' context net (model.py:157,162): per-sample additive
+    shifts of the component means and pre-softplus scales, constant over (h, w); logp_c = 0."""
+    B = x.shape[0]
+    M, K, D = mG.shape[:3]
+    c = torch.cat([emb[i][context[:, i]] for i in range(len(emb))], 1).reshape(B, 2, M, K, D)
+    logw = torch.log_softmax(wG, dim=-1)
+    out = []
+    for b0 in range(0, B, chunk):
+        cm = c[b0:b0 + chunk, 0].reshape(-1, M, K, D, 1, 1)
+        cs = c[b0:b0 + chunk, 1].reshape(-1, M, K, D, 1, 1)
+        mu, sig = mG.unsqueeze(0) + cm, F.softplus(sG.unsqueeze(0) + cs)
+        xv = x[b0:b0 + chunk].reshape(-1, 1, 1, *x.shape[1:])
+        lp = (-0.5 * ((xv - mu) / sig) ** 2 - torch.log(sig) - 0.5 * LOG_2PI).flatten(3).sum(-1)
+        out.append(torch.logsumexp(lp + logw, dim=-1))
+    return torch.cat(out, 0)
+
+
 # ---- prior ------------------------------------------------------------------------------
 def gmm_logprob(x, mG, sG, wG, chunk=64):
     """gaussian.py:138-161 (context-free): for each class-mixture m, logsumexp over K diagonal
@@ -340,7 +433,7 @@ def gmm_logprob(x, mG, sG, wG, chunk=64):
 # --------------------------------------------------------------------------------------
 # whole flow  (flowsequential.py:18-30)
 # --------------------------------------------------------------------------------------
-def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None):
+def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None, ctx=None, context=None, cnoise=()):
     """log p(x) for every class-mixture: returns (z, logp (B,M)).
 
     `u` is the dequantisation noise (uniform.py:31-34) and `eps` the list of Augment noises
@@ -352,6 +445,13 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None)
     M = params["dist.wG"].shape[0]
     logdet = torch.zeros((B, M), dtype=x.dtype)
     eps = list(eps)
+    cnoise = list(cnoise)          # specialist mode: one uniform noise tensor per context encoder, in layer order
+
+    def enc():
+        return ctx_encode(context, ctx, cnoise.pop(0))
+
+    def emb(prefix):
+        return [params[prefix + "context_net.0._embeddings.%d.weight" % i] for i in range(len(ctx["contexts"]))]
     for op in ops:
         kind, idx = op[0], op[1]
         pre = "%d." % idx
@@ -366,8 +466,28 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None)
             x, ldj = torch.cat([x, e], 1), std_normal_neg_logq(e)
         elif kind == "squeeze":
             x, ldj = squeeze_fwd(x, op[2]), torch.zeros(B, dtype=x.dtype)
+        elif kind == "conv1x1" and ctx is not None:
+            c, lc = enc()
+            x, ldj = conv1x1_ctx_fwd(x, params[pre + "NN"], params[pre + "CN.weight"], params[pre + "CN.bias"], c, lc,
+                                     ctx["contextflow"])
         elif kind == "conv1x1":
             x, ldj = conv1x1_fwd(x, params[pre + "NN"])
+        elif kind == "actnorm" and ctx is not None:
+            c, lc = enc()
+            if init_actnorm and ctx["contextflow"]:                # actnorm.py:46: only the contextflow branch initialises
+                t, logs = actnorm_stats(x)
+                params[pre + "NN_t"], params[pre + "NN_logs"] = t, logs
+                params[pre + "initialized"] = torch.tensor(1)
+            x, ldj = actnorm_ctx_fwd(x, params[pre + "NN_t"], params[pre + "NN_logs"], params[pre + "CN.weight"],
+                                     params[pre + "CN.bias"], c, lc, ctx["contextflow"])
+        elif kind == "coupling" and ctx is not None:
+            c, lc = enc()
+            x, ldj = coupling_ctx_fwd(x, params, pre, op[4], c, lc, ctx["contextflow"])
+        elif kind == "split" and ctx is not None:
+            cc = x.shape[1] // 2
+            ldj = gmm_ctx_logprob(x[:, cc:], params[pre + "dist.mG"], params[pre + "dist.sG"], params[pre + "dist.wG"],
+                                  emb(pre + "dist."), context)
+            x = x[:, :cc]
         elif kind == "actnorm":
             if init_actnorm:
                 t, logs = actnorm_stats(x)
@@ -387,7 +507,10 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None)
         logdet = logdet + (ldj if ldj.dim() == 2 else ldj.unsqueeze(-1))   # flowsequential.py:23
         if trace is not None:
             trace.append((kind, idx, x, ldj))
-    logp = gmm_logprob(x, params["dist.mG"], params["dist.sG"], params["dist.wG"])
+    if ctx is not None:
+        logp = gmm_ctx_logprob(x, params["dist.mG"], params["dist.sG"], params["dist.wG"], emb("dist."), context)
+    else:
+        logp = gmm_logprob(x, params["dist.mG"], params["dist.sG"], params["dist.wG"])
     return x, logp + logdet
 
 

@@ -14,21 +14,40 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .flow_oracle import K_COMPONENTS, vit_dims
+from .flow_oracle import K_COMPONENTS, ctx_width, vit_dims
 
 
-def _gmm(prefix, size, M, spec):
+def _gmm(prefix, size, M, spec, ctx=None):
     D, H, W = size
     spec[prefix + "mG"] = ((M, K_COMPONENTS, D, H, W), "normal")
     spec[prefix + "sG"] = ((M, K_COMPONENTS, D, H, W), "scale")
     spec[prefix + "wG"] = ((M, K_COMPONENTS), "normal")
+    if ctx is not None:               # model.py:157,162: CatEmbeddings(contexts, 2*M*K*D // len(contexts)), zero init
+        d = 2 * M * K_COMPONENTS * D // len(ctx["contexts"])
+        for i, k in enumerate(ctx["contexts"]):
+            spec[prefix + "context_net.0._embeddings.%d.weight" % i] = ((k, d), "small")
 
 
-def param_spec(ops, prior_size, mixtures):
+def _encoder(prefix, ctx, spec):
+    """Buffers of ContextEncoder(contexts, enc_emb, 'uniform') = Sequential(OneHotEncoder | EyeEncoder,
+    UniformCatDequantization) (model.py:30-90; rtdl/nn/_embeddings.py:131; dequantize.py:50-52)."""
+    K = ctx["contexts"]
+    if ctx["enc_emb"] == "onehot":
+        spec[prefix + "context_net.0.cardinalities"] = ((len(K),), ("ints", tuple(K)))
+        cats = [1] * sum(K)
+    else:
+        cats = list(K)
+    spec[prefix + "context_net.1.qbins"] = ((len(cats),), ("floats", tuple(float(v) for v in cats)))
+    spec[prefix + "context_net.1.ldj_per_dim"] = ((len(cats),), ("floats", tuple(-float(np.log(np.float32(v))) for v in cats)))
+
+
+def param_spec(ops, prior_size, mixtures, ctx=None):
     """OrderedDict name -> (shape, kind) in the reference's state_dict order
-    (flowsequential.py:8-12: `dist` is registered before the numbered layers)."""
+    (flowsequential.py:8-12: `dist` is registered before the numbered layers).  `ctx`: specialist description
+    (flow_oracle.ctx_width)."""
     spec = OrderedDict()
-    _gmm("dist.", prior_size, mixtures, spec)
+    _gmm("dist.", prior_size, mixtures, spec, ctx)
+    Cc = ctx_width(ctx) if ctx is not None else 0
     for op in ops:
         kind, idx = op[0], op[1]
         pre = "%d." % idx
@@ -42,19 +61,34 @@ def param_spec(ops, prior_size, mixtures):
         elif kind == "conv1x1":
             C = op[2][0]
             spec[pre + "NN"] = ((C, C), "orthogonal")                         # conv1x1.py:16-17
+            if ctx is not None:                                               # conv1x1.py:20-26 (zero init there)
+                _encoder(pre, ctx, spec)
+                spec[pre + "CN.weight"] = ((C * C, Cc), "small")
+                spec[pre + "CN.bias"] = ((C * C,), "small")
         elif kind == "actnorm":
             C = op[2][0]
             spec[pre + "NN_t"] = ((C,), "zeros")                              # actnorm.py:14-16
             spec[pre + "NN_logs"] = ((C,), "zeros")
             spec[pre + "initialized"] = ((), "flag")
+            if ctx is not None:                                               # actnorm.py:19-26
+                _encoder(pre, ctx, spec)
+                spec[pre + "CN.weight"] = ((2 * C, Cc), "small")
+                spec[pre + "CN.bias"] = ((2 * C,), "small")
         elif kind == "coupling":
             C = op[2][0]
             kh, kw = op[3]
             D, Hd, O = C // 2, C * 2, C                                        # coupling.py:17-19
-            for name, shp in (("NN.0", (Hd, D, 1, 1)), ("NN.2", (Hd, Hd, kh, kw)), ("NN.4", (O, Hd, 1, 1))):
+            if ctx is not None:                                               # coupling.py:23: registered before NN
+                _encoder(pre, ctx, spec)
+            Din = D + O if (ctx is not None and not ctx["contextflow"]) else D   # coupling.py:33-34 (concat)
+            for name, shp in (("NN.0", (Hd, Din, 1, 1)), ("NN.2", (Hd, Hd, kh, kw)), ("NN.4", (O, Hd, 1, 1))):
                 fan_in = shp[1] * shp[2] * shp[3]
                 spec[pre + name + ".weight"] = (shp, ("uniform", fan_in))
                 spec[pre + name + ".bias"] = ((shp[0],), ("uniform", fan_in))
+            if ctx is not None:                                               # coupling.py:37
+                for name, shp in (("CN.0", (Hd, Cc)), ("CN.2", (Hd, Hd)), ("CN.4", (O, Hd))):
+                    spec[pre + name + ".weight"] = (shp, ("uniform", shp[1]))
+                    spec[pre + name + ".bias"] = ((shp[0],), ("uniform", shp[1]))
         elif kind == "transcoupling":
             d = vit_dims(op[2], op[3])
             dim, pd, inner = d["dim"], d["patch_dim"], d["dim_head"]
@@ -81,7 +115,7 @@ def param_spec(ops, prior_size, mixtures):
                 spec[f + "3.weight"] = ((dim, dim), ("uniform", dim))
                 spec[f + "3.bias"] = ((dim,), ("uniform", dim))
         elif kind == "split":
-            _gmm(pre + "dist.", op[2], mixtures, spec)
+            _gmm(pre + "dist.", op[2], mixtures, spec, ctx)
     return spec
 
 
@@ -98,6 +132,12 @@ def gen_params(spec, seed=0, dtype=torch.float32):
             v = rs.standard_normal(shape)
         elif kind == "scale":          # pre-softplus scale, perturbed so that softplus is exercised
             v = 1.0 + 0.2 * rs.standard_normal(shape)
+        elif kind == "small":          # zero-initialised in the reference; small values so that the branch is exercised
+            v = 0.05 * rs.standard_normal(shape)
+        elif kind[0] == "ints":
+            out[name] = torch.tensor(kind[1], dtype=torch.int64); continue
+        elif kind[0] == "floats":
+            out[name] = torch.tensor(kind[1], dtype=torch.float32); continue
         elif kind == "ln_w":
             v = 1.0 + 0.1 * rs.standard_normal(shape)
         elif kind == "ln_b":

@@ -57,3 +57,29 @@ def unit(tag):
 def bpd(logp, name):
     D = int(np.prod(fo.CONFIGS[name][0]))
     return -torch.logsumexp(logp.double(), dim=-1) / (D * math.log(2.0))
+
+
+SPECIALIST = {
+    # fixture: (dataset, ctx description) — see tests/golden/make_golden_specialist.py
+    "mnist_eye_cf": ("mnist", dict(contexts=[64], enc_emb="eye", contextflow=True)),
+    "mnist_onehot": ("mnist", dict(contexts=[64], enc_emb="onehot", contextflow=False)),
+    "cifar10_onehot_cf": ("cifar10", dict(contexts=[15, 5], enc_emb="onehot", contextflow=True)),
+    "cifar10_eye": ("cifar10", dict(contexts=[15, 5], enc_emb="eye", contextflow=False)),
+}
+
+
+def load_specialist(fxname):
+    """Returns (dataset, ctx, ops, M, params(post first call), inputs dict) of a specialist fixture."""
+    name, ctx = SPECIALIST[fxname]
+    fx = dict(np.load(os.path.join(GOLDEN, "spec_%s.npz" % fxname)))
+    ops, prior_size, M = fo.program(name)
+    spec = op.param_spec(ops, prior_size, M, ctx)
+    params = op.gen_params(spec, int(fx["seed"]))
+    for k, v in fx.items():
+        if k.startswith("param:"):
+            params[k[6:]] = torch.from_numpy(v)
+    inp = dict(x=torch.from_numpy(fx["x"].astype(np.float32)), u=torch.from_numpy(fx["u"]),
+               eps=[torch.from_numpy(fx["eps%d" % j]) for j in range(8) if "eps%d" % j in fx],
+               context=torch.from_numpy(fx["context"]), cnoise=[torch.from_numpy(c) for c in fx["cnoise"]],
+               logp=torch.from_numpy(fx["logp"]), z=torch.from_numpy(fx["z"]))
+    return name, ctx, ops, M, params, inp

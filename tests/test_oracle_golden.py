@@ -167,3 +167,15 @@ def test_unit_spline_activation(tag):
     assert torch.allclose(fo.spline_activation_inv(t["z"], uw, uh, ud, 10.0), t["xrec"], rtol=1e-5, atol=1e-5)
     outside = t["x"].abs() > 10.0
     assert outside.any() and torch.equal(z[outside], t["x"][outside])
+
+
+@pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye"])
+def test_specialist_oracle_matches_reference(fxname):
+    """Context-conditioned (specialist) forward: every Conv1x1 / ActNorm / Coupling with its ContextEncoder + CN net,
+    context-shifted GMM priors — oracle vs the reference's logp on the captured noise."""
+    from tests.helpers import load_specialist
+    name, ctx, ops, M, params, inp = load_specialist(fxname)
+    z, lp = fo.flow_forward(ops, params, inp["x"], inp["u"], inp["eps"], ctx=ctx, context=inp["context"], cnoise=inp["cnoise"])
+    D = int(np.prod(fo.CONFIGS[name][0]))
+    assert (fo.bits_per_dim(lp, D) - fo.bits_per_dim(inp["logp"], D)).abs().max().item() < 1e-5
+    assert (z - inp["z"]).abs().max().item() < 2e-3
