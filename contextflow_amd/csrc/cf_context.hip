@@ -1,0 +1,199 @@
+// Context-conditioned (specialist) branches of the flow layers: every Conv1x1 / ActNorm /
+// Coupling of a specialist model owns a context encoder and a small CN net whose output turns the layer's parameters
+// into PER-SAMPLE parameters; the priors get per-sample shifts of their component means / scales.
+//
+// All of it is HBM- / VALU-bound work over (sample, channel, pixel); the CN nets themselves are cf_linear (MFMA).
+// One workgroup owns one sample in the three per-sample kernels, so the per-sample parameters live in LDS / registers.
+#include "cf_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kMaxC = 64;             // channels of the per-sample Conv1x1 (matrix in LDS: 16 KiB)
+
+// ContextEncoder = (OneHotEncoder | EyeEncoder) -> UniformCatDequantization (rtdl/nn/_embeddings.py:76-150,
+// dequantize.py:55-64): out[b, j] = (x[b, j] + u[b, j]) / qbins[j]; x = the integer context itself (eye) or its
+// one-hot code, column j belonging to the context variable whose cardinality range contains j.
+__global__ __launch_bounds__(256) void k_ctx_encode(const int64_t* __restrict__ ctx, const float* __restrict__ u,
+                                                    const float* __restrict__ qbins, const int64_t* __restrict__ card,
+                                                    float* __restrict__ out, int B, int nctx, int width, int onehot) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * width) return;
+    const int b = (int)(e / width), j = (int)(e - (int64_t)b * width);
+    float x;
+    if (onehot) {
+        int i = 0, off = 0;
+        while (i < nctx - 1 && j >= off + (int)card[i]) { off += (int)card[i]; ++i; }
+        x = (ctx[(int64_t)b * nctx + i] == (int64_t)(j - off)) ? 1.f : 0.f;
+    } else {
+        x = (float)ctx[(int64_t)b * nctx + j];
+    }
+    out[e] = (x + u[e]) / qbins[j];
+}
+
+// Conv1x1 with a context net (conv1x1.py:34-50): m = CN(c) reshaped (C, C) per sample;
+//   W_b = tril(m, -1) + diag(exp(diag m))            [+ NN - I under contextflow]
+//   z[b] = W_b x[b] per pixel;  ldj[b] = H W sum(diag m)   (the caller adds H W log|det NN| under contextflow -
+//   the reference's own expression, not the log-det of W_b).
+__global__ __launch_bounds__(256) void k_conv1x1_ctx(const float* __restrict__ x, const float* __restrict__ m,
+                                                     const float* __restrict__ Wm, float* __restrict__ z,
+                                                     float* __restrict__ ldj, int C, int HW, int64_t xbs) {
+    __shared__ float Wt[kMaxC * (kMaxC + 1)];         // Wt[i][o] = W_b[o][i], row stride C + 1
+    __shared__ float scr[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* mb = m + (int64_t)b * C * C;
+    float dsum = 0.f;
+    for (int e = tid; e < C * C; e += 256) {
+        const int o = e / C, i = e - o * C;
+        const float v = mb[e];
+        float w = o > i ? v : (o == i ? expf(v) : 0.f);
+        if (o == i) dsum += v;
+        if (Wm != nullptr) w += Wm[e] - (o == i ? 1.f : 0.f);
+        Wt[i * (C + 1) + o] = w;
+    }
+    dsum = cf_block_sum<4>(dsum, scr);                // also the barrier that publishes Wt
+    if (tid == 0) ldj[b] = dsum * (float)HW;
+    const float* xb = x + (int64_t)b * xbs;
+    float* zb = z + (int64_t)b * C * HW;
+    for (int e = tid; e < C * HW; e += 256) {
+        const int o = e / HW, p = e - o * HW;
+        float acc = 0.f;
+        for (int i = 0; i < C; ++i) acc = fmaf(Wt[i * (C + 1) + o], xb[(int64_t)i * HW + p], acc);
+        zb[e] = acc;
+    }
+}
+
+// ActNorm with a context net (actnorm.py:40-60): m = CN(c) = [t_b | logs_b] per sample (+ the shared NN_t / NN_logs
+// under contextflow); z = (x - t_b) exp(-logs_b); ldj[b] = sum_c logs_b (reference quirk: no H W factor).
+__global__ __launch_bounds__(256) void k_actnorm_ctx(const float* __restrict__ x, const float* __restrict__ m,
+                                                     const float* __restrict__ t, const float* __restrict__ logs,
+                                                     float* __restrict__ z, float* __restrict__ ldj, int C, int HW,
+                                                     int64_t xbs) {
+    __shared__ float tb[128], sb[128];
+    __shared__ float scr[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float lsum = 0.f;
+    if (tid < C) {
+        float tv = m[(int64_t)b * 2 * C + tid], lv = m[(int64_t)b * 2 * C + C + tid];
+        if (t != nullptr) { tv += t[tid]; lv += logs[tid]; }
+        tb[tid] = tv; sb[tid] = expf(-lv);
+        lsum = lv;
+    }
+    lsum = cf_block_sum<4>(lsum, scr);
+    if (tid == 0) ldj[b] = lsum;
+    const float* xb = x + (int64_t)b * xbs;
+    float* zb = z + (int64_t)b * C * HW;
+    for (int e = tid; e < C * HW; e += 256) { const int c = e / HW; zb[e] = (xb[e] - tb[c]) * sb[c]; }
+}
+
+// h[b, c, p] = act(h[b, c, p] + bias[b, c])      (the CN(c) term of the coupling net, coupling.py:44-47)
+__global__ __launch_bounds__(256) void k_add_sample_bias(float* __restrict__ h, const float* __restrict__ bias,
+                                                         int HW, int64_t total, int relu) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const float v = h[e] + bias[e / HW];
+        h[e] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// GaussianMixtureDistribution.log_prob with a context net (gaussian.py:142-158): per-sample additive shifts cm / cs
+// (B, 2, M, K, D) of the component means and pre-softplus scales, constant over (h, w):
+//   out[b, m] (+)= logsumexp_k [ logw[m,k] + sum_{d,p} ( -1/2 ((x - mu - cm)/sig)^2 - log sig - 1/2 log 2pi ) ],
+//   sig = softplus(sG + cs).  One workgroup per sample; x in LDS; a wave owns a (m, k) pair at a time.
+__global__ __launch_bounds__(256) void k_gmm_ctx(const float* __restrict__ x, const float* __restrict__ mG,
+                                                 const float* __restrict__ sG, const float* __restrict__ logw,
+                                                 const float* __restrict__ c, float* __restrict__ out, int M, int K,
+                                                 int D, int HW, int64_t xbs, int accumulate) {
+    extern __shared__ __align__(16) float lds[];
+    float* xs = lds;                       // [D*HW]
+    float* lp = lds + D * HW;              // [M*K]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = D * HW, MK = M * K;
+    for (int e = tid; e < N; e += 256) xs[e] = x[(int64_t)b * xbs + e];
+    __syncthreads();
+    const float* cb = c + (int64_t)b * 2 * MK * D;
+    for (int mk = wave; mk < MK; mk += 4) {
+        const float* mu = mG + (int64_t)mk * N;
+        const float* sg = sG + (int64_t)mk * N;
+        const float* cm = cb + (int64_t)mk * D;
+        const float* cs = cb + (int64_t)(MK + mk) * D;
+        float acc = 0.f;
+        for (int e = lane; e < N; e += 64) {
+            const int d = e / HW;
+            const float sv = sg[e] + cs[d];
+            const float sig = sv > 20.f ? sv : log1pf(expf(sv));            // softplus (threshold 20, as torch)
+            const float r = (xs[e] - mu[e] - cm[d]) / sig;
+            acc += -0.5f * r * r - logf(sig) - 0.91893853320467274178f;
+        }
+        acc = cf_wave_sum(acc);
+        if (lane == 0) lp[mk] = acc + logw[mk];
+    }
+    __syncthreads();
+    if (tid < M) {
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[tid * K + k]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(lp[tid * K + k] - mx);
+        const float v = mx + logf(s);
+        if (accumulate) out[(int64_t)b * M + tid] += v;
+        else out[(int64_t)b * M + tid] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cf_ctx_encode(const int64_t* ctx, const float* u, const float* qbins, const int64_t* card, float* out, int B, int nctx,
+                  int width, int onehot, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(ctx && u && qbins && out && B >= 0 && nctx > 0 && width > 0 && (!onehot || card));
+    const int64_t total = (int64_t)B * width;
+    k_ctx_encode<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, cf_s(stream)>>>(ctx, u, qbins, card, out, B, nctx,
+                                                                                       width, onehot);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, float* ldj, int B, int C, int HW,
+                   int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && m && z && ldj && B >= 0 && C > 0 && HW > 0);
+    if (C > kMaxC) { cf_set_error("cf_conv1x1_ctx: C=%d > %d unsupported", C, kMaxC); return CF_ERR_UNSUPPORTED; }
+    k_conv1x1_ctx<<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, m, Wm, z, ldj, C, HW, x_bstride);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_actnorm_ctx(const float* x, const float* m, const float* t, const float* logs, float* z, float* ldj, int B, int C,
+                   int HW, int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && m && z && ldj && B >= 0 && C > 0 && HW > 0 && ((t == nullptr) == (logs == nullptr)));
+    if (C > 128) { cf_set_error("cf_actnorm_ctx: C=%d > 128 unsupported", C); return CF_ERR_UNSUPPORTED; }
+    k_actnorm_ctx<<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, m, t, logs, z, ldj, C, HW, x_bstride);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_add_sample_bias(float* h, const float* bias, int B, int C, int HW, int relu, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(h && bias && B >= 0 && C > 0 && HW > 0);
+    const int64_t total = (int64_t)B * C * HW;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    k_add_sample_bias<<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(h, bias, HW, total, relu);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const float* logw, const float* c, float* out,
+                       int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && mG && sG && logw && c && out && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0 && M <= 256);
+    const size_t lds = (size_t)(D * HW + M * K) * sizeof(float);
+    if (lds > 64 * 1024) { cf_set_error("cf_gmm_ctx_logprob: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
+    k_gmm_ctx<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, M, K, D, HW, x_bstride, accumulate);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -16,7 +16,7 @@ constexpr int LIN_ROWS = 128;     // rows per workgroup (4 waves x 32)
 constexpr int LIN_COLS = 96;      // output features per workgroup (3 MFMA column tiles)
 
 // y[r, n] = act(sum_k x[r,k] W[n,k] + bias[n]) + res[r,n]
-// ACT: 0 none, 1 exact GELU (erf)                                    simple_vit.py:32-38,52-53
+// ACT: 0 none, 1 exact GELU (erf), 2 ReLU             simple_vit.py:32-38,52-53; coupling.py:37 (CN nets)
 template <int ACT>
 __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, const float* __restrict__ Wt,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
             if (row >= rows) continue;
             float v = acc[t][r] + bv;
             if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+            if (ACT == 2) v = fmaxf(v, 0.f);
             if (res) v += res[(int64_t)row * N + n];
             y[(int64_t)row * N + n] = v;
         }
@@ -162,23 +163,23 @@ extern "C" {
 int cf_linear(const float* x, const float* Wt, const float* bias, const float* res, float* y, int rows, int K, int N,
               int act, cf_stream_t stream) {
     if (rows == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
-    CF_REQUIRE(x && Wt && y && rows >= 0 && K > 0 && N > 0 && (act == 0 || act == 1));
+    CF_REQUIRE(x && Wt && y && rows >= 0 && K > 0 && N > 0 && act >= 0 && act <= 2);
     if (K > 128) { cf_set_error("cf_linear: K=%d > 128 unsupported", K); return CF_ERR_UNSUPPORTED; }
-    if (rows == 0) return 0;
     const int KP = ((K + 1) & ~1) | 1;                       // odd row stride: conflict-free operand reads
     const size_t lds = (size_t)(LIN_ROWS + LIN_COLS) * KP * sizeof(float);
     dim3 grid((rows + LIN_ROWS - 1) / LIN_ROWS, (N + LIN_COLS - 1) / LIN_COLS);
+    const void* fn = act == 0 ? (const void*)k_linear<0> : (act == 1 ? (const void*)k_linear<1> : (const void*)k_linear<2>);
     if (lds > 64 * 1024) {
-        static bool raised[2] = {false, false};
+        static bool raised[3] = {false, false, false};
         if (!raised[act]) {
-            hipError_t e = act ? hipFuncSetAttribute((const void*)k_linear<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                               : hipFuncSetAttribute((const void*)k_linear<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { cf_set_error("cf_linear: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
             raised[act] = true;
         }
     }
-    if (act) k_linear<1><<<grid, dim3(256), lds, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N, KP);
-    else k_linear<0><<<grid, dim3(256), lds, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N, KP);
+    if (act == 0) k_linear<0><<<grid, dim3(256), lds, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N, KP);
+    else if (act == 1) k_linear<1><<<grid, dim3(256), lds, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N, KP);
+    else k_linear<2><<<grid, dim3(256), lds, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N, KP);
     CF_LAUNCH_CHECK();
     return 0;
 }

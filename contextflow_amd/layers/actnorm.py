@@ -6,13 +6,12 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .flowlayer import FlowLayer, no_context
+from .flowlayer import FlowLayer
 
 
 class ActNorm(FlowLayer):
     def __init__(self, data_size, context_net=None, contextflow=False):
         super().__init__()
-        no_context("ActNorm", context_net)
         D, H, W = data_size if len(data_size) == 3 else (data_size[0], 1, 1)
         self.D, self.H, self.W = D, H, W
         self.NN_t = nn.Parameter(torch.zeros(D))
@@ -20,6 +19,14 @@ class ActNorm(FlowLayer):
         self.register_buffer("initialized", torch.tensor(0))
         self.context_net = context_net
         self.contextflow = contextflow
+        if self.context_net:                                # actnorm.py:19-26
+            self.C = self.context_net.C
+            self.CN = nn.Linear(self.C, 2 * D)
+            if self.contextflow:
+                self.NN_t.requires_grad_(False)
+                self.NN_logs.requires_grad_(False)
+                nn.init.zeros_(self.CN.weight)
+                nn.init.zeros_(self.CN.bias)
         self._init_done = False          # host mirror of the flag: no device sync per call
 
     def _load_from_state_dict(self, *args, **kwargs):
@@ -55,14 +62,36 @@ class ActNorm(FlowLayer):
                   _hip.p(out), _hip.p(s), B, C, HW, int(inverse), _hip.stream())
         return out, s
 
+    def _forward_ctx(self, x, context):
+        """actnorm.py:40-60: per-sample shift / log-scale CN(c), added to the shared ones under contextflow (the only
+        branch that runs the data-dependent init)."""
+        from .simple_vit import _linear
+        c, logp_c = self.context_net(context)
+        if self.contextflow and not self._init_done:
+            self.initialize(x)
+        x, xbs = _hip.bview(x)
+        B, C, H, W = x.shape
+        m = _linear(_hip.f32(c), self.CN)                   # (B, 2C)
+        t = _hip.f32(self.NN_t.detach()) if self.contextflow else None
+        logs = _hip.f32(self.NN_logs.detach()) if self.contextflow else None
+        z = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+        ldj = torch.empty(B, device=x.device, dtype=torch.float32)
+        _hip.call("cf_actnorm_ctx", _hip.p(x), _hip.p(m), _hip.p(t), _hip.p(logs), _hip.p(z), _hip.p(ldj), B, C, H * W, xbs,
+                  _hip.stream())
+        return z, ldj + logp_c * float(H * W)
+
     def forward(self, x, context=None):
         _hip.require_device(x)
+        if self.context_net:
+            return self._forward_ctx(x, context)
         if not self._init_done:
             self.initialize(x)
         z, s = self._run(x, False)
         return z, s.expand(x.shape[0])
 
     def reverse(self, z, context=None):
+        if self.context_net:
+            raise NotImplementedError("ActNorm.reverse with a context net (the reference's own is marked 'to update')")
         assert self._init_done
         return self._run(z, True)[0]
 

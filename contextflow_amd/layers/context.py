@@ -1,0 +1,125 @@
+"""Context encoders of the specialist mode (reference: contextflow/model.py:30-90, layers/dequantize.py:26-143,
+layers/rtdl/nn/_embeddings.py:76-285): a discrete context (B, n) of integer codes becomes the continuous vector c (B, C)
+that the CN nets of Conv1x1 / ActNorm / Coupling consume, plus a log-density term.
+
+Built: `enc_emb` eye | onehot with `enc_type` uniform (uniform dequantisation of the code) and the `embed` +
+`eyesample` table lookup of the priors.  The variational / argmax / probsample encoders (small conditional flows
+over the context) raise NotImplementedError.
+
+Module and buffer names follow the reference so that checkpoints load: ContextEncoder = Sequential(emb, encoder);
+OneHotEncoder.cardinalities, UniformCatDequantization.{qbins, ldj_per_dim}, CatEmbeddings._embeddings.N.weight."""
+import torch
+import torch.nn as nn
+
+from . import _hip
+
+
+class EyeEncoder(nn.Module):
+    """rtdl/nn/_embeddings.py:76-109: the integer context itself."""
+
+    def forward(self, x):
+        if x.ndim != 2:
+            raise ValueError("The input must have two dimensions")
+        return x, x
+
+
+class OneHotEncoder(nn.Module):
+    """rtdl/nn/_embeddings.py:112-150.  The one-hot code is produced inside cf_ctx_encode; this module only carries
+    the cardinalities."""
+
+    def __init__(self, cardinalities):
+        super().__init__()
+        self.register_buffer("cardinalities", torch.tensor(cardinalities))
+
+    def forward(self, x):
+        if x.ndim != 2:
+            raise ValueError("The input must have two dimensions")
+        return self, x                       # the encoder fuses the encoding with the dequantisation
+
+
+class CatEmbeddings(nn.Module):
+    """rtdl/nn/_embeddings.py:153-285 (stack=False, bias=False): concatenated embedding-table rows."""
+
+    def __init__(self, cardinalities, d_embedding, stack=False, bias=False, init="zeros"):
+        super().__init__()
+        if stack or bias:
+            raise NotImplementedError("CatEmbeddings: stack / bias variants are not used by create_model")
+        self._embeddings = nn.ModuleList([nn.Embedding(k, d_embedding) for k in cardinalities])
+        for m in self._embeddings:
+            if init == "zeros":
+                nn.init.zeros_(m.weight)
+            else:
+                nn.init.uniform_(m.weight, -d_embedding ** -0.5, d_embedding ** -0.5)
+
+    def forward(self, x):
+        if x.ndim != 2 or x.shape[1] != len(self._embeddings):
+            raise ValueError("x must be (batch, %d)" % len(self._embeddings))
+        out = [m.weight.detach()[x[:, i]] for i, m in enumerate(self._embeddings)]      # row gather (index op)
+        return torch.cat(out, 1), x
+
+
+class UniformCatDequantization(nn.Module):
+    """dequantize.py:26-70: z = (x + u) / K, u ~ U[0,1); ldj = sum_d(-log K_d * n_dims) for every sample.
+    `fixed_noise` (tests) replaces the draw."""
+
+    def __init__(self, num_cats=(1,)):
+        super().__init__()
+        self.D = len(num_cats)
+        self.register_buffer("qbins", torch.tensor(num_cats, dtype=torch.float))
+        self.register_buffer("ldj_per_dim", -torch.log(torch.tensor(num_cats, dtype=torch.float)))
+        self.fixed_noise = None
+
+    def forward(self, input):
+        x, context = input
+        dev = self.qbins.device
+        B = context.shape[0]
+        onehot = isinstance(x, OneHotEncoder)
+        width = self.D
+        u = self.fixed_noise if self.fixed_noise is not None else torch.rand((B, width), device=dev, dtype=torch.float32)
+        z = torch.empty(B, width, device=dev, dtype=torch.float32)
+        ctx = context.to(device=dev, dtype=torch.int64).contiguous()
+        card = x.cardinalities.to(torch.int64) if onehot else None
+        _hip.call("cf_ctx_encode", _hip.p(ctx), _hip.p(_hip.f32(u)), _hip.p(self.qbins), _hip.p(card), _hip.p(z), B,
+                  ctx.shape[1], width, int(onehot), _hip.stream())
+        ldj = (self.ldj_per_dim * width).sum(-1).repeat(B)           # dequantize.py:62 (num_dims = width)
+        return z, ldj
+
+    def reverse(self, z, context=None):
+        return (z * self.qbins).floor().clamp(min=0).minimum(self.qbins - 1).long()
+
+
+class EyeSampling(nn.Module):
+    """dequantize.py:129-142: pass-through, zero log-density."""
+
+    def forward(self, input):
+        x, _ = input
+        return x, torch.zeros(x.shape[0], device=x.device)
+
+    def reverse(self, z, context=None):
+        return z.long()
+
+
+class ContextEncoder(nn.Sequential):
+    """model.py:30-90."""
+
+    def __init__(self, contexts, enc_emb, enc_type, data_size, init="orthogonal"):
+        contexts = list(contexts)
+        if enc_emb == "onehot":
+            sz, emb, num_cats = sum(contexts), OneHotEncoder(contexts), sum(contexts) * [1]
+        elif enc_emb == "eye" and enc_type != "argmax":
+            sz, emb, num_cats = len(contexts), EyeEncoder(), contexts
+        elif enc_emb == "embed":
+            sz, emb, num_cats = data_size[0] * len(contexts), CatEmbeddings(contexts, data_size[0], init=init), None
+        else:
+            raise NotImplementedError("contextflow_amd ContextEncoder: enc-emb=%s with enc-type=%s" % (enc_emb, enc_type))
+        if enc_type == "uniform" and num_cats is not None:
+            encoder = UniformCatDequantization(num_cats=num_cats)
+        elif enc_type == "eyesample":
+            encoder = EyeSampling()
+        else:
+            raise NotImplementedError(
+                "contextflow_amd ContextEncoder: enc-type=%s (the variational / argmax / probsample encoders are "
+                "conditional flows over the context; not built)" % enc_type)
+        super().__init__(emb, encoder)
+        self.C = sz
+        self.contexts = contexts

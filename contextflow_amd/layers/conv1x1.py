@@ -1,9 +1,10 @@
-"""Invertible 1x1 convolution (reference: contextflow/layers/conv1x1.py:9-77), context-free branch."""
+"""Invertible 1x1 convolution (reference: contextflow/layers/conv1x1.py:9-77): the shared matrix of the generalist
+and the per-sample triangular matrix CN(c) of the specialist mode (conv1x1.py:34-50)."""
 import torch
 import torch.nn as nn
 
 from . import _hip
-from .flowlayer import FlowLayer, no_context
+from .flowlayer import FlowLayer
 
 
 def slogdet_inverse(W, want_inverse):
@@ -27,16 +28,40 @@ def conv1x1_apply(x, W, bias=None):
 class Conv1x1(FlowLayer):
     def __init__(self, data_size, context_net=None, contextflow=False):
         super().__init__()
-        no_context("Conv1x1", context_net)
         D, H, W = data_size if len(data_size) == 3 else (data_size[0], 1, 1)
         self.D, self.H, self.W = D, H, W
         self.NN = nn.Parameter(torch.empty(D, D))          # same parameter name as the reference
         nn.init.orthogonal_(self.NN)
         self.context_net = context_net
         self.contextflow = contextflow
+        if self.context_net:                               # conv1x1.py:20-26
+            self.C = self.context_net.C
+            self.CN = nn.Linear(self.C, D * D)
+            nn.init.zeros_(self.CN.weight)
+            nn.init.zeros_(self.CN.bias)
+            if self.contextflow:
+                self.NN.requires_grad_(False)
+
+    def _forward_ctx(self, x, context):
+        """conv1x1.py:34-50: per-sample triangular matrix from CN(c)."""
+        from .simple_vit import _linear
+        c, logp_c = self.context_net(context)
+        x, xbs = _hip.bview(x)
+        B, C, H, W = x.shape
+        m = _linear(_hip.f32(c), self.CN)                  # (B, C*C)
+        Wm = _hip.f32(self.NN.detach()) if self.contextflow else None
+        z = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+        ldj = torch.empty(B, device=x.device, dtype=torch.float32)
+        _hip.call("cf_conv1x1_ctx", _hip.p(x), _hip.p(m), _hip.p(Wm), _hip.p(z), _hip.p(ldj), B, C, H * W, xbs, _hip.stream())
+        if self.contextflow:
+            lad, _ = slogdet_inverse(Wm, False)
+            ldj = ldj + lad * float(H * W)
+        return z, ldj + logp_c * float(H * W)
 
     def forward(self, x, context=None):
         _hip.require_device(x, self.NN)
+        if self.context_net:
+            return self._forward_ctx(x, context)
         B, _, H, W = x.shape
         Wm = _hip.f32(self.NN.detach())
         z = conv1x1_apply(x, Wm)
@@ -45,6 +70,8 @@ class Conv1x1(FlowLayer):
 
     def reverse(self, z, context=None):
         _hip.require_device(z, self.NN)
+        if self.context_net:
+            raise NotImplementedError("Conv1x1.reverse with a context net (the reference's own is marked 'to update')")
         _, inv = slogdet_inverse(_hip.f32(self.NN.detach()), True)
         return conv1x1_apply(z, inv)                       # conv1x1.py:72
 

@@ -59,19 +59,67 @@ class _AffineCoupling(FlowLayer):
 class Coupling(_AffineCoupling):
     def __init__(self, data_channels, kernel_size=(1, 1), padding=(0, 0), context_net=None, contextflow=False):
         super().__init__()
-        no_context("Coupling", context_net)
         D, Hd, O = data_channels // 2, data_channels * 2, data_channels
-        self.context_net = context_net
+        self.context_net = context_net                     # registered before NN, as in the reference (key order)
         self.contextflow = contextflow
+        concat = bool(context_net) and not contextflow       # coupling.py:33-34: CN(c) concatenated to the net input
         self.NN = nn.Sequential(
-            nn.Conv2d(D, Hd, 1), nn.ReLU(),
+            nn.Conv2d(D + O if concat else D, Hd, 1), nn.ReLU(),
             nn.Conv2d(Hd, Hd, kernel_size, padding=padding, padding_mode="reflect"), nn.ReLU(),
             nn.Conv2d(Hd, O, 1))
+        if self.context_net:                               # coupling.py:31-37
+            if self.contextflow:
+                for p in self.NN.parameters():
+                    p.requires_grad_(False)
+            self.C = self.context_net.C
+            self.CN = nn.Sequential(nn.Linear(self.C, Hd), nn.ReLU(), nn.Linear(Hd, Hd), nn.ReLU(), nn.Linear(Hd, O))
 
     def net(self, x0):
         h = conv2d_reflect(x0, self.NN[0], True)
         h = conv2d_reflect(h, self.NN[2], True)
         return conv2d_reflect(h, self.NN[4], False)
+
+    def _net_ctx(self, x0, context):
+        """coupling.py:39-47: h = NN(x0) + CN(c) (contextflow) or NN([x0 ; CN(c) broadcast]) — the broadcast part of the
+        first 1x1 convolution is a per-sample bias W[:, D:] CN(c) + b."""
+        from .simple_vit import _linear
+        c, logp_c = self.context_net(context)
+        cn = _linear(_linear(_linear(_hip.f32(c), self.CN[0], act=2), self.CN[2], act=2), self.CN[4])    # (B, O)
+        x0, xbs = _hip.bview(x0)
+        B, D, H, W = x0.shape
+        st = _hip.stream()
+        if self.contextflow:
+            h = self.net(x0)
+            _hip.call("cf_add_sample_bias", _hip.p(h), _hip.p(cn), B, h.shape[1], H * W, 0, st)
+            return h, logp_c
+        c1 = self.NN[0]
+        w = _hip.f32(c1.weight.detach())
+        Hd = w.shape[0]
+        wx = w[:, :D].contiguous()
+        wc = w[:, D:, 0, 0].contiguous()
+        bias_b = torch.empty(B, Hd, device=x0.device, dtype=torch.float32)       # W[:, D:] cn_b + b
+        _hip.call("cf_linear", _hip.p(cn), _hip.p(wc), _hip.p(_hip.f32(c1.bias.detach())), None, _hip.p(bias_b), B,
+                  wc.shape[1], Hd, 0, st)
+        h1 = torch.empty(B, Hd, H, W, device=x0.device, dtype=torch.float32)
+        _hip.call("cf_conv2d_reflect", _hip.p(x0), _hip.p(wx), None, _hip.p(h1), B, D, Hd, H, W, 1, 1, 0, 0, 0, xbs, st)
+        _hip.call("cf_add_sample_bias", _hip.p(h1), _hip.p(bias_b), B, Hd, H * W, 1, st)
+        h = conv2d_reflect(h1, self.NN[2], True)
+        return conv2d_reflect(h, self.NN[4], False), logp_c
+
+    def forward(self, x, context=None):
+        if not self.context_net:
+            return super().forward(x, context)
+        _hip.require_device(x)
+        h, logp_c = self._net_ctx(x[:, : x.shape[1] // 2], context)
+        z, ldj = coupling_apply(x, h, False)
+        return z, ldj + logp_c * float(x.shape[2] * x.shape[3])
+
+    def reverse(self, z, context=None):
+        if not self.context_net:
+            return super().reverse(z, context)
+        _hip.require_device(z)
+        h, _ = self._net_ctx(z[:, : z.shape[1] // 2], context)
+        return coupling_apply(z, h, True)[0]
 
 
 class CouplingFC(Coupling):

@@ -78,7 +78,6 @@ def gmm_logprob(x, prepared, out=None, accumulate=False):
 class GaussianMixtureDistribution(nn.Module):
     def __init__(self, size, mixtures=2, components=8, context_net=None, contextflow=False):
         super().__init__()
-        no_context("GaussianMixtureDistribution", context_net)
         self.size = size
         D, H, W = size
         self.D = D
@@ -89,13 +88,34 @@ class GaussianMixtureDistribution(nn.Module):
         self.wG = nn.Parameter(torch.randn(M, K))
         self.context_net = context_net
         self.contextflow = contextflow
+        if self.context_net:                                # gaussian.py:130-137
+            self.C = self.context_net.C
+            if self.contextflow:
+                for p in (self.mG, self.sG, self.wG):
+                    p.requires_grad_(False)
 
     def prepared(self):
         return gmm_prepare(self.mG.detach(), self.sG.detach(), self.wG.detach())
 
+    def _log_prob_ctx(self, input, context):
+        """gaussian.py:146-158: per-sample shifts (B, 2, M, K, D) of the component means / pre-softplus scales."""
+        if isinstance(context, list):
+            context = context[0]
+        c, logp_c = self.context_net(context)
+        x, xbs = _hip.bview(input)
+        B, D, H, W = x.shape
+        M, K = self.M, self.K
+        logw = torch.log_softmax(_hip.f32(self.wG.detach()), dim=-1).contiguous()
+        out = torch.empty(B, M, device=x.device, dtype=torch.float32)
+        _hip.call("cf_gmm_ctx_logprob", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(_hip.f32(self.sG.detach())),
+                  _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(out), B, M, K, D, H * W, xbs, 0, _hip.stream())
+        return out + (logp_c * float(H * W)).unsqueeze(-1)
+
     def log_prob(self, input, context=None):
         """(B, M) class-mixture log-densities   gaussian.py:142-161."""
         _hip.require_device(input, self.mG)
+        if self.context_net:
+            return self._log_prob_ctx(input, context)
         return gmm_logprob(input, self.prepared())
 
     def sample(self, n_samples, context=None):

@@ -66,7 +66,11 @@ class FlowSequential(nn.Module):
     def _fusable(self):
         if not self.fused or not isinstance(self.dist, GaussianMixtureDistribution):
             return False
+        if getattr(self.dist, "context_net", None):
+            return False                     # specialist models run layer by layer (per-sample parameters)
         for m in self.sequence_modules:
+            if getattr(m, "context_net", None) or getattr(getattr(m, "dist", None), "context_net", None):
+                return False
             if isinstance(m, ActNorm) and not m.is_initialized():
                 return False
         return True

@@ -16,10 +16,8 @@ StudentMixtureDistribution = _stub("StudentMixtureDistribution", "--dist tdist; 
 ConditionalGaussianDistribution = _stub("ConditionalGaussianDistribution", "specialist context encoders")
 GaussianDistribution = _stub("GaussianDistribution", "unused by create_model")
 MultivariateGaussianMixtureDistribution = _stub("MultivariateGaussianMixtureDistribution", "unused by create_model")
-UniformCatDequantization = _stub("UniformCatDequantization", "specialist context encoders")
 VariationalCatDequantization = _stub("VariationalCatDequantization", "specialist context encoders")
 ArgmaxCatDequantization = _stub("ArgmaxCatDequantization", "specialist context encoders")
-EyeSampling = _stub("EyeSampling", "specialist context encoders")
 ProbSampling = _stub("ProbSampling", "specialist context encoders")
 SmoothLeakyRelu = _stub("SmoothLeakyRelu", "activation layers are disabled in every config")
 LearnableLeakyRelu = _stub("LearnableLeakyRelu", "activation layers are disabled in every config")

@@ -2,9 +2,10 @@
 without its module-global `c` (model.py:113,125 read `c.dataset`; here `config['dataset']`).
 
 Same call signature and the same layer order, so `state_dict` keys are identical (SURVEY.md
-Appendix B).  Only the generalist / context-free models are built here; specialist context encoders
-are a later scope row."""
-from .layers import (ActNorm, Augment, Conv1x1, Coupling, Dequantization, FlowSequential,
+Appendix B).  Generalist (context-free) models, and specialist models (`generalist=False`: every Conv1x1 / ActNorm /
+Coupling gets its own ContextEncoder, the priors an embedding lookup — model.py:117-162) for the conv couplings with
+the eye | onehot + uniform context encoders."""
+from .layers import (ActNorm, Augment, ContextEncoder, Conv1x1, Coupling, Dequantization, FlowSequential,
                      GaussianMixtureDistribution, LogitTransform, Normalization, SplitPrior, Squeeze,
                      StandardNormal, TransCoupling, UniformDistribution)
 
@@ -29,8 +30,22 @@ def preset_config(dataset, coupling=None):
 
 
 def create_model(config, data_size=(1, 1, 1), mixtures=1, contexts=(-1,)):
-    if not config.get("generalist", True):
-        raise NotImplementedError("specialist (context-conditioned) models: SURVEY.md §8(f) rank 2")
+    generalist = config.get("generalist", True)
+    contextflow = bool(config.get("contextflow", False))
+    enc_emb, enc_type = config.get("enc_emb", "onehot"), config.get("enc_type", "uniform")
+    contexts = list(contexts)
+
+    def ctxnet(data_size, init="orthogonal", emb=None, typ=None):          # kwargs_context[mode] (model.py:93,117)
+        if generalist:
+            return None
+        return ContextEncoder(contexts, emb or enc_emb, typ or enc_type, data_size, init=init)
+
+    def prior(size):                                                       # model.py:157,162: simple lookup
+        cn = ctxnet((2 * mixtures * COMPONENTS * size[0] // len(contexts),), init="zeros", emb="embed", typ="eyesample")
+        return GaussianMixtureDistribution(size=size, mixtures=mixtures, components=COMPONENTS, context_net=cn,
+                                           contextflow=contextflow)
+    if not generalist and config["coupling"] != "conv":
+        raise NotImplementedError("specialist models: only --coupling conv is built (SURVEY.md 8(f) rank 2)")
     if config.get("dist", "gauss") != "gauss":
         raise NotImplementedError("only the Gaussian-mixture prior is implemented")
     dataset = config["dataset"]
@@ -51,18 +66,19 @@ def create_model(config, data_size=(1, 1, 1), mixtures=1, contexts=(-1,)):
             layers.append(Squeeze(patch_size=patch))
             sz = (sz[0] * patch[0] * patch[1], sz[1] // patch[0], sz[2] // patch[1])
         for _ in range(config["block_size"]):
-            layers.append(Conv1x1(sz))
+            layers.append(Conv1x1(sz, context_net=ctxnet((sz[0],), init="zeros"), contextflow=contextflow))
             if config["actnorm"]:
-                layers.append(ActNorm(sz))
+                layers.append(ActNorm(sz, context_net=ctxnet((2 * sz[0],)), contextflow=contextflow))
             if config["coupling"] == "trans" and sz[1] % patch[0] == 0 and sz[2] % patch[1] == 0:
                 layers.append(TransCoupling(sz, patch))
             elif config["coupling"] == "conv":
-                layers.append(Coupling(sz[0], kernel_size=krn, padding=pad))
+                layers.append(Coupling(sz[0], kernel_size=krn, padding=pad, context_net=ctxnet((sz[0],)),
+                                       contextflow=contextflow))
             elif config["coupling"] == "maf":
                 raise NotImplementedError("--coupling maf is outside the hot path (SURVEY.md §2 row 15)")
             if dataset == "atm":
                 raise NotImplementedError("ATM topology (PermuteAxes) is outside the hot path")
         if config["split_prior"] and blk < config["num_blocks"] - 1:
             sz = (sz[0] // 2, sz[1], sz[2])
-            layers.append(SplitPrior(GaussianMixtureDistribution(size=sz, mixtures=mixtures, components=COMPONENTS)))
-    return FlowSequential(GaussianMixtureDistribution(size=sz, mixtures=mixtures, components=COMPONENTS), *layers)
+            layers.append(SplitPrior(prior(sz)))
+    return FlowSequential(prior(sz), *layers)

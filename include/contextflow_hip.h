@@ -160,7 +160,7 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
 
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; K <= 128.
- * act: 0 none, 1 exact (erf) GELU.   nn.Linear of patch embedding / to_qkv / to_out / FeedForward.   */
+ * act: 0 none, 1 exact (erf) GELU, 2 ReLU.   nn.Linear of patch embedding / to_qkv / to_out / FeedForward; CN nets. */
 int cf_linear(const float* x, const float* Wt, const float* bias, const float* res, float* y,
               int rows, int K, int N, int act, cf_stream_t stream);
 /* y[r,:] = LayerNorm(x[r,:])*w + b (+ pos[r % ntok,:] if pos != NULL); biased variance, eps.          */
@@ -222,6 +222,27 @@ int cf_coupling_apply_bwd(const float* x, const float* h, const float* gz, const
  * (actnorm.py:53-60), one workgroup per channel, fixed order                                                  */
 int cf_channel_sums(const float* a, const float* b2, float* out, int B, int C, int HW, int64_t a_bstride,
                     int64_t b_bstride, cf_stream_t stream);
+
+/* ---- specialist (context-conditioned) branches: SURVEY 8(f) rank 2 ------------------------------------------
+ * ContextEncoder (model.py:30-90) = OneHotEncoder | EyeEncoder (rtdl/nn/_embeddings.py:76-150) followed by
+ * UniformCatDequantization (dequantize.py:55-64): out (B,width) = (code(ctx) + u) / qbins.  ctx (B,nctx) int64,
+ * card (nctx) int64 cardinalities (one-hot only).                                                             */
+int cf_ctx_encode(const int64_t* ctx, const float* u, const float* qbins, const int64_t* card, float* out, int B, int nctx,
+                  int width, int onehot, cf_stream_t stream);
+/* Conv1x1 with a context net (conv1x1.py:34-50): m (B, C*C) = CN(c); W_b = tril(m,-1) + diag(exp(diag m))
+ * [+ Wm - I when Wm != NULL: contextflow]; z[b] = W_b x[b]; ldj[b] = H*W*sum(diag m).  C <= 64.                */
+int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, float* ldj, int B, int C, int HW,
+                   int64_t x_bstride, cf_stream_t stream);
+/* ActNorm with a context net (actnorm.py:40-60): m (B, 2C) = CN(c) = [t_b | logs_b] (+ t, logs when non-NULL:
+ * contextflow); z = (x - t_b) exp(-logs_b); ldj[b] = sum_c logs_b.                                             */
+int cf_actnorm_ctx(const float* x, const float* m, const float* t, const float* logs, float* z, float* ldj, int B, int C,
+                   int HW, int64_t x_bstride, cf_stream_t stream);
+/* h[b,c,:] = act(h[b,c,:] + bias[b,c]) in place (the CN(c) term of the coupling net, coupling.py:44-47)        */
+int cf_add_sample_bias(float* h, const float* bias, int B, int C, int HW, int relu, cf_stream_t stream);
+/* GMM log_prob with per-sample shifts c (B,2,M,K,D) of means / pre-softplus scales (gaussian.py:142-158);
+ * mG, sG (M,K,D,HW) raw parameters, logw = log_softmax(wG); out (B,M) assigned or accumulated.                  */
+int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const float* logw, const float* c, float* out,
+                       int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate, cf_stream_t stream);
 
 /* ---- log-det bookkeeping (layers/flowsequential.py:18-27) --------------------------------------- */
 /* out[b,m] = ldM[b,m] + ld1[b]                                                                      */

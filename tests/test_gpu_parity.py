@@ -624,3 +624,34 @@ def test_training_steps_reduce_the_loss_smap(L):
         losses.append(float(loss.detach()))
     assert all(math.isfinite(v) for v in losses), losses
     assert losses[-1] < losses[0] - 1e-3, losses
+
+
+# ------------------------------------------------------------------------------------------ specialist (context) mode
+@pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye"])
+def test_specialist_forward_matches_reference(L, fxname):
+    """Context-conditioned models (create_model(generalist=False), model.py:117-162): per-sample Conv1x1 / ActNorm /
+    Coupling parameters from the context encoders + CN nets, context-shifted GMM priors — logp against the reference's
+    own output on the captured noise (tests/golden/spec_*.npz)."""
+    import contextflow_amd as cfa
+    from tests.helpers import load_specialist
+    name, ctx, ops, M, params, inp = load_specialist(fxname)
+    cfg, ds, MM = cfa.preset_config(name)
+    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type="uniform", contextflow=ctx["contextflow"])
+    model = cfa.create_model(cfg, ds, MM, contexts=ctx["contexts"])
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).eval()
+    from tests.gpu_util import set_noise
+    set_noise(model, inp["u"], inp["eps"])
+    encs = [m for m in model.modules() if isinstance(m, cfa.layers.UniformCatDequantization)]
+    assert len(encs) == len(inp["cnoise"])
+    for e, c in zip(encs, inp["cnoise"]):
+        e.fixed_noise = c.to(DEV)
+    z, logp = model(inp["x"].to(DEV), inp["context"].to(DEV))
+    assert (bpd(logp.cpu(), name) - bpd(inp["logp"], name)).abs().max().item() < BPD_TOL
+    assert (z.cpu() - inp["z"]).abs().max().item() < 2e-3
+    # ragged batch / different contexts per sample: first two samples alone give the same rows
+    for e, c in zip(encs, inp["cnoise"]):
+        e.fixed_noise = c[:2].to(DEV)
+    set_noise(model, inp["u"][:2], [e[:2] for e in inp["eps"]])
+    _, logp2 = model(inp["x"][:2].to(DEV), inp["context"][:2].to(DEV))
+    assert (logp2 - logp[:2]).abs().max().item() < 2e-2
