@@ -96,17 +96,30 @@ def test_no_cpu_fallback():
                 assert "/root/reference" not in src, f
 
 
-def test_specialist_and_offpath_names_raise():
+def test_unbuilt_names_raise_and_specialist_layout():
+    """Names outside the built scope raise at construction; the specialist models that ARE built (eye | onehot +
+    uniform context encoders, conv couplings) have the reference's state_dict layout (oracle.params.param_spec is
+    checked key for key against the reference by tests/golden/make_golden_specialist.py)."""
     import contextflow_amd as cfa
+    from oracle import flow_oracle as fo, params as op
+    from tests.helpers import SPECIALIST
     L = cfa.layers
     with pytest.raises(NotImplementedError):
-        L.Conv1x1((4, 2, 2), context_net=object())
+        L.TransCoupling((26, 8, 1), (2, 1), context_net=object())
     with pytest.raises(NotImplementedError):
         L.MaskedCoupling(4)
+    with pytest.raises(NotImplementedError):
+        L.ContextEncoder([15, 5], "onehot", "vardeq", (16,))
     assert set(L.SplineActivation((2, 2, 2), individual_weights=True).state_dict()) == {
         "unnormalized_widths", "unnormalized_heights", "unnormalized_derivatives"}
-    with pytest.raises(NotImplementedError):
-        cfa.create_model(dict(dataset="mnist", generalist=False, num_blocks=1, block_size=1), (1, 32, 32), 10)
+    for fxname, (name, ctx) in SPECIALIST.items():
+        cfg, ds, M = cfa.preset_config(name)
+        cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type="uniform", contextflow=ctx["contextflow"])
+        sd = cfa.create_model(cfg, ds, M, contexts=ctx["contexts"]).state_dict()
+        ops, ps, MM = fo.program(name)
+        spec = op.param_spec(ops, ps, MM, ctx)
+        assert list(sd.keys()) == list(spec.keys()), fxname
+        assert all(tuple(sd[k].shape) == tuple(spec[k][0]) for k in sd), fxname
 
 
 def test_shard_bounds():

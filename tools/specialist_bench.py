@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Throughput of the specialist (context-conditioned) forward, layer by layer.  usage: specialist_bench.py [B] [iters]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import contextflow_amd as cfa
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = "cuda:0"
+for name, contexts, emb, cf in (("cifar10", [15, 5], "onehot", True), ("cifar10", [15, 5], "eye", False), ("mnist", [64], "eye", True)):
+    torch.manual_seed(0)
+    cfg, ds, M = cfa.preset_config(name)
+    cfg.update(generalist=False, enc_emb=emb, enc_type="uniform", contextflow=cf)
+    model = cfa.create_model(cfg, ds, M, contexts=contexts).to(dev).eval()
+    for p in model.parameters():                       # CN nets are zero-initialised: perturb so that they do something
+        if p.abs().max() == 0:
+            p.data.normal_(0, 0.02)
+    x = torch.randint(0, 256, (B, *ds), device=dev).float()
+    ctx = torch.stack([torch.randint(0, k, (B,), device=dev) for k in contexts], 1)
+    with torch.no_grad():
+        for _ in range(2):
+            model(x, ctx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            _, logp = model(x, ctx)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    print("%s enc=%s contextflow=%s B=%d: %.2f ms = %.0f samples/s (logp finite: %s)" % (
+        name, emb, cf, B, dt * 1e3, B / dt, bool(torch.isfinite(logp).all())))
