@@ -86,10 +86,12 @@ __global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm,
 // SQ: x is the UN-squeezed tensor (B, C/4, 2H, 2W); Squeeze((2,2)) (squeeze.py:10-11) is folded into the x
 // staging: one 16-byte load along the un-squeezed row = channels (4c'+2i1, +1) of squeezed pixels (x, x+1).
 // dbg (optional, tests only): dumps of y0, h1, h2, h as [rows][tiles*PIX].
-template <class G, bool SQ>
+// CTX: per-sample bias of the specialist coupling (see conditioner_net); sb = (B, C) or (B, 2C) floats.
+template <class G, bool SQ, int CTX = 0>
 __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
                                                    float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                   int64_t xbs, float* __restrict__ dbg, int flags) {
+                                                   int64_t xbs, float* __restrict__ dbg, int flags,
+                                                   const float* __restrict__ sb) {
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
     constexpr int WPX = 32 * PTW;                     // pixel columns owned by one wave
@@ -152,7 +154,14 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
         }
 
         f32x16 acc3[RT03][PTW];
-        conditioner_net<G>(acc3, lds, wsl, pix, pin, lane, tid, dbg, dbg_cols, tile);
+        if constexpr (CTX == 0) {
+            conditioner_net<G>(acc3, lds, wsl, pix, pin, lane, tid, dbg, dbg_cols, tile);
+        } else {
+            int soff[PTW];
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) soff[q] = min(smp[q], B - 1) * (CTX == 1 ? C : HID);
+            conditioner_net<G, CTX>(acc3, lds, wsl, pix, pin, lane, tid, dbg, dbg_cols, tile, sb, soff);
+        }
 
         float lsum[PTW];
 #pragma unroll
@@ -232,21 +241,21 @@ int launch_prepare(const float* Wm, const float* t, const float* logs, const flo
     return 0;
 }
 
-template <class G, bool SQ>
+template <class G, bool SQ, int CTX = 0>
 int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, int flags,
-                hipStream_t s) {
+                hipStream_t s, const float* sb = nullptr) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G, SQ, CTX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024);
             if (e != hipSuccess) { cf_set_error("cf_flow_step_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
             raised = true;
         }
     }
     const int grid = (B + G::SPW - 1) / G::SPW;
-    k_flow_step<G, SQ><<<dim3(grid), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags);
+    k_flow_step<G, SQ, CTX><<<dim3(grid), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags, sb);
     return 0;
 }
 
@@ -498,6 +507,32 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     const int sid = shape_id(C, H, W);
     if ((sid == 2 && B < 256 * G32::SPW) || (sid == 3 && B < 256 * G64::SPW)) flags = 2 << 16;
     return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, flags, stream);
+}
+
+// specialist coupling (coupling.py:39-47): the same fused step with a per-sample bias from the CN net.
+// mode 1: sbias (B, C) added to the conditioner OUTPUT (contextflow); mode 2: sbias (B, 2C) added before the first ReLU
+// (CN(c) concatenated to the conditioner input).  The caller packs `ws` with cf_flow_step_prepare; with an identity
+// matrix / zero ActNorm there, the kernel is the Coupling layer alone (per-sample Conv1x1 / ActNorm run before it).
+int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, int mode, int B, int C,
+                         int H, int W, int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && z && ldj_acc && ws && sbias && (mode == 1 || mode == 2) && B >= 0 && x_bstride >= (int64_t)C * H * W);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && x_bstride % 4 == 0);
+    const float* w = (const float*)ws;
+    int rc = 0;
+#define CF_STEPC(G) rc = mode == 1 ? launch_step<G, false, 1>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), sbias) \
+                                   : launch_step<G, false, 2>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), sbias)
+    switch (shape_id(C, H, W)) {
+        case 0: CF_STEPC(G8); break;
+        case 1: CF_STEPC(G16); break;
+        case 2: CF_STEPC(G32); break;
+        case 3: CF_STEPC(G64); break;
+        default: cf_set_error("cf_flow_step_fwd_ctx: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+#undef CF_STEPC
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // extern "C"

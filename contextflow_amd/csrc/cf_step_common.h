@@ -185,11 +185,15 @@ __device__ __forceinline__ void z_store(float* __restrict__ z, const float* __re
 // ---- the conditioner: phases 1-3 of a step (shared by the forward and the inverse kernel) --------------
 // In: Y0 = y0 plane (this wave's columns).  Out: acc3 = NN.4 output tiles (t rows / raw rows, packed-row
 // layout of chan_of_row).  Uses the H region of LDS for h1 / h2; two workgroup barriers.
-template <class G>
+// CTX (specialist mode, coupling.py:39-47): 0 none; 1 per-sample bias sb[sample][C] added to the net OUTPUT
+// (h = NN(x0) + CN(c), contextflow); 2 per-sample bias sb[sample][HID] added before the first ReLU (CN(c) concatenated
+// to the net input = W[:, D:] CN(c) through the first 1x1).  soff[q] = this lane's row offset into sb.
+template <class G, int CTX = 0>
 __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW], float* __restrict__ lds,
                                                 const float* __restrict__ wsl, const int (&pix)[G::PTW],
                                                 const int (&pin)[G::PTW], int lane, int tid, float* __restrict__ dbg,
-                                                int64_t dbg_cols, int tile) {
+                                                int64_t dbg_cols, int tile, const float* __restrict__ sb = nullptr,
+                                                const int* soff = nullptr) {
     constexpr int C = G::C, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
     float* Y0 = lds;
@@ -202,6 +206,17 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
         for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
             for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B1 + rt * 32, lk);
+        if constexpr (CTX == 2) {
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+                for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rt * 32 + tile_row(r, lk);
+                        if (row < HID) acc[rt][q][r] += sb[soff[q] + row];
+                    }
+        }
         dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(wsl + G::OFF_A1), Y0, pix, lane);
 #pragma unroll
         for (int rt = 0; rt < RT1; ++rt)
@@ -333,6 +348,19 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
     for (int rt = 0; rt < RT03; ++rt)
 #pragma unroll
         for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(wsl + G::OFF_B3 + rt * 32, lk);
+    if constexpr (CTX == 1) {
+#pragma unroll
+        for (int rt = 0; rt < RT03; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = chan_of_row<G>(rt * 32 + (r & 3) + 8 * (r >> 2)) ;      // lk = 0 row; lk = 1 is +4
+                    const int ch1 = chan_of_row<G>(rt * 32 + (r & 3) + 8 * (r >> 2) + 4);
+                    const int c = lk ? ch1 : ch;
+                    if ((lk ? ch1 : ch) >= 0) acc3[rt][q][r] += sb[soff[q] + c];
+                }
+    }
     dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(wsl + G::OFF_A3), H1, pix, lane);
 }
 

@@ -73,6 +73,7 @@ class Coupling(_AffineCoupling):
                     p.requires_grad_(False)
             self.C = self.context_net.C
             self.CN = nn.Sequential(nn.Linear(self.C, Hd), nn.ReLU(), nn.Linear(Hd, Hd), nn.ReLU(), nn.Linear(Hd, O))
+        self.fused = True                                  # specialist: one-kernel path when the geometry allows it
 
     def net(self, x0):
         h = conv2d_reflect(x0, self.NN[0], True)
@@ -106,10 +107,48 @@ class Coupling(_AffineCoupling):
         h = conv2d_reflect(h1, self.NN[2], True)
         return conv2d_reflect(h, self.NN[4], False), logp_c
 
+    def _fused_ctx(self, x, context):
+        """The Coupling layer as ONE fp32-MFMA kernel (the fused flow-step kernel with an identity 1x1 / ActNorm in
+        front) with the CN(c) term as a per-sample bias: on the conditioner output (contextflow) or before its first
+        ReLU (CN(c) concatenated to the conditioner input: W[:, D:] CN(c))."""
+        from .simple_vit import _linear
+        c, logp_c = self.context_net(context)
+        cn = _linear(_linear(_linear(_hip.f32(c), self.CN[0], act=2), self.CN[2], act=2), self.CN[4])    # (B, O)
+        x, xbs = _hip.bview(x)
+        B, C, H, W = x.shape
+        D = C // 2
+        dev, st, f, pp = x.device, _hip.stream(), _hip.f32, _hip.p
+        c1, c2, c3 = self.NN[0], self.NN[2], self.NN[4]
+        w1 = f(c1.weight.detach())
+        if self.contextflow:
+            mode, sbias = 1, cn
+        else:
+            wc = w1[:, D:, 0, 0].contiguous()
+            sbias = torch.empty(B, wc.shape[0], device=dev, dtype=torch.float32)
+            _hip.call("cf_linear", pp(cn), pp(wc), None, None, pp(sbias), B, wc.shape[1], wc.shape[0], 0, st)
+            mode, w1 = 2, w1[:, :D].contiguous()
+        eye = torch.eye(C, device=dev, dtype=torch.float32)
+        zero = torch.zeros(C, device=dev, dtype=torch.float32)
+        ws = torch.empty(_hip.lib().cf_flow_step_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+        _hip.call("cf_flow_step_prepare", pp(eye), pp(zero), pp(zero), pp(w1), pp(f(c1.bias.detach())),
+                  pp(f(c2.weight.detach())), pp(f(c2.bias.detach())), pp(f(c3.weight.detach())), pp(f(c3.bias.detach())),
+                  pp(ws), C, H, W, st)
+        z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+        ldj = torch.zeros(B, device=dev, dtype=torch.float32)
+        _hip.call("cf_flow_step_fwd_ctx", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), mode, B, C, H, W, xbs, st)
+        return z, ldj + logp_c * float(H * W)
+
+    def _fused_ctx_ok(self, x):
+        k = self.NN[2]
+        return (self.fused and x.dim() == 4 and tuple(k.kernel_size) == (3, 3) and tuple(k.padding) == (1, 1)
+                and bool(_hip.lib().cf_flow_step_supported(x.shape[1], x.shape[2], x.shape[3], 3, 3)))
+
     def forward(self, x, context=None):
         if not self.context_net:
             return super().forward(x, context)
         _hip.require_device(x)
+        if self._fused_ctx_ok(x):
+            return self._fused_ctx(x, context)
         h, logp_c = self._net_ctx(x[:, : x.shape[1] // 2], context)
         z, ldj = coupling_apply(x, h, False)
         return z, ldj + logp_c * float(x.shape[2] * x.shape[3])

@@ -126,6 +126,12 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs,
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                      int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 
+/* the fused step with a per-sample bias from the specialist coupling's CN net (coupling.py:39-47):
+ * mode 1: sbias (B,C) added to the conditioner output (contextflow); mode 2: sbias (B,2C) added before the
+ * first ReLU (CN(c) concatenated to the conditioner input).                                                   */
+int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, int mode, int B, int C,
+                         int H, int W, int64_t x_bstride, cf_stream_t stream);
+
 /* inverse of the fused step (coupling.py:68-73, actnorm.py:78, conv1x1.py:72): x = step^-1(z) in ONE kernel.
  * `ws` is the forward table of cf_flow_step_prepare (the conditioner is the same); `wsi` holds
  * Wm^-1 diag(e^{logs}) in fragment order and Wm^-1 t, built by cf_flow_step_inv_prepare.               */
