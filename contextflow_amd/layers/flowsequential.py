@@ -75,6 +75,13 @@ class FlowSequential(nn.Module):
                 return False
         return True
 
+    def _needs_only_init(self):
+        """True when the fused plan is blocked only by ActNorm layers that have not seen their first batch yet."""
+        if not self.fused or not isinstance(self.dist, GaussianMixtureDistribution) or getattr(self.dist, "context_net", None):
+            return False
+        return not any(getattr(m, "context_net", None) or getattr(getattr(m, "dist", None), "context_net", None)
+                       for m in self.sequence_modules)
+
     @staticmethod
     def _step_supported(conv, act, cpl, shape):
         if not (isinstance(conv, Conv1x1) and isinstance(act, ActNorm) and type(cpl) is Coupling):
@@ -273,9 +280,12 @@ class FlowSequential(nn.Module):
     # ------------------------------------------------------------------ reference API
     def forward(self, input, context=None):
         _hip.require_device(input)
-        if torch.is_grad_enabled() and self._fusable():
+        if torch.is_grad_enabled():
             params = [p for p in self.parameters() if p.requires_grad]
-            if params:                       # training: same kernels + a tape, hand-written backward (autograd.py)
+            if params and not self._fusable() and self._needs_only_init():
+                with torch.no_grad():        # first training call: the ActNorm data-dependent init (actnorm.py:28-35)
+                    self._forward_layers(input, context)
+            if params and self._fusable():   # training: same kernels + a tape, hand-written backward (autograd.py)
                 from .autograd import FlowLogProb
                 return FlowLogProb.apply(self, input, *params)
         with torch.no_grad():

@@ -501,8 +501,8 @@ def test_training_steps_reduce_the_loss(L):
     gt = torch.randint(0, M, (B,), generator=g)
     x = (torch.randint(0, 200, (B, *ds), generator=g).float() + 5.0 * gt.view(B, 1, 1, 1).float()).clamp(0, 255)
     x, gt = x.to(DEV), gt.to(DEV)
-    with torch.no_grad():
-        model(x)                                         # ActNorm data-dependent init
+    # no separate init call: as in the reference's loop, the first training forward runs the ActNorm data-dependent
+    # init itself and still returns a differentiable logp
     opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
     dim_inv = 1.0 / (ds[0] * ds[1] * ds[2])
     losses = []
