@@ -153,6 +153,39 @@ __global__ __launch_bounds__(256) void k_gmm_ctx(const float* __restrict__ x, co
     }
 }
 
+// ConditionalGaussianDistribution.sample (gaussian.py:263-270): c = [mean | log_scale] (B, 2D) from the context
+// embedding; x = mean + exp(log_scale) eps; logp[b] = sum_d (-1/2 log 2pi - log_scale - eps^2 / 2).
+__global__ __launch_bounds__(64) void k_cond_gauss_sample(const float* __restrict__ c, const float* __restrict__ eps,
+                                                          float* __restrict__ x, float* __restrict__ logp, int D) {
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const float mean = c[(int64_t)b * 2 * D + d], ls = c[(int64_t)b * 2 * D + D + d], e = eps[(int64_t)b * D + d];
+        const float xv = mean + expf(ls) * e;
+        x[(int64_t)b * D + d] = xv;
+        const float r = xv - mean;
+        acc += -0.91893853320467274178f - ls - 0.5f * expf(-2.0f * ls) * r * r;
+    }
+    acc = cf_wave_sum(acc);
+    if (threadIdx.x == 0) logp[b] = acc;
+}
+
+// Sigmoid activation layer with its log-det (activations.py:234-238, temperature 1):
+// y = sigmoid(x), ldj[b] = sum_d (-softplus(-x) - softplus(x)).
+__global__ __launch_bounds__(64) void k_sigmoid_ldj(const float* __restrict__ x, float* __restrict__ y,
+                                                    float* __restrict__ ldj, int D) {
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    for (int d = threadIdx.x; d < D; d += 64) {
+        const float v = x[(int64_t)b * D + d];
+        y[(int64_t)b * D + d] = 1.0f / (1.0f + expf(-v));
+        const float a = fabsf(v);
+        acc -= a + 2.0f * log1pf(expf(-a));            // softplus(v) + softplus(-v) = |v| + 2 log(1 + e^-|v|)
+    }
+    acc = cf_wave_sum(acc);
+    if (threadIdx.x == 0) ldj[b] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,6 +239,22 @@ int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const f
     const size_t lds = (size_t)(D * HW + M * K) * sizeof(float);
     if (lds > 64 * 1024) { cf_set_error("cf_gmm_ctx_logprob: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
     k_gmm_ctx<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, M, K, D, HW, x_bstride, accumulate);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_cond_gauss_sample(const float* c, const float* eps, float* x, float* logp, int B, int D, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(c && eps && x && logp && B >= 0 && D > 0);
+    k_cond_gauss_sample<<<dim3(B), dim3(64), 0, cf_s(stream)>>>(c, eps, x, logp, D);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_sigmoid_ldj(const float* x, float* y, float* ldj, int B, int D, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && y && ldj && B >= 0 && D > 0);
+    k_sigmoid_ldj<<<dim3(B), dim3(64), 0, cf_s(stream)>>>(x, y, ldj, D);
     CF_LAUNCH_CHECK();
     return 0;
 }

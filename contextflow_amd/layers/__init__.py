@@ -23,8 +23,8 @@ from .squeeze import Squeeze, UnSqueeze
 from .transforms import LogitTransform
 from .coupling import Coupling, CouplingFC, TransCoupling
 from .simple_vit import SimpleViT, posemb_sincos_2d
-from .context import (CatEmbeddings, ContextEncoder, EyeEncoder, EyeSampling, OneHotEncoder,
-                      UniformCatDequantization)
+from .context import (CatEmbeddings, ConditionalGaussianDistribution, ContextEncoder, EyeEncoder, EyeSampling,
+                      OneHotEncoder, UniformCatDequantization, VariationalCatDequantization)
 from .unsupported import *  # noqa: F401,F403
 
 _ref = _os.environ.get("CONTEXTFLOW_REFERENCE_LAYERS")

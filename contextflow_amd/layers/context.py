@@ -2,9 +2,9 @@
 layers/rtdl/nn/_embeddings.py:76-285): a discrete context (B, n) of integer codes becomes the continuous vector c (B, C)
 that the CN nets of Conv1x1 / ActNorm / Coupling consume, plus a log-density term.
 
-Built: `enc_emb` eye | onehot with `enc_type` uniform (uniform dequantisation of the code) and the `embed` +
-`eyesample` table lookup of the priors.  The variational / argmax / probsample encoders (small conditional flows
-over the context) raise NotImplementedError.
+Built: `enc_emb` eye | onehot with `enc_type` uniform (uniform dequantisation of the code) or vardeq (variational
+dequantisation: the noise comes from a small conditional flow over the context), and the `embed` + `eyesample` table
+lookup of the priors.  The argmax / probsample encoders raise NotImplementedError.
 
 Module and buffer names follow the reference so that checkpoints load: ContextEncoder = Sequential(emb, encoder);
 OneHotEncoder.cardinalities, UniformCatDequantization.{qbins, ldj_per_dim}, CatEmbeddings._embeddings.N.weight."""
@@ -88,6 +88,67 @@ class UniformCatDequantization(nn.Module):
         return (z * self.qbins).floor().clamp(min=0).minimum(self.qbins - 1).long()
 
 
+class ConditionalGaussianDistribution(nn.Module):
+    """gaussian.py:234-270: diagonal Gaussian whose mean / log-scale are looked up from the context."""
+
+    def __init__(self, size, mixtures=1, context_net=None, contextflow=False):
+        super().__init__()
+        assert mixtures == 1, "mixtures should be 1 in GaussianDistribution"
+        self.size, self.D, self.M = tuple(size), size[0], mixtures
+        self.context_net = context_net
+        self.contextflow = contextflow
+        self.fixed_noise = None
+
+    def sample(self, n_samples, context=None):
+        c, _ = self.context_net(context)                     # (B, 2D) = [mean | log_scale]
+        c = _hip.f32(c)
+        D = self.D
+        eps = self.fixed_noise if self.fixed_noise is not None else torch.randn(n_samples, D, device=c.device)
+        x = torch.empty(n_samples, D, device=c.device, dtype=torch.float32)
+        logp = torch.empty(n_samples, device=c.device, dtype=torch.float32)
+        _hip.call("cf_cond_gauss_sample", _hip.p(c), _hip.p(_hip.f32(eps)), _hip.p(x), _hip.p(logp), n_samples, D,
+                  _hip.stream())
+        return x, logp
+
+
+class VariationalCatDequantization(nn.Module):
+    """dequantize.py:73-123: z = (x + sigmoid(u)) / K with u from the encoder flow;
+    ldj = sum_d(-log K_d * n_dims) + ldj_sigmoid - log q(u)."""
+
+    def __init__(self, encoder, num_cats=(1,)):
+        super().__init__()
+        self.D = len(num_cats)
+        self.register_buffer("qbins", torch.tensor(num_cats, dtype=torch.float))
+        self.register_buffer("ldj_per_dim", -torch.log(torch.tensor(num_cats, dtype=torch.float)))
+        self.encoder = encoder
+        self.sigmoid = _Sigmoid()
+
+    def forward(self, input):
+        x, context = input
+        dev = self.qbins.device
+        B, width = context.shape[0], self.D
+        onehot = isinstance(x, OneHotEncoder)
+        ctx = context.to(device=dev, dtype=torch.int64).contiguous()
+        u, qu = self.encoder.sample(ctx, ctx)
+        su = torch.empty_like(u)
+        act_ldj = torch.empty(B, device=dev, dtype=torch.float32)
+        _hip.call("cf_sigmoid_ldj", _hip.p(u), _hip.p(su), _hip.p(act_ldj), B, width, _hip.stream())
+        z = torch.empty(B, width, device=dev, dtype=torch.float32)
+        card = x.cardinalities.to(torch.int64) if onehot else None
+        _hip.call("cf_ctx_encode", _hip.p(ctx), _hip.p(su), _hip.p(self.qbins), _hip.p(card), _hip.p(z), B, ctx.shape[1],
+                  width, int(onehot), _hip.stream())
+        ldj = (self.ldj_per_dim * width).sum(-1).repeat(B)
+        return z, ldj + act_ldj - qu
+
+
+class _Sigmoid(nn.Module):
+    """Parameter holder of activations.Sigmoid (buffer `temperature` = 1); the arithmetic is cf_sigmoid_ldj."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("temperature", torch.Tensor([1.0]))
+
+
 class EyeSampling(nn.Module):
     """dequantize.py:129-142: pass-through, zero log-density."""
 
@@ -114,6 +175,19 @@ class ContextEncoder(nn.Sequential):
             raise NotImplementedError("contextflow_amd ContextEncoder: enc-emb=%s with enc-type=%s" % (enc_emb, enc_type))
         if enc_type == "uniform" and num_cats is not None:
             encoder = UniformCatDequantization(num_cats=num_cats)
+        elif enc_type == "vardeq" and num_cats is not None:                   # model.py:52-79
+            from .actnorm import ActNormFC
+            from .conv1x1 import FC
+            from .coupling import CouplingFC
+            from .flowsequential import FlowInvSequential
+            if sz % 2:
+                raise NotImplementedError("vardeq context encoder with an odd code width (the reference's Augment path)")
+            layers = []
+            for _ in range(2):
+                layers += [FC((sz,)), ActNormFC((sz,)), CouplingFC(sz)]
+            cnet = CatEmbeddings(contexts, 2 * sz // len(contexts), init="zeros")
+            encoder = VariationalCatDequantization(
+                FlowInvSequential(ConditionalGaussianDistribution(size=(sz,), context_net=cnet), *layers), num_cats=num_cats)
         elif enc_type == "eyesample":
             encoder = EyeSampling()
         else:

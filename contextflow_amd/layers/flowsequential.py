@@ -368,8 +368,29 @@ class GraphedFlow:
 
 
 class FlowInvSequential(nn.Module):
-    """Sampling-direction flow used only by the specialist context encoders (flowsequential.py:42-68)."""
+    """Sampling-direction flow of the variational context encoders (flowsequential.py:42-68): draw from `dist`, push
+    the sample through the layers' forward, subtract their log-dets from the log-density."""
 
     def __init__(self, dist, *modules):
         super().__init__()
-        raise NotImplementedError("FlowInvSequential belongs to the specialist path (SURVEY.md §8(f) rank 2)")
+        self.dist = dist
+        for i, module in enumerate(modules):
+            self.add_module(str(i), module)
+        self.sequence_modules = modules
+
+    def __iter__(self):
+        yield from self.sequence_modules
+
+    def forward(self, input, context=None):
+        return self.sample(input, context)
+
+    def log_prob(self, input, context=None):
+        raise RuntimeError("InverseFlow does not support log_prob, see Flow instead.")
+
+    def sample(self, input, context=None):
+        with torch.no_grad():
+            output, logprob = self.dist.sample(input.size(0), context)
+            for module in self.sequence_modules:
+                output, ldj = module(output, context)
+                logprob = logprob - ldj
+        return output, logprob

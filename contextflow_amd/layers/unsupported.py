@@ -13,10 +13,8 @@ def _stub(name, why):
 MaskedCoupling = _stub("MaskedCoupling", "--coupling maf; not in the benchmark configs, inverse is a stub upstream")
 PermuteAxes = _stub("PermuteAxes", "ATM topology only")
 StudentMixtureDistribution = _stub("StudentMixtureDistribution", "--dist tdist; non-default prior")
-ConditionalGaussianDistribution = _stub("ConditionalGaussianDistribution", "specialist context encoders")
 GaussianDistribution = _stub("GaussianDistribution", "unused by create_model")
 MultivariateGaussianMixtureDistribution = _stub("MultivariateGaussianMixtureDistribution", "unused by create_model")
-VariationalCatDequantization = _stub("VariationalCatDequantization", "specialist context encoders")
 ArgmaxCatDequantization = _stub("ArgmaxCatDequantization", "specialist context encoders")
 ProbSampling = _stub("ProbSampling", "specialist context encoders")
 SmoothLeakyRelu = _stub("SmoothLeakyRelu", "activation layers are disabled in every config")

@@ -250,6 +250,12 @@ int cf_add_sample_bias(float* h, const float* bias, int B, int C, int HW, int re
 int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const float* logw, const float* c, float* out,
                        int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate, cf_stream_t stream);
 
+/* pieces of the variational context encoder (model.py:52-79, dequantize.py:104-118):
+ * ConditionalGaussianDistribution.sample (gaussian.py:263-270): c (B,2D) = [mean|log_scale], eps (B,D) ->
+ * x = mean + exp(log_scale) eps, logp (B); Sigmoid layer (activations.py:234-238): y, ldj (B).                 */
+int cf_cond_gauss_sample(const float* c, const float* eps, float* x, float* logp, int B, int D, cf_stream_t stream);
+int cf_sigmoid_ldj(const float* x, float* y, float* ldj, int B, int D, cf_stream_t stream);
+
 /* ---- log-det bookkeeping (layers/flowsequential.py:18-27) --------------------------------------- */
 /* out[b,m] = ldM[b,m] + ld1[b]                                                                      */
 int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream);

@@ -346,6 +346,47 @@ def ctx_encode(context, ctx, u):
     return z, ldj.repeat(x.shape[0])
 
 
+def _ctx_code(context, ctx, dtype):
+    K = ctx["contexts"]
+    if ctx["enc_emb"] == "onehot":
+        return (torch.cat([F.one_hot(context[:, i], K[i]) for i in range(len(K))], 1).to(dtype),
+                torch.ones(sum(K), dtype=torch.float32))
+    return context.to(dtype), torch.tensor(K, dtype=torch.float32)
+
+
+def ctx_encode_vardeq(context, ctx, params, prefix, eps):
+    """VariationalCatDequantization (dequantize.py:104-118) over the reference's encoder flow (model.py:52-79):
+    u ~ FlowInvSequential(ConditionalGaussianDistribution(embedding lookup), 2 x [FC, ActNormFC, CouplingFC])
+    (flowsequential.py:58-68, gaussian.py:263-270), then Sigmoid (activations.py:234-238):
+    z = (x + sigmoid(u)) / qbins, ldj = sum_d(-log qbins_d * n_dims) + ldj_sigmoid - log q(u).
+    `prefix` = '<layer>.context_net.1.'; ActNormFC parameters must be initialised (post first call)."""
+    x, qbins = _ctx_code(context, ctx, eps.dtype)
+    n = x.shape[1]
+    e = prefix + "encoder."
+    c = torch.cat([params[e + "dist.context_net._embeddings.%d.weight" % i][context[:, i]] for i in range(len(ctx["contexts"]))], 1)
+    mean, ls = c[:, :n], c[:, n:]
+    u = mean + ls.exp() * eps
+    logq = (-0.5 * LOG_2PI - ls - 0.5 * torch.exp(-2 * ls) * (u - mean) ** 2).sum(-1)
+    for l in range(2):
+        W = params[e + "%d.NN" % (3 * l)]                                          # FC (conv1x1.py:80-96)
+        u = u @ W.t()
+        logq = logq - torch.linalg.slogdet(W)[1]
+        t, logs = params[e + "%d.NN_t" % (3 * l + 1)], params[e + "%d.NN_logs" % (3 * l + 1)]      # ActNormFC
+        u = (u - t) * torch.exp(-logs)
+        logq = logq - logs.sum()
+        q = e + "%d." % (3 * l + 2)                                                # CouplingFC (1x1 convs)
+        h = F.relu(u[:, : n // 2] @ params[q + "NN.0.weight"].flatten(1).t() + params[q + "NN.0.bias"])
+        h = F.relu(h @ params[q + "NN.2.weight"].flatten(1).t() + params[q + "NN.2.bias"])
+        h = h @ params[q + "NN.4.weight"].flatten(1).t() + params[q + "NN.4.bias"]
+        tt, lsc = h[:, : n // 2], 2.0 * torch.tanh(h[:, n // 2:] / 2.0)
+        u = torch.cat([u[:, : n // 2], u[:, n // 2:] * torch.exp(lsc) + tt], 1)
+        logq = logq - lsc.sum(-1)
+    act_ldj = (-F.softplus(-u) - F.softplus(u)).sum(-1)                          # temperature 1
+    z = (x + torch.sigmoid(u)) / qbins.to(eps.dtype)
+    ldj = ((-torch.log(qbins)) * n).sum(-1).to(eps.dtype)
+    return z, ldj + act_ldj - logq
+
+
 def conv1x1_ctx_fwd(x, W, cn_w, cn_b, c, logp_c, contextflow):
     """conv1x1.py:34-50: per-sample triangular matrix from CN(c); log-det from its diagonal."""
     B, D, H, Wd = x.shape
@@ -447,7 +488,9 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None,
     eps = list(eps)
     cnoise = list(cnoise)          # specialist mode: one uniform noise tensor per context encoder, in layer order
 
-    def enc():
+    def enc(prefix=None):
+        if ctx.get("enc_type", "uniform") == "vardeq":
+            return ctx_encode_vardeq(context, ctx, params, prefix + "context_net.1.", cnoise.pop(0))
         return ctx_encode(context, ctx, cnoise.pop(0))
 
     def emb(prefix):
@@ -467,13 +510,13 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None,
         elif kind == "squeeze":
             x, ldj = squeeze_fwd(x, op[2]), torch.zeros(B, dtype=x.dtype)
         elif kind == "conv1x1" and ctx is not None:
-            c, lc = enc()
+            c, lc = enc(pre)
             x, ldj = conv1x1_ctx_fwd(x, params[pre + "NN"], params[pre + "CN.weight"], params[pre + "CN.bias"], c, lc,
                                      ctx["contextflow"])
         elif kind == "conv1x1":
             x, ldj = conv1x1_fwd(x, params[pre + "NN"])
         elif kind == "actnorm" and ctx is not None:
-            c, lc = enc()
+            c, lc = enc(pre)
             if init_actnorm and ctx["contextflow"]:                # actnorm.py:46: only the contextflow branch initialises
                 t, logs = actnorm_stats(x)
                 params[pre + "NN_t"], params[pre + "NN_logs"] = t, logs
@@ -481,7 +524,7 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None,
             x, ldj = actnorm_ctx_fwd(x, params[pre + "NN_t"], params[pre + "NN_logs"], params[pre + "CN.weight"],
                                      params[pre + "CN.bias"], c, lc, ctx["contextflow"])
         elif kind == "coupling" and ctx is not None:
-            c, lc = enc()
+            c, lc = enc(pre)
             x, ldj = coupling_ctx_fwd(x, params, pre, op[4], c, lc, ctx["contextflow"])
         elif kind == "split" and ctx is not None:
             cc = x.shape[1] // 2

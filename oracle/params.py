@@ -39,6 +39,21 @@ def _encoder(prefix, ctx, spec):
         cats = list(K)
     spec[prefix + "context_net.1.qbins"] = ((len(cats),), ("floats", tuple(float(v) for v in cats)))
     spec[prefix + "context_net.1.ldj_per_dim"] = ((len(cats),), ("floats", tuple(-float(np.log(np.float32(v))) for v in cats)))
+    if ctx.get("enc_type", "uniform") == "vardeq":     # model.py:52-79: the encoder flow of VariationalCatDequantization
+        n = len(cats)
+        e = prefix + "context_net.1.encoder."
+        for i, k in enumerate(K):
+            spec[e + "dist.context_net._embeddings.%d.weight" % i] = ((k, 2 * n // len(K)), "small")
+        for l in range(2):
+            spec[e + "%d.NN" % (3 * l)] = ((n, n), "orthogonal")
+            spec[e + "%d.NN_t" % (3 * l + 1)] = ((n,), "zeros")
+            spec[e + "%d.NN_logs" % (3 * l + 1)] = ((n,), "zeros")
+            spec[e + "%d.initialized" % (3 * l + 1)] = ((), "flag")
+            q = e + "%d." % (3 * l + 2)
+            for name, shp in (("NN.0", (2 * n, n // 2, 1, 1)), ("NN.2", (2 * n, 2 * n, 1, 1)), ("NN.4", (n, 2 * n, 1, 1))):
+                spec[q + name + ".weight"] = (shp, ("uniform", shp[1]))
+                spec[q + name + ".bias"] = ((shp[0],), ("uniform", shp[1]))
+        spec[prefix + "context_net.1.sigmoid.temperature"] = ((1,), ("floats", (1.0,)))
 
 
 def param_spec(ops, prior_size, mixtures, ctx=None):

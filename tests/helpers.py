@@ -65,6 +65,8 @@ SPECIALIST = {
     "mnist_onehot": ("mnist", dict(contexts=[64], enc_emb="onehot", contextflow=False)),
     "cifar10_onehot_cf": ("cifar10", dict(contexts=[15, 5], enc_emb="onehot", contextflow=True)),
     "cifar10_eye": ("cifar10", dict(contexts=[15, 5], enc_emb="eye", contextflow=False)),
+    "cifar10_onehot_vardeq": ("cifar10", dict(contexts=[15, 5], enc_emb="onehot", contextflow=False, enc_type="vardeq")),
+    "cifar10_eye_vardeq_cf": ("cifar10", dict(contexts=[15, 5], enc_emb="eye", contextflow=True, enc_type="vardeq")),
 }
 
 

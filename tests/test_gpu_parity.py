@@ -627,7 +627,8 @@ def test_training_steps_reduce_the_loss_smap(L):
 
 
 # ------------------------------------------------------------------------------------------ specialist (context) mode
-@pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye"])
+@pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye",
+                                    "cifar10_onehot_vardeq", "cifar10_eye_vardeq_cf"])
 def test_specialist_forward_matches_reference(L, fxname):
     """Context-conditioned models (create_model(generalist=False), model.py:117-162): per-sample Conv1x1 / ActNorm /
     Coupling parameters from the context encoders + CN nets, context-shifted GMM priors — logp against the reference's
@@ -636,18 +637,23 @@ def test_specialist_forward_matches_reference(L, fxname):
     from tests.helpers import load_specialist
     name, ctx, ops, M, params, inp = load_specialist(fxname)
     cfg, ds, MM = cfa.preset_config(name)
-    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type="uniform", contextflow=ctx["contextflow"])
+    enc_type = ctx.get("enc_type", "uniform")
+    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type=enc_type, contextflow=ctx["contextflow"])
     model = cfa.create_model(cfg, ds, MM, contexts=ctx["contexts"])
     model.load_state_dict(params, strict=True)
     model = model.to(DEV).eval()
     from tests.gpu_util import set_noise
     set_noise(model, inp["u"], inp["eps"])
-    encs = [m for m in model.modules() if isinstance(m, cfa.layers.UniformCatDequantization)]
+    noisy = cfa.layers.ConditionalGaussianDistribution if enc_type == "vardeq" else cfa.layers.UniformCatDequantization
+    encs = [m for m in model.modules() if isinstance(m, noisy)]
     assert len(encs) == len(inp["cnoise"])
     for e, c in zip(encs, inp["cnoise"]):
         e.fixed_noise = c.to(DEV)
     z, logp = model(inp["x"].to(DEV), inp["context"].to(DEV))
-    assert (bpd(logp.cpu(), name) - bpd(inp["logp"], name)).abs().max().item() < BPD_TOL
+    # |logp| reaches 1.4e5 in the vardeq fixture: one fp32 ulp there is 0.0156 nats = 7e-6 bits/dim, and the reference
+    # itself differs from its own fp64 evaluation by that much (make_golden_specialist.py prints 7.6e-6)
+    tol = 3e-5 if fxname == "cifar10_onehot_vardeq" else BPD_TOL
+    assert (bpd(logp.cpu(), name) - bpd(inp["logp"], name)).abs().max().item() < tol
     assert (z.cpu() - inp["z"]).abs().max().item() < 2e-3
     # ragged batch / different contexts per sample: first two samples alone give the same rows
     for e, c in zip(encs, inp["cnoise"]):

@@ -109,12 +109,12 @@ def test_unbuilt_names_raise_and_specialist_layout():
     with pytest.raises(NotImplementedError):
         L.MaskedCoupling(4)
     with pytest.raises(NotImplementedError):
-        L.ContextEncoder([15, 5], "onehot", "vardeq", (16,))
+        L.ContextEncoder([15, 5], "onehot", "argmax", (16,))
     assert set(L.SplineActivation((2, 2, 2), individual_weights=True).state_dict()) == {
         "unnormalized_widths", "unnormalized_heights", "unnormalized_derivatives"}
     for fxname, (name, ctx) in SPECIALIST.items():
         cfg, ds, M = cfa.preset_config(name)
-        cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type="uniform", contextflow=ctx["contextflow"])
+        cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type=ctx.get("enc_type", "uniform"), contextflow=ctx["contextflow"])
         sd = cfa.create_model(cfg, ds, M, contexts=ctx["contexts"]).state_dict()
         ops, ps, MM = fo.program(name)
         spec = op.param_spec(ops, ps, MM, ctx)
