@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .flowlayer import FlowLayer, no_context
+from .flowlayer import FlowLayer
 from .simple_vit import SimpleViT
 
 
@@ -180,19 +180,40 @@ class CouplingFC(Coupling):
 class TransCoupling(_AffineCoupling):
     def __init__(self, in_sz, p_sz, context_net=None, contextflow=False):
         super().__init__()
-        no_context("TransCoupling", context_net)
-        D, O = in_sz[0] // 2, in_sz[0]
+        D, Hd, O = in_sz[0] // 2, in_sz[0] * 2, in_sz[0]
         T = O * p_sz[0] * p_sz[1]                       # transformer width (coupling.py:108)
         self.context_net = context_net
         self.contextflow = contextflow
         self.in_sz, self.p_sz = tuple(in_sz), tuple(p_sz)
-        self.NN = nn.Sequential(SimpleViT(image_size=(in_sz[1], in_sz[2]), patch_size=p_sz, dim=T, depth=6, heads=1,
-                                          mlp_dim=T, channels=D))
+        vit = dict(image_size=(in_sz[1], in_sz[2]), patch_size=p_sz, dim=T, depth=6, heads=1, mlp_dim=T)
+        self.NN = nn.Sequential(SimpleViT(channels=D, **vit))
+        if self.context_net:                               # coupling.py:113-119
+            if not self.contextflow:
+                self.NN = SimpleViT(channels=D + O, **vit)  # input = [x0 ; CN(c) broadcast]; a direct child (key names)
+            else:
+                for p in self.NN.parameters():
+                    p.requires_grad_(False)
+            self.C = self.context_net.C
+            self.CN = nn.Sequential(nn.Linear(self.C, Hd), nn.ReLU(), nn.Linear(Hd, Hd), nn.ReLU(), nn.Linear(Hd, O))
         self.fused = True                                # one-kernel path when the geometry allows it
 
     def net(self, x0):
         """Conditioner output h (layer-by-layer kernels; also the fallback for unsupported geometries)."""
         return self.NN[0](x0)
+
+    def _net_ctx(self, x0, context):
+        """coupling.py:123-133 with a context net: h = ViT(x0) + CN(c) (contextflow) or ViT([x0 ; CN(c) broadcast]).
+        Quirk kept: logp_c is not multiplied by H*W here (unlike Coupling)."""
+        from .simple_vit import _linear
+        c, logp_c = self.context_net(context)
+        cn = _linear(_linear(_linear(_hip.f32(c), self.CN[0], act=2), self.CN[2], act=2), self.CN[4])    # (B, O)
+        B, _, H, W = x0.shape
+        if self.contextflow:
+            h = self.NN[0](x0)
+            _hip.call("cf_add_sample_bias", _hip.p(h), _hip.p(cn), B, h.shape[1], H * W, 0, _hip.stream())
+            return h, logp_c
+        xin = torch.cat([_hip.f32(x0), cn.view(B, -1, 1, 1).expand(B, cn.shape[1], H, W)], dim=1)   # concatenation: index op
+        return self.NN(xin), logp_c
 
     # ---- fused path: patchify -> ViT -> un-patchify -> affine map -> log-det in one kernel
     def _fused_ok(self, x):
@@ -237,12 +258,19 @@ class TransCoupling(_AffineCoupling):
 
     def forward(self, x, context=None):
         _hip.require_device(x)
+        if self.context_net:
+            h, logp_c = self._net_ctx(x[:, : x.shape[1] // 2], context)
+            z, ldj = coupling_apply(x, h, False)
+            return z, ldj + logp_c
         if self._fused_ok(x):
             return self._fused(x, False)
         return super().forward(x, context)
 
     def reverse(self, z, context=None):
         _hip.require_device(z)
+        if self.context_net:
+            h, _ = self._net_ctx(z[:, : z.shape[1] // 2], context)
+            return coupling_apply(z, h, True)[0]
         if self._fused_ok(z):
             return self._fused(z, True)[0]
         return super().reverse(z, context)

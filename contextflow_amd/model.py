@@ -44,8 +44,8 @@ def create_model(config, data_size=(1, 1, 1), mixtures=1, contexts=(-1,)):
         cn = ctxnet((2 * mixtures * COMPONENTS * size[0] // len(contexts),), init="zeros", emb="embed", typ="eyesample")
         return GaussianMixtureDistribution(size=size, mixtures=mixtures, components=COMPONENTS, context_net=cn,
                                            contextflow=contextflow)
-    if not generalist and config["coupling"] != "conv":
-        raise NotImplementedError("specialist models: only --coupling conv is built (SURVEY.md 8(f) rank 2)")
+    if not generalist and config["coupling"] not in ("conv", "trans"):
+        raise NotImplementedError("specialist models: --coupling conv | trans are built (SURVEY.md 8(f) rank 2)")
     if config.get("dist", "gauss") != "gauss":
         raise NotImplementedError("only the Gaussian-mixture prior is implemented")
     dataset = config["dataset"]
@@ -70,7 +70,7 @@ def create_model(config, data_size=(1, 1, 1), mixtures=1, contexts=(-1,)):
             if config["actnorm"]:
                 layers.append(ActNorm(sz, context_net=ctxnet((2 * sz[0],)), contextflow=contextflow))
             if config["coupling"] == "trans" and sz[1] % patch[0] == 0 and sz[2] % patch[1] == 0:
-                layers.append(TransCoupling(sz, patch))
+                layers.append(TransCoupling(sz, patch, context_net=ctxnet((sz[0],)), contextflow=contextflow))
             elif config["coupling"] == "conv":
                 layers.append(Coupling(sz[0], kernel_size=krn, padding=pad, context_net=ctxnet((sz[0],)),
                                        contextflow=contextflow))

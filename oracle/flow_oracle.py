@@ -217,12 +217,17 @@ def vit_dims(sz, patch):
                 depth=6, dim_head=64, patch_dim=(C // 2) * patch[0] * patch[1])
 
 
-def vit_net(x0, p, prefix, sz, patch):
-    """simple_vit.py:117-127 with Attention (:56-68), FeedForward (:30-40), Transformer (:71-88)."""
-    d = vit_dims(sz, patch)
+def vit_net(x0, p, prefix, sz, patch, concat=False):
+    """simple_vit.py:117-127 with Attention (:56-68), FeedForward (:30-40), Transformer (:71-88).
+    concat: the specialist non-contextflow variant (coupling.py:114-115): input = [x0 ; CN(c) broadcast], C/2 + C
+    channels, and the ViT is a direct child (`NN.` instead of `NN.0.`)."""
+    d = dict(vit_dims(sz, patch))
     B = x0.shape[0]
     p1, p2, gh, gw, dim = patch[0], patch[1], d["gh"], d["gw"], d["dim"]
-    q = prefix + "NN.0."
+    q = prefix + ("NN." if concat else "NN.0.")
+    if concat:
+        d["cin"] = x0.shape[1]
+        d["patch_dim"] = d["cin"] * p1 * p2
     # 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)'
     tok = x0.reshape(B, d["cin"], gh, p1, gw, p2).permute(0, 2, 4, 3, 5, 1).reshape(B, gh * gw, d["patch_dim"])
     tok = F.layer_norm(tok, (d["patch_dim"],), p[q + "to_patch_embedding.1.weight"], p[q + "to_patch_embedding.1.bias"])
@@ -435,6 +440,19 @@ def coupling_ctx_fwd(x, p, prefix, pad, c, logp_c, contextflow):
     return z, ldj + logp_c * H * Wd
 
 
+def transcoupling_ctx_fwd(x, p, prefix, sz, patch, c, logp_c, contextflow):
+    """coupling.py:123-147 with a context net; note: logp_c is NOT multiplied by H*W here (reference quirk)."""
+    B, C, H, Wd = x.shape
+    x0 = x[:, : C // 2]
+    cn = coupling_cn(c, p, prefix)
+    if contextflow:
+        h = vit_net(x0, p, prefix, sz, patch) + cn.view(B, -1, 1, 1)
+    else:
+        h = vit_net(torch.cat([x0, cn.view(B, -1, 1, 1).expand(B, cn.shape[1], H, Wd)], 1), p, prefix, sz, patch, concat=True)
+    z, ldj = coupling_apply_fwd(x, h)
+    return z, ldj + logp_c
+
+
 def gmm_ctx_logprob(x, mG, sG, wG, emb, context, chunk=16):
     """gaussian.py:142-158 with the 'embed' + 'eyesample' context net (model.py:157,162): per-sample additive
     shifts of the component means and pre-softplus scales, constant over (h, w); logp_c = 0."""
@@ -526,6 +544,9 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None,
         elif kind == "coupling" and ctx is not None:
             c, lc = enc(pre)
             x, ldj = coupling_ctx_fwd(x, params, pre, op[4], c, lc, ctx["contextflow"])
+        elif kind == "transcoupling" and ctx is not None:
+            c, lc = enc(pre)
+            x, ldj = transcoupling_ctx_fwd(x, params, pre, op[2], op[3], c, lc, ctx["contextflow"])
         elif kind == "split" and ctx is not None:
             cc = x.shape[1] // 2
             ldj = gmm_ctx_logprob(x[:, cc:], params[pre + "dist.mG"], params[pre + "dist.sG"], params[pre + "dist.wG"],

@@ -108,6 +108,11 @@ def param_spec(ops, prior_size, mixtures, ctx=None):
             d = vit_dims(op[2], op[3])
             dim, pd, inner = d["dim"], d["patch_dim"], d["dim_head"]
             q = pre + "NN.0."
+            if ctx is not None:                                               # coupling.py:107,113-119
+                _encoder(pre, ctx, spec)
+                if not ctx["contextflow"]:                                    # ViT over [x0 ; CN(c)], direct child
+                    C = op[2][0]
+                    pd, q = (C // 2 + C) * op[3][0] * op[3][1], pre + "NN."
             spec[q + "to_patch_embedding.1.weight"] = ((pd,), "ln_w")
             spec[q + "to_patch_embedding.1.bias"] = ((pd,), "ln_b")
             spec[q + "to_patch_embedding.2.weight"] = ((dim, pd), ("uniform", pd))
@@ -129,6 +134,11 @@ def param_spec(ops, prior_size, mixtures, ctx=None):
                 spec[f + "1.bias"] = ((dim,), ("uniform", dim))
                 spec[f + "3.weight"] = ((dim, dim), ("uniform", dim))
                 spec[f + "3.bias"] = ((dim,), ("uniform", dim))
+            if ctx is not None:
+                C = op[2][0]
+                for name, shp in (("CN.0", (2 * C, Cc)), ("CN.2", (2 * C, 2 * C)), ("CN.4", (C, 2 * C))):
+                    spec[pre + name + ".weight"] = (shp, ("uniform", shp[1]))
+                    spec[pre + name + ".bias"] = ((shp[0],), ("uniform", shp[1]))
         elif kind == "split":
             _gmm(pre + "dist.", op[2], mixtures, spec, ctx)
     return spec

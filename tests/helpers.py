@@ -67,6 +67,8 @@ SPECIALIST = {
     "cifar10_eye": ("cifar10", dict(contexts=[15, 5], enc_emb="eye", contextflow=False)),
     "cifar10_onehot_vardeq": ("cifar10", dict(contexts=[15, 5], enc_emb="onehot", contextflow=False, enc_type="vardeq")),
     "cifar10_eye_vardeq_cf": ("cifar10", dict(contexts=[15, 5], enc_emb="eye", contextflow=True, enc_type="vardeq")),
+    "smap_onehot_cf": ("smap", dict(contexts=[55], enc_emb="onehot", contextflow=True)),
+    "smap_eye": ("smap", dict(contexts=[55], enc_emb="eye", contextflow=False)),
 }
 
 

@@ -105,8 +105,6 @@ def test_unbuilt_names_raise_and_specialist_layout():
     from tests.helpers import SPECIALIST
     L = cfa.layers
     with pytest.raises(NotImplementedError):
-        L.TransCoupling((26, 8, 1), (2, 1), context_net=object())
-    with pytest.raises(NotImplementedError):
         L.MaskedCoupling(4)
     with pytest.raises(NotImplementedError):
         L.ContextEncoder([15, 5], "onehot", "argmax", (16,))

@@ -170,7 +170,7 @@ def test_unit_spline_activation(tag):
 
 
 @pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye",
-                                    "cifar10_onehot_vardeq", "cifar10_eye_vardeq_cf"])
+                                    "cifar10_onehot_vardeq", "cifar10_eye_vardeq_cf", "smap_onehot_cf", "smap_eye"])
 def test_specialist_oracle_matches_reference(fxname):
     """Context-conditioned (specialist) forward: every Conv1x1 / ActNorm / Coupling with its ContextEncoder + CN net,
     context-shifted GMM priors — oracle vs the reference's logp on the captured noise."""
@@ -178,5 +178,7 @@ def test_specialist_oracle_matches_reference(fxname):
     name, ctx, ops, M, params, inp = load_specialist(fxname)
     z, lp = fo.flow_forward(ops, params, inp["x"], inp["u"], inp["eps"], ctx=ctx, context=inp["context"], cnoise=inp["cnoise"])
     D = int(np.prod(fo.CONFIGS[name][0]))
-    assert (fo.bits_per_dim(lp, D) - fo.bits_per_dim(inp["logp"], D)).abs().max().item() < 1e-5
-    assert (z - inp["z"]).abs().max().item() < 2e-3
+    ref = fo.bits_per_dim(inp["logp"], D)
+    tol = max(1e-5, 1e-5 * ref.abs().max().item())      # |logp| ~ 1e6 in the un-normalised smap_eye configuration
+    assert (fo.bits_per_dim(lp, D) - ref).abs().max().item() < tol
+    assert (z - inp["z"]).abs().max().item() < 2e-3 * max(1.0, inp["z"].abs().max().item())
