@@ -21,9 +21,17 @@ __global__ __launch_bounds__(256) void k_ctx_encode(const int64_t* __restrict__ 
     if (e >= (int64_t)B * width) return;
     const int b = (int)(e / width), j = (int)(e - (int64_t)b * width);
     float x;
-    if (onehot) {
+    if (onehot) {                                     // modes 1 (one-hot) and 2 (binary sign code): find the variable
         int i = 0, off = 0;
         while (i < nctx - 1 && j >= off + (int)card[i]) { off += (int)card[i]; ++i; }
+        if (onehot == 2) {
+            // ArgmaxCatDequantization (dequantize.py:236-262): big-endian binary code of every context variable
+            // (card[i] = its number of bits), one zero pad column when the total is odd; z = u * (2 bit - 1)
+            const int nb = (int)card[i], k = j - off;
+            const int bit = (k < nb) ? (int)((ctx[(int64_t)b * nctx + i] >> (nb - 1 - k)) & 1) : 0;
+            out[e] = u[e] * (bit ? 1.f : -1.f);
+            return;
+        }
         x = (ctx[(int64_t)b * nctx + i] == (int64_t)(j - off)) ? 1.f : 0.f;
     } else {
         x = (float)ctx[(int64_t)b * nctx + j];
@@ -193,7 +201,7 @@ extern "C" {
 int cf_ctx_encode(const int64_t* ctx, const float* u, const float* qbins, const int64_t* card, float* out, int B, int nctx,
                   int width, int onehot, cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(ctx && u && qbins && out && B >= 0 && nctx > 0 && width > 0 && (!onehot || card));
+    CF_REQUIRE(ctx && u && out && B >= 0 && nctx > 0 && width > 0 && (!onehot || card) && (onehot == 2 || qbins));
     const int64_t total = (int64_t)B * width;
     k_ctx_encode<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, cf_s(stream)>>>(ctx, u, qbins, card, out, B, nctx,
                                                                                        width, onehot);

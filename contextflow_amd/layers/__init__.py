@@ -23,8 +23,9 @@ from .squeeze import Squeeze, UnSqueeze
 from .transforms import LogitTransform
 from .coupling import Coupling, CouplingFC, TransCoupling
 from .simple_vit import SimpleViT, posemb_sincos_2d
-from .context import (CatEmbeddings, ConditionalGaussianDistribution, ContextEncoder, EyeEncoder, EyeSampling,
-                      OneHotEncoder, UniformCatDequantization, VariationalCatDequantization)
+from .context import (ArgmaxCatDequantization, CatEmbeddings, ConditionalGaussianDistribution, ContextEncoder,
+                      EyeEncoder, EyeSampling, OneHotEncoder, ProbSampling, UniformCatDequantization,
+                      VariationalCatDequantization)
 from .unsupported import *  # noqa: F401,F403
 
 _ref = _os.environ.get("CONTEXTFLOW_REFERENCE_LAYERS")

@@ -4,6 +4,7 @@ This is the only place the product touches native code.  There is NO CPU fallbac
 library is missing, or a tensor is not on a ROCm device, the call raises.  (The CPU oracle lives in
 `oracle/` and is test infrastructure only.)
 """
+import collections
 import ctypes
 import os
 
@@ -149,5 +150,14 @@ def bview(t):
     return t, int(bs)
 
 
+_alive = collections.deque(maxlen=256)
+
+
 def p(t):
-    return _c_p(0) if t is None else _c_p(t.data_ptr())
+    """Device pointer of a tensor for the C ABI.  The tensor is also parked in a short ring buffer: a temporary built
+    inside an argument list (`p(x.contiguous())`) would otherwise be freed - and its block handed to the NEXT temporary
+    of the same argument list - before the launch that reads it is even enqueued."""
+    if t is None:
+        return _c_p(0)
+    _alive.append(t)
+    return _c_p(t.data_ptr())

@@ -2,9 +2,10 @@
 layers/rtdl/nn/_embeddings.py:76-285): a discrete context (B, n) of integer codes becomes the continuous vector c (B, C)
 that the CN nets of Conv1x1 / ActNorm / Coupling consume, plus a log-density term.
 
-Built: `enc_emb` eye | onehot with `enc_type` uniform (uniform dequantisation of the code) or vardeq (variational
-dequantisation: the noise comes from a small conditional flow over the context), and the `embed` + `eyesample` table
-lookup of the priors.  The argmax / probsample encoders raise NotImplementedError.
+Built: every combination `create_model` can produce (model.py:32-85) with an even code width: `enc_emb` eye | onehot
+with `enc_type` uniform (uniform dequantisation of the code) or vardeq (variational dequantisation: the noise comes
+from a small conditional flow over the context); eye + argmax (argmax surjection over binary codes); embed +
+eyesample (embedding rows, also the priors' lookup) and embed + probsample (sigmoid of a flow sample).
 
 Module and buffer names follow the reference so that checkpoints load: ContextEncoder = Sequential(emb, encoder);
 OneHotEncoder.cardinalities, UniformCatDequantization.{qbins, ldj_per_dim}, CatEmbeddings._embeddings.N.weight."""
@@ -141,6 +142,59 @@ class VariationalCatDequantization(nn.Module):
         return z, ldj + act_ldj - qu
 
 
+class ArgmaxCatDequantization(nn.Module):
+    """dequantize.py:170-270: z = sigmoid(u) * (2 bits(context) - 1) with u from the encoder flow; ldj = ldj_sigmoid - log q."""
+
+    def __init__(self, encoder, num_cats=(1,)):
+        super().__init__()
+        self.encoder = encoder
+        self.num_bits = self.cats2bits(list(num_cats))
+        self.sigmoid = _Sigmoid()
+
+    @staticmethod
+    def cats2bits(num_cats):
+        import math
+        if isinstance(num_cats, (list, tuple)):
+            return [int(math.ceil(math.log2(c))) for c in num_cats]
+        return int(math.ceil(math.log2(num_cats)))
+
+    def forward(self, input):
+        x, context = input
+        dev = self.sigmoid.temperature.device
+        ctx = context.to(device=dev, dtype=torch.int64).contiguous()
+        B = ctx.shape[0]
+        u, qu = self.encoder.sample(ctx, ctx)
+        width = u.shape[1]
+        su = torch.empty_like(u)
+        act_ldj = torch.empty(B, device=dev, dtype=torch.float32)
+        _hip.call("cf_sigmoid_ldj", _hip.p(u), _hip.p(su), _hip.p(act_ldj), B, width, _hip.stream())
+        bits = torch.tensor(self.num_bits, device=dev, dtype=torch.int64)
+        z = torch.empty(B, width, device=dev, dtype=torch.float32)
+        _hip.call("cf_ctx_encode", _hip.p(ctx), _hip.p(su), None, _hip.p(bits), _hip.p(z), B, ctx.shape[1], width, 2,
+                  _hip.stream())
+        return z, act_ldj - qu
+
+
+class ProbSampling(nn.Module):
+    """dequantize.py:145-167: the code is sigmoid(u), u from the encoder flow; ldj = ldj_sigmoid + log q (reference sign)."""
+
+    def __init__(self, encoder):
+        super().__init__()
+        self.encoder = encoder
+        self.sigmoid = _Sigmoid()
+
+    def forward(self, input):
+        x, context = input
+        dev = self.sigmoid.temperature.device
+        ctx = context.to(device=dev, dtype=torch.int64).contiguous()
+        B = ctx.shape[0]
+        u, qu = self.encoder.sample(ctx, ctx)
+        su = torch.empty_like(u)
+        act_ldj = torch.empty(B, device=dev, dtype=torch.float32)
+        _hip.call("cf_sigmoid_ldj", _hip.p(u), _hip.p(su), _hip.p(act_ldj), B, u.shape[1], _hip.stream())
+        return su, act_ldj + qu
+
+
 class _Sigmoid(nn.Module):
     """Parameter holder of activations.Sigmoid (buffer `temperature` = 1); the arithmetic is cf_sigmoid_ldj."""
 
@@ -167,33 +221,40 @@ class ContextEncoder(nn.Sequential):
         contexts = list(contexts)
         if enc_emb == "onehot":
             sz, emb, num_cats = sum(contexts), OneHotEncoder(contexts), sum(contexts) * [1]
-        elif enc_emb == "eye" and enc_type != "argmax":
+        elif enc_emb == "eye" and enc_type == "argmax":
+            sz = sum(ArgmaxCatDequantization.cats2bits(contexts))
+            sz, emb, num_cats = sz + sz % 2, EyeEncoder(), contexts
+        elif enc_emb == "eye":
             sz, emb, num_cats = len(contexts), EyeEncoder(), contexts
         elif enc_emb == "embed":
             sz, emb, num_cats = data_size[0] * len(contexts), CatEmbeddings(contexts, data_size[0], init=init), None
         else:
-            raise NotImplementedError("contextflow_amd ContextEncoder: enc-emb=%s with enc-type=%s" % (enc_emb, enc_type))
-        if enc_type == "uniform" and num_cats is not None:
-            encoder = UniformCatDequantization(num_cats=num_cats)
-        elif enc_type == "vardeq" and num_cats is not None:                   # model.py:52-79
+            raise NotImplementedError("contextflow_amd ContextEncoder: enc-emb=%s" % enc_emb)
+
+        def enc_flow():                                                       # model.py:52-66
             from .actnorm import ActNormFC
             from .conv1x1 import FC
             from .coupling import CouplingFC
             from .flowsequential import FlowInvSequential
             if sz % 2:
-                raise NotImplementedError("vardeq context encoder with an odd code width (the reference's Augment path)")
+                raise NotImplementedError("context encoder flow with an odd code width (the reference's Augment path)")
             layers = []
             for _ in range(2):
                 layers += [FC((sz,)), ActNormFC((sz,)), CouplingFC(sz)]
             cnet = CatEmbeddings(contexts, 2 * sz // len(contexts), init="zeros")
-            encoder = VariationalCatDequantization(
-                FlowInvSequential(ConditionalGaussianDistribution(size=(sz,), context_net=cnet), *layers), num_cats=num_cats)
-        elif enc_type == "eyesample":
+            return FlowInvSequential(ConditionalGaussianDistribution(size=(sz,), context_net=cnet), *layers)
+        if enc_type == "eyesample":
             encoder = EyeSampling()
+        elif enc_type == "probsample":
+            encoder = ProbSampling(enc_flow())
+        elif enc_type == "uniform" and num_cats is not None:
+            encoder = UniformCatDequantization(num_cats=num_cats)
+        elif enc_type == "vardeq" and num_cats is not None:
+            encoder = VariationalCatDequantization(enc_flow(), num_cats=num_cats)
+        elif enc_type == "argmax" and num_cats is not None:
+            encoder = ArgmaxCatDequantization(enc_flow(), num_cats=num_cats)
         else:
-            raise NotImplementedError(
-                "contextflow_amd ContextEncoder: enc-type=%s (the variational / argmax / probsample encoders are "
-                "conditional flows over the context; not built)" % enc_type)
+            raise NotImplementedError("contextflow_amd ContextEncoder: enc-emb=%s with enc-type=%s" % (enc_emb, enc_type))
         super().__init__(emb, encoder)
         self.C = sz
         self.contexts = contexts

@@ -15,7 +15,5 @@ PermuteAxes = _stub("PermuteAxes", "ATM topology only")
 StudentMixtureDistribution = _stub("StudentMixtureDistribution", "--dist tdist; non-default prior")
 GaussianDistribution = _stub("GaussianDistribution", "unused by create_model")
 MultivariateGaussianMixtureDistribution = _stub("MultivariateGaussianMixtureDistribution", "unused by create_model")
-ArgmaxCatDequantization = _stub("ArgmaxCatDequantization", "specialist context encoders")
-ProbSampling = _stub("ProbSampling", "specialist context encoders")
 SmoothLeakyRelu = _stub("SmoothLeakyRelu", "activation layers are disabled in every config")
 LearnableLeakyRelu = _stub("LearnableLeakyRelu", "activation layers are disabled in every config")

@@ -232,7 +232,8 @@ int cf_channel_sums(const float* a, const float* b2, float* out, int B, int C, i
 /* ---- specialist (context-conditioned) branches: SURVEY 8(f) rank 2 ------------------------------------------
  * ContextEncoder (model.py:30-90) = OneHotEncoder | EyeEncoder (rtdl/nn/_embeddings.py:76-150) followed by
  * UniformCatDequantization (dequantize.py:55-64): out (B,width) = (code(ctx) + u) / qbins.  ctx (B,nctx) int64,
- * card (nctx) int64 cardinalities (one-hot only).                                                             */
+ * card (nctx) int64 cardinalities (one-hot only).  onehot = 2: ArgmaxCatDequantization (dequantize.py:236-262):
+ * card = bits per variable, out = u * (2 bit - 1) over the big-endian binary codes (zero pad column if odd).  */
 int cf_ctx_encode(const int64_t* ctx, const float* u, const float* qbins, const int64_t* card, float* out, int B, int nctx,
                   int width, int onehot, cf_stream_t stream);
 /* Conv1x1 with a context net (conv1x1.py:34-50): m (B, C*C) = CN(c); W_b = tril(m,-1) + diag(exp(diag m))

@@ -331,9 +331,17 @@ def spline_activation_inv(y, uw, uh, ud, tail_bound=10.0):
 # `ctx` = dict(contexts=[K_0, K_1, ...], enc_emb='eye'|'onehot', contextflow=bool) describes the reference's
 # `ContextEncoder(contexts, enc_emb, 'uniform', ...)` (model.py:30-90) that every Conv1x1 / ActNorm / Coupling owns in
 # the specialist mode (model.py:117,130-143), and the 'embed' + 'eyesample' lookup of the priors (model.py:157,162).
-def ctx_width(ctx):
-    """ContextEncoder.C (model.py:33,42,87): one-hot width or number of context variables."""
-    return sum(ctx["contexts"]) if ctx["enc_emb"] == "onehot" else len(ctx["contexts"])
+def ctx_width(ctx, data_dim=None):
+    """ContextEncoder.C (model.py:33-47,87): one-hot width, number of context variables, (even) number of code bits
+    for argmax, or data_dim * number of variables for the embedding encoders."""
+    if ctx["enc_emb"] == "onehot":
+        return sum(ctx["contexts"])
+    if ctx["enc_emb"] == "embed":
+        return data_dim * len(ctx["contexts"])
+    if ctx.get("enc_type") == "argmax":
+        n = sum(argmax_bits(ctx["contexts"]))
+        return n + n % 2
+    return len(ctx["contexts"])
 
 
 def ctx_encode(context, ctx, u):
@@ -359,15 +367,9 @@ def _ctx_code(context, ctx, dtype):
     return context.to(dtype), torch.tensor(K, dtype=torch.float32)
 
 
-def ctx_encode_vardeq(context, ctx, params, prefix, eps):
-    """VariationalCatDequantization (dequantize.py:104-118) over the reference's encoder flow (model.py:52-79):
-    u ~ FlowInvSequential(ConditionalGaussianDistribution(embedding lookup), 2 x [FC, ActNormFC, CouplingFC])
-    (flowsequential.py:58-68, gaussian.py:263-270), then Sigmoid (activations.py:234-238):
-    z = (x + sigmoid(u)) / qbins, ldj = sum_d(-log qbins_d * n_dims) + ldj_sigmoid - log q(u).
-    `prefix` = '<layer>.context_net.1.'; ActNormFC parameters must be initialised (post first call)."""
-    x, qbins = _ctx_code(context, ctx, eps.dtype)
-    n = x.shape[1]
-    e = prefix + "encoder."
+def _enc_flow_sample(context, ctx, params, e, n, eps):
+    """FlowInvSequential(ConditionalGaussianDistribution, 2 x [FC, ActNormFC, CouplingFC]).sample
+    (flowsequential.py:58-68, gaussian.py:263-270, model.py:52-66): returns (u, log q(u))."""
     c = torch.cat([params[e + "dist.context_net._embeddings.%d.weight" % i][context[:, i]] for i in range(len(ctx["contexts"]))], 1)
     mean, ls = c[:, :n], c[:, n:]
     u = mean + ls.exp() * eps
@@ -386,6 +388,46 @@ def ctx_encode_vardeq(context, ctx, params, prefix, eps):
         tt, lsc = h[:, : n // 2], 2.0 * torch.tanh(h[:, n // 2:] / 2.0)
         u = torch.cat([u[:, : n // 2], u[:, n // 2:] * torch.exp(lsc) + tt], 1)
         logq = logq - lsc.sum(-1)
+    return u, logq
+
+
+def argmax_bits(contexts):
+    """ArgmaxCatDequantization.cats2bits (dequantize.py:189-194)."""
+    return [int(math.ceil(math.log2(k))) for k in contexts]
+
+
+def ctx_encode_argmax(context, ctx, params, prefix, eps):
+    """ArgmaxCatDequantization.forward (dequantize.py:236-262): z = sigmoid(u) * (2 bits - 1), ldj = ldj_sigmoid - log q."""
+    bits = argmax_bits(ctx["contexts"])
+    cols = []
+    for i, nb in enumerate(bits):
+        powers = 2 ** torch.arange(nb - 1, -1, -1)
+        cols.append((context[:, i, None] // powers) % 2)
+    code = torch.cat(cols, -1).to(eps.dtype)
+    if code.shape[1] % 2:
+        code = torch.cat([code, torch.zeros(code.shape[0], 1, dtype=eps.dtype)], -1)
+    u, logq = _enc_flow_sample(context, ctx, params, prefix + "encoder.", code.shape[1], eps)
+    act_ldj = (-F.softplus(-u) - F.softplus(u)).sum(-1)
+    return torch.sigmoid(u) * (code * 2 - 1), act_ldj - logq
+
+
+def ctx_encode_probsample(context, ctx, params, prefix, eps):
+    """ProbSampling.forward (dequantize.py:152-161): the code IS the sigmoid of the flow sample; ldj = ldj_sigmoid + log q
+    (the reference's sign)."""
+    u, logq = _enc_flow_sample(context, ctx, params, prefix + "encoder.", eps.shape[1], eps)
+    act_ldj = (-F.softplus(-u) - F.softplus(u)).sum(-1)
+    return torch.sigmoid(u), act_ldj + logq
+
+
+def ctx_encode_vardeq(context, ctx, params, prefix, eps):
+    """VariationalCatDequantization (dequantize.py:104-118) over the reference's encoder flow (model.py:52-79):
+    u ~ FlowInvSequential(ConditionalGaussianDistribution(embedding lookup), 2 x [FC, ActNormFC, CouplingFC])
+    (flowsequential.py:58-68, gaussian.py:263-270), then Sigmoid (activations.py:234-238):
+    z = (x + sigmoid(u)) / qbins, ldj = sum_d(-log qbins_d * n_dims) + ldj_sigmoid - log q(u).
+    `prefix` = '<layer>.context_net.1.'; ActNormFC parameters must be initialised (post first call)."""
+    x, qbins = _ctx_code(context, ctx, eps.dtype)
+    n = x.shape[1]
+    u, logq = _enc_flow_sample(context, ctx, params, prefix + "encoder.", n, eps)
     act_ldj = (-F.softplus(-u) - F.softplus(u)).sum(-1)                          # temperature 1
     z = (x + torch.sigmoid(u)) / qbins.to(eps.dtype)
     ldj = ((-torch.log(qbins)) * n).sum(-1).to(eps.dtype)
@@ -507,8 +549,16 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None,
     cnoise = list(cnoise)          # specialist mode: one uniform noise tensor per context encoder, in layer order
 
     def enc(prefix=None):
-        if ctx.get("enc_type", "uniform") == "vardeq":
+        et = ctx.get("enc_type", "uniform")
+        if et == "vardeq":
             return ctx_encode_vardeq(context, ctx, params, prefix + "context_net.1.", cnoise.pop(0))
+        if et == "argmax":
+            return ctx_encode_argmax(context, ctx, params, prefix + "context_net.1.", cnoise.pop(0))
+        if et == "probsample":
+            return ctx_encode_probsample(context, ctx, params, prefix + "context_net.1.", cnoise.pop(0))
+        if et == "eyesample":               # 'embed' + EyeSampling: the embedding rows themselves, no noise, no density
+            w = [params[prefix + "context_net.0._embeddings.%d.weight" % i] for i in range(len(ctx["contexts"]))]
+            return torch.cat([w[i][context[:, i]] for i in range(len(w))], 1), torch.zeros(context.shape[0], dtype=x.dtype)
         return ctx_encode(context, ctx, cnoise.pop(0))
 
     def emb(prefix):

@@ -28,32 +28,44 @@ def _gmm(prefix, size, M, spec, ctx=None):
             spec[prefix + "context_net.0._embeddings.%d.weight" % i] = ((k, d), "small")
 
 
-def _encoder(prefix, ctx, spec):
-    """Buffers of ContextEncoder(contexts, enc_emb, 'uniform') = Sequential(OneHotEncoder | EyeEncoder,
-    UniformCatDequantization) (model.py:30-90; rtdl/nn/_embeddings.py:131; dequantize.py:50-52)."""
+def _enc_flow(e, K, n, spec):
+    """FlowInvSequential(ConditionalGaussianDistribution(CatEmbeddings), 2 x [FC, ActNormFC, CouplingFC]) (model.py:52-79)."""
+    for i, k in enumerate(K):
+        spec[e + "dist.context_net._embeddings.%d.weight" % i] = ((k, 2 * n // len(K)), "small")
+    for l in range(2):
+        spec[e + "%d.NN" % (3 * l)] = ((n, n), "orthogonal")
+        spec[e + "%d.NN_t" % (3 * l + 1)] = ((n,), "zeros")
+        spec[e + "%d.NN_logs" % (3 * l + 1)] = ((n,), "zeros")
+        spec[e + "%d.initialized" % (3 * l + 1)] = ((), "flag")
+        q = e + "%d." % (3 * l + 2)
+        for name, shp in (("NN.0", (2 * n, n // 2, 1, 1)), ("NN.2", (2 * n, 2 * n, 1, 1)), ("NN.4", (n, 2 * n, 1, 1))):
+            spec[q + name + ".weight"] = (shp, ("uniform", shp[1]))
+            spec[q + name + ".bias"] = ((shp[0],), ("uniform", shp[1]))
+
+
+def _encoder(prefix, ctx, spec, data_dim):
+    """Entries of ContextEncoder(contexts, enc_emb, enc_type, (data_dim,)) = Sequential(embedding, encoder)
+    (model.py:30-90; rtdl/nn/_embeddings.py:76-285; dequantize.py:26-262).  Returns the encoder's output width C."""
     K = ctx["contexts"]
+    et = ctx.get("enc_type", "uniform")
+    C = ctx_width(ctx, data_dim)
+    p0, p1 = prefix + "context_net.0.", prefix + "context_net.1."
     if ctx["enc_emb"] == "onehot":
-        spec[prefix + "context_net.0.cardinalities"] = ((len(K),), ("ints", tuple(K)))
+        spec[p0 + "cardinalities"] = ((len(K),), ("ints", tuple(K)))
         cats = [1] * sum(K)
+    elif ctx["enc_emb"] == "embed":
+        for i, k in enumerate(K):
+            spec[p0 + "_embeddings.%d.weight" % i] = ((k, data_dim), "small")
+        cats = None
     else:
         cats = list(K)
-    spec[prefix + "context_net.1.qbins"] = ((len(cats),), ("floats", tuple(float(v) for v in cats)))
-    spec[prefix + "context_net.1.ldj_per_dim"] = ((len(cats),), ("floats", tuple(-float(np.log(np.float32(v))) for v in cats)))
-    if ctx.get("enc_type", "uniform") == "vardeq":     # model.py:52-79: the encoder flow of VariationalCatDequantization
-        n = len(cats)
-        e = prefix + "context_net.1.encoder."
-        for i, k in enumerate(K):
-            spec[e + "dist.context_net._embeddings.%d.weight" % i] = ((k, 2 * n // len(K)), "small")
-        for l in range(2):
-            spec[e + "%d.NN" % (3 * l)] = ((n, n), "orthogonal")
-            spec[e + "%d.NN_t" % (3 * l + 1)] = ((n,), "zeros")
-            spec[e + "%d.NN_logs" % (3 * l + 1)] = ((n,), "zeros")
-            spec[e + "%d.initialized" % (3 * l + 1)] = ((), "flag")
-            q = e + "%d." % (3 * l + 2)
-            for name, shp in (("NN.0", (2 * n, n // 2, 1, 1)), ("NN.2", (2 * n, 2 * n, 1, 1)), ("NN.4", (n, 2 * n, 1, 1))):
-                spec[q + name + ".weight"] = (shp, ("uniform", shp[1]))
-                spec[q + name + ".bias"] = ((shp[0],), ("uniform", shp[1]))
-        spec[prefix + "context_net.1.sigmoid.temperature"] = ((1,), ("floats", (1.0,)))
+    if et in ("uniform", "vardeq"):
+        spec[p1 + "qbins"] = ((len(cats),), ("floats", tuple(float(v) for v in cats)))
+        spec[p1 + "ldj_per_dim"] = ((len(cats),), ("floats", tuple(-float(np.log(np.float32(v))) for v in cats)))
+    if et in ("vardeq", "argmax", "probsample"):
+        _enc_flow(p1 + "encoder.", K, C, spec)
+        spec[p1 + "sigmoid.temperature"] = ((1,), ("floats", (1.0,)))
+    return C
 
 
 def param_spec(ops, prior_size, mixtures, ctx=None):
@@ -62,7 +74,6 @@ def param_spec(ops, prior_size, mixtures, ctx=None):
     (flow_oracle.ctx_width)."""
     spec = OrderedDict()
     _gmm("dist.", prior_size, mixtures, spec, ctx)
-    Cc = ctx_width(ctx) if ctx is not None else 0
     for op in ops:
         kind, idx = op[0], op[1]
         pre = "%d." % idx
@@ -77,7 +88,7 @@ def param_spec(ops, prior_size, mixtures, ctx=None):
             C = op[2][0]
             spec[pre + "NN"] = ((C, C), "orthogonal")                         # conv1x1.py:16-17
             if ctx is not None:                                               # conv1x1.py:20-26 (zero init there)
-                _encoder(pre, ctx, spec)
+                Cc = _encoder(pre, ctx, spec, C)
                 spec[pre + "CN.weight"] = ((C * C, Cc), "small")
                 spec[pre + "CN.bias"] = ((C * C,), "small")
         elif kind == "actnorm":
@@ -86,7 +97,7 @@ def param_spec(ops, prior_size, mixtures, ctx=None):
             spec[pre + "NN_logs"] = ((C,), "zeros")
             spec[pre + "initialized"] = ((), "flag")
             if ctx is not None:                                               # actnorm.py:19-26
-                _encoder(pre, ctx, spec)
+                Cc = _encoder(pre, ctx, spec, 2 * C)
                 spec[pre + "CN.weight"] = ((2 * C, Cc), "small")
                 spec[pre + "CN.bias"] = ((2 * C,), "small")
         elif kind == "coupling":
@@ -94,7 +105,7 @@ def param_spec(ops, prior_size, mixtures, ctx=None):
             kh, kw = op[3]
             D, Hd, O = C // 2, C * 2, C                                        # coupling.py:17-19
             if ctx is not None:                                               # coupling.py:23: registered before NN
-                _encoder(pre, ctx, spec)
+                Cc = _encoder(pre, ctx, spec, C)
             Din = D + O if (ctx is not None and not ctx["contextflow"]) else D   # coupling.py:33-34 (concat)
             for name, shp in (("NN.0", (Hd, Din, 1, 1)), ("NN.2", (Hd, Hd, kh, kw)), ("NN.4", (O, Hd, 1, 1))):
                 fan_in = shp[1] * shp[2] * shp[3]
@@ -109,7 +120,7 @@ def param_spec(ops, prior_size, mixtures, ctx=None):
             dim, pd, inner = d["dim"], d["patch_dim"], d["dim_head"]
             q = pre + "NN.0."
             if ctx is not None:                                               # coupling.py:107,113-119
-                _encoder(pre, ctx, spec)
+                Cc = _encoder(pre, ctx, spec, op[2][0])
                 if not ctx["contextflow"]:                                    # ViT over [x0 ; CN(c)], direct child
                     C = op[2][0]
                     pd, q = (C // 2 + C) * op[3][0] * op[3][1], pre + "NN."

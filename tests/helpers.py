@@ -69,6 +69,9 @@ SPECIALIST = {
     "cifar10_eye_vardeq_cf": ("cifar10", dict(contexts=[15, 5], enc_emb="eye", contextflow=True, enc_type="vardeq")),
     "smap_onehot_cf": ("smap", dict(contexts=[55], enc_emb="onehot", contextflow=True)),
     "smap_eye": ("smap", dict(contexts=[55], enc_emb="eye", contextflow=False)),
+    "cifar10_eye_argmax_cf": ("cifar10", dict(contexts=[15, 5], enc_emb="eye", contextflow=True, enc_type="argmax")),
+    "cifar10_embed_eyesample": ("cifar10", dict(contexts=[15, 5], enc_emb="embed", contextflow=False, enc_type="eyesample")),
+    "mnist_embed_probsample_cf": ("mnist", dict(contexts=[64], enc_emb="embed", contextflow=True, enc_type="probsample")),
 }
 
 
@@ -84,6 +87,7 @@ def load_specialist(fxname):
             params[k[6:]] = torch.from_numpy(v)
     inp = dict(x=torch.from_numpy(fx["x"].astype(np.float32)), u=torch.from_numpy(fx["u"]),
                eps=[torch.from_numpy(fx["eps%d" % j]) for j in range(8) if "eps%d" % j in fx],
-               context=torch.from_numpy(fx["context"]), cnoise=[torch.from_numpy(c) for c in fx["cnoise"]],
+               context=torch.from_numpy(fx["context"]),
+               cnoise=[torch.from_numpy(fx["cnoise%d" % j]) for j in range(200) if "cnoise%d" % j in fx],
                logp=torch.from_numpy(fx["logp"]), z=torch.from_numpy(fx["z"]))
     return name, ctx, ops, M, params, inp

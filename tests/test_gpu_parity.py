@@ -628,7 +628,8 @@ def test_training_steps_reduce_the_loss_smap(L):
 
 # ------------------------------------------------------------------------------------------ specialist (context) mode
 @pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye",
-                                    "cifar10_onehot_vardeq", "cifar10_eye_vardeq_cf", "smap_onehot_cf", "smap_eye"])
+                                    "cifar10_onehot_vardeq", "cifar10_eye_vardeq_cf", "smap_onehot_cf", "smap_eye",
+                                    "cifar10_eye_argmax_cf", "cifar10_embed_eyesample", "mnist_embed_probsample_cf"])
 def test_specialist_forward_matches_reference(L, fxname):
     """Context-conditioned models (create_model(generalist=False), model.py:117-162): per-sample Conv1x1 / ActNorm /
     Coupling parameters from the context encoders + CN nets, context-shifted GMM priors — logp against the reference's
@@ -644,7 +645,7 @@ def test_specialist_forward_matches_reference(L, fxname):
     model = model.to(DEV).eval()
     from tests.gpu_util import set_noise
     set_noise(model, inp["u"], inp["eps"])
-    noisy = cfa.layers.ConditionalGaussianDistribution if enc_type == "vardeq" else cfa.layers.UniformCatDequantization
+    noisy = cfa.layers.UniformCatDequantization if enc_type == "uniform" else cfa.layers.ConditionalGaussianDistribution
     encs = [m for m in model.modules() if isinstance(m, noisy)]
     assert len(encs) == len(inp["cnoise"])
     for e, c in zip(encs, inp["cnoise"]):

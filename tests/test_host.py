@@ -107,7 +107,7 @@ def test_unbuilt_names_raise_and_specialist_layout():
     with pytest.raises(NotImplementedError):
         L.MaskedCoupling(4)
     with pytest.raises(NotImplementedError):
-        L.ContextEncoder([15, 5], "onehot", "argmax", (16,))
+        L.ContextEncoder([64], "eye", "vardeq", (16,))          # odd code width: the reference's Augment path
     assert set(L.SplineActivation((2, 2, 2), individual_weights=True).state_dict()) == {
         "unnormalized_widths", "unnormalized_heights", "unnormalized_derivatives"}
     for fxname, (name, ctx) in SPECIALIST.items():
