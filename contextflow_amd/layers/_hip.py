@@ -4,7 +4,6 @@ This is the only place the product touches native code.  There is NO CPU fallbac
 library is missing, or a tensor is not on a ROCm device, the call raises.  (The CPU oracle lives in
 `oracle/` and is test infrastructure only.)
 """
-import collections
 import ctypes
 import os
 
@@ -150,14 +149,16 @@ def bview(t):
     return t, int(bs)
 
 
-_alive = collections.deque(maxlen=256)
+class _Ptr(ctypes.c_void_p):
+    """void* that keeps its tensor alive: a temporary built inside an argument list (`p(x.contiguous())`) would
+    otherwise be freed - and its block handed to the NEXT temporary of the same argument list - before the launch that
+    reads it is even enqueued.  The pointer object lives exactly until the C call has returned."""
+    _keep = None
 
 
 def p(t):
-    """Device pointer of a tensor for the C ABI.  The tensor is also parked in a short ring buffer: a temporary built
-    inside an argument list (`p(x.contiguous())`) would otherwise be freed - and its block handed to the NEXT temporary
-    of the same argument list - before the launch that reads it is even enqueued."""
     if t is None:
         return _c_p(0)
-    _alive.append(t)
-    return _c_p(t.data_ptr())
+    ptr = _Ptr(t.data_ptr())
+    ptr._keep = t
+    return ptr
