@@ -194,6 +194,172 @@ __global__ __launch_bounds__(64) void k_sigmoid_ldj(const float* __restrict__ x,
     if (threadIdx.x == 0) ldj[b] = acc;
 }
 
+// ---- backward of the context branches (specialist training under contextflow: the CN nets and the priors' embedding
+// tables are the trainable parameters; the generalist's own parameters are frozen, model.py / coupling.py:36) ------
+
+// Conv1x1 with a context net, backward: gx[b] = W_b^T gz[b];  G = sum_p gz[b][:,p] x[b][:,p]^T;
+// gm[b][o][i] = G[o][i] (o > i) | G[i][i] exp(m_ii) + H W gld[b] (o == i) | 0 (o < i)      (d/d CN(c) output)
+__global__ __launch_bounds__(256) void k_conv1x1_ctx_bwd(const float* __restrict__ x, const float* __restrict__ m,
+                                                         const float* __restrict__ Wm, const float* __restrict__ gz,
+                                                         const float* __restrict__ gld, float* __restrict__ gx,
+                                                         float* __restrict__ gm, int C, int HW, int64_t xbs, int64_t gzbs) {
+    __shared__ float Wb[kMaxC * (kMaxC + 1)];         // Wb[o][i], row stride C + 1
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* mb = m + (int64_t)b * C * C;
+    for (int e = tid; e < C * C; e += 256) {
+        const int o = e / C, i = e - o * C;
+        const float v = mb[e];
+        float w = o > i ? v : (o == i ? expf(v) : 0.f);
+        if (Wm != nullptr) w += Wm[e] - (o == i ? 1.f : 0.f);
+        Wb[o * (C + 1) + i] = w;
+    }
+    __syncthreads();
+    const float* xb = x + (int64_t)b * xbs;
+    const float* gb = gz + (int64_t)b * gzbs;
+    float* gxb = gx + (int64_t)b * C * HW;
+    for (int e = tid; e < C * HW; e += 256) {
+        const int i = e / HW, p = e - i * HW;
+        float acc = 0.f;
+        for (int o = 0; o < C; ++o) acc = fmaf(Wb[o * (C + 1) + i], gb[(int64_t)o * HW + p], acc);
+        gxb[e] = acc;
+    }
+    float* gmb = gm + (int64_t)b * C * C;
+    const float gl = gld[b] * (float)HW;
+    for (int e = tid; e < C * C; e += 256) {
+        const int o = e / C, i = e - o * C;
+        float g = 0.f;
+        if (o >= i) {
+            for (int p = 0; p < HW; ++p) g = fmaf(gb[(int64_t)o * HW + p], xb[(int64_t)i * HW + p], g);
+            if (o == i) g = g * expf(mb[e]) + gl;
+        }
+        gmb[e] = g;
+    }
+}
+
+// ActNorm with a context net, backward: gx = gz exp(-l_b); gm[b] = [ -exp(-l_b) sum_p gz | -sum_p gz z + gld[b] ]
+__global__ __launch_bounds__(256) void k_actnorm_ctx_bwd(const float* __restrict__ x, const float* __restrict__ m,
+                                                         const float* __restrict__ t, const float* __restrict__ logs,
+                                                         const float* __restrict__ gz, const float* __restrict__ gld,
+                                                         float* __restrict__ gx, float* __restrict__ gm, int C, int HW,
+                                                         int64_t xbs, int64_t gzbs) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xb = x + (int64_t)b * xbs;
+    const float* gb = gz + (int64_t)b * gzbs;
+    float* gxb = gx + (int64_t)b * C * HW;
+    for (int c = wave; c < C; c += 4) {               // a wave owns a channel at a time
+        float tv = m[(int64_t)b * 2 * C + c], lv = m[(int64_t)b * 2 * C + C + c];
+        if (t != nullptr) { tv += t[c]; lv += logs[c]; }
+        const float s = expf(-lv);
+        float s0 = 0.f, s1 = 0.f;
+        for (int p = lane; p < HW; p += 64) {
+            const float g = gb[(int64_t)c * HW + p], z = (xb[(int64_t)c * HW + p] - tv) * s;
+            gxb[(int64_t)c * HW + p] = g * s;
+            s0 += g; s1 = fmaf(g, z, s1);
+        }
+        s0 = cf_wave_sum(s0); s1 = cf_wave_sum(s1);
+        if (lane == 0) {
+            gm[(int64_t)b * 2 * C + c] = -s * s0;
+            gm[(int64_t)b * 2 * C + C + c] = gld[b] - s1;
+        }
+    }
+}
+
+// out[b, c] = sum_p a[b, c, p]      (d/d of a per-sample bias: row sums of a gradient plane)
+__global__ __launch_bounds__(256) void k_sample_channel_sums(const float* __restrict__ a, float* __restrict__ out, int HW,
+                                                             int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int p = lane; p < HW; p += 64) s += a[row * HW + p];
+    s = cf_wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+// y = gy * (x > 0)   (ReLU backward of the CN nets)
+__global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ x, const float* __restrict__ gy,
+                                                  float* __restrict__ out, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+        out[e] = x[e] > 0.f ? gy[e] : 0.f;
+}
+
+// GMM with a context net, backward w.r.t. x and the per-sample shifts (gaussian.py:142-158; parameters frozen):
+// r[mk] = g[b,m] softmax_k(lp)[mk];  with d = x - mu - cm, sig = softplus(s), s = sG + cs:
+//   gx[e]      = sum_mk r * (-d / sig^2)
+//   gc[0][mk][dch] = sum_hw r * d / sig^2
+//   gc[1][mk][dch] = sum_hw r * (d^2 / sig^3 - 1 / sig) * sigmoid(s)
+// One workgroup per sample; a wave owns (m,k) pairs; gx partials of the 4 waves are combined through LDS.
+__global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x, const float* __restrict__ mG,
+                                                     const float* __restrict__ sG, const float* __restrict__ logw,
+                                                     const float* __restrict__ c, const float* __restrict__ g,
+                                                     float* __restrict__ gx, float* __restrict__ gc, int M, int K, int D,
+                                                     int HW, int64_t xbs) {
+    extern __shared__ __align__(16) float lds[];
+    float* xs = lds;                       // [N]
+    float* lp = xs + D * HW;               // [MK] log-joint, then responsibilities
+    float* gxs = lp + M * K;               // [4][N] per-wave partial gx
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = D * HW, MK = M * K;
+    for (int e = tid; e < N; e += 256) xs[e] = x[(int64_t)b * xbs + e];
+    for (int e = tid; e < 4 * N; e += 256) gxs[e] = 0.f;
+    __syncthreads();
+    const float* cb = c + (int64_t)b * 2 * MK * D;
+    for (int mk = wave; mk < MK; mk += 4) {
+        const float* mu = mG + (int64_t)mk * N;
+        const float* sg = sG + (int64_t)mk * N;
+        const float* cm = cb + (int64_t)mk * D;
+        const float* cs = cb + (int64_t)(MK + mk) * D;
+        float acc = 0.f;
+        for (int e = lane; e < N; e += 64) {
+            const int d = e / HW;
+            const float sv = sg[e] + cs[d];
+            const float sig = sv > 20.f ? sv : __logf(1.0f + __expf(sv));
+            const float r = (xs[e] - mu[e] - cm[d]) * __frcp_rn(sig);
+            acc += -0.5f * r * r - __logf(sig) - 0.91893853320467274178f;
+        }
+        acc = cf_wave_sum(acc);
+        if (lane == 0) lp[mk] = acc + logw[mk];
+    }
+    __syncthreads();
+    if (tid < M) {                          // responsibilities times the upstream gradient
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[tid * K + k]);
+        float z = 0.f;
+        for (int k = 0; k < K; ++k) z += expf(lp[tid * K + k] - mx);
+        const float gm = g[(int64_t)b * M + tid] / z;
+        for (int k = 0; k < K; ++k) lp[tid * K + k] = expf(lp[tid * K + k] - mx) * gm;
+    }
+    __syncthreads();
+    float* gcb = gc + (int64_t)b * 2 * MK * D;
+    float* mine = gxs + wave * N;
+    for (int mk = wave; mk < MK; mk += 4) {
+        const float* mu = mG + (int64_t)mk * N;
+        const float* sg = sG + (int64_t)mk * N;
+        const float* cm = cb + (int64_t)mk * D;
+        const float* cs = cb + (int64_t)(MK + mk) * D;
+        const float r = lp[mk];
+        for (int d = 0; d < D; ++d) {       // channel by channel: the (mk, d) sums are wave reductions over h*w
+            float a0 = 0.f, a1 = 0.f;
+            const float cmd = cm[d], csd = cs[d];
+            for (int p = lane; p < HW; p += 64) {
+                const int e = d * HW + p;
+                const float sv = sg[e] + csd;
+                const float sig = sv > 20.f ? sv : __logf(1.0f + __expf(sv));
+                const float inv = __frcp_rn(sig), dd = xs[e] - mu[e] - cmd;
+                const float q = dd * inv * inv;                       // d / sig^2
+                const float dsig = sv > 20.f ? 1.f : __frcp_rn(1.0f + __expf(-sv));   // softplus'
+                mine[e] -= r * q;
+                a0 += q;
+                a1 += (dd * q * inv - inv) * dsig;
+            }
+            a0 = cf_wave_sum(a0); a1 = cf_wave_sum(a1);
+            if (lane == 0) { gcb[(int64_t)mk * D + d] = r * a0; gcb[(int64_t)(MK + mk) * D + d] = r * a1; }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < N; e += 256) gx[(int64_t)b * N + e] = (gxs[e] + gxs[N + e]) + (gxs[2 * N + e] + gxs[3 * N + e]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -263,6 +429,63 @@ int cf_sigmoid_ldj(const float* x, float* y, float* ldj, int B, int D, cf_stream
     if (B == 0) return 0;
     CF_REQUIRE(x && y && ldj && B >= 0 && D > 0);
     k_sigmoid_ldj<<<dim3(B), dim3(64), 0, cf_s(stream)>>>(x, y, ldj, D);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_conv1x1_ctx_bwd(const float* x, const float* m, const float* Wm, const float* gz, const float* gld, float* gx,
+                       float* gm, int B, int C, int HW, int64_t x_bstride, int64_t gz_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && m && gz && gld && gx && gm && B >= 0 && C > 0 && HW > 0);
+    if (C > kMaxC) { cf_set_error("cf_conv1x1_ctx_bwd: C=%d > %d unsupported", C, kMaxC); return CF_ERR_UNSUPPORTED; }
+    k_conv1x1_ctx_bwd<<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, m, Wm, gz, gld, gx, gm, C, HW, x_bstride, gz_bstride);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_actnorm_ctx_bwd(const float* x, const float* m, const float* t, const float* logs, const float* gz, const float* gld,
+                       float* gx, float* gm, int B, int C, int HW, int64_t x_bstride, int64_t gz_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && m && gz && gld && gx && gm && B >= 0 && C > 0 && HW > 0 && ((t == nullptr) == (logs == nullptr)));
+    k_actnorm_ctx_bwd<<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, m, t, logs, gz, gld, gx, gm, C, HW, x_bstride, gz_bstride);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_sample_channel_sums(const float* a, float* out, int B, int C, int HW, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(a && out && B >= 0 && C > 0 && HW > 0);
+    const int64_t rows = (int64_t)B * C;
+    k_sample_channel_sums<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, cf_s(stream)>>>(a, out, HW, rows);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_relu_bwd(const float* x, const float* gy, float* out, int64_t n, cf_stream_t stream) {
+    if (n == 0) return 0;
+    CF_REQUIRE(x && gy && out && n >= 0);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    k_relu_bwd<<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(x, gy, out, n);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float* logw, const float* c, const float* g,
+                   float* gx, float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && mG && sG && logw && c && g && gx && gc && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0 && M <= 256);
+    const size_t lds = (size_t)(5 * D * HW + M * K) * sizeof(float);
+    if (lds > 160 * 1024) { cf_set_error("cf_gmm_ctx_bwd: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("cf_gmm_ctx_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
+    k_gmm_ctx_bwd<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, gx, gc, M, K, D, HW, x_bstride);
     CF_LAUNCH_CHECK();
     return 0;
 }

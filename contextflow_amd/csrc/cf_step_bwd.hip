@@ -155,12 +155,16 @@ __device__ __forceinline__ void adj_axis(int c, int d, int N, int (&src)[2], boo
     src[1] = ok[1] ? e : 0;
 }
 
-template <class G, bool SQ>
+// CTX = 1: specialist coupling under contextflow (coupling.py:44): the conditioner output carries a per-sample bias
+// sb (B, C) = CN(c); only its log-scale half matters for the recompute (t does not enter any gradient); d/d sb is the
+// per-sample row sum of the s_gh plane, taken by the caller.
+template <class G, bool SQ, int CTX = 0>
 __global__ __launch_bounds__(256) void k_flow_step_bwd(
     const float* __restrict__ x, const float* __restrict__ gz, const float* __restrict__ gld,
     const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ gx,
     float* __restrict__ s_y0, float* __restrict__ s_h1, float* __restrict__ s_h2, float* __restrict__ s_gh,
-    float* __restrict__ s_gh2, float* __restrict__ s_gh1, float* __restrict__ s_gy, int B, int64_t xbs) {
+    float* __restrict__ s_gh2, float* __restrict__ s_gh1, float* __restrict__ s_gy, int B, int64_t xbs,
+    const float* __restrict__ sb) {
     using Bw = GeoBwd<G>;
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1, NR = (HALF <= 16 ? 8 : 16);
@@ -294,7 +298,11 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
         for (int q = 0; q < PTW; ++q)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
+                float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
+                if constexpr (CTX == 1) {
+                    const int idx = tile_row(r, lk);
+                    if (idx < HALF) raw += sb[(int64_t)min(b0 + pix[q] / HW, B - 1) * C + HALF + idx];
+                }
                 ls[q][r] = 2.0f - __fdividef(4.0f, __expf(raw) + 1.0f);
             }
     }
@@ -468,21 +476,21 @@ int launch_prepare_bwd(const float* Wm, const float* logs, const float* w1, cons
     return 0;
 }
 
-template <class G, bool SQ>
+template <class G, bool SQ, int CTX = 0>
 int launch_step_bwd(const float* x, const float* gz, const float* gld, const float* ws, const float* wsb, float* gx,
                     float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy, int B,
-                    int64_t xbs, hipStream_t s) {
+                    int64_t xbs, hipStream_t s, const float* sb = nullptr) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step_bwd<G, SQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step_bwd<G, SQ, CTX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { cf_set_error("cf_flow_step_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
             raised = true;
         }
     }
-    k_flow_step_bwd<G, SQ><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(
-        x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs);
+    k_flow_step_bwd<G, SQ, CTX><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(
+        x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs, sb);
     return 0;
 }
 
@@ -541,6 +549,32 @@ int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const vo
         default: cf_set_error("cf_flow_step_bwd: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_BWD
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of the specialist coupling under contextflow (cf_flow_step_fwd_ctx, mode 1): same kernel, the recompute
+// adds the per-sample bias sbias (B, C) to the conditioner output.  d/d sbias[b, c] = sum_p s_gh[b, c, p].
+int cf_flow_step_bwd_ctx(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb,
+                         const float* sbias, float* gx, float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2,
+                         float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && gz && gld && ws && wsb && sbias && gx && s_y0 && s_h1 && s_h2 && s_gh && s_gh2 && s_gh1 && s_gy);
+    CF_REQUIRE(x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(gz) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0);
+    const float* w = (const float*)ws;
+    const float* wb = (const float*)wsb;
+    int rc = 0;
+#define CF_BWDC(G) rc = launch_step_bwd<G, false, 1>(x, gz, gld, w, wb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream), sbias)
+    switch (shape_id(C, H, W)) {
+        case 0: CF_BWDC(B8); break;
+        case 1: CF_BWDC(B16); break;
+        case 2: CF_BWDC(B32); break;
+        case 3: CF_BWDC(B64); break;
+        default: cf_set_error("cf_flow_step_bwd_ctx: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+#undef CF_BWDC
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;

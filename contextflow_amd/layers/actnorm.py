@@ -62,7 +62,7 @@ class ActNorm(FlowLayer):
                   _hip.p(out), _hip.p(s), B, C, HW, int(inverse), _hip.stream())
         return out, s
 
-    def _forward_ctx(self, x, context):
+    def _forward_ctx(self, x, context, tape=None):
         """actnorm.py:40-60: per-sample shift / log-scale CN(c), added to the shared ones under contextflow (the only
         branch that runs the data-dependent init)."""
         from .simple_vit import _linear
@@ -78,6 +78,8 @@ class ActNorm(FlowLayer):
         ldj = torch.empty(B, device=x.device, dtype=torch.float32)
         _hip.call("cf_actnorm_ctx", _hip.p(x), _hip.p(m), _hip.p(t), _hip.p(logs), _hip.p(z), _hip.p(ldj), B, C, H * W, xbs,
                   _hip.stream())
+        if tape is not None:
+            tape.append(dict(x=x, c=_hip.f32(c), m=m))
         return z, ldj + logp_c * float(H * W)
 
     def forward(self, x, context=None):

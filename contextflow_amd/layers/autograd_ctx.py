@@ -1,0 +1,194 @@
+"""Training step of SPECIALIST models under contextflow (`create_model(generalist=False, contextflow=True)`:
+coupling.py:36, conv1x1.py:27, actnorm.py:23, gaussian.py:134 freeze the generalist's own parameters; the CN nets of
+every Conv1x1 / ActNorm / Coupling and the priors' embedding tables are what trains).
+
+One autograd.Function for the whole flow, layer by layer: the forward keeps each layer's input and the (stochastic)
+context-encoder output; the backward runs the data-gradient chain with HIP kernels (cf_conv1x1_ctx_bwd,
+cf_actnorm_ctx_bwd, the fused MFMA step-backward kernel with the per-sample CN(c) bias for the Coupling layers,
+cf_gmm_ctx_bwd) and turns the per-sample parameter gradients into CN / embedding gradients with library GEMMs.
+Built for the conv couplings with the encoders that have no trainable parameters of their own (eye | onehot + uniform)
+and for embedding lookups (embed + eyesample)."""
+import torch
+
+from . import _hip
+from .actnorm import ActNorm
+from .context import CatEmbeddings, EyeSampling, UniformCatDequantization
+from .conv1x1 import Conv1x1
+from .coupling import Coupling
+from .splitprior import SplitPrior
+from .squeeze import Squeeze, squeeze_op
+
+
+def _new(*shape, like):
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+def _check_encoder(enc):
+    if not isinstance(enc[1], (UniformCatDequantization, EyeSampling)):
+        raise NotImplementedError("specialist training with a %s context encoder (it has trainable parameters of its own)"
+                                  % type(enc[1]).__name__)
+
+
+def _encoder_backward(enc, context, gc, grads):
+    """d/d of the encoder output c: only the embedding lookup (embed + eyesample) has parameters."""
+    if isinstance(enc[0], CatEmbeddings):
+        _embedding_grads(enc[0], context, gc, grads)
+
+
+def _embedding_grads(emb, context, gc, grads):
+    o = 0
+    for i, m in enumerate(emb._embeddings):
+        d = m.weight.shape[1]
+        g = torch.zeros_like(m.weight, dtype=torch.float32)
+        g.index_add_(0, context[:, i].to(g.device), gc[:, o:o + d])           # scatter by context id (index op)
+        grads[m.weight] = g
+        o += d
+
+
+def _linear_bwd(x_in, lin, gy, grads):
+    grads[lin.weight] = gy.t() @ x_in
+    grads[lin.bias] = gy.sum(0)
+    return gy @ _hip.f32(lin.weight.detach())
+
+
+def _relu_bwd(act, gy):
+    out = torch.empty_like(gy)
+    _hip.call("cf_relu_bwd", _hip.p(act), _hip.p(gy), _hip.p(out), gy.numel(), _hip.stream())
+    return out
+
+
+def conv1x1_ctx_backward(m, rec, context, gz, gld, grads):
+    x, xbs = _hip.bview(rec["x"])
+    gzv, gzbs = _hip.bview(gz)
+    B, C, H, W = x.shape
+    gx = _new(B, C, H, W, like=x)
+    gm = _new(B, C * C, like=x)
+    Wm = _hip.f32(m.NN.detach()) if m.contextflow else None
+    _hip.call("cf_conv1x1_ctx_bwd", _hip.p(x), _hip.p(rec["m"]), _hip.p(Wm), _hip.p(gzv), _hip.p(gld), _hip.p(gx), _hip.p(gm),
+              B, C, H * W, xbs, gzbs, _hip.stream())
+    gc = _linear_bwd(rec["c"], m.CN, gm, grads)
+    _encoder_backward(m.context_net, context, gc, grads)
+    return gx
+
+
+def actnorm_ctx_backward(m, rec, context, gz, gld, grads):
+    x, xbs = _hip.bview(rec["x"])
+    gzv, gzbs = _hip.bview(gz)
+    B, C, H, W = x.shape
+    gx = _new(B, C, H, W, like=x)
+    gm = _new(B, 2 * C, like=x)
+    t = _hip.f32(m.NN_t.detach()) if m.contextflow else None
+    logs = _hip.f32(m.NN_logs.detach()) if m.contextflow else None
+    _hip.call("cf_actnorm_ctx_bwd", _hip.p(x), _hip.p(rec["m"]), _hip.p(t), _hip.p(logs), _hip.p(gzv), _hip.p(gld), _hip.p(gx),
+              _hip.p(gm), B, C, H * W, xbs, gzbs, _hip.stream())
+    gc = _linear_bwd(rec["c"], m.CN, gm, grads)
+    _encoder_backward(m.context_net, context, gc, grads)
+    return gx
+
+
+def coupling_ctx_backward(m, rec, context, gz, gld, grads):
+    """Coupling under contextflow: the fused step-backward kernel (identity 1x1 / ActNorm in front, per-sample bias in the
+    recompute); d/d CN(c) = per-sample row sums of the conditioner-output gradient plane."""
+    if rec["mode"] != 1:
+        raise NotImplementedError("specialist training without contextflow (all parameters train; not built)")
+    x, xbs = _hip.bview(rec["x"])
+    B, C, H, W = x.shape
+    HW, HALF, HID = H * W, C // 2, 2 * C
+    dev, st, f, pp, L = x.device, _hip.stream(), _hip.f32, _hip.p, _hip.lib()
+    c1, c2, c3 = m.NN[0], m.NN[2], m.NN[4]
+    eye = torch.eye(C, device=dev, dtype=torch.float32)
+    zero = torch.zeros(C, device=dev, dtype=torch.float32)
+    wsb = torch.empty(L.cf_flow_step_bwd_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+    _hip.call("cf_flow_step_bwd_prepare", pp(eye), pp(zero), pp(f(c1.weight.detach())), pp(f(c2.weight.detach())),
+              pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
+    new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
+    gx = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+    s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy = new(HALF), new(HID), new(HID), new(C), new(HID), new(HID), new(C)
+    gzc = f(gz).contiguous()
+    _hip.call("cf_flow_step_bwd_ctx", pp(x), pp(gzc), pp(f(gld)), pp(rec["ws"]), pp(wsb), pp(rec["cn"]), pp(gx), pp(s_y0),
+              pp(s_h1), pp(s_h2), pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, st)
+    gcn = _new(B, C, like=x)
+    _hip.call("cf_sample_channel_sums", pp(s_gh), pp(gcn), B, C, HW, st)
+    # CN = Linear -> ReLU -> Linear -> ReLU -> Linear   (coupling.py:37)
+    ga2 = _relu_bwd(rec["a2"], _linear_bwd(rec["a2"], m.CN[4], gcn, grads))
+    ga1 = _relu_bwd(rec["a1"], _linear_bwd(rec["a1"], m.CN[2], ga2, grads))
+    gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads)
+    _encoder_backward(m.context_net, context, gc, grads)
+    return gx
+
+
+def gmm_ctx_backward(dist, rec, g, grads):
+    """Context-shifted GMM: d/dx and the embedding-table gradients (mG / sG / wG are frozen under contextflow)."""
+    x, xbs = _hip.bview(rec["x"])
+    B, D, H, W = x.shape
+    M, K = dist.M, dist.K
+    gx = _new(B, D, H, W, like=x)
+    gc = _new(B, 2 * M * K * D, like=x)
+    _hip.call("cf_gmm_ctx_bwd", _hip.p(x), _hip.p(_hip.f32(dist.mG.detach())), _hip.p(_hip.f32(dist.sG.detach())),
+              _hip.p(rec["logw"]), _hip.p(rec["c"]), _hip.p(_hip.f32(g)), _hip.p(gx), _hip.p(gc), B, M, K, D, H * W, xbs,
+              _hip.stream())
+    _embedding_grads(dist.context_net[0], rec["context"], gc, grads)
+    return gx
+
+
+class SpecialistLogProb(torch.autograd.Function):
+    """logp (B, M) of a specialist FlowSequential with gradients for its trainable (context) parameters."""
+
+    @staticmethod
+    def forward(ctx, flow, x, context, *params):
+        B, M = x.shape[0], flow.mixtures
+        tape = []
+        logdet = torch.zeros(B, M, device=x.device, dtype=torch.float32)
+        for mod in flow.sequence_modules:
+            rec = []
+            if isinstance(mod, Conv1x1) and mod.context_net:
+                _check_encoder(mod.context_net)
+                x, ldj = mod._forward_ctx(x, context, rec)
+            elif isinstance(mod, ActNorm) and mod.context_net:
+                _check_encoder(mod.context_net)
+                x, ldj = mod._forward_ctx(x, context, rec)
+            elif type(mod) is Coupling and mod.context_net:
+                _check_encoder(mod.context_net)
+                if not mod._fused_ctx_ok(x):
+                    raise NotImplementedError("specialist training needs the fused coupling geometry (3x3, C in 8..64)")
+                x, ldj = mod._fused_ctx(x, context, rec)
+            elif isinstance(mod, SplitPrior) and getattr(mod.dist, "context_net", None):
+                c = x.shape[1] // 2
+                ldj = mod.dist._log_prob_ctx(x[:, c:], context, rec)
+                rec[0]["full"] = x
+                x = x[:, :c]
+            else:
+                if any(p.requires_grad for p in mod.parameters()):
+                    raise NotImplementedError("specialist training: %s has trainable parameters" % type(mod).__name__)
+                x, ldj = mod(x, context)
+            tape.append((mod, rec[0] if rec else None))
+            logdet += ldj if ldj.dim() == 2 else ldj.unsqueeze(-1)
+        rec = []
+        logp = flow.dist._log_prob_ctx(x, context, rec) + logdet
+        ctx.flow, ctx.tape, ctx.prior, ctx.params, ctx.context = flow, tape, rec[0], params, context
+        ctx.mark_non_differentiable(x)
+        return x, logp
+
+    @staticmethod
+    def backward(ctx, _gz_unused, glogp):
+        flow, tape, params, context = ctx.flow, ctx.tape, ctx.params, ctx.context
+        glogp = _hip.f32(glogp)
+        gld = glogp.sum(1).contiguous()
+        grads = {}
+        gz = gmm_ctx_backward(flow.dist, ctx.prior, glogp, grads)
+        for mod, rec in reversed(tape):
+            if rec is None:
+                if isinstance(mod, Squeeze):
+                    gz = squeeze_op(gz, mod.p, True)
+                    continue
+                break                                    # pre-processing: nothing trainable upstream
+            if isinstance(mod, SplitPrior):
+                g2 = gmm_ctx_backward(mod.dist, rec, glogp, grads)
+                gz = torch.cat([gz, g2], dim=1)
+            elif isinstance(mod, Conv1x1):
+                gz = conv1x1_ctx_backward(mod, rec, context, gz, gld, grads)
+            elif isinstance(mod, ActNorm):
+                gz = actnorm_ctx_backward(mod, rec, context, gz, gld, grads)
+            else:
+                gz = coupling_ctx_backward(mod, rec, context, gz, gld, grads)
+        return (None, None, None) + tuple(grads.get(p) for p in params)

@@ -42,8 +42,9 @@ class Conv1x1(FlowLayer):
             if self.contextflow:
                 self.NN.requires_grad_(False)
 
-    def _forward_ctx(self, x, context):
-        """conv1x1.py:34-50: per-sample triangular matrix from CN(c)."""
+    def _forward_ctx(self, x, context, tape=None):
+        """conv1x1.py:34-50: per-sample triangular matrix from CN(c).  `tape` (training): receives what the backward
+        needs - the encoder is stochastic, so its output must be kept, not recomputed."""
         from .simple_vit import _linear
         c, logp_c = self.context_net(context)
         x, xbs = _hip.bview(x)
@@ -56,6 +57,8 @@ class Conv1x1(FlowLayer):
         if self.contextflow:
             lad, _ = slogdet_inverse(Wm, False)
             ldj = ldj + lad * float(H * W)
+        if tape is not None:
+            tape.append(dict(x=x, c=_hip.f32(c), m=m))
         return z, ldj + logp_c * float(H * W)
 
     def forward(self, x, context=None):

@@ -107,13 +107,16 @@ class Coupling(_AffineCoupling):
         h = conv2d_reflect(h1, self.NN[2], True)
         return conv2d_reflect(h, self.NN[4], False), logp_c
 
-    def _fused_ctx(self, x, context):
+    def _fused_ctx(self, x, context, tape=None):
         """The Coupling layer as ONE fp32-MFMA kernel (the fused flow-step kernel with an identity 1x1 / ActNorm in
         front) with the CN(c) term as a per-sample bias: on the conditioner output (contextflow) or before its first
         ReLU (CN(c) concatenated to the conditioner input: W[:, D:] CN(c))."""
         from .simple_vit import _linear
         c, logp_c = self.context_net(context)
-        cn = _linear(_linear(_linear(_hip.f32(c), self.CN[0], act=2), self.CN[2], act=2), self.CN[4])    # (B, O)
+        c = _hip.f32(c)
+        a1 = _linear(c, self.CN[0], act=2)
+        a2 = _linear(a1, self.CN[2], act=2)
+        cn = _linear(a2, self.CN[4])                                                              # (B, O)
         x, xbs = _hip.bview(x)
         B, C, H, W = x.shape
         D = C // 2
@@ -136,6 +139,8 @@ class Coupling(_AffineCoupling):
         z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
         ldj = torch.zeros(B, device=dev, dtype=torch.float32)
         _hip.call("cf_flow_step_fwd_ctx", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), mode, B, C, H, W, xbs, st)
+        if tape is not None:
+            tape.append(dict(x=x, c=c, a1=a1, a2=a2, cn=cn, ws=ws, mode=mode))
         return z, ldj + logp_c * float(H * W)
 
     def _fused_ctx_ok(self, x):

@@ -97,7 +97,7 @@ class GaussianMixtureDistribution(nn.Module):
     def prepared(self):
         return gmm_prepare(self.mG.detach(), self.sG.detach(), self.wG.detach())
 
-    def _log_prob_ctx(self, input, context):
+    def _log_prob_ctx(self, input, context, tape=None):
         """gaussian.py:146-158: per-sample shifts (B, 2, M, K, D) of the component means / pre-softplus scales."""
         if isinstance(context, list):
             context = context[0]
@@ -109,6 +109,8 @@ class GaussianMixtureDistribution(nn.Module):
         out = torch.empty(B, M, device=x.device, dtype=torch.float32)
         _hip.call("cf_gmm_ctx_logprob", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(_hip.f32(self.sG.detach())),
                   _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(out), B, M, K, D, H * W, xbs, 0, _hip.stream())
+        if tape is not None:
+            tape.append(dict(x=x, c=_hip.f32(c), logw=logw, context=context))
         return out + (logp_c * float(H * W)).unsqueeze(-1)
 
     def log_prob(self, input, context=None):

@@ -75,6 +75,9 @@ class FlowSequential(nn.Module):
                 return False
         return True
 
+    def _specialist(self):
+        return bool(getattr(self.dist, "context_net", None))
+
     def _needs_only_init(self):
         """True when the fused plan is blocked only by ActNorm layers that have not seen their first batch yet."""
         if not self.fused or not isinstance(self.dist, GaussianMixtureDistribution) or getattr(self.dist, "context_net", None):
@@ -280,6 +283,14 @@ class FlowSequential(nn.Module):
     # ------------------------------------------------------------------ reference API
     def forward(self, input, context=None):
         _hip.require_device(input)
+        if torch.is_grad_enabled() and self._specialist():
+            params = [p for p in self.parameters() if p.requires_grad]
+            if params:                       # specialist training under contextflow (autograd_ctx.py)
+                if any(isinstance(m, ActNorm) and m.contextflow and not m.is_initialized() for m in self.sequence_modules):
+                    with torch.no_grad():    # first call: the ActNorm data-dependent init
+                        self._forward_layers(input, context)
+                from .autograd_ctx import SpecialistLogProb
+                return SpecialistLogProb.apply(self, input, context, *params)
         if torch.is_grad_enabled():
             params = [p for p in self.parameters() if p.requires_grad]
             if params and not self._fusable() and self._needs_only_init():

@@ -257,6 +257,26 @@ int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const f
 int cf_cond_gauss_sample(const float* c, const float* eps, float* x, float* logp, int B, int D, cf_stream_t stream);
 int cf_sigmoid_ldj(const float* x, float* y, float* ldj, int B, int D, cf_stream_t stream);
 
+/* ---- specialist training (contextflow: the CN nets and the priors' embedding tables train, the generalist's own
+ * parameters stay frozen - coupling.py:36, conv1x1.py:27, actnorm.py:23, gaussian.py:134) -------------------------
+ * backward of cf_flow_step_fwd_ctx mode 1: as cf_flow_step_bwd, the recompute adds sbias (B,C) to the conditioner
+ * output; d/d sbias[b,c] = sum_p s_gh[b,c,p] (cf_sample_channel_sums).                                          */
+int cf_flow_step_bwd_ctx(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb,
+                         const float* sbias, float* gx, float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2,
+                         float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, cf_stream_t stream);
+/* Conv1x1 / ActNorm with a context net, backward: gx (B,C,HW) dense and gm = d/d CN(c) output ((B,C*C) / (B,2C)).
+ * gld (B) = d/d of the layer's per-sample log-det.                                                              */
+int cf_conv1x1_ctx_bwd(const float* x, const float* m, const float* Wm, const float* gz, const float* gld, float* gx,
+                       float* gm, int B, int C, int HW, int64_t x_bstride, int64_t gz_bstride, cf_stream_t stream);
+int cf_actnorm_ctx_bwd(const float* x, const float* m, const float* t, const float* logs, const float* gz, const float* gld,
+                       float* gx, float* gm, int B, int C, int HW, int64_t x_bstride, int64_t gz_bstride, cf_stream_t stream);
+/* out[b,c] = sum_p a[b,c,p] ; out = gy * (x > 0)                                                               */
+int cf_sample_channel_sums(const float* a, float* out, int B, int C, int HW, cf_stream_t stream);
+int cf_relu_bwd(const float* x, const float* gy, float* out, int64_t n, cf_stream_t stream);
+/* context-shifted GMM, backward w.r.t. x (B,D,HW) and the per-sample shifts c (B,2,M,K,D); g (B,M) upstream      */
+int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float* logw, const float* c, const float* g,
+                   float* gx, float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride, cf_stream_t stream);
+
 /* ---- log-det bookkeeping (layers/flowsequential.py:18-27) --------------------------------------- */
 /* out[b,m] = ldM[b,m] + ld1[b]                                                                      */
 int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream);

@@ -663,3 +663,48 @@ def test_specialist_forward_matches_reference(L, fxname):
     set_noise(model, inp["u"][:2], [e[:2] for e in inp["eps"]])
     _, logp2 = model(inp["x"][:2].to(DEV), inp["context"][:2].to(DEV))
     assert (logp2 - logp[:2]).abs().max().item() < 2e-2 * max(1.0, 1e-5 * logp.abs().max().item())
+
+
+@pytest.mark.parametrize("fxname", ["mnist_eye_cf", "cifar10_onehot_cf"])
+def test_specialist_backward_against_autograd_oracle(L, fxname):
+    """Specialist training under contextflow: d sum(w * logp) / d (CN nets, prior embedding tables) from the hand-written
+    backward (autograd_ctx.py) against torch.autograd through the CPU oracle in fp64, same inputs / noise / parameters.
+    The generalist's own parameters are frozen (coupling.py:36 ...) and must receive no gradient."""
+    import contextflow_amd as cfa
+    from tests.helpers import load_specialist
+    from tests.gpu_util import set_noise
+    name, ctx, ops, M, params, inp = load_specialist(fxname)
+    B = inp["x"].shape[0]
+    g = torch.Generator().manual_seed(33)
+    wts = torch.randn(B, M, generator=g)
+    p64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in params.items()}
+    _, lp = fo.flow_forward(ops, p64, inp["x"].double(), inp["u"].double(), [e.double() for e in inp["eps"]], ctx=ctx,
+                            context=inp["context"], cnoise=[c.double() for c in inp["cnoise"]])
+    (lp * wts.double()).sum().backward()
+    cfg, ds, MM = cfa.preset_config(name)
+    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type="uniform", contextflow=True)
+    model = cfa.create_model(cfg, ds, MM, contexts=ctx["contexts"])
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).train()
+    set_noise(model, inp["u"], inp["eps"])
+    encs = [m for m in model.modules() if isinstance(m, cfa.layers.UniformCatDequantization)]
+    for e, c in zip(encs, inp["cnoise"]):
+        e.fixed_noise = c.to(DEV)
+    z, logp = model(inp["x"].to(DEV), inp["context"].to(DEV))
+    assert logp.requires_grad
+    assert (bpd(logp.detach().cpu(), name) - bpd(lp.detach().float(), name)).abs().max() < BPD_TOL
+    (logp * wts.to(DEV)).sum().backward()
+    checked = 0
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None, k
+            continue
+        assert ".CN." in k or "_embeddings" in k, k
+        ref = p64[k].grad
+        assert p.grad is not None, k
+        got = p.grad.detach().cpu().double()
+        scale = max(ref.abs().max().item(), 1e-3)
+        err = (got - ref).abs().max().item() / scale
+        assert err < 2e-3, "%s: relative grad error %.3e (scale %.3e)" % (k, err, scale)
+        checked += 1
+    assert checked >= 20
