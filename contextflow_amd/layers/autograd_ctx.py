@@ -23,6 +23,20 @@ def _new(*shape, like):
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
 
+def trainable(flow):
+    """True when this specialist flow can be trained here: contextflow (frozen generalist), conv couplings, context
+    encoders without trainable parameters of their own (uniform dequantisation, embedding lookup)."""
+    from .coupling import TransCoupling
+    ok = (UniformCatDequantization, EyeSampling)
+    for m in list(flow.sequence_modules) + [flow.dist]:
+        cn = getattr(m, "context_net", None) or getattr(getattr(m, "dist", None), "context_net", None)
+        if cn and (not isinstance(cn[1], ok) or not getattr(m, "contextflow", getattr(getattr(m, "dist", None), "contextflow", False))):
+            return False
+        if isinstance(m, TransCoupling) and cn:
+            return False
+    return True
+
+
 def _check_encoder(enc):
     if not isinstance(enc[1], (UniformCatDequantization, EyeSampling)):
         raise NotImplementedError("specialist training with a %s context encoder (it has trainable parameters of its own)"

@@ -284,8 +284,10 @@ class FlowSequential(nn.Module):
     def forward(self, input, context=None):
         _hip.require_device(input)
         if torch.is_grad_enabled() and self._specialist():
+            from .autograd_ctx import trainable as _trainable
             params = [p for p in self.parameters() if p.requires_grad]
-            if params:                       # specialist training under contextflow (autograd_ctx.py)
+            if params and _trainable(self):  # specialist training under contextflow (autograd_ctx.py); other
+                                             # specialist models evaluate only: they fall through to the no_grad path
                 if any(isinstance(m, ActNorm) and m.contextflow and not m.is_initialized() for m in self.sequence_modules):
                     with torch.no_grad():    # first call: the ActNorm data-dependent init
                         self._forward_layers(input, context)
