@@ -117,9 +117,14 @@ def main():
     rank, local_rank, world = cdist.env_world()
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
+    # BENCH_REHEARSAL=1 (developer, one-GPU box): all ranks share device 0 and talk over gloo, to exercise the N > 1 code
+    # path (sharding, broadcast, all-reduce, barriers) without N GPUs; the numbers of such a run mean nothing
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cdist.init_process_group("nccl")
+    cdist.init_process_group("gloo" if rehearsal else "nccl")
     _hip.lib()
     name = a.workload
 
