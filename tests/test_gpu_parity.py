@@ -708,3 +708,37 @@ def test_specialist_backward_against_autograd_oracle(L, fxname):
         assert err < 2e-3, "%s: relative grad error %.3e (scale %.3e)" % (k, err, scale)
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("name,channels", [("msl", 55), ("smd", 38)])
+def test_other_timeseries_presets_match_oracle(L, name, channels):
+    """MSL / SMD (model.py:211-216): the SMAP topology with 55 / 38 sensor channels - transformer width 112 / 80 is
+    beyond the fused ViT kernel (dim <= 64), so the layer-by-layer ViT kernels run; checked against the oracle (which the
+    reference fixtures pin on the same code path for SMAP)."""
+    import contextflow_amd as cfa
+    from oracle import params as op
+    ds = (channels, 8, 1)
+    ops, prior_size, M = fo.program("smap", data_size=ds)
+    spec = op.param_spec(ops, prior_size, M)
+    params = op.gen_params(spec, 3)
+    g = torch.Generator().manual_seed(8)
+    B = 5
+    x = torch.rand(B, *ds, generator=g)
+    eps = [torch.randn(B, 1, 8, 1, generator=g)] if channels % 2 else []
+    p_or = {k: v.clone() for k, v in params.items()}
+    _, lp_ref = fo.flow_forward(ops, p_or, x, None, eps, init_actnorm=True)
+    cfg, ds2, MM = cfa.preset_config(name)
+    assert tuple(ds2) == ds and MM == M
+    model = cfa.create_model(cfg, ds2, MM)
+    assert list(model.state_dict().keys()) == list(spec.keys())
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).eval()
+    from tests.gpu_util import set_noise
+    set_noise(model, None, eps)
+    with torch.no_grad():
+        _, lp1 = model(x.to(DEV))                   # first call: ActNorm init, layer by layer
+        set_noise(model, None, eps)
+        _, lp2 = model(x.to(DEV))                   # fused plan
+    D = channels * 8
+    for lp in (lp1, lp2):
+        assert (fo.bits_per_dim(lp.cpu(), D) - fo.bits_per_dim(lp_ref, D)).abs().max().item() < 2e-5
