@@ -360,6 +360,17 @@ __global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x
     for (int e = tid; e < N; e += 256) gx[(int64_t)b * N + e] = (gxs[e] + gxs[N + e]) + (gxs[2 * N + e] + gxs[3 * N + e]);
 }
 
+// h[b, c2, p] += x[b, c2 % C, p]   (the identity branch of MaskedResidualBlock2d: x repeated along channels,
+// autoregressive/masked_conv_2d.py:93-98)
+__global__ __launch_bounds__(256) void k_add_repeat(float* __restrict__ h, const float* __restrict__ x, int C2, int C,
+                                                    int HW, int64_t total) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / ((int64_t)C2 * HW);
+        const int r = (int)(e - b * (int64_t)C2 * HW), c2 = r / HW, p = r - c2 * HW;
+        h[e] += x[(b * C + (c2 % C)) * HW + p];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -486,6 +497,17 @@ int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float
         }
     }
     k_gmm_ctx_bwd<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, gx, gc, M, K, D, HW, x_bstride);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_add_repeat(float* h, const float* x, int B, int C2, int C, int HW, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(h && x && B >= 0 && C2 > 0 && C > 0 && HW > 0);
+    const int64_t total = (int64_t)B * C2 * HW;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    k_add_repeat<<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(h, x, C2, C, HW, total);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -23,6 +23,7 @@ from .squeeze import Squeeze, UnSqueeze
 from .transforms import LogitTransform
 from .coupling import Coupling, CouplingFC, TransCoupling
 from .simple_vit import SimpleViT, posemb_sincos_2d
+from .ar import MaskedCoupling
 from .context import (ArgmaxCatDequantization, CatEmbeddings, ConditionalGaussianDistribution, ContextEncoder,
                       EyeEncoder, EyeSampling, OneHotEncoder, ProbSampling, UniformCatDequantization,
                       VariationalCatDequantization)

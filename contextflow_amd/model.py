@@ -6,7 +6,7 @@ Appendix B).  Generalist (context-free) models, and specialist models (`generali
 Coupling gets its own ContextEncoder, the priors an embedding lookup — model.py:117-162) for the conv couplings with
 the eye | onehot + uniform context encoders."""
 from .layers import (ActNorm, Augment, ContextEncoder, Conv1x1, Coupling, Dequantization, FlowSequential,
-                     GaussianMixtureDistribution, LogitTransform, Normalization, SplitPrior, Squeeze,
+                     GaussianMixtureDistribution, LogitTransform, MaskedCoupling, Normalization, SplitPrior, Squeeze,
                      StandardNormal, TransCoupling, UniformDistribution)
 
 ALPHA = 1e-4
@@ -75,7 +75,8 @@ def create_model(config, data_size=(1, 1, 1), mixtures=1, contexts=(-1,)):
                 layers.append(Coupling(sz[0], kernel_size=krn, padding=pad, context_net=ctxnet((sz[0],)),
                                        contextflow=contextflow))
             elif config["coupling"] == "maf":
-                raise NotImplementedError("--coupling maf is outside the hot path (SURVEY.md §2 row 15)")
+                layers.append(MaskedCoupling(sz[0], kernel_size=krn, padding=pad, context_net=ctxnet((sz[0],)),
+                                             contextflow=contextflow))
             if dataset == "atm":
                 raise NotImplementedError("ATM topology (PermuteAxes) is outside the hot path")
         if config["split_prior"] and blk < config["num_blocks"] - 1:

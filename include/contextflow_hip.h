@@ -277,6 +277,10 @@ int cf_relu_bwd(const float* x, const float* gy, float* out, int64_t n, cf_strea
 int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float* logw, const float* c, const float* g,
                    float* gx, float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride, cf_stream_t stream);
 
+/* h[b,c2,:] += x[b, c2 % C, :] in place: identity branch of MaskedResidualBlock2d (`--coupling maf`,
+ * layers/autoregressive/masked_conv_2d.py:93-98)                                                                */
+int cf_add_repeat(float* h, const float* x, int B, int C2, int C, int HW, cf_stream_t stream);
+
 /* ---- log-det bookkeeping (layers/flowsequential.py:18-27) --------------------------------------- */
 /* out[b,m] = ldM[b,m] + ld1[b]                                                                      */
 int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream);

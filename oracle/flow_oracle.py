@@ -325,6 +325,34 @@ def spline_activation_inv(y, uw, uh, ud, tail_bound=10.0):
 
 
 
+def maf_mask(mask_type, cin, cout, kh, kw, data_channels):
+    """autoregressive/utils.py:27-91: causal spatial mask, channel-autoregressive centre tap."""
+    base = torch.ones(data_channels, data_channels).tril(-1 if mask_type == "A" else 0)
+    ch = base.repeat(cout // data_channels + 1, cin // data_channels + 1)[:cout, :cin]
+    mask = torch.ones(cout, cin, kh, kw)
+    mask[:, :, kh // 2, kw // 2] = ch
+    mask[:, :, kh // 2, kw // 2 + 1:] = 0
+    mask[:, :, kh // 2 + 1:] = 0
+    return mask
+
+
+def masked_coupling_fwd(x, p, prefix, pad):
+    """MaskedCoupling.forward (ar.py:33-57) over MaskedResidualBlock2d (masked_conv_2d.py:81-98): ReLU in FRONT of every
+    masked conv, identity = x repeated twice; all channels transformed; ldj = sum log_s."""
+    D = x.shape[1]
+
+    def conv(name, h, padding):
+        w = p[prefix + name + ".weight"] * p[prefix + name + ".mask"].to(h.dtype)
+        if padding[0] or padding[1]:
+            h = F.pad(h, (padding[1], padding[1], padding[0], padding[0]), mode="reflect")
+        return F.conv2d(h, w, p[prefix + name + ".bias"])
+    h = conv("NN.conv1", F.relu(x), (0, 0))
+    h = conv("NN.conv2", F.relu(h), pad)
+    h = conv("NN.conv3", F.relu(h), (0, 0)) + x.repeat(1, 2, 1, 1)
+    t, log_s = h[:, :D], 2.0 * torch.tanh(h[:, D:] / 2.0)
+    return x * torch.exp(log_s) + t, log_s.flatten(1).sum(-1)
+
+
 # --------------------------------------------------------------------------------------
 # specialist (context-conditioned) branches          SURVEY 8(f) rank 2
 # --------------------------------------------------------------------------------------

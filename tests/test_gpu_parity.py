@@ -3,6 +3,7 @@
 committed golden vectors produced by the reference.  Tolerances: bits/dim 1e-5 (BASELINE.json),
 activations 1e-5 relative to the tensor's scale."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -742,3 +743,18 @@ def test_other_timeseries_presets_match_oracle(L, name, channels):
     D = channels * 8
     for lp in (lp1, lp2):
         assert (fo.bits_per_dim(lp.cpu(), D) - fo.bits_per_dim(lp_ref, D)).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("tag,D,krn,pad", [("maf_3x3", 6, (3, 3), (1, 1)), ("maf_3x1", 8, (3, 1), (1, 0))])
+def test_masked_coupling_matches_reference(L, tag, D, krn, pad):
+    """MaskedCoupling (--coupling maf, ar.py:15-57) through the generic reflect-padded conv kernels against the
+    reference layer's outputs; the masks multiply the weights in place, as upstream."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "unit_maf.npz"))
+    m = L.MaskedCoupling(D, kernel_size=krn, padding=pad)
+    m.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(tag + "/sd:")}, strict=True)
+    m = m.to(DEV)
+    z, ldj = m(torch.from_numpy(fx[tag + "/x"]).to(DEV))
+    assert (z.cpu() - torch.from_numpy(fx[tag + "/z"])).abs().max() < 2e-5
+    assert (ldj.cpu() - torch.from_numpy(fx[tag + "/ldj"])).abs().max() < 2e-4
+    with pytest.raises(NotImplementedError):
+        m.reverse(z)

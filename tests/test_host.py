@@ -105,7 +105,9 @@ def test_unbuilt_names_raise_and_specialist_layout():
     from tests.helpers import SPECIALIST
     L = cfa.layers
     with pytest.raises(NotImplementedError):
-        L.MaskedCoupling(4)
+        L.MaskedCoupling(4, context_net=object())
+    assert set(L.MaskedCoupling(4, (3, 3), (1, 1)).state_dict()) == {
+        "NN.conv%d.%s" % (i, k) for i in (1, 2, 3) for k in ("weight", "bias", "mask")}
     with pytest.raises(NotImplementedError):
         L.ContextEncoder([64], "eye", "vardeq", (16,))          # odd code width: the reference's Augment path
     assert set(L.SplineActivation((2, 2, 2), individual_weights=True).state_dict()) == {

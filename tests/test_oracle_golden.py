@@ -183,3 +183,15 @@ def test_specialist_oracle_matches_reference(fxname):
     tol = max(1e-5, 1e-5 * ref.abs().max().item())      # |logp| ~ 1e6 in the un-normalised smap_eye configuration
     assert (fo.bits_per_dim(lp, D) - ref).abs().max().item() < tol
     assert (z - inp["z"]).abs().max().item() < 2e-3 * max(1.0, inp["z"].abs().max().item())
+
+
+@pytest.mark.parametrize("tag", ["maf_3x3", "maf_3x1"])
+def test_masked_coupling_oracle(tag):
+    """MaskedCoupling (--coupling maf) restatement against the reference layer's outputs (tests/golden/unit_maf.npz)."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "unit_maf.npz"))
+    p = {"0." + k[len(tag) + 4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(tag + "/sd:")}
+    x = torch.from_numpy(fx[tag + "/x"])
+    z, ldj = fo.masked_coupling_fwd(x, p, "0.", tuple(int(v) for v in fx[tag + "/pad"]))
+    assert (z - torch.from_numpy(fx[tag + "/z"])).abs().max() < 1e-5
+    assert (ldj - torch.from_numpy(fx[tag + "/ldj"])).abs().max() < 1e-4
