@@ -25,8 +25,7 @@ class EyeEncoder(nn.Module):
 
 
 class OneHotEncoder(nn.Module):
-    """rtdl/nn/_embeddings.py:112-150.  The one-hot code is produced inside cf_ctx_encode; this module only carries
-    the cardinalities."""
+    """rtdl/nn/_embeddings.py:112-150: concatenated one-hot codes of the context variables (an index op)."""
 
     def __init__(self, cardinalities):
         super().__init__()
@@ -35,7 +34,8 @@ class OneHotEncoder(nn.Module):
     def forward(self, x):
         if x.ndim != 2:
             raise ValueError("The input must have two dimensions")
-        return self, x                       # the encoder fuses the encoding with the dequantisation
+        cols = [torch.nn.functional.one_hot(x[:, i], int(k)) for i, k in enumerate(self.cardinalities.tolist())]
+        return torch.cat(cols, 1), x
 
 
 class CatEmbeddings(nn.Module):
@@ -71,17 +71,14 @@ class UniformCatDequantization(nn.Module):
         self.fixed_noise = None
 
     def forward(self, input):
-        x, context = input
+        x, context = input                                   # x: integer code (B, D) - the context itself or its one-hot
         dev = self.qbins.device
-        B = context.shape[0]
-        onehot = isinstance(x, OneHotEncoder)
-        width = self.D
+        B, width = x.shape[0], self.D
         u = self.fixed_noise if self.fixed_noise is not None else torch.rand((B, width), device=dev, dtype=torch.float32)
         z = torch.empty(B, width, device=dev, dtype=torch.float32)
-        ctx = context.to(device=dev, dtype=torch.int64).contiguous()
-        card = x.cardinalities.to(torch.int64) if onehot else None
-        _hip.call("cf_ctx_encode", _hip.p(ctx), _hip.p(_hip.f32(u)), _hip.p(self.qbins), _hip.p(card), _hip.p(z), B,
-                  ctx.shape[1], width, int(onehot), _hip.stream())
+        code = x.to(device=dev, dtype=torch.int64).contiguous()
+        _hip.call("cf_ctx_encode", _hip.p(code), _hip.p(_hip.f32(u)), _hip.p(self.qbins), None, _hip.p(z), B, width, width, 0,
+                  _hip.stream())
         ldj = (self.ldj_per_dim * width).sum(-1).repeat(B)           # dequantize.py:62 (num_dims = width)
         return z, ldj
 
@@ -127,17 +124,16 @@ class VariationalCatDequantization(nn.Module):
     def forward(self, input):
         x, context = input
         dev = self.qbins.device
-        B, width = context.shape[0], self.D
-        onehot = isinstance(x, OneHotEncoder)
+        B, width = x.shape[0], self.D
         ctx = context.to(device=dev, dtype=torch.int64).contiguous()
         u, qu = self.encoder.sample(ctx, ctx)
         su = torch.empty_like(u)
         act_ldj = torch.empty(B, device=dev, dtype=torch.float32)
         _hip.call("cf_sigmoid_ldj", _hip.p(u), _hip.p(su), _hip.p(act_ldj), B, width, _hip.stream())
         z = torch.empty(B, width, device=dev, dtype=torch.float32)
-        card = x.cardinalities.to(torch.int64) if onehot else None
-        _hip.call("cf_ctx_encode", _hip.p(ctx), _hip.p(su), _hip.p(self.qbins), _hip.p(card), _hip.p(z), B, ctx.shape[1],
-                  width, int(onehot), _hip.stream())
+        code = x.to(device=dev, dtype=torch.int64).contiguous()
+        _hip.call("cf_ctx_encode", _hip.p(code), _hip.p(su), _hip.p(self.qbins), None, _hip.p(z), B, width, width, 0,
+                  _hip.stream())
         ldj = (self.ldj_per_dim * width).sum(-1).repeat(B)
         return z, ldj + act_ldj - qu
 
