@@ -132,6 +132,68 @@ __global__ __launch_bounds__(256) void k_slogdet(const float* __restrict__ Wm, i
     }
 }
 
+// 64 < C <= 128, log|det| only (the ATM topology's 72 / 76-channel Conv1x1, model.py:149-151): the same scheme with
+// TWO rows per lane (row = lane + 64 h); the pivot row's slot h is wave-uniform.
+struct LuState2 {
+    double a[2][32];   // A[lane + 64 h][4 jj + w]
+    double piv[2];
+    bool used[2];
+};
+
+template <int K>
+__device__ __forceinline__ void lu_steps2(LuState2& s, double* colbuf, int C, int lane, int w) {
+    if constexpr (K < 128) {
+        if (K < C) {                                              // uniform
+            double* line = colbuf + (K & 1) * 128;
+            if (w == (K & 3)) { line[lane] = s.a[0][K >> 2]; line[64 + lane] = s.a[1][K >> 2]; }
+            __syncthreads();
+            const double ak0 = line[lane], ak1 = line[64 + lane];
+            const unsigned k0 = s.used[0] ? 0u : ((__float_as_uint((float)fabs(ak0)) & ~127u) | (unsigned)(127 - lane));
+            const unsigned k1 = s.used[1] ? 0u : ((__float_as_uint((float)fabs(ak1)) & ~127u) | (unsigned)(63 - lane));
+            unsigned key = k0 > k1 ? k0 : k1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned ok = (unsigned)__shfl_xor((int)key, o, 64); key = ok > key ? ok : key; }
+            const int r = __builtin_amdgcn_readfirstlane(127 - (int)(key & 127u));   // pivot row in [0, 128)
+            const int rl = r & 63;
+            const bool hi = r >= 64;                                                    // uniform
+            const double piv = readlane_f64(hi ? ak1 : ak0, rl);
+            const bool self0 = !hi && lane == rl, self1 = hi && lane == rl;
+            const double f0 = (self0 || s.used[0]) ? 0.0 : ak0 / piv;
+            const double f1 = (self1 || s.used[1]) ? 0.0 : ak1 / piv;
+#pragma unroll
+            for (int jj = K >> 2; jj < 32; ++jj) {
+                const double pr = readlane_f64(hi ? s.a[1][jj] : s.a[0][jj], rl);
+                s.a[0][jj] = fma(-f0, pr, s.a[0][jj]);
+                s.a[1][jj] = fma(-f1, pr, s.a[1][jj]);
+            }
+            if (self0) { s.used[0] = true; s.piv[0] = ak0; }
+            if (self1) { s.used[1] = true; s.piv[1] = ak1; }
+        }
+        lu_steps2<K + 1>(s, colbuf, C, lane, w);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_slogdet128(const float* __restrict__ Wm, int C, float* __restrict__ logabsdet) {
+    __shared__ double colbuf[2 * 128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    LuState2 s;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = lane + 64 * h;
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) {
+            const int j = 4 * jj + w;
+            s.a[h][jj] = (row < C && j < C) ? (double)Wm[row * C + j] : 0.0;
+        }
+        s.used[h] = row >= C; s.piv[h] = 1.0;
+    }
+    lu_steps2<0>(s, colbuf, C, lane, w);
+    if (w == 0) {
+        const double l = cf_wave_sum_d((lane < C ? log(fabs(s.piv[0])) : 0.0) + (lane + 64 < C ? log(fabs(s.piv[1])) : 0.0));
+        if (lane == 0) logabsdet[0] = (float)l;
+    }
+}
+
 template <int CMAX>
 void launch_slogdet(const float* Wm, int C, float* lad, float* inv, hipStream_t st) {
     if (inv == nullptr) k_slogdet<CMAX, false><<<dim3(1), dim3(256), 0, st>>>(Wm, C, lad, nullptr);
@@ -158,7 +220,15 @@ int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z,
 
 int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_stream_t stream) {
     CF_REQUIRE(Wm && logabsdet && C > 0);
-    if (C > kMaxLU) { cf_set_error("cf_slogdet_inverse: C=%d > %d unsupported", C, kMaxLU); return CF_ERR_UNSUPPORTED; }
+    if (C > kMaxLU) {
+        if (C > 128 || inv != nullptr) {
+            cf_set_error("cf_slogdet_inverse: C=%d unsupported (log|det| up to 128, inverse up to %d)", C, kMaxLU);
+            return CF_ERR_UNSUPPORTED;
+        }
+        k_slogdet128<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet);
+        CF_LAUNCH_CHECK();
+        return 0;
+    }
     if (C <= 8) launch_slogdet<8>(Wm, C, logabsdet, inv, cf_s(stream));
     else if (C <= 16) launch_slogdet<16>(Wm, C, logabsdet, inv, cf_s(stream));
     else if (C <= 32) launch_slogdet<32>(Wm, C, logabsdet, inv, cf_s(stream));

@@ -24,6 +24,7 @@ from .transforms import LogitTransform
 from .coupling import Coupling, CouplingFC, TransCoupling
 from .simple_vit import SimpleViT, posemb_sincos_2d
 from .ar import MaskedCoupling
+from .permute_axes import PermuteAxes
 from .context import (ArgmaxCatDequantization, CatEmbeddings, ConditionalGaussianDistribution, ContextEncoder,
                       EyeEncoder, EyeSampling, OneHotEncoder, ProbSampling, UniformCatDequantization,
                       VariationalCatDequantization)

@@ -27,6 +27,7 @@ from .dequantize import Dequantization
 from .distributions.gaussian import GaussianMixtureDistribution, StandardNormal, gmm_logprob
 from .distributions.uniform import UniformDistribution
 from .normalize import Normalization
+from .permute_axes import PermuteAxes
 from .splitprior import SplitPrior
 from .squeeze import Squeeze, squeeze_op
 from .transforms import LogitTransform
@@ -138,6 +139,8 @@ class FlowSequential(nn.Module):
                 continue
             if isinstance(m, Augment) and is3(shape) and m.split_dim == 1:
                 shape = (shape[0] + m.aug_size,) + shape[1:]
+            elif isinstance(m, PermuteAxes) and is3(shape):
+                shape = tuple(shape[a - 1] for a in m.permutation[1:])
             elif isinstance(m, (Squeeze, SplitPrior)):
                 shape = None            # unknown geometry from here on: everything else runs layer by layer
             ops.append(("layer", m))

@@ -10,7 +10,6 @@ def _stub(name, why):
     return type(name, (nn.Module,), {"__init__": __init__})
 
 
-PermuteAxes = _stub("PermuteAxes", "ATM topology only")
 StudentMixtureDistribution = _stub("StudentMixtureDistribution", "--dist tdist; non-default prior")
 GaussianDistribution = _stub("GaussianDistribution", "unused by create_model")
 MultivariateGaussianMixtureDistribution = _stub("MultivariateGaussianMixtureDistribution", "unused by create_model")

@@ -6,7 +6,7 @@ Appendix B).  Generalist (context-free) models, and specialist models (`generali
 Coupling gets its own ContextEncoder, the priors an embedding lookup — model.py:117-162) for the conv couplings with
 the eye | onehot + uniform context encoders."""
 from .layers import (ActNorm, Augment, ContextEncoder, Conv1x1, Coupling, Dequantization, FlowSequential,
-                     GaussianMixtureDistribution, LogitTransform, MaskedCoupling, Normalization, SplitPrior, Squeeze,
+                     GaussianMixtureDistribution, LogitTransform, MaskedCoupling, Normalization, PermuteAxes, SplitPrior, Squeeze,
                      StandardNormal, TransCoupling, UniformDistribution)
 
 ALPHA = 1e-4
@@ -16,6 +16,7 @@ COMPONENTS = 8
 PRESETS = {
     "mnist": ((1, 32, 32), 10, 2, 2, False, "conv"),
     "cifar10": ((3, 32, 32), 10, 3, 4, True, "conv"),
+    "atm": ((38, 144, 1), 2, 3, 4, True, "trans"),          # model.py:189-198: 26 + 12 variables, window 144
     "smap": ((25, 8, 1), 1, 2, 4, False, "trans"),
     "msl": ((55, 8, 1), 1, 2, 4, False, "trans"),
     "smd": ((38, 8, 1), 1, 2, 4, False, "trans"),
@@ -77,8 +78,9 @@ def create_model(config, data_size=(1, 1, 1), mixtures=1, contexts=(-1,)):
             elif config["coupling"] == "maf":
                 layers.append(MaskedCoupling(sz[0], kernel_size=krn, padding=pad, context_net=ctxnet((sz[0],)),
                                              contextflow=contextflow))
-            if dataset == "atm":
-                raise NotImplementedError("ATM topology (PermuteAxes) is outside the hot path")
+            if dataset == "atm":                          # model.py:149-151: swap channel and time axes
+                layers.append(PermuteAxes((0, 2, 1, 3)))
+                sz = (sz[1], sz[0], sz[2])
         if config["split_prior"] and blk < config["num_blocks"] - 1:
             sz = (sz[0] // 2, sz[1], sz[2])
             layers.append(SplitPrior(prior(sz)))

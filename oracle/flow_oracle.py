@@ -34,6 +34,7 @@ CONFIGS = {
     "mnist": ((1, 32, 32), 10, 2, 2, False, "conv"),
     "cifar10": ((3, 32, 32), 10, 3, 4, True, "conv"),
     "smap": ((25, 8, 1), 1, 2, 4, False, "trans"),
+    "atm": ((38, 144, 1), 2, 3, 4, True, "trans"),          # model.py:189-198,281
 }
 
 
@@ -71,6 +72,9 @@ def program(dataset, data_size=None, mixtures=None, num_blocks=None, block_size=
                 ops.append(("transcoupling", len(ops), sz, patch))
             elif coupling == "conv":
                 ops.append(("coupling", len(ops), sz, krn, pad))
+            if dataset == "atm":                              # model.py:149-151
+                ops.append(("permute", len(ops), (0, 2, 1, 3)))
+                sz = (sz[1], sz[0], sz[2])
         if split_prior and blk < num_blocks - 1:              # model.py:153-158
             sz = (sz[0] // 2, sz[1], sz[2])
             ops.append(("split", len(ops), sz))
@@ -605,6 +609,8 @@ def flow_forward(ops, params, x, u=None, eps=(), init_actnorm=False, trace=None,
             x, ldj = torch.cat([x, e], 1), std_normal_neg_logq(e)
         elif kind == "squeeze":
             x, ldj = squeeze_fwd(x, op[2]), torch.zeros(B, dtype=x.dtype)
+        elif kind == "permute":                                   # permute_axes.py:14-15
+            x, ldj = x.permute(op[2]).contiguous(), torch.zeros(B, dtype=x.dtype)
         elif kind == "conv1x1" and ctx is not None:
             c, lc = enc(pre)
             x, ldj = conv1x1_ctx_fwd(x, params[pre + "NN"], params[pre + "CN.weight"], params[pre + "CN.bias"], c, lc,

@@ -68,6 +68,7 @@ REF_CFG = {
     "mnist": dict(dataset="mnist", num_blocks=2, block_size=2, split_prior=False, coupling="conv", contexts=[-1]),
     "cifar10": dict(dataset="cifar10", num_blocks=3, block_size=4, split_prior=True, coupling="conv", contexts=[-1, -1]),
     "smap": dict(dataset="smap", num_blocks=2, block_size=4, split_prior=False, coupling="trans", contexts=[55]),
+    "atm": dict(dataset="atm", num_blocks=3, block_size=4, split_prior=True, coupling="trans", contexts=[68]),
 }
 
 
@@ -85,7 +86,7 @@ def build_reference(name):
 def synth_input(name, B, seed):
     g = torch.Generator().manual_seed(seed)
     C, H, W = fo.CONFIGS[name][0]
-    if name == "smap":
+    if name in ("smap", "atm"):
         return torch.rand(B, C, H, W, generator=g)
     return torch.randint(0, 256, (B, C, H, W), generator=g).float()
 
@@ -126,7 +127,7 @@ def end_to_end(name, B=4, seed=0):
         logp = flow.dist.log_prob(h, ctx) + logdet
     assert torch.equal(logp, logp_first) and torch.equal(h, z_first), name
 
-    fx = dict(x=x.numpy().astype(np.uint8) if name != "smap" else x.numpy(), logp=logp.numpy(), z=h.numpy(),
+    fx = dict(x=x.numpy().astype(np.uint8) if name not in ("smap", "atm") else x.numpy(), logp=logp.numpy(), z=h.numpy(),
               seed=np.int64(seed))
     if noise_u is not None:
         fx["u"] = noise_u.numpy()
@@ -141,7 +142,7 @@ def end_to_end(name, B=4, seed=0):
     keep.update(first_of.values())
     # first and last flow step of every resolution level + everything around split/squeeze
     for i, (kind, _, _) in enumerate(trace):
-        if kind in ("squeeze", "split", "augment", "logit"):
+        if kind in ("squeeze", "split", "augment", "logit") and name != "atm":
             keep.update({i, min(i + 1, len(trace) - 1), min(i + 2, len(trace) - 1), min(i + 3, len(trace) - 1)})
     keep.update({len(trace) - 1, len(trace) - 2, len(trace) - 3})
     for i, (kind, out, ldj) in enumerate(trace):

@@ -186,7 +186,7 @@ def test_fused_step_phases(L, C, H, W, B, squeeze):
 
 
 # ------------------------------------------------------------------------------------------ end to end
-@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap", "atm"])
 @pytest.mark.parametrize("fused", [False, True])
 def test_e2e_golden(L, name, fused):
     from tests.gpu_util import build_model, set_noise
@@ -205,7 +205,7 @@ def test_e2e_golden(L, name, fused):
     assert (model.log_prob(x.to(DEV)).cpu() - logp.cpu()).abs().max() == 0     # deterministic given the noise
 
 
-@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap", "atm"])
 def test_e2e_actnorm_first_call(L, name):
     """First call on un-initialised ActNorms reproduces the reference's data-dependent init."""
     from tests.gpu_util import build_model, set_noise

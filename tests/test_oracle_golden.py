@@ -10,7 +10,7 @@ BPD_TOL = 1e-5     # BASELINE.json: bits/dim within 1e-5 of the reference
 Z_TOL = 1e-5
 
 
-@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap", "atm"])
 def test_e2e_logp_and_trace(name):
     ops, _, M, params, fx = load_e2e(name)
     x, u, eps = e2e_inputs(name, fx)
@@ -32,7 +32,7 @@ def test_e2e_logp_and_trace(name):
             assert (zi - zr).abs().max() <= 1e-4 * max(1.0, zr.abs().max().item()), (i, kind)
 
 
-@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap", "atm"])
 def test_e2e_actnorm_init(name):
     """First call: data-dependent ActNorm init must reproduce the reference's post-init state."""
     ops, _, M, post, fx = load_e2e(name)
@@ -45,7 +45,7 @@ def test_e2e_actnorm_init(name):
     assert (bpd(logp, name) - bpd(torch.from_numpy(fx["logp"]), name)).abs().max() < BPD_TOL
 
 
-@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap", "atm"])
 def test_fp64_noise_floor(name):
     """The oracle in fp64 against the reference in fp64: restatement is exact up to fp64 rounding."""
     ops, _, M, params, fx = load_e2e(name)
