@@ -23,7 +23,7 @@ import torch  # noqa: E402
 
 FLOP_PER_SAMPLE_STEP = {"cifar10": 2 * (2555904 + 65536), "mnist": None}   # MACs of one flow step x2
 PEAK_F32_MFMA_TFLOPS = 157.3                                              # MI355X_MICROARCH.md, dense fp32 matrix
-DIMS = {"cifar10": 3072, "mnist": 1024, "smap": 200}
+DIMS = {"cifar10": 3072, "mnist": 1024, "smap": 200, "atm": 38 * 144}
 
 
 def parse():
@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cifar10", choices=["cifar10", "mnist", "smap"])
+    ap.add_argument("--workload", default="cifar10", choices=["cifar10", "mnist", "smap", "atm"])
     ap.add_argument("--global-batch", type=int, default=524288)
     ap.add_argument("--chunk", type=int, default=65536, help="samples per kernel launch sequence on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -42,11 +42,11 @@ def parse():
 def synth(name, n, dev, seed):
     """Synthetic input resident in HBM: uint8-valued fp32 images (what Dequantization receives) or [0,1) series."""
     g = torch.Generator(device=dev).manual_seed(seed)
-    C, H, W = {"cifar10": (3, 32, 32), "mnist": (1, 32, 32), "smap": (25, 8, 1)}[name]
+    C, H, W = {"cifar10": (3, 32, 32), "mnist": (1, 32, 32), "smap": (25, 8, 1), "atm": (38, 144, 1)}[name]
     out = torch.empty(n, C, H, W, device=dev, dtype=torch.float32)
     for i in range(0, n, 65536):                      # piecewise: randint materialises int64
         m = min(65536, n - i)
-        if name == "smap":
+        if name in ("smap", "atm"):
             out[i:i + m] = torch.rand(m, C, H, W, device=dev, generator=g)
         else:
             out[i:i + m] = torch.randint(0, 256, (m, C, H, W), device=dev, generator=g).float()
@@ -91,7 +91,7 @@ def cpu_baseline(name, seconds):
     B = 256
     g = torch.Generator().manual_seed(0)
     C, H, W = fo.CONFIGS[name][0]
-    x = torch.rand(B, C, H, W, generator=g) if name == "smap" else torch.randint(0, 256, (B, C, H, W), generator=g).float()
+    x = torch.rand(B, C, H, W, generator=g) if name in ("smap", "atm") else torch.randint(0, 256, (B, C, H, W), generator=g).float()
     u = torch.rand(B, C, H, W, generator=g)
     eps = [torch.randn(B, 1, H, W, generator=g)]
     with torch.no_grad():
@@ -197,7 +197,7 @@ def main():
                 "kernel_time_share": round(ms * 1e-3 / dt, 3)}
 
     if rank == 0:
-        label = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap": "SMAP trans flow"}[name]
+        label = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap": "SMAP trans flow", "atm": "ATM trans flow"}[name]
         out = {"metric": "samples/s fwd+logdet (log p(x) (B,M)), %s" % label,
                "value": round(G * a.steps / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
