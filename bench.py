@@ -142,7 +142,8 @@ def main():
     nll_acc = torch.zeros(1, dtype=torch.float64, device=dev)
     events = []
 
-    def step(timed):
+    @torch.no_grad()                                   # density evaluation (experiment_cl.py:163-185 runs it under no_grad):
+    def step(timed):                                   # no autograd tape, no W^-1 for the backward
         nll_acc.zero_()
         for c0 in range(0, hi - lo, a.chunk):
             xb = x[c0:c0 + a.chunk]
