@@ -133,7 +133,8 @@ def main():
     cfg, data_size, M = cfa.preset_config(name)
     model = cfa.create_model(cfg, data_size, M).to(dev)
     if rank == 0:
-        model(synth(name, 256, dev, seed=999))
+        with torch.no_grad():
+            model(synth(name, 256, dev, seed=999))
     cdist.broadcast_parameters(model, src=0)
 
     G = a.global_batch
