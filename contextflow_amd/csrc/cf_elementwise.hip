@@ -119,6 +119,75 @@ int launch_sample(const float* x, const float* u, float* y, float* ldj, int B, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// pre-processing with the noise drawn INSIDE the kernel (no separate RNG kernels, no 4-byte/element noise tensors
+// through HBM): Philox4x32-10 keyed by `seed`, counter = (float4 index, kind, offset) - one call gives the four
+// uniforms of a float4 of pixels.  The augment channel (augment.py:14-18, gaussian.py:50-72) is filled with
+// Box-Muller normals from the same generator and contributes -log q(eps) = sum(eps^2/2 + log(2 pi)/2).
+// state[0] = offset, advanced by k_rng_advance on the same stream (so that a captured graph draws fresh noise on
+// every replay).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(unsigned r) { return (float)(r >> 8) * 5.9604644775390625e-08f; }   // [0, 1), 24 bits
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_preprocess_rng(const float* __restrict__ x, float* __restrict__ y,
+                                                       float* __restrict__ ldj, const unsigned long long* __restrict__ state,
+                                                       unsigned long long seed, int n4, int aug4, int64_t x_bstride,
+                                                       int64_t y_bstride, float t1, float s1, float t2, float s2, float c0) {
+    __shared__ float red[NT / 64];
+    const int b = blockIdx.x;
+    const unsigned long long off = state[0];
+    const unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    const float* xb = x + (int64_t)b * x_bstride;
+    float* yb = y + (int64_t)b * y_bstride;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n4; i += NT) {
+        float r[4];
+        unsigned rn[4];
+        vload<4>(xb + (int64_t)i * 4, r);
+        const unsigned long long idx = (unsigned long long)b * (unsigned)(n4 + aug4) + (unsigned)i;
+        philox4x32_10((unsigned)idx, (unsigned)(idx >> 32), (unsigned)off, (unsigned)(off >> 32), k0, k1, rn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = ((r[j] + u01(rn[j])) / s1 + t1) / s2 + t2;
+            const float l0 = logf(v), l1 = logf(1.0f - v);
+            r[j] = l0 - l1;
+            acc += -l0 - l1;
+        }
+        vstore<4>(yb + (int64_t)i * 4, r);
+    }
+    for (int i = threadIdx.x; i < aug4; i += NT) {            // augment channel: 4 standard normals per Philox call
+        unsigned rn[4];
+        float e[4];
+        const unsigned long long idx = (unsigned long long)b * (unsigned)(n4 + aug4) + (unsigned)(n4 + i);
+        philox4x32_10((unsigned)idx, (unsigned)(idx >> 32), (unsigned)off, (unsigned)(off >> 32), k0, k1, rn);
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const float rad = sqrtf(-2.0f * logf(1.0f - u01(rn[j]))), ang = 6.28318530717958647692f * u01(rn[j + 1]);
+            e[j] = rad * cosf(ang); e[j + 1] = rad * sinf(ang);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += 0.5f * e[j] * e[j] + 0.5f * kLog2Pi;
+        vstore<4>(yb + (int64_t)(n4 + i) * 4, e);
+    }
+    acc = cf_block_sum<NT / 64>(acc, red);
+    if (threadIdx.x == 0) ldj[b] = acc + c0;
+}
+
+__global__ void k_rng_advance(unsigned long long* state) { state[0] += 1; }
+
+// ---------------------------------------------------------------------------------------------
 // squeeze: out[b, c*p1*p2 + i1*p2 + i2, h, w] = in[b, c, h*p1+i1, w*p2+i2]     squeeze.py:10-14
 // thread per element of the SQUEEZED tensor (coalesced on that side)
 // ---------------------------------------------------------------------------------------------
@@ -310,6 +379,20 @@ int cf_preprocess_fwd(const float* x, const float* u, float* y, float* ldj, int 
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && u && y && ldj && B >= 0 && N > 0 && y_bstride >= N);
     launch_sample<1>(x, u, y, ldj, B, N, N, y_bstride, t1, s1, t2, s2, ldj_const, cf_s(stream));
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_preprocess_rng_fwd(const float* x, float* y, float* ldj, uint64_t* rng_state, uint64_t seed, int B, int N,
+                          int aug_n, int64_t y_bstride, float t1, float s1, float t2, float s2, float ldj_const,
+                          cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && y && ldj && rng_state && B >= 0 && N > 0 && aug_n >= 0 && y_bstride >= N + aug_n);
+    CF_REQUIRE(N % 4 == 0 && aug_n % 4 == 0 && y_bstride % 4 == 0 && aligned16(x) && aligned16(y));
+    k_preprocess_rng<256><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, y, ldj, (const unsigned long long*)rng_state,
+                                                                  (unsigned long long)seed, N / 4, aug_n / 4, N, y_bstride,
+                                                                  t1, s1, t2, s2, ldj_const);
+    k_rng_advance<<<dim3(1), dim3(1), 0, cf_s(stream)>>>((unsigned long long*)rng_state);
     CF_LAUNCH_CHECK();
     return 0;
 }

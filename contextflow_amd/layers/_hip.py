@@ -26,6 +26,7 @@ SIGNATURES = {
     "cf_sigmoid": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "cf_floor": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "cf_preprocess_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
+    "cf_preprocess_rng_fwd": (_c_int, [_c_p] * 4 + [ctypes.c_uint64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
     "cf_std_normal_nll": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_i64, _c_p]),
     "cf_squeeze": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_int, _c_p]),
     "cf_conv1x1_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_p]),

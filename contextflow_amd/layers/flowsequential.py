@@ -45,13 +45,14 @@ class FlowSequential(nn.Module):
         self.step_events = None      # bench.py: list collecting (start, end, batch, C) HIP events per step-kernel launch
         self._plans = {}             # input (C,H,W) -> op list
         self._side = {}              # device index -> side stream for the parameter transforms
+        self._rng, self._rng_seed = {}, 0   # device index -> position of the in-kernel noise stream
 
     def __iter__(self):
         yield from self.sequence_modules
 
     def __getstate__(self):              # streams / cached plans are per-process runtime state
         d = self.__dict__.copy()
-        d["_plans"], d["_side"], d["step_events"] = {}, {}, None
+        d["_plans"], d["_side"], d["step_events"], d["_rng"] = {}, {}, None, {}
         return d
 
     # ------------------------------------------------------------------ layer-by-layer mode
@@ -147,6 +148,14 @@ class FlowSequential(nn.Module):
             i += 1
         return ops
 
+    def _rng_state(self, dev):
+        """Device-resident position of the in-kernel noise stream (one uint64 per device), seeded from torch's seed."""
+        st = self._rng.get(dev.index)
+        if st is None:
+            self._rng_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            st = self._rng[dev.index] = torch.zeros(1, device=dev, dtype=torch.int64)
+        return st
+
     def _side_stream(self, dev):
         s = self._side.get(dev.index)
         if s is None:
@@ -209,11 +218,22 @@ class FlowSequential(nn.Module):
                 xin = _hip.f32(x)
                 C, H, W = xin.shape[1:]
                 N = C * H * W
-                u = _hip.f32(deq.dist.sample(B, context=xin)[0])
                 ca = aug.aug_size if aug is not None else 0
                 y = torch.empty(B, C + ca, H, W, device=dev, dtype=torch.float32)
                 cst = -N * math.log(n1._s) - N * math.log(n2._s)      # normalize.py:42-49, twice
                 ldp = ld1 if k == 0 else torch.empty_like(ld1)         # the kernel assigns its per-sample ldj
+                if (deq.dist.fixed_noise is None and (aug is None or aug.distribution.fixed_noise is None)
+                        and N % 4 == 0 and (ca * H * W) % 4 == 0):
+                    # noise drawn inside the kernel (Philox, keyed by torch's seed): dequantisation uniforms and the
+                    # Augment channel's normals never travel through HBM as tensors of their own
+                    state = self._rng_state(dev)
+                    _hip.call("cf_preprocess_rng_fwd", _hip.p(xin), _hip.p(y), _hip.p(ldp), _hip.p(state), self._rng_seed, B, N,
+                              ca * H * W, (C + ca) * H * W, n1._t, n1._s, n2._t, n2._s, cst, st)
+                    if ldp is not ld1:
+                        ld1 += ldp
+                    x = y
+                    continue
+                u = _hip.f32(deq.dist.sample(B, context=xin)[0])
                 _hip.call("cf_preprocess_fwd", _hip.p(xin), _hip.p(u), _hip.p(y), _hip.p(ldp), B, N, (C + ca) * H * W,
                           n1._t, n1._s, n2._t, n2._s, cst, st)
                 if ldp is not ld1:

@@ -50,6 +50,13 @@ int cf_floor(const float* x, float* y, int64_t n, cf_stream_t stream);
  * y = logit(v) written with batch stride y_bstride, ldj[b] = ldj_const + sum(-log v - log(1-v)).   */
 int cf_preprocess_fwd(const float* x, const float* u, float* y, float* ldj, int B, int N, int64_t y_bstride,
                       float t1, float s1, float t2, float s2, float ldj_const, cf_stream_t stream);
+/* the same fused pre-processing with the noise drawn inside the kernel (Philox4x32-10; u ~ U[0,1) per element,
+ * eps ~ N(0,1) for the `aug_n` elements of the Augment channel appended after the N image elements, whose
+ * -log q(eps) is added to ldj).  rng_state: one uint64 on the device (the stream position, advanced by the call -
+ * graph replays therefore draw fresh noise); seed: the generator key.  N, aug_n, y_bstride multiples of 4.     */
+int cf_preprocess_rng_fwd(const float* x, float* y, float* ldj, uint64_t* rng_state, uint64_t seed, int B, int N,
+                          int aug_n, int64_t y_bstride, float t1, float s1, float t2, float s2, float ldj_const,
+                          cf_stream_t stream);
 /* out[b] = 0.5*sum(eps^2) + 0.5*N*log(2 pi)  = -log N(eps;0,I)  Augment ldj (augment.py:14-18,
  * distributions/gaussian.py:50-54); eps rows have stride eps_bstride.                              */
 int cf_std_normal_nll(const float* eps, float* out, int B, int N, int64_t eps_bstride, cf_stream_t stream);

@@ -758,3 +758,41 @@ def test_masked_coupling_matches_reference(L, tag, D, krn, pad):
     assert (ldj.cpu() - torch.from_numpy(fx[tag + "/ldj"])).abs().max() < 2e-4
     with pytest.raises(NotImplementedError):
         m.reverse(z)
+
+
+def test_in_kernel_noise_statistics(L):
+    """cf_preprocess_rng_fwd (Philox inside the kernel): the implied dequantisation noise is U[0,1), the Augment channel
+    N(0,1), the log-det equals the one the explicit-noise kernel gives for that very noise, and consecutive calls (and
+    therefore graph replays) draw fresh noise."""
+    from contextflow_amd.layers import _hip
+    B, C, H, W = 64, 3, 32, 32
+    N, A = C * H * W, H * W
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (B, C, H, W), generator=g).float().to(DEV)
+    t1, s1, t2, s2 = 0.0, 256.0, 1e-4, 1.0 / (1.0 - 2e-4)
+    cst = -N * math.log(s1) - N * math.log(s2)
+    state = torch.zeros(1, device=DEV, dtype=torch.int64)
+    outs = []
+    for _ in range(2):
+        y = torch.empty(B, C + 1, H, W, device=DEV)
+        ldj = torch.empty(B, device=DEV)
+        _hip.call("cf_preprocess_rng_fwd", _hip.p(x), _hip.p(y), _hip.p(ldj), _hip.p(state), 1234, B, N, A, (C + 1) * H * W,
+                  t1, s1, t2, s2, cst, _hip.stream())
+        outs.append((y, ldj))
+    assert int(state.item()) == 2
+    y, ldj = outs[0]
+    v = torch.sigmoid(y[:, :C].double())                          # v = ((x+u)/256)(1-2a) + a
+    u = ((v - t2) * s2 - t1) * s1 - x.double()
+    assert u.min() > -1e-3 and u.max() < 1 + 1e-3
+    assert abs(u.mean().item() - 0.5) < 5e-3 and abs(u.var().item() - 1 / 12) < 2e-3
+    eps = y[:, C:].double()
+    assert abs(eps.mean().item()) < 2e-2 and abs(eps.var().item() - 1.0) < 3e-2
+    assert abs((eps ** 3).mean().item()) < 5e-2 and abs((eps ** 4).mean().item() - 3.0) < 0.15
+    ref = cst + (-torch.log(v) - torch.log1p(-v)).flatten(1).sum(-1) + (0.5 * eps ** 2 + 0.5 * math.log(2 * math.pi)).flatten(1).sum(-1)
+    assert (ldj.double().cpu() - ref.cpu()).abs().max() < 2e-2
+    assert (outs[1][0] - y).abs().max() > 0.1                     # second call: different noise
+    # correlation between neighbouring pixels / samples of the uniforms is absent
+    uu = u.flatten(1)
+    c1 = torch.corrcoef(torch.stack([uu[:, :-1].flatten(), uu[:, 1:].flatten()]))[0, 1].abs().item()
+    c2 = torch.corrcoef(torch.stack([uu[:-1].flatten(), uu[1:].flatten()]))[0, 1].abs().item()
+    assert c1 < 1e-2 and c2 < 1e-2
