@@ -32,8 +32,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cifar10", choices=["cifar10", "mnist", "smap", "atm"])
-    ap.add_argument("--global-batch", type=int, default=524288)
-    ap.add_argument("--chunk", type=int, default=65536, help="samples per kernel launch sequence on one rank")
+    ap.add_argument("--global-batch", type=int, default=2097152)
+    ap.add_argument("--chunk", type=int, default=262144, help="samples per kernel launch sequence on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
