@@ -796,3 +796,25 @@ def test_in_kernel_noise_statistics(L):
     c1 = torch.corrcoef(torch.stack([uu[:, :-1].flatten(), uu[:, 1:].flatten()]))[0, 1].abs().item()
     c2 = torch.corrcoef(torch.stack([uu[:-1].flatten(), uu[1:].flatten()]))[0, 1].abs().item()
     assert c1 < 1e-2 and c2 < 1e-2
+
+
+def test_large_launch_equals_chunked(L):
+    """One 262 144-sample call (4.3e9 activation elements per tensor: beyond 32-bit element indices) gives exactly the
+    rows that four 65 536-sample calls give on the same inputs and noise - the bench's default chunk size is safe."""
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e("cifar10")
+    model = build_model("cifar10", params).eval()
+    B, step = 262144, 65536
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randint(0, 256, (B, 3, 32, 32), device=DEV, generator=g, dtype=torch.int32).float()
+    u = torch.rand(B, 3, 32, 32, device=DEV, generator=g)
+    eps = torch.randn(B, 1, 32, 32, device=DEV, generator=g)
+    with torch.no_grad():
+        set_noise(model, u, [eps])
+        _, big = model(x)
+        big = big.clone()
+        for c0 in range(0, B, step):
+            set_noise(model, u[c0:c0 + step], [eps[c0:c0 + step]])
+            _, part = model(x[c0:c0 + step])
+            assert torch.equal(part, big[c0:c0 + step]), c0
+    assert torch.isfinite(big).all()
