@@ -204,8 +204,14 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx_bwd(const float* __restrict
                                                          const float* __restrict__ gld, float* __restrict__ gx,
                                                          float* __restrict__ gm, int C, int HW, int64_t xbs, int64_t gzbs) {
     __shared__ float Wb[kMaxC * (kMaxC + 1)];         // Wb[o][i], row stride C + 1
+    extern __shared__ __align__(16) float dyn[];      // xs[C*HW] | gs[C*HW]: this sample's input and upstream gradient
+    float* xs = dyn;
+    float* gs = dyn + C * HW;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* mb = m + (int64_t)b * C * C;
+    const float* xb = x + (int64_t)b * xbs;
+    const float* gb = gz + (int64_t)b * gzbs;
+    for (int e = tid; e < C * HW; e += 256) { xs[e] = xb[e]; gs[e] = gb[e]; }
     for (int e = tid; e < C * C; e += 256) {
         const int o = e / C, i = e - o * C;
         const float v = mb[e];
@@ -214,13 +220,11 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx_bwd(const float* __restrict
         Wb[o * (C + 1) + i] = w;
     }
     __syncthreads();
-    const float* xb = x + (int64_t)b * xbs;
-    const float* gb = gz + (int64_t)b * gzbs;
     float* gxb = gx + (int64_t)b * C * HW;
     for (int e = tid; e < C * HW; e += 256) {
         const int i = e / HW, p = e - i * HW;
         float acc = 0.f;
-        for (int o = 0; o < C; ++o) acc = fmaf(Wb[o * (C + 1) + i], gb[(int64_t)o * HW + p], acc);
+        for (int o = 0; o < C; ++o) acc = fmaf(Wb[o * (C + 1) + i], gs[o * HW + p], acc);
         gxb[e] = acc;
     }
     float* gmb = gm + (int64_t)b * C * C;
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx_bwd(const float* __restrict
         const int o = e / C, i = e - o * C;
         float g = 0.f;
         if (o >= i) {
-            for (int p = 0; p < HW; ++p) g = fmaf(gb[(int64_t)o * HW + p], xb[(int64_t)i * HW + p], g);
+            for (int p = 0; p < HW; ++p) g = fmaf(gs[o * HW + p], xs[i * HW + p], g);
             if (o == i) g = g * expf(mb[e]) + gl;
         }
         gmb[e] = g;
@@ -338,22 +342,29 @@ __global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x
         const float* cm = cb + (int64_t)mk * D;
         const float* cs = cb + (int64_t)(MK + mk) * D;
         const float r = lp[mk];
-        for (int d = 0; d < D; ++d) {       // channel by channel: the (mk, d) sums are wave reductions over h*w
+        // the (mk, channel) sums are reductions over h*w: a wave covers SEG = min(64, HW) pixels of 64/SEG channels at
+        // a time (all 64 lanes busy also for the 4x4 prior), segmented shuffle reduction inside each channel's lanes
+        const int SEG = HW < 64 ? HW : 64, CPW = 64 / SEG;
+        const int sub = lane / SEG, pl = lane - sub * SEG;
+        for (int d0 = 0; d0 < D; d0 += CPW) {
+            const int d = d0 + sub;
             float a0 = 0.f, a1 = 0.f;
-            const float cmd = cm[d], csd = cs[d];
-            for (int p = lane; p < HW; p += 64) {
-                const int e = d * HW + p;
-                const float sv = sg[e] + csd;
-                const float sig = sv > 20.f ? sv : __logf(1.0f + __expf(sv));
-                const float inv = __frcp_rn(sig), dd = xs[e] - mu[e] - cmd;
-                const float q = dd * inv * inv;                       // d / sig^2
-                const float dsig = sv > 20.f ? 1.f : __frcp_rn(1.0f + __expf(-sv));   // softplus'
-                mine[e] -= r * q;
-                a0 += q;
-                a1 += (dd * q * inv - inv) * dsig;
+            if (d < D) {
+                const float cmd = cm[d], csd = cs[d];
+                for (int p = pl; p < HW; p += SEG) {
+                    const int e = d * HW + p;
+                    const float sv = sg[e] + csd;
+                    const float sig = sv > 20.f ? sv : __logf(1.0f + __expf(sv));
+                    const float inv = __frcp_rn(sig), dd = xs[e] - mu[e] - cmd;
+                    const float q = dd * inv * inv;                       // d / sig^2
+                    const float dsig = sv > 20.f ? 1.f : __frcp_rn(1.0f + __expf(-sv));   // softplus'
+                    mine[e] -= r * q;
+                    a0 += q;
+                    a1 += (dd * q * inv - inv) * dsig;
+                }
             }
-            a0 = cf_wave_sum(a0); a1 = cf_wave_sum(a1);
-            if (lane == 0) { gcb[(int64_t)mk * D + d] = r * a0; gcb[(int64_t)(MK + mk) * D + d] = r * a1; }
+            for (int o = SEG >> 1; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
+            if (pl == 0 && d < D) { gcb[(int64_t)mk * D + d] = r * a0; gcb[(int64_t)(MK + mk) * D + d] = r * a1; }
         }
     }
     __syncthreads();
@@ -449,7 +460,11 @@ int cf_conv1x1_ctx_bwd(const float* x, const float* m, const float* Wm, const fl
     if (B == 0) return 0;
     CF_REQUIRE(x && m && gz && gld && gx && gm && B >= 0 && C > 0 && HW > 0);
     if (C > kMaxC) { cf_set_error("cf_conv1x1_ctx_bwd: C=%d > %d unsupported", C, kMaxC); return CF_ERR_UNSUPPORTED; }
-    k_conv1x1_ctx_bwd<<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, m, Wm, gz, gld, gx, gm, C, HW, x_bstride, gz_bstride);
+    const size_t lds = (size_t)2 * C * HW * sizeof(float);
+    if (lds + sizeof(float) * kMaxC * (kMaxC + 1) > 64 * 1024) {
+        cf_set_error("cf_conv1x1_ctx_bwd: C*HW=%d too large for the LDS staging", C * HW); return CF_ERR_UNSUPPORTED;
+    }
+    k_conv1x1_ctx_bwd<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, m, Wm, gz, gld, gx, gm, C, HW, x_bstride, gz_bstride);
     CF_LAUNCH_CHECK();
     return 0;
 }

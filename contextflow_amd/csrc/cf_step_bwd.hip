@@ -157,7 +157,8 @@ __device__ __forceinline__ void adj_axis(int c, int d, int N, int (&src)[2], boo
 
 // CTX = 1: specialist coupling under contextflow (coupling.py:44): the conditioner output carries a per-sample bias
 // sb (B, C) = CN(c); only its log-scale half matters for the recompute (t does not enter any gradient); d/d sb is the
-// per-sample row sum of the s_gh plane, taken by the caller.
+// per-sample row sum of the s_gh plane, taken by the caller.  The generalist's weights are frozen in that mode, so the
+// six operand planes of the weight-gradient GEMMs are not written at all (156 of 172 KB per sample at C = 16).
 template <class G, bool SQ, int CTX = 0>
 __global__ __launch_bounds__(256) void k_flow_step_bwd(
     const float* __restrict__ x, const float* __restrict__ gz, const float* __restrict__ gld,
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 if (idx < HALF) Y0[idx * PIX + pix[q]] = acc0[0][q][r];
                 y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
             }
-        rows_store_t<G, HALF, HALF>(s_y0, Y0, b0, B, wave, lane);
+        if constexpr (CTX == 0) rows_store_t<G, HALF, HALF>(s_y0, Y0, b0, B, wave, lane);   // weight-gradient operand plane
     }
     unsigned m1[RT1][PTW], m2[RT1][PTW];       // ReLU masks of h1 / h2, one bit per accumulator register
     {   // phase 1
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 m1[rt][q] = m;
             }
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);
-        rows_store_t<G, HID, HID>(s_h1, H1, b0, B, wave, lane);
+        if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_h1, H1, b0, B, wave, lane);   // weight-gradient operand plane
     }
     __syncthreads();                     // h1 complete (taps cross waves)
     {   // phase 2 (compiler-scheduled form; the backward is not yet tuned per shape)
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 m2[rt][q] = m;
             }
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);
-        rows_store_t<G, HID, HID>(s_h2, H1, b0, B, wave, lane);
+        if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_h2, H1, b0, B, wave, lane);   // weight-gradient operand plane
     }
     // phase 3 -> t, raw
     float ls[PTW][NR];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 for (int r = 0; r < 16; ++r)
                     if (!((m2[rt][q] >> r) & 1u)) acc[rt][q][r] = 0.f;
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);       // g_h2 plane over the whole H region (own columns)
-        rows_store_t<G, HID, HID>(s_gh2, H1, b0, B, wave, lane);
+        if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_gh2, H1, b0, B, wave, lane);   // weight-gradient operand plane
     }
     __syncthreads();                     // g_h2 complete: the transposed 3x3 reads neighbouring waves' columns
     {   // g_h1 = (NN.2^T (*) g_h2) * [h1 > 0]: adjoint of the reflect-padded gather.  Output pixel p of tap (dy,dx)
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 for (int r = 0; r < 16; ++r)
                     if (!((m1[rt][q] >> r) & 1u)) acc[rt][q][r] = 0.f;
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);       // g_h1 plane
-        rows_store_t<G, HID, HID>(s_gh1, H1, b0, B, wave, lane);
+        if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_gh1, H1, b0, B, wave, lane);   // weight-gradient operand plane
     }
     {   // g_y0 = NN.0^T g_h1 + g_z0 ;  g_y plane = [g_y0 | g_y1] -> Y0 (HALF rows) + ... stored as C rows in the H region
         f32x16 acc[1][PTW];
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 if (idx < HALF) GY[(HALF + idx) * PIX + pix[q]] = gy1[q][r];
             }
         }
-        rows_store_t<G, C, C>(s_gy, GY, b0, B, wave, lane);
+        if constexpr (CTX == 0) rows_store_t<G, C, C>(s_gy, GY, b0, B, wave, lane);   // weight-gradient operand plane
         // g_x = (e^{-logs} Wm)^T g_y
         f32x16 ax[Bw::RTI][PTW];
 #pragma unroll
@@ -560,7 +561,7 @@ int cf_flow_step_bwd_ctx(const float* x, const float* gz, const float* gld, cons
                          const float* sbias, float* gx, float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2,
                          float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(x && gz && gld && ws && wsb && sbias && gx && s_y0 && s_h1 && s_h2 && s_gh && s_gh2 && s_gh1 && s_gy);
+    CF_REQUIRE(x && gz && gld && ws && wsb && sbias && gx && s_gh);     // the other planes are not written in this mode
     CF_REQUIRE(x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(gz) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0);
     const float* w = (const float*)ws;

@@ -107,7 +107,7 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
         raise NotImplementedError("specialist training without contextflow (all parameters train; not built)")
     x, xbs = _hip.bview(rec["x"])
     B, C, H, W = x.shape
-    HW, HALF, HID = H * W, C // 2, 2 * C
+    HW = H * W
     dev, st, f, pp, L = x.device, _hip.stream(), _hip.f32, _hip.p, _hip.lib()
     c1, c2, c3 = m.NN[0], m.NN[2], m.NN[4]
     eye = torch.eye(C, device=dev, dtype=torch.float32)
@@ -115,12 +115,11 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
     wsb = torch.empty(L.cf_flow_step_bwd_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
     _hip.call("cf_flow_step_bwd_prepare", pp(eye), pp(zero), pp(f(c1.weight.detach())), pp(f(c2.weight.detach())),
               pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
-    new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
     gx = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
-    s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy = new(HALF), new(HID), new(HID), new(C), new(HID), new(HID), new(C)
+    s_gh = torch.empty(B, C, HW, device=dev, dtype=torch.float32)     # the only plane this mode writes (frozen weights)
     gzc = f(gz).contiguous()
-    _hip.call("cf_flow_step_bwd_ctx", pp(x), pp(gzc), pp(f(gld)), pp(rec["ws"]), pp(wsb), pp(rec["cn"]), pp(gx), pp(s_y0),
-              pp(s_h1), pp(s_h2), pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, st)
+    _hip.call("cf_flow_step_bwd_ctx", pp(x), pp(gzc), pp(f(gld)), pp(rec["ws"]), pp(wsb), pp(rec["cn"]), pp(gx), None,
+              None, None, pp(s_gh), None, None, None, B, C, H, W, xbs, st)
     gcn = _new(B, C, like=x)
     _hip.call("cf_sample_channel_sums", pp(s_gh), pp(gcn), B, C, HW, st)
     # CN = Linear -> ReLU -> Linear -> ReLU -> Linear   (coupling.py:37)

@@ -267,7 +267,8 @@ int cf_sigmoid_ldj(const float* x, float* y, float* ldj, int B, int D, cf_stream
 /* ---- specialist training (contextflow: the CN nets and the priors' embedding tables train, the generalist's own
  * parameters stay frozen - coupling.py:36, conv1x1.py:27, actnorm.py:23, gaussian.py:134) -------------------------
  * backward of cf_flow_step_fwd_ctx mode 1: as cf_flow_step_bwd, the recompute adds sbias (B,C) to the conditioner
- * output; d/d sbias[b,c] = sum_p s_gh[b,c,p] (cf_sample_channel_sums).                                          */
+ * output; d/d sbias[b,c] = sum_p s_gh[b,c,p] (cf_sample_channel_sums).  Only gx and s_gh are written: the weights
+ * are frozen in this mode, the other operand planes may be NULL.                                                 */
 int cf_flow_step_bwd_ctx(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb,
                          const float* sbias, float* gx, float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2,
                          float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, cf_stream_t stream);
