@@ -87,11 +87,13 @@ __global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm,
 // staging: one 16-byte load along the un-squeezed row = channels (4c'+2i1, +1) of squeezed pixels (x, x+1).
 // dbg (optional, tests only): dumps of y0, h1, h2, h as [rows][tiles*PIX].
 // CTX: per-sample bias of the specialist coupling (see conditioner_net); sb = (B, C) or (B, 2C) floats.
-template <class G, bool SQ, int CTX = 0>
+// DUMP (training): y0 and the post-ReLU h1 / h2 planes are also written to the tape `tp`; the backward kernel then
+// loads them instead of recomputing phases 1 and 2 (cf_step_bwd.hip, TAPED).
+template <class G, bool SQ, int CTX = 0, bool DUMP = false>
 __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
                                                    float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
                                                    int64_t xbs, float* __restrict__ dbg, int flags,
-                                                   const float* __restrict__ sb) {
+                                                   const float* __restrict__ sb, StepTape tp) {
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
     constexpr int WPX = 32 * PTW;                     // pixel columns owned by one wave
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
                 y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
             }
         z_store<G>(z, Y0, b0, 0, B, wave, lane);
+        if constexpr (DUMP) rows_store_t<G, HALF, HALF>(tp.y0, Y0, b0, B, wave, lane);
         if (dbg) {
             __syncthreads();
             for (int e = tid; e < HALF * PIX; e += 256) dbg[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = Y0[e];
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
 
         f32x16 acc3[RT03][PTW];
         if constexpr (CTX == 0) {
-            conditioner_net<G>(acc3, lds, wsl, pix, pin, lane, tid, dbg, dbg_cols, tile);
+            conditioner_net<G, 0, DUMP>(acc3, lds, wsl, pix, pin, lane, tid, dbg, dbg_cols, tile, nullptr, nullptr, tp, B);
         } else {
             int soff[PTW];
 #pragma unroll
@@ -241,21 +244,21 @@ int launch_prepare(const float* Wm, const float* t, const float* logs, const flo
     return 0;
 }
 
-template <class G, bool SQ, int CTX = 0>
+template <class G, bool SQ, int CTX = 0, bool DUMP = false>
 int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, int flags,
-                hipStream_t s, const float* sb = nullptr) {
+                hipStream_t s, const float* sb = nullptr, StepTape tp = StepTape{nullptr, nullptr, nullptr}) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G, SQ, CTX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G, SQ, CTX, DUMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024);
             if (e != hipSuccess) { cf_set_error("cf_flow_step_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
             raised = true;
         }
     }
     const int grid = (B + G::SPW - 1) / G::SPW;
-    k_flow_step<G, SQ, CTX><<<dim3(grid), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags, sb);
+    k_flow_step<G, SQ, CTX, DUMP><<<dim3(grid), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags, sb, tp);
     return 0;
 }
 
@@ -507,6 +510,34 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     const int sid = shape_id(C, H, W);
     if ((sid == 2 && B < 256 * G32::SPW) || (sid == 3 && B < 256 * G64::SPW)) flags = 2 << 16;
     return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, flags, stream);
+}
+
+// training forward: the same step, and the conditioner's intermediate planes y0 (B, C/2, H, W), h1, h2 (B, 2C, H, W;
+// post-ReLU) go to the caller's tape.  cf_flow_step_bwd_taped consumes them: it skips the recompute of the two big
+// contractions and uses the planes directly as the operands of the weight-gradient GEMMs.
+int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* t_y0, float* t_h1, float* t_h2,
+                           int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && z && ldj_acc && ws && t_y0 && t_h1 && t_h2 && x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(t_y0) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_h1) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0);
+    const float* w = (const float*)ws;
+    const StepTape tp{t_y0, t_h1, t_h2};
+    int rc = 0;
+#define CF_STEPT(G) rc = in_squeeze ? launch_step<G, true, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp) \
+                                    : launch_step<G, false, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp)
+    switch (shape_id(C, H, W)) {
+        case 0: CF_STEPT(G8); break;
+        case 1: CF_STEPT(G16); break;
+        case 2: CF_STEPT(G32); break;
+        case 3: CF_STEPT(G64); break;
+        default: cf_set_error("cf_flow_step_fwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+#undef CF_STEPT
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
 }
 
 // specialist coupling (coupling.py:39-47): the same fused step with a per-sample bias from the CN net.

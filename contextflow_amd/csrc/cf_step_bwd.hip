@@ -58,22 +58,6 @@ __global__ __launch_bounds__(256) void k_step_pack_bwd(const float* __restrict__
     }
 }
 
-// rows_store for a target tensor with CT channels per sample
-template <class G, int NROWS, int CT>
-__device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const float* __restrict__ plane, int tb0, int B,
-                                             int wave, int lane) {
-    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX;
-#pragma unroll
-    for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
-        const int n = i * 64 + lane;
-        const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
-        const int b = tb0 + col / HW;
-        if (idx < NROWS && b < B)
-            *reinterpret_cast<float4*>(dst + (int64_t)b * CT * HW + (int64_t)idx * HW + col % HW) =
-                *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
-    }
-}
-
 template <class G, int RT>
 __device__ __forceinline__ void tiles_to_plane(const f32x16 (&acc)[RT][G::PTW], float* __restrict__ plane, int nrows,
                                                const int (&pix)[G::PTW], int lk) {
@@ -159,7 +143,9 @@ __device__ __forceinline__ void adj_axis(int c, int d, int N, int (&src)[2], boo
 // sb (B, C) = CN(c); only its log-scale half matters for the recompute (t does not enter any gradient); d/d sb is the
 // per-sample row sum of the s_gh plane, taken by the caller.  The generalist's weights are frozen in that mode, so the
 // six operand planes of the weight-gradient GEMMs are not written at all (156 of 172 KB per sample at C = 16).
-template <class G, bool SQ, int CTX = 0>
+// TAPED: s_y0 / s_h1 / s_h2 are INPUTS written by the training forward (cf_flow_step_fwd_taped): h1 / h2 are loaded for
+// their ReLU masks and as the operand of phase 3, the two big contractions of the recompute (phases 1, 2) are skipped.
+template <class G, bool SQ, int CTX = 0, bool TAPED = false>
 __global__ __launch_bounds__(256) void k_flow_step_bwd(
     const float* __restrict__ x, const float* __restrict__ gz, const float* __restrict__ gld,
     const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ gx,
@@ -199,9 +185,30 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 if (idx < HALF) Y0[idx * PIX + pix[q]] = acc0[0][q][r];
                 y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
             }
-        if constexpr (CTX == 0) rows_store_t<G, HALF, HALF>(s_y0, Y0, b0, B, wave, lane);   // weight-gradient operand plane
+        if constexpr (CTX == 0 && !TAPED) rows_store_t<G, HALF, HALF>(s_y0, Y0, b0, B, wave, lane);   // weight-gradient operand plane
     }
     unsigned m1[RT1][PTW], m2[RT1][PTW];       // ReLU masks of h1 / h2, one bit per accumulator register
+    if constexpr (TAPED) {
+        // post-ReLU planes from the tape -> this wave's columns of the H region -> masks in the accumulator layout
+        auto plane_mask = [&](unsigned (&m)[RT1][PTW]) {
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) {
+                    unsigned b = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rt * 32 + tile_row(r, lk);
+                        if (row < HID) b |= (H1[row * PIX + pix[q]] > 0.f ? 1u : 0u) << r;
+                    }
+                    m[rt][q] = b;
+                }
+        };
+        rows_load_t<G, HID, HID>(s_h1, H1, b0, B, wave, lane);
+        plane_mask(m1);
+        rows_load_t<G, HID, HID>(s_h2, H1, b0, B, wave, lane);
+        plane_mask(m2);
+    } else {
     {   // phase 1
         f32x16 acc[RT1][PTW];
 #pragma unroll
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
             }
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);
         if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_h2, H1, b0, B, wave, lane);   // weight-gradient operand plane
+    }
     }
     // phase 3 -> t, raw
     float ls[PTW][NR];
@@ -477,7 +485,7 @@ int launch_prepare_bwd(const float* Wm, const float* logs, const float* w1, cons
     return 0;
 }
 
-template <class G, bool SQ, int CTX = 0>
+template <class G, bool SQ, int CTX = 0, bool TAPED = false>
 int launch_step_bwd(const float* x, const float* gz, const float* gld, const float* ws, const float* wsb, float* gx,
                     float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy, int B,
                     int64_t xbs, hipStream_t s, const float* sb = nullptr) {
@@ -485,12 +493,12 @@ int launch_step_bwd(const float* x, const float* gz, const float* gld, const flo
     if (lds_bytes > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step_bwd<G, SQ, CTX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step_bwd<G, SQ, CTX, TAPED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { cf_set_error("cf_flow_step_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
             raised = true;
         }
     }
-    k_flow_step_bwd<G, SQ, CTX><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(
+    k_flow_step_bwd<G, SQ, CTX, TAPED><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(
         x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs, sb);
     return 0;
 }
@@ -550,6 +558,37 @@ int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const vo
         default: cf_set_error("cf_flow_step_bwd: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_BWD
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of a step whose forward was cf_flow_step_fwd_taped: s_y0 / s_h1 / s_h2 are read, not written.
+int cf_flow_step_bwd_taped(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
+                           const float* t_y0, const float* t_h1, const float* t_h2, float* s_gh, float* s_gh2,
+                           float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, int in_squeeze,
+                           cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && gz && gld && ws && wsb && gx && t_y0 && t_h1 && t_h2 && s_gh && s_gh2 && s_gh1 && s_gy);
+    CF_REQUIRE(x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(gz) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(t_h1) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0);
+    const float* w = (const float*)ws;
+    const float* wb = (const float*)wsb;
+    float* y0 = const_cast<float*>(t_y0);
+    float* h1 = const_cast<float*>(t_h1);
+    float* h2 = const_cast<float*>(t_h2);
+    int rc = 0;
+#define CF_BWDT(G) rc = in_squeeze ? launch_step_bwd<G, true, 0, true>(x, gz, gld, w, wb, gx, y0, h1, h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream)) \
+                                   : launch_step_bwd<G, false, 0, true>(x, gz, gld, w, wb, gx, y0, h1, h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream))
+    switch (shape_id(C, H, W)) {
+        case 0: CF_BWDT(B8); break;
+        case 1: CF_BWDT(B16); break;
+        case 2: CF_BWDT(B32); break;
+        case 3: CF_BWDT(B64); break;
+        default: cf_set_error("cf_flow_step_bwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+#undef CF_BWDT
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;

@@ -182,18 +182,60 @@ __device__ __forceinline__ void z_store(float* __restrict__ z, const float* __re
     rows_store<G, G::HALF>(z, plane, tb0, ch0, B, wave, lane);
 }
 
+// rows_store for a target tensor with CT channels per sample, and its inverse (global -> this wave's columns of a plane)
+template <class G, int NROWS, int CT>
+__device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const float* __restrict__ plane, int tb0, int B,
+                                             int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX;
+#pragma unroll
+    for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
+        const int n = i * 64 + lane;
+        const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+        const int b = tb0 + col / HW;
+        if (idx < NROWS && b < B)
+            *reinterpret_cast<float4*>(dst + (int64_t)b * CT * HW + (int64_t)idx * HW + col % HW) =
+                *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
+    }
+}
+template <class G, int NROWS, int CT>
+__device__ __forceinline__ void rows_load_t(const float* __restrict__ src, float* __restrict__ plane, int tb0, int B,
+                                            int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX;
+#pragma unroll
+    for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
+        const int n = i * 64 + lane;
+        const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
+        const int b = tb0 + col / HW;
+        if (idx < NROWS) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b < B) v = *reinterpret_cast<const float4*>(src + (int64_t)b * CT * HW + (int64_t)idx * HW + col % HW);
+            *reinterpret_cast<float4*>(&plane[idx * PIX + col]) = v;
+        }
+    }
+}
+
+// training tape of a step (forward with DUMP writes, backward with TAPED reads): y0 (B, C/2, H, W), h1 / h2 (B, 2C, H, W),
+// the post-ReLU hidden planes of the conditioner
+struct StepTape {
+    float* y0;
+    float* h1;
+    float* h2;
+};
+
 // ---- the conditioner: phases 1-3 of a step (shared by the forward and the inverse kernel) --------------
 // In: Y0 = y0 plane (this wave's columns).  Out: acc3 = NN.4 output tiles (t rows / raw rows, packed-row
 // layout of chan_of_row).  Uses the H region of LDS for h1 / h2; two workgroup barriers.
 // CTX (specialist mode, coupling.py:39-47): 0 none; 1 per-sample bias sb[sample][C] added to the net OUTPUT
 // (h = NN(x0) + CN(c), contextflow); 2 per-sample bias sb[sample][HID] added before the first ReLU (CN(c) concatenated
 // to the net input = W[:, D:] CN(c) through the first 1x1).  soff[q] = this lane's row offset into sb.
-template <class G, int CTX = 0>
+// DUMP (training): the post-ReLU h1 / h2 planes go to the tape (16-byte stores of this wave's own columns).
+template <class G, int CTX = 0, bool DUMP = false>
 __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW], float* __restrict__ lds,
                                                 const float* __restrict__ wsl, const int (&pix)[G::PTW],
                                                 const int (&pin)[G::PTW], int lane, int tid, float* __restrict__ dbg,
                                                 int64_t dbg_cols, int tile, const float* __restrict__ sb = nullptr,
-                                                const int* soff = nullptr) {
+                                                const int* soff = nullptr, StepTape tp = StepTape{nullptr, nullptr, nullptr},
+                                                int B = 0) {
     constexpr int C = G::C, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
     float* Y0 = lds;
@@ -227,6 +269,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     const int row = rt * 32 + tile_row(r, lk);
                     if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
                 }
+        if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h1, H1, tile * G::SPW, B, tid >> 6, lane);
     }
     __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' columns
     if (dbg) {
@@ -335,6 +378,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     const int row = rt * 32 + tile_row(r, lk);
                     if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
                 }
+        if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h2, H1, tile * G::SPW, B, tid >> 6, lane);
     }
     // no barrier: phase 3 reads only this wave's own pixel columns of h2
     if (dbg) {

@@ -51,6 +51,8 @@ SIGNATURES = {
     "cf_flow_step_bwd_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_bwd_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_p]),
     "cf_flow_step_bwd": (_c_int, [_c_p] * 13 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
+    "cf_flow_step_bwd_taped": (_c_int, [_c_p] * 13 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
+    "cf_flow_step_fwd_taped": (_c_int, [_c_p] * 7 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_wgrad_ws_bytes": (_c_i64, [_c_int] * 6),
     "cf_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
     "cf_linear": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),

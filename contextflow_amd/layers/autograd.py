@@ -50,8 +50,9 @@ def gmm_backward(x, dist, prepared, g):
 
 
 # ------------------------------------------------------------------------------------------------ flow step
-def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None):
+def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
+    planes: (y0, h1, h2) written by cf_flow_step_fwd_taped, or None = recompute them from x.
     Returns (dL/dx in the layout of x, {param: grad})."""
     C, H, W = shape
     HW, HALF, HID = H * W, C // 2, 2 * C
@@ -66,9 +67,15 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None):
               pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
     new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
     gx = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
-    s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy = new(HALF), new(HID), new(HID), new(C), new(HID), new(HID), new(C)
+    s_gh, s_gh2, s_gh1, s_gy = new(C), new(HID), new(HID), new(C)
     gzc = f(gz)
-    _hip.call("cf_flow_step_bwd", pp(xv), pp(gzc), pp(f(gld)), pp(ws), pp(wsb), pp(gx), pp(s_y0), pp(s_h1), pp(s_h2),
+    if planes is None:
+        s_y0, s_h1, s_h2 = new(HALF), new(HID), new(HID)
+        entry = "cf_flow_step_bwd"
+    else:
+        s_y0, s_h1, s_h2 = planes
+        entry = "cf_flow_step_bwd_taped"
+    _hip.call(entry, pp(xv), pp(gzc), pp(f(gld)), pp(ws), pp(wsb), pp(gx), pp(s_y0), pp(s_h1), pp(s_h2),
               pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, int(squeeze), st)
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts (cf_wgrad)
     def wgrad(A, Bm, taps):
@@ -145,8 +152,8 @@ class FlowLogProb(torch.autograd.Function):
                 add(gp)
                 gz = torch.cat([gz, g2], dim=1)
             elif kind == "step":
-                _, xin, sq, conv, act, cpl, shape, ws, winv = rec
-                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv)
+                _, xin, sq, conv, act, cpl, shape, ws, winv, planes = rec
+                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes)
                 add(gp)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)

@@ -161,6 +161,17 @@ int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const vo
                      float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy,
                      int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 
+/* Taped training pair.  cf_flow_step_fwd_taped = cf_flow_step_fwd that also writes the conditioner's intermediate
+ * planes t_y0 (B, C/2, H*W), t_h1, t_h2 (B, 2C, H*W; post-ReLU, Coupling.NN of coupling.py:26-27).
+ * cf_flow_step_bwd_taped = cf_flow_step_bwd that READS those planes (masks of the two ReLUs, operand of the last 1x1)
+ * instead of recomputing the two big contractions, and leaves them in place as operands of cf_wgrad. */
+int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* t_y0, float* t_h1, float* t_h2,
+                           int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
+int cf_flow_step_bwd_taped(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
+                           const float* t_y0, const float* t_h1, const float* t_h2, float* s_gh, float* s_gh2,
+                           float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, int in_squeeze,
+                           cf_stream_t stream);
+
 /* weight gradient as a split-K MFMA GEMM over (sample, pixel):
  *   gw[t][m][n] = sum_{b,p} A[b][m][p] * Bm[b][n][src_t(p)],  t < taps (1, or 9 = 3x3 reflect-shifted pixels)
  *   gbias[m]    = sum_{b,p} A[b][m][p]                         (optional)

@@ -463,6 +463,40 @@ def test_backward_against_autograd_oracle(L, name, B):
     assert checked >= 30
 
 
+@pytest.mark.parametrize("name,B", [("mnist", 37), ("cifar10", 70)])
+def test_taped_backward_equals_recompute(L, name, B):
+    """Training forward that tapes y0 / h1 / h2 (cf_flow_step_fwd_taped) + the backward that loads them
+    (cf_flow_step_bwd_taped) against the backward that recomputes everything from the step input: same logp bit for
+    bit, same gradients (the planes hold the same values either way); ragged last tiles at every level."""
+    from tests.gpu_util import build_model, set_noise
+    from contextflow_amd.layers import flowsequential as fs
+    ops, _, M, params, fx = load_e2e(name)
+    C, H, W = fo.CONFIGS[name][0]
+    g = torch.Generator().manual_seed(33)
+    x = torch.randint(0, 256, (B, C, H, W), generator=g).float()
+    u = torch.rand(B, C, H, W, generator=g)
+    eps = [torch.randn(B, 1, H, W, generator=g)]
+    wts = torch.randn(B, M, generator=g).to(DEV)
+    out = {}
+    try:
+        for taped in (True, False):
+            fs.TAPE_PLANES = taped
+            model = build_model(name, params)
+            set_noise(model, u, eps)
+            model.train()
+            _, logp = model(x.to(DEV))
+            (logp * wts).sum().backward()
+            out[taped] = (logp.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    finally:
+        fs.TAPE_PLANES = True
+    assert torch.equal(out[True][0], out[False][0])
+    assert out[True][1].keys() == out[False][1].keys() and len(out[True][1]) >= 30
+    for k, ga in out[True][1].items():
+        gb = out[False][1][k]
+        scale = max(gb.abs().max().item(), 1e-6)
+        assert (ga - gb).abs().max().item() / scale < 1e-5, k
+
+
 # ------------------------------------------------------------------------------------------ HIP graph replay
 @pytest.mark.parametrize("name", ["mnist", "cifar10"])
 def test_graph_capture_matches_eager(L, name):

@@ -5,6 +5,10 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import contextflow_amd as cfa
+from contextflow_amd.layers import flowsequential as _fs
+
+if os.environ.get("CF_TAPE_PLANES") is not None:     # A/B: 0 = the backward recomputes the conditioner planes
+    _fs.TAPE_PLANES = os.environ["CF_TAPE_PLANES"] != "0"
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
