@@ -106,59 +106,110 @@ __global__ __launch_bounds__(256) void k_add_sample_bias(float* __restrict__ h, 
 // GaussianMixtureDistribution.log_prob with a context net (gaussian.py:142-158): per-sample additive shifts cm / cs
 // (B, 2, M, K, D) of the component means and pre-softplus scales, constant over (h, w):
 //   out[b, m] (+)= logsumexp_k [ logw[m,k] + sum_{d,p} ( -1/2 ((x - mu - cm)/sig)^2 - log sig - 1/2 log 2pi ) ],
-//   sig = softplus(sG + cs).  One workgroup per sample; x in LDS; a wave owns a (m, k) pair at a time.
-__global__ __launch_bounds__(256) void k_gmm_ctx(const float* __restrict__ x, const float* __restrict__ mG,
-                                                 const float* __restrict__ sG, const float* __restrict__ logw,
-                                                 const float* __restrict__ c, float* __restrict__ out, int M, int K,
-                                                 int D, int HW, int64_t xbs, int accumulate) {
-    extern __shared__ __align__(16) float lds[];
-    float* xs = lds;                       // [D*HW]
-    float* lp = lds + D * HW;              // [M*K]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = D * HW, MK = M * K;
-    for (int e = tid; e < N; e += 256) xs[e] = x[(int64_t)b * xbs + e];
-    __syncthreads();
-    const float* cb = c + (int64_t)b * 2 * MK * D;
-    for (int mk = wave; mk < MK; mk += 4) {
+//   sig = softplus(sG + cs).
+// Work layout (forward and backward): a workgroup owns S samples (x in LDS), so every mu / sG value fetched from L2 is
+// used S times; a wave owns whole channels - SEG = 2^k <= min(64, HW) lanes walk the pixels of one channel, 64/SEG
+// channels side by side - so the per-channel shifts are loaded once per (component, channel) and no index division
+// happens per term.  4 transcendentals per term (exp, log, rcp, log) on the hardware units: ~1e-7 relative each, far
+// below the 1e-5 bits/dim tolerance after the sum over D*HW terms.
+struct GmmCtxLanes {
+    int SEG, CPW, G, sub, pl;
+    __device__ __forceinline__ GmmCtxLanes(int D, int HW, int lane) {
+        SEG = 64;
+        while (SEG > HW) SEG >>= 1;                 // largest power of two <= min(64, HW)
+        CPW = 64 / SEG;
+        G = (D + CPW - 1) / CPW;                    // channel groups of the sample
+        sub = lane / SEG;
+        pl = lane - sub * SEG;
+    }
+};
+
+__device__ __forceinline__ float softplus_fast(float s) { return s > 20.f ? s : __logf(1.0f + __expf(s)); }   // threshold 20, as torch
+
+// log-joint lp[s][mk] of the S samples of this workgroup -> LDS (all threads must call; ends with a barrier)
+template <int S>
+__device__ __forceinline__ void gmm_ctx_logjoint(const float* __restrict__ xs, float* __restrict__ lpw, float* __restrict__ lp,
+                                                 const float* __restrict__ mG, const float* __restrict__ sG,
+                                                 const float* __restrict__ logw, const float* __restrict__ c, const int64_t (&co)[S], int MK,
+                                                 int D, int HW, int lane, int wave) {
+    const GmmCtxLanes L(D, HW, lane);
+    const int N = D * HW;
+    for (int mk = 0; mk < MK; ++mk) {
         const float* mu = mG + (int64_t)mk * N;
         const float* sg = sG + (int64_t)mk * N;
-        const float* cm = cb + (int64_t)mk * D;
-        const float* cs = cb + (int64_t)(MK + mk) * D;
-        // 4 transcendentals per term (exp, log, log, rcp) on the hardware units: ~1e-7 relative each, far below the
-        // 1e-5 bits/dim tolerance after the sum over D*HW terms; two independent chains per lane for latency
-        float acc0 = 0.f, acc1 = 0.f;
-        int e = lane;
-        for (; e + 64 < N; e += 128) {
-            const int d0 = e / HW, d1 = (e + 64) / HW;
-            const float s0 = sg[e] + cs[d0], s1 = sg[e + 64] + cs[d1];
-            const float g0 = s0 > 20.f ? s0 : __logf(1.0f + __expf(s0));      // softplus (threshold 20, as torch)
-            const float g1 = s1 > 20.f ? s1 : __logf(1.0f + __expf(s1));
-            const float r0 = (xs[e] - mu[e] - cm[d0]) * __frcp_rn(g0);
-            const float r1 = (xs[e + 64] - mu[e + 64] - cm[d1]) * __frcp_rn(g1);
-            acc0 += -0.5f * r0 * r0 - __logf(g0);
-            acc1 += -0.5f * r1 * r1 - __logf(g1);
+        float acc[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = 0.f;
+        for (int g = wave; g < L.G; g += 4) {
+            const int d = g * L.CPW + L.sub;
+            if (d < D) {
+                float cm[S], cs[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) { cm[s] = c[co[s] + mk * D + d]; cs[s] = c[co[s] + (MK + mk) * D + d]; }
+                for (int p = L.pl; p < HW; p += L.SEG) {
+                    const int e = d * HW + p;
+                    const float m = mu[e], sv = sg[e];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float sig = softplus_fast(sv + cs[s]);
+                        const float r = (xs[s * N + e] - m - cm[s]) * __frcp_rn(sig);
+                        acc[s] += -0.5f * r * r - __logf(sig);
+                    }
+                }
+            }
         }
-        for (; e < N; e += 64) {
-            const int d = e / HW;
-            const float sv = sg[e] + cs[d];
-            const float sig = sv > 20.f ? sv : __logf(1.0f + __expf(sv));
-            const float r = (xs[e] - mu[e] - cm[d]) * __frcp_rn(sig);
-            acc0 += -0.5f * r * r - __logf(sig);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float v = cf_wave_sum(acc[s]);
+            if (lane == 0) lpw[(wave * S + s) * MK + mk] = v;
         }
-        float acc = acc0 + acc1 - 0.91893853320467274178f * (float)((N - lane + 63) / 64);
-        acc = cf_wave_sum(acc);
-        if (lane == 0) lp[mk] = acc + logw[mk];
     }
     __syncthreads();
-    if (tid < M) {
-        float mx = -INFINITY;
-        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[tid * K + k]);
-        float s = 0.f;
-        for (int k = 0; k < K; ++k) s += expf(lp[tid * K + k] - mx);
-        const float v = mx + logf(s);
-        if (accumulate) out[(int64_t)b * M + tid] += v;
-        else out[(int64_t)b * M + tid] = v;
+    for (int i = threadIdx.x; i < S * MK; i += 256) {
+        const int mk = i % MK;
+        lp[i] = ((lpw[i] + lpw[S * MK + i]) + (lpw[2 * S * MK + i] + lpw[3 * S * MK + i])) - 0.91893853320467274178f * (float)N +
+                logw[mk];
     }
+    __syncthreads();
+}
+
+// lp_out (optional, (B, M*K)): the per-component log-joints, kept by the training forward for cf_gmm_ctx_bwd
+template <int S>
+__global__ __launch_bounds__(256) void k_gmm_ctx(const float* __restrict__ x, const float* __restrict__ mG,
+                                                 const float* __restrict__ sG, const float* __restrict__ logw,
+                                                 const float* __restrict__ c, float* __restrict__ out,
+                                                 float* __restrict__ lp_out, int B, int M, int K, int D, int HW,
+                                                 int64_t xbs, int accumulate) {
+    extern __shared__ __align__(16) float lds[];
+    const int N = D * HW, MK = M * K;
+    float* xs = lds;                       // [S][N]
+    float* lpw = xs + S * N;               // [4][S][MK] per-wave partial sums
+    float* lp = lpw + 4 * S * MK;          // [S][MK]
+    const int b0 = blockIdx.x * S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t co[S];                         // offsets of the samples' shift rows in c (offsets, not pointers: see cf_step_common.h)
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int b = min(b0 + s, B - 1);                       // ragged last workgroup: recompute the last sample
+        co[s] = (int64_t)b * 2 * MK * D;
+        for (int e = tid; e < N; e += 256) xs[s * N + e] = x[(int64_t)b * xbs + e];
+    }
+    __syncthreads();
+    gmm_ctx_logjoint<S>(xs, lpw, lp, mG, sG, logw, c, co, MK, D, HW, lane, wave);
+    for (int i = tid; i < S * M; i += 256) {
+        const int s = i / M, m = i - s * M;
+        if (b0 + s >= B) continue;
+        const float* l = lp + s * MK + m * K;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, l[k]);
+        float z = 0.f;
+        for (int k = 0; k < K; ++k) z += expf(l[k] - mx);
+        const float v = mx + logf(z);
+        if (accumulate) out[(int64_t)(b0 + s) * M + m] += v;
+        else out[(int64_t)(b0 + s) * M + m] = v;
+    }
+    if (lp_out)
+        for (int i = tid; i < S * MK; i += 256)
+            if (b0 + i / MK < B) lp_out[(int64_t)b0 * MK + i] = lp[i];
 }
 
 // ConditionalGaussianDistribution.sample (gaussian.py:263-270): c = [mean | log_scale] (B, 2D) from the context
@@ -292,83 +343,112 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ x, c
 //   gx[e]      = sum_mk r * (-d / sig^2)
 //   gc[0][mk][dch] = sum_hw r * d / sig^2
 //   gc[1][mk][dch] = sum_hw r * (d^2 / sig^3 - 1 / sig) * sigmoid(s)
-// One workgroup per sample; a wave owns (m,k) pairs; gx partials of the 4 waves are combined through LDS.
+// Same work layout as k_gmm_ctx: S samples per workgroup, a wave owns channels.  With the channel fixed and the
+// component loop inside, gx accumulates in registers (PIT pixels per lane and sample) and the (component, channel)
+// sums are segmented shuffle reductions over the SEG lanes of the channel.  lp_in (optional): the log-joints kept by
+// the forward; without it they are recomputed first.
+template <int S>
 __global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x, const float* __restrict__ mG,
                                                      const float* __restrict__ sG, const float* __restrict__ logw,
                                                      const float* __restrict__ c, const float* __restrict__ g,
-                                                     float* __restrict__ gx, float* __restrict__ gc, int M, int K, int D,
-                                                     int HW, int64_t xbs) {
+                                                     const float* __restrict__ lp_in, float* __restrict__ gx,
+                                                     float* __restrict__ gc, int B, int M, int K, int D, int HW,
+                                                     int64_t xbs) {
+    constexpr int PIT = 4;                 // pixels per lane and pass
     extern __shared__ __align__(16) float lds[];
-    float* xs = lds;                       // [N]
-    float* lp = xs + D * HW;               // [MK] log-joint, then responsibilities
-    float* gxs = lp + M * K;               // [4][N] per-wave partial gx
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = D * HW, MK = M * K;
-    for (int e = tid; e < N; e += 256) xs[e] = x[(int64_t)b * xbs + e];
-    for (int e = tid; e < 4 * N; e += 256) gxs[e] = 0.f;
-    __syncthreads();
-    const float* cb = c + (int64_t)b * 2 * MK * D;
-    for (int mk = wave; mk < MK; mk += 4) {
-        const float* mu = mG + (int64_t)mk * N;
-        const float* sg = sG + (int64_t)mk * N;
-        const float* cm = cb + (int64_t)mk * D;
-        const float* cs = cb + (int64_t)(MK + mk) * D;
-        float acc = 0.f;
-        for (int e = lane; e < N; e += 64) {
-            const int d = e / HW;
-            const float sv = sg[e] + cs[d];
-            const float sig = sv > 20.f ? sv : __logf(1.0f + __expf(sv));
-            const float r = (xs[e] - mu[e] - cm[d]) * __frcp_rn(sig);
-            acc += -0.5f * r * r - __logf(sig) - 0.91893853320467274178f;
-        }
-        acc = cf_wave_sum(acc);
-        if (lane == 0) lp[mk] = acc + logw[mk];
+    float* xs = lds;                       // [S][N]
+    float* lpw = xs + S * N;               // [4][S][MK]
+    float* lp = lpw + 4 * S * MK;          // [S][MK] log-joint, then responsibilities x upstream gradient
+    const int b0 = blockIdx.x * S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t co[S];
+    bool live[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int b = min(b0 + s, B - 1);
+        live[s] = b0 + s < B;
+        co[s] = (int64_t)b * 2 * MK * D;
+        for (int e = tid; e < N; e += 256) xs[s * N + e] = x[(int64_t)b * xbs + e];
     }
     __syncthreads();
-    if (tid < M) {                          // responsibilities times the upstream gradient
+    if (lp_in) {
+        for (int i = tid; i < S * MK; i += 256) lp[i] = lp_in[(int64_t)min(b0 + i / MK, B - 1) * MK + i % MK];
+        __syncthreads();
+    } else {
+        gmm_ctx_logjoint<S>(xs, lpw, lp, mG, sG, logw, c, co, MK, D, HW, lane, wave);
+    }
+    float* rr = lpw;                       // [S][MK] responsibilities (lpw is free now)
+    for (int i = tid; i < S * M; i += 256) {
+        const int s = i / M, m = i - s * M;
+        const float* l = lp + s * MK + m * K;
         float mx = -INFINITY;
-        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[tid * K + k]);
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, l[k]);
         float z = 0.f;
-        for (int k = 0; k < K; ++k) z += expf(lp[tid * K + k] - mx);
-        const float gm = g[(int64_t)b * M + tid] / z;
-        for (int k = 0; k < K; ++k) lp[tid * K + k] = expf(lp[tid * K + k] - mx) * gm;
+        for (int k = 0; k < K; ++k) z += expf(l[k] - mx);
+        const float gm = g[(int64_t)min(b0 + s, B - 1) * M + m] / z;
+        for (int k = 0; k < K; ++k) rr[s * MK + m * K + k] = expf(l[k] - mx) * gm;
     }
     __syncthreads();
-    float* gcb = gc + (int64_t)b * 2 * MK * D;
-    float* mine = gxs + wave * N;
-    for (int mk = wave; mk < MK; mk += 4) {
-        const float* mu = mG + (int64_t)mk * N;
-        const float* sg = sG + (int64_t)mk * N;
-        const float* cm = cb + (int64_t)mk * D;
-        const float* cs = cb + (int64_t)(MK + mk) * D;
-        const float r = lp[mk];
-        // the (mk, channel) sums are reductions over h*w: a wave covers SEG = min(64, HW) pixels of 64/SEG channels at
-        // a time (all 64 lanes busy also for the 4x4 prior), segmented shuffle reduction inside each channel's lanes
-        const int SEG = HW < 64 ? HW : 64, CPW = 64 / SEG;
-        const int sub = lane / SEG, pl = lane - sub * SEG;
-        for (int d0 = 0; d0 < D; d0 += CPW) {
-            const int d = d0 + sub;
-            float a0 = 0.f, a1 = 0.f;
-            if (d < D) {
-                const float cmd = cm[d], csd = cs[d];
-                for (int p = pl; p < HW; p += SEG) {
-                    const int e = d * HW + p;
-                    const float sv = sg[e] + csd;
-                    const float sig = sv > 20.f ? sv : __logf(1.0f + __expf(sv));
-                    const float inv = __frcp_rn(sig), dd = xs[e] - mu[e] - cmd;
-                    const float q = dd * inv * inv;                       // d / sig^2
-                    const float dsig = sv > 20.f ? 1.f : __frcp_rn(1.0f + __expf(-sv));   // softplus'
-                    mine[e] -= r * q;
-                    a0 += q;
-                    a1 += (dd * q * inv - inv) * dsig;
+    const GmmCtxLanes L(D, HW, lane);
+    for (int gi = wave; gi < L.G; gi += 4) {
+        const int d = gi * L.CPW + L.sub;
+        const bool dok = d < D;
+        for (int p0 = 0; p0 < HW; p0 += PIT * L.SEG) {          // one pass unless HW > 4 SEG
+            float gxa[S][PIT];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) gxa[s][it] = 0.f;
+            for (int mk = 0; mk < MK; ++mk) {
+                const float* mu = mG + (int64_t)mk * N;
+                const float* sg = sG + (int64_t)mk * N;
+                float cm[S], cs[S], a0[S], a1[S], r[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    r[s] = rr[s * MK + mk];
+                    cm[s] = dok ? c[co[s] + mk * D + d] : 0.f;
+                    cs[s] = dok ? c[co[s] + (MK + mk) * D + d] : 0.f;
+                    a0[s] = 0.f;
+                    a1[s] = 0.f;
+                }
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) {
+                    const int p = p0 + it * L.SEG + L.pl;
+                    if (dok && p < HW) {
+                        const int e = d * HW + p;
+                        const float m = mu[e], sv = sg[e];
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const float t = sv + cs[s];
+                            const float sig = softplus_fast(t);
+                            const float inv = __frcp_rn(sig), dd = xs[s * N + e] - m - cm[s];
+                            const float q = dd * inv * inv;                                  // d / sig^2
+                            const float dsig = t > 20.f ? 1.f : __frcp_rn(1.0f + __expf(-t));   // softplus'
+                            gxa[s][it] = fmaf(-r[s], q, gxa[s][it]);
+                            a0[s] += q;
+                            a1[s] += (dd * q * inv - inv) * dsig;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    for (int o = L.SEG >> 1; o > 0; o >>= 1) { a0[s] += __shfl_xor(a0[s], o, 64); a1[s] += __shfl_xor(a1[s], o, 64); }
+                    if (L.pl == 0 && dok && live[s]) {
+                        float* gcb = gc + co[s];
+                        if (p0 == 0) { gcb[mk * D + d] = r[s] * a0[s]; gcb[(MK + mk) * D + d] = r[s] * a1[s]; }
+                        else { gcb[mk * D + d] += r[s] * a0[s]; gcb[(MK + mk) * D + d] += r[s] * a1[s]; }
+                    }
                 }
             }
-            for (int o = SEG >> 1; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
-            if (pl == 0 && d < D) { gcb[(int64_t)mk * D + d] = r * a0; gcb[(int64_t)(MK + mk) * D + d] = r * a1; }
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int it = 0; it < PIT; ++it) {
+                    const int p = p0 + it * L.SEG + L.pl;
+                    if (dok && p < HW && live[s]) gx[(int64_t)(b0 + s) * N + d * HW + p] = gxa[s][it];
+                }
         }
     }
-    __syncthreads();
-    for (int e = tid; e < N; e += 256) gx[(int64_t)b * N + e] = (gxs[e] + gxs[N + e]) + (gxs[2 * N + e] + gxs[3 * N + e]);
 }
 
 // h[b, c2, p] += x[b, c2 % C, p]   (the identity branch of MaskedResidualBlock2d: x repeated along channels,
@@ -428,13 +508,35 @@ int cf_add_sample_bias(float* h, const float* bias, int B, int C, int HW, int re
     return 0;
 }
 
+// samples per workgroup of the context-GMM kernels: as many as fit (x of S samples + the log-joint scratch in LDS)
+static int gmm_ctx_group(int N, int MK, size_t* lds) {
+    for (int S = 4; S >= 1; S >>= 1) {
+        *lds = (size_t)(S * N + 5 * S * MK) * sizeof(float);
+        if (*lds <= 64 * 1024) return S;
+    }
+    return *lds <= 160 * 1024 ? 1 : 0;
+}
+
 int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const float* logw, const float* c, float* out,
-                       int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate, cf_stream_t stream) {
+                       float* lp_out, int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate,
+                       cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(x && mG && sG && logw && c && out && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0 && M <= 256);
-    const size_t lds = (size_t)(D * HW + M * K) * sizeof(float);
-    if (lds > 64 * 1024) { cf_set_error("cf_gmm_ctx_logprob: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
-    k_gmm_ctx<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, M, K, D, HW, x_bstride, accumulate);
+    CF_REQUIRE(x && mG && sG && logw && c && out && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
+    size_t lds;
+    const int S = gmm_ctx_group(D * HW, M * K, &lds);
+    if (S == 0) { cf_set_error("cf_gmm_ctx_logprob: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("cf_gmm_ctx_logprob: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
+    const dim3 grid((B + S - 1) / S);
+    if (S == 4) k_gmm_ctx<4><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, x_bstride, accumulate);
+    else if (S == 2) k_gmm_ctx<2><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, x_bstride, accumulate);
+    else k_gmm_ctx<1><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, x_bstride, accumulate);
     CF_LAUNCH_CHECK();
     return 0;
 }
@@ -498,20 +600,25 @@ int cf_relu_bwd(const float* x, const float* gy, float* out, int64_t n, cf_strea
 }
 
 int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float* logw, const float* c, const float* g,
-                   float* gx, float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride, cf_stream_t stream) {
+                   const float* lp, float* gx, float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride,
+                   cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(x && mG && sG && logw && c && g && gx && gc && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0 && M <= 256);
-    const size_t lds = (size_t)(5 * D * HW + M * K) * sizeof(float);
-    if (lds > 160 * 1024) { cf_set_error("cf_gmm_ctx_bwd: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
+    CF_REQUIRE(x && mG && sG && logw && c && g && gx && gc && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
+    size_t lds;
+    const int S = gmm_ctx_group(D * HW, M * K, &lds);
+    if (S == 0) { cf_set_error("cf_gmm_ctx_bwd: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { cf_set_error("cf_gmm_ctx_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
             raised = true;
         }
     }
-    k_gmm_ctx_bwd<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, gx, gc, M, K, D, HW, x_bstride);
+    const dim3 grid((B + S - 1) / S);
+    if (S == 4) k_gmm_ctx_bwd<4><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride);
+    else if (S == 2) k_gmm_ctx_bwd<2><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride);
+    else k_gmm_ctx_bwd<1><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -79,7 +79,7 @@ SIGNATURES = {
     "cf_actnorm_ctx_bwd": (_c_int, [_c_p] * 8 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
     "cf_sample_channel_sums": (_c_int, [_c_p] * 2 + [_c_int] * 3 + [_c_p]),
     "cf_relu_bwd": (_c_int, [_c_p] * 3 + [_c_i64, _c_p]),
-    "cf_gmm_ctx_bwd": (_c_int, [_c_p] * 8 + [_c_int] * 5 + [_c_i64, _c_p]),
+    "cf_gmm_ctx_bwd": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_i64, _c_p]),
     "cf_add_repeat": (_c_int, [_c_p] * 2 + [_c_int] * 4 + [_c_p]),
     "cf_cond_gauss_sample": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_p]),
     "cf_sigmoid_ldj": (_c_int, [_c_p] * 3 + [_c_int, _c_int, _c_p]),
@@ -87,7 +87,7 @@ SIGNATURES = {
     "cf_conv1x1_ctx": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
     "cf_actnorm_ctx": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_i64, _c_p]),
     "cf_add_sample_bias": (_c_int, [_c_p] * 2 + [_c_int] * 4 + [_c_p]),
-    "cf_gmm_ctx_logprob": (_c_int, [_c_p] * 6 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
+    "cf_gmm_ctx_logprob": (_c_int, [_c_p] * 7 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
     "cf_logdet_combine": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     "cf_nll_sum": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_p]),
 }

@@ -138,7 +138,7 @@ def gmm_ctx_backward(dist, rec, g, grads):
     gx = _new(B, D, H, W, like=x)
     gc = _new(B, 2 * M * K * D, like=x)
     _hip.call("cf_gmm_ctx_bwd", _hip.p(x), _hip.p(_hip.f32(dist.mG.detach())), _hip.p(_hip.f32(dist.sG.detach())),
-              _hip.p(rec["logw"]), _hip.p(rec["c"]), _hip.p(_hip.f32(g)), _hip.p(gx), _hip.p(gc), B, M, K, D, H * W, xbs,
+              _hip.p(rec["logw"]), _hip.p(rec["c"]), _hip.p(_hip.f32(g)), _hip.p(rec.get("lp")), _hip.p(gx), _hip.p(gc), B, M, K, D, H * W, xbs,
               _hip.stream())
     _embedding_grads(dist.context_net[0], rec["context"], gc, grads)
     return gx

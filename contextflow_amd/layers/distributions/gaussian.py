@@ -107,10 +107,12 @@ class GaussianMixtureDistribution(nn.Module):
         M, K = self.M, self.K
         logw = torch.log_softmax(_hip.f32(self.wG.detach()), dim=-1).contiguous()
         out = torch.empty(B, M, device=x.device, dtype=torch.float32)
+        # training: keep the per-component log-joints for the backward (it then skips their recompute)
+        lp = torch.empty(B, M * K, device=x.device, dtype=torch.float32) if tape is not None else None
         _hip.call("cf_gmm_ctx_logprob", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(_hip.f32(self.sG.detach())),
-                  _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(out), B, M, K, D, H * W, xbs, 0, _hip.stream())
+                  _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(out), _hip.p(lp), B, M, K, D, H * W, xbs, 0, _hip.stream())
         if tape is not None:
-            tape.append(dict(x=x, c=_hip.f32(c), logw=logw, context=context))
+            tape.append(dict(x=x, c=_hip.f32(c), logw=logw, context=context, lp=lp))
         return out + (logp_c * float(H * W)).unsqueeze(-1)
 
     def log_prob(self, input, context=None):

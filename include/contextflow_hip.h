@@ -265,9 +265,11 @@ int cf_actnorm_ctx(const float* x, const float* m, const float* t, const float* 
 /* h[b,c,:] = act(h[b,c,:] + bias[b,c]) in place (the CN(c) term of the coupling net, coupling.py:44-47)        */
 int cf_add_sample_bias(float* h, const float* bias, int B, int C, int HW, int relu, cf_stream_t stream);
 /* GMM log_prob with per-sample shifts c (B,2,M,K,D) of means / pre-softplus scales (gaussian.py:142-158);
- * mG, sG (M,K,D,HW) raw parameters, logw = log_softmax(wG); out (B,M) assigned or accumulated.                  */
+ * mG, sG (M,K,D,HW) raw parameters, logw = log_softmax(wG); out (B,M) assigned or accumulated.
+ * lp_out (optional, (B, M*K)): the per-component log-joints, for cf_gmm_ctx_bwd of the same forward.            */
 int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const float* logw, const float* c, float* out,
-                       int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate, cf_stream_t stream);
+                       float* lp_out, int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate,
+                       cf_stream_t stream);
 
 /* pieces of the variational context encoder (model.py:52-79, dequantize.py:104-118):
  * ConditionalGaussianDistribution.sample (gaussian.py:263-270): c (B,2D) = [mean|log_scale], eps (B,D) ->
@@ -292,9 +294,11 @@ int cf_actnorm_ctx_bwd(const float* x, const float* m, const float* t, const flo
 /* out[b,c] = sum_p a[b,c,p] ; out = gy * (x > 0)                                                               */
 int cf_sample_channel_sums(const float* a, float* out, int B, int C, int HW, cf_stream_t stream);
 int cf_relu_bwd(const float* x, const float* gy, float* out, int64_t n, cf_stream_t stream);
-/* context-shifted GMM, backward w.r.t. x (B,D,HW) and the per-sample shifts c (B,2,M,K,D); g (B,M) upstream      */
+/* context-shifted GMM, backward w.r.t. x (B,D,HW) and the per-sample shifts c (B,2,M,K,D); g (B,M) upstream;
+ * lp (optional, (B, M*K)): lp_out of the forward - NULL = the log-joints are recomputed.                         */
 int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float* logw, const float* c, const float* g,
-                   float* gx, float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride, cf_stream_t stream);
+                   const float* lp, float* gx, float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride,
+                   cf_stream_t stream);
 
 /* h[b,c2,:] += x[b, c2 % C, :] in place: identity branch of MaskedResidualBlock2d (`--coupling maf`,
  * layers/autoregressive/masked_conv_2d.py:93-98)                                                                */

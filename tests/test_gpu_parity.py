@@ -497,6 +497,47 @@ def test_taped_backward_equals_recompute(L, name, B):
         assert (ga - gb).abs().max().item() / scale < 1e-5, k
 
 
+@pytest.mark.parametrize("D,H,W,M,K,B", [(8, 16, 16, 10, 5, 7), (16, 8, 8, 10, 5, 9), (64, 4, 4, 10, 5, 6), (8, 7, 7, 3, 2, 5),
+                                           (4, 14, 14, 2, 3, 3), (2, 40, 32, 2, 2, 5), (3, 1, 1, 4, 1, 2)])
+def test_gmm_ctx_kernels_against_torch(L, D, H, W, M, K, B):
+    """cf_gmm_ctx_logprob / cf_gmm_ctx_bwd (several samples per workgroup, channels per wave) against the formula of
+    gaussian.py:142-158 in fp64 with torch.autograd: non power-of-two h*w (49, 196), h*w above one register pass
+    (1280), a single pixel, batches that leave a ragged last workgroup; with and without the kept log-joints."""
+    from contextflow_amd.layers import _hip
+    g = torch.Generator().manual_seed(D * 100 + H)
+    HW, MK = H * W, M * K
+    x = torch.randn(B, D, H, W, generator=g)
+    mG, sG = 0.5 * torch.randn(M, K, D, H, W, generator=g), 0.5 * torch.randn(M, K, D, H, W, generator=g) + 0.5
+    logw = torch.log_softmax(torch.randn(M, K, generator=g), -1)
+    c = 0.3 * torch.randn(B, 2, M, K, D, generator=g)
+    gout = torch.randn(B, M, generator=g)
+    # fp64 reference
+    xr, cr = x.double().requires_grad_(True), c.double().requires_grad_(True)
+    mu = mG.double().unsqueeze(0) + cr[:, 0].reshape(B, M, K, D, 1, 1)
+    sig = torch.nn.functional.softplus(sG.double().unsqueeze(0) + cr[:, 1].reshape(B, M, K, D, 1, 1))
+    lpr = (-0.5 * ((xr.reshape(B, 1, 1, D, H, W) - mu) / sig) ** 2 - torch.log(sig) - 0.5 * math.log(2 * math.pi)).flatten(3).sum(-1) + logw.double()
+    ref = torch.logsumexp(lpr, -1)
+    (ref * gout.double()).sum().backward()
+    d = lambda t: t.contiguous().to(DEV)
+    xd, md, sd, ld, cd, gd = d(x), d(mG), d(sG), d(logw), d(c), d(gout)
+    out = torch.full((B, M), 2.0, device=DEV)
+    lp = torch.empty(B, MK, device=DEV)
+    st = _hip.stream()
+    _hip.call("cf_gmm_ctx_logprob", _hip.p(xd), _hip.p(md), _hip.p(sd), _hip.p(ld), _hip.p(cd), _hip.p(out), _hip.p(lp),
+              B, M, K, D, HW, D * HW, 1, st)
+    scale = ref.abs().max().item()
+    assert ((out.cpu().double() - 2.0) - ref.detach()).abs().max().item() < 2e-6 * scale + 1e-4
+    assert (lp.cpu().double() - lpr.detach().reshape(B, MK)).abs().max().item() < 2e-6 * scale + 1e-4
+    for kept in (lp, None):
+        gx = torch.full((B, D, H, W), float("nan"), device=DEV)
+        gc = torch.full((B, 2 * MK * D), float("nan"), device=DEV)
+        _hip.call("cf_gmm_ctx_bwd", _hip.p(xd), _hip.p(md), _hip.p(sd), _hip.p(ld), _hip.p(cd), _hip.p(gd), _hip.p(kept),
+                  _hip.p(gx), _hip.p(gc), B, M, K, D, HW, D * HW, st)
+        for got, want in ((gx.cpu().double(), xr.grad), (gc.cpu().double().view_as(cr.grad), cr.grad)):
+            assert torch.isfinite(got).all()
+            assert (got - want).abs().max().item() < 1e-4 * max(want.abs().max().item(), 1e-3)
+
+
 # ------------------------------------------------------------------------------------------ HIP graph replay
 @pytest.mark.parametrize("name", ["mnist", "cifar10"])
 def test_graph_capture_matches_eager(L, name):
