@@ -127,10 +127,20 @@ struct GmmCtxLanes {
 __device__ __forceinline__ float softplus_fast(float s) { return s > 20.f ? s : __logf(1.0f + __expf(s)); }   // threshold 20, as torch
 
 // log-joint lp[s][mk] of the S samples of this workgroup -> LDS (all threads must call; ends with a barrier)
-template <int S>
+// TAB: the scale shifts take few distinct values (embedding lookups, model.py:157,162): 1/sig and sum log sig come from
+// tables indexed by the sample's key (cf_gmm_ctx_tables) - no transcendental left in the term loop.
+struct GmmTab {
+    const float* inv;      // (U, MK, N)  1 / softplus(sG + cs_u)
+    const float* dsig;     // (U, MK, N)  softplus'(sG + cs_u)    (backward only)
+    const float* lsum;     // (U, MK)     sum_e log softplus(sG + cs_u)
+    const int* key;        // (B)         u of every sample
+};
+
+template <int S, bool TAB>
 __device__ __forceinline__ void gmm_ctx_logjoint(const float* __restrict__ xs, float* __restrict__ lpw, float* __restrict__ lp,
                                                  const float* __restrict__ mG, const float* __restrict__ sG,
-                                                 const float* __restrict__ logw, const float* __restrict__ c, const int64_t (&co)[S], int MK,
+                                                 const float* __restrict__ logw, const float* __restrict__ c, const int64_t (&co)[S],
+                                                 const GmmTab& tb, const int64_t (&io)[S], int b0, int B, int MK,
                                                  int D, int HW, int lane, int wave) {
     const GmmCtxLanes L(D, HW, lane);
     const int N = D * HW;
@@ -148,12 +158,21 @@ __device__ __forceinline__ void gmm_ctx_logjoint(const float* __restrict__ xs, f
                 for (int s = 0; s < S; ++s) { cm[s] = c[co[s] + mk * D + d]; cs[s] = c[co[s] + (MK + mk) * D + d]; }
                 for (int p = L.pl; p < HW; p += L.SEG) {
                     const int e = d * HW + p;
-                    const float m = mu[e], sv = sg[e];
+                    if constexpr (TAB) {
+                        const float m = mu[e];
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const float sig = softplus_fast(sv + cs[s]);
-                        const float r = (xs[s * N + e] - m - cm[s]) * __frcp_rn(sig);
-                        acc[s] += -0.5f * r * r - __logf(sig);
+                        for (int s = 0; s < S; ++s) {
+                            const float r = (xs[s * N + e] - m - cm[s]) * tb.inv[io[s] + (int64_t)mk * N + e];
+                            acc[s] = fmaf(-0.5f * r, r, acc[s]);
+                        }
+                    } else {
+                        const float m = mu[e], sv = sg[e];
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            const float sig = softplus_fast(sv + cs[s]);
+                            const float r = (xs[s * N + e] - m - cm[s]) * __frcp_rn(sig);
+                            acc[s] += -0.5f * r * r - __logf(sig);
+                        }
                     }
                 }
             }
@@ -167,34 +186,60 @@ __device__ __forceinline__ void gmm_ctx_logjoint(const float* __restrict__ xs, f
     __syncthreads();
     for (int i = threadIdx.x; i < S * MK; i += 256) {
         const int mk = i % MK;
-        lp[i] = ((lpw[i] + lpw[S * MK + i]) + (lpw[2 * S * MK + i] + lpw[3 * S * MK + i])) - 0.91893853320467274178f * (float)N +
-                logw[mk];
+        float v = ((lpw[i] + lpw[S * MK + i]) + (lpw[2 * S * MK + i] + lpw[3 * S * MK + i])) - 0.91893853320467274178f * (float)N +
+                  logw[mk];
+        if constexpr (TAB) v -= tb.lsum[(int64_t)tb.key[min(b0 + i / MK, B - 1)] * MK + mk];
+        lp[i] = v;
     }
     __syncthreads();
 }
 
+// tables of GmmTab: one workgroup per (u, mk) row
+__global__ __launch_bounds__(256) void k_gmm_ctx_tables(const float* __restrict__ sG, const float* __restrict__ cst,
+                                                        float* __restrict__ inv, float* __restrict__ dsig,
+                                                        float* __restrict__ lsum, int MK, int D, int HW) {
+    __shared__ float part[4];
+    const int u = blockIdx.x / MK, mk = blockIdx.x - u * MK, N = D * HW, tid = threadIdx.x;
+    const float* sg = sG + (int64_t)mk * N;
+    const float* cs = cst + ((int64_t)u * MK + mk) * D;
+    const int64_t o = ((int64_t)u * MK + mk) * N;
+    float acc = 0.f;
+    for (int e = tid; e < N; e += 256) {
+        const float t = sg[e] + cs[e / HW];
+        const float sig = softplus_fast(t);
+        inv[o + e] = __frcp_rn(sig);
+        if (dsig) dsig[o + e] = t > 20.f ? 1.f : __frcp_rn(1.0f + __expf(-t));
+        acc += __logf(sig);
+    }
+    acc = cf_wave_sum(acc);
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) lsum[(int64_t)u * MK + mk] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // lp_out (optional, (B, M*K)): the per-component log-joints, kept by the training forward for cf_gmm_ctx_bwd
-template <int S>
+template <int S, bool TAB>
 __global__ __launch_bounds__(256) void k_gmm_ctx(const float* __restrict__ x, const float* __restrict__ mG,
                                                  const float* __restrict__ sG, const float* __restrict__ logw,
                                                  const float* __restrict__ c, float* __restrict__ out,
                                                  float* __restrict__ lp_out, int B, int M, int K, int D, int HW,
-                                                 int64_t xbs, int accumulate) {
+                                                 int64_t xbs, int accumulate, GmmTab tb) {
     extern __shared__ __align__(16) float lds[];
     const int N = D * HW, MK = M * K;
     float* xs = lds;                       // [S][N]
     float* lpw = xs + S * N;               // [4][S][MK] per-wave partial sums
     float* lp = lpw + 4 * S * MK;          // [S][MK]
     const int b0 = blockIdx.x * S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int64_t co[S];                         // offsets of the samples' shift rows in c (offsets, not pointers: see cf_step_common.h)
+    int64_t co[S], io[S];                  // offsets of the samples' shift rows in c (offsets, not pointers: see cf_step_common.h)
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int b = min(b0 + s, B - 1);                       // ragged last workgroup: recompute the last sample
         co[s] = (int64_t)b * 2 * MK * D;
+        io[s] = TAB ? (int64_t)tb.key[b] * MK * N : 0;
         for (int e = tid; e < N; e += 256) xs[s * N + e] = x[(int64_t)b * xbs + e];
     }
     __syncthreads();
-    gmm_ctx_logjoint<S>(xs, lpw, lp, mG, sG, logw, c, co, MK, D, HW, lane, wave);
+    gmm_ctx_logjoint<S, TAB>(xs, lpw, lp, mG, sG, logw, c, co, tb, io, b0, B, MK, D, HW, lane, wave);
     for (int i = tid; i < S * M; i += 256) {
         const int s = i / M, m = i - s * M;
         if (b0 + s >= B) continue;
@@ -347,13 +392,13 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ x, c
 // component loop inside, gx accumulates in registers (PIT pixels per lane and sample) and the (component, channel)
 // sums are segmented shuffle reductions over the SEG lanes of the channel.  lp_in (optional): the log-joints kept by
 // the forward; without it they are recomputed first.
-template <int S>
+template <int S, bool TAB>
 __global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x, const float* __restrict__ mG,
                                                      const float* __restrict__ sG, const float* __restrict__ logw,
                                                      const float* __restrict__ c, const float* __restrict__ g,
                                                      const float* __restrict__ lp_in, float* __restrict__ gx,
                                                      float* __restrict__ gc, int B, int M, int K, int D, int HW,
-                                                     int64_t xbs) {
+                                                     int64_t xbs, GmmTab tb) {
     constexpr int PIT = 4;                 // pixels per lane and pass
     extern __shared__ __align__(16) float lds[];
     const int N = D * HW, MK = M * K;
@@ -361,13 +406,14 @@ __global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x
     float* lpw = xs + S * N;               // [4][S][MK]
     float* lp = lpw + 4 * S * MK;          // [S][MK] log-joint, then responsibilities x upstream gradient
     const int b0 = blockIdx.x * S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int64_t co[S];
+    int64_t co[S], io[S];
     bool live[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int b = min(b0 + s, B - 1);
         live[s] = b0 + s < B;
         co[s] = (int64_t)b * 2 * MK * D;
+        io[s] = TAB ? (int64_t)tb.key[b] * MK * N : 0;
         for (int e = tid; e < N; e += 256) xs[s * N + e] = x[(int64_t)b * xbs + e];
     }
     __syncthreads();
@@ -375,7 +421,7 @@ __global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x
         for (int i = tid; i < S * MK; i += 256) lp[i] = lp_in[(int64_t)min(b0 + i / MK, B - 1) * MK + i % MK];
         __syncthreads();
     } else {
-        gmm_ctx_logjoint<S>(xs, lpw, lp, mG, sG, logw, c, co, MK, D, HW, lane, wave);
+        gmm_ctx_logjoint<S, TAB>(xs, lpw, lp, mG, sG, logw, c, co, tb, io, b0, B, MK, D, HW, lane, wave);
     }
     float* rr = lpw;                       // [S][MK] responsibilities (lpw is free now)
     for (int i = tid; i < S * M; i += 256) {
@@ -416,14 +462,22 @@ __global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x
                     const int p = p0 + it * L.SEG + L.pl;
                     if (dok && p < HW) {
                         const int e = d * HW + p;
-                        const float m = mu[e], sv = sg[e];
+                        const float m = mu[e];
+                        float sv = 0.f;
+                        if constexpr (!TAB) sv = sg[e];
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
-                            const float t = sv + cs[s];
-                            const float sig = softplus_fast(t);
-                            const float inv = __frcp_rn(sig), dd = xs[s * N + e] - m - cm[s];
+                            float inv, dsig;
+                            if constexpr (TAB) {
+                                inv = tb.inv[io[s] + (int64_t)mk * N + e];
+                                dsig = tb.dsig[io[s] + (int64_t)mk * N + e];
+                            } else {
+                                const float t = sv + cs[s];
+                                inv = __frcp_rn(softplus_fast(t));
+                                dsig = t > 20.f ? 1.f : __frcp_rn(1.0f + __expf(-t));           // softplus'
+                            }
+                            const float dd = xs[s * N + e] - m - cm[s];
                             const float q = dd * inv * inv;                                  // d / sig^2
-                            const float dsig = t > 20.f ? 1.f : __frcp_rn(1.0f + __expf(-t));   // softplus'
                             gxa[s][it] = fmaf(-r[s], q, gxa[s][it]);
                             a0[s] += q;
                             a1[s] += (dd * q * inv - inv) * dsig;
@@ -460,6 +514,59 @@ __global__ __launch_bounds__(256) void k_add_repeat(float* __restrict__ h, const
         const int r = (int)(e - b * (int64_t)C2 * HW), c2 = r / HW, p = r - c2 * HW;
         h[e] += x[(b * C + (c2 % C)) * HW + p];
     }
+}
+
+// samples per workgroup of the context-GMM kernels: as many as fit (x of S samples + the log-joint scratch in LDS)
+static int gmm_ctx_group(int N, int MK, size_t* lds) {
+    for (int S = 4; S >= 1; S >>= 1) {
+        *lds = (size_t)(S * N + 5 * S * MK) * sizeof(float);
+        if (*lds <= 64 * 1024) return S;
+    }
+    return *lds <= 160 * 1024 ? 1 : 0;
+}
+
+template <bool TAB>
+static int gmm_ctx_fwd_launch(const char* who, const float* x, const float* mG, const float* sG, const float* logw, const float* c,
+                              float* out, float* lp_out, int B, int M, int K, int D, int HW, int64_t xbs, int accumulate,
+                              GmmTab tb, hipStream_t st) {
+    size_t lds;
+    const int S = gmm_ctx_group(D * HW, M * K, &lds);
+    if (S == 0) { cf_set_error("%s: D*HW=%d needs %zu B of LDS", who, D * HW, lds); return CF_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx<1, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("%s: cannot raise dynamic LDS: %s", who, hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
+    const dim3 grid((B + S - 1) / S);
+    if (S == 4) k_gmm_ctx<4, TAB><<<grid, dim3(256), lds, st>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, xbs, accumulate, tb);
+    else if (S == 2) k_gmm_ctx<2, TAB><<<grid, dim3(256), lds, st>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, xbs, accumulate, tb);
+    else k_gmm_ctx<1, TAB><<<grid, dim3(256), lds, st>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, xbs, accumulate, tb);
+    return 0;
+}
+
+template <bool TAB>
+static int gmm_ctx_bwd_launch(const char* who, const float* x, const float* mG, const float* sG, const float* logw, const float* c,
+                              const float* g, const float* lp, float* gx, float* gc, int B, int M, int K, int D, int HW,
+                              int64_t xbs, GmmTab tb, hipStream_t st) {
+    size_t lds;
+    const int S = gmm_ctx_group(D * HW, M * K, &lds);
+    if (S == 0) { cf_set_error("%s: D*HW=%d needs %zu B of LDS", who, D * HW, lds); return CF_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx_bwd<1, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("%s: cannot raise dynamic LDS: %s", who, hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
+    const dim3 grid((B + S - 1) / S);
+    if (S == 4) k_gmm_ctx_bwd<4, TAB><<<grid, dim3(256), lds, st>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, xbs, tb);
+    else if (S == 2) k_gmm_ctx_bwd<2, TAB><<<grid, dim3(256), lds, st>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, xbs, tb);
+    else k_gmm_ctx_bwd<1, TAB><<<grid, dim3(256), lds, st>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, xbs, tb);
+    return 0;
 }
 
 }  // namespace
@@ -508,35 +615,35 @@ int cf_add_sample_bias(float* h, const float* bias, int B, int C, int HW, int re
     return 0;
 }
 
-// samples per workgroup of the context-GMM kernels: as many as fit (x of S samples + the log-joint scratch in LDS)
-static int gmm_ctx_group(int N, int MK, size_t* lds) {
-    for (int S = 4; S >= 1; S >>= 1) {
-        *lds = (size_t)(S * N + 5 * S * MK) * sizeof(float);
-        if (*lds <= 64 * 1024) return S;
-    }
-    return *lds <= 160 * 1024 ? 1 : 0;
-}
-
 int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const float* logw, const float* c, float* out,
                        float* lp_out, int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate,
                        cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && mG && sG && logw && c && out && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
-    size_t lds;
-    const int S = gmm_ctx_group(D * HW, M * K, &lds);
-    if (S == 0) { cf_set_error("cf_gmm_ctx_logprob: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
-    if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_gmm_ctx_logprob: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
-    }
-    const dim3 grid((B + S - 1) / S);
-    if (S == 4) k_gmm_ctx<4><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, x_bstride, accumulate);
-    else if (S == 2) k_gmm_ctx<2><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, x_bstride, accumulate);
-    else k_gmm_ctx<1><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, x_bstride, accumulate);
+    int rc = gmm_ctx_fwd_launch<false>("cf_gmm_ctx_logprob", x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, x_bstride, accumulate,
+                                       GmmTab{nullptr, nullptr, nullptr, nullptr}, cf_s(stream));
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_ctx_tables(const float* sG, const float* cs_tab, float* inv_sig, float* dsig, float* lsum, int U, int MK, int D,
+                      int HW, cf_stream_t stream) {
+    if (U == 0) return 0;
+    CF_REQUIRE(sG && cs_tab && inv_sig && lsum && U > 0 && MK > 0 && D > 0 && HW > 0);
+    k_gmm_ctx_tables<<<dim3(U * MK), dim3(256), 0, cf_s(stream)>>>(sG, cs_tab, inv_sig, dsig, lsum, MK, D, HW);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_ctx_logprob_tab(const float* x, const float* mG, const float* inv_sig, const float* lsum, const float* logw,
+                           const float* c, const int* key, float* out, float* lp_out, int B, int M, int K, int D, int HW,
+                           int64_t x_bstride, int accumulate, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && mG && inv_sig && lsum && logw && c && key && out && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
+    int rc = gmm_ctx_fwd_launch<true>("cf_gmm_ctx_logprob_tab", x, mG, nullptr, logw, c, out, lp_out, B, M, K, D, HW, x_bstride,
+                                      accumulate, GmmTab{inv_sig, nullptr, lsum, key}, cf_s(stream));
+    if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
 }
@@ -604,21 +711,21 @@ int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float
                    cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && mG && sG && logw && c && g && gx && gc && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
-    size_t lds;
-    const int S = gmm_ctx_group(D * HW, M * K, &lds);
-    if (S == 0) { cf_set_error("cf_gmm_ctx_bwd: D*HW=%d needs %zu B of LDS", D * HW, lds); return CF_ERR_UNSUPPORTED; }
-    if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_gmm_ctx_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
-    }
-    const dim3 grid((B + S - 1) / S);
-    if (S == 4) k_gmm_ctx_bwd<4><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride);
-    else if (S == 2) k_gmm_ctx_bwd<2><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride);
-    else k_gmm_ctx_bwd<1><<<grid, dim3(256), lds, cf_s(stream)>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride);
+    int rc = gmm_ctx_bwd_launch<false>("cf_gmm_ctx_bwd", x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride,
+                                       GmmTab{nullptr, nullptr, nullptr, nullptr}, cf_s(stream));
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_ctx_bwd_tab(const float* x, const float* mG, const float* inv_sig, const float* dsig, const float* lsum,
+                       const float* logw, const float* c, const int* key, const float* g, const float* lp, float* gx,
+                       float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && mG && inv_sig && dsig && lsum && logw && c && key && g && gx && gc && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
+    int rc = gmm_ctx_bwd_launch<true>("cf_gmm_ctx_bwd_tab", x, mG, nullptr, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride,
+                                      GmmTab{inv_sig, dsig, lsum, key}, cf_s(stream));
+    if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
 }

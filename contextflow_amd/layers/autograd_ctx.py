@@ -137,9 +137,16 @@ def gmm_ctx_backward(dist, rec, g, grads):
     M, K = dist.M, dist.K
     gx = _new(B, D, H, W, like=x)
     gc = _new(B, 2 * M * K * D, like=x)
-    _hip.call("cf_gmm_ctx_bwd", _hip.p(x), _hip.p(_hip.f32(dist.mG.detach())), _hip.p(_hip.f32(dist.sG.detach())),
-              _hip.p(rec["logw"]), _hip.p(rec["c"]), _hip.p(_hip.f32(g)), _hip.p(rec.get("lp")), _hip.p(gx), _hip.p(gc), B, M, K, D, H * W, xbs,
-              _hip.stream())
+    tab = rec.get("tab")
+    if tab is not None:                       # scale shifts by table lookup (embedding context net)
+        key, inv, dsig, lsum = tab
+        _hip.call("cf_gmm_ctx_bwd_tab", _hip.p(x), _hip.p(_hip.f32(dist.mG.detach())), _hip.p(inv), _hip.p(dsig), _hip.p(lsum),
+                  _hip.p(rec["logw"]), _hip.p(rec["c"]), _hip.p(key), _hip.p(_hip.f32(g)), _hip.p(rec.get("lp")), _hip.p(gx),
+                  _hip.p(gc), B, M, K, D, H * W, xbs, _hip.stream())
+    else:
+        _hip.call("cf_gmm_ctx_bwd", _hip.p(x), _hip.p(_hip.f32(dist.mG.detach())), _hip.p(_hip.f32(dist.sG.detach())),
+                  _hip.p(rec["logw"]), _hip.p(rec["c"]), _hip.p(_hip.f32(g)), _hip.p(rec.get("lp")), _hip.p(gx), _hip.p(gc), B, M,
+                  K, D, H * W, xbs, _hip.stream())
     _embedding_grads(dist.context_net[0], rec["context"], gc, grads)
     return gx
 

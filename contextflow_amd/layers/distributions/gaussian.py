@@ -97,6 +97,50 @@ class GaussianMixtureDistribution(nn.Module):
     def prepared(self):
         return gmm_prepare(self.mG.detach(), self.sG.detach(), self.wG.detach())
 
+    def _scale_tables(self, context, need_dsig):
+        """Table form of the scale shifts when the context net is the embedding lookup of model.py:157,162 (CatEmbeddings +
+        EyeSampling): the pre-softplus shift of a sample depends only on the context variables whose embedding columns
+        fall in the scale half of the concatenated row, i.e. on a key with few values.  Returns (key (B) int32, inv_sig,
+        dsig | None, lsum) or None when the context net is anything else (per-sample kernel then)."""
+        from ..context import CatEmbeddings, EyeSampling
+        cn = self.context_net
+        if not (len(cn) == 2 and isinstance(cn[0], CatEmbeddings) and isinstance(cn[1], EyeSampling)):
+            return None
+        embs = list(cn[0]._embeddings)
+        D, H, W = self.size
+        half, dE = self.M * self.K * D, embs[0].embedding_dim
+        if dE * len(embs) != 2 * half:
+            return None
+        rel = [i for i in range(len(embs)) if (i + 1) * dE > half]          # variables that reach the scale half
+        U = 1
+        strides = {}
+        for i in reversed(rel):
+            strides[i] = U
+            U *= embs[i].num_embeddings
+        if U * half * H * W * 4 > (256 << 20):
+            return None
+        dev = self.sG.device
+        ver = (need_dsig, self.sG._version, str(dev)) + tuple(e.weight._version for e in embs)
+        cache = getattr(self, "_tab_cache", None)
+        if cache is None or cache[0] != ver:
+            grid = torch.zeros(U, len(embs), dtype=torch.long, device=dev)
+            u = torch.arange(U, device=dev)
+            for i in rel:
+                grid[:, i] = (u // strides[i]) % embs[i].num_embeddings
+            rows, _ = cn[0](grid)
+            cs_tab = _hip.f32(rows[:, half:])
+            inv = torch.empty(U, half * H * W, device=dev, dtype=torch.float32)
+            dsig = torch.empty_like(inv) if need_dsig else None
+            lsum = torch.empty(U, self.M * self.K, device=dev, dtype=torch.float32)
+            _hip.call("cf_gmm_ctx_tables", _hip.p(_hip.f32(self.sG.detach())), _hip.p(cs_tab), _hip.p(inv), _hip.p(dsig),
+                      _hip.p(lsum), U, self.M * self.K, D, H * W, _hip.stream())
+            cache = self._tab_cache = (ver, inv, dsig, lsum)
+        ctx = context.to(device=dev, dtype=torch.long)
+        key = torch.zeros(ctx.shape[0], dtype=torch.long, device=dev)
+        for i in rel:
+            key += ctx[:, i] * strides[i]
+        return (key.to(torch.int32),) + cache[1:]
+
     def _log_prob_ctx(self, input, context, tape=None):
         """gaussian.py:146-158: per-sample shifts (B, 2, M, K, D) of the component means / pre-softplus scales."""
         if isinstance(context, list):
@@ -109,10 +153,17 @@ class GaussianMixtureDistribution(nn.Module):
         out = torch.empty(B, M, device=x.device, dtype=torch.float32)
         # training: keep the per-component log-joints for the backward (it then skips their recompute)
         lp = torch.empty(B, M * K, device=x.device, dtype=torch.float32) if tape is not None else None
-        _hip.call("cf_gmm_ctx_logprob", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(_hip.f32(self.sG.detach())),
-                  _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(out), _hip.p(lp), B, M, K, D, H * W, xbs, 0, _hip.stream())
+        tab = self._scale_tables(context, tape is not None)
+        if tab is not None:
+            key, inv, dsig, lsum = tab
+            _hip.call("cf_gmm_ctx_logprob_tab", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(inv), _hip.p(lsum),
+                      _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(key), _hip.p(out), _hip.p(lp), B, M, K, D, H * W, xbs, 0,
+                      _hip.stream())
+        else:
+            _hip.call("cf_gmm_ctx_logprob", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(_hip.f32(self.sG.detach())),
+                      _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(out), _hip.p(lp), B, M, K, D, H * W, xbs, 0, _hip.stream())
         if tape is not None:
-            tape.append(dict(x=x, c=_hip.f32(c), logw=logw, context=context, lp=lp))
+            tape.append(dict(x=x, c=_hip.f32(c), logw=logw, context=context, lp=lp, tab=tab))
         return out + (logp_c * float(H * W)).unsqueeze(-1)
 
     def log_prob(self, input, context=None):

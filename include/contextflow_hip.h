@@ -270,6 +270,16 @@ int cf_add_sample_bias(float* h, const float* bias, int B, int C, int HW, int re
 int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const float* logw, const float* c, float* out,
                        float* lp_out, int B, int M, int K, int D, int HW, int64_t x_bstride, int accumulate,
                        cf_stream_t stream);
+/* Table form for scale shifts that take only U distinct values (the priors of create_model look their shifts up in
+ * embedding tables, model.py:157,162): cf_gmm_ctx_tables turns cs_tab (U, M*K, D) into inv_sig = 1/softplus(sG + cs_u),
+ * dsig = softplus'(sG + cs_u) (optional; backward) - both (U, M*K, D*HW) - and lsum (U, M*K) = sum log softplus(..).
+ * cf_gmm_ctx_logprob_tab = cf_gmm_ctx_logprob with key (B) int32 = u of every sample; c still supplies the per-sample
+ * mean shifts (its scale half is not read).  Same results, no transcendental per term.                          */
+int cf_gmm_ctx_tables(const float* sG, const float* cs_tab, float* inv_sig, float* dsig, float* lsum, int U, int MK, int D,
+                      int HW, cf_stream_t stream);
+int cf_gmm_ctx_logprob_tab(const float* x, const float* mG, const float* inv_sig, const float* lsum, const float* logw,
+                           const float* c, const int* key, float* out, float* lp_out, int B, int M, int K, int D, int HW,
+                           int64_t x_bstride, int accumulate, cf_stream_t stream);
 
 /* pieces of the variational context encoder (model.py:52-79, dequantize.py:104-118):
  * ConditionalGaussianDistribution.sample (gaussian.py:263-270): c (B,2D) = [mean|log_scale], eps (B,D) ->
@@ -299,6 +309,9 @@ int cf_relu_bwd(const float* x, const float* gy, float* out, int64_t n, cf_strea
 int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float* logw, const float* c, const float* g,
                    const float* lp, float* gx, float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride,
                    cf_stream_t stream);
+int cf_gmm_ctx_bwd_tab(const float* x, const float* mG, const float* inv_sig, const float* dsig, const float* lsum,
+                       const float* logw, const float* c, const int* key, const float* g, const float* lp, float* gx,
+                       float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride, cf_stream_t stream);
 
 /* h[b,c2,:] += x[b, c2 % C, :] in place: identity branch of MaskedResidualBlock2d (`--coupling maf`,
  * layers/autoregressive/masked_conv_2d.py:93-98)                                                                */

@@ -536,6 +536,34 @@ def test_gmm_ctx_kernels_against_torch(L, D, H, W, M, K, B):
         for got, want in ((gx.cpu().double(), xr.grad), (gc.cpu().double().view_as(cr.grad), cr.grad)):
             assert torch.isfinite(got).all()
             assert (got - want).abs().max().item() < 1e-4 * max(want.abs().max().item(), 1e-3)
+    # table form: the scale shifts of the batch take U = 3 distinct values, picked by a key per sample
+    U = 3
+    cs_tab = 0.3 * torch.randn(U, MK, D, generator=g)
+    key = torch.randint(0, U, (B,), generator=g)
+    c2 = c.clone()
+    c2[:, 1] = cs_tab[key].reshape(B, M, K, D)
+    c2d, keyd = d(c2), key.to(torch.int32).to(DEV)
+    inv, dsg = torch.empty(U, MK * D * HW, device=DEV), torch.empty(U, MK * D * HW, device=DEV)
+    lsum = torch.empty(U, MK, device=DEV)
+    _hip.call("cf_gmm_ctx_tables", _hip.p(sd), _hip.p(d(cs_tab)), _hip.p(inv), _hip.p(dsg), _hip.p(lsum), U, MK, D, HW, st)
+    res = {}
+    for tab in (False, True):
+        out, lp = torch.zeros(B, M, device=DEV), torch.empty(B, MK, device=DEV)
+        gx, gc = torch.full((B, D, H, W), float("nan"), device=DEV), torch.full((B, 2 * MK * D), float("nan"), device=DEV)
+        if tab:
+            _hip.call("cf_gmm_ctx_logprob_tab", _hip.p(xd), _hip.p(md), _hip.p(inv), _hip.p(lsum), _hip.p(ld), _hip.p(c2d),
+                      _hip.p(keyd), _hip.p(out), _hip.p(lp), B, M, K, D, HW, D * HW, 0, st)
+            _hip.call("cf_gmm_ctx_bwd_tab", _hip.p(xd), _hip.p(md), _hip.p(inv), _hip.p(dsg), _hip.p(lsum), _hip.p(ld), _hip.p(c2d),
+                      _hip.p(keyd), _hip.p(gd), None, _hip.p(gx), _hip.p(gc), B, M, K, D, HW, D * HW, st)
+        else:
+            _hip.call("cf_gmm_ctx_logprob", _hip.p(xd), _hip.p(md), _hip.p(sd), _hip.p(ld), _hip.p(c2d), _hip.p(out), _hip.p(lp),
+                      B, M, K, D, HW, D * HW, 0, st)
+            _hip.call("cf_gmm_ctx_bwd", _hip.p(xd), _hip.p(md), _hip.p(sd), _hip.p(ld), _hip.p(c2d), _hip.p(gd), None, _hip.p(gx),
+                      _hip.p(gc), B, M, K, D, HW, D * HW, st)
+        res[tab] = (out, lp, gx, gc)
+    for a, b_ in zip(res[True], res[False]):
+        assert torch.isfinite(a).all()
+        assert (a - b_).abs().max().item() < 2e-5 * max(b_.abs().max().item(), 1e-3)
 
 
 # ------------------------------------------------------------------------------------------ HIP graph replay
