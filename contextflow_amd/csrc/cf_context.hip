@@ -9,7 +9,6 @@
 
 namespace {
 
-constexpr int kMaxC = 64;             // channels of the per-sample Conv1x1 (matrix in LDS: 16 KiB)
 
 // ContextEncoder = (OneHotEncoder | EyeEncoder) -> UniformCatDequantization (rtdl/nn/_embeddings.py:76-150,
 // dequantize.py:55-64): out[b, j] = (x[b, j] + u[b, j]) / qbins[j]; x = the integer context itself (eye) or its
@@ -43,31 +42,53 @@ __global__ __launch_bounds__(256) void k_ctx_encode(const int64_t* __restrict__ 
 //   W_b = tril(m, -1) + diag(exp(diag m))            [+ NN - I under contextflow]
 //   z[b] = W_b x[b] per pixel;  ldj[b] = H W sum(diag m)   (the caller adds H W log|det NN| under contextflow -
 //   the reference's own expression, not the log-det of W_b).
+// One workgroup per sample: W_b^T (row stride CP = C rounded up to 8, zero padded) and x in LDS; a thread owns one
+// pixel and 8 output channels at a time - per input channel one x read and two 16-byte (broadcast) reads of W_b^T.
 __global__ __launch_bounds__(256) void k_conv1x1_ctx(const float* __restrict__ x, const float* __restrict__ m,
                                                      const float* __restrict__ Wm, float* __restrict__ z,
                                                      float* __restrict__ ldj, int C, int HW, int64_t xbs) {
-    __shared__ float Wt[kMaxC * (kMaxC + 1)];         // Wt[i][o] = W_b[o][i], row stride C + 1
+    extern __shared__ __align__(16) float dyn[];
     __shared__ float scr[4];
+    const int CP = (C + 7) & ~7;
+    float* Wt = dyn;                                  // Wt[i][o] = W_b[o][i], row stride CP
+    float* xs = dyn + C * CP;                         // [C][HW]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* mb = m + (int64_t)b * C * C;
-    float dsum = 0.f;
-    for (int e = tid; e < C * C; e += 256) {
-        const int o = e / C, i = e - o * C;
-        const float v = mb[e];
-        float w = o > i ? v : (o == i ? expf(v) : 0.f);
-        if (o == i) dsum += v;
-        if (Wm != nullptr) w += Wm[e] - (o == i ? 1.f : 0.f);
-        Wt[i * (C + 1) + o] = w;
-    }
-    dsum = cf_block_sum<4>(dsum, scr);                // also the barrier that publishes Wt
-    if (tid == 0) ldj[b] = dsum * (float)HW;
     const float* xb = x + (int64_t)b * xbs;
+    float dsum = 0.f;
+    for (int e = tid; e < C * CP; e += 256) {
+        const int i = e / CP, o = e - i * CP;
+        float w = 0.f;
+        if (o < C) {
+            const float v = mb[o * C + i];
+            w = o > i ? v : (o == i ? expf(v) : 0.f);
+            if (o == i) dsum += v;
+            if (Wm != nullptr) w += Wm[o * C + i] - (o == i ? 1.f : 0.f);
+        }
+        Wt[e] = w;
+    }
+    for (int e = tid; e < C * HW; e += 256) xs[e] = xb[e];
+    dsum = cf_block_sum<4>(dsum, scr);                // also the barrier that publishes Wt / xs
+    if (tid == 0) ldj[b] = dsum * (float)HW;
     float* zb = z + (int64_t)b * C * HW;
-    for (int e = tid; e < C * HW; e += 256) {
-        const int o = e / HW, p = e - o * HW;
-        float acc = 0.f;
-        for (int i = 0; i < C; ++i) acc = fmaf(Wt[i * (C + 1) + o], xb[(int64_t)i * HW + p], acc);
-        zb[e] = acc;
+    const int nob = CP >> 3;
+    for (int e = tid; e < nob * HW; e += 256) {
+        const int ob = e / HW, p = e - ob * HW, o0 = ob * 8;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int i = 0; i < C; ++i) {
+            const float xv = xs[i * HW + p];
+            const float4 w0 = *reinterpret_cast<const float4*>(&Wt[i * CP + o0]);
+            const float4 w1 = *reinterpret_cast<const float4*>(&Wt[i * CP + o0 + 4]);
+            acc[0] = fmaf(w0.x, xv, acc[0]); acc[1] = fmaf(w0.y, xv, acc[1]);
+            acc[2] = fmaf(w0.z, xv, acc[2]); acc[3] = fmaf(w0.w, xv, acc[3]);
+            acc[4] = fmaf(w1.x, xv, acc[4]); acc[5] = fmaf(w1.y, xv, acc[5]);
+            acc[6] = fmaf(w1.z, xv, acc[6]); acc[7] = fmaf(w1.w, xv, acc[7]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (o0 + k < C) zb[(int64_t)(o0 + k) * HW + p] = acc[k];
     }
 }
 
@@ -295,41 +316,70 @@ __global__ __launch_bounds__(64) void k_sigmoid_ldj(const float* __restrict__ x,
 
 // Conv1x1 with a context net, backward: gx[b] = W_b^T gz[b];  G = sum_p gz[b][:,p] x[b][:,p]^T;
 // gm[b][o][i] = G[o][i] (o > i) | G[i][i] exp(m_ii) + H W gld[b] (o == i) | 0 (o < i)      (d/d CN(c) output)
+// One workgroup per sample; W_b (row stride CP), x and gz (row stride HWP = odd: the (o, i) products below walk rows
+// with one lane per row) in LDS.
 __global__ __launch_bounds__(256) void k_conv1x1_ctx_bwd(const float* __restrict__ x, const float* __restrict__ m,
                                                          const float* __restrict__ Wm, const float* __restrict__ gz,
                                                          const float* __restrict__ gld, float* __restrict__ gx,
                                                          float* __restrict__ gm, int C, int HW, int64_t xbs, int64_t gzbs) {
-    __shared__ float Wb[kMaxC * (kMaxC + 1)];         // Wb[o][i], row stride C + 1
-    extern __shared__ __align__(16) float dyn[];      // xs[C*HW] | gs[C*HW]: this sample's input and upstream gradient
-    float* xs = dyn;
-    float* gs = dyn + C * HW;
+    extern __shared__ __align__(16) float dyn[];
+    const int CP = (C + 7) & ~7, HWP = HW | 1;
+    float* Wb = dyn;                                  // Wb[o][i], row stride CP (zero padded)
+    float* xs = dyn + C * CP;                         // [C][HWP]
+    float* gs = xs + C * HWP;                         // [C][HWP]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* mb = m + (int64_t)b * C * C;
     const float* xb = x + (int64_t)b * xbs;
     const float* gb = gz + (int64_t)b * gzbs;
-    for (int e = tid; e < C * HW; e += 256) { xs[e] = xb[e]; gs[e] = gb[e]; }
-    for (int e = tid; e < C * C; e += 256) {
-        const int o = e / C, i = e - o * C;
-        const float v = mb[e];
-        float w = o > i ? v : (o == i ? expf(v) : 0.f);
-        if (Wm != nullptr) w += Wm[e] - (o == i ? 1.f : 0.f);
-        Wb[o * (C + 1) + i] = w;
+    for (int e = tid; e < C * HW; e += 256) {
+        const int c = e / HW, p = e - c * HW;
+        xs[c * HWP + p] = xb[e];
+        gs[c * HWP + p] = gb[e];
+    }
+    for (int e = tid; e < C * CP; e += 256) {
+        const int o = e / CP, i = e - o * CP;
+        float w = 0.f;
+        if (i < C) {
+            const float v = mb[o * C + i];
+            w = o > i ? v : (o == i ? expf(v) : 0.f);
+            if (Wm != nullptr) w += Wm[o * C + i] - (o == i ? 1.f : 0.f);
+        }
+        Wb[e] = w;
     }
     __syncthreads();
     float* gxb = gx + (int64_t)b * C * HW;
-    for (int e = tid; e < C * HW; e += 256) {
-        const int i = e / HW, p = e - i * HW;
-        float acc = 0.f;
-        for (int o = 0; o < C; ++o) acc = fmaf(Wb[o * (C + 1) + i], gs[o * HW + p], acc);
-        gxb[e] = acc;
+    const int nib = CP >> 3;
+    for (int e = tid; e < nib * HW; e += 256) {       // gx = W_b^T gz: a pixel and 8 input channels per thread
+        const int ib = e / HW, p = e - ib * HW, i0 = ib * 8;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int o = 0; o < C; ++o) {
+            const float gv = gs[o * HWP + p];
+            const float4 w0 = *reinterpret_cast<const float4*>(&Wb[o * CP + i0]);
+            const float4 w1 = *reinterpret_cast<const float4*>(&Wb[o * CP + i0 + 4]);
+            acc[0] = fmaf(w0.x, gv, acc[0]); acc[1] = fmaf(w0.y, gv, acc[1]);
+            acc[2] = fmaf(w0.z, gv, acc[2]); acc[3] = fmaf(w0.w, gv, acc[3]);
+            acc[4] = fmaf(w1.x, gv, acc[4]); acc[5] = fmaf(w1.y, gv, acc[5]);
+            acc[6] = fmaf(w1.z, gv, acc[6]); acc[7] = fmaf(w1.w, gv, acc[7]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k < C) gxb[(int64_t)(i0 + k) * HW + p] = acc[k];
     }
     float* gmb = gm + (int64_t)b * C * C;
     const float gl = gld[b] * (float)HW;
-    for (int e = tid; e < C * C; e += 256) {
+    for (int e = tid; e < C * C; e += 256) {          // lanes walk i (rows of xs: odd stride), o is shared
         const int o = e / C, i = e - o * C;
         float g = 0.f;
         if (o >= i) {
-            for (int p = 0; p < HW; ++p) g = fmaf(gs[o * HW + p], xs[i * HW + p], g);
+            const float* go = gs + o * HWP;
+            const float* xi = xs + i * HWP;
+            float g0 = 0.f, g1 = 0.f;
+            int p = 0;
+            for (; p + 1 < HW; p += 2) { g0 = fmaf(go[p], xi[p], g0); g1 = fmaf(go[p + 1], xi[p + 1], g1); }
+            if (p < HW) g0 = fmaf(go[p], xi[p], g0);
+            g = g0 + g1;
             if (o == i) g = g * expf(mb[e]) + gl;
         }
         gmb[e] = g;
@@ -588,8 +638,17 @@ int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, fl
                    int64_t x_bstride, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && m && z && ldj && B >= 0 && C > 0 && HW > 0);
-    if (C > kMaxC) { cf_set_error("cf_conv1x1_ctx: C=%d > %d unsupported", C, kMaxC); return CF_ERR_UNSUPPORTED; }
-    k_conv1x1_ctx<<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, m, Wm, z, ldj, C, HW, x_bstride);
+    const size_t lds = (size_t)(C * ((C + 7) & ~7) + C * HW) * sizeof(float);
+    if (lds > 160 * 1024) { cf_set_error("cf_conv1x1_ctx: C=%d, H*W=%d need %zu B of LDS", C, HW, lds); return CF_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv1x1_ctx, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("cf_conv1x1_ctx: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
+    k_conv1x1_ctx<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, m, Wm, z, ldj, C, HW, x_bstride);
     CF_LAUNCH_CHECK();
     return 0;
 }
@@ -668,10 +727,15 @@ int cf_conv1x1_ctx_bwd(const float* x, const float* m, const float* Wm, const fl
                        float* gm, int B, int C, int HW, int64_t x_bstride, int64_t gz_bstride, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && m && gz && gld && gx && gm && B >= 0 && C > 0 && HW > 0);
-    if (C > kMaxC) { cf_set_error("cf_conv1x1_ctx_bwd: C=%d > %d unsupported", C, kMaxC); return CF_ERR_UNSUPPORTED; }
-    const size_t lds = (size_t)2 * C * HW * sizeof(float);
-    if (lds + sizeof(float) * kMaxC * (kMaxC + 1) > 64 * 1024) {
-        cf_set_error("cf_conv1x1_ctx_bwd: C*HW=%d too large for the LDS staging", C * HW); return CF_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)(C * ((C + 7) & ~7) + 2 * C * (HW | 1)) * sizeof(float);
+    if (lds > 160 * 1024) { cf_set_error("cf_conv1x1_ctx_bwd: C=%d, H*W=%d need %zu B of LDS", C, HW, lds); return CF_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv1x1_ctx_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("cf_conv1x1_ctx_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
     }
     k_conv1x1_ctx_bwd<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, m, Wm, gz, gld, gx, gm, C, HW, x_bstride, gz_bstride);
     CF_LAUNCH_CHECK();

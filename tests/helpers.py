@@ -72,6 +72,8 @@ SPECIALIST = {
     "cifar10_eye_argmax_cf": ("cifar10", dict(contexts=[15, 5], enc_emb="eye", contextflow=True, enc_type="argmax")),
     "cifar10_embed_eyesample": ("cifar10", dict(contexts=[15, 5], enc_emb="embed", contextflow=False, enc_type="eyesample")),
     "mnist_embed_probsample_cf": ("mnist", dict(contexts=[64], enc_emb="embed", contextflow=True, enc_type="probsample")),
+    "atm_onehot_cf": ("atm", dict(contexts=[68], enc_emb="onehot", contextflow=True)),
+    "atm_embed_eyesample_cf": ("atm", dict(contexts=[68], enc_emb="embed", contextflow=True, enc_type="eyesample")),
 }
 
 

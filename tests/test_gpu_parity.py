@@ -566,6 +566,39 @@ def test_gmm_ctx_kernels_against_torch(L, D, H, W, M, K, B):
         assert (a - b_).abs().max().item() < 2e-5 * max(b_.abs().max().item(), 1e-3)
 
 
+@pytest.mark.parametrize("C,HW,B,cf", [(16, 256, 5, True), (64, 16, 7, False), (76, 72, 3, True), (26, 8, 4, True), (3, 5, 2, False)])
+def test_conv1x1_ctx_kernels_against_torch(L, C, HW, B, cf):
+    """Per-sample Conv1x1 (conv1x1.py:34-50): W_b = tril(m,-1) + diag(exp(diag m)) [+ NN - I under contextflow],
+    z = W_b x, ldj = H W sum diag m - forward and backward (gx, d/dm) against torch.autograd in fp64.  76 channels is
+    the ATM specialist (README.md:64-69)."""
+    from contextflow_amd.layers import _hip
+    g = torch.Generator().manual_seed(C + HW)
+    x = torch.randn(B, C, HW, generator=g)
+    m = 0.3 * torch.randn(B, C, C, generator=g)
+    Wm = torch.linalg.qr(torch.randn(C, C, generator=g))[0].contiguous() if cf else None
+    gz, gld = torch.randn(B, C, HW, generator=g), torch.randn(B, generator=g)
+    xr, mr = x.double().requires_grad_(True), m.double().requires_grad_(True)
+    Wb = torch.tril(mr, -1) + torch.diag_embed(torch.exp(torch.diagonal(mr, dim1=1, dim2=2)))
+    if cf:
+        Wb = Wb + Wm.double() - torch.eye(C, dtype=torch.float64)
+    zr = Wb @ xr
+    ldr = HW * torch.diagonal(mr, dim1=1, dim2=2).sum(-1)
+    ((zr * gz.double()).sum() + (ldr * gld.double()).sum()).backward()
+    d = lambda t: None if t is None else t.contiguous().to(DEV)
+    xd, md, Wd, gzd, gldd = d(x), d(m.reshape(B, C * C)), d(Wm), d(gz), d(gld)
+    z, ldj = torch.empty(B, C, HW, device=DEV), torch.empty(B, device=DEV)
+    st = _hip.stream()
+    _hip.call("cf_conv1x1_ctx", _hip.p(xd), _hip.p(md), _hip.p(Wd), _hip.p(z), _hip.p(ldj), B, C, HW, C * HW, st)
+    assert (z.cpu().double() - zr.detach()).abs().max().item() < 1e-4 * max(1.0, zr.abs().max().item())
+    assert (ldj.cpu().double() - ldr.detach()).abs().max().item() < 1e-4 * max(1.0, ldr.abs().max().item())
+    gx, gm = torch.full((B, C, HW), float("nan"), device=DEV), torch.full((B, C * C), float("nan"), device=DEV)
+    _hip.call("cf_conv1x1_ctx_bwd", _hip.p(xd), _hip.p(md), _hip.p(Wd), _hip.p(gzd), _hip.p(gldd), _hip.p(gx), _hip.p(gm),
+              B, C, HW, C * HW, C * HW, st)
+    for got, want in ((gx.cpu().double(), xr.grad), (gm.cpu().double().view(B, C, C), mr.grad)):
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() < 1e-4 * max(want.abs().max().item(), 1e-3)
+
+
 # ------------------------------------------------------------------------------------------ HIP graph replay
 @pytest.mark.parametrize("name", ["mnist", "cifar10"])
 def test_graph_capture_matches_eager(L, name):
@@ -733,7 +766,8 @@ def test_training_steps_reduce_the_loss_smap(L):
 # ------------------------------------------------------------------------------------------ specialist (context) mode
 @pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye",
                                     "cifar10_onehot_vardeq", "cifar10_eye_vardeq_cf", "smap_onehot_cf", "smap_eye",
-                                    "cifar10_eye_argmax_cf", "cifar10_embed_eyesample", "mnist_embed_probsample_cf"])
+                                    "cifar10_eye_argmax_cf", "cifar10_embed_eyesample", "mnist_embed_probsample_cf",
+                                    "atm_onehot_cf", "atm_embed_eyesample_cf"])
 def test_specialist_forward_matches_reference(L, fxname):
     """Context-conditioned models (create_model(generalist=False), model.py:117-162): per-sample Conv1x1 / ActNorm /
     Coupling parameters from the context encoders + CN nets, context-shifted GMM priors — logp against the reference's
