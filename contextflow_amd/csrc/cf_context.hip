@@ -48,10 +48,10 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx(const float* __restrict__ x
                                                      const float* __restrict__ Wm, float* __restrict__ z,
                                                      float* __restrict__ ldj, int C, int HW, int64_t xbs) {
     extern __shared__ __align__(16) float dyn[];
-    __shared__ float scr[4];
     const int CP = (C + 7) & ~7;
     float* Wt = dyn;                                  // Wt[i][o] = W_b[o][i], row stride CP
     float* xs = dyn + C * CP;                         // [C][HW]
+    float* scr = xs + C * HW;                         // [4] (inside the dynamic block: no static LDS next to a 160 KiB request)
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* mb = m + (int64_t)b * C * C;
     const float* xb = x + (int64_t)b * xbs;
@@ -638,7 +638,7 @@ int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, fl
                    int64_t x_bstride, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && m && z && ldj && B >= 0 && C > 0 && HW > 0);
-    const size_t lds = (size_t)(C * ((C + 7) & ~7) + C * HW) * sizeof(float);
+    const size_t lds = (size_t)(C * ((C + 7) & ~7) + C * HW + 4) * sizeof(float);
     if (lds > 160 * 1024) { cf_set_error("cf_conv1x1_ctx: C=%d, H*W=%d need %zu B of LDS", C, HW, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
         static bool raised = false;

@@ -12,7 +12,8 @@
 namespace {
 
 constexpr int kLnBlocks = 256;      // partial-sum rows of cf_layernorm_bwd
-constexpr int kLnMaxPer = 8;        // features per lane: dim <= 128
+constexpr int kLnMaxPer = 16;       // features per lane: dim <= 256 (ATM: transformer width 152)
+constexpr int kLnMaxDim = 16 * kLnMaxPer;
 
 // LayerNorm backward (biased variance, eps; forward: simple_vit.py:33,50,74,104-106).  16 lanes per row, 16 rows per
 // pass, grid-stride over row groups.  gx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat));
@@ -20,7 +21,7 @@ constexpr int kLnMaxPer = 8;        // features per lane: dim <= 128
 __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ gy, float* __restrict__ gx,
                                                        float* __restrict__ part, int rows, int dim, float eps) {
-    __shared__ float red[16][2 * 128];
+    __shared__ float red[16][2 * kLnMaxDim];
     const int g = threadIdx.x & 15, rg = threadIdx.x >> 4;
     float aw[kLnMaxPer], ab[kLnMaxPer];
 #pragma unroll
@@ -65,11 +66,11 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < kLnMaxPer; ++i) {
         const int j = g + 16 * i;
-        if (j < dim) { red[rg][j] = aw[i]; red[rg][128 + j] = ab[i]; }
+        if (j < dim) { red[rg][j] = aw[i]; red[rg][kLnMaxDim + j] = ab[i]; }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * dim; e += 256) {
-        const int j = e < dim ? e : 128 + (e - dim);
+        const int j = e < dim ? e : kLnMaxDim + (e - dim);
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += red[r][j];

@@ -200,6 +200,65 @@ void launch_slogdet(const float* Wm, int C, float* lad, float* inv, hipStream_t 
     else k_slogdet<CMAX, true><<<dim3(1), dim3(256), 0, st>>>(Wm, C, lad, inv);
 }
 
+// Inverse for 64 < C <= 128 (ATM: 76-channel Conv1x1, training only: d log|det W| / dW = W^-T).  In-place Gauss-Jordan
+// with partial pivoting on an fp32 copy in LDS (row stride C + 1), one workgroup; the column swaps that undo the row
+// pivoting run at the end.  Conv1x1 weights start orthogonal and stay well conditioned.
+__global__ __launch_bounds__(256) void k_inverse_lds(const float* __restrict__ Wm, int C, float* __restrict__ inv) {
+    extern __shared__ float A[];                   // [C][C+1]
+    __shared__ int piv[128];
+    __shared__ float colk[128];
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    const int S = C + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < C * C; e += 256) A[(e / C) * S + (e % C)] = Wm[e];
+    __syncthreads();
+    for (int k = 0; k < C; ++k) {
+        // pivot search over rows k .. C-1 of column k
+        float best = -1.f;
+        int bi = k;
+        for (int r = k + tid; r < C; r += 256) {
+            const float v = fabsf(A[r * S + k]);
+            if (v > best) { best = v; bi = r; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float b = rv[0];
+            int p = ri[0];
+            for (int w = 1; w < 4; ++w)
+                if (rv[w] > b || (rv[w] == b && ri[w] < p)) { b = rv[w]; p = ri[w]; }
+            piv[k] = p;
+        }
+        __syncthreads();
+        const int p = piv[k];
+        if (p != k)
+            for (int c = tid; c < C; c += 256) { const float t = A[k * S + c]; A[k * S + c] = A[p * S + c]; A[p * S + c] = t; }
+        __syncthreads();
+        const float d = 1.0f / A[k * S + k];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) A[k * S + c] = (c == k ? 1.0f : A[k * S + c]) * d;
+        for (int r = tid; r < C; r += 256) colk[r] = A[r * S + k];
+        __syncthreads();
+        for (int e = tid; e < C * C; e += 256) {
+            const int r = e / C, c = e - r * C;
+            if (r != k) A[r * S + c] = (c == k ? 0.f : A[r * S + c]) - colk[r] * A[k * S + c];
+        }
+        __syncthreads();
+    }
+    for (int k = C - 1; k >= 0; --k) {
+        const int p = piv[k];
+        if (p != k)
+            for (int r = tid; r < C; r += 256) { const float t = A[r * S + k]; A[r * S + k] = A[r * S + p]; A[r * S + p] = t; }
+        __syncthreads();
+    }
+    for (int e = tid; e < C * C; e += 256) inv[e] = A[(e / C) * S + (e % C)];
+}
+
 }  // namespace
 
 extern "C" {
@@ -221,11 +280,20 @@ int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z,
 int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_stream_t stream) {
     CF_REQUIRE(Wm && logabsdet && C > 0);
     if (C > kMaxLU) {
-        if (C > 128 || inv != nullptr) {
-            cf_set_error("cf_slogdet_inverse: C=%d unsupported (log|det| up to 128, inverse up to %d)", C, kMaxLU);
-            return CF_ERR_UNSUPPORTED;
-        }
+        if (C > 128) { cf_set_error("cf_slogdet_inverse: C=%d unsupported (up to 128)", C); return CF_ERR_UNSUPPORTED; }
         k_slogdet128<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet);
+        if (inv != nullptr) {
+            const size_t lds = (size_t)C * (C + 1) * sizeof(float);
+            if (lds > 64 * 1024) {
+                static bool raised = false;
+                if (!raised) {
+                    hipError_t e = hipFuncSetAttribute((const void*)k_inverse_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // + ~1 KiB static
+                    if (e != hipSuccess) { cf_set_error("cf_slogdet_inverse: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+                    raised = true;
+                }
+            }
+            k_inverse_lds<<<dim3(1), dim3(256), lds, cf_s(stream)>>>(Wm, C, inv);
+        }
         CF_LAUNCH_CHECK();
         return 0;
     }

@@ -14,7 +14,8 @@ from . import _hip
 from .actnorm import ActNorm
 from .context import CatEmbeddings, EyeSampling, UniformCatDequantization
 from .conv1x1 import Conv1x1
-from .coupling import Coupling
+from .coupling import Coupling, TransCoupling
+from .permute_axes import PermuteAxes
 from .splitprior import SplitPrior
 from .squeeze import Squeeze, squeeze_op
 
@@ -24,15 +25,12 @@ def _new(*shape, like):
 
 
 def trainable(flow):
-    """True when this specialist flow can be trained here: contextflow (frozen generalist), conv couplings, context
-    encoders without trainable parameters of their own (uniform dequantisation, embedding lookup)."""
-    from .coupling import TransCoupling
+    """True when this specialist flow can be trained here: contextflow (frozen generalist), conv or transformer
+    couplings, context encoders without trainable parameters of their own (uniform dequantisation, embedding lookup)."""
     ok = (UniformCatDequantization, EyeSampling)
     for m in list(flow.sequence_modules) + [flow.dist]:
         cn = getattr(m, "context_net", None) or getattr(getattr(m, "dist", None), "context_net", None)
         if cn and (not isinstance(cn[1], ok) or not getattr(m, "contextflow", getattr(getattr(m, "dist", None), "contextflow", False))):
-            return False
-        if isinstance(m, TransCoupling) and cn:
             return False
     return True
 
@@ -130,6 +128,31 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
     return gx
 
 
+def transcoupling_ctx_backward(m, rec, context, gz, gld, grads):
+    """TransCoupling under contextflow (coupling.py:123-133): h = ViT(x0) + CN(c), the ViT frozen.  The ViT is re-run with
+    a tape (as in the generalist backward), d/d CN(c) = per-sample row sums of d/dh, d/dx0 through the ViT."""
+    from .autograd_layers import vit_backward, vit_forward_taped
+    x, xbs = _hip.bview(rec["x"])
+    gzv, gzbs = _hip.bview(gz)
+    B, C, H, W = x.shape
+    half, st = C // 2, _hip.stream()
+    h, vtape = vit_forward_taped(m.NN[0], x[:, :half])
+    _hip.call("cf_add_sample_bias", _hip.p(h), _hip.p(rec["cn"]), B, C, H * W, 0, st)
+    gx = _new(B, C, H, W, like=x)
+    ghd = _new(B, C, H, W, like=x)
+    _hip.call("cf_coupling_apply_bwd", _hip.p(x), _hip.p(h), _hip.p(gzv), _hip.p(_hip.f32(gld)), _hip.p(gx), _hip.p(ghd),
+              B, C, H * W, xbs, gzbs, st)
+    gcn = _new(B, C, like=x)
+    _hip.call("cf_sample_channel_sums", _hip.p(ghd), _hip.p(gcn), B, C, H * W, st)
+    ga2 = _relu_bwd(rec["a2"], _linear_bwd(rec["a2"], m.CN[4], gcn, grads))
+    ga1 = _relu_bwd(rec["a1"], _linear_bwd(rec["a1"], m.CN[2], ga2, grads))
+    gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads)
+    _encoder_backward(m.context_net, context, gc, grads)
+    frozen = {}                                   # the ViT's own parameter gradients: computed by the shared chain, unused
+    gx[:, :half] += vit_backward(m.NN[0], vtape, ghd, frozen)
+    return gx
+
+
 def gmm_ctx_backward(dist, rec, g, grads):
     """Context-shifted GMM: d/dx and the embedding-table gradients (mG / sG / wG are frozen under contextflow)."""
     x, xbs = _hip.bview(rec["x"])
@@ -172,6 +195,11 @@ class SpecialistLogProb(torch.autograd.Function):
                 if not mod._fused_ctx_ok(x):
                     raise NotImplementedError("specialist training needs the fused coupling geometry (3x3, C in 8..64)")
                 x, ldj = mod._fused_ctx(x, context, rec)
+            elif isinstance(mod, TransCoupling) and mod.context_net:
+                _check_encoder(mod.context_net)
+                if not mod.contextflow:
+                    raise NotImplementedError("specialist training without contextflow (all parameters train; not built)")
+                x, ldj = mod._forward_ctx(x, context, rec)
             elif isinstance(mod, SplitPrior) and getattr(mod.dist, "context_net", None):
                 c = x.shape[1] // 2
                 ldj = mod.dist._log_prob_ctx(x[:, c:], context, rec)
@@ -201,6 +229,9 @@ class SpecialistLogProb(torch.autograd.Function):
                 if isinstance(mod, Squeeze):
                     gz = squeeze_op(gz, mod.p, True)
                     continue
+                if isinstance(mod, PermuteAxes):
+                    gz = gz.permute(mod.inverse_permutation).contiguous()
+                    continue
                 break                                    # pre-processing: nothing trainable upstream
             if isinstance(mod, SplitPrior):
                 g2 = gmm_ctx_backward(mod.dist, rec, glogp, grads)
@@ -209,6 +240,8 @@ class SpecialistLogProb(torch.autograd.Function):
                 gz = conv1x1_ctx_backward(mod, rec, context, gz, gld, grads)
             elif isinstance(mod, ActNorm):
                 gz = actnorm_ctx_backward(mod, rec, context, gz, gld, grads)
+            elif isinstance(mod, TransCoupling):
+                gz = transcoupling_ctx_backward(mod, rec, context, gz, gld, grads)
             else:
                 gz = coupling_ctx_backward(mod, rec, context, gz, gld, grads)
         return (None, None, None) + tuple(grads.get(p) for p in params)

@@ -168,6 +168,7 @@ def layer_backward(m, x_in, gz, gld):
     from .augment import Augment
     from .conv1x1 import Conv1x1
     from .coupling import TransCoupling
+    from .permute_axes import PermuteAxes
     if isinstance(m, TransCoupling):
         return transcoupling_backward(m, x_in, gz, gld)
     if type(m) is Conv1x1:
@@ -176,4 +177,6 @@ def layer_backward(m, x_in, gz, gld):
         return actnorm_backward(m, x_in, gz, gld)
     if isinstance(m, Augment) and m.split_dim == 1:
         return gz[:, : x_in.shape[1]], {}
+    if isinstance(m, PermuteAxes):
+        return gz.permute(m.inverse_permutation).contiguous(), {}
     raise NotImplementedError("no backward for layer %s in the fused plan" % type(m).__name__)

@@ -206,12 +206,17 @@ class TransCoupling(_AffineCoupling):
         """Conditioner output h (layer-by-layer kernels; also the fallback for unsupported geometries)."""
         return self.NN[0](x0)
 
-    def _net_ctx(self, x0, context):
+    def _net_ctx(self, x0, context, tape=None):
         """coupling.py:123-133 with a context net: h = ViT(x0) + CN(c) (contextflow) or ViT([x0 ; CN(c) broadcast]).
         Quirk kept: logp_c is not multiplied by H*W here (unlike Coupling)."""
         from .simple_vit import _linear
         c, logp_c = self.context_net(context)
-        cn = _linear(_linear(_linear(_hip.f32(c), self.CN[0], act=2), self.CN[2], act=2), self.CN[4])    # (B, O)
+        c = _hip.f32(c)
+        a1 = _linear(c, self.CN[0], act=2)
+        a2 = _linear(a1, self.CN[2], act=2)
+        cn = _linear(a2, self.CN[4])                                                              # (B, O)
+        if tape is not None:                  # training (contextflow): what the CN-net backward needs
+            tape.append(dict(c=c, a1=a1, a2=a2, cn=cn))
         B, _, H, W = x0.shape
         if self.contextflow:
             h = self.NN[0](x0)
@@ -264,12 +269,17 @@ class TransCoupling(_AffineCoupling):
     def forward(self, x, context=None):
         _hip.require_device(x)
         if self.context_net:
-            h, logp_c = self._net_ctx(x[:, : x.shape[1] // 2], context)
-            z, ldj = coupling_apply(x, h, False)
-            return z, ldj + logp_c
+            return self._forward_ctx(x, context)
         if self._fused_ok(x):
             return self._fused(x, False)
         return super().forward(x, context)
+
+    def _forward_ctx(self, x, context, tape=None):
+        h, logp_c = self._net_ctx(x[:, : x.shape[1] // 2], context, tape)
+        if tape is not None:
+            tape[-1]["x"] = x
+        z, ldj = coupling_apply(x, h, False)
+        return z, ldj + logp_c
 
     def reverse(self, z, context=None):
         _hip.require_device(z)

@@ -423,7 +423,7 @@ def test_edge_batches_and_layouts(L, name):
 
 
 # ------------------------------------------------------------------------------------------ training step (backward)
-@pytest.mark.parametrize("name,B", [("mnist", 6), ("cifar10", 5), ("smap", 7)])
+@pytest.mark.parametrize("name,B", [("mnist", 6), ("cifar10", 5), ("smap", 7), ("atm", 3)])
 def test_backward_against_autograd_oracle(L, name, B):
     """d sum(w * logp) / d parameters: the hand-written backward (fused HIP step-backward kernel, the layer-by-layer
     backward of TransCoupling / SimpleViT for smap, library GEMMs) against torch.autograd run through the CPU oracle
@@ -432,7 +432,7 @@ def test_backward_against_autograd_oracle(L, name, B):
     ops, _, M, params, fx = load_e2e(name)
     C, H, W = fo.CONFIGS[name][0]
     g = torch.Generator().manual_seed(21)
-    x = torch.rand(B, C, H, W, generator=g) if name == "smap" else torch.randint(0, 256, (B, C, H, W), generator=g).float()
+    x = torch.rand(B, C, H, W, generator=g) if name in ("smap", "atm") else torch.randint(0, 256, (B, C, H, W), generator=g).float()
     u = torch.rand(B, C, H, W, generator=g)
     eps = [torch.randn(B, 1, H, W, generator=g)]
     wts = torch.randn(B, M, generator=g)
@@ -599,6 +599,27 @@ def test_conv1x1_ctx_kernels_against_torch(L, C, HW, B, cf):
         assert (got - want).abs().max().item() < 1e-4 * max(want.abs().max().item(), 1e-3)
 
 
+@pytest.mark.parametrize("C", [1, 3, 8, 16, 33, 64, 65, 76, 128])
+def test_slogdet_inverse_against_torch(L, C):
+    """cf_slogdet_inverse (conv1x1.py:21-31: torch.slogdet / torch.inverse per call): register-resident LU up to 64
+    channels, two rows per lane + the LDS Gauss-Jordan inverse up to 128 (ATM: 76) - against torch.linalg in fp64 on
+    a perturbed orthogonal matrix with permuted rows (forces pivoting)."""
+    from contextflow_amd.layers import _hip
+    g = torch.Generator().manual_seed(C)
+    q = torch.linalg.qr(torch.randn(C, C, generator=g))[0]
+    Wm = ((q + 0.05 * torch.randn(C, C, generator=g)) * (0.5 + torch.rand(C, 1, generator=g)))[torch.randperm(C, generator=g)].contiguous()
+    lad, inv = torch.empty(1, device=DEV), torch.full((C, C), float("nan"), device=DEV)
+    Wd = Wm.to(DEV)
+    _hip.call("cf_slogdet_inverse", _hip.p(Wd), C, _hip.p(lad), _hip.p(inv), _hip.stream())
+    ref_l = torch.linalg.slogdet(Wm.double())[1].item()
+    ref_i = torch.linalg.inv(Wm.double())
+    assert abs(lad.item() - ref_l) < 1e-5 * max(1.0, abs(ref_l))
+    assert (inv.cpu().double() - ref_i).abs().max().item() < 2e-5 * ref_i.abs().max().item()
+    lad2 = torch.empty(1, device=DEV)
+    _hip.call("cf_slogdet_inverse", _hip.p(Wd), C, _hip.p(lad2), None, _hip.stream())       # log|det| alone
+    assert abs(lad2.item() - ref_l) < 1e-5 * max(1.0, abs(ref_l))
+
+
 # ------------------------------------------------------------------------------------------ HIP graph replay
 @pytest.mark.parametrize("name", ["mnist", "cifar10"])
 def test_graph_capture_matches_eager(L, name):
@@ -693,17 +714,17 @@ def test_layer_backward_kernels_against_torch(L):
         t = t.to(DEV).contiguous()
         keep.append(t)
         return _hip.p(t)
-    # LayerNorm
-    rows, dim = 4 * 37 + 3, 52
-    x = torch.randn(rows, dim, generator=g); w = torch.randn(dim, generator=g); b = torch.randn(dim, generator=g); gy = torch.randn(rows, dim, generator=g)
-    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
-    torch.nn.functional.layer_norm(x64, (dim,), w64, b64, 1e-5).backward(gy.double())
-    gx = torch.empty(rows, dim, device=DEV); nparts = _hip.lib().cf_layernorm_bwd_parts()
-    part = torch.empty(nparts, 2 * dim, device=DEV)
-    _hip.call("cf_layernorm_bwd", P(x.cpu()), P(w.cpu()), P(gy.cpu()), _hip.p(gx), _hip.p(part), rows, dim, 1e-5, st())
-    s = part.sum(0).cpu().double()
-    assert (gx.cpu().double() - x64.grad).abs().max() < 1e-4
-    assert (s[:dim] - w64.grad).abs().max() < 1e-3 and (s[dim:] - b64.grad).abs().max() < 1e-3
+    # LayerNorm (dim 152 = the ATM transformer width)
+    for rows, dim in ((4 * 37 + 3, 52), (36 * 5 + 1, 152), (7, 256)):
+        x = torch.randn(rows, dim, generator=g); w = torch.randn(dim, generator=g); b = torch.randn(dim, generator=g); gy = torch.randn(rows, dim, generator=g)
+        x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+        torch.nn.functional.layer_norm(x64, (dim,), w64, b64, 1e-5).backward(gy.double())
+        gx = torch.empty(rows, dim, device=DEV); nparts = _hip.lib().cf_layernorm_bwd_parts()
+        part = torch.empty(nparts, 2 * dim, device=DEV)
+        _hip.call("cf_layernorm_bwd", P(x.cpu()), P(w.cpu()), P(gy.cpu()), _hip.p(gx), _hip.p(part), rows, dim, 1e-5, st())
+        s = part.sum(0).cpu().double()
+        assert (gx.cpu().double() - x64.grad).abs().max() < 1e-4
+        assert (s[:dim] - w64.grad).abs().max() < 1e-3 and (s[dim:] - b64.grad).abs().max() < 1e-3
     # attention
     B, N, dh = 9, 4, 64
     qkv = torch.randn(B * N, 3 * dh, generator=g); go = torch.randn(B * N, dh, generator=g)
@@ -803,7 +824,7 @@ def test_specialist_forward_matches_reference(L, fxname):
     assert (logp2 - logp[:2]).abs().max().item() < 2e-2 * max(1.0, 1e-5 * logp.abs().max().item())
 
 
-@pytest.mark.parametrize("fxname", ["mnist_eye_cf", "cifar10_onehot_cf"])
+@pytest.mark.parametrize("fxname", ["mnist_eye_cf", "cifar10_onehot_cf", "smap_onehot_cf", "atm_onehot_cf", "atm_embed_eyesample_cf"])
 def test_specialist_backward_against_autograd_oracle(L, fxname):
     """Specialist training under contextflow: d sum(w * logp) / d (CN nets, prior embedding tables) from the hand-written
     backward (autograd_ctx.py) against torch.autograd through the CPU oracle in fp64, same inputs / noise / parameters.
@@ -820,12 +841,13 @@ def test_specialist_backward_against_autograd_oracle(L, fxname):
                             context=inp["context"], cnoise=[c.double() for c in inp["cnoise"]])
     (lp * wts.double()).sum().backward()
     cfg, ds, MM = cfa.preset_config(name)
-    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type="uniform", contextflow=True)
+    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type=ctx.get("enc_type", "uniform"), contextflow=True)
     model = cfa.create_model(cfg, ds, MM, contexts=ctx["contexts"])
     model.load_state_dict(params, strict=True)
     model = model.to(DEV).train()
     set_noise(model, inp["u"], inp["eps"])
     encs = [m for m in model.modules() if isinstance(m, cfa.layers.UniformCatDequantization)]
+    assert len(encs) == len(inp["cnoise"])
     for e, c in zip(encs, inp["cnoise"]):
         e.fixed_noise = c.to(DEV)
     z, logp = model(inp["x"].to(DEV), inp["context"].to(DEV))
