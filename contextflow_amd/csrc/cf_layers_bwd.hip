@@ -79,52 +79,56 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
 }
 
 // single-head attention backward on N tokens per sample (forward: k_attention, simple_vit.py:56-68).
-// qkv rows [q | k | v], go = d/d out; gqkv rows [dq | dk | dv].  One 64-thread block per sample; the softmax is
+// qkv rows [q | k | v], go = d/d out; gqkv rows [dq | dk | dv].  One workgroup per sample; the softmax is
 // recomputed.  dS = P o (dP - rowsum(P o dP)), dP = go V^T, dV = P^T go, dQ = scale dS K, dK = scale dS^T Q.
-__global__ __launch_bounds__(64) void k_attention_bwd(const float* __restrict__ qkv, const float* __restrict__ go,
-                                                      float* __restrict__ gqkv, int N, int dh, float scale) {
+// LDS rows have odd strides (3 dh + 1, dh + 1, N + 1): the products walk rows / columns with one lane each.
+__global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__ qkv, const float* __restrict__ go,
+                                                       float* __restrict__ gqkv, int N, int dh, float scale) {
     extern __shared__ __align__(16) float lds[];
-    float* s_qkv = lds;                     // [N][3 dh]
-    float* s_go = s_qkv + N * 3 * dh;       // [N][dh]
-    float* P = s_go + N * dh;               // [N][N]
-    float* dS = P + N * N;                  // [N][N]
+    const int RS = 3 * dh + 1, GS = dh + 1, NS = N | 1, nt = blockDim.x;
+    float* s_qkv = lds;                     // [N][RS]
+    float* s_go = s_qkv + N * RS;           // [N][GS]
+    float* P = s_go + N * GS;               // [N][NS]
+    float* dS = P + N * NS;                 // [N][NS]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* src = qkv + (int64_t)b * N * 3 * dh;
     const float* gsrc = go + (int64_t)b * N * dh;
-    for (int e = tid; e < N * 3 * dh; e += 64) s_qkv[e] = src[e];
-    for (int e = tid; e < N * dh; e += 64) s_go[e] = gsrc[e];
+    for (int e = tid; e < N * 3 * dh; e += nt) s_qkv[(e / (3 * dh)) * RS + e % (3 * dh)] = src[e];
+    for (int e = tid; e < N * dh; e += nt) s_go[(e / dh) * GS + e % dh] = gsrc[e];
     __syncthreads();
-    for (int e = tid; e < N * N; e += 64) {
+    for (int e = tid; e < N * N; e += nt) {
         const int i = e / N, j = e - i * N;
-        const float* q = s_qkv + i * 3 * dh;
-        const float* k = s_qkv + j * 3 * dh + dh;
-        const float* v = s_qkv + j * 3 * dh + 2 * dh;
-        const float* g = s_go + i * dh;
+        const float* q = s_qkv + i * RS;
+        const float* k = s_qkv + j * RS + dh;
+        const float* v = s_qkv + j * RS + 2 * dh;
+        const float* g = s_go + i * GS;
         float s = 0.f, d = 0.f;
         for (int c = 0; c < dh; ++c) { s = fmaf(q[c], k[c], s); d = fmaf(g[c], v[c], d); }
-        P[e] = s * scale;
-        dS[e] = d;                          // dP for now
+        P[i * NS + j] = s * scale;
+        dS[i * NS + j] = d;                 // dP for now
     }
     __syncthreads();
-    for (int i = tid; i < N; i += 64) {     // row softmax, then dS = P o (dP - sum_j P dP)
+    for (int i = tid; i < N; i += nt) {     // row softmax, then dS = P o (dP - sum_j P dP)
+        float* Pi = P + i * NS;
+        float* Di = dS + i * NS;
         float m = -INFINITY;
-        for (int j = 0; j < N; ++j) m = fmaxf(m, P[i * N + j]);
+        for (int j = 0; j < N; ++j) m = fmaxf(m, Pi[j]);
         float z = 0.f;
-        for (int j = 0; j < N; ++j) { const float ev = expf(P[i * N + j] - m); P[i * N + j] = ev; z += ev; }
+        for (int j = 0; j < N; ++j) { const float ev = expf(Pi[j] - m); Pi[j] = ev; z += ev; }
         const float rz = 1.0f / z;
         float dot = 0.f;
-        for (int j = 0; j < N; ++j) { P[i * N + j] *= rz; dot = fmaf(P[i * N + j], dS[i * N + j], dot); }
-        for (int j = 0; j < N; ++j) dS[i * N + j] = P[i * N + j] * (dS[i * N + j] - dot);
+        for (int j = 0; j < N; ++j) { Pi[j] *= rz; dot = fmaf(Pi[j], Di[j], dot); }
+        for (int j = 0; j < N; ++j) Di[j] = Pi[j] * (Di[j] - dot);
     }
     __syncthreads();
     float* dst = gqkv + (int64_t)b * N * 3 * dh;
-    for (int e = tid; e < N * dh; e += 64) {
+    for (int e = tid; e < N * dh; e += nt) {
         const int i = e / dh, c = e - i * dh;
         float dq = 0.f, dk = 0.f, dv = 0.f;
         for (int j = 0; j < N; ++j) {
-            dq = fmaf(dS[i * N + j], s_qkv[j * 3 * dh + dh + c], dq);          // dS[i][j] K[j][c]
-            dk = fmaf(dS[j * N + i], s_qkv[j * 3 * dh + c], dk);               // dS[j][i] Q[j][c]
-            dv = fmaf(P[j * N + i], s_go[j * dh + c], dv);                     // P[j][i] go[j][c]
+            dq = fmaf(dS[i * NS + j], s_qkv[j * RS + dh + c], dq);          // dS[i][j] K[j][c]
+            dk = fmaf(dS[j * NS + i], s_qkv[j * RS + c], dk);               // dS[j][i] Q[j][c]
+            dv = fmaf(P[j * NS + i], s_go[j * GS + c], dv);                 // P[j][i] go[j][c]
         }
         dst[i * 3 * dh + c] = dq * scale;
         dst[i * 3 * dh + dh + c] = dk * scale;
@@ -205,9 +209,9 @@ int cf_layernorm_bwd(const float* x, const float* w, const float* gy, float* gx,
 int cf_attention_bwd(const float* qkv, const float* go, float* gqkv, int B, int N, int dh, float scale, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(qkv && go && gqkv && B >= 0 && N > 0 && dh > 0);
-    const size_t lds = (size_t)(N * 3 * dh + N * dh + 2 * N * N) * sizeof(float);
+    const size_t lds = (size_t)(N * (3 * dh + 1) + N * (dh + 1) + 2 * N * (N | 1)) * sizeof(float);
     if (lds > 64 * 1024) { cf_set_error("cf_attention_bwd: N=%d dh=%d needs %zu B of LDS", N, dh, lds); return CF_ERR_UNSUPPORTED; }
-    k_attention_bwd<<<dim3(B), dim3(64), lds, cf_s(stream)>>>(qkv, go, gqkv, N, dh, scale);
+    k_attention_bwd<<<dim3(B), dim3(N >= 16 ? 256 : 64), lds, cf_s(stream)>>>(qkv, go, gqkv, N, dh, scale);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -2,8 +2,8 @@
 //
 // The dense contractions (patch embedding, qkv, out-projection, MLP) run on the exact-fp32 matrix
 // cores (v_mfma_f32_32x32x2_f32): rows = samples x tokens, K, N <= a few hundred.  One workgroup
-// owns 128 rows x (<= 96) output features; X and the W slice are staged once in LDS with an odd
-// row stride, so both MFMA operand reads (lane -> row, lane>>5 -> k) are bank-conflict free.
+// owns 128 rows x (<= 96) output features; X and the W slice go through LDS in K-chunks of 32 with
+// an odd row stride, so both MFMA operand reads (lane -> row, lane>>5 -> k) are bank-conflict free.
 // LayerNorm, the tiny (tokens x tokens) attention and the patch index maps are VALU kernels.
 #include "cf_common.h"
 #include <math.h>
@@ -14,43 +14,63 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LIN_ROWS = 128;     // rows per workgroup (4 waves x 32)
 constexpr int LIN_COLS = 96;      // output features per workgroup (3 MFMA column tiles)
+constexpr int LIN_KC = 32;        // K chunk staged in LDS per pass
+constexpr int LIN_KP = LIN_KC + 1;   // odd row stride: conflict-free operand reads (lane -> row)
 
 // y[r, n] = act(sum_k x[r,k] W[n,k] + bias[n]) + res[r,n]
 // ACT: 0 none, 1 exact GELU (erf), 2 ReLU             simple_vit.py:32-38,52-53; coupling.py:37 (CN nets)
+// K is walked in chunks of 32 through a 29 KiB LDS stage (any K; 4-5 workgroups per CU overlap each other's staging
+// and MFMA phases); the next chunk's global loads are issued into registers before the MFMAs of the current one.
 template <int ACT>
 __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, const float* __restrict__ Wt,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
-                                                float* __restrict__ y, int rows, int K, int N, int KP) {
-    extern __shared__ __align__(16) float lds[];
-    float* xs = lds;                      // [LIN_ROWS][KP]
-    float* ws = lds + LIN_ROWS * KP;      // [LIN_COLS][KP]
+                                                float* __restrict__ y, int rows, int K, int N) {
+    __shared__ float xs[LIN_ROWS * LIN_KP];
+    __shared__ float ws[LIN_COLS * LIN_KP];
+    constexpr int NXI = LIN_ROWS * LIN_KC / 256, NWI = LIN_COLS * LIN_KC / 256;   // staged elements per thread: 16 + 12
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * LIN_ROWS, n0 = blockIdx.y * LIN_COLS;
-    const int K2 = (K + 1) & ~1;          // even K for the x2 MFMA; the pad column is zero
-    for (int e = tid; e < LIN_ROWS * K2; e += 256) {
-        const int r = e / K2, k = e - r * K2;
-        xs[r * KP + k] = (r0 + r < rows && k < K) ? x[(int64_t)(r0 + r) * K + k] : 0.f;
-    }
-    for (int e = tid; e < LIN_COLS * K2; e += 256) {
-        const int n = e / K2, k = e - n * K2;
-        ws[n * KP + k] = (n0 + n < N && k < K) ? Wt[(int64_t)(n0 + n) * K + k] : 0.f;
-    }
-    __syncthreads();
+    const int sk = tid & 31, sr = tid >> 5;              // staging: column k of the chunk, first row (rows sr + 8 i)
+    float xr[NXI], wr[NWI];
+    auto fetch = [&](int k0) {
+        const int k = k0 + sk;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int r = r0 + sr + 8 * i;
+            xr[i] = (r < rows && k < K) ? x[(int64_t)r * K + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            const int n = n0 + sr + 8 * i;
+            wr[i] = (n < N && k < K) ? Wt[(int64_t)n * K + k] : 0.f;
+        }
+    };
     f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     const int li = lane & 31, lk = lane >> 5;
-    const float* xa = xs + (wave * 32 + li) * KP + lk;     // A[i = row][k]
-    const float* wb = ws + li * KP + lk;                    // B[k][j = feature]
-    for (int k0 = 0; k0 < K2; k0 += 2) {
-        const float a = xa[k0];
+    const float* xa = xs + (wave * 32 + li) * LIN_KP + lk;     // A[i = row][k]
+    const float* wb = ws + li * LIN_KP + lk;                    // B[k][j = feature]
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += LIN_KC) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const float b = wb[t * 32 * KP + k0];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        for (int i = 0; i < NXI; ++i) xs[(sr + 8 * i) * LIN_KP + sk] = xr[i];
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) ws[(sr + 8 * i) * LIN_KP + sk] = wr[i];
+        __syncthreads();
+        if (k0 + LIN_KC < K) fetch(k0 + LIN_KC);
+#pragma unroll
+        for (int kk = 0; kk < LIN_KC; kk += 2) {
+            const float a = xa[kk];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float b = wb[t * 32 * LIN_KP + kk];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
         }
+        __syncthreads();
     }
     // D[i][j]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -100,26 +120,28 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 }
 
 // single-head attention on N tokens per sample: out = softmax(q k^T * scale) v.   simple_vit.py:56-68
-// qkv rows are [q | k | v] of width 3*dh; one 64-thread block per sample.
-__global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv, float* __restrict__ out, int N, int dh,
-                                                  float scale) {
+// qkv rows are [q | k | v] of width 3*dh; one workgroup per sample.  LDS rows have the odd stride 3 dh + 1: the q k^T
+// products walk the k rows with one lane per row.
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, float* __restrict__ out, int N, int dh,
+                                                   float scale) {
     extern __shared__ __align__(16) float lds[];
-    float* s_qkv = lds;                   // [N][3*dh]
-    float* dots = lds + N * 3 * dh;       // [N][N]
+    const int RS = 3 * dh + 1, nt = blockDim.x;
+    float* s_qkv = lds;                   // [N][RS]
+    float* dots = lds + N * RS;           // [N][N]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* src = qkv + (int64_t)b * N * 3 * dh;
-    for (int e = tid; e < N * 3 * dh; e += 64) s_qkv[e] = src[e];
+    for (int e = tid; e < N * 3 * dh; e += nt) s_qkv[(e / (3 * dh)) * RS + e % (3 * dh)] = src[e];
     __syncthreads();
-    for (int e = tid; e < N * N; e += 64) {
+    for (int e = tid; e < N * N; e += nt) {
         const int i = e / N, j = e - i * N;
-        const float* q = s_qkv + i * 3 * dh;
-        const float* k = s_qkv + j * 3 * dh + dh;
-        float acc = 0.f;
-        for (int d = 0; d < dh; ++d) acc = fmaf(q[d], k[d], acc);
-        dots[e] = acc * scale;
+        const float* q = s_qkv + i * RS;
+        const float* k = s_qkv + j * RS + dh;
+        float a0 = 0.f, a1 = 0.f;
+        for (int d = 0; d < dh; d += 2) { a0 = fmaf(q[d], k[d], a0); a1 = fmaf(q[d + 1], k[d + 1], a1); }
+        dots[e] = (a0 + a1) * scale;
     }
     __syncthreads();
-    for (int i = tid; i < N; i += 64) {
+    for (int i = tid; i < N; i += nt) {
         float mx = -INFINITY;
         for (int j = 0; j < N; ++j) mx = fmaxf(mx, dots[i * N + j]);
         float sum = 0.f;
@@ -128,10 +150,10 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv,
         for (int j = 0; j < N; ++j) dots[i * N + j] *= inv;
     }
     __syncthreads();
-    for (int e = tid; e < N * dh; e += 64) {
+    for (int e = tid; e < N * dh; e += nt) {
         const int i = e / dh, d = e - i * dh;
         float acc = 0.f;
-        for (int j = 0; j < N; ++j) acc = fmaf(dots[i * N + j], s_qkv[j * 3 * dh + 2 * dh + d], acc);
+        for (int j = 0; j < N; ++j) acc = fmaf(dots[i * N + j], s_qkv[j * RS + 2 * dh + d], acc);
         out[((int64_t)b * N + i) * dh + d] = acc;
     }
 }
@@ -164,22 +186,10 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
               int act, cf_stream_t stream) {
     if (rows == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && Wt && y && rows >= 0 && K > 0 && N > 0 && act >= 0 && act <= 2);
-    if (K > 128) { cf_set_error("cf_linear: K=%d > 128 unsupported", K); return CF_ERR_UNSUPPORTED; }
-    const int KP = ((K + 1) & ~1) | 1;                       // odd row stride: conflict-free operand reads
-    const size_t lds = (size_t)(LIN_ROWS + LIN_COLS) * KP * sizeof(float);
     dim3 grid((rows + LIN_ROWS - 1) / LIN_ROWS, (N + LIN_COLS - 1) / LIN_COLS);
-    const void* fn = act == 0 ? (const void*)k_linear<0> : (act == 1 ? (const void*)k_linear<1> : (const void*)k_linear<2>);
-    if (lds > 64 * 1024) {
-        static bool raised[3] = {false, false, false};
-        if (!raised[act]) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_linear: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised[act] = true;
-        }
-    }
-    if (act == 0) k_linear<0><<<grid, dim3(256), lds, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N, KP);
-    else if (act == 1) k_linear<1><<<grid, dim3(256), lds, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N, KP);
-    else k_linear<2><<<grid, dim3(256), lds, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N, KP);
+    if (act == 0) k_linear<0><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
+    else if (act == 1) k_linear<1><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
+    else k_linear<2><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
     CF_LAUNCH_CHECK();
     return 0;
 }
@@ -197,10 +207,10 @@ int cf_layernorm(const float* x, const float* w, const float* b, const float* po
 int cf_attention(const float* qkv, float* out, int B, int N, int dh, float scale, cf_stream_t stream) {
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(qkv && out && B >= 0 && N > 0 && dh > 0);
-    const size_t lds = (size_t)(N * 3 * dh + N * N) * sizeof(float);
+    CF_REQUIRE(dh % 2 == 0);
+    const size_t lds = (size_t)(N * (3 * dh + 1) + N * N) * sizeof(float);
     if (lds > 64 * 1024) { cf_set_error("cf_attention: N=%d dh=%d needs %zu B of LDS", N, dh, lds); return CF_ERR_UNSUPPORTED; }
-    if (B == 0) return 0;
-    k_attention<<<dim3(B), dim3(64), lds, cf_s(stream)>>>(qkv, out, N, dh, scale);
+    k_attention<<<dim3(B), dim3(N >= 16 ? 256 : 64), lds, cf_s(stream)>>>(qkv, out, N, dh, scale);
     CF_LAUNCH_CHECK();
     return 0;
 }

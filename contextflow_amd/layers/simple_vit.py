@@ -32,25 +32,6 @@ def _linear(x, lin, res=None, act=0):
     N = lin.weight.shape[0]
     b = _hip.f32(lin.bias.detach()) if lin.bias is not None else None
     w = _hip.f32(lin.weight.detach())
-    if K > 128:                          # cf_linear stages whole rows of K in LDS: wider inputs go in K-chunks,
-        if act != 0:                     # each chunk accumulating onto the previous partial result through `res`;
-            assert res is None           # the activation then runs as its own elementwise kernel
-            y = _linear(x, lin, None, 0)
-            out = torch.empty_like(y)
-            if act == 1:
-                _hip.call("cf_gelu", _hip.p(y), None, _hip.p(out), y.numel(), 0, _hip.stream())
-            else:
-                _hip.call("cf_relu_bwd", _hip.p(y), _hip.p(y), _hip.p(out), y.numel(), _hip.stream())
-            return out
-        y = res
-        for k0 in range(0, K, 128):
-            k1 = min(k0 + 128, K)
-            part = torch.empty(rows, N, device=x.device, dtype=torch.float32)
-            xk, wk = x[:, k0:k1].contiguous(), w[:, k0:k1].contiguous()   # named: both must be alive when the call is enqueued
-            _hip.call("cf_linear", _hip.p(xk), _hip.p(wk), _hip.p(b if k0 == 0 else None), _hip.p(y), _hip.p(part), rows,
-                      k1 - k0, N, 0, _hip.stream())
-            y = part
-        return y
     y = torch.empty(rows, N, device=x.device, dtype=torch.float32)
     _hip.call("cf_linear", _hip.p(x), _hip.p(w), _hip.p(b), _hip.p(res), _hip.p(y), rows, K, N, act, _hip.stream())
     return y

@@ -183,7 +183,7 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
              int taps, cf_stream_t stream);
 
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
-/* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; K <= 128.
+/* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; any K, N.
  * act: 0 none, 1 exact (erf) GELU, 2 ReLU.   nn.Linear of patch embedding / to_qkv / to_out / FeedForward; CN nets. */
 int cf_linear(const float* x, const float* Wt, const float* bias, const float* res, float* y,
               int rows, int K, int N, int act, cf_stream_t stream);

@@ -725,16 +725,31 @@ def test_layer_backward_kernels_against_torch(L):
         s = part.sum(0).cpu().double()
         assert (gx.cpu().double() - x64.grad).abs().max() < 1e-4
         assert (s[:dim] - w64.grad).abs().max() < 1e-3 and (s[dim:] - b64.grad).abs().max() < 1e-3
-    # attention
-    B, N, dh = 9, 4, 64
-    qkv = torch.randn(B * N, 3 * dh, generator=g); go = torch.randn(B * N, dh, generator=g)
-    q64 = qkv.double().requires_grad_(True)
-    q, k, v = q64.view(B, N, 3 * dh).split(dh, dim=-1)
-    out = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1) @ v
-    out.backward(go.double().view(B, N, dh))
-    gq = torch.empty(B * N, 3 * dh, device=DEV)
-    _hip.call("cf_attention_bwd", P(qkv.cpu()), P(go.cpu()), _hip.p(gq), B, N, dh, dh ** -0.5, st())
-    assert (gq.cpu().double() - q64.grad).abs().max() < 1e-4
+    # attention, forward and backward (4 tokens: SMAP; 36 / 9: ATM levels)
+    for B, N, dh in ((9, 4, 64), (5, 36, 64), (3, 9, 64), (2, 17, 32)):
+        qkv = torch.randn(B * N, 3 * dh, generator=g); go = torch.randn(B * N, dh, generator=g)
+        q64 = qkv.double().requires_grad_(True)
+        q, k, v = q64.view(B, N, 3 * dh).split(dh, dim=-1)
+        out = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1) @ v
+        out.backward(go.double().view(B, N, dh))
+        of = torch.empty(B * N, dh, device=DEV)
+        _hip.call("cf_attention", P(qkv.cpu()), _hip.p(of), B, N, dh, dh ** -0.5, st())
+        assert (of.cpu().double() - out.detach().reshape(B * N, dh)).abs().max() < 1e-5
+        gq = torch.empty(B * N, 3 * dh, device=DEV)
+        _hip.call("cf_attention_bwd", P(qkv.cpu()), P(go.cpu()), _hip.p(gq), B, N, dh, dh ** -0.5, st())
+        assert (gq.cpu().double() - q64.grad).abs().max() < 1e-4
+    # linear: K walked in chunks of 32 (ragged last chunk, odd K), ragged rows / features, bias, residual, activations
+    for rows, K, N, act, use_res in ((300, 152, 152, 0, True), (129, 7, 200, 2, False), (64, 33, 5, 1, False), (1000, 256, 96, 0, False),
+                                     (37, 128, 97, 1, True)):
+        xl = torch.randn(rows, K, generator=g); wl = torch.randn(N, K, generator=g) / K ** 0.5; bl = torch.randn(N, generator=g)
+        rl = torch.randn(rows, N, generator=g) if use_res else None
+        ref = xl.double() @ wl.double().t() + bl.double()
+        ref = torch.nn.functional.gelu(ref) if act == 1 else (torch.relu(ref) if act == 2 else ref)
+        if use_res:
+            ref = ref + rl.double()
+        yl = torch.full((rows, N), float("nan"), device=DEV)
+        _hip.call("cf_linear", P(xl), P(wl), P(bl), P(rl) if use_res else None, _hip.p(yl), rows, K, N, act, st())
+        assert (yl.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (rows, K, N, act)
     # GELU
     xg = torch.randn(1000, generator=g) * 2; gg = torch.randn(1000, generator=g)
     x64 = xg.double().requires_grad_(True)

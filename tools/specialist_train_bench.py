@@ -8,12 +8,12 @@ import contextflow_amd as cfa
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = "cuda:0"
-for name, contexts, emb in (("cifar10", [15, 5], "onehot"), ("mnist", [64], "eye")):
+for name, contexts, emb in (("cifar10", [15, 5], "onehot"), ("mnist", [64], "eye"), ("smap", [55], "onehot"), ("atm", [68], "onehot")):
     torch.manual_seed(0)
     cfg, ds, M = cfa.preset_config(name)
     cfg.update(generalist=False, enc_emb=emb, enc_type="uniform", contextflow=True)
     model = cfa.create_model(cfg, ds, M, contexts=contexts).to(dev)
-    x = torch.randint(0, 256, (B, *ds), device=dev).float()
+    x = torch.rand(B, *ds, device=dev) if name in ("smap", "atm") else torch.randint(0, 256, (B, *ds), device=dev).float()
     gt = torch.randint(0, M, (B,), device=dev)
     ctx = torch.stack([torch.randint(0, k, (B,), device=dev) for k in contexts], 1)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -24,7 +24,7 @@ for name, contexts, emb in (("cifar10", [15, 5], "onehot"), ("mnist", [64], "eye
     def step():
         opt.zero_grad(set_to_none=True)
         logp = dim_inv * model.log_prob(x, ctx)
-        loss = torch.nn.functional.cross_entropy(logp, gt)
+        loss = torch.nn.functional.cross_entropy(logp, gt) if M > 1 else -logp.mean()
         loss.backward()
         opt.step()
         return loss.detach()

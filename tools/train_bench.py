@@ -17,7 +17,7 @@ dev = "cuda:0"
 torch.manual_seed(0)
 cfg, ds, M = cfa.preset_config(name)
 model = cfa.create_model(cfg, ds, M).to(dev)
-x = torch.rand(B, *ds, device=dev) if name == "smap" else torch.randint(0, 256, (B, *ds), device=dev).float()
+x = torch.rand(B, *ds, device=dev) if name in ("smap", "atm", "msl", "smd") else torch.randint(0, 256, (B, *ds), device=dev).float()
 gt = torch.randint(0, M, (B,), device=dev)
 with torch.no_grad():
     model(x[:256])                                   # ActNorm init
