@@ -11,56 +11,69 @@
 
 namespace {
 
-constexpr int kLnBlocks = 256;      // partial-sum rows of cf_layernorm_bwd
+constexpr int kLnBlocks = 1024;     // partial-sum rows of cf_layernorm_bwd (4 workgroups per CU)
 constexpr int kLnMaxPer = 16;       // features per lane: dim <= 256 (ATM: transformer width 152)
 constexpr int kLnMaxDim = 16 * kLnMaxPer;
 
 // LayerNorm backward (biased variance, eps; forward: simple_vit.py:33,50,74,104-106).  16 lanes per row, 16 rows per
-// pass, grid-stride over row groups.  gx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat));
+// pass, grid-stride over row groups; a row's x and gy are read ONCE into registers (16 values per lane: dim <= 256).
+// gx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat));
 // partial[blk][j] = sum_rows gy*xhat, partial[blk][dim + j] = sum_rows gy.
 __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ gy, float* __restrict__ gx,
                                                        float* __restrict__ part, int rows, int dim, float eps) {
     __shared__ float red[16][2 * kLnMaxDim];
     const int g = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    float aw[kLnMaxPer], ab[kLnMaxPer];
+    float aw[kLnMaxPer], ab[kLnMaxPer], wv[kLnMaxPer];
 #pragma unroll
-    for (int i = 0; i < kLnMaxPer; ++i) { aw[i] = 0.f; ab[i] = 0.f; }
+    for (int i = 0; i < kLnMaxPer; ++i) { aw[i] = 0.f; ab[i] = 0.f; wv[i] = (g + 16 * i < dim) ? w[g + 16 * i] : 0.f; }
     const float inv = 1.0f / (float)dim;
     for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < rows; r0 += (int64_t)gridDim.x * 16) {
         const int64_t row = r0 + rg;
         const bool ok = row < rows;
         const float* xr = x + (ok ? row : 0) * dim;
         const float* gr = gy + (ok ? row : 0) * dim;
+        float xv[kLnMaxPer], gv[kLnMaxPer];
+#pragma unroll
+        for (int i = 0; i < kLnMaxPer; ++i) {
+            const int j = g + 16 * i;
+            const bool in = j < dim;
+            xv[i] = in ? xr[j] : 0.f;
+            gv[i] = (in && ok) ? gr[j] : 0.f;
+        }
         float s = 0.f;
-        for (int j = g; j < dim; j += 16) s += xr[j];
+#pragma unroll
+        for (int i = 0; i < kLnMaxPer; ++i) s += xv[i];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         const float mean = s * inv;
         float v = 0.f;
-        for (int j = g; j < dim; j += 16) { const float d = xr[j] - mean; v = fmaf(d, d, v); }
+#pragma unroll
+        for (int i = 0; i < kLnMaxPer; ++i) {
+            const float d = (g + 16 * i < dim) ? xv[i] - mean : 0.f;
+            xv[i] = d;
+            v = fmaf(d, d, v);
+        }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         const float rstd = 1.0f / sqrtf(v * inv + eps);
         float s1 = 0.f, s2 = 0.f;
-        for (int j = g; j < dim; j += 16) {
-            const float gw = gr[j] * w[j], xh = (xr[j] - mean) * rstd;
-            s1 += gw; s2 = fmaf(gw, xh, s2);
+#pragma unroll
+        for (int i = 0; i < kLnMaxPer; ++i) {
+            xv[i] *= rstd;                                               // xhat
+            const float gw = gv[i] * wv[i];
+            s1 += gw;
+            s2 = fmaf(gw, xv[i], s2);
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
         s1 *= inv; s2 *= inv;
-        if (ok) {
 #pragma unroll
-            for (int i = 0; i < kLnMaxPer; ++i) {
-                const int j = g + 16 * i;
-                if (j < dim) {
-                    const float xh = (xr[j] - mean) * rstd, gv = gr[j];
-                    gx[row * dim + j] = rstd * (gv * w[j] - s1 - xh * s2);
-                    aw[i] = fmaf(gv, xh, aw[i]);
-                    ab[i] += gv;
-                }
-            }
+        for (int i = 0; i < kLnMaxPer; ++i) {
+            const int j = g + 16 * i;
+            if (ok && j < dim) gx[row * dim + j] = rstd * (gv[i] * wv[i] - s1 - xv[i] * s2);
+            aw[i] = fmaf(gv[i], xv[i], aw[i]);                           // gv = 0 for rows past the end
+            ab[i] += gv[i];
         }
     }
 #pragma unroll
@@ -93,19 +106,30 @@ __global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* src = qkv + (int64_t)b * N * 3 * dh;
     const float* gsrc = go + (int64_t)b * N * dh;
-    for (int e = tid; e < N * 3 * dh; e += nt) s_qkv[(e / (3 * dh)) * RS + e % (3 * dh)] = src[e];
-    for (int e = tid; e < N * dh; e += nt) s_go[(e / dh) * GS + e % dh] = gsrc[e];
+    for (int r = tid >> 6; r < N; r += nt >> 6) {         // a wave per row: no index division
+        for (int c = tid & 63; c < 3 * dh; c += 64) s_qkv[r * RS + c] = src[r * 3 * dh + c];
+        for (int c = tid & 63; c < dh; c += 64) s_go[r * GS + c] = gsrc[r * dh + c];
+    }
     __syncthreads();
-    for (int e = tid; e < N * N; e += nt) {
-        const int i = e / N, j = e - i * N;
-        const float* q = s_qkv + i * RS;
+    // P = q k^T and dP = go v^T: a thread owns key j and 2 query rows - one k / v read feeds 2 FMAs each
+    const int NQ = (N + 1) >> 1;
+    for (int e = tid; e < NQ * N; e += nt) {
+        const int iq = e / N, j = e - iq * N, i0 = iq * 2, i1 = min(i0 + 1, N - 1);
         const float* k = s_qkv + j * RS + dh;
         const float* v = s_qkv + j * RS + 2 * dh;
-        const float* g = s_go + i * GS;
-        float s = 0.f, d = 0.f;
-        for (int c = 0; c < dh; ++c) { s = fmaf(q[c], k[c], s); d = fmaf(g[c], v[c], d); }
-        P[i * NS + j] = s * scale;
-        dS[i * NS + j] = d;                 // dP for now
+        const float* q0 = s_qkv + i0 * RS;
+        const float* q1 = s_qkv + i1 * RS;
+        const float* g0 = s_go + i0 * GS;
+        const float* g1 = s_go + i1 * GS;
+        float s0 = 0.f, s1 = 0.f, d0 = 0.f, d1 = 0.f;
+        for (int c = 0; c < dh; ++c) {
+            const float kv = k[c], vv = v[c];
+            s0 = fmaf(q0[c], kv, s0); s1 = fmaf(q1[c], kv, s1);
+            d0 = fmaf(g0[c], vv, d0); d1 = fmaf(g1[c], vv, d1);
+        }
+        P[i0 * NS + j] = s0 * scale;
+        dS[i0 * NS + j] = d0;               // dP for now
+        if (i0 + 1 < N) { P[i1 * NS + j] = s1 * scale; dS[i1 * NS + j] = d1; }
     }
     __syncthreads();
     for (int i = tid; i < N; i += nt) {     // row softmax, then dS = P o (dP - sum_j P dP)

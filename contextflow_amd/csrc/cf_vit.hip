@@ -91,6 +91,131 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
     }
 }
 
+// Weight / bias gradient of a Linear over row-major activations (backward of k_linear; simple_vit.py's nn.Linear):
+//   gW[n][k] = sum_r gy[r][n] x[r][k],   gb[n] = sum_r gy[r][n]        (rows = samples x tokens: 1e5 .. 1e6)
+// A split-K GEMM whose reduction dimension is the ROW index: both MFMA operands come straight from row-major LDS tiles
+// with lanes along the feature dimension (A[i = n][k = r] = gy[r][n], B[k = r][j = kcol] = x[r][kcol]) - no transposes.
+// The bias gradient rides along as column K of x (ones).  The NT x KT output tiles (32 x 32) are dealt round-robin
+// to the 4 waves (<= WG_TPW each, a block of 4 WG_TPW tiles per blockIdx.y); blockIdx.x walks 32-row chunks with a
+// grid stride and leaves ONE partial per workgroup; k_linear_wgrad_reduce sums them in a fixed order.
+constexpr int WG_RC = 32;         // rows per staged chunk
+constexpr int WG_TPW = 8;         // output tiles per wave
+constexpr int WG_MAXF = 12;       // 32-feature column blocks of gy and [x | 1] together
+constexpr int WG_LS = WG_MAXF * 32;   // LDS row stride (floats): 48 KiB per workgroup
+
+// TPW = tiles per wave of this launch (1..WG_TPW): slots past the last tile recompute tile 0 and are not stored - a
+// branch around an MFMA would put a full LDS wait in front of every one of them.
+template <int TPW>
+__global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ part, int rows, int K, int N, int NT, int KT, int ybase) {
+    // one LDS row = the 32-feature blocks [gy (NT) | x, 1, 0.. (KT)] of one activation row at the FIXED stride WG_LS: the
+    // operand reads of the MFMA loop are then base register + immediate offset (no address arithmetic between MFMAs)
+    __shared__ float lds[WG_RC * WG_LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    const int NS = NT * 32, ntiles = NT * KT, t0 = (ybase + blockIdx.y) * 4 * WG_TPW;
+    int aoff[TPW], boff[TPW];
+    bool live[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = t0 + wave + 4 * i;
+        live[i] = t < ntiles;
+        const int tt = live[i] ? t : 0;
+        aoff[i] = lk * WG_LS + (tt / KT) * 32 + li;
+        boff[i] = lk * WG_LS + NS + (tt % KT) * 32 + li;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // staging: a thread owns the 32-feature column c32 of rows (tid>>5) + 8 i.  Two workgroups per CU overlap each
+    // other's staging and MFMA phases.
+    const int nchunks = (rows + WG_RC - 1) / WG_RC;
+    const int c32 = tid & 31, rs = tid >> 5;
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int r0 = c * WG_RC;
+        // branch-free batch: all 4 x WG_MAXF loads of a thread are in flight together (clamped addresses; the values of
+        // padding positions are replaced afterwards), then the LDS writes
+        float stg[WG_RC / 8][WG_MAXF];
+#pragma unroll
+        for (int i = 0; i < WG_RC / 8; ++i) {
+            const int r = r0 + rs + 8 * i;
+            const int64_t rc = r < rows ? r : rows - 1;
+#pragma unroll
+            for (int cb = 0; cb < WG_MAXF; ++cb) {
+                const bool isg = cb < NT;                                         // uniform
+                const int col = cb * 32 + c32 - (isg ? 0 : NS);                   // n, or k
+                const float* src = isg ? gy + rc * N + min(col, N - 1) : x + rc * K + min(col, K - 1);
+                stg[i][cb] = *src;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WG_RC / 8; ++i) {
+            const int r = rs + 8 * i;
+            const bool ok = r0 + r < rows;
+#pragma unroll
+            for (int cb = 0; cb < WG_MAXF; ++cb) {
+                const bool isg = cb < NT;
+                const int col = cb * 32 + c32 - (isg ? 0 : NS);
+                const float v = isg ? ((ok && col < N) ? stg[i][cb] : 0.f)        // rows past the end contribute nothing
+                                    : (col < K ? stg[i][cb] : (col == K ? 1.f : 0.f));
+                lds[r * WG_LS + cb * 32 + c32] = v;
+            }
+        }
+        __syncthreads();
+        // operands of row pair rr + 2 are requested before the MFMAs of row pair rr (two register sets)
+        float oa[2][TPW], ob[2][TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { oa[0][i] = lds[aoff[i]]; ob[0][i] = lds[boff[i]]; }
+#pragma unroll
+        for (int rr = 0; rr < WG_RC; rr += 2) {
+            const int cur = (rr >> 1) & 1;
+            if (rr + 2 < WG_RC) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) { oa[cur ^ 1][i] = lds[aoff[i] + (rr + 2) * WG_LS]; ob[cur ^ 1][i] = lds[boff[i] + (rr + 2) * WG_LS]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][i], ob[cur][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // partial of this workgroup: full 32 x 32 tiles, [tile][i = n][j = kcol]
+    float* pw = part + (int64_t)blockIdx.x * ntiles * 1024;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        if (!live[i]) continue;
+        float* pt = pw + (int64_t)(t0 + wave + 4 * i) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pt[((r & 3) + 8 * (r >> 2) + 4 * lk) * 32 + li] = acc[i][r];
+    }
+}
+
+// 64 output elements per workgroup, the G partials split over the 4 waves (every 4th partial each), then summed across
+// the waves in a fixed order
+__global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gW,
+                                                             float* __restrict__ gb, int K, int N, int KT, int ntiles, int G) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;                 // element of the padded tile storage
+    const float* p = part + e;
+    float s0 = 0.f, s1 = 0.f;
+    int g = wave;
+    for (; g + 4 < G; g += 8) { s0 += p[(int64_t)g * ntiles * 1024]; s1 += p[(int64_t)(g + 4) * ntiles * 1024]; }
+    if (g < G) s0 += p[(int64_t)g * ntiles * 1024];
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const int t = e >> 10, n = (t / KT) * 32 + ((e >> 5) & 31), k = (t % KT) * 32 + (e & 31);
+        if (n < N) {
+            if (k < K) gW[(int64_t)n * K + k] = v;
+            else if (k == K && gb) gb[n] = v;
+        }
+    }
+}
+
 // LayerNorm over the last dim (biased variance, eps) + optional positional embedding add:
 // y[r, :] = LN(x[r, :]) * w + b (+ pe[r % ntok, :]).  16 lanes per row.   simple_vit.py:33,50,74,104-106,122
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ w,
@@ -130,15 +255,27 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     float* dots = lds + N * RS;           // [N][N]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* src = qkv + (int64_t)b * N * 3 * dh;
-    for (int e = tid; e < N * 3 * dh; e += nt) s_qkv[(e / (3 * dh)) * RS + e % (3 * dh)] = src[e];
+    for (int r = tid >> 6; r < N; r += nt >> 6)           // a wave per row: no index division
+        for (int c = tid & 63; c < 3 * dh; c += 64) s_qkv[r * RS + c] = src[r * 3 * dh + c];
     __syncthreads();
-    for (int e = tid; e < N * N; e += nt) {
-        const int i = e / N, j = e - i * N;
-        const float* q = s_qkv + i * RS;
+    // q k^T: a thread owns key j and 4 query rows - one k read feeds 4 FMAs (the q reads are wave broadcasts)
+    const int NQ = (N + 3) >> 2;
+    for (int e = tid; e < NQ * N; e += nt) {
+        const int iq = e / N, j = e - iq * N, i0 = iq * 4;
         const float* k = s_qkv + j * RS + dh;
-        float a0 = 0.f, a1 = 0.f;
-        for (int d = 0; d < dh; d += 2) { a0 = fmaf(q[d], k[d], a0); a1 = fmaf(q[d + 1], k[d + 1], a1); }
-        dots[e] = (a0 + a1) * scale;
+        const float* q0 = s_qkv + i0 * RS;
+        const float* q1 = s_qkv + min(i0 + 1, N - 1) * RS;
+        const float* q2 = s_qkv + min(i0 + 2, N - 1) * RS;
+        const float* q3 = s_qkv + min(i0 + 3, N - 1) * RS;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int d = 0; d < dh; ++d) {
+            const float kv = k[d];
+            a0 = fmaf(q0[d], kv, a0); a1 = fmaf(q1[d], kv, a1); a2 = fmaf(q2[d], kv, a2); a3 = fmaf(q3[d], kv, a3);
+        }
+        dots[i0 * N + j] = a0 * scale;
+        if (i0 + 1 < N) dots[(i0 + 1) * N + j] = a1 * scale;
+        if (i0 + 2 < N) dots[(i0 + 2) * N + j] = a2 * scale;
+        if (i0 + 3 < N) dots[(i0 + 3) * N + j] = a3 * scale;
     }
     __syncthreads();
     for (int i = tid; i < N; i += nt) {
@@ -150,11 +287,23 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
         for (int j = 0; j < N; ++j) dots[i * N + j] *= inv;
     }
     __syncthreads();
-    for (int e = tid; e < N * dh; e += nt) {
-        const int i = e / dh, d = e - i * dh;
-        float acc = 0.f;
-        for (int j = 0; j < N; ++j) acc = fmaf(dots[i * N + j], s_qkv[j * RS + 2 * dh + d], acc);
-        out[((int64_t)b * N + i) * dh + d] = acc;
+    // P v: a thread owns feature d of 4 output rows - one v read feeds 4 FMAs
+    for (int e = tid; e < NQ * dh; e += nt) {
+        const int iq = e / dh, d = e - iq * dh, i0 = iq * 4;
+        const float* p0 = dots + i0 * N;
+        const float* p1 = dots + min(i0 + 1, N - 1) * N;
+        const float* p2 = dots + min(i0 + 2, N - 1) * N;
+        const float* p3 = dots + min(i0 + 3, N - 1) * N;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float vv = s_qkv[j * RS + 2 * dh + d];
+            a0 = fmaf(p0[j], vv, a0); a1 = fmaf(p1[j], vv, a1); a2 = fmaf(p2[j], vv, a2); a3 = fmaf(p3[j], vv, a3);
+        }
+        float* o = out + ((int64_t)b * N + i0) * dh + d;
+        o[0] = a0;
+        if (i0 + 1 < N) o[dh] = a1;
+        if (i0 + 2 < N) o[2 * dh] = a2;
+        if (i0 + 3 < N) o[3 * dh] = a3;
     }
 }
 
@@ -190,6 +339,45 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
     if (act == 0) k_linear<0><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
     else if (act == 1) k_linear<1><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
     else k_linear<2><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+static int linear_wgrad_groups(int rows) {
+    const int chunks = (rows + WG_RC - 1) / WG_RC;
+    return chunks < 512 ? (chunks > 0 ? chunks : 1) : 512;      // two workgroups per CU
+}
+
+int64_t cf_linear_wgrad_ws_bytes(int rows, int K, int N) {
+    const int NT = (N + 31) / 32, KT = (K + 1 + 31) / 32;
+    return (int64_t)linear_wgrad_groups(rows) * NT * KT * 1024 * sizeof(float);
+}
+
+int cf_linear_wgrad(const float* x, const float* gy, float* gW, float* gb, void* ws, int rows, int K, int N,
+                    cf_stream_t stream) {
+    CF_REQUIRE(x && gy && gW && ws && rows >= 0 && K > 0 && N > 0);
+    const int NT = (N + 31) / 32, KT = (K + 1 + 31) / 32, ntiles = NT * KT;
+    if (NT + KT > WG_MAXF) { cf_set_error("cf_linear_wgrad: K=%d + N=%d wider than %d features", K, N, 32 * WG_MAXF - 1); return CF_ERR_UNSUPPORTED; }
+    const int G = linear_wgrad_groups(rows);
+    float* part = (float*)ws;
+    // full blocks of 4 WG_TPW tiles, then the remainder with exactly as many tile slots per wave as it needs
+    const int full = ntiles / (4 * WG_TPW), rem = ntiles - full * 4 * WG_TPW;
+    hipStream_t st = cf_s(stream);
+    if (full > 0) k_linear_wgrad<WG_TPW><<<dim3(G, full), dim3(256), 0, st>>>(x, gy, part, rows, K, N, NT, KT, 0);
+#define CF_WG_TAIL(T) k_linear_wgrad<T><<<dim3(G), dim3(256), 0, st>>>(x, gy, part, rows, K, N, NT, KT, full)
+    switch ((rem + 3) / 4) {
+        case 0: break;
+        case 1: CF_WG_TAIL(1); break;
+        case 2: CF_WG_TAIL(2); break;
+        case 3: CF_WG_TAIL(3); break;
+        case 4: CF_WG_TAIL(4); break;
+        case 5: CF_WG_TAIL(5); break;
+        case 6: CF_WG_TAIL(6); break;
+        case 7: CF_WG_TAIL(7); break;
+        default: CF_WG_TAIL(8); break;
+    }
+#undef CF_WG_TAIL
+    k_linear_wgrad_reduce<<<dim3(ntiles * 16), dim3(256), 0, cf_s(stream)>>>(part, gW, gb, K, N, KT, ntiles, G);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -55,6 +55,8 @@ SIGNATURES = {
     "cf_flow_step_fwd_taped": (_c_int, [_c_p] * 7 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_wgrad_ws_bytes": (_c_i64, [_c_int] * 6),
     "cf_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
+    "cf_linear_wgrad_ws_bytes": (_c_i64, [_c_int] * 3),
+    "cf_linear_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_p]),
     "cf_linear": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),
     "cf_layernorm": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_f, _c_p]),
     "cf_attention": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),

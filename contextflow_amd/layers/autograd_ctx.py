@@ -148,8 +148,7 @@ def transcoupling_ctx_backward(m, rec, context, gz, gld, grads):
     ga1 = _relu_bwd(rec["a1"], _linear_bwd(rec["a1"], m.CN[2], ga2, grads))
     gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads)
     _encoder_backward(m.context_net, context, gc, grads)
-    frozen = {}                                   # the ViT's own parameter gradients: computed by the shared chain, unused
-    gx[:, :half] += vit_backward(m.NN[0], vtape, ghd, frozen)
+    gx[:, :half] += vit_backward(m.NN[0], vtape, ghd, None)       # grads = None: the ViT is frozen, data gradient only
     return gx
 
 

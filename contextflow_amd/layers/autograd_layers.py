@@ -19,12 +19,32 @@ def _new(*shape, like):
 
 # ------------------------------------------------------------------------------------------------ small pieces
 def _linear_bwd(x_in, lin, gy, grads, need_gx=True):
-    """y = x W^T + b: gx = gy W, gW = gy^T x, gb = column sums."""
+    """y = x W^T + b: gx = gy W (cf_linear with the transposed weight), gW = gy^T x and gb = column sums (cf_linear_wgrad:
+    split-K MFMA GEMM over the rows).  grads = None: the layer is frozen, only gx is computed."""
     W = _hip.f32(lin.weight.detach())
-    grads[lin.weight] = gy.t() @ x_in
-    if lin.bias is not None:
-        grads[lin.bias] = gy.sum(0)
-    return gy @ W if need_gx else None
+    N, K = W.shape
+    rows = x_in.shape[0]
+    gy = gy.contiguous()
+    st = _hip.stream()
+    if grads is not None and (N + 31) // 32 + (K + 32) // 32 > 12:     # wider than cf_linear_wgrad's LDS stage: library GEMM
+        grads[lin.weight] = gy.t() @ x_in
+        if lin.bias is not None:
+            grads[lin.bias] = gy.sum(0)
+    elif grads is not None:
+        x_in = x_in.contiguous()
+        gW = _new(N, K, like=gy)
+        gb = _new(N, like=gy) if lin.bias is not None else None
+        ws = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, K, N), device=gy.device, dtype=torch.uint8)
+        _hip.call("cf_linear_wgrad", _hip.p(x_in), _hip.p(gy), _hip.p(gW), _hip.p(gb), _hip.p(ws), rows, K, N, st)
+        grads[lin.weight] = gW
+        if gb is not None:
+            grads[lin.bias] = gb
+    if not need_gx:
+        return None
+    gx = _new(rows, K, like=gy)
+    Wt = W.t().contiguous()
+    _hip.call("cf_linear", _hip.p(gy), _hip.p(Wt), None, None, _hip.p(gx), rows, N, K, 0, st)
+    return gx
 
 
 def _layernorm_bwd(x_in, ln, gy, grads):
@@ -34,8 +54,9 @@ def _layernorm_bwd(x_in, ln, gy, grads):
     part = _new(nparts, 2 * dim, like=x_in)
     _hip.call("cf_layernorm_bwd", _hip.p(x_in), _hip.p(_hip.f32(ln.weight.detach())), _hip.p(gy), _hip.p(gx), _hip.p(part),
               rows, dim, float(ln.eps), _hip.stream())
-    s = part.sum(0)
-    grads[ln.weight], grads[ln.bias] = s[:dim], s[dim:]
+    if grads is not None:
+        s = part.sum(0)
+        grads[ln.weight], grads[ln.bias] = s[:dim], s[dim:]
     return gx
 
 

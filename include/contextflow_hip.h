@@ -187,6 +187,12 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
  * act: 0 none, 1 exact (erf) GELU, 2 ReLU.   nn.Linear of patch embedding / to_qkv / to_out / FeedForward; CN nets. */
 int cf_linear(const float* x, const float* Wt, const float* bias, const float* res, float* y,
               int rows, int K, int N, int act, cf_stream_t stream);
+/* backward of cf_linear w.r.t. its parameters: gW (N,K) = gy^T x, gb (N) = column sums of gy (gb may be NULL); split-K
+ * fp32-MFMA GEMM over the rows, partials in ws (cf_linear_wgrad_ws_bytes) summed in a fixed order.
+ * ceil(N/32) + ceil((K+1)/32) <= 12 (the ViT widths of every preset); wider: CF_ERR_UNSUPPORTED.                */
+int64_t cf_linear_wgrad_ws_bytes(int rows, int K, int N);
+int cf_linear_wgrad(const float* x, const float* gy, float* gW, float* gb, void* ws, int rows, int K, int N,
+                    cf_stream_t stream);
 /* y[r,:] = LayerNorm(x[r,:])*w + b (+ pos[r % ntok,:] if pos != NULL); biased variance, eps.          */
 int cf_layernorm(const float* x, const float* w, const float* b, const float* pos, float* y,
                  int rows, int dim, int ntok, float eps, cf_stream_t stream);

@@ -750,6 +750,15 @@ def test_layer_backward_kernels_against_torch(L):
         yl = torch.full((rows, N), float("nan"), device=DEV)
         _hip.call("cf_linear", P(xl), P(wl), P(bl), P(rl) if use_res else None, _hip.p(yl), rows, K, N, act, st())
         assert (yl.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (rows, K, N, act)
+    # weight / bias gradient of a Linear: split-K over the rows (ragged last chunk, > 256 chunks, several tile blocks)
+    for rows, K, N in ((300, 152, 152), (36 * 300 + 5, 152, 192), (129, 7, 200), (64, 33, 5), (2000, 150, 200), (5, 64, 64)):
+        xl = torch.randn(rows, K, generator=g); gl = torch.randn(rows, N, generator=g)
+        gW, gb = torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV)
+        wsb = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, K, N), device=DEV, dtype=torch.uint8)
+        _hip.call("cf_linear_wgrad", P(xl), P(gl), _hip.p(gW), _hip.p(gb), _hip.p(wsb), rows, K, N, st())
+        rW, rb = gl.double().t() @ xl.double(), gl.double().sum(0)
+        assert (gW.cpu().double() - rW).abs().max() < 2e-5 * max(1.0, rW.abs().max().item()), (rows, K, N)
+        assert (gb.cpu().double() - rb).abs().max() < 2e-5 * max(1.0, rb.abs().max().item()), (rows, K, N)
     # GELU
     xg = torch.randn(1000, generator=g) * 2; gg = torch.randn(1000, generator=g)
     x64 = xg.double().requires_grad_(True)
