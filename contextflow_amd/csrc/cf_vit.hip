@@ -13,7 +13,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LIN_ROWS = 128;     // rows per workgroup (4 waves x 32)
-constexpr int LIN_COLS = 96;      // output features per workgroup (3 MFMA column tiles)
 constexpr int LIN_KC = 32;        // K chunk staged in LDS per pass
 constexpr int LIN_KP = LIN_KC + 1;   // odd row stride: conflict-free operand reads (lane -> row)
 
@@ -21,33 +20,38 @@ constexpr int LIN_KP = LIN_KC + 1;   // odd row stride: conflict-free operand re
 // ACT: 0 none, 1 exact GELU (erf), 2 ReLU             simple_vit.py:32-38,52-53; coupling.py:37 (CN nets)
 // K is walked in chunks of 32 through a 29 KiB LDS stage (any K; 4-5 workgroups per CU overlap each other's staging
 // and MFMA phases); the next chunk's global loads are issued into registers before the MFMAs of the current one.
-template <int ACT>
+template <int ACT, int NTL>
 __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, const float* __restrict__ Wt,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 float* __restrict__ y, int rows, int K, int N) {
     __shared__ float xs[LIN_ROWS * LIN_KP];
+    constexpr int LIN_COLS = 32 * NTL;                 // output features per workgroup (NTL MFMA column tiles)
     __shared__ float ws[LIN_COLS * LIN_KP];
-    constexpr int NXI = LIN_ROWS * LIN_KC / 256, NWI = LIN_COLS * LIN_KC / 256;   // staged elements per thread: 16 + 12
+    constexpr int NXI = LIN_ROWS * LIN_KC / 256, NWI = LIN_COLS * LIN_KC / 256;   // staged elements per thread: 16 + 4 NTL
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * LIN_ROWS, n0 = blockIdx.y * LIN_COLS;
     const int sk = tid & 31, sr = tid >> 5;              // staging: column k of the chunk, first row (rows sr + 8 i)
+    // branch-free fetch: clamped 32-bit offsets from the workgroup's base pointers (the values of out-of-range
+    // positions are replaced by zeros afterwards), all loads of a chunk in flight together
+    const float* __restrict__ xb = x + (int64_t)r0 * K;
+    const float* __restrict__ wbp = Wt + (int64_t)n0 * K;
+    const int rmax = rows - 1 - r0, nmax = N - 1 - n0;
+    int xo[NXI], wo[NWI];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) xo[i] = min(sr + 8 * i, rmax) * K;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) wo[i] = min(sr + 8 * i, nmax) * K;
     float xr[NXI], wr[NWI];
     auto fetch = [&](int k0) {
-        const int k = k0 + sk;
+        const int kc = min(k0 + sk, K - 1);
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) {
-            const int r = r0 + sr + 8 * i;
-            xr[i] = (r < rows && k < K) ? x[(int64_t)r * K + k] : 0.f;
-        }
+        for (int i = 0; i < NXI; ++i) xr[i] = xb[xo[i] + kc];
 #pragma unroll
-        for (int i = 0; i < NWI; ++i) {
-            const int n = n0 + sr + 8 * i;
-            wr[i] = (n < N && k < K) ? Wt[(int64_t)n * K + k] : 0.f;
-        }
+        for (int i = 0; i < NWI; ++i) wr[i] = wbp[wo[i] + kc];
     };
-    f32x16 acc[3];
+    f32x16 acc[NTL];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NTL; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     const int li = lane & 31, lk = lane >> 5;
@@ -55,17 +59,18 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
     const float* wb = ws + li * LIN_KP + lk;                    // B[k][j = feature]
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += LIN_KC) {
+        const bool kin = k0 + sk < K;                     // masks are applied here, after the loads have landed
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) xs[(sr + 8 * i) * LIN_KP + sk] = xr[i];
+        for (int i = 0; i < NXI; ++i) xs[(sr + 8 * i) * LIN_KP + sk] = (kin && sr + 8 * i <= rmax) ? xr[i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < NWI; ++i) ws[(sr + 8 * i) * LIN_KP + sk] = wr[i];
+        for (int i = 0; i < NWI; ++i) ws[(sr + 8 * i) * LIN_KP + sk] = (kin && sr + 8 * i <= nmax) ? wr[i] : 0.f;
         __syncthreads();
         if (k0 + LIN_KC < K) fetch(k0 + LIN_KC);
 #pragma unroll
         for (int kk = 0; kk < LIN_KC; kk += 2) {
             const float a = xa[kk];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NTL; ++t) {
                 const float b = wb[t * 32 * LIN_KP + kk];
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
             }
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
     }
     // D[i][j]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NTL; ++t) {
         const int n = n0 + t * 32 + li;
         if (n >= N) continue;
         const float bv = bias ? bias[n] : 0.f;
@@ -335,10 +340,19 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
               int act, cf_stream_t stream) {
     if (rows == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && Wt && y && rows >= 0 && K > 0 && N > 0 && act >= 0 && act <= 2);
-    dim3 grid((rows + LIN_ROWS - 1) / LIN_ROWS, (N + LIN_COLS - 1) / LIN_COLS);
-    if (act == 0) k_linear<0><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
-    else if (act == 1) k_linear<1><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
-    else k_linear<2><<<grid, dim3(256), 0, cf_s(stream)>>>(x, Wt, bias, res, y, rows, K, N);
+    // column tiles per workgroup: 3 (96 features).  5 / 6 tiles (N = 152 / 192 in one pass, no padded MFMA work) were
+    // measured: faster at 65 K rows, slower at 147 K rows and in the ATM forward end to end - fewer, longer workgroups
+    // quantise worse over the 256 CUs (tools/dev/lin_sweep.py)
+    const int nt = (N + 31) / 32, ntl = 3;
+    dim3 grid((rows + LIN_ROWS - 1) / LIN_ROWS, (nt + ntl - 1) / ntl);
+    hipStream_t st = cf_s(stream);
+#define CF_LIN(A, T) k_linear<A, T><<<grid, dim3(256), 0, st>>>(x, Wt, bias, res, y, rows, K, N)
+#define CF_LIN_A(T) (act == 0 ? CF_LIN(0, T) : (act == 1 ? CF_LIN(1, T) : CF_LIN(2, T)))
+    if (ntl == 3) CF_LIN_A(3);
+    else if (ntl == 5) CF_LIN_A(5);
+    else CF_LIN_A(6);
+#undef CF_LIN_A
+#undef CF_LIN
     CF_LAUNCH_CHECK();
     return 0;
 }
