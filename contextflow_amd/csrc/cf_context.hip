@@ -566,6 +566,34 @@ __global__ __launch_bounds__(256) void k_add_repeat(float* __restrict__ h, const
     }
 }
 
+// Gradient w.r.t. the prior's OWN parameters for specialists trained without contextflow (gaussian.py:130-137: mG / sG / wG
+// stay trainable), table form of the scale shifts:
+//   gm[mk][e] = sum_b r[b][mk] d / sig^2,   gs[mk][e] = sum_b r[b][mk] (d^2 / sig^3 - 1 / sig) softplus'(s)
+// with d = x - mu - cm, r = upstream gradient x responsibility.  A thread owns one (mk, e) and walks a slab of SB
+// samples; the per-slab partials (nb, MK, N) are summed by the caller in slab order.
+__global__ __launch_bounds__(256) void k_gmm_ctx_pgrad(const float* __restrict__ x, const float* __restrict__ mG,
+                                                       const float* __restrict__ c, const float* __restrict__ r,
+                                                       float* __restrict__ pgm, float* __restrict__ pgs, int B, int MK,
+                                                       int D, int HW, int64_t xbs, int SB, GmmTab tb) {
+    const int N = D * HW, e = blockIdx.x * 256 + threadIdx.x, mk = blockIdx.y;
+    if (e >= N) return;
+    const int d = e / HW, b0 = blockIdx.z * SB, b1 = min(B, b0 + SB);
+    const float mu = mG[(int64_t)mk * N + e];
+    float am = 0.f, as = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const int64_t o = ((int64_t)tb.key[b] * MK + mk) * N + e;
+        const float rb = r[(int64_t)b * MK + mk];
+        const float iv = tb.inv[o], ds = tb.dsig[o];
+        const float dd = x[(int64_t)b * xbs + e] - mu - c[(int64_t)b * 2 * MK * D + mk * D + d];
+        const float q = dd * iv * iv;
+        am = fmaf(rb, q, am);
+        as = fmaf(rb, (dd * q * iv - iv) * ds, as);
+    }
+    const int64_t po = ((int64_t)blockIdx.z * MK + mk) * N + e;
+    pgm[po] = am;
+    pgs[po] = as;
+}
+
 // samples per workgroup of the context-GMM kernels: as many as fit (x of S samples + the log-joint scratch in LDS)
 static int gmm_ctx_group(int N, int MK, size_t* lds) {
     for (int S = 4; S >= 1; S >>= 1) {
@@ -790,6 +818,19 @@ int cf_gmm_ctx_bwd_tab(const float* x, const float* mG, const float* inv_sig, co
     int rc = gmm_ctx_bwd_launch<true>("cf_gmm_ctx_bwd_tab", x, mG, nullptr, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride,
                                       GmmTab{inv_sig, dsig, lsum, key}, cf_s(stream));
     if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_ctx_pgrad_tab(const float* x, const float* mG, const float* inv_sig, const float* dsig, const float* c,
+                          const int* key, const float* r, float* pgm, float* pgs, int B, int M, int K, int D, int HW,
+                          int64_t x_bstride, int slab, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && mG && inv_sig && dsig && c && key && r && pgm && pgs && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0 && slab > 0);
+    const int N = D * HW, nb = (B + slab - 1) / slab;
+    CF_REQUIRE(M * K <= 65535 && nb <= 65535);
+    k_gmm_ctx_pgrad<<<dim3((N + 255) / 256, M * K, nb), dim3(256), 0, cf_s(stream)>>>(
+        x, mG, c, r, pgm, pgs, B, M * K, D, HW, x_bstride, slab, GmmTab{inv_sig, dsig, nullptr, key});
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
             int soff[PTW];
 #pragma unroll
             for (int q = 0; q < PTW; ++q) soff[q] = min(smp[q], B - 1) * (CTX == 1 ? C : HID);
-            conditioner_net<G, CTX>(acc3, lds, wsl, pix, pin, lane, tid, dbg, dbg_cols, tile, sb, soff);
+            conditioner_net<G, CTX, DUMP>(acc3, lds, wsl, pix, pin, lane, tid, dbg, dbg_cols, tile, sb, soff, tp, B);
         }
 
         float lsum[PTW];
@@ -561,6 +561,33 @@ int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* w
         default: cf_set_error("cf_flow_step_fwd_ctx: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEPC
+    if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// training forward of the specialist coupling WITHOUT contextflow (mode 2: CN(c) enters before the first ReLU and every
+// parameter trains): cf_flow_step_fwd_ctx that also writes the tape planes of cf_flow_step_fwd_taped.  The per-sample
+// bias only shapes h1, which the backward loads - cf_flow_step_bwd_taped needs no context argument.
+int cf_flow_step_fwd_ctx_taped(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, float* t_y0,
+                               float* t_h1, float* t_h2, int B, int C, int H, int W, int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && z && ldj_acc && ws && sbias && t_y0 && t_h1 && t_h2 && x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(t_y0) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_h1) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0);
+    const float* w = (const float*)ws;
+    const StepTape tp{t_y0, t_h1, t_h2};
+    int rc = 0;
+#define CF_STEPCT(G) rc = launch_step<G, false, 2, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), sbias, tp)
+    switch (shape_id(C, H, W)) {
+        case 0: CF_STEPCT(G8); break;
+        case 1: CF_STEPCT(G16); break;
+        case 2: CF_STEPCT(G32); break;
+        case 3: CF_STEPCT(G64); break;
+        default: cf_set_error("cf_flow_step_fwd_ctx_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+    }
+#undef CF_STEPCT
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;

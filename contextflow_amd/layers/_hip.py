@@ -75,6 +75,7 @@ SIGNATURES = {
     "cf_gelu": (_c_int, [_c_p] * 3 + [_c_i64, _c_int, _c_p]),
     "cf_coupling_apply_bwd": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
     "cf_channel_sums": (_c_int, [_c_p] * 3 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
+    "cf_flow_step_fwd_ctx_taped": (_c_int, [_c_p] * 8 + [_c_int] * 4 + [_c_i64, _c_p]),
     "cf_flow_step_fwd_ctx": (_c_int, [_c_p] * 5 + [_c_int] * 5 + [_c_i64, _c_p]),
     "cf_flow_step_bwd_ctx": (_c_int, [_c_p] * 14 + [_c_int] * 4 + [_c_i64, _c_p]),
     "cf_conv1x1_ctx_bwd": (_c_int, [_c_p] * 7 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "cf_gmm_ctx_tables": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),
     "cf_gmm_ctx_logprob_tab": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
     "cf_gmm_ctx_bwd_tab": (_c_int, [_c_p] * 12 + [_c_int] * 5 + [_c_i64, _c_p]),
+    "cf_gmm_ctx_pgrad_tab": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
     "cf_gmm_ctx_bwd": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_i64, _c_p]),
     "cf_add_repeat": (_c_int, [_c_p] * 2 + [_c_int] * 4 + [_c_p]),
     "cf_cond_gauss_sample": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_p]),

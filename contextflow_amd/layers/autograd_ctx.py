@@ -25,12 +25,18 @@ def _new(*shape, like):
 
 
 def trainable(flow):
-    """True when this specialist flow can be trained here: contextflow (frozen generalist), conv or transformer
-    couplings, context encoders without trainable parameters of their own (uniform dequantisation, embedding lookup)."""
+    """True when this specialist flow can be trained here: context encoders without trainable parameters of their own
+    (uniform dequantisation, embedding lookup); contextflow (frozen generalist) with conv or transformer couplings, or
+    every parameter training (no contextflow) with conv couplings."""
     ok = (UniformCatDequantization, EyeSampling)
     for m in list(flow.sequence_modules) + [flow.dist]:
         cn = getattr(m, "context_net", None) or getattr(getattr(m, "dist", None), "context_net", None)
-        if cn and (not isinstance(cn[1], ok) or not getattr(m, "contextflow", getattr(getattr(m, "dist", None), "contextflow", False))):
+        if not cn:
+            continue
+        if not isinstance(cn[1], ok):
+            return False
+        cf = getattr(m, "contextflow", getattr(getattr(m, "dist", None), "contextflow", False))
+        if not cf and isinstance(m, TransCoupling):
             return False
     return True
 
@@ -98,33 +104,68 @@ def actnorm_ctx_backward(m, rec, context, gz, gld, grads):
     return gx
 
 
-def coupling_ctx_backward(m, rec, context, gz, gld, grads):
-    """Coupling under contextflow: the fused step-backward kernel (identity 1x1 / ActNorm in front, per-sample bias in the
-    recompute); d/d CN(c) = per-sample row sums of the conditioner-output gradient plane."""
-    if rec["mode"] != 1:
-        raise NotImplementedError("specialist training without contextflow (all parameters train; not built)")
-    x, xbs = _hip.bview(rec["x"])
-    B, C, H, W = x.shape
-    HW = H * W
-    dev, st, f, pp, L = x.device, _hip.stream(), _hip.f32, _hip.p, _hip.lib()
-    c1, c2, c3 = m.NN[0], m.NN[2], m.NN[4]
-    eye = torch.eye(C, device=dev, dtype=torch.float32)
-    zero = torch.zeros(C, device=dev, dtype=torch.float32)
-    wsb = torch.empty(L.cf_flow_step_bwd_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
-    _hip.call("cf_flow_step_bwd_prepare", pp(eye), pp(zero), pp(f(c1.weight.detach())), pp(f(c2.weight.detach())),
-              pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
-    gx = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
-    s_gh = torch.empty(B, C, HW, device=dev, dtype=torch.float32)     # the only plane this mode writes (frozen weights)
-    gzc = f(gz).contiguous()
-    _hip.call("cf_flow_step_bwd_ctx", pp(x), pp(gzc), pp(f(gld)), pp(rec["ws"]), pp(wsb), pp(rec["cn"]), pp(gx), None,
-              None, None, pp(s_gh), None, None, None, B, C, H, W, xbs, st)
-    gcn = _new(B, C, like=x)
-    _hip.call("cf_sample_channel_sums", pp(s_gh), pp(gcn), B, C, HW, st)
-    # CN = Linear -> ReLU -> Linear -> ReLU -> Linear   (coupling.py:37)
+def _cn_chain_backward(m, rec, context, gcn, grads):
+    """CN = Linear -> ReLU -> Linear -> ReLU -> Linear (coupling.py:37) and the context encoder behind it."""
     ga2 = _relu_bwd(rec["a2"], _linear_bwd(rec["a2"], m.CN[4], gcn, grads))
     ga1 = _relu_bwd(rec["a1"], _linear_bwd(rec["a1"], m.CN[2], ga2, grads))
     gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads)
     _encoder_backward(m.context_net, context, gc, grads)
+
+
+def coupling_ctx_backward(m, rec, context, gz, gld, grads):
+    """Coupling with a context net through the fused step-backward kernel (identity 1x1 / ActNorm in front).
+    contextflow (mode 1): the conditioner is frozen, CN(c) is a bias on its output - d/d CN(c) = per-sample row sums of the
+    conditioner-output gradient plane.  Without contextflow (mode 2): CN(c) enters through the extra input channels of
+    the first 1x1 (a per-sample bias before its ReLU) and every parameter trains - the backward kernel loads the planes the
+    forward taped, the weight gradients are the generalist's GEMMs plus two small products for the context columns."""
+    x, xbs = _hip.bview(rec["x"])
+    B, C, H, W = x.shape
+    HW, D, HID = H * W, C // 2, 2 * C
+    dev, st, f, pp, L = x.device, _hip.stream(), _hip.f32, _hip.p, _hip.lib()
+    c1, c2, c3 = m.NN[0], m.NN[2], m.NN[4]
+    w1 = f(c1.weight.detach())
+    eye = torch.eye(C, device=dev, dtype=torch.float32)
+    zero = torch.zeros(C, device=dev, dtype=torch.float32)
+    wsb = torch.empty(L.cf_flow_step_bwd_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+    w1x = w1 if rec["mode"] == 1 else w1[:, :D].contiguous()
+    _hip.call("cf_flow_step_bwd_prepare", pp(eye), pp(zero), pp(w1x), pp(f(c2.weight.detach())),
+              pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
+    gx = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+    s_gh = torch.empty(B, C, HW, device=dev, dtype=torch.float32)
+    gzc = f(gz).contiguous()
+    if rec["mode"] == 1:                                                  # s_gh is the only plane this mode writes
+        _hip.call("cf_flow_step_bwd_ctx", pp(x), pp(gzc), pp(f(gld)), pp(rec["ws"]), pp(wsb), pp(rec["cn"]), pp(gx), None,
+                  None, None, pp(s_gh), None, None, None, B, C, H, W, xbs, st)
+        gcn = _new(B, C, like=x)
+        _hip.call("cf_sample_channel_sums", pp(s_gh), pp(gcn), B, C, HW, st)
+        _cn_chain_backward(m, rec, context, gcn, grads)
+        return gx
+    new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
+    y0, h1, h2 = rec["planes"]
+    s_gh2, s_gh1, s_gy = new(HID), new(HID), new(C)
+    _hip.call("cf_flow_step_bwd_taped", pp(x), pp(gzc), pp(f(gld)), pp(rec["ws"]), pp(wsb), pp(gx), pp(y0), pp(h1), pp(h2),
+              pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, 0, st)
+
+    def wgrad(A, Bm, taps):
+        MR, NR = A.shape[1], Bm.shape[1]
+        gw = torch.empty(taps, MR, NR, device=dev, dtype=torch.float32)
+        gb = torch.empty(MR, device=dev, dtype=torch.float32)
+        wsw = torch.empty(L.cf_wgrad_ws_bytes(B, MR, NR, H, W, taps), device=dev, dtype=torch.uint8)
+        _hip.call("cf_wgrad", pp(A), pp(Bm), pp(gw), pp(gb), pp(wsw), B, MR, NR, H, W, taps, st)
+        return gw, gb
+
+    gw3, gb3 = wgrad(s_gh, h2, 1)
+    gw2, gb2 = wgrad(s_gh2, h1, 9)
+    gw1, gb1 = wgrad(s_gh1, y0, 1)
+    # context columns of the first 1x1: its input there is CN(c), constant over the pixels
+    s1 = _new(B, HID, like=x)
+    _hip.call("cf_sample_channel_sums", pp(s_gh1), pp(s1), B, HID, HW, st)
+    wc = w1[:, D:, 0, 0]                                                  # (HID, O)
+    grads[c1.weight] = torch.cat([gw1[0], s1.t() @ rec["cn"]], dim=1).reshape(c1.weight.shape)
+    grads[c1.bias] = gb1
+    grads[c2.weight], grads[c2.bias] = gw2.permute(1, 2, 0).reshape(c2.weight.shape), gb2
+    grads[c3.weight], grads[c3.bias] = gw3[0].reshape(c3.weight.shape), gb3
+    _cn_chain_backward(m, rec, context, s1 @ wc, grads)
     return gx
 
 
@@ -144,10 +185,7 @@ def transcoupling_ctx_backward(m, rec, context, gz, gld, grads):
               B, C, H * W, xbs, gzbs, st)
     gcn = _new(B, C, like=x)
     _hip.call("cf_sample_channel_sums", _hip.p(ghd), _hip.p(gcn), B, C, H * W, st)
-    ga2 = _relu_bwd(rec["a2"], _linear_bwd(rec["a2"], m.CN[4], gcn, grads))
-    ga1 = _relu_bwd(rec["a1"], _linear_bwd(rec["a1"], m.CN[2], ga2, grads))
-    gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads)
-    _encoder_backward(m.context_net, context, gc, grads)
+    _cn_chain_backward(m, rec, context, gcn, grads)
     gx[:, :half] += vit_backward(m.NN[0], vtape, ghd, None)       # grads = None: the ViT is frozen, data gradient only
     return gx
 
@@ -170,6 +208,21 @@ def gmm_ctx_backward(dist, rec, g, grads):
                   _hip.p(rec["logw"]), _hip.p(rec["c"]), _hip.p(_hip.f32(g)), _hip.p(rec.get("lp")), _hip.p(gx), _hip.p(gc), B, M,
                   K, D, H * W, xbs, _hip.stream())
     _embedding_grads(dist.context_net[0], rec["context"], gc, grads)
+    if not dist.contextflow:                  # the prior's own parameters train too (gaussian.py:130-137)
+        if tab is None or rec.get("lp") is None:
+            raise NotImplementedError("prior parameter gradients need the embedding-lookup context net (table form)")
+        gf = _hip.f32(g)
+        r = (torch.softmax(rec["lp"].view(B, M, K), dim=-1) * gf.unsqueeze(-1)).reshape(B, M * K).contiguous()
+        slab = 256
+        nb = (B + slab - 1) // slab
+        pgm = _new(nb, M * K, D * H * W, like=x)
+        pgs = _new(nb, M * K, D * H * W, like=x)
+        _hip.call("cf_gmm_ctx_pgrad_tab", _hip.p(x), _hip.p(_hip.f32(dist.mG.detach())), _hip.p(inv), _hip.p(dsig),
+                  _hip.p(rec["c"]), _hip.p(key), _hip.p(r), _hip.p(pgm), _hip.p(pgs), B, M, K, D, H * W, xbs, slab, _hip.stream())
+        grads[dist.mG] = pgm.sum(0).view_as(dist.mG)
+        grads[dist.sG] = pgs.sum(0).view_as(dist.sG)
+        R = r.sum(0).view(M, K)
+        grads[dist.wG] = R - R.sum(-1, keepdim=True) * torch.softmax(_hip.f32(dist.wG.detach()), dim=-1)
     return gx
 
 

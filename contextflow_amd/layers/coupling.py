@@ -138,9 +138,16 @@ class Coupling(_AffineCoupling):
                   pp(ws), C, H, W, st)
         z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
         ldj = torch.zeros(B, device=dev, dtype=torch.float32)
-        _hip.call("cf_flow_step_fwd_ctx", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), mode, B, C, H, W, xbs, st)
+        planes = None
+        if tape is not None and mode == 2:
+            # every parameter trains: the forward kernel also writes y0 / h1 / h2 and the backward loads them
+            planes = tuple(torch.empty(B, r, H * W, device=dev, dtype=torch.float32) for r in (D, 2 * C, 2 * C))
+            _hip.call("cf_flow_step_fwd_ctx_taped", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), pp(planes[0]), pp(planes[1]),
+                      pp(planes[2]), B, C, H, W, xbs, st)
+        else:
+            _hip.call("cf_flow_step_fwd_ctx", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), mode, B, C, H, W, xbs, st)
         if tape is not None:
-            tape.append(dict(x=x, c=c, a1=a1, a2=a2, cn=cn, ws=ws, mode=mode))
+            tape.append(dict(x=x, c=c, a1=a1, a2=a2, cn=cn, ws=ws, mode=mode, planes=planes))
         return z, ldj + logp_c * float(H * W)
 
     def _fused_ctx_ok(self, x):

@@ -167,6 +167,10 @@ int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const vo
  * instead of recomputing the two big contractions, and leaves them in place as operands of cf_wgrad. */
 int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* t_y0, float* t_h1, float* t_h2,
                            int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
+/* specialist coupling without contextflow (coupling.py:45-47: CN(c) concatenated to the conditioner input = per-sample
+ * bias sbias (B, 2C) before the first ReLU): training forward with the tape planes; backward = cf_flow_step_bwd_taped. */
+int cf_flow_step_fwd_ctx_taped(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, float* t_y0,
+                               float* t_h1, float* t_h2, int B, int C, int H, int W, int64_t x_bstride, cf_stream_t stream);
 int cf_flow_step_bwd_taped(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
                            const float* t_y0, const float* t_h1, const float* t_h2, float* s_gh, float* s_gh2,
                            float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, int in_squeeze,
@@ -318,6 +322,12 @@ int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float
 int cf_gmm_ctx_bwd_tab(const float* x, const float* mG, const float* inv_sig, const float* dsig, const float* lsum,
                        const float* logw, const float* c, const int* key, const float* g, const float* lp, float* gx,
                        float* gc, int B, int M, int K, int D, int HW, int64_t x_bstride, cf_stream_t stream);
+/* specialists trained WITHOUT contextflow keep the prior's own parameters trainable (gaussian.py:130-137): per-slab
+ * partial sums pgm / pgs (ceil(B/slab), M*K, D*HW) of d/d mG and d/d sG; r (B, M*K) = upstream gradient x responsibility
+ * (softmax_k of the kept log-joints); the caller sums the slabs in order.                                          */
+int cf_gmm_ctx_pgrad_tab(const float* x, const float* mG, const float* inv_sig, const float* dsig, const float* c,
+                          const int* key, const float* r, float* pgm, float* pgs, int B, int M, int K, int D, int HW,
+                          int64_t x_bstride, int slab, cf_stream_t stream);
 
 /* h[b,c2,:] += x[b, c2 % C, :] in place: identity branch of MaskedResidualBlock2d (`--coupling maf`,
  * layers/autoregressive/masked_conv_2d.py:93-98)                                                                */

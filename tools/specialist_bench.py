@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of the specialist (context-conditioned) forward, layer by layer.  usage: specialist_bench.py [B] [iters]"""
+"""Throughput of the specialist (context-conditioned) forward, layer by layer.
+usage: specialist_bench.py [B] [iters] [only: index of one configuration]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,9 +9,12 @@ import contextflow_amd as cfa
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = "cuda:0"
-for name, contexts, emb, cf, typ in (("cifar10", [15, 5], "onehot", True, "uniform"), ("cifar10", [15, 5], "eye", False, "uniform"),
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+for idx, (name, contexts, emb, cf, typ) in enumerate((("cifar10", [15, 5], "onehot", True, "uniform"), ("cifar10", [15, 5], "eye", False, "uniform"),
                                      ("cifar10", [15, 5], "onehot", False, "vardeq"), ("mnist", [64], "eye", True, "uniform"),
-                                     ("smap", [55], "onehot", True, "uniform")):
+                                     ("smap", [55], "onehot", True, "uniform"))):
+    if only is not None and idx != only:
+        continue
     torch.manual_seed(0)
     cfg, ds, M = cfa.preset_config(name)
     cfg.update(generalist=False, enc_emb=emb, enc_type=typ, contextflow=cf)
