@@ -12,7 +12,8 @@ import torch
 
 from . import _hip
 from .actnorm import ActNorm
-from .context import CatEmbeddings, EyeSampling, UniformCatDequantization
+from .context import (ArgmaxCatDequantization, CatEmbeddings, EyeSampling, ProbSampling, UniformCatDequantization,
+                      VariationalCatDequantization)
 from .conv1x1 import Conv1x1
 from .coupling import Coupling, TransCoupling
 from .permute_axes import PermuteAxes
@@ -28,7 +29,7 @@ def trainable(flow):
     """True when this specialist flow can be trained here: context encoders without trainable parameters of their own
     (uniform dequantisation, embedding lookup); contextflow (frozen generalist) with conv or transformer couplings, or
     every parameter training (no contextflow) with conv couplings."""
-    ok = (UniformCatDequantization, EyeSampling)
+    ok = (UniformCatDequantization, EyeSampling, VariationalCatDequantization, ArgmaxCatDequantization, ProbSampling)
     for m in list(flow.sequence_modules) + [flow.dist]:
         cn = getattr(m, "context_net", None) or getattr(getattr(m, "dist", None), "context_net", None)
         if not cn:
@@ -42,15 +43,129 @@ def trainable(flow):
 
 
 def _check_encoder(enc):
-    if not isinstance(enc[1], (UniformCatDequantization, EyeSampling)):
-        raise NotImplementedError("specialist training with a %s context encoder (it has trainable parameters of its own)"
-                                  % type(enc[1]).__name__)
+    if not isinstance(enc[1], (UniformCatDequantization, EyeSampling, VariationalCatDequantization, ArgmaxCatDequantization,
+                               ProbSampling)):
+        raise NotImplementedError("specialist training with a %s context encoder" % type(enc[1]).__name__)
 
 
-def _encoder_backward(enc, context, gc, grads):
-    """d/d of the encoder output c: only the embedding lookup (embed + eyesample) has parameters."""
-    if isinstance(enc[0], CatEmbeddings):
-        _embedding_grads(enc[0], context, gc, grads)
+def _encoder_backward(enc, context, gc, grads, glq=None):
+    """d/d of the encoder's outputs: gc = d/dc (B, width), glq = d/d logp_c (B).  uniform / eyesample encoders have no
+    parameters of their own (only the embedding lookup in front has); vardeq / argmax / probsample draw their noise from a
+    small conditional flow whose parameters train (model.py:52-79)."""
+    if isinstance(enc[1], (UniformCatDequantization, EyeSampling)):
+        if isinstance(enc[0], CatEmbeddings):
+            _embedding_grads(enc[0], context, gc, grads)
+        return
+    _flow_encoder_backward(enc[1], context, gc, glq, grads)
+
+
+def _dense_bwd(x_in, W2d, gy, need_gx=True):
+    """y = x W^T (+ b): (gx, gW, gb) through cf_linear / cf_linear_wgrad."""
+    N, K = W2d.shape
+    rows = x_in.shape[0]
+    gy, x_in, st = gy.contiguous(), x_in.contiguous(), _hip.stream()
+    gW, gb = _new(N, K, like=gy), _new(N, like=gy)
+    ws = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, K, N), device=gy.device, dtype=torch.uint8)
+    _hip.call("cf_linear_wgrad", _hip.p(x_in), _hip.p(gy), _hip.p(gW), _hip.p(gb), _hip.p(ws), rows, K, N, st)
+    gx = None
+    if need_gx:
+        gx = _new(rows, K, like=gy)
+        Wt = W2d.t().contiguous()
+        _hip.call("cf_linear", _hip.p(gy), _hip.p(Wt), None, None, _hip.p(gx), rows, N, K, 0, st)
+    return gx, gW, gb
+
+
+def _dense(x_in, W2d, b, act):
+    x_in = x_in.contiguous()
+    y = _new(x_in.shape[0], W2d.shape[0], like=x_in)
+    _hip.call("cf_linear", _hip.p(x_in), _hip.p(W2d), _hip.p(b), None, _hip.p(y), x_in.shape[0], W2d.shape[1],
+              W2d.shape[0], act, _hip.stream())
+    return y
+
+
+def _couplingfc_backward(m, x_in, gz, gld, grads):
+    """CouplingFC (coupling.py:76-98: the affine coupling on (B, n) with 1x1 "convolutions" = Linear layers)."""
+    B, n = x_in.shape
+    half, st = n // 2, _hip.stream()
+    convs = (m.NN[0], m.NN[2], m.NN[4])
+    Ws = [_hip.f32(c.weight.detach()).flatten(1).contiguous() for c in convs]
+    bs = [_hip.f32(c.bias.detach()) for c in convs]
+    x0 = x_in[:, :half].contiguous()
+    a1 = _dense(x0, Ws[0], bs[0], 2)
+    a2 = _dense(a1, Ws[1], bs[1], 2)
+    h = _dense(a2, Ws[2], bs[2], 0)
+    gx, gh = _new(B, n, like=x_in), _new(B, n, like=x_in)
+    xc, gzc, gldc = x_in.contiguous(), _hip.f32(gz).contiguous(), _hip.f32(gld).contiguous()
+    _hip.call("cf_coupling_apply_bwd", _hip.p(xc), _hip.p(h), _hip.p(gzc), _hip.p(gldc), _hip.p(gx), _hip.p(gh), B, n, 1, n, n,
+              st)
+    g2, gW3, gb3 = _dense_bwd(a2, Ws[2], gh)
+    g1, gW2, gb2 = _dense_bwd(a1, Ws[1], _relu_bwd(a2, g2))
+    g0, gW1, gb1 = _dense_bwd(x0, Ws[0], _relu_bwd(a1, g1))
+    for c, gW, gb in zip(convs, (gW1, gW2, gW3), (gb1, gb2, gb3)):
+        grads[c.weight], grads[c.bias] = gW.view_as(c.weight), gb
+    gx[:, :half] += g0
+    return gx
+
+
+def _flow_encoder_backward(encoder, context, gc, glq, grads):
+    """Backward of VariationalCatDequantization / ArgmaxCatDequantization / ProbSampling (dequantize.py:104-118, 236-262,
+    152-161) and of the FlowInvSequential they sample from (flowsequential.py:58-68: Gaussian draw, then the layers'
+    forward, log q = log N - sum ldj).  The draw is replayed from the kept noise; the (B, n) intermediates are recomputed."""
+    from .actnorm import ActNormFC
+    from .autograd_layers import actnorm_backward, conv1x1_backward
+    from .conv1x1 import FC
+    from .coupling import CouplingFC
+    flow = encoder.encoder
+    dist = flow.dist
+    dev = gc.device
+    ctx = context.to(device=dev, dtype=torch.int64).contiguous()
+    B, n, st = ctx.shape[0], dist.D, _hip.stream()
+    glq = _hip.f32(glq).contiguous()
+    # ---- replay: Gaussian draw, layers (inputs kept), sigmoid
+    cemb = _hip.f32(dist.context_net(ctx)[0]).contiguous()   # (B, 2n) = [mean | log_scale]
+    eps = _hip.f32(dist.last_eps).contiguous()
+    u = _new(B, n, like=gc)
+    lq0 = _new(B, like=gc)
+    _hip.call("cf_cond_gauss_sample", _hip.p(cemb), _hip.p(eps), _hip.p(u), _hip.p(lq0), B, n, st)
+    inputs = []
+    with torch.no_grad():
+        for mod in flow.sequence_modules:
+            inputs.append(u)
+            u, _ = mod(u, ctx)
+    u = u.contiguous()
+    su = torch.empty_like(u)
+    act_ldj = _new(B, like=gc)
+    _hip.call("cf_sigmoid_ldj", _hip.p(u), _hip.p(su), _hip.p(act_ldj), B, n, st)
+    # ---- heads: d/d sigmoid(u) from d/dc, sign of log q in the encoder's log-density
+    if isinstance(encoder, VariationalCatDequantization):    # z = (x + su) / K ; ldj = const + act_ldj - log q
+        gsu, sq = gc / encoder.qbins, -1.0
+    elif isinstance(encoder, ArgmaxCatDequantization):       # z = su * (2 bits - 1) ; ldj = act_ldj - log q
+        bits = torch.tensor(encoder.num_bits, device=dev, dtype=torch.int64)
+        ones = torch.ones(B, n, device=dev, dtype=torch.float32)
+        sign = _new(B, n, like=gc)
+        _hip.call("cf_ctx_encode", _hip.p(ctx), _hip.p(ones), None, _hip.p(bits), _hip.p(sign), B, ctx.shape[1], n, 2, st)
+        gsu, sq = gc * sign, -1.0
+    else:                                                    # ProbSampling: z = su ; ldj = act_ldj + log q (reference sign)
+        gsu, sq = gc, 1.0
+    gu = gsu * su * (1.0 - su) + glq.unsqueeze(1) * (1.0 - 2.0 * su)      # d act_ldj / du = 1 - 2 sigmoid(u)
+    glogq = sq * glq                                         # d/d log q(u);  log q = log N(u0) - sum_layers ldj
+    for mod, xin in zip(reversed(flow.sequence_modules), reversed(inputs)):
+        if isinstance(mod, FC):
+            g4, gp = conv1x1_backward(mod, xin.view(B, n, 1, 1), gu.contiguous().view(B, n, 1, 1), -glogq)
+            gu = g4.view(B, n)
+        elif isinstance(mod, ActNormFC):
+            g4, gp = actnorm_backward(mod, xin.view(B, n, 1, 1), gu.contiguous().view(B, n, 1, 1), -glogq)
+            gu = g4.view(B, n)
+        elif isinstance(mod, CouplingFC):
+            gp = {}
+            gu = _couplingfc_backward(mod, xin, gu, -glogq, gp)
+        else:
+            raise NotImplementedError("encoder flow layer %s" % type(mod).__name__)
+        grads.update(gp)
+    # ---- the draw u0 = mean + exp(ls) eps, log N(u0) = sum(-1/2 log 2pi - ls - eps^2 / 2)
+    ls = cemb[:, n:]
+    gcemb = torch.cat([gu, gu * torch.exp(ls) * eps - glogq.unsqueeze(1)], dim=1)
+    _embedding_grads(dist.context_net, ctx, gcemb, grads)
 
 
 def _embedding_grads(emb, context, gc, grads):
@@ -85,7 +200,7 @@ def conv1x1_ctx_backward(m, rec, context, gz, gld, grads):
     _hip.call("cf_conv1x1_ctx_bwd", _hip.p(x), _hip.p(rec["m"]), _hip.p(Wm), _hip.p(gzv), _hip.p(gld), _hip.p(gx), _hip.p(gm),
               B, C, H * W, xbs, gzbs, _hip.stream())
     gc = _linear_bwd(rec["c"], m.CN, gm, grads)
-    _encoder_backward(m.context_net, context, gc, grads)
+    _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W))      # ldj += H W logp_c
     return gx
 
 
@@ -100,16 +215,17 @@ def actnorm_ctx_backward(m, rec, context, gz, gld, grads):
     _hip.call("cf_actnorm_ctx_bwd", _hip.p(x), _hip.p(rec["m"]), _hip.p(t), _hip.p(logs), _hip.p(gzv), _hip.p(gld), _hip.p(gx),
               _hip.p(gm), B, C, H * W, xbs, gzbs, _hip.stream())
     gc = _linear_bwd(rec["c"], m.CN, gm, grads)
-    _encoder_backward(m.context_net, context, gc, grads)
+    _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W))      # ldj += H W logp_c
     return gx
 
 
-def _cn_chain_backward(m, rec, context, gcn, grads):
-    """CN = Linear -> ReLU -> Linear -> ReLU -> Linear (coupling.py:37) and the context encoder behind it."""
+def _cn_chain_backward(m, rec, context, gcn, grads, glq):
+    """CN = Linear -> ReLU -> Linear -> ReLU -> Linear (coupling.py:37) and the context encoder behind it; glq = d/d of the
+    encoder's log-density term of the layer's log-det."""
     ga2 = _relu_bwd(rec["a2"], _linear_bwd(rec["a2"], m.CN[4], gcn, grads))
     ga1 = _relu_bwd(rec["a1"], _linear_bwd(rec["a1"], m.CN[2], ga2, grads))
     gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads)
-    _encoder_backward(m.context_net, context, gc, grads)
+    _encoder_backward(m.context_net, context, gc, grads, glq)
 
 
 def coupling_ctx_backward(m, rec, context, gz, gld, grads):
@@ -138,7 +254,7 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
                   None, None, pp(s_gh), None, None, None, B, C, H, W, xbs, st)
         gcn = _new(B, C, like=x)
         _hip.call("cf_sample_channel_sums", pp(s_gh), pp(gcn), B, C, HW, st)
-        _cn_chain_backward(m, rec, context, gcn, grads)
+        _cn_chain_backward(m, rec, context, gcn, grads, f(gld) * float(HW))      # ldj += H W logp_c (coupling.py:43)
         return gx
     new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
     y0, h1, h2 = rec["planes"]
@@ -165,7 +281,7 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
     grads[c1.bias] = gb1
     grads[c2.weight], grads[c2.bias] = gw2.permute(1, 2, 0).reshape(c2.weight.shape), gb2
     grads[c3.weight], grads[c3.bias] = gw3[0].reshape(c3.weight.shape), gb3
-    _cn_chain_backward(m, rec, context, s1 @ wc, grads)
+    _cn_chain_backward(m, rec, context, s1 @ wc, grads, f(gld) * float(HW))
     return gx
 
 
@@ -185,7 +301,7 @@ def transcoupling_ctx_backward(m, rec, context, gz, gld, grads):
               B, C, H * W, xbs, gzbs, st)
     gcn = _new(B, C, like=x)
     _hip.call("cf_sample_channel_sums", _hip.p(ghd), _hip.p(gcn), B, C, H * W, st)
-    _cn_chain_backward(m, rec, context, gcn, grads)
+    _cn_chain_backward(m, rec, context, gcn, grads, _hip.f32(gld))          # quirk: no H W factor here (coupling.py:126)
     gx[:, :half] += vit_backward(m.NN[0], vtape, ghd, None)       # grads = None: the ViT is frozen, data gradient only
     return gx
 

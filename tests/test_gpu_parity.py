@@ -849,7 +849,8 @@ def test_specialist_forward_matches_reference(L, fxname):
 
 
 @pytest.mark.parametrize("fxname", ["mnist_eye_cf", "cifar10_onehot_cf", "smap_onehot_cf", "atm_onehot_cf", "atm_embed_eyesample_cf",
-                                    "mnist_onehot", "cifar10_eye", "cifar10_embed_eyesample"])
+                                    "mnist_onehot", "cifar10_eye", "cifar10_embed_eyesample", "cifar10_eye_vardeq_cf",
+                                    "cifar10_eye_argmax_cf", "mnist_embed_probsample_cf", "cifar10_onehot_vardeq"])
 def test_specialist_backward_against_autograd_oracle(L, fxname):
     """Specialist training: d sum(w * logp) / d parameters from the hand-written backward (autograd_ctx.py) against
     torch.autograd through the CPU oracle in fp64, same inputs / noise / parameters.  Under contextflow the generalist's
@@ -872,7 +873,8 @@ def test_specialist_backward_against_autograd_oracle(L, fxname):
     model.load_state_dict(params, strict=True)
     model = model.to(DEV).train()
     set_noise(model, inp["u"], inp["eps"])
-    encs = [m for m in model.modules() if isinstance(m, cfa.layers.UniformCatDequantization)]
+    noisy = cfa.layers.UniformCatDequantization if ctx.get("enc_type", "uniform") == "uniform" else cfa.layers.ConditionalGaussianDistribution
+    encs = [m for m in model.modules() if isinstance(m, noisy)]
     assert len(encs) == len(inp["cnoise"])
     for e, c in zip(encs, inp["cnoise"]):
         e.fixed_noise = c.to(DEV)
@@ -887,7 +889,7 @@ def test_specialist_backward_against_autograd_oracle(L, fxname):
             assert p.grad is None, k
             continue
         if ctx["contextflow"]:
-            assert ".CN." in k or "_embeddings" in k, k
+            assert ".CN." in k or "_embeddings" in k or ".context_net." in k, k     # only context parameters train
         ref = p64[k].grad
         if ref is None or float(ref.abs().max()) == 0.0:           # takes no part in this configuration (e.g. Conv1x1.NN)
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
