@@ -200,13 +200,18 @@ void launch_slogdet(const float* Wm, int C, float* lad, float* inv, hipStream_t 
     else k_slogdet<CMAX, true><<<dim3(1), dim3(256), 0, st>>>(Wm, C, lad, inv);
 }
 
-// Inverse for 64 < C <= 128 (ATM: 76-channel Conv1x1, training only: d log|det W| / dW = W^-T).  In-place Gauss-Jordan
-// with partial pivoting on an fp32 copy in LDS (row stride C + 1), one workgroup; the column swaps that undo the row
-// pivoting run at the end.  Conv1x1 weights start orthogonal and stay well conditioned.
-__global__ __launch_bounds__(256) void k_inverse_lds(const float* __restrict__ Wm, int C, float* __restrict__ inv) {
+// Inverse for 64 < C <= 128 (ATM: 76-channel Conv1x1, training only: d log|det W| / dW = W^-T) and log|det| + inverse
+// for 128 < C <= 192 (the FC layers of the ATM context-encoder flows: width 144 / 152, model.py:52-66).  In-place
+// Gauss-Jordan with partial pivoting on an fp32 copy in LDS (row stride C + 1), one workgroup; the column swaps that
+// undo the row pivoting run at the end; log|det| = sum log|pivot| accumulated in fp64.  Conv1x1 weights start orthogonal
+// and stay well conditioned.
+constexpr int kMaxLdsLU = 192;
+__global__ __launch_bounds__(256) void k_inverse_lds(const float* __restrict__ Wm, int C, float* __restrict__ inv,
+                                                     float* __restrict__ logabsdet) {
     extern __shared__ float A[];                   // [C][C+1]
-    __shared__ int piv[128];
-    __shared__ float colk[128];
+    __shared__ int piv[kMaxLdsLU];
+    __shared__ float colk[kMaxLdsLU];
+    double lad = 0.0;                              // thread 0
     __shared__ float rv[4];
     __shared__ int ri[4];
     const int S = C + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -239,7 +244,9 @@ __global__ __launch_bounds__(256) void k_inverse_lds(const float* __restrict__ W
         if (p != k)
             for (int c = tid; c < C; c += 256) { const float t = A[k * S + c]; A[k * S + c] = A[p * S + c]; A[p * S + c] = t; }
         __syncthreads();
-        const float d = 1.0f / A[k * S + k];
+        const float pk = A[k * S + k];
+        const float d = 1.0f / pk;
+        if (tid == 0) lad += log(fabs((double)pk));
         __syncthreads();
         for (int c = tid; c < C; c += 256) A[k * S + c] = (c == k ? 1.0f : A[k * S + c]) * d;
         for (int r = tid; r < C; r += 256) colk[r] = A[r * S + k];
@@ -256,7 +263,9 @@ __global__ __launch_bounds__(256) void k_inverse_lds(const float* __restrict__ W
             for (int r = tid; r < C; r += 256) { const float t = A[r * S + k]; A[r * S + k] = A[r * S + p]; A[r * S + p] = t; }
         __syncthreads();
     }
-    for (int e = tid; e < C * C; e += 256) inv[e] = A[(e / C) * S + (e % C)];
+    if (inv != nullptr)
+        for (int e = tid; e < C * C; e += 256) inv[e] = A[(e / C) * S + (e % C)];
+    if (logabsdet != nullptr && tid == 0) logabsdet[0] = (float)lad;
 }
 
 }  // namespace
@@ -266,11 +275,19 @@ extern "C" {
 int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z, int B, int C, int HW,
                    int64_t x_bstride, int64_t z_bstride, cf_stream_t stream) {
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
-    CF_REQUIRE(x && Wm && z && B >= 0 && C > 0 && C <= 128 && HW > 0);
+    CF_REQUIRE(x && Wm && z && B >= 0 && C > 0 && C <= 192 && HW > 0);
     const int64_t npix = (int64_t)B * HW;
     if (npix == 0) return 0;
     const int Cp = (C + 7) / 8 * 8;
     const size_t lds = (size_t)C * Cp * sizeof(float);
+    if (lds > 64 * 1024) {                      // 128 < C <= 192: the FC layers of the ATM context-encoder flows
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv1x1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { cf_set_error("cf_conv1x1_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
+            raised = true;
+        }
+    }
     k_conv1x1<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), lds, cf_s(stream)>>>(x, Wm, bias, z, C, Cp, HW, npix,
                                                                                       x_bstride, z_bstride);
     CF_LAUNCH_CHECK();
@@ -280,19 +297,19 @@ int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z,
 int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_stream_t stream) {
     CF_REQUIRE(Wm && logabsdet && C > 0);
     if (C > kMaxLU) {
-        if (C > 128) { cf_set_error("cf_slogdet_inverse: C=%d unsupported (up to 128)", C); return CF_ERR_UNSUPPORTED; }
-        k_slogdet128<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet);
-        if (inv != nullptr) {
+        if (C > kMaxLdsLU) { cf_set_error("cf_slogdet_inverse: C=%d unsupported (up to %d)", C, kMaxLdsLU); return CF_ERR_UNSUPPORTED; }
+        if (C <= 128) k_slogdet128<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(Wm, C, logabsdet);
+        if (inv != nullptr || C > 128) {
             const size_t lds = (size_t)C * (C + 1) * sizeof(float);
             if (lds > 64 * 1024) {
                 static bool raised = false;
                 if (!raised) {
-                    hipError_t e = hipFuncSetAttribute((const void*)k_inverse_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   // + ~1 KiB static
+                    hipError_t e = hipFuncSetAttribute((const void*)k_inverse_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + ~2 KiB static
                     if (e != hipSuccess) { cf_set_error("cf_slogdet_inverse: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
                     raised = true;
                 }
             }
-            k_inverse_lds<<<dim3(1), dim3(256), lds, cf_s(stream)>>>(Wm, C, inv);
+            k_inverse_lds<<<dim3(1), dim3(256), lds, cf_s(stream)>>>(Wm, C, inv, C > 128 ? logabsdet : nullptr);
         }
         CF_LAUNCH_CHECK();
         return 0;

@@ -64,9 +64,12 @@ def _dense_bwd(x_in, W2d, gy, need_gx=True):
     N, K = W2d.shape
     rows = x_in.shape[0]
     gy, x_in, st = gy.contiguous(), x_in.contiguous(), _hip.stream()
-    gW, gb = _new(N, K, like=gy), _new(N, like=gy)
-    ws = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, K, N), device=gy.device, dtype=torch.uint8)
-    _hip.call("cf_linear_wgrad", _hip.p(x_in), _hip.p(gy), _hip.p(gW), _hip.p(gb), _hip.p(ws), rows, K, N, st)
+    if (N + 31) // 32 + (K + 32) // 32 > 12:                  # wider than cf_linear_wgrad's LDS stage: library GEMM
+        gW, gb = gy.t() @ x_in, gy.sum(0)
+    else:
+        gW, gb = _new(N, K, like=gy), _new(N, like=gy)
+        ws = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, K, N), device=gy.device, dtype=torch.uint8)
+        _hip.call("cf_linear_wgrad", _hip.p(x_in), _hip.p(gy), _hip.p(gW), _hip.p(gb), _hip.p(ws), rows, K, N, st)
     gx = None
     if need_gx:
         gx = _new(rows, K, like=gy)

@@ -68,10 +68,11 @@ int cf_squeeze(const float* x, float* y, int B, int C, int H, int W, int p1, int
                int64_t x_bstride, int64_t y_bstride, int inverse, cf_stream_t stream);
 
 /* ---- Conv1x1 (layers/conv1x1.py:52-57,72) ------------------------------------------------------ */
-/* z[b,o,p] = sum_i Wm[o,i] x[b,i,p] (+ bias[o] if bias != NULL); C <= 128.                         */
+/* z[b,o,p] = sum_i Wm[o,i] x[b,i,p] (+ bias[o] if bias != NULL); C <= 192.                         */
 int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z, int B, int C, int HW,
                    int64_t x_bstride, int64_t z_bstride, cf_stream_t stream);
-/* logabsdet[0] = log|det Wm| (LU with partial pivoting in fp64); if inv != NULL also Wm^-1 (C x C). */
+/* logabsdet[0] = log|det Wm| (LU with partial pivoting; fp64 in registers up to C = 128, an fp32 LDS copy with
+ * fp64 accumulation of log|pivot| up to 192); if inv != NULL also Wm^-1 (C x C).                          */
 int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_stream_t stream);
 
 /* ---- ActNorm (layers/actnorm.py:28-35,53-60,78) ------------------------------------------------- */

@@ -74,6 +74,9 @@ SPECIALIST = {
     "mnist_embed_probsample_cf": ("mnist", dict(contexts=[64], enc_emb="embed", contextflow=True, enc_type="probsample")),
     "atm_onehot_cf": ("atm", dict(contexts=[68], enc_emb="onehot", contextflow=True)),
     "atm_embed_eyesample_cf": ("atm", dict(contexts=[68], enc_emb="embed", contextflow=True, enc_type="eyesample")),
+    "atm_onehot_vardeq_cf": ("atm", dict(contexts=[68], enc_emb="onehot", contextflow=True, enc_type="vardeq")),
+    "atm_eye_argmax_cf": ("atm", dict(contexts=[68], enc_emb="eye", contextflow=True, enc_type="argmax")),
+    "atm_embed_probsample_cf": ("atm", dict(contexts=[68], enc_emb="embed", contextflow=True, enc_type="probsample")),
 }
 
 

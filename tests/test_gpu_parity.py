@@ -599,10 +599,11 @@ def test_conv1x1_ctx_kernels_against_torch(L, C, HW, B, cf):
         assert (got - want).abs().max().item() < 1e-4 * max(want.abs().max().item(), 1e-3)
 
 
-@pytest.mark.parametrize("C", [1, 3, 8, 16, 33, 64, 65, 76, 128])
+@pytest.mark.parametrize("C", [1, 3, 8, 16, 33, 64, 65, 76, 128, 129, 152, 192])
 def test_slogdet_inverse_against_torch(L, C):
     """cf_slogdet_inverse (conv1x1.py:21-31: torch.slogdet / torch.inverse per call): register-resident LU up to 64
-    channels, two rows per lane + the LDS Gauss-Jordan inverse up to 128 (ATM: 76) - against torch.linalg in fp64 on
+    channels, two rows per lane + the LDS Gauss-Jordan inverse up to 128 (ATM: 76), LDS Gauss-Jordan for both up to 192
+    (the 144 / 152-wide FC layers of the ATM context-encoder flows) - against torch.linalg in fp64 on
     a perturbed orthogonal matrix with permuted rows (forces pivoting)."""
     from contextflow_amd.layers import _hip
     g = torch.Generator().manual_seed(C)
@@ -812,7 +813,8 @@ def test_training_steps_reduce_the_loss_smap(L):
 @pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye",
                                     "cifar10_onehot_vardeq", "cifar10_eye_vardeq_cf", "smap_onehot_cf", "smap_eye",
                                     "cifar10_eye_argmax_cf", "cifar10_embed_eyesample", "mnist_embed_probsample_cf",
-                                    "atm_onehot_cf", "atm_embed_eyesample_cf"])
+                                    "atm_onehot_cf", "atm_embed_eyesample_cf", "atm_onehot_vardeq_cf", "atm_eye_argmax_cf",
+                                    "atm_embed_probsample_cf"])
 def test_specialist_forward_matches_reference(L, fxname):
     """Context-conditioned models (create_model(generalist=False), model.py:117-162): per-sample Conv1x1 / ActNorm /
     Coupling parameters from the context encoders + CN nets, context-shifted GMM priors — logp against the reference's
@@ -901,6 +903,47 @@ def test_specialist_backward_against_autograd_oracle(L, fxname):
         assert err < 2e-3, "%s: relative grad error %.3e (scale %.3e)" % (k, err, scale)
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("name,contexts,emb,typ,cflow", [
+    ("mnist", [64], "eye", "uniform", False),            # README.md:56
+    ("cifar10", [15, 5], "onehot", "vardeq", False),     # README.md:61
+    ("atm", [68], "onehot", "vardeq", True),             # README.md:66
+    ("atm", [68], "eye", "argmax", True),                # README.md:67
+    ("atm", [68], "embed", "probsample", True),          # README.md:69
+])
+def test_specialist_training_modes_of_the_readme(L, name, contexts, emb, typ, cflow):
+    """A few AdamW steps of the specialist training modes the reference's README lists that have no gradient fixture of their
+    own (the per-layer backward pieces are pinned by test_specialist_backward_against_autograd_oracle): the loss stays
+    finite and improves, every trainable tensor that takes part receives a finite gradient."""
+    import contextflow_amd as cfa
+    torch.manual_seed(0)
+    cfg, ds, M = cfa.preset_config(name)
+    cfg.update(generalist=False, enc_emb=emb, enc_type=typ, contextflow=cflow)
+    model = cfa.create_model(cfg, ds, M, contexts=contexts).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    B = 24
+    x = torch.rand(B, *ds, generator=g) if name == "atm" else torch.randint(0, 256, (B, *ds), generator=g).float()
+    ctx = torch.stack([torch.randint(0, k, (B,), generator=g) for k in contexts], 1)
+    gt = torch.randint(0, M, (B,), generator=g)
+    x, ctx, gt = x.to(DEV), ctx.to(DEV), gt.to(DEV)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=5e-4)
+    dim_inv = 1.0 / (ds[0] * ds[1] * ds[2])
+    losses = []
+    for it in range(8):
+        opt.zero_grad(set_to_none=True)
+        logp = dim_inv * model.log_prob(x, ctx)
+        assert logp.requires_grad
+        loss = torch.nn.functional.cross_entropy(logp, gt)
+        loss.backward()
+        if it == 0:
+            got = [p for p in params if p.grad is not None]
+            assert len(got) >= 20 and all(torch.isfinite(p.grad).all() for p in got)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(math.isfinite(v) for v in losses), losses
+    assert min(losses[1:]) < losses[0], losses            # the encoders draw fresh noise every step: the loss is stochastic
 
 
 @pytest.mark.parametrize("name,channels", [("msl", 55), ("smd", 38)])

@@ -172,7 +172,8 @@ def test_unit_spline_activation(tag):
 @pytest.mark.parametrize("fxname", ["mnist_eye_cf", "mnist_onehot", "cifar10_onehot_cf", "cifar10_eye",
                                     "cifar10_onehot_vardeq", "cifar10_eye_vardeq_cf", "smap_onehot_cf", "smap_eye",
                                     "cifar10_eye_argmax_cf", "cifar10_embed_eyesample", "mnist_embed_probsample_cf",
-                                    "atm_onehot_cf", "atm_embed_eyesample_cf"])
+                                    "atm_onehot_cf", "atm_embed_eyesample_cf", "atm_onehot_vardeq_cf", "atm_eye_argmax_cf",
+                                    "atm_embed_probsample_cf"])
 def test_specialist_oracle_matches_reference(fxname):
     """Context-conditioned (specialist) forward: every Conv1x1 / ActNorm / Coupling with its ContextEncoder + CN net,
     context-shifted GMM priors — oracle vs the reference's logp on the captured noise."""
