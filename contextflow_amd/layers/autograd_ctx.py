@@ -26,18 +26,14 @@ def _new(*shape, like):
 
 
 def trainable(flow):
-    """True when this specialist flow can be trained here: context encoders without trainable parameters of their own
-    (uniform dequantisation, embedding lookup); contextflow (frozen generalist) with conv or transformer couplings, or
-    every parameter training (no contextflow) with conv couplings."""
+    """True when this specialist flow can be trained here: every context encoder create_model builds, conv and
+    transformer couplings, with contextflow (frozen generalist) or without (every parameter trains)."""
     ok = (UniformCatDequantization, EyeSampling, VariationalCatDequantization, ArgmaxCatDequantization, ProbSampling)
     for m in list(flow.sequence_modules) + [flow.dist]:
         cn = getattr(m, "context_net", None) or getattr(getattr(m, "dist", None), "context_net", None)
         if not cn:
             continue
         if not isinstance(cn[1], ok):
-            return False
-        cf = getattr(m, "contextflow", getattr(getattr(m, "dist", None), "contextflow", False))
-        if not cf and isinstance(m, TransCoupling):
             return False
     return True
 
@@ -289,23 +285,37 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
 
 
 def transcoupling_ctx_backward(m, rec, context, gz, gld, grads):
-    """TransCoupling under contextflow (coupling.py:123-133): h = ViT(x0) + CN(c), the ViT frozen.  The ViT is re-run with
-    a tape (as in the generalist backward), d/d CN(c) = per-sample row sums of d/dh, d/dx0 through the ViT."""
+    """TransCoupling with a context net (coupling.py:123-133).  contextflow: h = ViT(x0) + CN(c) with the ViT frozen -
+    the ViT is re-run with a tape (as in the generalist backward), d/d CN(c) = per-sample row sums of d/dh, d/dx0 through
+    the ViT (data gradient only).  Without contextflow: h = ViT([x0 ; CN(c) broadcast over the window]) and every
+    parameter trains - d/d CN(c) = the row sums of the ViT's input gradient over its context channels."""
     from .autograd_layers import vit_backward, vit_forward_taped
     x, xbs = _hip.bview(rec["x"])
     gzv, gzbs = _hip.bview(gz)
     B, C, H, W = x.shape
     half, st = C // 2, _hip.stream()
-    h, vtape = vit_forward_taped(m.NN[0], x[:, :half])
-    _hip.call("cf_add_sample_bias", _hip.p(h), _hip.p(rec["cn"]), B, C, H * W, 0, st)
+    if m.contextflow:
+        h, vtape = vit_forward_taped(m.NN[0], x[:, :half])
+        _hip.call("cf_add_sample_bias", _hip.p(h), _hip.p(rec["cn"]), B, C, H * W, 0, st)
+    else:
+        cn = rec["cn"]
+        xin = torch.cat([_hip.f32(x[:, :half]), cn.view(B, -1, 1, 1).expand(B, cn.shape[1], H, W)], dim=1)   # index op
+        h, vtape = vit_forward_taped(m.NN, xin)
     gx = _new(B, C, H, W, like=x)
     ghd = _new(B, C, H, W, like=x)
     _hip.call("cf_coupling_apply_bwd", _hip.p(x), _hip.p(h), _hip.p(gzv), _hip.p(_hip.f32(gld)), _hip.p(gx), _hip.p(ghd),
               B, C, H * W, xbs, gzbs, st)
-    gcn = _new(B, C, like=x)
-    _hip.call("cf_sample_channel_sums", _hip.p(ghd), _hip.p(gcn), B, C, H * W, st)
+    if m.contextflow:
+        gcn = _new(B, C, like=x)
+        _hip.call("cf_sample_channel_sums", _hip.p(ghd), _hip.p(gcn), B, C, H * W, st)
+        gx[:, :half] += vit_backward(m.NN[0], vtape, ghd, None)       # grads = None: the ViT is frozen, data gradient only
+    else:
+        gxin = vit_backward(m.NN, vtape, ghd, grads)
+        gx[:, :half] += gxin[:, :half]
+        gctx = gxin[:, half:].contiguous()
+        gcn = _new(B, gctx.shape[1], like=x)
+        _hip.call("cf_sample_channel_sums", _hip.p(gctx), _hip.p(gcn), B, gctx.shape[1], H * W, st)
     _cn_chain_backward(m, rec, context, gcn, grads, _hip.f32(gld))          # quirk: no H W factor here (coupling.py:126)
-    gx[:, :half] += vit_backward(m.NN[0], vtape, ghd, None)       # grads = None: the ViT is frozen, data gradient only
     return gx
 
 
@@ -368,8 +378,6 @@ class SpecialistLogProb(torch.autograd.Function):
                 x, ldj = mod._fused_ctx(x, context, rec)
             elif isinstance(mod, TransCoupling) and mod.context_net:
                 _check_encoder(mod.context_net)
-                if not mod.contextflow:
-                    raise NotImplementedError("specialist training without contextflow (all parameters train; not built)")
                 x, ldj = mod._forward_ctx(x, context, rec)
             elif isinstance(mod, SplitPrior) and getattr(mod.dist, "context_net", None):
                 c = x.shape[1] // 2

@@ -852,7 +852,7 @@ def test_specialist_forward_matches_reference(L, fxname):
 
 @pytest.mark.parametrize("fxname", ["mnist_eye_cf", "cifar10_onehot_cf", "smap_onehot_cf", "atm_onehot_cf", "atm_embed_eyesample_cf",
                                     "mnist_onehot", "cifar10_eye", "cifar10_embed_eyesample", "cifar10_eye_vardeq_cf",
-                                    "cifar10_eye_argmax_cf", "mnist_embed_probsample_cf", "cifar10_onehot_vardeq"])
+                                    "cifar10_eye_argmax_cf", "mnist_embed_probsample_cf", "cifar10_onehot_vardeq", "smap_eye"])
 def test_specialist_backward_against_autograd_oracle(L, fxname):
     """Specialist training: d sum(w * logp) / d parameters from the hand-written backward (autograd_ctx.py) against
     torch.autograd through the CPU oracle in fp64, same inputs / noise / parameters.  Under contextflow the generalist's
