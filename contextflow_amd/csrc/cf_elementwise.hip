@@ -326,6 +326,67 @@ __global__ __launch_bounds__(256) void k_nll_sum(const float* __restrict__ logp,
     if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- elementwise flow activations with their log-det (activations.py:34-118, 213-245) ---------------------------
+// mode 0 Identity, 1 LeakyRelu(a), 2 SmoothLeakyRelu(a): a x + (1 - a) softplus(x), 3 SmoothTanh(a, b): tanh(a x) + b x,
+// 4 Sigmoid(temperature a, eps b), 5 LearnableLeakyRelu: slope sigmoid(*slope_logit) + 0.5 read on the device.
+// One workgroup per row of D elements: y, and ldj[row] = sum log|f'(x)| (forward only).  The inverses of the smooth
+// activations are the reference's Newton iteration (100 steps from x0 = y, derivative clamped at 1e-2).
+__device__ __forceinline__ float act_f(int mode, float x, float a, float b) {
+    switch (mode) {
+        case 1: case 5: return x < 0.f ? a * x : x;
+        case 2: return a * x + (1.f - a) * (fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))));     // logsumexp(0, x)
+        case 3: return tanhf(a * x) + b * x;
+        case 4: return 1.0f / (1.0f + expf(-a * x));
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_df(int mode, float x, float a, float b) {
+    switch (mode) {
+        case 1: case 5: return x < 0.f ? a : 1.f;
+        case 2: return a + (1.f - a) / (1.f + expf(-x));
+        case 3: { const float c = coshf(a * x); return b + a / (c * c); }
+        default: return 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_activation(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ ldj,
+                                                    int D, int mode, float a, float b, const float* __restrict__ slope_logit,
+                                                    int inverse) {
+    __shared__ float scr[4];
+    const int64_t row = blockIdx.x;
+    if (mode == 5) a = 1.0f / (1.0f + expf(-slope_logit[0])) + 0.5f;
+    float acc = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float v = x[row * D + d];
+        float out;
+        if (!inverse) {
+            out = act_f(mode, v, a, b);
+            if (mode == 4) {                              // log T - softplus(-T x) - softplus(T x)
+                const float t = fabsf(a * v);
+                acc += logf(a) - (t + 2.0f * log1pf(expf(-t)));
+            } else if (mode != 0) {
+                acc += logf(fabsf(act_df(mode, v, a, b)));
+            }
+        } else if (mode == 1 || mode == 5) {
+            out = v < 0.f ? v / a : v;
+        } else if (mode == 2 || mode == 3) {
+            float xi = v;
+            for (int it = 0; it < 100; ++it) xi -= (act_f(mode, xi, a, b) - v) / fmaxf(act_df(mode, xi, a, b), 1e-2f);
+            out = xi;
+        } else if (mode == 4) {
+            const float z = fminf(fmaxf(v, b), 1.0f - b);
+            out = (logf(z) - log1pf(-z)) / a;
+        } else {
+            out = v;
+        }
+        y[row * D + d] = out;
+    }
+    if (!inverse && ldj != nullptr) {
+        acc = cf_block_sum<4>(acc, scr);
+        if (threadIdx.x == 0) ldj[row] = acc;
+    }
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -480,6 +541,16 @@ int cf_nll_sum(const float* logp, double* acc, int B, int M, cf_stream_t stream)
     int blocks = (B + 255) / 256;
     if (blocks > 256) blocks = 256;
     k_nll_sum<<<dim3(blocks), dim3(256), 0, cf_s(stream)>>>(logp, acc, B, M);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_activation(const float* x, float* y, float* ldj, int64_t rows, int D, int mode, float a, float b,
+                  const float* slope_logit, int inverse, cf_stream_t stream) {
+    if (rows == 0) return 0;
+    CF_REQUIRE(x && y && rows >= 0 && rows <= 0x7fffffff && D > 0 && mode >= 0 && mode <= 5 && (inverse || ldj) &&
+               (mode != 5 || slope_logit));
+    k_activation<<<dim3((unsigned)rows), dim3(256), 0, cf_s(stream)>>>(x, y, ldj, D, mode, a, b, slope_logit, inverse);
     CF_LAUNCH_CHECK();
     return 0;
 }

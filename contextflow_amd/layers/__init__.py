@@ -17,7 +17,8 @@ from .distributions import StandardNormal, GaussianMixtureDistribution, UniformD
 from .splitprior import SplitPrior
 from .flowsequential import FlowSequential, FlowInvSequential, GraphedFlow
 from .conv1x1 import Conv1x1, FC
-from .activations import FlowActivationLayer, SplineActivation
+from .activations import (FlowActivationLayer, Identity, LeakyRelu, LearnableLeakyRelu, Sigmoid, SmoothLeakyRelu, SmoothTanh,
+                          SplineActivation)
 from .actnorm import ActNorm, ActNormFC
 from .squeeze import Squeeze, UnSqueeze
 from .transforms import LogitTransform

@@ -13,5 +13,3 @@ def _stub(name, why):
 StudentMixtureDistribution = _stub("StudentMixtureDistribution", "--dist tdist; non-default prior")
 GaussianDistribution = _stub("GaussianDistribution", "unused by create_model")
 MultivariateGaussianMixtureDistribution = _stub("MultivariateGaussianMixtureDistribution", "unused by create_model")
-SmoothLeakyRelu = _stub("SmoothLeakyRelu", "activation layers are disabled in every config")
-LearnableLeakyRelu = _stub("LearnableLeakyRelu", "activation layers are disabled in every config")

@@ -298,6 +298,14 @@ int cf_gmm_ctx_logprob_tab(const float* x, const float* mG, const float* inv_sig
 int cf_cond_gauss_sample(const float* c, const float* eps, float* x, float* logp, int B, int D, cf_stream_t stream);
 int cf_sigmoid_ldj(const float* x, float* y, float* ldj, int B, int D, cf_stream_t stream);
 
+/* ---- elementwise flow activations (layers/activations.py:34-118, 213-245) -------------------------------------------
+ * x, y: (rows, D); forward: y = f(x), ldj[row] = sum_d log|f'(x)|; inverse: y = f^-1(x) (ldj unused, may be NULL).
+ * mode 0 Identity | 1 LeakyRelu(a) | 2 SmoothLeakyRelu(a) | 3 SmoothTanh(a, b) | 4 Sigmoid(temperature a, eps b: the
+ * clamp of the inverse) | 5 LearnableLeakyRelu (slope = sigmoid(*slope_logit) + 0.5, read on the device).  The smooth
+ * activations invert by the reference's Newton iteration (100 steps, derivative clamped at 1e-2).                   */
+int cf_activation(const float* x, float* y, float* ldj, int64_t rows, int D, int mode, float a, float b,
+                  const float* slope_logit, int inverse, cf_stream_t stream);
+
 /* ---- specialist training (contextflow: the CN nets and the priors' embedding tables train, the generalist's own
  * parameters stay frozen - coupling.py:36, conv1x1.py:27, actnorm.py:23, gaussian.py:134) -------------------------
  * backward of cf_flow_step_fwd_ctx mode 1: as cf_flow_step_bwd, the recompute adds sbias (B,C) to the conditioner

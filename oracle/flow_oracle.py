@@ -693,3 +693,47 @@ def flow_inverse_layers(ops, params, z, upto=None):
 def bits_per_dim(logp, dims):
     """-logsumexp_m logp / (D ln 2), D = prod of the un-augmented data size."""
     return -torch.logsumexp(logp, dim=-1) / (dims * math.log(2.0))
+
+
+# ---- elementwise flow activations (activations.py:34-118, 213-245) --------------------------------------------------
+def activation_fwd(kind, x, a=0.0, b=0.0):
+    """(y, ldj).  kind: identity | leaky(alpha=a) | smooth_leaky(alpha=a) | smooth_tanh(alpha=a, beta=b) |
+    sigmoid(temperature=a).  ldj sums log|f'| over every non-batch element (activations.py:19-22); the Sigmoid layer sums
+    over the LAST dim only (activations.py:234-238)."""
+    if kind == "sigmoid":
+        t = torch.as_tensor(a, dtype=x.dtype)
+        xs = t * x
+        return torch.sigmoid(xs), (torch.log(t) - F.softplus(-xs) - F.softplus(xs)).sum(-1)
+    if kind == "identity":
+        y, d = x, torch.ones_like(x)
+    elif kind == "leaky":
+        y, d = torch.where(x < 0, a * x, x), torch.where(x < 0, torch.full_like(x, a), torch.ones_like(x))
+    elif kind == "smooth_leaky":
+        y = a * x + (1 - a) * torch.logsumexp(torch.stack((torch.zeros_like(x), x)), dim=0)
+        d = a + (1 - a) * torch.sigmoid(x)
+    elif kind == "smooth_tanh":
+        y, d = torch.tanh(a * x) + b * x, b + a / torch.cosh(a * x) ** 2
+    else:
+        raise ValueError(kind)
+    return y, torch.log(torch.abs(d)).flatten(1).sum(-1)
+
+
+def activation_inv(kind, y, a=0.0, b=0.0, eps=0.0):
+    """Inverse: closed form for the piecewise-linear ones and the sigmoid, the reference's Newton iteration
+    (activations.py:25-31: 100 steps from x0 = y, derivative clamped at 1e-2) for the smooth ones."""
+    if kind == "identity":
+        return y
+    if kind == "leaky":
+        return torch.where(y < 0, y / a, y)
+    if kind == "sigmoid":
+        z = torch.clamp(y, eps, 1 - eps)
+        return (torch.log(z) - torch.log1p(-z)) / a
+    x = y
+    for _ in range(100):
+        f, _ = activation_fwd(kind, x, a, b)
+        if kind == "smooth_leaky":
+            d = a + (1 - a) * torch.sigmoid(x)
+        else:
+            d = b + a / torch.cosh(a * x) ** 2
+        x = x - (f - y) / torch.clamp(d, min=1e-2)
+    return x

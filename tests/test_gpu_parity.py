@@ -621,6 +621,38 @@ def test_slogdet_inverse_against_torch(L, C):
     assert abs(lad2.item() - ref_l) < 1e-5 * max(1.0, abs(ref_l))
 
 
+@pytest.mark.parametrize("tag", ["identity", "leaky", "smooth_leaky", "smooth_tanh", "learnable_leaky", "sigmoid"])
+def test_activation_layers_match_reference(L, tag):
+    """Identity / LeakyRelu / SmoothLeakyRelu / SmoothTanh / LearnableLeakyRelu / Sigmoid (activations.py:34-118, 213-245)
+    through cf_activation: forward, log-det and inverse against the reference classes' outputs (unit_act.npz); a larger
+    random tensor round-trips."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "unit_act.npz"))
+    a, b = (float(v) for v in fx[tag + "/ab"])
+    m = {"identity": lambda: L.Identity(), "leaky": lambda: L.LeakyRelu(a), "smooth_leaky": lambda: L.SmoothLeakyRelu(a),
+         "smooth_tanh": lambda: L.SmoothTanh(a, b), "learnable_leaky": lambda: L.LearnableLeakyRelu(),
+         "sigmoid": lambda: L.Sigmoid(temperature=a, eps=1e-4)}[tag]().to(DEV)
+    if tag == "learnable_leaky":
+        with torch.no_grad():
+            m.alpha_logit.fill_(0.3)
+        assert abs(float(m.get_alpha()) - a) < 1e-6
+    x = torch.from_numpy(fx[tag + "/x"]).to(DEV)
+    z, ldj = m(x)
+    assert z.shape == x.shape and tuple(ldj.shape) == tuple(fx[tag + "/ldj"].shape)
+    assert (z.cpu() - torch.from_numpy(fx[tag + "/z"])).abs().max() < 2e-6
+    assert (ldj.cpu() - torch.from_numpy(fx[tag + "/ldj"])).abs().max() < 2e-4
+    assert (m.logdet(x) - ldj).abs().max() == 0
+    xr = m.reverse(torch.from_numpy(fx[tag + "/z"]).to(DEV))
+    assert (xr.cpu() - torch.from_numpy(fx[tag + "/xr"])).abs().max() < 2e-5
+    g = torch.Generator().manual_seed(3)
+    big = (3.0 * torch.randn(33, 7, 16, 16, generator=g)).to(DEV) if tag != "sigmoid" else (3.0 * torch.randn(33, 1000, generator=g)).to(DEV)
+    zb, lb = m(big)
+    assert torch.isfinite(zb).all() and torch.isfinite(lb).all()
+    tol = 2e-3 if tag == "sigmoid" else 1e-4                      # sigmoid saturates: the logit of 1 - 1e-4 is the clamp
+    sel = (zb > 2e-4) & (zb < 1 - 2e-4) if tag == "sigmoid" else torch.ones_like(zb, dtype=torch.bool)
+    assert ((m.reverse(zb) - big).abs()[sel]).max() < tol * max(1.0, big.abs().max().item())
+    assert m(torch.zeros(0, 4, 2, 2, device=DEV) if tag != "sigmoid" else torch.zeros(0, 4, device=DEV))[0].shape[0] == 0
+
+
 # ------------------------------------------------------------------------------------------ HIP graph replay
 @pytest.mark.parametrize("name", ["mnist", "cifar10"])
 def test_graph_capture_matches_eager(L, name):

@@ -197,3 +197,22 @@ def test_masked_coupling_oracle(tag):
     z, ldj = fo.masked_coupling_fwd(x, p, "0.", tuple(int(v) for v in fx[tag + "/pad"]))
     assert (z - torch.from_numpy(fx[tag + "/z"])).abs().max() < 1e-5
     assert (ldj - torch.from_numpy(fx[tag + "/ldj"])).abs().max() < 1e-4
+
+
+ACT_CASES = {"identity": "identity", "leaky": "leaky", "smooth_leaky": "smooth_leaky", "smooth_tanh": "smooth_tanh",
+             "learnable_leaky": "leaky", "sigmoid": "sigmoid"}
+
+
+@pytest.mark.parametrize("tag", sorted(ACT_CASES))
+def test_activation_oracle(tag):
+    """Elementwise activation layers (activations.py:34-118, 213-245): restatement against the reference classes' forward,
+    log-det and inverse (tests/golden/unit_act.npz)."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "unit_act.npz"))
+    a, b = (float(v) for v in fx[tag + "/ab"])
+    x = torch.from_numpy(fx[tag + "/x"])
+    z, ldj = fo.activation_fwd(ACT_CASES[tag], x, a, b)
+    assert (z - torch.from_numpy(fx[tag + "/z"])).abs().max() < 1e-6
+    assert (ldj - torch.from_numpy(fx[tag + "/ldj"])).abs().max() < 1e-4
+    xr = fo.activation_inv(ACT_CASES[tag], torch.from_numpy(fx[tag + "/z"]), a, b, eps=1e-4)
+    assert (xr - torch.from_numpy(fx[tag + "/xr"])).abs().max() < 1e-5
