@@ -13,7 +13,7 @@ from .flowlayer import FlowLayer, PreprocessingFlowLayer, ModifiedGradFlowLayer
 from .dequantize import Dequantization
 from .normalize import Normalization
 from .augment import Augment
-from .distributions import StandardNormal, GaussianMixtureDistribution, UniformDistribution
+from .distributions import StandardNormal, GaussianDistribution, GaussianMixtureDistribution, UniformDistribution
 from .splitprior import SplitPrior
 from .flowsequential import FlowSequential, FlowInvSequential, GraphedFlow
 from .conv1x1 import Conv1x1, FC

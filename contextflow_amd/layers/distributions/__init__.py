@@ -1,4 +1,4 @@
-from .gaussian import StandardNormal, GaussianMixtureDistribution, gmm_prepare, gmm_logprob
+from .gaussian import StandardNormal, GaussianDistribution, GaussianMixtureDistribution, gmm_prepare, gmm_logprob
 from .uniform import UniformDistribution
 
-__all__ = ["StandardNormal", "GaussianMixtureDistribution", "UniformDistribution"]
+__all__ = ["StandardNormal", "GaussianDistribution", "GaussianMixtureDistribution", "UniformDistribution"]

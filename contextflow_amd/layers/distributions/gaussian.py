@@ -75,6 +75,38 @@ def gmm_logprob(x, prepared, out=None, accumulate=False):
     return out
 
 
+class GaussianDistribution(nn.Module):
+    """gaussian.py:75-115: diagonal Gaussian with one (frozen) mean / pre-softplus scale per channel; log_prob (B,) sums
+    over (C, H, W).  Evaluated by the mixture kernel with M = K = 1 (the parameters broadcast over the pixels)."""
+
+    def __init__(self, size, mixtures=1, context_net=None, contextflow=False):
+        super().__init__()
+        assert mixtures == 1, "mixtures should be 1 in GaussianDistribution"
+        self.size = size
+        self.D = D = size[0]
+        self.M = mixtures
+        self.m = nn.Parameter(torch.zeros(D, 1, 1), requires_grad=False)
+        self.s = nn.Parameter(torch.ones(D, 1, 1), requires_grad=False)
+        self.context_net = context_net
+        self.contextflow = contextflow
+
+    def forward(self, input, context=None):
+        return self.log_prob(input, context)
+
+    def log_prob(self, input, context=None, sum=True):
+        _hip.require_device(input, self.m)
+        B, C, H, W = input.shape
+        mG = _hip.f32(self.m.detach()).expand(C, H, W).contiguous().view(1, 1, C, H, W)
+        sG = _hip.f32(self.s.detach()).expand(C, H, W).contiguous().view(1, 1, C, H, W)
+        wG = torch.zeros(1, 1, device=input.device, dtype=torch.float32)
+        return gmm_logprob(input, gmm_prepare(mG, sG, wG)).view(B)
+
+    def sample(self, n_samples, context=None):
+        eps = torch.randn(n_samples, *self.size, device=self.m.device, dtype=torch.float32)
+        x = _hip.f32(self.m.detach()) + torch.nn.functional.softplus(_hip.f32(self.s.detach())) * eps
+        return x, self.log_prob(x, context)
+
+
 class GaussianMixtureDistribution(nn.Module):
     def __init__(self, size, mixtures=2, components=8, context_net=None, contextflow=False):
         super().__init__()

@@ -11,5 +11,4 @@ def _stub(name, why):
 
 
 StudentMixtureDistribution = _stub("StudentMixtureDistribution", "--dist tdist; non-default prior")
-GaussianDistribution = _stub("GaussianDistribution", "unused by create_model")
 MultivariateGaussianMixtureDistribution = _stub("MultivariateGaussianMixtureDistribution", "unused by create_model")

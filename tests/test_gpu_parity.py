@@ -653,6 +653,24 @@ def test_activation_layers_match_reference(L, tag):
     assert m(torch.zeros(0, 4, 2, 2, device=DEV) if tag != "sigmoid" else torch.zeros(0, 4, device=DEV))[0].shape[0] == 0
 
 
+def test_gaussian_distribution(L):
+    """GaussianDistribution (gaussian.py:75-115): per-channel diagonal Gaussian, log_prob summed over (C, H, W) - against
+    torch.distributions in fp64; state_dict keys m / s as upstream."""
+    g = torch.Generator().manual_seed(2)
+    C, H, W, B = 6, 5, 3, 7
+    dist = L.GaussianDistribution((C, H, W)).to(DEV)
+    assert set(dist.state_dict()) == {"m", "s"}
+    with torch.no_grad():
+        dist.m.copy_(torch.randn(C, 1, 1, generator=g))
+        dist.s.copy_(torch.randn(C, 1, 1, generator=g))
+    x = torch.randn(B, C, H, W, generator=g)
+    ref = torch.distributions.Normal(dist.m.cpu().double(), torch.nn.functional.softplus(dist.s.cpu().double())).log_prob(x.double()).sum((1, 2, 3))
+    lp = dist.log_prob(x.to(DEV))
+    assert tuple(lp.shape) == (B,) and (lp.cpu().double() - ref).abs().max() < 1e-4
+    xs, lps = dist.sample(5)
+    assert tuple(xs.shape) == (5, C, H, W) and (dist.log_prob(xs) - lps).abs().max() == 0
+
+
 # ------------------------------------------------------------------------------------------ HIP graph replay
 @pytest.mark.parametrize("name", ["mnist", "cifar10"])
 def test_graph_capture_matches_eager(L, name):
