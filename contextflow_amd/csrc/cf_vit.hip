@@ -13,41 +13,51 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LIN_ROWS = 128;     // rows per workgroup (4 waves x 32)
-constexpr int LIN_KC = 32;        // K chunk staged in LDS per pass
+constexpr int LIN_KC = 16;        // K chunk staged in LDS per pass
 constexpr int LIN_KP = LIN_KC + 1;   // odd row stride: conflict-free operand reads (lane -> row)
 
 // y[r, n] = act(sum_k x[r,k] W[n,k] + bias[n]) + res[r,n]
 // ACT: 0 none, 1 exact GELU (erf), 2 ReLU             simple_vit.py:32-38,52-53; coupling.py:37 (CN nets)
-// K is walked in chunks of 32 through a 29 KiB LDS stage (any K; 4-5 workgroups per CU overlap each other's staging
-// and MFMA phases); the next chunk's global loads are issued into registers before the MFMAs of the current one.
-template <int ACT, int NTL>
+// K is walked in chunks of 16 through a 15 KiB LDS stage (any K; 5 workgroups per CU overlap each other's staging
+// and MFMA phases - 32- and 64-wide chunks measured slower); the next chunk's global loads are issued into registers
+// before the MFMAs of the current one.
+template <int ACT, int NTL, bool VEC>
 __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, const float* __restrict__ Wt,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 float* __restrict__ y, int rows, int K, int N) {
     __shared__ float xs[LIN_ROWS * LIN_KP];
     constexpr int LIN_COLS = 32 * NTL;                 // output features per workgroup (NTL MFMA column tiles)
     __shared__ float ws[LIN_COLS * LIN_KP];
-    constexpr int NXI = LIN_ROWS * LIN_KC / 256, NWI = LIN_COLS * LIN_KC / 256;   // staged elements per thread: 16 + 4 NTL
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * LIN_ROWS, n0 = blockIdx.y * LIN_COLS;
-    const int sk = tid & 31, sr = tid >> 5;              // staging: column k of the chunk, first row (rows sr + 8 i)
-    // branch-free fetch: clamped 32-bit offsets from the workgroup's base pointers (the values of out-of-range
-    // positions are replaced by zeros afterwards), all loads of a chunk in flight together
+    // staging.  VEC (K % 4 == 0): a thread fetches 16 bytes = 4 consecutive k of a row (rows sr + RSTEP i); otherwise one
+    // float per load.  Branch-free: clamped 32-bit offsets from the workgroup's base pointers (out-of-range positions
+    // are replaced by zeros when the values go to LDS), all loads of a chunk in flight together.
+    constexpr int EPL = VEC ? 4 : 1;                     // floats per load
+    constexpr int RSTEP = 256 * EPL / LIN_KC;            // rows covered by one load of the 256 threads
+    constexpr int NXI = LIN_ROWS / RSTEP, NWI = (LIN_COLS + RSTEP - 1) / RSTEP;
+    const int sk = (tid % (LIN_KC / EPL)) * EPL, sr = tid / (LIN_KC / EPL);
     const float* __restrict__ xb = x + (int64_t)r0 * K;
     const float* __restrict__ wbp = Wt + (int64_t)n0 * K;
     const int rmax = rows - 1 - r0, nmax = N - 1 - n0;
     int xo[NXI], wo[NWI];
 #pragma unroll
-    for (int i = 0; i < NXI; ++i) xo[i] = min(sr + 8 * i, rmax) * K;
+    for (int i = 0; i < NXI; ++i) xo[i] = min(sr + RSTEP * i, rmax) * K;
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) wo[i] = min(sr + 8 * i, nmax) * K;
-    float xr[NXI], wr[NWI];
+    for (int i = 0; i < NWI; ++i) wo[i] = min(sr + RSTEP * i, nmax) * K;
+    float xr[NXI][EPL], wr[NWI][EPL];
     auto fetch = [&](int k0) {
-        const int kc = min(k0 + sk, K - 1);
+        const int kc = min(k0 + sk, K - EPL);
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) xr[i] = xb[xo[i] + kc];
+        for (int i = 0; i < NXI; ++i) {
+            if constexpr (VEC) { const float4 v = *reinterpret_cast<const float4*>(xb + xo[i] + kc); xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w; }
+            else xr[i][0] = xb[xo[i] + kc];
+        }
 #pragma unroll
-        for (int i = 0; i < NWI; ++i) wr[i] = wbp[wo[i] + kc];
+        for (int i = 0; i < NWI; ++i) {
+            if constexpr (VEC) { const float4 v = *reinterpret_cast<const float4*>(wbp + wo[i] + kc); wr[i][0] = v.x; wr[i][1] = v.y; wr[i][2] = v.z; wr[i][3] = v.w; }
+            else wr[i][0] = wbp[wo[i] + kc];
+        }
     };
     f32x16 acc[NTL];
 #pragma unroll
@@ -61,9 +71,14 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
     for (int k0 = 0; k0 < K; k0 += LIN_KC) {
         const bool kin = k0 + sk < K;                     // masks are applied here, after the loads have landed
 #pragma unroll
-        for (int i = 0; i < NXI; ++i) xs[(sr + 8 * i) * LIN_KP + sk] = (kin && sr + 8 * i <= rmax) ? xr[i] : 0.f;
+        for (int i = 0; i < NXI; ++i)
 #pragma unroll
-        for (int i = 0; i < NWI; ++i) ws[(sr + 8 * i) * LIN_KP + sk] = (kin && sr + 8 * i <= nmax) ? wr[i] : 0.f;
+            for (int j = 0; j < EPL; ++j) xs[(sr + RSTEP * i) * LIN_KP + sk + j] = (kin && sr + RSTEP * i <= rmax) ? xr[i][j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NWI; ++i)
+#pragma unroll
+            for (int j = 0; j < EPL; ++j)
+                if (sr + RSTEP * i < LIN_COLS) ws[(sr + RSTEP * i) * LIN_KP + sk + j] = (kin && sr + RSTEP * i <= nmax) ? wr[i][j] : 0.f;
         __syncthreads();
         if (k0 + LIN_KC < K) fetch(k0 + LIN_KC);
 #pragma unroll
@@ -343,14 +358,15 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
     // column tiles per workgroup: 3 (96 features).  5 / 6 tiles (N = 152 / 192 in one pass, no padded MFMA work) were
     // measured: faster at 65 K rows, slower at 147 K rows and in the ATM forward end to end - fewer, longer workgroups
     // quantise worse over the 256 CUs (tools/dev/lin_sweep.py)
-    const int nt = (N + 31) / 32, ntl = 3;
+    constexpr int ntl = 3;
+    const int nt = (N + 31) / 32;
     dim3 grid((rows + LIN_ROWS - 1) / LIN_ROWS, (nt + ntl - 1) / ntl);
     hipStream_t st = cf_s(stream);
-#define CF_LIN(A, T) k_linear<A, T><<<grid, dim3(256), 0, st>>>(x, Wt, bias, res, y, rows, K, N)
-#define CF_LIN_A(T) (act == 0 ? CF_LIN(0, T) : (act == 1 ? CF_LIN(1, T) : CF_LIN(2, T)))
-    if (ntl == 3) CF_LIN_A(3);
-    else if (ntl == 5) CF_LIN_A(5);
-    else CF_LIN_A(6);
+    const bool vec = K % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Wt)) & 15) == 0;
+#define CF_LIN(A, T, V) k_linear<A, T, V><<<grid, dim3(256), 0, st>>>(x, Wt, bias, res, y, rows, K, N)
+#define CF_LIN_A(T, V) (act == 0 ? CF_LIN(0, T, V) : (act == 1 ? CF_LIN(1, T, V) : CF_LIN(2, T, V)))
+    if (vec) CF_LIN_A(3, true);
+    else CF_LIN_A(3, false);
 #undef CF_LIN_A
 #undef CF_LIN
     CF_LAUNCH_CHECK();

@@ -133,8 +133,7 @@ def _flow_encoder_backward(encoder, context, gc, glq, grads):
             u, _ = mod(u, ctx)
     u = u.contiguous()
     su = torch.empty_like(u)
-    act_ldj = _new(B, like=gc)
-    _hip.call("cf_sigmoid_ldj", _hip.p(u), _hip.p(su), _hip.p(act_ldj), B, n, st)
+    _hip.call("cf_sigmoid_ldj", _hip.p(u), _hip.p(su), _hip.p(_new(B, like=gc)), B, n, st)     # only sigmoid(u) is needed here
     # ---- heads: d/d sigmoid(u) from d/dc, sign of log q in the encoder's log-density
     if isinstance(encoder, VariationalCatDequantization):    # z = (x + su) / K ; ldj = const + act_ldj - log q
         gsu, sq = gc / encoder.qbins, -1.0
