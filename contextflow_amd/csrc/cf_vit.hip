@@ -2,7 +2,7 @@
 //
 // The dense contractions (patch embedding, qkv, out-projection, MLP) run on the exact-fp32 matrix
 // cores (v_mfma_f32_32x32x2_f32): rows = samples x tokens, K, N <= a few hundred.  One workgroup
-// owns 128 rows x (<= 96) output features; X and the W slice go through LDS in K-chunks of 32 with
+// owns 128 rows x (<= 96) output features; X and the W slice go through LDS in K-chunks of 16 with
 // an odd row stride, so both MFMA operand reads (lane -> row, lane>>5 -> k) are bank-conflict free.
 // LayerNorm, the tiny (tokens x tokens) attention and the patch index maps are VALU kernels.
 #include "cf_common.h"
