@@ -106,10 +106,27 @@ __global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* src = qkv + (int64_t)b * N * 3 * dh;
     const float* gsrc = go + (int64_t)b * N * dh;
-    for (int r = tid >> 6; r < N; r += nt >> 6) {         // a wave per row: no index division
-        for (int c = tid & 63; c < 3 * dh; c += 64) s_qkv[r * RS + c] = src[r * 3 * dh + c];
-        for (int c = tid & 63; c < dh; c += 64) s_go[r * GS + c] = gsrc[r * dh + c];
-    }
+    // staging in batches of 8 independent 16-byte loads per thread (dh is a multiple of 4, rows are 16-byte aligned)
+    auto stage = [&](const float* g, float* l, int width, int stride) {
+        const int q4 = width / 4, total = N * q4;
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        for (int e0 = tid; e0 < total; e0 += 8 * nt) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = g4[min(e0 + i * nt, total - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * nt;
+                if (e < total) {
+                    const int r = e / q4, c = 4 * (e - r * q4);
+                    float* d = l + r * stride + c;
+                    d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+                }
+            }
+        }
+    };
+    stage(src, s_qkv, 3 * dh, RS);
+    stage(gsrc, s_go, dh, GS);
     __syncthreads();
     // P = q k^T and dP = go v^T: a thread owns key j and 2 query rows - one k / v read feeds 2 FMAs each
     const int NQ = (N + 1) >> 1;
@@ -232,7 +249,8 @@ int cf_layernorm_bwd(const float* x, const float* w, const float* gy, float* gx,
 
 int cf_attention_bwd(const float* qkv, const float* go, float* gqkv, int B, int N, int dh, float scale, cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(qkv && go && gqkv && B >= 0 && N > 0 && dh > 0);
+    CF_REQUIRE(qkv && go && gqkv && B >= 0 && N > 0 && dh > 0 && dh % 4 == 0 &&
+               ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(go)) & 15) == 0);
     const size_t lds = (size_t)(N * (3 * dh + 1) + N * (dh + 1) + 2 * N * (N | 1)) * sizeof(float);
     if (lds > 64 * 1024) { cf_set_error("cf_attention_bwd: N=%d dh=%d needs %zu B of LDS", N, dh, lds); return CF_ERR_UNSUPPORTED; }
     k_attention_bwd<<<dim3(B), dim3(N >= 16 ? 256 : 64), lds, cf_s(stream)>>>(qkv, go, gqkv, N, dh, scale);

@@ -275,8 +275,26 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     float* dots = lds + N * RS;           // [N][N]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* src = qkv + (int64_t)b * N * 3 * dh;
-    for (int r = tid >> 6; r < N; r += nt >> 6)           // a wave per row: no index division
-        for (int c = tid & 63; c < 3 * dh; c += 64) s_qkv[r * RS + c] = src[r * 3 * dh + c];
+    // staging in batches of 8 independent 16-byte loads per thread (one dependent load -> store round trip per element
+    // was the whole cost of this kernel); 3 dh is a multiple of 4 and the rows of qkv are 16-byte aligned
+    {
+        const int q4 = 3 * dh / 4, total = N * q4;                    // float4 per row, per sample
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int e0 = tid; e0 < total; e0 += 8 * nt) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src4[min(e0 + i * nt, total - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = e0 + i * nt;
+                if (e < total) {
+                    const int r = e / q4, c = 4 * (e - r * q4);
+                    float* d = s_qkv + r * RS + c;
+                    d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+                }
+            }
+        }
+    }
     __syncthreads();
     // q k^T: a thread owns key j and 4 query rows - one k read feeds 4 FMAs (the q reads are wave broadcasts)
     const int NQ = (N + 3) >> 2;
@@ -298,13 +316,20 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
         if (i0 + 3 < N) dots[(i0 + 3) * N + j] = a3 * scale;
     }
     __syncthreads();
-    for (int i = tid; i < N; i += nt) {
+    // row softmax: 8 lanes per row (columns j = l, l + 8, ...), max / sum through xor shuffles inside the group
+    for (int i = tid >> 3; i < N; i += nt >> 3) {
+        const int l = tid & 7;
+        float* row = dots + i * N;
         float mx = -INFINITY;
-        for (int j = 0; j < N; ++j) mx = fmaxf(mx, dots[i * N + j]);
+        for (int j = l; j < N; j += 8) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         float sum = 0.f;
-        for (int j = 0; j < N; ++j) { const float e = expf(dots[i * N + j] - mx); dots[i * N + j] = e; sum += e; }
+        for (int j = l; j < N; j += 8) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         const float inv = 1.0f / sum;
-        for (int j = 0; j < N; ++j) dots[i * N + j] *= inv;
+        for (int j = l; j < N; j += 8) row[j] *= inv;
     }
     __syncthreads();
     // P v: a thread owns feature d of 4 output rows - one v read feeds 4 FMAs
@@ -425,7 +450,7 @@ int cf_layernorm(const float* x, const float* w, const float* b, const float* po
 int cf_attention(const float* qkv, float* out, int B, int N, int dh, float scale, cf_stream_t stream) {
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(qkv && out && B >= 0 && N > 0 && dh > 0);
-    CF_REQUIRE(dh % 2 == 0);
+    CF_REQUIRE(dh % 4 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0);
     const size_t lds = (size_t)(N * (3 * dh + 1) + N * N) * sizeof(float);
     if (lds > 64 * 1024) { cf_set_error("cf_attention: N=%d dh=%d needs %zu B of LDS", N, dh, lds); return CF_ERR_UNSUPPORTED; }
     k_attention<<<dim3(B), dim3(N >= 16 ? 256 : 64), lds, cf_s(stream)>>>(qkv, out, N, dh, scale);
