@@ -238,6 +238,8 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __rest
 
 // LayerNorm over the last dim (biased variance, eps) + optional positional embedding add:
 // y[r, :] = LN(x[r, :]) * w + b (+ pe[r % ntok, :]).  16 lanes per row.   simple_vit.py:33,50,74,104-106,122
+// CACHED (dim <= 256): the row is read once into registers (16 values per lane, all loads in flight together).
+template <bool CACHED>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ b, const float* __restrict__ pe,
                                                    float* __restrict__ y, int rows, int dim, int ntok, float eps) {
@@ -245,22 +247,47 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool ok = row < rows;
     const float* xr = x + (ok ? row : 0) * dim;
+    float xv[CACHED ? 16 : 1];
     float s = 0.f;
-    for (int j = g; j < dim; j += 16) s += xr[j];
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xv[i] = (g + 16 * i < dim) ? xr[g + 16 * i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += xv[i];
+    } else {
+        for (int j = g; j < dim; j += 16) s += xr[j];
+    }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / (float)dim;
     float v = 0.f;
-    for (int j = g; j < dim; j += 16) { const float d = xr[j] - mean; v = fmaf(d, d, v); }
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float d = (g + 16 * i < dim) ? xv[i] - mean : 0.f; xv[i] = d; v = fmaf(d, d, v); }
+    } else {
+        for (int j = g; j < dim; j += 16) { const float d = xr[j] - mean; v = fmaf(d, d, v); }
+    }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     const float rstd = 1.0f / sqrtf(v / (float)dim + eps);
     if (!ok) return;
     const float* per = pe ? pe + (row % ntok) * dim : nullptr;
-    for (int j = g; j < dim; j += 16) {
-        float o = (xr[j] - mean) * rstd * w[j] + b[j];
-        if (per) o += per[j];
-        y[row * dim + j] = o;
+    if constexpr (CACHED) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = g + 16 * i;
+            if (j < dim) {
+                float o = xv[i] * rstd * w[j] + b[j];
+                if (per) o += per[j];
+                y[row * dim + j] = o;
+            }
+        }
+    } else {
+        for (int j = g; j < dim; j += 16) {
+            float o = (xr[j] - mean) * rstd * w[j] + b[j];
+            if (per) o += per[j];
+            y[row * dim + j] = o;
+        }
     }
 }
 
@@ -442,7 +469,8 @@ int cf_layernorm(const float* x, const float* w, const float* b, const float* po
     if (rows == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && w && b && y && rows >= 0 && dim > 0 && (pos == nullptr || ntok > 0));
     if (rows == 0) return 0;
-    k_layernorm<<<dim3((rows + 15) / 16), dim3(256), 0, cf_s(stream)>>>(x, w, b, pos, y, rows, dim, ntok > 0 ? ntok : 1, eps);
+    if (dim <= 256) k_layernorm<true><<<dim3((rows + 15) / 16), dim3(256), 0, cf_s(stream)>>>(x, w, b, pos, y, rows, dim, ntok > 0 ? ntok : 1, eps);
+    else k_layernorm<false><<<dim3((rows + 15) / 16), dim3(256), 0, cf_s(stream)>>>(x, w, b, pos, y, rows, dim, ntok > 0 ? ntok : 1, eps);
     CF_LAUNCH_CHECK();
     return 0;
 }
