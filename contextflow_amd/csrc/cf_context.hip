@@ -42,6 +42,34 @@ __global__ __launch_bounds__(256) void k_ctx_encode(const int64_t* __restrict__ 
 //   W_b = tril(m, -1) + diag(exp(diag m))            [+ NN - I under contextflow]
 //   z[b] = W_b x[b] per pixel;  ldj[b] = H W sum(diag m)   (the caller adds H W log|det NN| under contextflow -
 //   the reference's own expression, not the log-det of W_b).
+// global -> LDS copy of n contiguous floats by the 256 threads of a workgroup, in batches of 8 independent loads per
+// thread (16-byte loads when n and the source allow): a `dst[e] = src[e]` loop with a runtime bound is compiled to one
+// dependent load -> store round trip per element, which makes these one-workgroup-per-sample kernels latency-bound.
+__device__ __forceinline__ void stage_copy(float* __restrict__ dst, const float* __restrict__ src, int n, int tid) {
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int n4 = n >> 2;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int e0 = tid; e0 < n4; e0 += 8 * 256) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = s4[min(e0 + i * 256, n4 - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (e0 + i * 256 < n4) d4[e0 + i * 256] = v[i];
+        }
+    } else {
+        for (int e0 = tid; e0 < n; e0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src[min(e0 + i * 256, n - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (e0 + i * 256 < n) dst[e0 + i * 256] = v[i];
+        }
+    }
+}
+
 // One workgroup per sample: W_b^T (row stride CP = C rounded up to 8, zero padded) and x in LDS; a thread owns one
 // pixel and 8 output channels at a time - per input channel one x read and two 16-byte (broadcast) reads of W_b^T.
 __global__ __launch_bounds__(256) void k_conv1x1_ctx(const float* __restrict__ x, const float* __restrict__ m,
@@ -52,22 +80,25 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx(const float* __restrict__ x
     float* Wt = dyn;                                  // Wt[i][o] = W_b[o][i], row stride CP
     float* xs = dyn + C * CP;                         // [C][HW]
     float* scr = xs + C * HW;                         // [4] (inside the dynamic block: no static LDS next to a 160 KiB request)
+    float* ms = scr + 4;                              // [C*C] this sample's CN(c) output, staged before the transposed read
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* mb = m + (int64_t)b * C * C;
     const float* xb = x + (int64_t)b * xbs;
+    stage_copy(ms, mb, C * C, tid);
+    __syncthreads();
     float dsum = 0.f;
     for (int e = tid; e < C * CP; e += 256) {
         const int i = e / CP, o = e - i * CP;
         float w = 0.f;
         if (o < C) {
-            const float v = mb[o * C + i];
+            const float v = ms[o * C + i];
             w = o > i ? v : (o == i ? expf(v) : 0.f);
             if (o == i) dsum += v;
             if (Wm != nullptr) w += Wm[o * C + i] - (o == i ? 1.f : 0.f);
         }
         Wt[e] = w;
     }
-    for (int e = tid; e < C * HW; e += 256) xs[e] = xb[e];
+    stage_copy(xs, xb, C * HW, tid);                  // xs is 16-byte aligned: C * CP is a multiple of 8
     dsum = cf_block_sum<4>(dsum, scr);                // also the barrier that publishes Wt / xs
     if (tid == 0) ldj[b] = dsum * (float)HW;
     float* zb = z + (int64_t)b * C * HW;
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(256) void k_gmm_ctx(const float* __restrict__ x, co
         const int b = min(b0 + s, B - 1);                       // ragged last workgroup: recompute the last sample
         co[s] = (int64_t)b * 2 * MK * D;
         io[s] = TAB ? (int64_t)tb.key[b] * MK * N : 0;
-        for (int e = tid; e < N; e += 256) xs[s * N + e] = x[(int64_t)b * xbs + e];
+        stage_copy(xs + s * N, x + (int64_t)b * xbs, N, tid);
     }
     __syncthreads();
     gmm_ctx_logjoint<S, TAB>(xs, lpw, lp, mG, sG, logw, c, co, tb, io, b0, B, MK, D, HW, lane, wave);
@@ -331,10 +362,15 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx_bwd(const float* __restrict
     const float* mb = m + (int64_t)b * C * C;
     const float* xb = x + (int64_t)b * xbs;
     const float* gb = gz + (int64_t)b * gzbs;
-    for (int e = tid; e < C * HW; e += 256) {
-        const int c = e / HW, p = e - c * HW;
-        xs[c * HWP + p] = xb[e];
-        gs[c * HWP + p] = gb[e];
+    for (int e0 = tid; e0 < C * HW; e0 += 4 * 256) {   // batches of independent loads (padded rows: scalar stores)
+        float xv[4], gv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int e = min(e0 + i * 256, C * HW - 1); xv[i] = xb[e]; gv[i] = gb[e]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = e0 + i * 256;
+            if (e < C * HW) { const int c = e / HW, p = e - c * HW; xs[c * HWP + p] = xv[i]; gs[c * HWP + p] = gv[i]; }
+        }
     }
     for (int e = tid; e < C * CP; e += 256) {
         const int o = e / CP, i = e - o * CP;
@@ -464,7 +500,7 @@ __global__ __launch_bounds__(256) void k_gmm_ctx_bwd(const float* __restrict__ x
         live[s] = b0 + s < B;
         co[s] = (int64_t)b * 2 * MK * D;
         io[s] = TAB ? (int64_t)tb.key[b] * MK * N : 0;
-        for (int e = tid; e < N; e += 256) xs[s * N + e] = x[(int64_t)b * xbs + e];
+        stage_copy(xs + s * N, x + (int64_t)b * xbs, N, tid);
     }
     __syncthreads();
     if (lp_in) {
@@ -666,7 +702,7 @@ int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, fl
                    int64_t x_bstride, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && m && z && ldj && B >= 0 && C > 0 && HW > 0);
-    const size_t lds = (size_t)(C * ((C + 7) & ~7) + C * HW + 4) * sizeof(float);
+    const size_t lds = (size_t)(C * ((C + 7) & ~7) + C * HW + 4 + C * C) * sizeof(float);
     if (lds > 160 * 1024) { cf_set_error("cf_conv1x1_ctx: C=%d, H*W=%d need %zu B of LDS", C, HW, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
         static bool raised = false;
