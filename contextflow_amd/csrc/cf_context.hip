@@ -42,6 +42,13 @@ __global__ __launch_bounds__(256) void k_ctx_encode(const int64_t* __restrict__ 
 //   W_b = tril(m, -1) + diag(exp(diag m))            [+ NN - I under contextflow]
 //   z[b] = W_b x[b] per pixel;  ldj[b] = H W sum(diag m)   (the caller adds H W log|det NN| under contextflow -
 //   the reference's own expression, not the log-det of W_b).
+// row stride of the transposed per-sample matrix in LDS: C rounded up to 8 (16-byte rows for the float4 reads), plus 4
+// when that is a multiple of 32 (the transposed writes would otherwise all land in one bank)
+__host__ __device__ inline int conv1x1_ctx_cp(int C) {
+    const int cp = (C + 7) & ~7;
+    return (cp & 31) == 0 ? cp + 4 : cp;
+}
+
 // global -> LDS copy of n contiguous floats by the 256 threads of a workgroup, in batches of 8 independent loads per
 // thread (16-byte loads when n and the source allow): a `dst[e] = src[e]` loop with a runtime bound is compiled to one
 // dependent load -> store round trip per element, which makes these one-workgroup-per-sample kernels latency-bound.
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx(const float* __restrict__ x
                                                      const float* __restrict__ Wm, float* __restrict__ z,
                                                      float* __restrict__ ldj, int C, int HW, int64_t xbs) {
     extern __shared__ __align__(16) float dyn[];
-    const int CP = (C + 7) & ~7;
+    const int CP = conv1x1_ctx_cp(C);
     float* Wt = dyn;                                  // Wt[i][o] = W_b[o][i], row stride CP
     float* xs = dyn + C * CP;                         // [C][HW]
     float* scr = xs + C * HW;                         // [4] (inside the dynamic block: no static LDS next to a 160 KiB request)
@@ -87,16 +94,27 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx(const float* __restrict__ x
     stage_copy(ms, mb, C * C, tid);
     __syncthreads();
     float dsum = 0.f;
-    for (int e = tid; e < C * CP; e += 256) {
-        const int i = e / CP, o = e - i * CP;
-        float w = 0.f;
-        if (o < C) {
-            const float v = ms[o * C + i];
-            w = o > i ? v : (o == i ? expf(v) : 0.f);
-            if (o == i) dsum += v;
-            if (Wm != nullptr) w += Wm[o * C + i] - (o == i ? 1.f : 0.f);
+    // lanes walk i: ms read without bank conflicts, Wt written at stride CP; the shared NN matrix is fetched in batches of
+    // independent loads (a load inside the element loop costs one full memory latency per element)
+    for (int e0 = tid; e0 < CP * C; e0 += 8 * 256) {
+        float wm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wm[k] = Wm != nullptr ? Wm[min(e0 + k * 256, C * C - 1)] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + k * 256;
+            if (e < CP * C) {
+                const int o = e / C, i = e - o * C;
+                float w = 0.f;
+                if (o < C) {
+                    const float v = ms[e];
+                    w = o > i ? v : (o == i ? expf(v) : 0.f);
+                    if (o == i) dsum += v;
+                    if (Wm != nullptr) w += wm[k] - (o == i ? 1.f : 0.f);
+                }
+                Wt[i * CP + o] = w;
+            }
         }
-        Wt[e] = w;
     }
     stage_copy(xs, xb, C * HW, tid);                  // xs is 16-byte aligned: C * CP is a multiple of 8
     dsum = cf_block_sum<4>(dsum, scr);                // also the barrier that publishes Wt / xs
@@ -372,15 +390,27 @@ __global__ __launch_bounds__(256) void k_conv1x1_ctx_bwd(const float* __restrict
             if (e < C * HW) { const int c = e / HW, p = e - c * HW; xs[c * HWP + p] = xv[i]; gs[c * HWP + p] = gv[i]; }
         }
     }
-    for (int e = tid; e < C * CP; e += 256) {
-        const int o = e / CP, i = e - o * CP;
-        float w = 0.f;
-        if (i < C) {
-            const float v = mb[o * C + i];
-            w = o > i ? v : (o == i ? expf(v) : 0.f);
-            if (Wm != nullptr) w += Wm[o * C + i] - (o == i ? 1.f : 0.f);
+    for (int e0 = tid; e0 < C * CP; e0 += 8 * 256) {   // batches of independent loads (see k_conv1x1_ctx)
+        float mv[8], wm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = min(e0 + k * 256, C * CP - 1), o = e / CP, i = min(e - o * CP, C - 1);
+            mv[k] = mb[o * C + i];
+            wm[k] = Wm != nullptr ? Wm[o * C + i] : 0.f;
         }
-        Wb[e] = w;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + k * 256;
+            if (e < C * CP) {
+                const int o = e / CP, i = e - o * CP;
+                float w = 0.f;
+                if (i < C) {
+                    w = o > i ? mv[k] : (o == i ? expf(mv[k]) : 0.f);
+                    if (Wm != nullptr) w += wm[k] - (o == i ? 1.f : 0.f);
+                }
+                Wb[e] = w;
+            }
+        }
     }
     __syncthreads();
     float* gxb = gx + (int64_t)b * C * HW;
@@ -702,7 +732,7 @@ int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, fl
                    int64_t x_bstride, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && m && z && ldj && B >= 0 && C > 0 && HW > 0);
-    const size_t lds = (size_t)(C * ((C + 7) & ~7) + C * HW + 4 + C * C) * sizeof(float);
+    const size_t lds = (size_t)(C * conv1x1_ctx_cp(C) + C * HW + 4 + C * C) * sizeof(float);
     if (lds > 160 * 1024) { cf_set_error("cf_conv1x1_ctx: C=%d, H*W=%d need %zu B of LDS", C, HW, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
         static bool raised = false;
