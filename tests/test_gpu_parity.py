@@ -2,6 +2,7 @@
 (libcontextflow_hip.so via contextflow_amd.layers) and is checked against the oracle and/or the
 committed golden vectors produced by the reference.  Tolerances: bits/dim 1e-5 (BASELINE.json),
 activations 1e-5 relative to the tensor's scale."""
+import ctypes
 import math
 import os
 
@@ -302,6 +303,25 @@ def test_abi_errors(L):
     assert lib.cf_flow_step_supported(12, 6, 10, 3, 3) == 0
     with pytest.raises(RuntimeError):
         L.Squeeze((2, 2))(torch.zeros(1, 1, 2, 2))           # CPU tensor: no fallback
+    # empty batches: every batched entry point returns 0 without touching its (null) pointers
+    N = None
+    assert lib.cf_flow_step_fwd_taped(N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, 0, N) == 0
+    assert lib.cf_flow_step_bwd_taped(N, N, N, N, N, N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, 0, N) == 0
+    assert lib.cf_flow_step_fwd_ctx_taped(N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, N) == 0
+    assert lib.cf_gmm_ctx_logprob(N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
+    assert lib.cf_gmm_ctx_logprob_tab(N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
+    assert lib.cf_gmm_ctx_bwd(N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, N) == 0
+    assert lib.cf_gmm_ctx_bwd_tab(N, N, N, N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, N) == 0
+    assert lib.cf_gmm_ctx_pgrad_tab(N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 256, N) == 0
+    assert lib.cf_gmm_ctx_tables(N, N, N, N, N, 0, 4, 4, 16, N) == 0
+    assert lib.cf_conv1x1_ctx(N, N, N, N, N, 0, 16, 64, 1024, N) == 0
+    assert lib.cf_conv1x1_ctx_bwd(N, N, N, N, N, N, N, 0, 16, 64, 1024, 1024, N) == 0
+    assert lib.cf_linear(N, N, N, N, N, 0, 8, 8, 0, N) == 0
+    assert lib.cf_activation(N, N, N, 0, 8, 2, 0.3, 0.0, N, 0, N) == 0
+    assert lib.cf_attention(N, N, 0, 4, 64, 0.125, N) == 0
+    # shapes outside a kernel's range are refused with a message, not launched
+    assert lib.cf_slogdet_inverse(ctypes.c_void_p(16), 193, ctypes.c_void_p(16), N, N) == -2 and b"193" in lib.cf_last_error()
+    assert lib.cf_linear_wgrad(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), N, ctypes.c_void_p(16), 8, 300, 300, N) == -2
 
 
 @pytest.mark.parametrize("tag,indiv", [("spline_shared", False), ("spline_indiv", True)])
