@@ -204,6 +204,7 @@ struct GmmTab {
     const float* dsig;     // (U, MK, N)  softplus'(sG + cs_u)    (backward only)
     const float* lsum;     // (U, MK)     sum_e log softplus(sG + cs_u)
     const int* key;        // (B)         u of every sample
+    const int* ckey;       // (B) or NULL: the mean shifts come from a table too - c is then (Um, MK, D) and ckey its row
 };
 
 template <int S, bool TAB>
@@ -225,7 +226,7 @@ __device__ __forceinline__ void gmm_ctx_logjoint(const float* __restrict__ xs, f
             if (d < D) {
                 float cm[S], cs[S];
 #pragma unroll
-                for (int s = 0; s < S; ++s) { cm[s] = c[co[s] + mk * D + d]; cs[s] = c[co[s] + (MK + mk) * D + d]; }
+                for (int s = 0; s < S; ++s) { cm[s] = c[co[s] + mk * D + d]; cs[s] = TAB ? 0.f : c[co[s] + (MK + mk) * D + d]; }
                 for (int p = L.pl; p < HW; p += L.SEG) {
                     const int e = d * HW + p;
                     if constexpr (TAB) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void k_gmm_ctx(const float* __restrict__ x, co
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int b = min(b0 + s, B - 1);                       // ragged last workgroup: recompute the last sample
-        co[s] = (int64_t)b * 2 * MK * D;
+        co[s] = (TAB && tb.ckey) ? (int64_t)tb.ckey[b] * MK * D : (int64_t)b * 2 * MK * D;
         io[s] = TAB ? (int64_t)tb.key[b] * MK * N : 0;
         stage_copy(xs + s * N, x + (int64_t)b * xbs, N, tid);
     }
@@ -774,7 +775,7 @@ int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const f
     if (B == 0) return 0;
     CF_REQUIRE(x && mG && sG && logw && c && out && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
     int rc = gmm_ctx_fwd_launch<false>("cf_gmm_ctx_logprob", x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, x_bstride, accumulate,
-                                       GmmTab{nullptr, nullptr, nullptr, nullptr}, cf_s(stream));
+                                       GmmTab{nullptr, nullptr, nullptr, nullptr, nullptr}, cf_s(stream));
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
@@ -790,12 +791,12 @@ int cf_gmm_ctx_tables(const float* sG, const float* cs_tab, float* inv_sig, floa
 }
 
 int cf_gmm_ctx_logprob_tab(const float* x, const float* mG, const float* inv_sig, const float* lsum, const float* logw,
-                           const float* c, const int* key, float* out, float* lp_out, int B, int M, int K, int D, int HW,
-                           int64_t x_bstride, int accumulate, cf_stream_t stream) {
+                           const float* c, const int* ckey, const int* key, float* out, float* lp_out, int B, int M, int K,
+                           int D, int HW, int64_t x_bstride, int accumulate, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && mG && inv_sig && lsum && logw && c && key && out && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
     int rc = gmm_ctx_fwd_launch<true>("cf_gmm_ctx_logprob_tab", x, mG, nullptr, logw, c, out, lp_out, B, M, K, D, HW, x_bstride,
-                                      accumulate, GmmTab{inv_sig, nullptr, lsum, key}, cf_s(stream));
+                                      accumulate, GmmTab{inv_sig, nullptr, lsum, key, ckey}, cf_s(stream));
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
@@ -870,7 +871,7 @@ int cf_gmm_ctx_bwd(const float* x, const float* mG, const float* sG, const float
     if (B == 0) return 0;
     CF_REQUIRE(x && mG && sG && logw && c && g && gx && gc && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
     int rc = gmm_ctx_bwd_launch<false>("cf_gmm_ctx_bwd", x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride,
-                                       GmmTab{nullptr, nullptr, nullptr, nullptr}, cf_s(stream));
+                                       GmmTab{nullptr, nullptr, nullptr, nullptr, nullptr}, cf_s(stream));
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
@@ -882,7 +883,7 @@ int cf_gmm_ctx_bwd_tab(const float* x, const float* mG, const float* inv_sig, co
     if (B == 0) return 0;
     CF_REQUIRE(x && mG && inv_sig && dsig && lsum && logw && c && key && g && gx && gc && B >= 0 && M > 0 && K > 0 && D > 0 && HW > 0);
     int rc = gmm_ctx_bwd_launch<true>("cf_gmm_ctx_bwd_tab", x, mG, nullptr, logw, c, g, lp, gx, gc, B, M, K, D, HW, x_bstride,
-                                      GmmTab{inv_sig, dsig, lsum, key}, cf_s(stream));
+                                      GmmTab{inv_sig, dsig, lsum, key, nullptr}, cf_s(stream));
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
@@ -896,7 +897,7 @@ int cf_gmm_ctx_pgrad_tab(const float* x, const float* mG, const float* inv_sig, 
     const int N = D * HW, nb = (B + slab - 1) / slab;
     CF_REQUIRE(M * K <= 65535 && nb <= 65535);
     k_gmm_ctx_pgrad<<<dim3((N + 255) / 256, M * K, nb), dim3(256), 0, cf_s(stream)>>>(
-        x, mG, c, r, pgm, pgs, B, M * K, D, HW, x_bstride, slab, GmmTab{inv_sig, dsig, nullptr, key});
+        x, mG, c, r, pgm, pgs, B, M * K, D, HW, x_bstride, slab, GmmTab{inv_sig, dsig, nullptr, key, nullptr});
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -83,7 +83,7 @@ SIGNATURES = {
     "cf_sample_channel_sums": (_c_int, [_c_p] * 2 + [_c_int] * 3 + [_c_p]),
     "cf_relu_bwd": (_c_int, [_c_p] * 3 + [_c_i64, _c_p]),
     "cf_gmm_ctx_tables": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),
-    "cf_gmm_ctx_logprob_tab": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
+    "cf_gmm_ctx_logprob_tab": (_c_int, [_c_p] * 10 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
     "cf_gmm_ctx_bwd_tab": (_c_int, [_c_p] * 12 + [_c_int] * 5 + [_c_i64, _c_p]),
     "cf_gmm_ctx_pgrad_tab": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
     "cf_gmm_ctx_bwd": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_i64, _c_p]),

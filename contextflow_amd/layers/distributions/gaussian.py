@@ -130,10 +130,11 @@ class GaussianMixtureDistribution(nn.Module):
         return gmm_prepare(self.mG.detach(), self.sG.detach(), self.wG.detach())
 
     def _scale_tables(self, context, need_dsig):
-        """Table form of the scale shifts when the context net is the embedding lookup of model.py:157,162 (CatEmbeddings +
-        EyeSampling): the pre-softplus shift of a sample depends only on the context variables whose embedding columns
-        fall in the scale half of the concatenated row, i.e. on a key with few values.  Returns (key (B) int32, inv_sig,
-        dsig | None, lsum) or None when the context net is anything else (per-sample kernel then)."""
+        """Table form of the context shifts when the context net is the embedding lookup of model.py:157,162 (CatEmbeddings +
+        EyeSampling): the concatenated embedding row is [mean shifts | pre-softplus scale shifts], so each half depends
+        only on the context variables whose embedding columns fall in it, i.e. on a key with few values.  Returns
+        (key (B) int32, inv_sig, dsig | None, lsum, ckey (B) int32, cm_tab (Um, M*K*D)) or None when the context net is
+        anything else (per-sample kernel then)."""
         from ..context import CatEmbeddings, EyeSampling
         cn = self.context_net
         if not (len(cn) == 2 and isinstance(cn[0], CatEmbeddings) and isinstance(cn[1], EyeSampling)):
@@ -143,54 +144,73 @@ class GaussianMixtureDistribution(nn.Module):
         half, dE = self.M * self.K * D, embs[0].embedding_dim
         if dE * len(embs) != 2 * half:
             return None
-        rel = [i for i in range(len(embs)) if (i + 1) * dE > half]          # variables that reach the scale half
-        U = 1
-        strides = {}
-        for i in reversed(rel):
-            strides[i] = U
-            U *= embs[i].num_embeddings
-        if U * half * H * W * 4 > (256 << 20):
+
+        def keyed(rel):                       # mixed-radix key over the relevant variables, and the grid of all its values
+            U, strides = 1, {}
+            for i in reversed(rel):
+                strides[i] = U
+                U *= embs[i].num_embeddings
+            return U, strides
+        rel_s = [i for i in range(len(embs)) if (i + 1) * dE > half]        # variables that reach the scale half
+        rel_m = [i for i in range(len(embs)) if i * dE < half]              # ... the mean half
+        Us, st_s = keyed(rel_s)
+        Um, st_m = keyed(rel_m)
+        if Us * half * H * W * 4 > (256 << 20) or Um * half * 4 > (256 << 20):
             return None
         dev = self.sG.device
         ver = (need_dsig, self.sG._version, str(dev)) + tuple(e.weight._version for e in embs)
         cache = getattr(self, "_tab_cache", None)
         if cache is None or cache[0] != ver:
-            grid = torch.zeros(U, len(embs), dtype=torch.long, device=dev)
-            u = torch.arange(U, device=dev)
-            for i in rel:
-                grid[:, i] = (u // strides[i]) % embs[i].num_embeddings
-            rows, _ = cn[0](grid)
-            cs_tab = _hip.f32(rows[:, half:])
-            inv = torch.empty(U, half * H * W, device=dev, dtype=torch.float32)
+            def rows(U, rel, strides):
+                grid = torch.zeros(U, len(embs), dtype=torch.long, device=dev)
+                u = torch.arange(U, device=dev)
+                for i in rel:
+                    grid[:, i] = (u // strides[i]) % embs[i].num_embeddings
+                return cn[0](grid)[0]
+            cs_tab = _hip.f32(rows(Us, rel_s, st_s)[:, half:])
+            cm_tab = _hip.f32(rows(Um, rel_m, st_m)[:, :half])
+            inv = torch.empty(Us, half * H * W, device=dev, dtype=torch.float32)
             dsig = torch.empty_like(inv) if need_dsig else None
-            lsum = torch.empty(U, self.M * self.K, device=dev, dtype=torch.float32)
+            lsum = torch.empty(Us, self.M * self.K, device=dev, dtype=torch.float32)
             _hip.call("cf_gmm_ctx_tables", _hip.p(_hip.f32(self.sG.detach())), _hip.p(cs_tab), _hip.p(inv), _hip.p(dsig),
-                      _hip.p(lsum), U, self.M * self.K, D, H * W, _hip.stream())
-            cache = self._tab_cache = (ver, inv, dsig, lsum)
+                      _hip.p(lsum), Us, self.M * self.K, D, H * W, _hip.stream())
+            cache = self._tab_cache = (ver, inv, dsig, lsum, cm_tab)
         ctx = context.to(device=dev, dtype=torch.long)
-        key = torch.zeros(ctx.shape[0], dtype=torch.long, device=dev)
-        for i in rel:
-            key += ctx[:, i] * strides[i]
-        return (key.to(torch.int32),) + cache[1:]
+
+        def key_of(rel, strides):
+            key = torch.zeros(ctx.shape[0], dtype=torch.long, device=dev)
+            for i in rel:
+                key += ctx[:, i] * strides[i]
+            return key.to(torch.int32)
+        return (key_of(rel_s, st_s),) + cache[1:4] + (key_of(rel_m, st_m), cache[4])
 
     def _log_prob_ctx(self, input, context, tape=None):
         """gaussian.py:146-158: per-sample shifts (B, 2, M, K, D) of the component means / pre-softplus scales."""
         if isinstance(context, list):
             context = context[0]
-        c, logp_c = self.context_net(context)
         x, xbs = _hip.bview(input)
         B, D, H, W = x.shape
         M, K = self.M, self.K
         logw = torch.log_softmax(_hip.f32(self.wG.detach()), dim=-1).contiguous()
         out = torch.empty(B, M, device=x.device, dtype=torch.float32)
+        tab = self._scale_tables(context, tape is not None)
+        if tab is not None and tape is None:
+            # evaluation with the embedding-lookup context net: both halves of the shift come from tables indexed by a
+            # key per sample - the (B, 2 M K D) rows of embeddings are never gathered (logp_c of the lookup is 0)
+            key, inv, _, lsum, ckey, cm_tab = tab
+            _hip.call("cf_gmm_ctx_logprob_tab", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(inv), _hip.p(lsum),
+                      _hip.p(logw), _hip.p(cm_tab), _hip.p(ckey), _hip.p(key), _hip.p(out), None, B, M, K, D, H * W, xbs, 0,
+                      _hip.stream())
+            return out
+        c, logp_c = self.context_net(context)
         # training: keep the per-component log-joints for the backward (it then skips their recompute)
         lp = torch.empty(B, M * K, device=x.device, dtype=torch.float32) if tape is not None else None
-        tab = self._scale_tables(context, tape is not None)
         if tab is not None:
-            key, inv, dsig, lsum = tab
+            key, inv, dsig, lsum = tab[:4]
             _hip.call("cf_gmm_ctx_logprob_tab", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(inv), _hip.p(lsum),
-                      _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(key), _hip.p(out), _hip.p(lp), B, M, K, D, H * W, xbs, 0,
+                      _hip.p(logw), _hip.p(_hip.f32(c)), None, _hip.p(key), _hip.p(out), _hip.p(lp), B, M, K, D, H * W, xbs, 0,
                       _hip.stream())
+            tab = tab[:4]
         else:
             _hip.call("cf_gmm_ctx_logprob", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(_hip.f32(self.sG.detach())),
                       _hip.p(logw), _hip.p(_hip.f32(c)), _hip.p(out), _hip.p(lp), B, M, K, D, H * W, xbs, 0, _hip.stream())

@@ -285,12 +285,14 @@ int cf_gmm_ctx_logprob(const float* x, const float* mG, const float* sG, const f
  * embedding tables, model.py:157,162): cf_gmm_ctx_tables turns cs_tab (U, M*K, D) into inv_sig = 1/softplus(sG + cs_u),
  * dsig = softplus'(sG + cs_u) (optional; backward) - both (U, M*K, D*HW) - and lsum (U, M*K) = sum log softplus(..).
  * cf_gmm_ctx_logprob_tab = cf_gmm_ctx_logprob with key (B) int32 = u of every sample; c still supplies the per-sample
- * mean shifts (its scale half is not read).  Same results, no transcendental per term.                          */
+ * mean shifts (its scale half is not read) - or, with ckey (B) != NULL, c is itself a table (Um, M*K, D) of the distinct
+ * mean shifts and ckey the row of every sample (no per-sample gather of embedding rows at all).  Same results, no
+ * transcendental per term.                                                                                       */
 int cf_gmm_ctx_tables(const float* sG, const float* cs_tab, float* inv_sig, float* dsig, float* lsum, int U, int MK, int D,
                       int HW, cf_stream_t stream);
 int cf_gmm_ctx_logprob_tab(const float* x, const float* mG, const float* inv_sig, const float* lsum, const float* logw,
-                           const float* c, const int* key, float* out, float* lp_out, int B, int M, int K, int D, int HW,
-                           int64_t x_bstride, int accumulate, cf_stream_t stream);
+                           const float* c, const int* ckey, const int* key, float* out, float* lp_out, int B, int M, int K,
+                           int D, int HW, int64_t x_bstride, int accumulate, cf_stream_t stream);
 
 /* pieces of the variational context encoder (model.py:52-79, dequantize.py:104-118):
  * ConditionalGaussianDistribution.sample (gaussian.py:263-270): c (B,2D) = [mean|log_scale], eps (B,D) ->

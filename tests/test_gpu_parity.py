@@ -309,7 +309,7 @@ def test_abi_errors(L):
     assert lib.cf_flow_step_bwd_taped(N, N, N, N, N, N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, 0, N) == 0
     assert lib.cf_flow_step_fwd_ctx_taped(N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, N) == 0
     assert lib.cf_gmm_ctx_logprob(N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
-    assert lib.cf_gmm_ctx_logprob_tab(N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
+    assert lib.cf_gmm_ctx_logprob_tab(N, N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
     assert lib.cf_gmm_ctx_bwd(N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, N) == 0
     assert lib.cf_gmm_ctx_bwd_tab(N, N, N, N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, N) == 0
     assert lib.cf_gmm_ctx_pgrad_tab(N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 256, N) == 0
@@ -572,7 +572,18 @@ def test_gmm_ctx_kernels_against_torch(L, D, H, W, M, K, B):
         gx, gc = torch.full((B, D, H, W), float("nan"), device=DEV), torch.full((B, 2 * MK * D), float("nan"), device=DEV)
         if tab:
             _hip.call("cf_gmm_ctx_logprob_tab", _hip.p(xd), _hip.p(md), _hip.p(inv), _hip.p(lsum), _hip.p(ld), _hip.p(c2d),
-                      _hip.p(keyd), _hip.p(out), _hip.p(lp), B, M, K, D, HW, D * HW, 0, st)
+                      None, _hip.p(keyd), _hip.p(out), _hip.p(lp), B, M, K, D, HW, D * HW, 0, st)
+            # the mean shifts from a table of their own (Um = 2 distinct rows) instead of per-sample rows
+            cm_tab = d(c2[:2, 0].reshape(2, MK * D))
+            ckey = torch.randint(0, 2, (B,), generator=g)
+            c3 = c2.clone()
+            c3[:, 0] = c2[:2, 0][ckey]
+            o_ref, o_tab = torch.zeros(B, M, device=DEV), torch.zeros(B, M, device=DEV)
+            _hip.call("cf_gmm_ctx_logprob_tab", _hip.p(xd), _hip.p(md), _hip.p(inv), _hip.p(lsum), _hip.p(ld), _hip.p(d(c3)),
+                      None, _hip.p(keyd), _hip.p(o_ref), None, B, M, K, D, HW, D * HW, 0, st)
+            _hip.call("cf_gmm_ctx_logprob_tab", _hip.p(xd), _hip.p(md), _hip.p(inv), _hip.p(lsum), _hip.p(ld), _hip.p(cm_tab),
+                      _hip.p(ckey.to(torch.int32).to(DEV)), _hip.p(keyd), _hip.p(o_tab), None, B, M, K, D, HW, D * HW, 0, st)
+            assert torch.equal(o_ref, o_tab)
             _hip.call("cf_gmm_ctx_bwd_tab", _hip.p(xd), _hip.p(md), _hip.p(inv), _hip.p(dsg), _hip.p(lsum), _hip.p(ld), _hip.p(c2d),
                       _hip.p(keyd), _hip.p(gd), None, _hip.p(gx), _hip.p(gc), B, M, K, D, HW, D * HW, st)
         else:
