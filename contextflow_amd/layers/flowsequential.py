@@ -254,7 +254,9 @@ class FlowSequential(nn.Module):
                 planes = None
                 if tape is not None:
                     ws, winv = ws
-                    if TAPE_PLANES:          # training: the forward kernel writes y0 / h1 / h2, the backward loads them
+                    # training: the forward kernel writes y0 / h1 / h2, the backward loads them - unless the planes of this
+                    # step would take more than 1/64 of the device memory (huge batches: recompute form, 4.5x less tape)
+                    if TAPE_PLANES and 18 * B * C * H * W <= torch.cuda.get_device_properties(dev).total_memory // 64:
                         planes = tuple(torch.empty(B, r, H * W, device=dev, dtype=torch.float32) for r in (C // 2, 2 * C, 2 * C))
                     tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws, winv, planes))
                 x, xbs = _hip.bview(x)
