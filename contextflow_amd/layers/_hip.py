@@ -53,6 +53,7 @@ SIGNATURES = {
     "cf_flow_step_bwd": (_c_int, [_c_p] * 13 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_flow_step_bwd_taped": (_c_int, [_c_p] * 13 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_flow_step_fwd_taped": (_c_int, [_c_p] * 7 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
+    "cf_step_param_grads": (_c_int, [_c_p] * 7 + [_c_int] + [_c_p] * 3 + [_c_int, _c_p]),
     "cf_wgrad_ws_bytes": (_c_i64, [_c_int] * 6),
     "cf_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
     "cf_linear_wgrad_ws_bytes": (_c_i64, [_c_int] * 3),

@@ -50,9 +50,10 @@ def gmm_backward(x, dist, prepared, g):
 
 
 # ------------------------------------------------------------------------------------------------ flow step
-def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None):
+def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
     planes: (y0, h1, h2) written by cf_flow_step_fwd_taped, or None = recompute them from x.
+    gsum: 1-element tensor sum(gld) (the same for every step of a backward pass), or None.
     Returns (dL/dx in the layout of x, {param: grad})."""
     C, H, W = shape
     HW, HALF, HID = H * W, C // 2, 2 * C
@@ -94,17 +95,21 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
     gWp, gbp = wgrad(s_gy, xs.reshape(B, C, HW), 1)
     gw3, gw1, gWp = gw3[0], gw1[0], gWp[0]
     gw2 = gw2.permute(1, 2, 0).reshape(HID, HID, 3, 3)
-    # ---- chain to Conv1x1 / ActNorm parameters:  W' = diag(s) Wm, b' = -t s, s = exp(-logs)
-    s = torch.exp(-logs)
-    G = gld.sum()
+    # ---- chain to Conv1x1 / ActNorm parameters (W' = diag(s) Wm, b' = -t s, s = exp(-logs)): one small kernel
+    if gsum is None:
+        gsum = gld.sum().reshape(1)
     if winv is None:
         lad = torch.empty(1, device=dev, dtype=torch.float32)
         winv = torch.empty(C, C, device=dev, dtype=torch.float32)
         _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
+    gNN = torch.empty(C, C, device=dev, dtype=torch.float32)
+    gt = torch.empty(C, device=dev, dtype=torch.float32)
+    glogs = torch.empty(C, device=dev, dtype=torch.float32)
+    gWpc = gWp.contiguous()
+    _hip.call("cf_step_param_grads", pp(gWpc), pp(gbp), pp(Wm), pp(t), pp(logs), pp(f(winv)), pp(f(gsum)), HW, pp(gNN), pp(gt),
+              pp(glogs), C, st)
     grads = {
-        conv.NN: s.unsqueeze(1) * gWp + (G * HW) * winv.t(),                  # + d(H W log|det W|)/dW
-        act.NN_t: -s * gbp,
-        act.NN_logs: -(gWp * (s.unsqueeze(1) * Wm)).sum(1) + gbp * t * s + G,   # quirk: ldj = +sum(logs)
+        conv.NN: gNN.view_as(conv.NN), act.NN_t: gt.view_as(act.NN_t), act.NN_logs: glogs.view_as(act.NN_logs),   # quirk: ldj = +sum(logs)
         c1.weight: gw1.reshape(c1.weight.shape), c1.bias: gb1,
         c2.weight: gw2, c2.bias: gb2,
         c3.weight: gw3.reshape(c3.weight.shape), c3.bias: gb3,
@@ -132,6 +137,7 @@ class FlowLogProb(torch.autograd.Function):
         flow, tape, params = ctx.flow, ctx.tape, ctx.params
         glogp = _hip.f32(glogp)
         gld = glogp.sum(1).contiguous()                     # d/d ld1[b]: logp = ldM + ld1[:, None]
+        gsum = gld.sum().reshape(1)                         # shared by the parameter chains of all steps
         acc = {}
 
         def add(d):
@@ -153,7 +159,7 @@ class FlowLogProb(torch.autograd.Function):
                 gz = torch.cat([gz, g2], dim=1)
             elif kind == "step":
                 _, xin, sq, conv, act, cpl, shape, ws, winv, planes = rec
-                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes)
+                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum)
                 add(gp)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)

@@ -177,6 +177,13 @@ int cf_flow_step_bwd_taped(const float* x, const float* gz, const float* gld, co
                            float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, int in_squeeze,
                            cf_stream_t stream);
 
+/* Conv1x1 / ActNorm parameter gradients of a fused step from the gradients of its folded matrix / bias (gWp (C,C) and
+ * gbp (C) = the wgrad of the g_y plane against the step input): gNN = diag(s) gWp + G H W Wm^-T, gt = -s gbp,
+ * glogs = -rowsum(gWp o diag(s) Wm) + gbp t s + G, s = exp(-logs), G = gld_sum[0] = sum_b d/d ld1[b] (device scalar). */
+int cf_step_param_grads(const float* gWp, const float* gbp, const float* Wm, const float* t, const float* logs,
+                        const float* winv, const float* gld_sum, int HW, float* gNN, float* gt, float* glogs, int C,
+                        cf_stream_t stream);
+
 /* weight gradient as a split-K MFMA GEMM over (sample, pixel):
  *   gw[t][m][n] = sum_{b,p} A[b][m][p] * Bm[b][n][src_t(p)],  t < taps (1, or 9 = 3x3 reflect-shifted pixels)
  *   gbias[m]    = sum_{b,p} A[b][m][p]                         (optional)
