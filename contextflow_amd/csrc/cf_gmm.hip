@@ -227,6 +227,36 @@ __global__ __launch_bounds__(256) void k_gmm_finish(const float* __restrict__ q,
     out[e] = accumulate ? out[e] + r : r;
 }
 
+// finishing kernel of the backward: sum the D-split partials, r[b, mk] = softmax_k(cst - q/2)[mk] * g[b, m]
+// (responsibilities times the upstream gradient).  one thread per (b, m)
+__global__ __launch_bounds__(256) void k_gmm_resp_finish(const float* __restrict__ q, const float* __restrict__ cst,
+                                                         const float* __restrict__ g, float* __restrict__ r, int B, int M,
+                                                         int K, int nsplit) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)B * M) return;
+    const int b = (int)(e / M), m = (int)(e - (int64_t)b * M);
+    const int MK = M * K;
+    float l[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < K) {
+            float s = 0.f;
+            for (int z = 0; z < nsplit; ++z) s += q[((int64_t)z * B + b) * MK + m * K + k];
+            l[k] = cst[m * K + k] - 0.5f * s;
+            mx = fmaxf(mx, l[k]);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < K) { l[k] = expf(l[k] - mx); sum += l[k]; }
+    const float sc = g[e] / sum;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < K) r[(int64_t)b * MK + m * K + k] = l[k] * sc;
+}
+
 // prior sampling (gaussian.py:163-169): x[n,:] = mG[row_n,:] + softplus(sG[row_n,:]) * eps[n,:], row_n = m*K + k_n
 __global__ __launch_bounds__(256) void k_gmm_sample(const float* __restrict__ mG, const float* __restrict__ sG,
                                                     const int64_t* __restrict__ rows, const float* __restrict__ eps,
@@ -326,6 +356,38 @@ int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float*
         else       { if (vec) CF_GO(5, true, false); else CF_GO(5, false, false); }
     }
 #undef CF_GO
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward of the mixture prior, first half: r (B, M*K) = responsibilities x upstream gradient g (B, M), D split over
+// blockIdx.z when the batch alone does not fill the chip.  ws: cf_gmm_resp_ws_bytes(...) bytes.
+int64_t cf_gmm_resp_ws_bytes(int B, int M, int K, int D) {
+    const int ns = choose_nsplit(B, M * K, D);
+    return (int64_t)ns * B * M * K * sizeof(float);
+}
+
+int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cst, const float* g, float* r, void* ws, int B,
+                int M, int K, int D, int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && a && bm && cst && g && r && ws && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
+    const int MK = M * K;
+    const bool small = MK <= 16;
+    int ns = choose_nsplit(B, MK, D);
+    int dsplit = D;
+    if (ns > 1) { dsplit = ((D + ns - 1) / ns + DC - 1) / DC * DC; ns = (D + dsplit - 1) / dsplit; }
+    const bool vec = (D % 4 == 0) && (x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(bm) & 15) == 0) &&
+                     (dsplit % 4 == 0);
+    const int mkb = small ? 16 : 80;
+    dim3 grid((B + TB - 1) / TB, (MK + mkb - 1) / mkb, ns);
+    float* q = (float*)ws;
+#define CF_GO(MKT, V) k_gmm_logprob<MKT, V, true><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, bm, nullptr, nullptr, q, B, MK, K, D, dsplit, x_bstride, 0, M)
+    if (small) { if (vec) CF_GO(1, true); else CF_GO(1, false); }
+    else       { if (vec) CF_GO(5, true); else CF_GO(5, false); }
+#undef CF_GO
+    const int64_t n = (int64_t)B * M;
+    k_gmm_resp_finish<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cf_s(stream)>>>(q, cst, g, r, B, M, K, ns);
     CF_LAUNCH_CHECK();
     return 0;
 }

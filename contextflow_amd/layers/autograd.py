@@ -25,10 +25,10 @@ def gmm_backward(x, dist, prepared, g):
     a, bm, cst, M, K, D = prepared
     xv, xbs = _hip.bview(x)
     B = xv.shape[0]
-    q = torch.empty(B, M * K, device=xv.device, dtype=torch.float32)
-    _hip.call("cf_gmm_quad", _hip.p(xv), _hip.p(a), _hip.p(bm), _hip.p(q), B, M, K, D, xbs, _hip.stream())
-    lp = (cst.unsqueeze(0) - 0.5 * q).view(B, M, K)
-    r = (torch.softmax(lp, dim=-1) * g.unsqueeze(-1)).reshape(B, M * K)      # responsibilities x upstream
+    r = torch.empty(B, M * K, device=xv.device, dtype=torch.float32)          # responsibilities x upstream
+    ws = torch.empty(_hip.lib().cf_gmm_resp_ws_bytes(B, M, K, D), device=xv.device, dtype=torch.uint8)
+    _hip.call("cf_gmm_resp", _hip.p(xv), _hip.p(a), _hip.p(bm), _hip.p(cst), _hip.p(_hip.f32(g)), _hip.p(r), _hip.p(ws), B, M, K,
+              D, xbs, _hip.stream())
     xf = xv.reshape(B, -1) if xv.is_contiguous() else xv.contiguous().reshape(B, -1)
     # d/dx = -sum_mk r a (x a + bm)
     gx = -(xf * (r @ (a * a)) + r @ (a * bm))

@@ -112,6 +112,12 @@ int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float*
  * softmax_k(cst - q/2) from it.                                                                        */
 int cf_gmm_quad(const float* x, const float* a, const float* bm, float* q, int B, int M, int K, int D,
                 int64_t x_bstride, cf_stream_t stream);
+/* backward, first half in one call: r (B, M*K) = softmax_k(cst - q/2) * g[b, m] - the component responsibilities times the
+ * upstream gradient g (B, M); the reduction over D is split over workgroups when B alone does not fill the chip.
+ * ws: cf_gmm_resp_ws_bytes(...) bytes.                                                                          */
+int64_t cf_gmm_resp_ws_bytes(int B, int M, int K, int D);
+int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cst, const float* g, float* r, void* ws, int B,
+                int M, int K, int D, int64_t x_bstride, cf_stream_t stream);
 /* prior sampling (gaussian.py:163-169): out[n,:] = mG[rows[n],:] + softplus(sG[rows[n],:]) * eps[n,:];
  * rows[n] = m*K + k_n (int64, component drawn by the caller), eps ~ N(0,1) supplied by the caller.      */
 int cf_gmm_sample(const float* mG, const float* sG, const int64_t* rows, const float* eps, float* out, int N, int D,
