@@ -257,6 +257,41 @@ __global__ __launch_bounds__(256) void k_gmm_resp_finish(const float* __restrict
         if (k < K) r[(int64_t)b * MK + m * K + k] = l[k] * sc;
 }
 
+// ---- elementwise pieces of the mixture backward (autograd.py gmm_backward), one launch each instead of a chain of
+// parameter-sized torch kernels ------------------------------------------------------------------------------------
+// A2 = a a, AB = a bm: right-hand sides of the two (B x MK) x (MK x D) products of d/dx
+__global__ __launch_bounds__(256) void k_gmm_bwd_coeffs(const float* __restrict__ a, const float* __restrict__ bm,
+                                                        float* __restrict__ A2, float* __restrict__ AB, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float av = a[e];
+        A2[e] = av * av;
+        AB[e] = av * bm[e];
+    }
+}
+// gx[b, d] = -(x[b, d] G1[b, d] + G2[b, d]),  G1 = r A2, G2 = r AB
+__global__ __launch_bounds__(256) void k_gmm_bwd_gx(const float* __restrict__ x, const float* __restrict__ G1,
+                                                    const float* __restrict__ G2, float* __restrict__ gx, int D, int64_t xbs,
+                                                    int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t b = e / D;
+        gx[e] = -fmaf(x[b * xbs + (e - b * D)], G1[e], G2[e]);
+    }
+}
+// parameter gradients from the batch sums S0 (MK) = sum_b r, S1 = r^T x, S2 = r^T x^2 (MK x D):
+//   t = a x + bm;  g_mu = a sum_b r t;  g_sG = a (sum_b r t^2 - S0) sigmoid(sG)      (softplus' = sigmoid)
+__global__ __launch_bounds__(256) void k_gmm_bwd_params(const float* __restrict__ a, const float* __restrict__ bm,
+                                                        const float* __restrict__ sG, const float* __restrict__ S0,
+                                                        const float* __restrict__ S1, const float* __restrict__ S2,
+                                                        float* __restrict__ gmu, float* __restrict__ gsig, int D, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float av = a[e], bv = bm[e], s0 = S0[e / D], s1 = S1[e], s2 = S2[e];
+        const float rt = av * s1 + bv * s0;
+        const float rt2 = av * av * s2 + 2.0f * av * bv * s1 + bv * bv * s0;
+        gmu[e] = av * rt;
+        gsig[e] = av * (rt2 - s0) / (1.0f + expf(-sG[e]));
+    }
+}
+
 // prior sampling (gaussian.py:163-169): x[n,:] = mG[row_n,:] + softplus(sG[row_n,:]) * eps[n,:], row_n = m*K + k_n
 __global__ __launch_bounds__(256) void k_gmm_sample(const float* __restrict__ mG, const float* __restrict__ sG,
                                                     const int64_t* __restrict__ rows, const float* __restrict__ eps,
@@ -388,6 +423,35 @@ int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cs
 #undef CF_GO
     const int64_t n = (int64_t)B * M;
     k_gmm_resp_finish<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cf_s(stream)>>>(q, cst, g, r, B, M, K, ns);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+static unsigned gmm_ew_blocks(int64_t n) { const int64_t b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b > 0 ? b : 1)); }
+
+int cf_gmm_bwd_coeffs(const float* a, const float* bm, float* A2, float* AB, int MK, int D, cf_stream_t stream) {
+    CF_REQUIRE(a && bm && A2 && AB && MK > 0 && D > 0);
+    const int64_t n = (int64_t)MK * D;
+    k_gmm_bwd_coeffs<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, A2, AB, n);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_bwd_gx(const float* x, const float* G1, const float* G2, float* gx, int B, int D, int64_t x_bstride,
+                  cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && G1 && G2 && gx && D > 0 && x_bstride >= D);
+    const int64_t n = (int64_t)B * D;
+    k_gmm_bwd_gx<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(x, G1, G2, gx, D, x_bstride, n);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_gmm_bwd_params(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
+                      float* gmu, float* gsig, int MK, int D, cf_stream_t stream) {
+    CF_REQUIRE(a && bm && sG && S0 && S1 && S2 && gmu && gsig && MK > 0 && D > 0);
+    const int64_t n = (int64_t)MK * D;
+    k_gmm_bwd_params<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, sG, S0, S1, S2, gmu, gsig, D, n);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -29,22 +29,27 @@ def gmm_backward(x, dist, prepared, g):
     ws = torch.empty(_hip.lib().cf_gmm_resp_ws_bytes(B, M, K, D), device=xv.device, dtype=torch.uint8)
     _hip.call("cf_gmm_resp", _hip.p(xv), _hip.p(a), _hip.p(bm), _hip.p(cst), _hip.p(_hip.f32(g)), _hip.p(r), _hip.p(ws), B, M, K,
               D, xbs, _hip.stream())
+    dev, st, pp = xv.device, _hip.stream(), _hip.p
+    MK = M * K
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    # d/dx = -sum_mk r a (x a + bm) = -(x (r A2) + r AB): two library GEMMs (B x MK)(MK x D) and one combining kernel
+    A2, AB = new(MK, D), new(MK, D)
+    _hip.call("cf_gmm_bwd_coeffs", pp(a), pp(bm), pp(A2), pp(AB), MK, D, st)
+    gx = new(B, D)
+    _hip.call("cf_gmm_bwd_gx", pp(xv), pp(r @ A2), pp(r @ AB), pp(gx), B, D, xbs, st)
+    # parameter sums over the batch: plain GEMMs (MK x B) x (B x D), then one kernel for the chain to mG / sG
     xf = xv.reshape(B, -1) if xv.is_contiguous() else xv.contiguous().reshape(B, -1)
-    # d/dx = -sum_mk r a (x a + bm)
-    gx = -(xf * (r @ (a * a)) + r @ (a * bm))
-    # parameter sums over the batch: plain GEMMs (80 x B) x (B x D)
-    S0 = r.sum(0).unsqueeze(-1)                      # (MK, 1)
-    S1 = r.t() @ xf                                  # (MK, D)
-    S2 = r.t() @ (xf * xf)
-    rt = a * S1 + bm * S0                            # sum_b r t
-    rt2 = a * a * S2 + 2 * a * bm * S1 + bm * bm * S0
-    g_mu = a * rt
-    g_sigma = a * (rt2 - S0)
-    sG = dist.sG.detach().reshape(M * K, D)
+    rt_ = r.t()
+    S0 = r.sum(0)
+    S1 = rt_ @ xf
+    S2 = rt_ @ (xf * xf)
+    g_mu, g_sigma = new(MK, D), new(MK, D)
+    sG = _hip.f32(dist.sG.detach()).reshape(MK, D)
+    _hip.call("cf_gmm_bwd_params", pp(a), pp(bm), pp(sG), pp(S0), pp(S1), pp(S2), pp(g_mu), pp(g_sigma), MK, D, st)
     grads = {
         dist.mG: g_mu.view_as(dist.mG),
-        dist.sG: (g_sigma * torch.sigmoid(sG)).view_as(dist.sG),        # softplus' = sigmoid
-        dist.wG: r.sum(0).view(M, K) - g.sum(0).unsqueeze(-1) * torch.softmax(dist.wG.detach(), dim=-1),
+        dist.sG: g_sigma.view_as(dist.sG),
+        dist.wG: S0.view(M, K) - g.sum(0).unsqueeze(-1) * torch.softmax(dist.wG.detach(), dim=-1),
     }
     return gx.view(xv.shape), grads
 

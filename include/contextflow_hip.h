@@ -115,6 +115,14 @@ int cf_gmm_quad(const float* x, const float* a, const float* bm, float* q, int B
 /* backward, first half in one call: r (B, M*K) = softmax_k(cst - q/2) * g[b, m] - the component responsibilities times the
  * upstream gradient g (B, M); the reduction over D is split over workgroups when B alone does not fill the chip.
  * ws: cf_gmm_resp_ws_bytes(...) bytes.                                                                          */
+/* elementwise pieces of the mixture backward: A2 = a a, AB = a bm (M*K, D);  gx = -(x G1 + G2) with G1 = r A2, G2 = r AB
+ * (B, D);  g_mu / g_sG (M*K, D) from the batch sums S0 = sum_b r (M*K), S1 = r^T x, S2 = r^T x^2 (M*K, D):
+ * g_mu = a (a S1 + bm S0), g_sG = a (a^2 S2 + 2 a bm S1 + bm^2 S0 - S0) sigmoid(sG).                              */
+int cf_gmm_bwd_coeffs(const float* a, const float* bm, float* A2, float* AB, int MK, int D, cf_stream_t stream);
+int cf_gmm_bwd_gx(const float* x, const float* G1, const float* G2, float* gx, int B, int D, int64_t x_bstride,
+                  cf_stream_t stream);
+int cf_gmm_bwd_params(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
+                      float* gmu, float* gsig, int MK, int D, cf_stream_t stream);
 int64_t cf_gmm_resp_ws_bytes(int B, int M, int K, int D);
 int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cst, const float* g, float* r, void* ws, int B,
                 int M, int K, int D, int64_t x_bstride, cf_stream_t stream);
