@@ -527,11 +527,12 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
     int rc = 0;
 #define CF_STEPT(G) rc = in_squeeze ? launch_step<G, true, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp) \
                                     : launch_step<G, false, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp)
+    // small batches (the reference trains with 256 samples): the half-size workgroup geometry, as in cf_flow_step_fwd
     switch (shape_id(C, H, W)) {
         case 0: CF_STEPT(G8); break;
         case 1: CF_STEPT(G16); break;
-        case 2: CF_STEPT(G32); break;
-        case 3: CF_STEPT(G64); break;
+        case 2: if (B < 256 * G32::SPW) CF_STEPT(G32v2); else CF_STEPT(G32); break;
+        case 3: if (B < 256 * G64::SPW) CF_STEPT(G64v2); else CF_STEPT(G64); break;
         default: cf_set_error("cf_flow_step_fwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEPT
