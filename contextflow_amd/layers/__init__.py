@@ -4,10 +4,8 @@ Same class names, constructor signatures, `forward/reverse/logdet` contract and 
 underneath, every arithmetic op of the density path is a hand-written gfx950 kernel reached through
 the C ABI in include/contextflow_hip.h.
 
-To resolve sub-packages this package does not re-implement (the reference's vendored `layers.rtdl`),
-set CONTEXTFLOW_REFERENCE_LAYERS=/path/to/contextflow/layers: it is appended to this package's
-search path."""
-import os as _os
+The reference's scripts import it under the top-level name `layers`: contextflow_amd/dropin/layers is that binding
+and `python -m contextflow_amd.run <script>` the launcher."""
 
 from .flowlayer import FlowLayer, PreprocessingFlowLayer, ModifiedGradFlowLayer
 from .dequantize import Dequantization
@@ -30,7 +28,3 @@ from .context import (ArgmaxCatDequantization, CatEmbeddings, ConditionalGaussia
                       EyeEncoder, EyeSampling, OneHotEncoder, ProbSampling, UniformCatDequantization,
                       VariationalCatDequantization)
 from .unsupported import *  # noqa: F401,F403
-
-_ref = _os.environ.get("CONTEXTFLOW_REFERENCE_LAYERS")
-if _ref and _os.path.isdir(_ref):
-    __path__.append(_ref)

@@ -5,8 +5,8 @@
  * `layers` (contextflow/layers/__init__.py:1-14) whose classes implement
  * FlowLayer.forward/reverse/logdet (contextflow/layers/flowlayer.py:7-24).  This library is the
  * seam *underneath* those classes: each entry point below replaces the torch arithmetic of the
- * reference lines it cites.  the modules in `contextflow_amd/layers/` bind it with ctypes
- * (contextflow_amd/_lib.py); INTEGRATION.md shows the binding a reference maintainer would add.
+ * reference lines it cites.  The modules in `contextflow_amd/layers/` bind it with ctypes
+ * (contextflow_amd/layers/_hip.py); INTEGRATION.md shows the binding a reference maintainer would add.
  *
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer to contiguous fp32 (NCHW for activations) unless noted;
