@@ -27,6 +27,21 @@ void cf_set_error(const char* fmt, ...);
 
 static inline hipStream_t cf_s(cf_stream_t s) { return (hipStream_t)s; }
 
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel: the > 64 KiB dynamic-LDS opt-in is therefore
+// taken once per (kernel, device), not once per process.  `done` is the caller's function-local bit set.
+#include <atomic>
+static inline int cf_raise_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done, const char* who) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { cf_set_error("%s: hipGetDevice: %s", who, hipGetErrorString(e)); return (int)e; }
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { cf_set_error("%s: cannot raise dynamic LDS to %d B: %s", who, bytes, hipGetErrorString(e)); return (int)e; }
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------
 __device__ __forceinline__ float cf_wave_sum(float v) {
 #pragma unroll

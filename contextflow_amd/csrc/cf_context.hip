@@ -678,12 +678,8 @@ static int gmm_ctx_fwd_launch(const char* who, const float* x, const float* mG, 
     const int S = gmm_ctx_group(D * HW, M * K, &lds);
     if (S == 0) { cf_set_error("%s: D*HW=%d needs %zu B of LDS", who, D * HW, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx<1, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("%s: cannot raise dynamic LDS: %s", who, hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_gmm_ctx<1, TAB>, 160 * 1024, raised, __func__)) return rc_;
     }
     const dim3 grid((B + S - 1) / S);
     if (S == 4) k_gmm_ctx<4, TAB><<<grid, dim3(256), lds, st>>>(x, mG, sG, logw, c, out, lp_out, B, M, K, D, HW, xbs, accumulate, tb);
@@ -700,12 +696,8 @@ static int gmm_ctx_bwd_launch(const char* who, const float* x, const float* mG, 
     const int S = gmm_ctx_group(D * HW, M * K, &lds);
     if (S == 0) { cf_set_error("%s: D*HW=%d needs %zu B of LDS", who, D * HW, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_gmm_ctx_bwd<1, TAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("%s: cannot raise dynamic LDS: %s", who, hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_gmm_ctx_bwd<1, TAB>, 160 * 1024, raised, __func__)) return rc_;
     }
     const dim3 grid((B + S - 1) / S);
     if (S == 4) k_gmm_ctx_bwd<4, TAB><<<grid, dim3(256), lds, st>>>(x, mG, sG, logw, c, g, lp, gx, gc, B, M, K, D, HW, xbs, tb);
@@ -736,12 +728,8 @@ int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, fl
     const size_t lds = (size_t)(C * conv1x1_ctx_cp(C) + C * HW + 4 + C * C) * sizeof(float);
     if (lds > 160 * 1024) { cf_set_error("cf_conv1x1_ctx: C=%d, H*W=%d need %zu B of LDS", C, HW, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_conv1x1_ctx, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_conv1x1_ctx: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_conv1x1_ctx, 160 * 1024, raised, __func__)) return rc_;
     }
     k_conv1x1_ctx<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, m, Wm, z, ldj, C, HW, x_bstride);
     CF_LAUNCH_CHECK();
@@ -825,12 +813,8 @@ int cf_conv1x1_ctx_bwd(const float* x, const float* m, const float* Wm, const fl
     const size_t lds = (size_t)(C * ((C + 7) & ~7) + 2 * C * (HW | 1)) * sizeof(float);
     if (lds > 160 * 1024) { cf_set_error("cf_conv1x1_ctx_bwd: C=%d, H*W=%d need %zu B of LDS", C, HW, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_conv1x1_ctx_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_conv1x1_ctx_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_conv1x1_ctx_bwd, 160 * 1024, raised, __func__)) return rc_;
     }
     k_conv1x1_ctx_bwd<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, m, Wm, gz, gld, gx, gm, C, HW, x_bstride, gz_bstride);
     CF_LAUNCH_CHECK();

@@ -236,9 +236,9 @@ __global__ __launch_bounds__(256) void k_actnorm_partial(const float* __restrict
     }
 }
 
-// actnorm.py:31-33: mean, log(unbiased std + 1e-8)
-__global__ __launch_bounds__(64) void k_actnorm_final(const double* __restrict__ ws, float* __restrict__ t,
-                                                      float* __restrict__ logs, int C, double n) {
+// per-channel totals of the split partials: sums[c] = sum x, sums[C + c] = sum x^2 (fp64).  Kept as their own tensor so
+// that data-parallel ranks can all-reduce them (2C doubles per layer) and initialise from the GLOBAL batch statistics
+__global__ __launch_bounds__(64) void k_actnorm_reduce(const double* __restrict__ ws, double* __restrict__ sums, int C) {
     const int c = blockIdx.x;
     double a0 = 0.0, a1 = 0.0;
     for (int s = threadIdx.x; s < kStatSplits; s += 64) {
@@ -246,13 +246,22 @@ __global__ __launch_bounds__(64) void k_actnorm_final(const double* __restrict__
         a1 += ws[((int64_t)c * kStatSplits + s) * 2 + 1];
     }
     a0 = cf_wave_sum_d(a0); a1 = cf_wave_sum_d(a1);
-    if (threadIdx.x == 0) {
-        const double mean = a0 / n;
-        double var = (a1 - a0 * mean) / (n - 1.0);
-        if (var < 0.0) var = 0.0;
-        t[c] = (float)mean;
-        logs[c] = (float)log(sqrt(var) + 1e-8);
-    }
+    if (threadIdx.x == 0) { sums[c] = a0; sums[C + c] = a1; }
+}
+
+// actnorm.py:31-33: mean, log(unbiased std + 1e-8); n = number of elements per channel behind the sums.  `n_dev`
+// (optional) overrides n from device memory: the all-reduced element count of a sharded batch
+__global__ __launch_bounds__(256) void k_actnorm_from_sums(const double* __restrict__ sums, const double* __restrict__ n_dev,
+                                                           double n, float* __restrict__ t, float* __restrict__ logs, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (n_dev != nullptr) n = n_dev[0];
+    const double a0 = sums[c], a1 = sums[C + c];
+    const double mean = a0 / n;
+    double var = (a1 - a0 * mean) / (n - 1.0);
+    if (var < 0.0) var = 0.0;
+    t[c] = (float)mean;
+    logs[c] = (float)log(sqrt(var) + 1e-8);
 }
 
 template <bool INV>
@@ -480,15 +489,31 @@ int cf_squeeze(const float* x, float* y, int B, int C, int H, int W, int p1, int
     return 0;
 }
 
-int64_t cf_actnorm_stats_ws_bytes(int C) { return (int64_t)C * kStatSplits * 2 * sizeof(double); }
+int64_t cf_actnorm_stats_ws_bytes(int C) { return (int64_t)C * (kStatSplits + 1) * 2 * sizeof(double); }
+
+int cf_actnorm_sums(const float* x, double* sums, void* ws, int B, int C, int HW, int64_t x_bstride, cf_stream_t stream) {
+    CF_REQUIRE(x && sums && ws && B > 0 && C > 0 && HW > 0);
+    k_actnorm_partial<<<dim3(C, kStatSplits), dim3(256), 0, cf_s(stream)>>>(x, (double*)ws, B, C, HW, x_bstride);
+    k_actnorm_reduce<<<dim3(C), dim3(64), 0, cf_s(stream)>>>((const double*)ws, sums, C);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_actnorm_from_sums(const double* sums, const double* count_dev, double count, float* t, float* logs, int C,
+                         cf_stream_t stream) {
+    CF_REQUIRE(sums && t && logs && C > 0 && (count_dev || count > 1.0));
+    k_actnorm_from_sums<<<dim3((C + 255) / 256), dim3(256), 0, cf_s(stream)>>>(sums, count_dev, count, t, logs, C);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
 
 int cf_actnorm_stats(const float* x, float* t, float* logs, void* ws, int B, int C, int HW, int64_t x_bstride,
                      cf_stream_t stream) {
     CF_REQUIRE(x && t && logs && ws && B > 0 && C > 0 && HW > 0 && (int64_t)B * HW > 1);
-    k_actnorm_partial<<<dim3(C, kStatSplits), dim3(256), 0, cf_s(stream)>>>(x, (double*)ws, B, C, HW, x_bstride);
-    k_actnorm_final<<<dim3(C), dim3(64), 0, cf_s(stream)>>>((const double*)ws, t, logs, C, (double)B * HW);
-    CF_LAUNCH_CHECK();
-    return 0;
+    double* sums = (double*)ws + (int64_t)C * kStatSplits * 2;
+    int rc = cf_actnorm_sums(x, sums, ws, B, C, HW, x_bstride, stream);
+    if (rc) return rc;
+    return cf_actnorm_from_sums(sums, nullptr, (double)B * HW, t, logs, C, stream);
 }
 
 int cf_actnorm(const float* x, const float* t, const float* logs, float* z, float* ldj_scalar, int B, int C, int HW,

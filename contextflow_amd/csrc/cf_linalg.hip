@@ -281,12 +281,8 @@ int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z,
     const int Cp = (C + 7) / 8 * 8;
     const size_t lds = (size_t)C * Cp * sizeof(float);
     if (lds > 64 * 1024) {                      // 128 < C <= 192: the FC layers of the ATM context-encoder flows
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_conv1x1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_conv1x1_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_conv1x1, 160 * 1024, raised, __func__)) return rc_;
     }
     k_conv1x1<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), lds, cf_s(stream)>>>(x, Wm, bias, z, C, Cp, HW, npix,
                                                                                       x_bstride, z_bstride);
@@ -302,12 +298,8 @@ int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_
         if (inv != nullptr || C > 128) {
             const size_t lds = (size_t)C * (C + 1) * sizeof(float);
             if (lds > 64 * 1024) {
-                static bool raised = false;
-                if (!raised) {
-                    hipError_t e = hipFuncSetAttribute((const void*)k_inverse_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + ~2 KiB static
-                    if (e != hipSuccess) { cf_set_error("cf_slogdet_inverse: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-                    raised = true;
-                }
+                static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_inverse_lds, 152 * 1024, raised, __func__)) return rc_;
             }
             k_inverse_lds<<<dim3(1), dim3(256), lds, cf_s(stream)>>>(Wm, C, inv, C > 128 ? logabsdet : nullptr);
         }

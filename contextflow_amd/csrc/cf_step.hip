@@ -249,13 +249,8 @@ int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, in
                 hipStream_t s, const float* sb = nullptr, StepTape tp = StepTape{nullptr, nullptr, nullptr}) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step<G, SQ, CTX, DUMP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_flow_step_fwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_flow_step<G, SQ, CTX, DUMP>, 160 * 1024, raised, __func__)) return rc_;
     }
     const int grid = (B + G::SPW - 1) / G::SPW;
     k_flow_step<G, SQ, CTX, DUMP><<<dim3(grid), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags, sb, tp);
@@ -372,12 +367,8 @@ template <class G>
 int launch_step_inv(const float* z, float* x, const float* ws, const float* wsi, int B, int64_t zbs, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step_inv<G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_flow_step_inv: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_flow_step_inv<G>, 160 * 1024, raised, __func__)) return rc_;
     }
     k_flow_step_inv<G><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(z, x, ws, wsi, B, zbs);
     return 0;

@@ -491,12 +491,8 @@ int launch_step_bwd(const float* x, const float* gz, const float* gld, const flo
                     int64_t xbs, hipStream_t s, const float* sb = nullptr) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_flow_step_bwd<G, SQ, CTX, TAPED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_flow_step_bwd: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_flow_step_bwd<G, SQ, CTX, TAPED>, 160 * 1024, raised, __func__)) return rc_;
     }
     k_flow_step_bwd<G, SQ, CTX, TAPED><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(
         x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs, sb);

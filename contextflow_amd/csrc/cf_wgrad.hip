@@ -352,12 +352,8 @@ int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float
     constexpr size_t lds_comb = KW > 1 ? (size_t)(NT * TAPS * 1024 + NT * 64) * 4 : 0;
     constexpr size_t lds = lds_main > lds_comb ? lds_main : lds_comb;
     if (lds > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_wgrad<H, W, TAPS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) { cf_set_error("cf_wgrad: cannot raise dynamic LDS: %s", hipGetErrorString(e)); return (int)e; }
-            raised = true;
-        }
+        static std::atomic<uint64_t> raised{0};
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_wgrad<H, W, TAPS, NT>, 160 * 1024, raised, __func__)) return rc_;
     }
     const int mtiles = (MR + 31) / 32;
     const int splits = wgrad_splits(B, MR, HW);

@@ -23,7 +23,6 @@ def init_process_group(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -55,15 +54,53 @@ def mean_bits_per_dim(reduced, dims):
 
 
 def broadcast_parameters(module, src=0):
-    """Replicate parameters and buffers from `src` (after rank `src` ran the ActNorm data-dependent init)."""
+    """Replicate parameters and buffers from `src` (after rank `src` ran the ActNorm data-dependent init): ONE flat
+    message per dtype (the cifar10 flow: 6 MB of fp32 + 12 int64 flags) instead of one tiny broadcast per tensor, written
+    back with `copy_` so that every tensor's version counter moves (parameter-derived caches key on it)."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return
+    tensors = list(module.parameters()) + list(module.buffers())
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src)
+        for dtype in sorted({t.dtype for t in tensors}, key=str):
+            group = [t for t in tensors if t.dtype == dtype and t.numel() > 0]
+            flat = torch.cat([t.detach().reshape(-1) for t in group])
+            dist.broadcast(flat, src=src)
+            o = 0
+            for t in group:
+                n = t.numel()
+                t.copy_(flat[o:o + n].view_as(t))
+                o += n
     for m in module.modules():
         if hasattr(m, "_init_done") and hasattr(m, "initialized"):
             m._init_done = bool(int(m.initialized.item()))
+        if hasattr(m, "invalidate_caches"):
+            m.invalidate_caches()
+
+
+def allreduce_actnorm_sums(sums):
+    """ActNorm's data-dependent init over a SHARDED batch (actnorm.py:28-35): `sums` = fp64
+    [sum x (C) | sum x^2 (C) | elements per channel (1)] of this rank's shard, summed in place over the ranks - one
+    (2C+1)-double message per ActNorm layer, after which every rank derives the same t / logs as a single process would
+    from the whole batch (cf_actnorm_from_sums).  No-op for world size 1."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums
+
+
+class sharded_actnorm_init:
+    """Context manager for the first (initialising) forward of a data-parallel run: every rank passes ITS shard of the
+    init batch through the model and all ranks end up with the global-batch ActNorm statistics - instead of rank 0
+    initialising alone and broadcasting (`broadcast_parameters`)."""
+
+    def __enter__(self):
+        from .layers.actnorm import ActNorm
+        self._prev, ActNorm.sharded_init = ActNorm.sharded_init, True
+        return self
+
+    def __exit__(self, *exc):
+        from .layers.actnorm import ActNorm
+        ActNorm.sharded_init = self._prev
+        return False
 
 
 def allreduce_gradients(module, bucket_bytes=32 << 20):

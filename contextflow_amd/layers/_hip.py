@@ -33,6 +33,8 @@ SIGNATURES = {
     "cf_slogdet_inverse": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p]),
     "cf_actnorm_stats_ws_bytes": (_c_i64, [_c_int]),
     "cf_actnorm_stats": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_p]),
+    "cf_actnorm_sums": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_p]),
+    "cf_actnorm_from_sums": (_c_int, [_c_p, _c_p, ctypes.c_double, _c_p, _c_p, _c_int, _c_p]),
     "cf_actnorm": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "cf_conv2d_reflect": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_i64, _c_p]),
     "cf_coupling_apply": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
@@ -134,19 +136,69 @@ def check(rc, what=""):
         raise RuntimeError("libcontextflow_hip %s failed (code %d): %s" % (what, rc, msg))
 
 
+class _Stream(ctypes.c_void_p):
+    """hipStream_t argument produced by `stream()`: `call` re-derives it from the device of the tensor arguments."""
+
+
+def stream(device=None):
+    """torch's current stream on `device` (default: the current device).  Passed to `call`, it is only a placeholder:
+    `call` substitutes the current stream of the device the tensor arguments live on."""
+    return _Stream(torch.cuda.current_stream(device).cuda_stream)
+
+
+def device_of(args):
+    """The one device every tensor argument (wrapped by `p`) lives on; None for host-only entry points.  Tensors on two
+    different devices in one call are a caller bug and raise."""
+    dev = None
+    for a in args:
+        t = getattr(a, "_keep", None)
+        if t is None:
+            continue
+        d = t.device
+        if dev is None:
+            dev = d
+        elif d != dev:
+            raise RuntimeError("contextflow_amd: tensors of one call live on different devices (%s and %s)" % (dev, d))
+    return dev
+
+
+# indirection for the host-side test of the device selection (tests/test_host.py)
+_current_device = torch.cuda.current_device
+_device_ctx = torch.cuda.device
+_current_stream = torch.cuda.current_stream
+
+
 def call(name, *args):
-    check(getattr(lib(), name)(*args), name)
-
-
-def stream():
-    return _c_p(torch.cuda.current_stream().cuda_stream)
+    """Enqueue one entry point.  The kernels are launched on the device that OWNS the tensors, on torch's current stream
+    of that device - not on whatever device happens to be current (the reference selects `cuda:N` without
+    torch.cuda.set_device, model.py:170)."""
+    fn = getattr(lib(), name)
+    dev = device_of(args)
+    if dev is None or dev.index is None or dev.index == _current_device():
+        return check(fn(*args), name)
+    with _device_ctx(dev):
+        st = None
+        args = list(args)
+        for i, a in enumerate(args):
+            if isinstance(a, _Stream):
+                if st is None:
+                    st = _Stream(_current_stream(dev).cuda_stream)
+                args[i] = st
+        return check(fn(*args), name)
 
 
 def require_device(*tensors):
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 "contextflow_amd layers run on a ROCm device only (got a %s tensor); there is no CPU path" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("contextflow_amd: tensors on different devices (%s and %s)" % (dev, t.device))
 
 
 def f32(t):

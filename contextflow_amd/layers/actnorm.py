@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .flowlayer import FlowLayer
+from .flowlayer import FlowLayer, encoder_noise
 
 
 class ActNorm(FlowLayer):
@@ -36,6 +36,10 @@ class ActNorm(FlowLayer):
     def is_initialized(self):
         return self._init_done
 
+    # data-parallel first call: True = every rank contributes its shard's per-channel sums and all ranks initialise from
+    # the GLOBAL batch statistics (contextflow_amd.dist.sharded_actnorm_init); False = each process uses what it sees
+    sharded_init = False
+
     def initialize(self, x):
         """actnorm.py:28-35 on the device: two-stage fp64 reduction of sum x and sum x^2 per channel."""
         x, xbs = _hip.bview(x)
@@ -44,10 +48,19 @@ class ActNorm(FlowLayer):
         ws = torch.empty(_hip.lib().cf_actnorm_stats_ws_bytes(C), device=x.device, dtype=torch.uint8)
         t = torch.empty(C, device=x.device, dtype=torch.float32)
         logs = torch.empty(C, device=x.device, dtype=torch.float32)
-        _hip.call("cf_actnorm_stats", _hip.p(x), _hip.p(t), _hip.p(logs), _hip.p(ws), B, C, HW, xbs, _hip.stream())
+        if ActNorm.sharded_init:
+            from ..dist import allreduce_actnorm_sums
+            sums = torch.zeros(2 * C + 1, device=x.device, dtype=torch.float64)     # [sum x | sum x^2 | elements per channel]
+            if B > 0:
+                _hip.call("cf_actnorm_sums", _hip.p(x), _hip.p(sums), _hip.p(ws), B, C, HW, xbs, _hip.stream())
+                sums[2 * C] = float(B * HW)
+            allreduce_actnorm_sums(sums)
+            _hip.call("cf_actnorm_from_sums", _hip.p(sums), _hip.p(sums[2 * C:]), 0.0, _hip.p(t), _hip.p(logs), C, _hip.stream())
+        else:
+            _hip.call("cf_actnorm_stats", _hip.p(x), _hip.p(t), _hip.p(logs), _hip.p(ws), B, C, HW, xbs, _hip.stream())
         with torch.no_grad():
-            self.NN_t.data.copy_(t)
-            self.NN_logs.data.copy_(logs)
+            self.NN_t.copy_(t)
+            self.NN_logs.copy_(logs)
             self.initialized.fill_(1)
         self._init_done = True
 
@@ -79,7 +92,7 @@ class ActNorm(FlowLayer):
         _hip.call("cf_actnorm_ctx", _hip.p(x), _hip.p(m), _hip.p(t), _hip.p(logs), _hip.p(z), _hip.p(ldj), B, C, H * W, xbs,
                   _hip.stream())
         if tape is not None:
-            tape.append(dict(x=x, c=_hip.f32(c), m=m))
+            tape.append(dict(x=x, c=_hip.f32(c), m=m, eps=encoder_noise(self.context_net)))
         return z, ldj + logp_c * float(H * W)
 
     def forward(self, x, context=None):

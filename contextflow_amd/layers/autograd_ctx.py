@@ -44,7 +44,7 @@ def _check_encoder(enc):
         raise NotImplementedError("specialist training with a %s context encoder" % type(enc[1]).__name__)
 
 
-def _encoder_backward(enc, context, gc, grads, glq=None):
+def _encoder_backward(enc, context, gc, grads, glq=None, eps=None):
     """d/d of the encoder's outputs: gc = d/dc (B, width), glq = d/d logp_c (B).  uniform / eyesample encoders have no
     parameters of their own (only the embedding lookup in front has); vardeq / argmax / probsample draw their noise from a
     small conditional flow whose parameters train (model.py:52-79)."""
@@ -52,7 +52,7 @@ def _encoder_backward(enc, context, gc, grads, glq=None):
         if isinstance(enc[0], CatEmbeddings):
             _embedding_grads(enc[0], context, gc, grads)
         return
-    _flow_encoder_backward(enc[1], context, gc, glq, grads)
+    _flow_encoder_backward(enc[1], context, gc, glq, grads, eps)
 
 
 def _dense_bwd(x_in, W2d, gy, need_gx=True):
@@ -106,7 +106,7 @@ def _couplingfc_backward(m, x_in, gz, gld, grads):
     return gx
 
 
-def _flow_encoder_backward(encoder, context, gc, glq, grads):
+def _flow_encoder_backward(encoder, context, gc, glq, grads, eps):
     """Backward of VariationalCatDequantization / ArgmaxCatDequantization / ProbSampling (dequantize.py:104-118, 236-262,
     152-161) and of the FlowInvSequential they sample from (flowsequential.py:58-68: Gaussian draw, then the layers'
     forward, log q = log N - sum ldj).  The draw is replayed from the kept noise; the (B, n) intermediates are recomputed."""
@@ -122,7 +122,9 @@ def _flow_encoder_backward(encoder, context, gc, glq, grads):
     glq = _hip.f32(glq).contiguous()
     # ---- replay: Gaussian draw, layers (inputs kept), sigmoid
     cemb = _hip.f32(dist.context_net(ctx)[0]).contiguous()   # (B, 2n) = [mean | log_scale]
-    eps = _hip.f32(dist.last_eps).contiguous()
+    if eps is None:
+        raise RuntimeError("encoder backward without the taped noise of its forward")
+    eps = _hip.f32(eps).contiguous()
     u = _new(B, n, like=gc)
     lq0 = _new(B, like=gc)
     _hip.call("cf_cond_gauss_sample", _hip.p(cemb), _hip.p(eps), _hip.p(u), _hip.p(lq0), B, n, st)
@@ -198,7 +200,7 @@ def conv1x1_ctx_backward(m, rec, context, gz, gld, grads):
     _hip.call("cf_conv1x1_ctx_bwd", _hip.p(x), _hip.p(rec["m"]), _hip.p(Wm), _hip.p(gzv), _hip.p(gld), _hip.p(gx), _hip.p(gm),
               B, C, H * W, xbs, gzbs, _hip.stream())
     gc = _linear_bwd(rec["c"], m.CN, gm, grads)
-    _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W))      # ldj += H W logp_c
+    _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W), rec.get("eps"))   # ldj += H W logp_c
     return gx
 
 
@@ -213,7 +215,7 @@ def actnorm_ctx_backward(m, rec, context, gz, gld, grads):
     _hip.call("cf_actnorm_ctx_bwd", _hip.p(x), _hip.p(rec["m"]), _hip.p(t), _hip.p(logs), _hip.p(gzv), _hip.p(gld), _hip.p(gx),
               _hip.p(gm), B, C, H * W, xbs, gzbs, _hip.stream())
     gc = _linear_bwd(rec["c"], m.CN, gm, grads)
-    _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W))      # ldj += H W logp_c
+    _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W), rec.get("eps"))   # ldj += H W logp_c
     return gx
 
 
@@ -223,7 +225,7 @@ def _cn_chain_backward(m, rec, context, gcn, grads, glq):
     ga2 = _relu_bwd(rec["a2"], _linear_bwd(rec["a2"], m.CN[4], gcn, grads))
     ga1 = _relu_bwd(rec["a1"], _linear_bwd(rec["a1"], m.CN[2], ga2, grads))
     gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads)
-    _encoder_backward(m.context_net, context, gc, grads, glq)
+    _encoder_backward(m.context_net, context, gc, grads, glq, rec.get("eps"))
 
 
 def coupling_ctx_backward(m, rec, context, gz, gld, grads):

@@ -102,7 +102,7 @@ class ConditionalGaussianDistribution(nn.Module):
         c = _hip.f32(c)
         D = self.D
         eps = self.fixed_noise if self.fixed_noise is not None else torch.randn(n_samples, D, device=c.device)
-        self.last_eps = eps                                  # the training backward replays the draw (autograd_ctx.py)
+        self.last_eps = eps                                  # picked up by the caller's tape record (encoder_noise)
         x = torch.empty(n_samples, D, device=c.device, dtype=torch.float32)
         logp = torch.empty(n_samples, device=c.device, dtype=torch.float32)
         _hip.call("cf_cond_gauss_sample", _hip.p(c), _hip.p(_hip.f32(eps)), _hip.p(x), _hip.p(logp), n_samples, D,

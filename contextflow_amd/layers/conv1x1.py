@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .flowlayer import FlowLayer
+from .flowlayer import FlowLayer, encoder_noise
 
 
 def slogdet_inverse(W, want_inverse):
@@ -58,7 +58,7 @@ class Conv1x1(FlowLayer):
             lad, _ = slogdet_inverse(Wm, False)
             ldj = ldj + lad * float(H * W)
         if tape is not None:
-            tape.append(dict(x=x, c=_hip.f32(c), m=m))
+            tape.append(dict(x=x, c=_hip.f32(c), m=m, eps=encoder_noise(self.context_net)))
         return z, ldj + logp_c * float(H * W)
 
     def forward(self, x, context=None):

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _hip
-from .flowlayer import FlowLayer
+from .flowlayer import FlowLayer, encoder_noise
 from .simple_vit import SimpleViT
 
 
@@ -147,7 +147,7 @@ class Coupling(_AffineCoupling):
         else:
             _hip.call("cf_flow_step_fwd_ctx", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), mode, B, C, H, W, xbs, st)
         if tape is not None:
-            tape.append(dict(x=x, c=c, a1=a1, a2=a2, cn=cn, ws=ws, mode=mode, planes=planes))
+            tape.append(dict(x=x, c=c, a1=a1, a2=a2, cn=cn, ws=ws, mode=mode, planes=planes, eps=encoder_noise(self.context_net)))
         return z, ldj + logp_c * float(H * W)
 
     def _fused_ctx_ok(self, x):
@@ -223,7 +223,7 @@ class TransCoupling(_AffineCoupling):
         a2 = _linear(a1, self.CN[2], act=2)
         cn = _linear(a2, self.CN[4])                                                              # (B, O)
         if tape is not None:                  # training (contextflow): what the CN-net backward needs
-            tape.append(dict(c=c, a1=a1, a2=a2, cn=cn))
+            tape.append(dict(c=c, a1=a1, a2=a2, cn=cn, eps=encoder_noise(self.context_net)))
         B, _, H, W = x0.shape
         if self.contextflow:
             h = self.NN[0](x0)

@@ -158,7 +158,9 @@ class GaussianMixtureDistribution(nn.Module):
         if Us * half * H * W * 4 > (256 << 20) or Um * half * 4 > (256 << 20):
             return None
         dev = self.sG.device
-        ver = (need_dsig, self.sG._version, str(dev)) + tuple(e.weight._version for e in embs)
+        # (storage, version) of every tensor the tables are built from; writes through `.data` bump no version counter:
+        # callers that do that (none in this package) must drop `_tab_cache` themselves (FlowSequential.invalidate_caches)
+        ver = (need_dsig, self.sG._version, self.sG.data_ptr(), str(dev)) + tuple((e.weight._version, e.weight.data_ptr()) for e in embs)
         cache = getattr(self, "_tab_cache", None)
         if cache is None or cache[0] != ver:
             def rows(U, rel, strides):
@@ -179,8 +181,8 @@ class GaussianMixtureDistribution(nn.Module):
 
         def key_of(rel, strides):
             key = torch.zeros(ctx.shape[0], dtype=torch.long, device=dev)
-            for i in rel:
-                key += ctx[:, i] * strides[i]
+            for i in rel:        # clamped: an out-of-range code must not index past the tables (the lookup would raise)
+                key += ctx[:, i].clamp(0, embs[i].num_embeddings - 1) * strides[i]
             return key.to(torch.int32)
         return (key_of(rel_s, st_s),) + cache[1:4] + (key_of(rel_m, st_m), cache[4])
 

@@ -34,3 +34,11 @@ def no_context(module_name, context_net):
     if context_net:
         raise NotImplementedError(
             "%s: context-conditioned (specialist) variant is not implemented in contextflow_amd yet" % module_name)
+
+
+def encoder_noise(context_net):
+    """The Gaussian draw a flow-type encoder (vardeq / argmax / probsample) made in the call that just returned, None
+    for the parameter-free encoders.  The training forward stores it in ITS tape record, so that a second forward before
+    the backward (summed micro-batches, an evaluation pass in between) cannot change the noise the backward replays."""
+    flow = getattr(context_net[1], "encoder", None)
+    return getattr(getattr(flow, "dist", None), "last_eps", None)

@@ -49,14 +49,14 @@ class FlowSequential(nn.Module):
         self.step_events = None      # bench.py: list collecting (start, end, batch, C) HIP events per step-kernel launch
         self._plans = {}             # input (C,H,W) -> op list
         self._side = {}              # device index -> side stream for the parameter transforms
-        self._rng, self._rng_seed = {}, 0   # device index -> position of the in-kernel noise stream
+        self._rng, self._rng_seed, self._rng_latched = {}, 0, {}   # device index -> position of the in-kernel noise stream / seed it was started under
 
     def __iter__(self):
         yield from self.sequence_modules
 
     def __getstate__(self):              # streams / cached plans are per-process runtime state
         d = self.__dict__.copy()
-        d["_plans"], d["_side"], d["step_events"], d["_rng"] = {}, {}, None, {}
+        d["_plans"], d["_side"], d["step_events"], d["_rng"], d["_rng_latched"] = {}, {}, None, {}, {}
         return d
 
     # ------------------------------------------------------------------ layer-by-layer mode
@@ -153,11 +153,22 @@ class FlowSequential(nn.Module):
         return ops
 
     def _rng_state(self, dev):
-        """Device-resident position of the in-kernel noise stream (one uint64 per device), seeded from torch's seed."""
+        """Device-resident position of the in-kernel noise stream (one uint64 per device).  The Philox key follows
+        torch's seed: after `torch.manual_seed(s)` the stream restarts from position 0 under the new key, so reseeding
+        reproduces the noise as it does in the reference (uniform.py:32, gaussian.py:69).  Data-parallel ranks fold their
+        rank into the key: equal seeds on every rank still give every rank its own dequantisation / Augment noise."""
+        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         st = self._rng.get(dev.index)
         if st is None:
-            self._rng_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
             st = self._rng[dev.index] = torch.zeros(1, device=dev, dtype=torch.int64)
+            self._rng_latched[dev.index] = seed
+        elif self._rng_latched.get(dev.index) != seed:
+            st.zero_()
+            self._rng_latched[dev.index] = seed
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        self._rng_seed = (seed ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
         return st
 
     def _side_stream(self, dev):
@@ -269,10 +280,10 @@ class FlowSequential(nn.Module):
                 events = self.step_events
                 if events is not None:       # HIP events on the launch stream, bracketing exactly this kernel
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
+                    e0.record(main)
                 _hip.call("cf_flow_step_fwd", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), B, C, H, W, xbs, int(sq), st)
                 if events is not None:
-                    e1.record()
+                    e1.record(main)
                     events.append((e0, e1, B, C))
                 x = z
             elif kind == "squeeze":

@@ -81,6 +81,13 @@ int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_
 int64_t cf_actnorm_stats_ws_bytes(int C);
 int cf_actnorm_stats(const float* x, float* t, float* logs, void* ws, int B, int C, int HW, int64_t x_bstride,
                      cf_stream_t stream);
+/* The two halves of cf_actnorm_stats, for a batch sharded over data-parallel ranks: every rank computes
+ * sums[0:C] = sum x, sums[C:2C] = sum x^2 (fp64) of ITS shard, the ranks all-reduce the 2C doubles and their element
+ * counts, and cf_actnorm_from_sums turns the global sums into t / logs - the statistics actnorm.py:28-35 takes from the
+ * whole batch.  count = elements per channel behind the sums; count_dev (device, may be NULL) overrides it.          */
+int cf_actnorm_sums(const float* x, double* sums, void* ws, int B, int C, int HW, int64_t x_bstride, cf_stream_t stream);
+int cf_actnorm_from_sums(const double* sums, const double* count_dev, double count, float* t, float* logs, int C,
+                         cf_stream_t stream);
 /* inverse=0: z = (x - t)*exp(-logs), ldj_scalar[0] = sum_c logs (reference quirk: no H*W factor);
  * inverse=1: z = x*exp(logs) + t (ldj_scalar may be NULL).                                          */
 int cf_actnorm(const float* x, const float* t, const float* logs, float* z, float* ldj_scalar,

@@ -192,6 +192,48 @@ def gen_params(spec, seed=0, dtype=torch.float32):
     return out
 
 
+def stress_params(params, spec, seed, raw_gain, sg_lo=-4.0, sg_hi=6.0):
+    """Trained-like parameter regime for the stress fixtures (tests/golden/e2e_*_stress.npz), applied to `gen_params`
+    output BEFORE the first (ActNorm-initialising) call:
+      * Conv1x1 weights W = diag(d) Q, d log-spaced over three decades in shuffled order (condition number 1e3): output
+        channel c has scale d_c, so the data-dependent ActNorm init that follows lands on log-scales of both signs
+        spread over +-3.45, as after training;
+      * the conditioner's output layer scaled by `raw_gain` on the rows that produce the raw log-scale (conv couplings:
+        second half of NN.4; transformer couplings: the final LayerNorm's affine), so that raw / 2 drives tanh deep into
+        saturation on part of the elements (coupling.py:52-57);
+      * mixture scales sG uniform in [sg_lo, sg_hi] (default softplus: 0.018 ... 6) instead of ~1 (gaussian.py:142-161);
+        the fixture generator then moves the component means onto latent samples (stored in the fixture), as a fitted
+        mixture has them.
+    Deterministic given (params, seed) except the LAPACK-dependent Conv1x1 factors, which the fixtures store."""
+    out = OrderedDict((k, v.clone()) for k, v in params.items())
+    for name, (shape, kind) in spec.items():
+        rs = np.random.RandomState((seed * 1000003 + zlib.crc32(("stress:" + name).encode())) % (2 ** 32))
+        if kind == "orthogonal" and name.endswith(".NN") and len(shape) == 2:
+            C = shape[0]
+            q, r = np.linalg.qr(rs.standard_normal(shape))
+            d = rs.permutation(np.logspace(-1.5, 1.5, C)) if C > 1 else np.ones(1)
+            out[name] = torch.from_numpy(d[:, None] * (q * np.sign(np.diag(r))[None, :])).to(params[name].dtype)
+        elif kind == "scale":
+            out[name] = torch.from_numpy(rs.uniform(sg_lo, sg_hi, size=shape)).to(params[name].dtype)
+        elif name.endswith(("NN.4.weight", "NN.4.bias")) and ".CN." not in name:
+            half = shape[0] // 2
+            out[name][half:] *= raw_gain
+        elif name.endswith(("transformer.norm.weight", "transformer.norm.bias")):
+            out[name] *= raw_gain
+    return out
+
+
+def stress_means(zin, sG, seed, name):
+    """Component means of a fitted mixture for the stress fixtures: slot j = (m, k) sits on latent sample j mod B,
+    offset by half a standard deviation of its own (softplus(sG)) per element."""
+    MK = sG.shape[0] * sG.shape[1]
+    rs = np.random.RandomState((seed * 1000003 + zlib.crc32(("stress-mean:" + name).encode())) % (2 ** 32))
+    delta = torch.from_numpy(0.5 * rs.standard_normal((MK,) + tuple(sG.shape[2:]))).to(sG.dtype)
+    idx = torch.arange(MK) % zin.shape[0]
+    sig = torch.nn.functional.softplus(sG.reshape((MK,) + tuple(sG.shape[2:])))
+    return (zin[idx].to(sG.dtype) + sig * delta).reshape(sG.shape)
+
+
 LAPACK_DEPENDENT = ("orthogonal",)
 
 

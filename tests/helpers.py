@@ -11,12 +11,15 @@ from oracle import params as op
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def load_e2e(name):
-    """Returns (ops, prior_size, M, params(post ActNorm init), fixture dict)."""
-    fx = dict(np.load(os.path.join(GOLDEN, "e2e_%s.npz" % name)))
+def load_e2e(name, tag=None):
+    """Returns (ops, prior_size, M, params(post ActNorm init), fixture dict).  tag = "stress" | "extreme": the
+    trained-like parameter regimes of make_golden.end_to_end_stress (oracle.params.stress_params)."""
+    fx = dict(np.load(os.path.join(GOLDEN, "e2e_%s%s.npz" % (name, "_" + tag if tag else ""))))
     ops, prior_size, M = fo.program(name)
     spec = op.param_spec(ops, prior_size, M)
     params = op.gen_params(spec, int(fx["seed"]))
+    if tag:
+        params = op.stress_params(params, spec, int(fx["seed"]), float(fx["raw_gain"]), float(fx["sg_lo"]))
     for k, v in fx.items():
         if k.startswith("param:"):
             params[k[6:]] = torch.from_numpy(v)
@@ -28,10 +31,23 @@ def pre_init_params(name, fx):
     ops, prior_size, M = fo.program(name)
     spec = op.param_spec(ops, prior_size, M)
     params = op.gen_params(spec, int(fx["seed"]))
+    if "raw_gain" in fx:
+        params = op.stress_params(params, spec, int(fx["seed"]), float(fx["raw_gain"]), float(fx["sg_lo"]))
     for k, v in fx.items():
-        if k.startswith("param:") and spec[k[6:]][1] == "orthogonal":
+        if k.startswith("param:") and (spec[k[6:]][1] == "orthogonal" or k.endswith("mG")):
             params[k[6:]] = torch.from_numpy(v)
     return params
+
+
+def stress_tolerance(fx, tag):
+    """bits/dim bar of a stress fixture: 1e-5 (BASELINE.json) where the reference's own fp32 answer sits well inside it
+    ("stress": measured 2.6e-6 .. 3.0e-6 from its fp64 run); for "extreme" the reference's fp32 result is itself up to
+    7.5e-6 from its fp64 run, so no fp32 implementation can be held to 1e-5 of it: the bar is max(1e-5, 3 x that floor)."""
+    floor = float(fx["floor_bpd"])
+    if tag == "stress":
+        assert floor < 3.5e-6
+        return 1e-5
+    return max(1e-5, 3.0 * floor)
 
 
 def e2e_inputs(name, fx):

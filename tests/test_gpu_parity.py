@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import flow_oracle as fo                     # noqa: E402
-from tests.helpers import load_e2e, pre_init_params, e2e_inputs, unit, bpd   # noqa: E402
+from tests.helpers import load_e2e, pre_init_params, e2e_inputs, unit, bpd, stress_tolerance   # noqa: E402
 
 BPD_TOL = 1e-5
 DEV = "cuda:0"
@@ -75,6 +75,36 @@ def test_actnorm_init_and_apply(L):
     z2, ldj2 = m(t["x2"].to(DEV))
     close(z2, t["z2"]); close(ldj2, t["ldj2"])
     close(m.reverse(t["z2"].to(DEV)), t["x2rec"])
+
+
+def test_actnorm_sharded_init_equals_whole_batch(L):
+    """cf_actnorm_sums + cf_actnorm_from_sums (the data-parallel init): sums of two ragged shards added
+    together give the parameters of the whole-batch init, and the sharded_init code path of the layer (world size 1)
+    reproduces the reference's post-init parameters."""
+    from contextflow_amd.dist import sharded_actnorm_init
+    from contextflow_amd.layers import _hip
+    t, sd = unit("actnorm")
+    x = t["x"].to(DEV)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.shape[2] * x.shape[3]
+    lib = _hip.lib()
+    tot = torch.zeros(2 * C, device=DEV, dtype=torch.float64)
+    for lo, hi in ((0, 3), (3, B)):
+        xs = x[lo:hi].contiguous()
+        sums = torch.empty(2 * C, device=DEV, dtype=torch.float64)
+        ws = torch.empty(lib.cf_actnorm_stats_ws_bytes(C), device=DEV, dtype=torch.uint8)
+        _hip.call("cf_actnorm_sums", _hip.p(xs), _hip.p(sums), _hip.p(ws), hi - lo, C, HW, C * HW, _hip.stream())
+        tot += sums
+    tt, logs = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    cnt = torch.tensor([float(B * HW)], device=DEV, dtype=torch.float64)
+    _hip.call("cf_actnorm_from_sums", _hip.p(tot), _hip.p(cnt), 0.0, _hip.p(tt), _hip.p(logs), C, _hip.stream())
+    close(tt, sd["NN_t"], 1e-6); close(logs, sd["NN_logs"], 1e-6)
+    m = L.ActNorm((C, x.shape[2], x.shape[3])).to(DEV)
+    with sharded_actnorm_init():
+        z, _ = m(x)
+    assert m.is_initialized()
+    close(m.NN_t, sd["NN_t"], 1e-6); close(m.NN_logs, sd["NN_logs"], 1e-6)
+    close(z, t["z"])
 
 
 def test_squeeze(L):
@@ -204,6 +234,40 @@ def test_e2e_golden(L, name, fused):
     assert (logp.cpu() - ref).abs().max().item() / (D * math.log(2)) < BPD_TOL
     close(z, torch.from_numpy(fx["z"]), tol=2e-5)
     assert (model.log_prob(x.to(DEV)).cpu() - logp.cpu()).abs().max() == 0     # deterministic given the noise
+
+
+@pytest.mark.parametrize("tag", ["stress", "extreme"])
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_e2e_stress_regimes(L, name, fused, tag):
+    """Trained-like parameter regimes (tests/golden/make_golden.py: end_to_end_stress) against the reference's own
+    output: coupling raw log-scales up to +-25 (tanh saturated), ActNorm log-scales of -4.7 .. +5, Conv1x1 of condition
+    number 1e3, mixture sigmas 0.13 .. 6 ("stress", B = 64, bar 1e-5 bits/dim) or 0.018 .. 6 with |raw| up to 27
+    ("extreme": bar = 3x the reference's own fp32-vs-fp64 distance, stored in the fixture)."""
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e(name, tag)
+    x, u, eps = e2e_inputs(name, fx)
+    tol = stress_tolerance(fx, tag)
+    model = build_model(name, params)
+    model.fused = fused
+    set_noise(model, u, eps)
+    z, logp = model(x.to(DEV))
+    ref, ref64 = torch.from_numpy(fx["logp"]), torch.from_numpy(fx["logp_f64"])
+    d32 = (bpd(logp.cpu(), name) - bpd(ref, name)).abs().max().item()
+    d64 = (bpd(logp.cpu(), name) - bpd(ref64, name)).abs().max().item()
+    print("%s %s fused=%s: |d bits/dim| vs reference fp32 %.2e, vs reference fp64 %.2e (reference fp32 vs fp64 %.2e)"
+          % (name, tag, fused, d32, d64, float(fx["floor_bpd"])))
+    assert d32 < tol and d64 < tol, (d32, d64, tol)
+    zr = torch.from_numpy(fx["z"])
+    assert (z.cpu() - zr).abs().max().item() <= 2e-4 * max(1.0, zr.abs().max().item())
+    # first call on un-initialised ActNorms (init on ill-conditioned Conv1x1 outputs), then the fused plan
+    model = build_model(name, pre_init_params(name, fx))
+    model.fused = fused
+    set_noise(model, u, eps)
+    _, logp1 = model(x.to(DEV))
+    assert (bpd(logp1.cpu(), name) - bpd(ref, name)).abs().max().item() < tol
+    _, logp2 = model(x.to(DEV))
+    assert (bpd(logp2.cpu(), name) - bpd(ref, name)).abs().max().item() < tol
 
 
 @pytest.mark.parametrize("name", ["mnist", "cifar10", "smap", "atm"])

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built):
     assert _hip.lib().cf_flow_step_supported(64, 4, 4, 3, 3) == 1
     assert _hip.lib().cf_flow_step_supported(26, 8, 1, 3, 1) == 0
     assert _hip.lib().cf_flow_step_ws_bytes(16, 16, 16) > 4 * 10064
-    assert _hip.lib().cf_actnorm_stats_ws_bytes(16) == 16 * 64 * 2 * 8
+    assert _hip.lib().cf_actnorm_stats_ws_bytes(16) == 16 * 65 * 2 * 8
 
 
 def test_gfx950_code_object(built):
@@ -195,3 +195,111 @@ def test_two_rank_gradient_allreduce_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+INIT_WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from contextflow_amd.dist import init_process_group, shard_bounds, allreduce_actnorm_sums, broadcast_parameters
+rank, _, world = init_process_group("gloo")
+fx = np.load(os.path.join(sys.argv[1], "tests", "golden", "unit_layers.npz"))
+x = torch.from_numpy(fx["actnorm/x"]).double()              # the reference's first (initialising) batch, (5, 7, 3, 4)
+lo, hi = shard_bounds(x.shape[0], rank, world)              # ragged shards: 3 + 2 samples
+xs = x[lo:hi]
+C = x.shape[1]
+# what cf_actnorm_sums leaves on each rank (fp64 per-channel sums of ITS shard), here with torch standing in for the kernel
+sums = torch.cat([xs.sum((0, 2, 3)), (xs * xs).sum((0, 2, 3)), torch.tensor([float(xs.shape[0] * 12)], dtype=torch.float64)])
+allreduce_actnorm_sums(sums)
+n = float(sums[2 * C])
+assert n == 5 * 12
+mean = sums[:C] / n                                           # cf_actnorm_from_sums (actnorm.py:31-33)
+var = ((sums[C:2 * C] - sums[:C] * mean) / (n - 1.0)).clamp_min(0)
+logs = torch.log(var.sqrt() + 1e-8)
+assert torch.allclose(mean.float(), torch.from_numpy(fx["actnorm/sd:NN_t"]), rtol=1e-6, atol=1e-7), rank
+assert torch.allclose(logs.float(), torch.from_numpy(fx["actnorm/sd:NN_logs"]), rtol=1e-6, atol=1e-7), rank
+
+# bucketed parameter broadcast: fp32 parameters + an int64 buffer, rank 1 starts from different values
+torch.manual_seed(rank)
+m = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+m[1].num_batches_tracked.fill_(40 + rank)
+versions = [p._version for p in m.parameters()]
+broadcast_parameters(m, src=0)
+torch.manual_seed(0)
+ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+for a, b in zip(m.parameters(), ref.parameters()):
+    assert torch.equal(a, b), rank
+assert int(m[1].num_batches_tracked) == 40
+assert all(p._version > v for p, v in zip(m.parameters(), versions))     # parameter-derived caches key on the version
+dist.barrier()
+if rank == 0: print("OK")
+'''
+
+
+def test_two_rank_sharded_actnorm_init_and_bucketed_broadcast_gloo(tmp_path):
+    """SURVEY.md 8(e): rank-sharded ActNorm init (all-reduce of per-channel sum x, sum x^2, count) equals the
+    global-batch init of the reference's fixture; parameters travel as one flat message per dtype."""
+    script = tmp_path / "iworker.py"
+    script.write_text(INIT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0]
+
+
+def test_calls_run_on_the_device_that_owns_the_tensors(built, monkeypatch):
+    """`_hip.call` launches on the device the tensor arguments live on, on that device's current stream - the reference
+    picks `cuda:N` without torch.cuda.set_device (model.py:170).  Host-side check of the selection logic with stand-in
+    tensors (a one-GPU box cannot show a second device): a recording entry point replaces the library."""
+    import contextlib
+    import ctypes
+    import types
+    from contextflow_amd.layers import _hip
+
+    def fake(index):
+        t = types.SimpleNamespace(device=torch.device("cuda", index))
+        ptr = _hip._Ptr(0x1000 * (index + 1))
+        ptr._keep = t
+        return ptr
+
+    log = []
+
+    class FakeLib:
+        def cf_probe(self, *args):
+            log.append(("launch", state["current"], [a.value for a in args if isinstance(a, _hip._Stream)]))
+            return 0
+
+    state = {"current": 0}
+
+    @contextlib.contextmanager
+    def device_ctx(dev):
+        prev, state["current"] = state["current"], dev.index
+        log.append(("enter", dev.index))
+        try:
+            yield
+        finally:
+            state["current"] = prev
+            log.append(("exit", dev.index))
+
+    monkeypatch.setattr(_hip, "lib", lambda: FakeLib())
+    monkeypatch.setattr(_hip, "_current_device", lambda: state["current"])
+    monkeypatch.setattr(_hip, "_device_ctx", device_ctx)
+    monkeypatch.setattr(_hip, "_current_stream", lambda dev: types.SimpleNamespace(cuda_stream=0xABC0 + dev.index))
+    st0 = _hip._Stream(0xABC0)                       # what `_hip.stream()` returned under the current device 0
+
+    _hip.call("cf_probe", fake(0), fake(0), 7, st0)  # tensors on the current device: no guard, the stream as passed
+    assert log == [("launch", 0, [0xABC0])]
+    del log[:]
+    _hip.call("cf_probe", fake(3), None, fake(3), st0)   # tensors on cuda:3 while cuda:0 is current
+    assert log == [("enter", 3), ("launch", 3, [0xABC3]), ("exit", 3)], log
+    assert state["current"] == 0
+    with pytest.raises(RuntimeError, match="different devices"):
+        _hip.call("cf_probe", fake(0), fake(1), st0)
+    assert _hip.device_of([3, None, ctypes.c_void_p(5)]) is None      # host-only entry points: nothing to select
+    cpu, cuda = torch.zeros(1), types.SimpleNamespace(is_cuda=True, device=torch.device("cuda", 1))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _hip.require_device(cpu)
+    with pytest.raises(RuntimeError, match="different devices"):
+        _hip.require_device(cuda, types.SimpleNamespace(is_cuda=True, device=torch.device("cuda", 0)))

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import flow_oracle as fo
-from tests.helpers import load_e2e, pre_init_params, e2e_inputs, unit, bpd
+from tests.helpers import load_e2e, pre_init_params, e2e_inputs, unit, bpd, stress_tolerance
 
 BPD_TOL = 1e-5     # BASELINE.json: bits/dim within 1e-5 of the reference
 Z_TOL = 1e-5
@@ -54,6 +54,39 @@ def test_fp64_noise_floor(name):
     _, logp = fo.flow_forward(ops, p64, x.double(), None if u is None else u.double(), [e.double() for e in eps])
     ref = torch.from_numpy(fx["logp_f64"])
     assert (logp - ref).abs().max() < 1e-7 * ref.abs().max()
+
+
+@pytest.mark.parametrize("tag", ["stress", "extreme"])
+@pytest.mark.parametrize("name", ["mnist", "cifar10", "smap"])
+def test_e2e_stress_regimes(name, tag):
+    """Trained-like parameters (saturated coupling log-scales, ActNorm log-scales of +-3..5, Conv1x1 of condition number
+    1e3, mixture scales far from 1): the oracle against the reference's own output, in fp32 within the bits/dim bar and
+    in fp64 to rounding; the fixture really is in the regime it claims."""
+    ops, _, M, params, fx = load_e2e(name, tag)
+    x, u, eps = e2e_inputs(name, fx)
+    tol = stress_tolerance(fx, tag)
+    _, logp = fo.flow_forward(ops, params, x, u, eps)
+    ref, ref64 = torch.from_numpy(fx["logp"]), torch.from_numpy(fx["logp_f64"])
+    assert (bpd(logp, name) - bpd(ref, name)).abs().max() < tol
+    assert (bpd(logp, name) - bpd(ref64, name)).abs().max() < tol
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
+    _, logp64 = fo.flow_forward(ops, p64, x.double(), None if u is None else u.double(), [e.double() for e in eps])
+    assert (bpd(logp64, name) - bpd(ref64, name)).abs().max() < 1e-9
+    # regime checks
+    assert fx["raw_absmax"].max() > 8.0 and np.median(fx["raw_absmax"]) > 7.0
+    logs = torch.cat([v for k, v in params.items() if k.endswith("NN_logs")])
+    assert logs.min() < -3.0 and logs.max() > 3.0
+    conds = [torch.linalg.cond(v.double()).item() for k, v in params.items() if k.endswith(".NN") and v.dim() == 2]
+    assert min(conds) > 900
+    sg = torch.cat([v.flatten() for k, v in params.items() if k.endswith("sG")])
+    assert sg.max() > 5.9 and sg.min() < float(fx["sg_lo"]) + 0.1
+    # ActNorm first call (data-dependent init on the ill-conditioned Conv1x1 outputs)
+    pre = pre_init_params(name, fx)
+    _, logp_first = fo.flow_forward(ops, pre, x, u, eps, init_actnorm=True)
+    for k in params:
+        if k.endswith(("NN_t", "NN_logs")):
+            assert torch.allclose(pre[k], params[k], rtol=1e-4, atol=5e-5), k
+    assert (bpd(logp_first, name) - bpd(ref, name)).abs().max() < tol
 
 
 def test_inverse_mnist():
