@@ -89,11 +89,13 @@ __global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm,
 // CTX: per-sample bias of the specialist coupling (see conditioner_net); sb = (B, C) or (B, 2C) floats.
 // DUMP (training): y0 and the post-ReLU h1 / h2 planes are also written to the tape `tp`; the backward kernel then
 // loads them instead of recomputing phases 1 and 2 (cf_step_bwd.hip, TAPED).
-template <class G, bool SQ, int CTX = 0, bool DUMP = false>
+// DBG: the test-only instantiation that honours `dbg`; the production kernels carry no dump branches at all.
+template <class G, bool SQ, int CTX = 0, bool DUMP = false, bool DBG = false>
 __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restrict__ x, float* __restrict__ z,
                                                    float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                   int64_t xbs, float* __restrict__ dbg, int flags,
+                                                   int64_t xbs, float* __restrict__ dbg_arg, int flags,
                                                    const float* __restrict__ sb, StepTape tp) {
+    float* const dbg = DBG ? dbg_arg : nullptr;
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
     constexpr int WPX = 32 * PTW;                     // pixel columns owned by one wave
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
         for (int rt = 0; rt < RT03; ++rt)
 #pragma unroll
             for (int q = 0; q < PTW; ++q) acc0[rt][q] = bias_tile(wsl + G::OFF_B0 + rt * 32, lk);
-        dense_phase<G, G::KS0, G::NG0, RT03>(acc0, reinterpret_cast<const float4*>(wsl + G::OFF_A0), H1, pix, lane);
+        dense_phase<G, G::KS0, G::NG0, RT03>(acc0, ws_rsrc(wsl, G::WS_FLOATS), G::OFF_A0, H1, pix, lane);
         // first half: conditioner input -> LDS, and it is also the first half of the output (coupling.py:65);
         // second half (x1 after Conv1x1+ActNorm) stays in registers until the epilogue
         float y1[PTW][HALF <= 16 ? 8 : 16];
@@ -176,9 +178,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
                 if (idx < HALF) {
                     const float tt = acc3[0][q][r];
                     const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
-                    // log_s = 2 tanh(raw/2) = 2 - 4/(e^raw + 1)  (coupling.py:55-56) on the hardware exp/rcp path:
-                    // |abs err| ~1e-7 per element, i.e. ~1e-8 bits/dim after the per-sample sum (tolerance 1e-5)
-                    const float ls = 2.0f - __fdividef(4.0f, __expf(raw) + 1.0f);
+                    const float ls = cf_log_scale(raw);
                     Y0[idx * PIX + pix[q]] = fmaf(y1[q][r], __expf(ls), tt);      // coupling.py:63 (z1, staged in LDS)
                     lsum[q] += ls;
                     if (dbg) {
@@ -244,16 +244,16 @@ int launch_prepare(const float* Wm, const float* t, const float* logs, const flo
     return 0;
 }
 
-template <class G, bool SQ, int CTX = 0, bool DUMP = false>
+template <class G, bool SQ, int CTX = 0, bool DUMP = false, bool DBG = false>
 int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, int flags,
                 hipStream_t s, const float* sb = nullptr, StepTape tp = StepTape{nullptr, nullptr, nullptr}) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
         static std::atomic<uint64_t> raised{0};
-        if (int rc_ = cf_raise_dynamic_lds((const void*)k_flow_step<G, SQ, CTX, DUMP>, 160 * 1024, raised, __func__)) return rc_;
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_flow_step<G, SQ, CTX, DUMP, DBG>, 160 * 1024, raised, __func__)) return rc_;
     }
     const int grid = (B + G::SPW - 1) / G::SPW;
-    k_flow_step<G, SQ, CTX, DUMP><<<dim3(grid), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags, sb, tp);
+    k_flow_step<G, SQ, CTX, DUMP, DBG><<<dim3(grid), dim3(256), lds_bytes, s>>>(x, z, ldj, ws, B, xbs, dbg, flags, sb, tp);
     return 0;
 }
 
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__
             if (idx < HALF) {
                 const float tt = acc3[0][q][r];
                 const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
-                const float ls = 2.0f - __fdividef(4.0f, __expf(raw) + 1.0f);
+                const float ls = cf_log_scale(raw);
                 H1[idx * PIX + pix[q]] = z0[q][r];
                 H1[(HALF + idx) * PIX + pix[q]] = (z1[q][r] - tt) * __expf(-ls);
             }
@@ -471,6 +471,22 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
 #define CF_STEP(G) rc = in_squeeze ? launch_step<G, true>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream)) \
                                    : launch_step<G, false>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream))
     const int variant = (flags >> 16) & 15;
+    if (dbg != nullptr) {                  // per-phase dumps (tests): the default geometry of each shape only
+        CF_REQUIRE(variant == 0);
+#define CF_STEPD(G) rc = in_squeeze ? launch_step<G, true, 0, false, true>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream)) \
+                                    : launch_step<G, false, 0, false, true>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream))
+        switch (shape_id(C, H, W)) {
+            case 0: CF_STEPD(G8); break;
+            case 1: CF_STEPD(G16); break;
+            case 2: CF_STEPD(G32); break;
+            case 3: CF_STEPD(G64); break;
+            default: cf_set_error("cf_flow_step_fwd_debug: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+        }
+#undef CF_STEPD
+        if (rc) return rc;
+        CF_LAUNCH_CHECK();
+        return 0;
+    }
     switch (shape_id(C, H, W) * 4 + variant) {
         case 0: CF_STEP(G8); break;
         case 4: CF_STEP(G16); break;

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 unsigned m = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = fmaxf(acc[rt][q][r], 0.f);
+                    const float v = cf_relu(acc[rt][q][r]);
                     m |= (acc[rt][q][r] > 0.f ? 1u : 0u) << r;
                     acc[rt][q][r] = v;
                 }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     m |= (acc[rt][q][r] > 0.f ? 1u : 0u) << r;
-                    acc[rt][q][r] = fmaxf(acc[rt][q][r], 0.f);
+                    acc[rt][q][r] = cf_relu(acc[rt][q][r]);
                 }
                 m2[rt][q] = m;
             }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                     const int idx = tile_row(r, lk);
                     if (idx < HALF) raw += sb[(int64_t)min(b0 + pix[q] / HW, B - 1) * C + HALF + idx];
                 }
-                ls[q][r] = 2.0f - __fdividef(4.0f, __expf(raw) + 1.0f);
+                ls[q][r] = cf_log_scale(raw);
             }
     }
 

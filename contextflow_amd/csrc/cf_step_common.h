@@ -68,6 +68,15 @@ __device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ bias32, in
     return a;
 }
 __device__ __forceinline__ int tile_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+// ReLU as ONE integer max on the bit pattern (negative floats are negative integers; -0 -> +0).  fmaxf(x, 0) costs two
+// VALU instructions here (hipcc quiets a possible sNaN with v_max x,x first), and in the MFMA kernels every VALU
+// instruction is time the matrix pipe of that SIMD stands still.
+__device__ __forceinline__ float cf_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+// log_s = 2 tanh(raw / 2) = 2 - 4 / (e^raw + 1)   (coupling.py:55-56) on the hardware exp / rcp path (v_exp_f32, v_rcp_f32:
+// 1 ulp each): |abs err| <= ~3e-7 per element, i.e. ~1e-8 bits/dim after the per-sample sum (tolerance 1e-5; measured on
+// the stress fixtures with |raw| up to 25: tests/test_gpu_parity.py::test_e2e_stress_regimes).  e^raw = inf gives 2,
+// e^raw = 0 gives -2 exactly.  (`__fdividef` is an IEEE division on this toolchain: ~10 more VALU per element.)
+__device__ __forceinline__ float cf_log_scale(float raw) { return fmaf(-4.0f, __builtin_amdgcn_rcpf(__expf(raw) + 1.0f), 2.0f); }
 __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
 // Operands of one 4-k-step group: RT weight fragments (one 16-byte load each) and 4*PTW activation values.
@@ -91,19 +100,33 @@ __device__ __forceinline__ void group_mma(f32x16 (&acc)[RT][PTW], const GroupOps
     }
 }
 
+// Packed weight fragments are fetched through a buffer resource: `buffer_load_dwordx4 v, v_lane16, s[rsrc], s_off offen`
+// takes the group / row-tile / tap offset as a SCALAR, so no per-load 64-bit vector address arithmetic sits between the
+// MFMAs (the flat form costs v_lshl_add_u64 / v_add_co / v_addc per fragment).
+typedef __amdgpu_buffer_rsrc_t ws_rsrc_t;
+__device__ __forceinline__ ws_rsrc_t ws_rsrc(const float* ws, int floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, floats * 4, 0x00020000);
+}
+// fragment at float offset `foff` (wave-uniform) + this lane's 16 bytes
+__device__ __forceinline__ float4 ws_frag(ws_rsrc_t rs, int lane, int foff) {
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, foff * 4, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+
 // One dense phase whose B operand is an LDS plane [k][PIX]:  acc[rt][q] += A_frag * plane
 //   KS real k-steps, NG groups of 4, RT row tiles, frags = packed A of this phase.
 // Software pipeline: the operands of group g+1 are requested BEFORE the MFMAs of group g are issued
 // (sched_barrier pins the loads there: left alone, hipcc sinks them next to their first use and every
 // group then stalls on an L2 round trip).
-template <class G, int KS, int NG, int RT>
-__device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const float4* __restrict__ frags,
-                                            const float* __restrict__ plane, const int (&pix)[G::PTW], int lane) {
+template <class G, int KS, int NG, int RT, class FRAG>
+__device__ __forceinline__ void dense_phase_impl(f32x16 (&acc)[RT][G::PTW], FRAG frag,
+                                                 const float* __restrict__ plane, const int (&pix)[G::PTW], int lane) {
     const int lk = lane >> 5;
     GroupOps<RT, G::PTW> ops[2];
     auto load = [&](int g, GroupOps<RT, G::PTW>& o) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) o.a[rt] = frags[(g * RT + rt) * 64 + lane];
+        for (int rt = 0; rt < RT; ++rt) o.a[rt] = frag(g * RT + rt);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -117,6 +140,17 @@ __device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const flo
         __builtin_amdgcn_sched_barrier(0);
         group_mma<RT, G::PTW>(acc, ops[g & 1], KS - 4 * g);
     }
+}
+template <class G, int KS, int NG, int RT>
+__device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], const float4* __restrict__ frags,
+                                            const float* __restrict__ plane, const int (&pix)[G::PTW], int lane) {
+    dense_phase_impl<G, KS, NG, RT>(acc, [&](int i) { return frags[i * 64 + lane]; }, plane, pix, lane);
+}
+// same, fragments through a buffer resource at float offset `foff`
+template <class G, int KS, int NG, int RT>
+__device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], ws_rsrc_t rs, int foff,
+                                            const float* __restrict__ plane, const int (&pix)[G::PTW], int lane) {
+    dense_phase_impl<G, KS, NG, RT>(acc, [&](int i) { return ws_frag(rs, lane, foff + i * 256); }, plane, pix, lane);
 }
 
 // ---- wave-local staging of activations with 16-byte global accesses ---------------------------------
@@ -241,6 +275,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
     float* Y0 = lds;
     float* H1 = lds + HALF * PIX;
     const int lk = lane >> 5;
+    const ws_rsrc_t rs = ws_rsrc(wsl, G::WS_FLOATS);
     // ================= phase 1: h1 = relu(NN.0 y0 + b)                      (coupling.py:26)
     {
         f32x16 acc[RT1][PTW];
@@ -259,7 +294,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                         if (row < HID) acc[rt][q][r] += sb[soff[q] + row];
                     }
         }
-        dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(wsl + G::OFF_A1), Y0, pix, lane);
+        dense_phase<G, G::KS1, G::NG1, RT1>(acc, rs, G::OFF_A1, Y0, pix, lane);
 #pragma unroll
         for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
@@ -267,7 +302,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + tile_row(r, lk);
-                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                    if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
                 }
         if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h1, H1, tile * G::SPW, B, tid >> 6, lane);
     }
@@ -284,7 +319,6 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
         for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
             for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(wsl + G::OFF_B2 + rt * 32, lk);
-        const float4* frags = reinterpret_cast<const float4*>(wsl + G::OFF_A2);
         // reflect-padded source pixel of a tap, as an index into lds[] (offsets, not pointers: a pointer array
         // loses the LDS address space and hipcc falls back to flat loads)
         auto tap_src = [&](int tap, int (&src)[PTW]) {
@@ -301,7 +335,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
             // compiler-scheduled form: one tap per loop trip, all NCG groups of the tap unrolled
             float4 a_cur[RT1], a_nxt[RT1];
 #pragma unroll
-            for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = frags[rt * 64 + lane];
+            for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = ws_frag(rs, lane, G::OFF_A2 + rt * 256);
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 int src[PTW];
@@ -312,7 +346,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     const int gn = min(g + 1, G::NG2 - 1);
 #pragma unroll
                     for (int rt = 0; rt < RT1; ++rt)
-                        a_nxt[rt] = G::ABL == 1 ? make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg) : frags[(gn * RT1 + rt) * 64 + lane];
+                        a_nxt[rt] = G::ABL == 1 ? make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg) : ws_frag(rs, lane, G::OFF_A2 + (gn * RT1 + rt) * 256);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -332,7 +366,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
             // g+1 are requested before the MFMAs of group g (two register sets, loads pinned by sched_barrier);
             // the source pixel of a tap is computed once per tap, one tap ahead.
             GroupOps<RT1, PTW> ops[2];
-            auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+            auto load = [&](int fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {   // fr: float offset of the group
                 if constexpr (G::ABL == 1) {                      // timing ablation: operands from registers only
 #pragma unroll
                     for (int rt = 0; rt < RT1; ++rt) o.a[rt] = make_float4(0.5f, 0.25f, -0.5f, 0.125f + cg);
@@ -343,7 +377,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     return;
                 }
 #pragma unroll
-                for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
+                for (int rt = 0; rt < RT1; ++rt) o.a[rt] = ws_frag(rs, lane, fr + rt * 256);
 #pragma unroll
                 for (int q = 0; q < PTW; ++q)
 #pragma unroll
@@ -351,14 +385,14 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
             };
             int src_cur[PTW], src_nxt[PTW];
             tap_src(0, src_cur);
-            load(frags, src_cur, 0, ops[0]);
+            load(G::OFF_A2, src_cur, 0, ops[0]);
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 tap_src(min(tap + 1, 8), src_nxt);
-                const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
+                const int fr = G::OFF_A2 + tap * G::NCG * RT1 * 256;
 #pragma unroll
                 for (int cg = 0; cg < G::NCG; ++cg) {                       // NCG is even: static ping-pong
-                    const float4* fn = fr + (cg + 1) * RT1 * 64;            // fragments of the next group
+                    const int fn = fr + (cg + 1) * RT1 * 256;               // fragments of the next group
                     if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
                     else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);       // first group of the next tap
                     __builtin_amdgcn_sched_barrier(0);
@@ -376,7 +410,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + tile_row(r, lk);
-                    if (row < HID) H1[row * PIX + pix[q]] = fmaxf(acc[rt][q][r], 0.f);
+                    if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
                 }
         if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h2, H1, tile * G::SPW, B, tid >> 6, lane);
     }
@@ -405,7 +439,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     if ((lk ? ch1 : ch) >= 0) acc3[rt][q][r] += sb[soff[q] + c];
                 }
     }
-    dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(wsl + G::OFF_A3), H1, pix, lane);
+    dense_phase<G, G::KS3, G::NG3, RT03>(acc3, rs, G::OFF_A3, H1, pix, lane);
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------
