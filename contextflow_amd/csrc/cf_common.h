@@ -42,6 +42,17 @@ static inline int cf_raise_dynamic_lds(const void* kernel, int bytes, std::atomi
     return 0;
 }
 
+// Hand-off of LDS data between the LANES OF ONE WAVE (a lane reads what another lane of its wave wrote, with no
+// workgroup barrier in between).  The hardware keeps one wave's LDS instructions in order, but the COMPILER reasons per
+// thread: a later ds_read whose address differs from this thread's own earlier ds_write may be hoisted above it (seen:
+// hipcc moved phase-3 operand reads above the h2 plane stores of k_flow_step_small).  A wavefront-scope fence pins
+// the order in the compiler; it emits no instruction of its own.
+__device__ __forceinline__ void cf_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------
 __device__ __forceinline__ float cf_wave_sum(float v) {
 #pragma unroll

@@ -72,6 +72,33 @@ __global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm,
         const int ch = chan_of_row<G>(rt * 32 + (lane & 31)), k = 2 * (4 * g + j) + (lane >> 5);
         ws[G::OFF_A3 + e] = (ch >= 0 && k < G::HID) ? w3[ch * G::HID + k] : 0.f;
     }
+    if constexpr (G::SMALL) {
+        // operands of the 16x16x4 phases: A fragment of k-step s, lane l = A[row = l & 15][k = 4 s + (l >> 4)];
+        // element e = (group * 64 + lane) * 4 + j holds k-step 4 group + j
+        for (int p = gtid; p < 16; p += gsz) {
+            const int ch = chan_of_row16<G>(p);
+            ws[G::OFF_SB0 + p] = ch >= 0 ? -t[ch] * expf(-logs[ch]) : 0.f;
+            ws[G::OFF_SB3 + p] = ch >= 0 ? b3[ch] : 0.f;
+        }
+        for (int e = gtid; e < G::SG0 * 256; e += gsz) {
+            const int jj = e & 3, ln = (e >> 2) & 63, gg = e >> 8, ch = chan_of_row16<G>(ln & 15), k = 4 * (4 * gg + jj) + (ln >> 4);
+            ws[G::OFF_SA0 + e] = (ch >= 0 && k < G::C) ? expf(-logs[ch]) * Wm[ch * G::C + k] : 0.f;
+        }
+        for (int e = gtid; e < G::SG3 * 256; e += gsz) {
+            const int jj = e & 3, ln = (e >> 2) & 63, gg = e >> 8, ch = chan_of_row16<G>(ln & 15), k = 4 * (4 * gg + jj) + (ln >> 4);
+            ws[G::OFF_SA3 + e] = (ch >= 0 && k < G::HID) ? w3[ch * G::HID + k] : 0.f;
+        }
+        if constexpr (G::HID16) {
+            for (int e = gtid; e < G::SG1 * 256; e += gsz) {               // NN.0: 16 rows x HALF
+                const int jj = e & 3, ln = (e >> 2) & 63, gg = e >> 8, row = ln & 15, k = 4 * (4 * gg + jj) + (ln >> 4);
+                ws[G::OFF_SA1 + e] = k < G::HALF ? w1[row * G::HALF + k] : 0.f;
+            }
+            for (int e = gtid; e < 9 * 256; e += gsz) {                    // NN.2: group = tap, k = input channel
+                const int jj = e & 3, ln = (e >> 2) & 63, tap = e >> 8, row = ln & 15, ci = 4 * jj + (ln >> 4);
+                ws[G::OFF_SA2 + e] = w2[(row * G::HID + ci) * 9 + tap];
+            }
+        }
+    }
 }
 
 // ---- the step kernel ---------------------------------------------------------------------------------
@@ -131,6 +158,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
         for (int q = 0; q < PTW; ++q) { smp[q] = b0 + pix[q] / HW; live[q] = smp[q] < B; }
 
         x_to_lds<G, SQ>(xr, H1, wave, lane);
+        cf_wave_sync();                 // x plane: written 16 bytes per lane, read as MFMA operands by other lanes
 
         // ================= phase 0: y = (e^{-logs} Wm) x - t e^{-logs}        (conv1x1.py:54 + actnorm.py:59)
         f32x16 acc0[RT03][PTW];
@@ -150,6 +178,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
                 if (idx < HALF) Y0[idx * PIX + pix[q]] = acc0[0][q][r];
                 y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
             }
+        cf_wave_sync();                 // y0 plane complete for this wave's columns
         z_store<G>(z, Y0, b0, 0, B, wave, lane);
         if constexpr (DUMP) rows_store_t<G, HALF, HALF>(tp.y0, Y0, b0, B, wave, lane);
         if (dbg) {
@@ -189,7 +218,9 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
                 }
             }
         }
+        cf_wave_sync();                 // z1 plane complete for this wave's columns
         z_store<G>(z, Y0, b0, HALF, B, wave, lane);
+        cf_wave_sync();                 // ... and read back, before the log-det scratch below reuses those words
 
         // per-sample reduction of log_s: lanes of one sample inside a 32-pixel tile first (shuffles) ...
         constexpr int SEG = HW < 32 ? HW : 32;            // lanes (pixels) of one sample inside a tile
@@ -231,6 +262,190 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
             __syncthreads();
         }
     }
+}
+
+// ---- small-channel forward step (C = 8 / 16 on 16x16 images: first resolution level of mnist / cifar10) ------------
+// Same data flow as k_flow_step, one sample per workgroup, but the phases with <= 16 output rows run on
+// v_mfma_f32_16x16x4_f32 tiles (same flop/cycle as 32x32x2, no padding rows):
+//   phase 0  [y0 | y1] = W'x + b'   16 packed rows (chan_of_row16)                        K = C
+//   phase 1  h1 = relu(NN.0 y0)     C = 16: 32 rows on 32x32x2 (conditioner_net);  C = 8: 16 rows on 16x16x4
+//   phase 2  3x3 reflect conv       C = 16: 32x32x2, taps unrolled;                 C = 8: 16x16x4, a column tile is one
+//                                   image row, so the reflected source row of a tap is a scalar
+//   phase 3  [t | raw] = NN.4 h2    16 packed rows                                        K = 2C
+// Result tile of the 16x16x4 form: column (pixel) = lane & 15, rows 4 (lane >> 4) + r in the 4 registers; the packing
+// puts t, raw and y1 of channels 2g, 2g+1 into lane group g, so the affine epilogue is lane-local again.
+// In the 16-row phases lanes l and l + 16 read the same bank (rows k, k+1 of a [row][256] plane): a 2-way conflict on
+// ~100 ds_read_b32 per wave, i.e. a few hundred LDS cycles against ~22 000 MFMA cycles.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class G, bool SQ, bool DBG = false>
+__global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
+                                                                  float* __restrict__ ldj_acc, const float* __restrict__ ws,
+                                                                  int B, int64_t xbs, float* __restrict__ dbg) {
+    static_assert(G::SMALL, "16x16 images, one sample per workgroup, C <= 16");
+    constexpr int C = G::C, W = 16, H = 16, PIX = 256, HALF = G::HALF, HID = G::HID, PTW = G::PTW;
+    constexpr int XI = C * PTW / 8;
+    extern __shared__ __align__(16) float lds[];
+    float* Y0 = lds;                    // [HALF][PIX]
+    float* H1 = lds + HALF * PIX;       // [HID][PIX]: x plane, then h1, then h2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int tile = blockIdx.x;        // = sample index
+    const int colb = wave * 64 + l15;   // this lane's pixel column in column tile 0 (tile ct: + 16 ct)
+
+    float4 xr[XI];
+    x_load<G, SQ>(xr, x, xbs, tile, B, wave, lane);
+    const ws_rsrc_t rs = ws_rsrc(ws, G::WS_FLOATS);
+    x_to_lds<G, SQ>(xr, H1, wave, lane);
+    cf_wave_sync();
+
+    // ================= phase 0: [y0 | y1] = (e^{-logs} Wm) x - t e^{-logs}   (conv1x1.py:54 + actnorm.py:59)
+    f32x4 acc0[4];
+    {
+        const float4 b = *reinterpret_cast<const float4*>(ws + G::OFF_SB0 + 4 * lg);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { acc0[ct][0] = b.x; acc0[ct][1] = b.y; acc0[ct][2] = b.z; acc0[ct][3] = b.w; }
+#pragma unroll
+        for (int g = 0; g < G::SG0; ++g) {
+            const float4 a = ws_frag(rs, lane, G::OFF_SA0 + g * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * (4 * g + e) < C) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), H1[(4 * (4 * g + e) + lg) * PIX + colb + 16 * ct],
+                                                                        acc0[ct], 0, 0, 0);
+                }
+        }
+    }
+    // first half -> LDS (conditioner input and first half of the output, coupling.py:65); y1 stays in acc0[.][2..3]
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (2 * lg + j < HALF) Y0[(2 * lg + j) * PIX + colb + 16 * ct] = acc0[ct][j];
+    cf_wave_sync();
+    z_store<G>(z, Y0, tile, 0, B, wave, lane);
+    const int64_t dbg_cols = (int64_t)B * PIX;       // test-only dumps (DBG): planes as [rows][B * PIX], see k_flow_step
+    auto dump = [&](const float* plane, int rows, int row0) {
+        __syncthreads();
+        for (int e = tid; e < rows * PIX; e += 256) dbg[(int64_t)(row0 + e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = plane[e];
+        __syncthreads();
+    };
+    if constexpr (DBG) dump(Y0, HALF, 0);
+
+    // ================= phases 1, 2: h2 = relu(NN.2 (*) relu(NN.0 y0 + b) + b)   (coupling.py:26-27)
+    if constexpr (!G::HID16) {
+        const int li = lane & 31;
+        int pix[PTW], pin[PTW];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q]; }
+        f32x16 unused[G::RT03][PTW];
+        conditioner_net<G, 0, false, 2>(unused, lds, ws, pix, pin, lane, tid, DBG ? dbg : nullptr, dbg_cols, tile);
+    } else {
+        f32x4 a1[4];
+        {
+            const float4 b = *reinterpret_cast<const float4*>(ws + G::OFF_B1 + 4 * lg);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { a1[ct][0] = b.x; a1[ct][1] = b.y; a1[ct][2] = b.z; a1[ct][3] = b.w; }
+            const float4 a = ws_frag(rs, lane, G::OFF_SA1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * e < HALF) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        a1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), Y0[(4 * e + lg) * PIX + colb + 16 * ct], a1[ct], 0, 0, 0);
+                }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a1[ct][r]);
+        }
+        __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' image rows
+        if constexpr (DBG) dump(H1, HID, C);
+        f32x4 a2[4];
+        {
+            const float4 b = *reinterpret_cast<const float4*>(ws + G::OFF_B2 + 4 * lg);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { a2[ct][0] = b.x; a2[ct][1] = b.y; a2[ct][2] = b.z; a2[ct][3] = b.w; }
+            int xo[3];                   // reflected source column per dx, plus this lane's k row of the h1 plane
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                int xx = l15 + d - 1;
+                xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+                xo[d] = HALF * PIX + lg * PIX + xx;
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float4 a = ws_frag(rs, lane, G::OFF_SA2 + tap * 256);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    int yy = wave * 4 + ct + tap / 3 - 1;            // wave-uniform: a column tile is one image row
+                    yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+                    const int src = xo[tap % 3] + yy * W;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        a2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), lds[src + 4 * e * PIX], a2[ct], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                 // every wave has finished reading h1
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a2[ct][r]);
+        if constexpr (DBG) dump(H1, HID, C + HID);
+    }
+    cf_wave_sync();                      // h2: every lane's rows in place before other lanes read them as operands
+
+    // ================= phase 3: [t | raw] = NN.4 h2 + b   (coupling.py:28); reads this wave's own columns of h2 only
+    f32x4 acc3[4];
+    {
+        const float4 b = *reinterpret_cast<const float4*>(ws + G::OFF_SB3 + 4 * lg);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { acc3[ct][0] = b.x; acc3[ct][1] = b.y; acc3[ct][2] = b.z; acc3[ct][3] = b.w; }
+#pragma unroll
+        for (int g = 0; g < G::SG3; ++g) {
+            const float4 a = ws_frag(rs, lane, G::OFF_SA3 + g * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * (4 * g + e) < HID) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc3[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), H1[(4 * (4 * g + e) + lg) * PIX + colb + 16 * ct],
+                                                                        acc3[ct], 0, 0, 0);
+                }
+        }
+    }
+    // ================= affine map and log-det   (coupling.py:52-66)
+    float lsum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (2 * lg + j < HALF) {
+                const float ls = cf_log_scale(acc3[ct][j + 2]);
+                Y0[(2 * lg + j) * PIX + colb + 16 * ct] = fmaf(acc0[ct][j + 2], __expf(ls), acc3[ct][j]);     // z1, staged in LDS
+                lsum += ls;
+                if constexpr (DBG) {
+                    float* d = dbg + (int64_t)(C + 2 * HID) * dbg_cols + (int64_t)tile * PIX + colb + 16 * ct;
+                    d[(int64_t)(2 * lg + j) * dbg_cols] = acc3[ct][j];
+                    d[(int64_t)(HALF + 2 * lg + j) * dbg_cols] = acc3[ct][j + 2];
+                }
+            }
+    cf_wave_sync();
+    z_store<G>(z, Y0, tile, HALF, B, wave, lane);
+    cf_wave_sync();
+    lsum = cf_wave_sum(lsum);
+    if (lane == 0) Y0[wave * 64] = lsum;          // own column (its z1 value has been read back by z_store already)
+    __syncthreads();
+    if (tid == 0 && tile < B) ldj_acc[tile] += ws[0] + ((Y0[0] + Y0[64]) + (Y0[128] + Y0[192]));
+}
+
+template <class G, bool SQ, bool DBG = false>
+int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s,
+                      float* dbg = nullptr) {
+    k_flow_step_small<G, SQ, DBG><<<dim3(B), dim3(256), (size_t)G::LDS_FLOATS * sizeof(float), s>>>(x, z, ldj, ws, B, xbs, dbg);
+    return 0;
 }
 
 template <class G>
@@ -307,6 +522,7 @@ __global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__
     float4 zr[XI];
     x_load<G, false>(zr, z, zbs, tile, B, wave, lane);
     x_to_lds<G, false>(zr, H1, wave, lane);                      // z plane: rows [0,HALF) = z0, [HALF,C) = z1
+    cf_wave_sync();
     float z0[PTW][NR], z1[PTW][NR];
 #pragma unroll
     for (int q = 0; q < PTW; ++q)
@@ -318,8 +534,10 @@ __global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__
             z1[q][r] = ok ? H1[(HALF + idx) * PIX + pix[q]] : 0.f;
             if (ok) Y0[idx * PIX + pix[q]] = z0[q][r];           // conditioner input
         }
+    cf_wave_sync();
     f32x16 acc3[RT03][PTW];
     conditioner_net<G>(acc3, lds, ws, pix, pin, lane, tid, nullptr, 0, tile);
+    cf_wave_sync();                      // phase 3 has read h2: its words are reused for the y plane
     // y = [z0 | (z1 - t) e^{-log_s}] as the operand plane of the last phase (this wave's columns of the H region)
 #pragma unroll
     for (int q = 0; q < PTW; ++q)
@@ -334,6 +552,7 @@ __global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__
                 H1[(HALF + idx) * PIX + pix[q]] = (z1[q][r] - tt) * __expf(-ls);
             }
         }
+    cf_wave_sync();
     f32x16 acc[I::RTI][PTW];
 #pragma unroll
     for (int rt = 0; rt < I::RTI; ++rt)
@@ -351,6 +570,7 @@ __global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__
                 const int row = rt * 32 + tile_row(r, lk);
                 if (row < C) Xp[row * PIX + pix[q]] = acc[rt][q][r];
             }
+    cf_wave_sync();
     rows_store<G, C>(x, Xp, b0, 0, B, wave, lane);
 }
 
@@ -471,6 +691,17 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
 #define CF_STEP(G) rc = in_squeeze ? launch_step<G, true>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream)) \
                                    : launch_step<G, false>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream))
     const int variant = (flags >> 16) & 15;
+    if (dbg != nullptr && variant == 3 && shape_id(C, H, W) <= 1 && shape_id(C, H, W) >= 0) {     // dumps of k_flow_step_small
+        if (shape_id(C, H, W) == 0)
+            rc = in_squeeze ? launch_step_small<G8s, true, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), dbg)
+                            : launch_step_small<G8s, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), dbg);
+        else
+            rc = in_squeeze ? launch_step_small<G16s, true, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), dbg)
+                            : launch_step_small<G16s, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), dbg);
+        if (rc) return rc;
+        CF_LAUNCH_CHECK();
+        return 0;
+    }
     if (dbg != nullptr) {                  // per-phase dumps (tests): the default geometry of each shape only
         CF_REQUIRE(variant == 0);
 #define CF_STEPD(G) rc = in_squeeze ? launch_step<G, true, 0, false, true>(x, z, ldj_acc, w, B, x_bstride, dbg, flags, cf_s(stream)) \
@@ -489,10 +720,13 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
     }
     switch (shape_id(C, H, W) * 4 + variant) {
         case 0: CF_STEP(G8); break;
+        case 3: rc = in_squeeze ? launch_step_small<G8s, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))
+                                : launch_step_small<G8s, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
         case 4: CF_STEP(G16); break;
         case 5: CF_STEP(G16v1); break;
         case 6: CF_STEP(G16v2); break;
-        case 7: CF_STEP(G16v3); break;
+        case 7: rc = in_squeeze ? launch_step_small<G16s, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))
+                                : launch_step_small<G16s, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
         case 8: CF_STEP(G32); break;
         case 9: CF_STEP(G32v1); break;
         case 10: CF_STEP(G32v2); break;
@@ -516,6 +750,7 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     int flags = 0;
     const int sid = shape_id(C, H, W);
     if ((sid == 2 && B < 256 * G32::SPW) || (sid == 3 && B < 256 * G64::SPW)) flags = 2 << 16;
+    if (sid == 0 || sid == 1) flags = 3 << 16;      // 16x16 images: k_flow_step_small
     return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, flags, stream);
 }
 

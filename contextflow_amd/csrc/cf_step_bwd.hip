@@ -70,6 +70,7 @@ __device__ __forceinline__ void tiles_to_plane(const f32x16 (&acc)[RT][G::PTW], 
                 const int row = rt * 32 + tile_row(r, lk);
                 if (row < nrows) plane[row * G::PIX + pix[q]] = acc[rt][q][r];
             }
+    cf_wave_sync();                      // other lanes of this wave read these rows next
 }
 
 // ---- adjoint of the reflect-padded 3x3 gather (g_h2 -> g_h1) --------------------------------------------------

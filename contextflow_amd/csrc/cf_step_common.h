@@ -40,7 +40,21 @@ struct Geo {
     static constexpr int OFF_A1 = OFF_A0 + NG0 * RT03 * 256;
     static constexpr int OFF_A2 = OFF_A1 + NG1 * RT1 * 256;
     static constexpr int OFF_A3 = OFF_A2 + NG2 * RT1 * 256;
-    static constexpr int WS_FLOATS = OFF_A3 + NG3 * RT03 * 256;
+    // 16-row phases on v_mfma_f32_16x16x4_f32 (k_flow_step_small: C <= 16 on 16x16 images, one sample per workgroup).
+    // With <= 16 real output rows a 32x32x2 tile spends half (or three quarters) of its cycles on padding rows; the
+    // 16x16x4 form has the same flop/cycle and no padding.  Extra packed operands, 4 k-steps (16 k) per float4 group:
+    //   S0 = e^{-logs} Wm (rows: packed y0 / y1), S3 = NN.4 (rows: packed t / raw); when the hidden planes are one
+    //   16-row tile too (C = 8): S1 = NN.0, S2 = NN.2 (9 taps).  SB0 / SB3: the 16 packed-row biases.
+    static constexpr bool SMALL = (H == 16 && W == 16 && SPW == 1 && C <= 16);
+    static constexpr bool HID16 = SMALL && HID == 16;
+    static constexpr int SG0 = (C + 15) / 16, SG3 = (HID + 15) / 16, SG1 = (HALF + 15) / 16;
+    static constexpr int OFF_SB0 = OFF_A3 + NG3 * RT03 * 256;
+    static constexpr int OFF_SB3 = OFF_SB0 + (SMALL ? 16 : 0);
+    static constexpr int OFF_SA0 = OFF_SB3 + (SMALL ? 16 : 0);
+    static constexpr int OFF_SA3 = OFF_SA0 + (SMALL ? SG0 * 256 : 0);
+    static constexpr int OFF_SA1 = OFF_SA3 + (SMALL ? SG3 * 256 : 0);
+    static constexpr int OFF_SA2 = OFF_SA1 + (HID16 ? SG1 * 256 : 0);
+    static constexpr int WS_FLOATS = OFF_SA2 + (HID16 ? 9 * 256 : 0);
     static constexpr int LDS_FLOATS = (HALF + HID) * PIX;
     // waves per SIMD the register allocator must leave room for = workgroups per CU the LDS footprint admits
     static constexpr int MINW = (160 * 1024) / (LDS_FLOATS * 4) >= 4 ? 4 : ((160 * 1024) / (LDS_FLOATS * 4) >= 2 ? 2 : 1);
@@ -54,6 +68,12 @@ struct Geo {
 // then share a lane and differ by a fixed register offset.
 template <class G> __host__ __device__ constexpr int chan_of_row(int p) {
     return ((p % G::HP) < G::HALF) ? (p / G::HP) * G::HALF + (p % G::HP) : -1;
+}
+
+// 16-row packing of the 16x16x4 phases: row 4g + j (g = lane >> 4 owns it in the result tile): j = 0,1 -> first-half
+// channel 2g + j, j = 2,3 -> second-half channel HALF + 2g + (j - 2): t / raw / y1 of one channel again share a lane.
+template <class G> __host__ __device__ constexpr int chan_of_row16(int p) {
+    return (2 * (p >> 2) + (p & 1) < G::HALF) ? ((p & 2) ? G::HALF : 0) + 2 * (p >> 2) + (p & 1) : -1;
 }
 
 // ---- helpers -----------------------------------------------------------------------------------------
@@ -123,6 +143,7 @@ template <class G, int KS, int NG, int RT, class FRAG>
 __device__ __forceinline__ void dense_phase_impl(f32x16 (&acc)[RT][G::PTW], FRAG frag,
                                                  const float* __restrict__ plane, const int (&pix)[G::PTW], int lane) {
     const int lk = lane >> 5;
+    cf_wave_sync();                      // the operand plane was written by other lanes of this wave
     GroupOps<RT, G::PTW> ops[2];
     auto load = [&](int g, GroupOps<RT, G::PTW>& o) {
 #pragma unroll
@@ -192,6 +213,7 @@ __device__ __forceinline__ void x_to_lds(const float4 (&xr)[G::C * G::PTW / 8], 
             *reinterpret_cast<float2*>(&plane[(2 * cp + 1) * PIX + col]) = make_float2(xr[i].y, xr[i].w);
         }
     }
+    cf_wave_sync();
 }
 
 // write NROWS channel rows (channels ch0 .. ch0+NROWS-1 of a (B,C,H,W) tensor) from an LDS plane [row][PIX]
@@ -200,6 +222,7 @@ template <class G, int NROWS>
 __device__ __forceinline__ void rows_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
                                            int wave, int lane) {
     constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, C = G::C;
+    cf_wave_sync();                      // rows written by other lanes of this wave
 #pragma unroll
     for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
         const int n = i * 64 + lane;
@@ -209,6 +232,7 @@ __device__ __forceinline__ void rows_store(float* __restrict__ z, const float* _
             *reinterpret_cast<float4*>(z + (int64_t)b * C * HW + (int64_t)(ch0 + idx) * HW + col % HW) =
                 *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
     }
+    cf_wave_sync();                      // ... read back before anyone reuses the words
 }
 template <class G>
 __device__ __forceinline__ void z_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
@@ -221,6 +245,7 @@ template <class G, int NROWS, int CT>
 __device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const float* __restrict__ plane, int tb0, int B,
                                              int wave, int lane) {
     constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX;
+    cf_wave_sync();
 #pragma unroll
     for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
         const int n = i * 64 + lane;
@@ -230,11 +255,13 @@ __device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const floa
             *reinterpret_cast<float4*>(dst + (int64_t)b * CT * HW + (int64_t)idx * HW + col % HW) =
                 *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
     }
+    cf_wave_sync();
 }
 template <class G, int NROWS, int CT>
 __device__ __forceinline__ void rows_load_t(const float* __restrict__ src, float* __restrict__ plane, int tb0, int B,
                                             int wave, int lane) {
     constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX;
+    cf_wave_sync();                      // earlier readers of these words (other lanes) are done
 #pragma unroll
     for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
         const int n = i * 64 + lane;
@@ -246,6 +273,7 @@ __device__ __forceinline__ void rows_load_t(const float* __restrict__ src, float
             *reinterpret_cast<float4*>(&plane[idx * PIX + col]) = v;
         }
     }
+    cf_wave_sync();
 }
 
 // training tape of a step (forward with DUMP writes, backward with TAPED reads): y0 (B, C/2, H, W), h1 / h2 (B, 2C, H, W),
@@ -263,7 +291,8 @@ struct StepTape {
 // (h = NN(x0) + CN(c), contextflow); 2 per-sample bias sb[sample][HID] added before the first ReLU (CN(c) concatenated
 // to the net input = W[:, D:] CN(c) through the first 1x1).  soff[q] = this lane's row offset into sb.
 // DUMP (training): the post-ReLU h1 / h2 planes go to the tape (16-byte stores of this wave's own columns).
-template <class G, int CTX = 0, bool DUMP = false>
+// UPTO = 2: stop once h2 sits in LDS (k_flow_step_small runs the last 1x1 on 16x16x4 tiles itself; acc3 untouched).
+template <class G, int CTX = 0, bool DUMP = false, int UPTO = 3>
 __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW], float* __restrict__ lds,
                                                 const float* __restrict__ wsl, const int (&pix)[G::PTW],
                                                 const int (&pin)[G::PTW], int lane, int tid, float* __restrict__ dbg,
@@ -304,7 +333,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     const int row = rt * 32 + tile_row(r, lk);
                     if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
                 }
-        if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h1, H1, tile * G::SPW, B, tid >> 6, lane);
+        if constexpr (DUMP) { cf_wave_sync(); rows_store_t<G, HID, HID>(tp.h1, H1, tile * G::SPW, B, tid >> 6, lane); }
     }
     __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' columns
     if (dbg) {
@@ -331,7 +360,54 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                 src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
             }
         };
-        if constexpr (G::PIPE == 0) {
+        if constexpr (G::PIPE == 2) {
+            // every tap unrolled (compiler-scheduled inside).  The reflect-padded source offset of a tap splits into a row
+            // part per (dy, pixel tile) and a column part per dx - the column inside the image row is the same for every
+            // tile because W divides 32 - so the whole 3x3 costs 3 + 3 PTW reflections and one add per (tap, tile),
+            // instead of a reflection pair per tap and tile inside the MFMA stream (27 VALU per tap at C = 16).
+            static_assert(32 % W == 0, "a 32-pixel tile must hold whole image rows");
+            int yo[3][PTW], xo[3];
+            const int xin = pin[0] % W;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                int xx = xin + d - 1;
+                xo[d] = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) {
+                    int yy = pin[q] / W + d - 1;
+                    yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+                    yo[d][q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + lk * PIX;
+                }
+            }
+            float4 a_cur[RT1], a_nxt[RT1];
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = ws_frag(rs, lane, G::OFF_A2 + rt * 256);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                int src[PTW];
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) src[q] = yo[tap / 3][q] + xo[tap % 3];
+#pragma unroll
+                for (int cg = 0; cg < G::NCG; ++cg) {
+                    const int g = tap * G::NCG + cg;
+                    const int gn = g + 1 < G::NG2 ? g + 1 : G::NG2 - 1;
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) a_nxt[rt] = ws_frag(rs, lane, G::OFF_A2 + (gn * RT1 + rt) * 256);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int q = 0; q < PTW; ++q) {
+                            const float bv = lds[src[q] + (8 * cg + 2 * e) * PIX];
+#pragma unroll
+                            for (int rt = 0; rt < RT1; ++rt)
+                                acc[rt][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a_cur[rt], e), bv, acc[rt][q], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt) a_cur[rt] = a_nxt[rt];
+                }
+            }
+        } else if constexpr (G::PIPE == 0) {
             // compiler-scheduled form: one tap per loop trip, all NCG groups of the tap unrolled
             float4 a_cur[RT1], a_nxt[RT1];
 #pragma unroll
@@ -412,15 +488,17 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     const int row = rt * 32 + tile_row(r, lk);
                     if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
                 }
+        cf_wave_sync();              // h2 rows of all lanes in place (read below by other lanes of this wave)
         if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h2, H1, tile * G::SPW, B, tid >> 6, lane);
     }
-    // no barrier: phase 3 reads only this wave's own pixel columns of h2
+    // no workgroup barrier: phase 3 reads only this wave's own pixel columns of h2
     if (dbg) {
         __syncthreads();
         float* d = dbg + (int64_t)(C + HID) * dbg_cols;
         for (int e = tid; e < HID * PIX; e += 256) d[(int64_t)(e / PIX) * dbg_cols + (int64_t)tile * PIX + (e % PIX)] = H1[e];
     }
 
+    if constexpr (UPTO < 3) return;
     // ================= phase 3: h = NN.4 h2 + b ; affine map ; log-det        (coupling.py:28,52-66)
 #pragma unroll
     for (int rt = 0; rt < RT03; ++rt)
@@ -452,9 +530,10 @@ using G16 = Geo<16, 16, 16, 1, 0>;
 using G32 = Geo<32, 8, 8, 4, 1>;
 using G64 = Geo<64, 4, 4, 16, 1>;
 // alternates kept for tools/step_bench.py, reachable only through cf_flow_step_fwd_debug (flags bits 16..19)
+using G16s = Geo<16, 16, 16, 1, 2>;      // k_flow_step_small: 16x16x4 tiles for the 16-row phases, taps unrolled
+using G8s = Geo<8, 16, 16, 1, 2>;
 using G16v1 = Geo<16, 16, 16, 1, 1>;
 using G16v2 = Geo<16, 16, 16, 2, 1>;
-using G16v3 = Geo<16, 16, 16, 2, 0>;
 using G32v1 = Geo<32, 8, 8, 4, 0>;
 using G32v2 = Geo<32, 8, 8, 2, 1>;
 using G32v3 = Geo<32, 8, 8, 8, 0>;

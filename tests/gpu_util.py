@@ -27,8 +27,9 @@ def set_noise(model, u, eps, dev=DEV):
             m.distribution.fixed_noise = eps.pop(0).to(dev) if eps else None
 
 
-def fused_step_debug(x, conv, act, cpl, squeeze=False):
-    """Run cf_flow_step_prepare + the debug variant of the step kernel; returns z, ldj, dumps."""
+def fused_step_debug(x, conv, act, cpl, squeeze=False, variant=0):
+    """Run cf_flow_step_prepare + the debug variant of the step kernel; returns z, ldj, dumps.  variant 3 (16x16 images):
+    the dumps of k_flow_step_small."""
     L = _hip.lib()
     fn = L.cf_flow_step_fwd_debug
     fn.restype = ctypes.c_int
@@ -47,7 +48,7 @@ def fused_step_debug(x, conv, act, cpl, squeeze=False):
     dbg = torch.full((2 * C + 4 * C, cols), float("nan"), device=x.device)
     z = torch.empty(B, C, H, W, device=x.device)
     ldj = torch.zeros(B, device=x.device)
-    _hip.check(fn(pp(x), pp(z), pp(ldj), pp(ws), B, C, H, W, C * H * W, int(squeeze), pp(dbg), 0, _hip.stream()),
+    _hip.check(fn(pp(x), pp(z), pp(ldj), pp(ws), B, C, H, W, C * H * W, int(squeeze), pp(dbg), variant << 16, _hip.stream()),
                "cf_flow_step_fwd_debug")
     torch.cuda.synchronize()
     HID, HALF = 2 * C, C // 2
@@ -56,4 +57,11 @@ def fused_step_debug(x, conv, act, cpl, squeeze=False):
         v = dbg[r0:r0 + rows, : B * H * W].reshape(rows, B, H, W).permute(1, 0, 2, 3)
         return v.contiguous()
 
-    return z, ldj, dict(y0=plane(0, HALF), h1=plane(C, HID), h2=plane(C + HID, HID), h=plane(C + 2 * HID, C))
+    # the production entry point on the same operands (small batches / 16x16 images take other kernel variants than the
+    # dump kernel above: half-size workgroups, k_flow_step_small)
+    z2 = torch.full((B, C, H, W), float("nan"), device=x.device)
+    ldj2 = torch.zeros(B, device=x.device)
+    _hip.call("cf_flow_step_fwd", pp(x), pp(z2), pp(ldj2), pp(ws), B, C, H, W, C * H * W, int(squeeze), _hip.stream())
+    torch.cuda.synchronize()
+    return z, ldj, dict(y0=plane(0, HALF), h1=plane(C, HID), h2=plane(C + HID, HID), h=plane(C + 2 * HID, C), z_prod=z2,
+                        ldj_prod=ldj2)

@@ -214,6 +214,13 @@ def test_fused_step_phases(L, C, H, W, B, squeeze):
     close(d["y0"], y[:, : C // 2]); close(d["h1"], h1); close(d["h2"], h2); close(d["h"], h)
     close(z, zref)
     close(ldj, l0 + l1 + l2, tol=1e-5)
+    if H == 16:                                            # 16x16 images: every plane of k_flow_step_small as well
+        z, ldj, d2 = fused_step_debug(xin.to(DEV).contiguous(), conv, act, cpl, squeeze=squeeze, variant=3)
+        close(d2["y0"], y[:, : C // 2]); close(d2["h1"], h1); close(d2["h2"], h2); close(d2["h"], h)
+        close(z, zref)
+        close(ldj, l0 + l1 + l2, tol=1e-5)
+    close(d["z_prod"], zref)                               # cf_flow_step_fwd: the kernel variant production picks
+    close(d["ldj_prod"], l0 + l1 + l2, tol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------ end to end
@@ -550,8 +557,9 @@ def test_backward_against_autograd_oracle(L, name, B):
 @pytest.mark.parametrize("name,B", [("mnist", 37), ("cifar10", 70)])
 def test_taped_backward_equals_recompute(L, name, B):
     """Training forward that tapes y0 / h1 / h2 (cf_flow_step_fwd_taped) + the backward that loads them
-    (cf_flow_step_bwd_taped) against the backward that recomputes everything from the step input: same logp bit for
-    bit, same gradients (the planes hold the same values either way); ragged last tiles at every level."""
+    (cf_flow_step_bwd_taped) against the backward that recomputes everything from the step input: same logp (to fp32
+    rounding: on 16x16 images the un-taped forward runs k_flow_step_small, whose 16x16x4 tiles sum k in another order),
+    same gradients (the planes hold the same values either way); ragged last tiles at every level."""
     from tests.gpu_util import build_model, set_noise
     from contextflow_amd.layers import flowsequential as fs
     ops, _, M, params, fx = load_e2e(name)
@@ -573,7 +581,7 @@ def test_taped_backward_equals_recompute(L, name, B):
             out[taped] = (logp.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
     finally:
         fs.TAPE_PLANES = True
-    assert torch.equal(out[True][0], out[False][0])
+    assert (bpd(out[True][0].cpu(), name) - bpd(out[False][0].cpu(), name)).abs().max().item() < 1e-6
     assert out[True][1].keys() == out[False][1].keys() and len(out[True][1]) >= 30
     for k, ga in out[True][1].items():
         gb = out[False][1][k]

@@ -16,12 +16,12 @@ lib = _hip.lib()
 fn = lib.cf_flow_step_fwd_debug
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-FLOP = 2 * (2555904 + 65536)
+FLOP = None
 dev = "cuda:0"
 variants = [("base", 0)]
 for a in sys.argv[2:]:
     variants.append((a, int(a, 0)))
-for C, H, W, nslots in ((16, 16, 16, 4), (32, 8, 8, 2), (64, 4, 4, 2)):
+for C, H, W, nslots in ((8, 16, 16, 4), (16, 16, 16, 4), (32, 8, 8, 2), (64, 4, 4, 2)):
     torch.manual_seed(0)
     conv, act, cpl = L.Conv1x1((C, H, W)).to(dev), L.ActNorm((C, H, W)).to(dev), L.Coupling(C, (3, 3), (1, 1)).to(dev)
     x = torch.randn(B, C, H, W, device=dev)
@@ -48,5 +48,5 @@ for C, H, W, nslots in ((16, 16, 16, 4), (32, 8, 8, 2), (64, 4, 4, 2)):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        res.append("%s: %.3f ms %.1f TF" % (name, ms, B * FLOP / ms / 1e9))
+        res.append("%s: %.3f ms %.1f TF" % (name, ms, B * 80 * H * W * C * C / ms / 1e9))
     print("C%d B%d | " % (C, B) + " | ".join(res), flush=True)
