@@ -18,12 +18,23 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # before the first GPU call: RCCL needs dmabuf IPC on this pool
 
 import torch  # noqa: E402
 
-FLOP_PER_SAMPLE_STEP = {"cifar10": 2 * (2555904 + 65536), "mnist": None}   # MACs of one flow step x2
 PEAK_F32_MFMA_TFLOPS = 157.3                                              # MI355X_MICROARCH.md, dense fp32 matrix
 DIMS = {"cifar10": 3072, "mnist": 1024, "smap": 200, "atm": 38 * 144}
+SHAPES = {"cifar10": (3, 32, 32), "mnist": (1, 32, 32), "smap": (25, 8, 1), "atm": (38, 144, 1)}
+LABEL = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap": "SMAP trans flow", "atm": "ATM trans flow"}
+# Algorithmic flop of ONE launch of the dominant kernel per sample (counted on the reference with hooks):
+#  conv flows: k_flow_step = Conv1x1 (C^2 HW MAC) + coupling net (C/2*2C + 9*2C*2C + 2C*C = 39 C^2 MAC per pixel)
+#              = 2 * 40 C^2 HW flop  (cifar10: 5 242 880 at every level; mnist: 1 310 720 at C = 8, 5 242 880 at C = 32);
+#  smap: k_vit_step = Conv1x1 26x26x8 + SimpleViT linears 454 688 + attention QK^T / PV 12 288 MAC = 944 768 flop.
+VIT_FLOP_PER_SAMPLE = {"smap": 2 * (26 * 26 * 8 + 454688 + 12288)}
+
+
+def step_flop(C, HW):
+    return 80 * C * C * HW
 
 
 def parse():
@@ -35,14 +46,14 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=2097152)
     ap.add_argument("--chunk", type=int, default=262144, help="samples per kernel launch sequence on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the mnist / smap / small-batch lines (N = 1 only)")
     return ap.parse_args()
 
 
 def synth(name, n, dev, seed):
     """Synthetic input resident in HBM: uint8-valued fp32 images (what Dequantization receives) or [0,1) series."""
     g = torch.Generator(device=dev).manual_seed(seed)
-    C, H, W = {"cifar10": (3, 32, 32), "mnist": (1, 32, 32), "smap": (25, 8, 1), "atm": (38, 144, 1)}[name]
+    C, H, W = SHAPES[name]
     out = torch.empty(n, C, H, W, device=dev, dtype=torch.float32)
     for i in range(0, n, 65536):                      # piecewise: randint materialises int64
         m = min(65536, n - i)
@@ -80,31 +91,157 @@ def host_cores():
     return n
 
 
-def cpu_baseline(name, seconds):
-    """The oracle (a CPU port of the reference path, pinned to the reference by tests/golden) timed on
-    this box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(name, B=256, iters=10, warmups=3):
+    """The oracle (a CPU port of the reference path, pinned to the reference by tests/golden) timed on this box's host
+    cores on a bounded sample of the same workload, as BASELINE.md section 3 prescribes: torch threads = usable cores,
+    no_grad, 3 warm-ups, median of >= 10 iterations of one batch."""
     from oracle import flow_oracle as fo, params as op
     cores = host_cores()
     torch.set_num_threads(cores)
     ops, prior, M = fo.program(name)
     params = op.gen_params(op.param_spec(ops, prior, M), seed=0)
-    B = 256
     g = torch.Generator().manual_seed(0)
     C, H, W = fo.CONFIGS[name][0]
     x = torch.rand(B, C, H, W, generator=g) if name in ("smap", "atm") else torch.randint(0, 256, (B, C, H, W), generator=g).float()
     u = torch.rand(B, C, H, W, generator=g)
     eps = [torch.randn(B, 1, H, W, generator=g)]
+    times = []
     with torch.no_grad():
-        fo.flow_forward(ops, params, x, u, eps, init_actnorm=True)      # init + warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
+        fo.flow_forward(ops, params, x, u, eps, init_actnorm=True)      # ActNorm init
+        for i in range(warmups + iters):
+            t0 = time.perf_counter()
             fo.flow_forward(ops, params, x, u, eps)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt >= seconds or n >= 200:
-                break
-    return {"value": round(n * B / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d batches of %d %s-shaped samples, oracle/flow_oracle.py fp32, torch %d threads" % (n, B, name, cores)}
+            if i >= warmups:
+                times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(B / med, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "median of %d forward passes over one batch of %d %s-shaped samples after %d warm-ups, "
+                      "oracle/flow_oracle.py fp32, torch %d threads" % (iters, B, name, warmups, cores)}
+
+
+def build(name, dev, rank=0):
+    """Reference init under a fixed seed; rank 0 runs the ActNorm data-dependent init on 256 synthetic samples."""
+    import contextflow_amd as cfa
+    torch.manual_seed(0)
+    cfg, data_size, M = cfa.preset_config(name)
+    model = cfa.create_model(cfg, data_size, M).to(dev)
+    if rank == 0:
+        with torch.no_grad():
+            model(synth(name, 256, dev, seed=999))
+    return model, cfg
+
+
+def kernel_events(model, name):
+    """Turn on the HIP-event probes around the dominant kernel of this workload; returns the list they fill."""
+    from contextflow_amd.layers import coupling
+    ev = []
+    if name in VIT_FLOP_PER_SAMPLE:
+        coupling.VIT_EVENTS = ev
+    else:
+        model.step_events = ev
+    return ev
+
+
+def roofline(events, name, dt):
+    """Roofline of the dominant kernel (fp32 MFMA): algorithmic flop of the launches / their measured durations."""
+    if not events:
+        return None
+    vit = name in VIT_FLOP_PER_SAMPLE
+    ms = sum(e[0].elapsed_time(e[1]) for e in events)
+    flop = sum(e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4])) for e in events)
+    ach = flop / (ms * 1e-3) / 1e12
+    per = {}
+    for e in events:
+        k = "vit" if vit else "C%d" % e[3]
+        per.setdefault(k, [0.0, 0.0])
+        per[k][0] += e[0].elapsed_time(e[1])
+        per[k][1] += e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4]))
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp) and not vit and name == "cifar10":   # PMC-measured HBM bytes (profiles/), scaled to this run's launch size
+        tj = json.load(open(tp))
+        avg_b = sum(e[2] for e in events) / len(events)
+        traffic = int(tj["k_flow_step_bytes_per_launch"] / tj["batch_per_launch"] * avg_b)
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "kernel": "k_vit_step (Conv1x1+ActNorm+TransCoupling fused, v_mfma_f32_32x32x2_f32)" if vit else
+                      "k_flow_step / k_flow_step_small (Conv1x1+ActNorm+Coupling fused, v_mfma_f32_32x32x2_f32 + 16x16x4_f32)",
+            "launches": len(events), "avg_launch_ms": round(ms / len(events), 4),
+            "per_level_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
+            "kernel_time_share": round(ms * 1e-3 / dt, 3)}
+
+
+def total_flop_per_sample(name):
+    return {"cifar10": 62914560, "mnist": 13107200, "smap": 7361536 + 2 * 98304}[name]
+
+
+def secondary_throughput(name, dev, G, chunk, steps, warmup, cpu):
+    """The other single-GPU BASELINE.json configs at a saturating batch: same loop as the headline, one GPU."""
+    from contextflow_amd.layers import _hip, coupling
+    model, cfg = build(name, dev)
+    x = synth(name, G, dev, seed=2000)
+    nll = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    @torch.no_grad()
+    def step():
+        nll.zero_()
+        for c0 in range(0, G, chunk):
+            _, logp = model(x[c0:c0 + chunk])
+            _hip.call("cf_nll_sum", _hip.p(logp), _hip.p(nll), logp.shape[0], logp.shape[1], _hip.stream())
+    for _ in range(warmup):
+        step()
+    ev = kernel_events(model, name)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.step_events, coupling.VIT_EVENTS = None, None
+    out = {"metric": "samples/s fwd+logdet (log p(x) (B,M)), %s" % LABEL[name], "value": round(G * steps / dt, 1),
+           "unit": "samples/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+           "config": {"workload": "%s --coupling %s, generalist, reference init" % (name, cfg["coupling"]), "global_batch": G, "chunk": chunk},
+           "bits_per_dim": round(float(-(nll / G) / (DIMS[name] * math.log(2.0))), 6), "roofline": roofline(ev, name, dt)}
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline(name)
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    del model, x
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_small_batch(name, dev, B, cpu, iters=300):
+    """The reference's operating point (config.py:10: batch 256; BASELINE config 1: 64): latency of ONE eval forward
+    through the public API (`flow.log_prob(x)` under no_grad), eagerly launched and - the default once a shape repeats -
+    replayed from the captured HIP graph.  roofline = all dense flop of the call / its wall time (whole call, not one
+    kernel: at these sizes the call is launch- and latency-bound)."""
+    model, cfg = build(name, dev)
+    x = synth(name, B, dev, seed=3000)
+    res = {}
+    with torch.no_grad():
+        for mode in ("eager", "graph"):
+            model.auto_graph = mode == "graph"
+            for _ in range(20):
+                model.log_prob(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                model.log_prob(x)
+            torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t0) / iters
+    best = min(res.values())
+    tf = total_flop_per_sample(name) * B / best / 1e12
+    out = {"metric": "samples/s fwd+logdet, %s, one batch of %d per call" % (LABEL[name], B), "value": round(B / best, 1),
+           "unit": "samples/s", "config": {"workload": "%s --coupling %s" % (name, cfg["coupling"]), "batch": B, "iters": iters},
+           "us_per_call": {k: round(v * 1e6, 1) for k, v in res.items()},
+           "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "basis": "whole call (launch-bound regime)"}}
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline(name, B=B)
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -128,21 +265,14 @@ def main():
     _hip.lib()
     name = a.workload
 
-    # model: reference init under a fixed seed; rank 0 runs the ActNorm data-dependent init, then broadcast
-    torch.manual_seed(0)
-    cfg, data_size, M = cfa.preset_config(name)
-    model = cfa.create_model(cfg, data_size, M).to(dev)
-    if rank == 0:
-        with torch.no_grad():
-            model(synth(name, 256, dev, seed=999))
+    # model: reference init under a fixed seed; rank 0 runs the ActNorm data-dependent init, then ONE flat broadcast
+    model, cfg = build(name, dev, rank)
     cdist.broadcast_parameters(model, src=0)
 
     G = a.global_batch
     lo, hi = cdist.shard_bounds(G, rank, world)
     x = synth(name, hi - lo, dev, seed=1000 + rank)
     nll_acc = torch.zeros(1, dtype=torch.float64, device=dev)
-    events = []
-
     @torch.no_grad()                                   # density evaluation (experiment_cl.py:163-185 runs it under no_grad):
     def step(timed):                                   # no autograd tape, no W^-1 for the backward
         nll_acc.zero_()
@@ -160,47 +290,27 @@ def main():
 
     for _ in range(a.warmup):
         red = step(False)
-    model.step_events = events if FLOP_PER_SAMPLE_STEP.get(name) else None
+    events = kernel_events(model, name)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         red = step(True)
     fence()
     dt = time.perf_counter() - t0
-    model.step_events = None
+    from contextflow_amd.layers import coupling as _cpl
+    model.step_events, _cpl.VIT_EVENTS = None, None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     bpd = cdist.mean_bits_per_dim(red.cpu(), DIMS[name])
-
-    # roofline of the dominant kernel (k_flow_step, fp32 MFMA): algorithmic flops / measured duration
-    roof = None
-    if events:
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in events)
-        flops = sum(b * FLOP_PER_SAMPLE_STEP[name] for _, _, b, _ in events)
-        ach = flops / (ms * 1e-3) / 1e12
-        per = {}
-        for e0, e1, b, c in events:
-            k = "C%d" % c
-            per.setdefault(k, [0.0, 0.0])
-            per[k][0] += e0.elapsed_time(e1); per[k][1] += b * FLOP_PER_SAMPLE_STEP[name]
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):          # PMC-measured HBM bytes (profiles/, tools/profile.sh), scaled to this run's launch size
-            tj = json.load(open(tp))
-            avg_b = sum(b for _, _, b, _ in events) / len(events)
-            traffic = int(tj["k_flow_step_bytes_per_launch"] / tj["batch_per_launch"] * avg_b)
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "kernel": "k_flow_step (Conv1x1+ActNorm+Coupling fused, v_mfma_f32_32x32x2_f32)",
-                "launches": len(events), "avg_launch_ms": round(ms / len(events), 4),
-                "per_level_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
-                "kernel_time_share": round(ms * 1e-3 / dt, 3)}
+    roof = roofline(events, name, dt)
+    comm = {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+            "rehearsal_gloo_on_one_device": rehearsal}
 
     if rank == 0:
-        label = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap": "SMAP trans flow", "atm": "ATM trans flow"}[name]
-        out = {"metric": "samples/s fwd+logdet (log p(x) (B,M)), %s" % label,
+        out = {"metric": "samples/s fwd+logdet (log p(x) (B,M)), %s" % LABEL[name],
                "value": round(G * a.steps / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -208,10 +318,23 @@ def main():
                           if name == "cifar10" else "%s --coupling %s" % (name, cfg["coupling"]),
                           "global_batch": G, "per_gpu_batch": hi - lo, "chunk": a.chunk, "parallelism": "dp%d" % world,
                           "collective": "all_reduce(sum log p, count) fp64 x2 per step"},
-               "bits_per_dim": round(bpd, 6), "roofline": roof}
+               "bits_per_dim": round(bpd, 6), "roofline": roof, "comm": comm}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(name, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(name)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        if world == 1 and not a.no_secondary and name == "cifar10":
+            # the other single-GPU configs of BASELINE.json and the batch sizes of SURVEY.md 8(d); the headline fields above
+            # are unaffected (measured first, their buffers released)
+            del model, x
+            torch.cuda.empty_cache()
+            cpu = not a.no_cpu_baseline
+            out["secondary"] = [
+                secondary_throughput("mnist", dev, 2097152, 262144, 3, 1, cpu),
+                secondary_throughput("smap", dev, 4194304, 524288, 3, 1, cpu),
+                secondary_small_batch("cifar10", dev, 64, cpu),
+                secondary_small_batch("cifar10", dev, 256, cpu=False),     # its CPU baseline is the headline's (batch 256)
+                secondary_small_batch("mnist", dev, 64, cpu),
+            ]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

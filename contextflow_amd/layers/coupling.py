@@ -11,6 +11,8 @@ import torch.nn as nn
 
 from . import _hip
 from .flowlayer import FlowLayer, encoder_noise
+
+VIT_EVENTS = None        # bench.py: list collecting (start, end, batch) HIP events per fused ViT-coupling launch
 from .simple_vit import SimpleViT
 
 
@@ -269,8 +271,15 @@ class TransCoupling(_AffineCoupling):
             vit.pos_embedding = vit.pos_embedding.to(x.device).contiguous()
         z = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
         ldj = None if inverse else torch.empty(B, device=x.device, dtype=torch.float32)
+        events = VIT_EVENTS
+        if events is not None:               # bench.py: HIP events on the launch stream around exactly this kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(x.device))
         _hip.call("cf_vit_coupling", _hip.p(x), _hip.p(z), _hip.p(ldj), _hip.p(ws), _hip.p(vit.pos_embedding),
                   B, C, H, W, p1, p2, dim, depth, xbs, int(inverse), st)
+        if events is not None:
+            e1.record(torch.cuda.current_stream(x.device))
+            events.append((e0, e1, B))
         return z, ldj
 
     def forward(self, x, context=None):

@@ -46,9 +46,16 @@ class FlowSequential(nn.Module):
             self.add_module(str(i), module)
         self.sequence_modules = modules
         self.fused = True
-        self.step_events = None      # bench.py: list collecting (start, end, batch, C) HIP events per step-kernel launch
+        self.step_events = None      # bench.py: list collecting (start, end, batch, C, H*W) HIP events per step-kernel launch
         self._plans = {}             # input (C,H,W) -> op list
         self._side = {}              # device index -> side stream for the parameter transforms
+        # evaluation (no_grad): the packed step workspaces / GMM tables are kept between calls and rebuilt only when a
+        # parameter they derive from changes (keyed on the tensors' version counters; `.to()` / `_apply` drops them)
+        self._prep = {}              # (plan key, op index) -> (versions, buffers)
+        # launch-bound regime: after AUTO_GRAPH_AFTER identical-shape no_grad calls with unchanged parameters the fused
+        # forward is captured into a HIP graph and replayed (batches up to AUTO_GRAPH_MAX_BATCH); set False to disable
+        self.auto_graph = True
+        self._graphs = {}            # (shape, device) -> [stable calls, versions, GraphedFlow | None]
         self._rng, self._rng_seed, self._rng_latched = {}, 0, {}   # device index -> position of the in-kernel noise stream / seed it was started under
 
     def __iter__(self):
@@ -57,7 +64,25 @@ class FlowSequential(nn.Module):
     def __getstate__(self):              # streams / cached plans are per-process runtime state
         d = self.__dict__.copy()
         d["_plans"], d["_side"], d["step_events"], d["_rng"], d["_rng_latched"] = {}, {}, None, {}, {}
+        d["_prep"], d["_graphs"] = {}, {}
         return d
+
+    def invalidate_caches(self):
+        """Drop everything derived from parameter VALUES (packed step workspaces, mixture tables, captured graphs).  Needed
+        only after writes that bypass the version counters (`param.data.copy_(...)`); optimizer steps, `load_state_dict`,
+        `.to()` are noticed without it."""
+        self._prep.clear()
+        self._graphs.clear()
+        for m in self.modules():
+            if hasattr(m, "_tab_cache"):
+                m._tab_cache = None
+
+    def _apply(self, fn, *a, **k):         # .to() / .cuda() / .float(): new storages, same version counters
+        self._prep, self._graphs, self._plans = {}, {}, {}
+        return super()._apply(fn, *a, **k)
+
+    def _versions(self):
+        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
 
     # ------------------------------------------------------------------ layer-by-layer mode
     def _forward_layers(self, input, context):
@@ -197,29 +222,52 @@ class FlowSequential(nn.Module):
         main = torch.cuda.current_stream(dev)
         side = self._side_stream(dev)
 
-        # ---- parameter transforms on the side stream (overlap the main stream's kernels)
-        side.wait_stream(main)
+        # ---- parameter transforms: kept from the previous call while the parameters they derive from are unchanged
+        # (evaluation); otherwise rebuilt on the side stream, overlapping the main stream's kernels
         prepared = {}
-        with torch.cuda.stream(side):
-            for k, op in enumerate(plan):
-                if op[0] == "step":
-                    prepared[k] = self._prepare_step(op[1], op[2], op[3], op[4], dev)
-                    if tape is not None:     # training: W^-1 for d(log|det W|)/dW, off the critical path
-                        Cc = op[4][0]
-                        winv = torch.empty(Cc, Cc, device=dev, dtype=torch.float32)
-                        lad = torch.empty(1, device=dev, dtype=torch.float32)
-                        _hip.call("cf_slogdet_inverse", _hip.p(_hip.f32(op[1].NN.detach())), Cc, _hip.p(lad), _hip.p(winv), _hip.stream())
-                        prepared[k] = (prepared[k], winv)
-                elif op[0] == "split":
-                    prepared[k] = op[1].dist.prepared()
-                else:
-                    continue
-                ev = torch.cuda.Event()
-                ev.record(side)
-                prepared[k] = (prepared[k], ev)
-            prior = self.dist.prepared()
-            ev_prior = torch.cuda.Event()
-            ev_prior.record(side)
+        cache_ok = tape is None
+        todo = []
+        for k, op in enumerate(plan):
+            if op[0] == "step":
+                srcs = (op[1].NN, op[2].NN_t, op[2].NN_logs) + tuple(p for c in (op[3].NN[0], op[3].NN[2], op[3].NN[4]) for p in (c.weight, c.bias))
+            elif op[0] == "split":
+                srcs = (op[1].dist.mG, op[1].dist.sG, op[1].dist.wG)
+            else:
+                continue
+            ver = tuple(t._version for t in srcs) + (dev.index,)
+            hit = self._prep.get((key, k)) if cache_ok else None
+            if hit is not None and hit[0] == ver:
+                prepared[k] = (hit[1], None)
+            else:
+                todo.append((k, op, ver))
+        pver = tuple(t._version for t in (self.dist.mG, self.dist.sG, self.dist.wG)) + (dev.index,)
+        hit = self._prep.get((key, "prior")) if cache_ok else None
+        prior, ev_prior = (hit[1], None) if (hit is not None and hit[0] == pver) else (None, None)
+        if todo or prior is None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for k, op, ver in todo:
+                    if op[0] == "step":
+                        buf = self._prepare_step(op[1], op[2], op[3], op[4], dev)
+                        if tape is not None:     # training: W^-1 for d(log|det W|)/dW, off the critical path
+                            Cc = op[4][0]
+                            winv = torch.empty(Cc, Cc, device=dev, dtype=torch.float32)
+                            lad = torch.empty(1, device=dev, dtype=torch.float32)
+                            _hip.call("cf_slogdet_inverse", _hip.p(_hip.f32(op[1].NN.detach())), Cc, _hip.p(lad), _hip.p(winv), _hip.stream())
+                            buf = (buf, winv)
+                    else:
+                        buf = op[1].dist.prepared()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    prepared[k] = (buf, ev)
+                    if cache_ok:
+                        self._prep[(key, k)] = (ver, buf)
+                if prior is None:
+                    prior = self.dist.prepared()
+                    ev_prior = torch.cuda.Event()
+                    ev_prior.record(side)
+                    if cache_ok:
+                        self._prep[(key, "prior")] = (pver, prior)
 
         ld1 = torch.zeros(B, device=dev, dtype=torch.float32)       # per-sample scalar log-dets
         ldM = torch.zeros(B, M, device=dev, dtype=torch.float32)    # per-mixture terms (priors)
@@ -261,7 +309,8 @@ class FlowSequential(nn.Module):
             elif kind == "step":
                 _, conv, act, cpl, (C, H, W), sq = op
                 ws, ev = prepared[k]
-                main.wait_event(ev)
+                if ev is not None:
+                    main.wait_event(ev)
                 planes = None
                 if tape is not None:
                     ws, winv = ws
@@ -284,7 +333,7 @@ class FlowSequential(nn.Module):
                 _hip.call("cf_flow_step_fwd", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), B, C, H, W, xbs, int(sq), st)
                 if events is not None:
                     e1.record(main)
-                    events.append((e0, e1, B, C))
+                    events.append((e0, e1, B, C, H * W))
                 x = z
             elif kind == "squeeze":
                 if tape is not None:
@@ -292,7 +341,8 @@ class FlowSequential(nn.Module):
                 x = squeeze_op(x, op[1].p, False)
             elif kind == "split":
                 prep, ev = prepared[k]
-                main.wait_event(ev)
+                if ev is not None:
+                    main.wait_event(ev)
                 if tape is not None:
                     tape.append(("split", x, op[1].dist, prep))
                 c = x.shape[1] // 2
@@ -306,7 +356,8 @@ class FlowSequential(nn.Module):
                     ldM += ldj
                 else:
                     ld1 += ldj
-        main.wait_event(ev_prior)
+        if ev_prior is not None:
+            main.wait_event(ev_prior)
         if tape is not None:
             tape.append(("prior", x, self.dist, prior))
         gmm_logprob(x, prior, out=ldM, accumulate=True)
@@ -321,11 +372,13 @@ class FlowSequential(nn.Module):
                     yield from _bufs(u)
 
         for v in prepared.values():
-            for buf in _bufs(v[0]):
-                buf.record_stream(main)
-        for buf in prior:
-            if torch.is_tensor(buf):
-                buf.record_stream(main)
+            if v[1] is not None:
+                for buf in _bufs(v[0]):
+                    buf.record_stream(main)
+        if ev_prior is not None:
+            for buf in prior:
+                if torch.is_tensor(buf):
+                    buf.record_stream(main)
         return x, logp
 
     # ------------------------------------------------------------------ reference API
@@ -351,8 +404,50 @@ class FlowSequential(nn.Module):
                 return FlowLogProb.apply(self, input, *params)
         with torch.no_grad():
             if self._fusable():
+                g = self._auto_graph(input)
+                if g is not None:
+                    z, logp = g(input)
+                    return z.clone(), logp.clone()       # the graph's static outputs are overwritten by the next replay
                 return self._forward_fused(input, context)
             return self._forward_layers(input, context)
+
+    AUTO_GRAPH_AFTER = 2
+    AUTO_GRAPH_MAX_BATCH = 4096
+
+    def _auto_graph(self, x):
+        """Graph replay for small, repeated evaluation batches (the reference's operating point is B = 256, config.py:10:
+        ~20 launches of a few microseconds of work each).  Conditions: same shape / dtype / device as the previous calls,
+        parameters unchanged since (version counters), in-kernel noise (no injected test noise), no event probes, not
+        already capturing.  Anything else runs eagerly, and a parameter update drops the graph."""
+        if (not self.auto_graph or self.step_events is not None or x.dim() != 4 or x.shape[0] == 0
+                or x.shape[0] > self.AUTO_GRAPH_MAX_BATCH or torch.cuda.is_current_stream_capturing()):
+            return None
+        for m in self.sequence_modules:
+            d = getattr(m, "dist", None) or getattr(m, "distribution", None)
+            if d is not None and getattr(d, "fixed_noise", None) is not None:
+                return None
+        gkey = (tuple(x.shape), x.dtype, x.device)
+        ver = self._versions()
+        st = self._graphs.get(gkey)
+        if st is None or st[1] != ver:
+            if len(self._graphs) >= 8:                   # bounded: each graph owns its intermediates
+                self._graphs.clear()
+            self._graphs[gkey] = [1, ver, None]
+            return None
+        if st[2] is None:
+            st[0] += 1
+            if st[0] <= self.AUTO_GRAPH_AFTER:
+                return None
+            st[2] = GraphedFlow(self, x, warmup=1)
+        return st[2]
+
+    def capture_train_step(self, example_input, loss_fn, optimizer, warmup=3):
+        """One whole training step - forward, loss, hand-written backward, optimizer update - captured into ONE HIP graph
+        (at the reference's batch of 256 a step is ~330 launches of a few microseconds each: launch-bound).  Returns
+        `step(x, *loss_args) -> loss` that copies its arguments into static buffers and replays; `loss_fn(logp, *loss_args)`
+        maps the (B, M) log-densities to a scalar.  The optimizer must be capturable (`torch.optim.AdamW(..., capturable=
+        True)`); ActNorm layers must be initialised (run one forward first)."""
+        return GraphedTrainStep(self, example_input, loss_fn, optimizer, warmup)
 
     def log_prob(self, input, context=None):
         return self.forward(input, context)[1]
@@ -426,6 +521,50 @@ class GraphedFlow:
         self.static_in.copy_(x)
         self.graph.replay()
         return self.static_z, self.static_logp
+
+
+class GraphedTrainStep:
+    """See FlowSequential.capture_train_step."""
+
+    def __init__(self, flow, example, loss_fn, optimizer, warmup=3, loss_args=()):
+        _hip.require_device(example)
+        if not flow._fusable() and not flow._specialist():
+            raise RuntimeError("capture_train_step needs initialised ActNorms: run one forward first")
+        self.flow, self.loss_fn, self.opt = flow, loss_fn, optimizer
+        self.static_in = example.detach().clone()
+        self.static_args = None
+        self.graph = None
+        self.warmup = warmup
+
+    def _step(self):
+        self.opt.zero_grad(set_to_none=False)
+        logp = self.flow.log_prob(self.static_in)
+        loss = self.loss_fn(logp, *self.static_args)
+        loss.backward()
+        self.opt.step()
+        return loss
+
+    def __call__(self, x, *loss_args):
+        if self.graph is None:
+            self.static_args = tuple(a.detach().clone() if torch.is_tensor(a) else a for a in loss_args)
+            self.static_in.copy_(x)
+            dev = self.static_in.device
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):                   # warm-up steps are real optimizer steps
+                for _ in range(self.warmup):
+                    self._step()
+            torch.cuda.current_stream(dev).wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_loss = self._step()
+            return self.static_loss
+        self.static_in.copy_(x)
+        for dst, src in zip(self.static_args, loss_args):
+            if torch.is_tensor(dst):
+                dst.copy_(src)
+        self.graph.replay()
+        return self.static_loss
 
 
 class FlowInvSequential(nn.Module):
