@@ -203,26 +203,53 @@ __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict_
     }
 }
 
-// finishing kernel for the D-split form: sum partials, logsumexp.  one thread per (b, m)
+// finishing kernel for the D-split form: sum partials, logsumexp.  One thread per (b, component): the partial sums of
+// one sample are read as runs of MK consecutive floats; the K log-joints of a mixture meet in LDS.  A block holds
+// SPB = blockDim / MK whole samples (small batches are latency-bound: the one-thread-per-(b, m) form with its
+// 2 K nsplit strided loads per thread took longer than the main kernel).
 __global__ __launch_bounds__(256) void k_gmm_finish(const float* __restrict__ q, const float* __restrict__ cst,
                                                     float* __restrict__ out, int B, int M, int K, int nsplit,
                                                     int accumulate) {
+    __shared__ float l[256];
+    const int MK = M * K, spb = blockDim.x / MK;
+    const int sl = threadIdx.x / MK, mk = threadIdx.x - sl * MK;
+    const int b = blockIdx.x * spb + sl;
+    const bool live = b < B && sl < spb;
+    float s = 0.f;
+    if (live)
+        for (int z = 0; z < nsplit; ++z) s += q[((int64_t)z * B + b) * MK + mk];
+    l[threadIdx.x] = live ? cst[mk] - 0.5f * s : 0.f;
+    __syncthreads();
+    if (live && mk % K == 0) {
+        const float* lp = l + threadIdx.x;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[k]);
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += expf(lp[k] - mx);
+        const float r = mx + logf(sum);
+        const int64_t e = (int64_t)b * M + mk / K;
+        out[e] = accumulate ? out[e] + r : r;
+    }
+}
+
+// same for mixtures with more than 256 components in all: one thread per (b, m)
+__global__ __launch_bounds__(256) void k_gmm_finish_bm(const float* __restrict__ q, const float* __restrict__ cst,
+                                                       float* __restrict__ out, int B, int M, int K, int nsplit,
+                                                       int accumulate) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)B * M) return;
     const int b = (int)(e / M), m = (int)(e - (int64_t)b * M);
     const int MK = M * K;
+    float lj[16];
     float mx = -INFINITY;
     for (int k = 0; k < K; ++k) {
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += q[((int64_t)z * B + b) * MK + m * K + k];
-        mx = fmaxf(mx, cst[m * K + k] - 0.5f * s);
+        lj[k] = cst[m * K + k] - 0.5f * s;
+        mx = fmaxf(mx, lj[k]);
     }
     float sum = 0.f;
-    for (int k = 0; k < K; ++k) {
-        float s = 0.f;
-        for (int z = 0; z < nsplit; ++z) s += q[((int64_t)z * B + b) * MK + m * K + k];
-        sum += expf(cst[m * K + k] - 0.5f * s - mx);
-    }
+    for (int k = 0; k < K; ++k) sum += expf(lj[k] - mx);
     const float r = mx + logf(sum);
     out[e] = accumulate ? out[e] + r : r;
 }
@@ -309,7 +336,7 @@ int choose_nsplit(int B, int MK, int D) {
     const int mkb = MK <= 16 ? 16 : 80;
     const int64_t base = (int64_t)((B + TB - 1) / TB) * ((MK + mkb - 1) / mkb);
     int ns = 1;
-    while (base * ns < 512 && ns < 16 && D / (ns * 2) >= 4 * DC) ns *= 2;
+    while (base * ns < 512 && ns < 64 && D / (ns * 2) >= DC) ns *= 2;
     return ns;
 }
 
@@ -384,8 +411,13 @@ int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float*
     if (ns > 1) {
         if (small) { if (vec) CF_GO(1, true, true); else CF_GO(1, false, true); }
         else       { if (vec) CF_GO(5, true, true); else CF_GO(5, false, true); }
-        const int64_t n = (int64_t)B * M;
-        k_gmm_finish<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cf_s(stream)>>>(q, cst, out, B, M, K, ns, accumulate);
+        const int spb = 256 / MK;
+        if (spb >= 1) {
+            k_gmm_finish<<<dim3((unsigned)((B + spb - 1) / spb)), dim3(spb * MK), 0, cf_s(stream)>>>(q, cst, out, B, M, K, ns, accumulate);
+        } else {
+            const int64_t n = (int64_t)B * M;
+            k_gmm_finish_bm<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cf_s(stream)>>>(q, cst, out, B, M, K, ns, accumulate);
+        }
     } else {
         if (small) { if (vec) CF_GO(1, true, false); else CF_GO(1, false, false); }
         else       { if (vec) CF_GO(5, true, false); else CF_GO(5, false, false); }

@@ -74,6 +74,10 @@ SIGNATURES = {
     "cf_vit_flat_params": (_c_i64, [_c_int] * 3),
     "cf_vit_prepare": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_p]),
     "cf_vit_coupling": (_c_int, [_c_p] * 5 + [_c_int] * 8 + [_c_i64, _c_int, _c_p]),
+    "cf_vit_step_supported": (_c_int, [_c_int] * 8),
+    "cf_vit_step_ws_bytes": (_c_i64, [_c_int] * 2),
+    "cf_vit_step_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 2 + [_c_p]),
+    "cf_vit_step_fwd": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
     "cf_spline_table_floats": (_c_i64, [_c_int, _c_int]),
     "cf_spline_prepare": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_f, _c_p]),
     "cf_spline": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_p]),

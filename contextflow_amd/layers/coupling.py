@@ -245,6 +245,49 @@ class TransCoupling(_AffineCoupling):
             return False
         return bool(_hip.lib().cf_vit_supported(C, H, W, self.p_sz[0], self.p_sz[1], vit.dim, att.dim_head, att.heads))
 
+    def step_supported(self, shape):
+        """True when Conv1x1 -> ActNorm -> this layer can run as ONE kernel (cf_vit_step_fwd)."""
+        if not self.fused or self.context_net or tuple(shape) != self.in_sz:
+            return False
+        vit = self.NN[0]
+        att = vit.transformer.layers[0][0] if len(vit.transformer.layers) else None
+        if att is None:
+            return False
+        C, H, W = shape
+        return bool(_hip.lib().cf_vit_step_supported(C, H, W, self.p_sz[0], self.p_sz[1], vit.dim, att.dim_head, att.heads))
+
+    def step_sources(self):
+        """Parameters the packed step workspace derives from (cache key of FlowSequential)."""
+        return tuple(self.NN[0].parameters())
+
+    def step_prepare(self, Wm, t, logs, dev):
+        """Pack Conv1x1 / ActNorm / ViT parameters into the fragment order of the one-kernel step."""
+        vit = self.NN[0]
+        C, depth = self.in_sz[0], len(vit.transformer.layers)
+        ws = torch.empty(_hip.lib().cf_vit_step_ws_bytes(C, depth), device=dev, dtype=torch.uint8)
+        if vit.pos_embedding.device != dev:
+            vit.pos_embedding = vit.pos_embedding.to(dev).contiguous()
+        flat = self._flat_params()
+        _hip.call("cf_vit_step_prepare", _hip.p(_hip.f32(Wm.detach())), _hip.p(_hip.f32(t.detach())), _hip.p(_hip.f32(logs.detach())),
+                  _hip.p(flat), _hip.p(_hip.f32(vit.pos_embedding)), _hip.p(ws), C, depth, _hip.stream())
+        return ws
+
+    def step_forward(self, x, ws, ld1, h_out=None):
+        """z = TransCoupling(ActNorm(Conv1x1(x))) and ld1 += the step's log-det, one launch."""
+        x, xbs = _hip.bview(x)
+        B, C = x.shape[0], x.shape[1]
+        depth = len(self.NN[0].transformer.layers)
+        z = torch.empty(B, C, x.shape[2], x.shape[3], device=x.device, dtype=torch.float32)
+        events = VIT_EVENTS
+        if events is not None:               # bench.py: HIP events on the launch stream around exactly this kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(x.device))
+        _hip.call("cf_vit_step_fwd", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), _hip.p(h_out), B, C, depth, xbs, _hip.stream())
+        if events is not None:
+            e1.record(torch.cuda.current_stream(x.device))
+            events.append((e0, e1, B))
+        return z
+
     def _flat_params(self):
         vit = self.NN[0]
         tpe = vit.to_patch_embedding

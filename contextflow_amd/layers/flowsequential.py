@@ -22,7 +22,7 @@ from . import _hip
 from .actnorm import ActNorm
 from .augment import Augment
 from .conv1x1 import Conv1x1
-from .coupling import Coupling
+from .coupling import Coupling, TransCoupling
 from .dequantize import Dequantization
 from .distributions.gaussian import GaussianMixtureDistribution, StandardNormal, gmm_logprob
 from .distributions.uniform import UniformDistribution
@@ -151,6 +151,12 @@ class FlowSequential(nn.Module):
                 ops.append(("step", m, mods[i + 1], mods[i + 2], shape, False))
                 i += 3
                 continue
+            if (is3(shape) and i + 2 < n and isinstance(m, Conv1x1) and isinstance(mods[i + 1], ActNorm)
+                    and isinstance(mods[i + 2], TransCoupling) and m.D == shape[0] and mods[i + 1].D == shape[0]
+                    and not m.context_net and not mods[i + 1].context_net and mods[i + 2].step_supported(shape)):
+                ops.append(("vstep", m, mods[i + 1], mods[i + 2], shape))       # transformer-coupling step, one kernel
+                i += 3
+                continue
             if isinstance(m, Squeeze) and is3(shape):
                 sq = (shape[0] * m.p[0] * m.p[1], shape[1] // m.p[0], shape[2] // m.p[1])
                 if (tuple(m.p) == (2, 2) and shape[1] % 2 == 0 and shape[2] % 2 == 0 and i + 3 < n
@@ -230,6 +236,10 @@ class FlowSequential(nn.Module):
         for k, op in enumerate(plan):
             if op[0] == "step":
                 srcs = (op[1].NN, op[2].NN_t, op[2].NN_logs) + tuple(p for c in (op[3].NN[0], op[3].NN[2], op[3].NN[4]) for p in (c.weight, c.bias))
+            elif op[0] == "vstep":
+                if tape is not None:
+                    continue                 # training runs the three layers with their own backward kernels
+                srcs = (op[1].NN, op[2].NN_t, op[2].NN_logs) + op[3].step_sources()
             elif op[0] == "split":
                 srcs = (op[1].dist.mG, op[1].dist.sG, op[1].dist.wG)
             else:
@@ -255,6 +265,8 @@ class FlowSequential(nn.Module):
                             lad = torch.empty(1, device=dev, dtype=torch.float32)
                             _hip.call("cf_slogdet_inverse", _hip.p(_hip.f32(op[1].NN.detach())), Cc, _hip.p(lad), _hip.p(winv), _hip.stream())
                             buf = (buf, winv)
+                    elif op[0] == "vstep":
+                        buf = op[3].step_prepare(op[1].NN, op[2].NN_t, op[2].NN_logs, dev)
                     else:
                         buf = op[1].dist.prepared()
                     ev = torch.cuda.Event()
@@ -335,6 +347,17 @@ class FlowSequential(nn.Module):
                     e1.record(main)
                     events.append((e0, e1, B, C, H * W))
                 x = z
+            elif kind == "vstep":
+                if tape is not None:
+                    for m in op[1:4]:
+                        tape.append(("layer", m, x))
+                        x, ldj = m(x, context)
+                        ld1 += ldj
+                    continue
+                ws, ev = prepared[k]
+                if ev is not None:
+                    main.wait_event(ev)
+                x = op[3].step_forward(x, ws, ld1)
             elif kind == "squeeze":
                 if tape is not None:
                     tape.append(("squeeze", tuple(op[1].p)))

@@ -253,6 +253,19 @@ int cf_vit_prepare(const float* flat_params, void* ws, int patch_dim, int dim, i
 int cf_vit_coupling(const float* x, float* z, float* ldj, const void* ws, const float* pos, int B, int C, int H, int W,
                     int p1, int p2, int dim, int depth, int64_t x_bstride, int inverse, cf_stream_t stream);
 
+/* One transformer-coupling flow step (model.py:129-147 with --coupling trans: Conv1x1 -> ActNorm -> TransCoupling) as ONE
+ * kernel, activations register-resident between x and z (csrc/cf_vit_step.hip).  Geometry: C = 26 channels on 8 x 1
+ * windows, patch (2,1), dim = 2C, one head of 64 (SMAP; cf_vit_step_supported).  prepare: Wm (C,C), ActNorm t / logs (C),
+ * the ViT parameters flattened in the order of cf_vit_prepare, pos (4, dim); ws: cf_vit_step_ws_bytes(C, depth) bytes.
+ * fwd: z (B,C,8,1); ldj_acc[b] += 8 log|det Wm| + sum logs + sum log_s (conv1x1.py:53, actnorm.py:58, coupling.py:151);
+ * h_out (optional, may be NULL): the conditioner's output [t | raw], (B,C,8,1).                                         */
+int cf_vit_step_supported(int C, int H, int W, int p1, int p2, int dim, int dim_head, int heads);
+int64_t cf_vit_step_ws_bytes(int C, int depth);
+int cf_vit_step_prepare(const float* Wm, const float* t, const float* logs, const float* flat_vit_params, const float* pos,
+                        void* ws, int C, int depth, cf_stream_t stream);
+int cf_vit_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, float* h_out, int B, int C, int depth,
+                    int64_t x_bstride, cf_stream_t stream);
+
 /* ---- SplineActivation: monotone rational-quadratic spline, linear tails (layers/activations.py:120-211,
  * layers/splines/rational_quadratic.py:21-176) ----------------------------------------------------- */
 /* knot tables: P parameter sets (1 = shared weights, C*H*W = individual_weights) of K bins;

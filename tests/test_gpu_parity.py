@@ -184,6 +184,42 @@ def test_transcoupling(L, tag, fused):
     close(m.reverse(t["z"].to(DEV)), t["xrec"], tol=1e-4)
 
 
+@pytest.mark.parametrize("B", [3, 37])
+def test_vit_step_kernel(L, B):
+    """Conv1x1 -> ActNorm -> TransCoupling as ONE register-resident kernel (cf_vit_step_fwd, SMAP geometry): with an
+    identity Conv1x1 / ActNorm it must reproduce the reference's TransCoupling vectors (conditioner output h, z, log-det);
+    with random ones, the composition of the three oracle layers at a ragged batch (last wave partly filled)."""
+    from contextflow_amd.layers import _hip
+    t, sd = unit("trans_ts")
+    sz = tuple(int(v) for v in t["in_sz"]); patch = tuple(int(v) for v in t["p"])
+    C = sz[0]
+    m = L.TransCoupling(sz, patch)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    assert m.step_supported(sz)
+    # identity front: the layer alone against the reference's own output
+    x = t["x"].to(DEV)
+    ws = m.step_prepare(torch.eye(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.device(DEV))
+    ld = torch.zeros(x.shape[0], device=DEV)
+    h = torch.full_like(x, float("nan"))
+    z = m.step_forward(x, ws, ld, h_out=h)
+    close(h, t["h"], tol=2e-5); close(z, t["z"], tol=2e-5); close(ld, t["ldj"], tol=2e-5)
+    # random Conv1x1 / ActNorm in front, ragged batch, accumulation into a non-zero running log-det
+    g = torch.Generator().manual_seed(B)
+    Wm = torch.linalg.qr(torch.randn(C, C, generator=g))[0] + 0.1 * torch.randn(C, C, generator=g)
+    tt, logs = 0.3 * torch.randn(C, generator=g), 0.4 * torch.randn(C, generator=g)
+    xx = torch.randn(B, *sz, generator=g)
+    p = {"0." + k: v for k, v in sd.items()}
+    y, l0 = fo.conv1x1_fwd(xx, Wm)
+    y, l1 = fo.actnorm_fwd(y, tt, logs)
+    zref, l2 = fo.transcoupling_fwd(y, p, "0.", sz, patch)
+    ws = m.step_prepare(Wm.to(DEV), tt.to(DEV), logs.to(DEV), torch.device(DEV))
+    ld = torch.full((B,), 1.5, device=DEV)
+    z = m.step_forward(xx.to(DEV), ws, ld)
+    close(z, zref, tol=2e-5)
+    close(ld, 1.5 + l0 + l1 + l2, tol=2e-5)
+
+
 # ------------------------------------------------------------------------------------------ fused step kernel
 @pytest.mark.parametrize("squeeze", [False, True])
 @pytest.mark.parametrize("C,H,W,B", [(16, 16, 16, 3), (32, 8, 8, 5), (64, 4, 4, 11), (8, 16, 16, 2), (32, 8, 8, 8), (64, 4, 4, 16)])
