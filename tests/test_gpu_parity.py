@@ -377,7 +377,9 @@ def test_full_size_properties(L, name, B):
     sl = slice(B - 37, B - 4)
     set_noise(model, None if u is None else u[sl], [eps[0][sl]])
     _, lp_slice = model(x[sl].to(DEV))
-    assert (lp_slice - logp[sl]).abs().max().item() / D < 1e-6
+    # (the mixture kernels split the feature dimension over more workgroups for small batches: another summation order,
+    # a few ulp of |logp| ~ 6e3)
+    assert (lp_slice - logp[sl]).abs().max().item() / D < 3e-6
     _, ref = fo.flow_forward(ops, params, x[sl], None if u is None else u[sl], [eps[0][sl]])
     assert (bpd(lp_slice.cpu(), name) - bpd(ref, name)).abs().max() < BPD_TOL
     # (3) permutation equivariance
