@@ -7,10 +7,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-secondary $@"
 echo "== kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
 grep '"metric"' $OUT/trace.log | tail -1
-PARGS="--steps 1 --warmup 1 --no-cpu-baseline --global-batch 16384 $@"
+PARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-secondary --global-batch 16384 --chunk 16384 $@"
 i=0
 for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "FETCH_SIZE" "WRITE_SIZE" \

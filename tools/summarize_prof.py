@@ -53,7 +53,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     print("### %s\n" % os.path.basename(d))
     print("| kernel | launches | " + " | ".join(names) + " |")
     print("|---|---|" + "---|" * len(names))
-    keep = [k for k in acc if k.startswith(("k_flow_step", "k_gmm_logprob", "k_sample", "k_squeeze"))]
+    keep = [k for k in acc if k.startswith(("k_flow_step", "k_vit_step", "k_gmm_logprob", "k_gmm_finish", "k_preprocess", "k_sample", "k_squeeze"))]
     for k in sorted(keep):
         n = max(cnt[k].values())
         print("| `%s` | %d | " % (k, n) + " | ".join("%.4g" % (acc[k][c] / max(cnt[k][c], 1)) for c in names) + " |")
@@ -83,6 +83,10 @@ fetch, nf = pmc_avg("FETCH_SIZE")
 write, nw = pmc_avg("WRITE_SIZE")
 levels, tot_b, tot_n = {}, 0.0, 0
 for k in fetch:
+    if k.startswith("k_vit_step<") and k in write:
+        byt = (2.0 * fetch[k] + write[k]) * 1024.0
+        levels[k] = {"hbm_bytes_per_launch": round(byt), "algorithmic_bytes_per_launch": 16384 * 2 * 26 * 8 * 4, "launches": nf[k]}
+        tot_b += byt * nf[k]; tot_n += nf[k]
     if k.startswith("k_flow_step") and k in write:
         m = re.search(r"Geo<(\d+), (\d+), (\d+)", k)
         C, H, W = (int(v) for v in m.groups())
