@@ -587,7 +587,9 @@ def test_backward_against_autograd_oracle(L, name, B):
         got = p.grad.detach().cpu().double()
         scale = max(ref.abs().max().item(), 1e-3)
         err = (got - ref).abs().max().item() / scale
-        assert err < 2e-3, "%s: relative grad error %.3e (scale %.3e)" % (k, err, scale)
+        # measured (tools/dev/bwd_errors.py, profiles/r2_backward_errors.md): worst tensor 4.6e-5 (cifar10 split-prior
+        # means), every tensor below the error fp32 torch.autograd itself makes on the same graph (up to 1.8e-4)
+        assert err < 1e-4, "%s: relative grad error %.3e (scale %.3e)" % (k, err, scale)
         checked += 1
     assert checked >= 30
 
@@ -1091,7 +1093,7 @@ def test_specialist_backward_against_autograd_oracle(L, fxname):
         got = p.grad.detach().cpu().double()
         scale = max(ref.abs().max().item(), 1e-3)
         err = (got - ref).abs().max().item() / scale
-        assert err < 2e-3, "%s: relative grad error %.3e (scale %.3e)" % (k, err, scale)
+        assert err < 2e-4, "%s: relative grad error %.3e (scale %.3e)" % (k, err, scale)
         checked += 1
     assert checked >= 20
 
