@@ -287,12 +287,15 @@ __global__ __launch_bounds__(256) void k_gmm_resp_finish(const float* __restrict
 // ---- elementwise pieces of the mixture backward (autograd.py gmm_backward), one launch each instead of a chain of
 // parameter-sized torch kernels ------------------------------------------------------------------------------------
 // A2 = a a, AB = a bm: right-hand sides of the two (B x MK) x (MK x D) products of d/dx
+// TR: outputs transposed, (D, MK) - the Wt operand of cf_linear for G = r A  (coalesced writes, strided L2-resident reads)
+template <bool TR>
 __global__ __launch_bounds__(256) void k_gmm_bwd_coeffs(const float* __restrict__ a, const float* __restrict__ bm,
-                                                        float* __restrict__ A2, float* __restrict__ AB, int64_t n) {
+                                                        float* __restrict__ A2, float* __restrict__ AB, int64_t n, int MK, int D) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        const float av = a[e];
+        const int64_t src = TR ? (e % MK) * D + e / MK : e;
+        const float av = a[src];
         A2[e] = av * av;
-        AB[e] = av * bm[e];
+        AB[e] = av * bm[src];
     }
 }
 // gx[b, d] = -(x[b, d] G1[b, d] + G2[b, d]),  G1 = r A2, G2 = r AB
@@ -461,10 +464,12 @@ int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cs
 
 static unsigned gmm_ew_blocks(int64_t n) { const int64_t b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b > 0 ? b : 1)); }
 
-int cf_gmm_bwd_coeffs(const float* a, const float* bm, float* A2, float* AB, int MK, int D, cf_stream_t stream) {
+int cf_gmm_bwd_coeffs(const float* a, const float* bm, float* A2, float* AB, int MK, int D, int transposed,
+                      cf_stream_t stream) {
     CF_REQUIRE(a && bm && A2 && AB && MK > 0 && D > 0);
     const int64_t n = (int64_t)MK * D;
-    k_gmm_bwd_coeffs<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, A2, AB, n);
+    if (transposed) k_gmm_bwd_coeffs<true><<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, A2, AB, n, MK, D);
+    else k_gmm_bwd_coeffs<false><<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, A2, AB, n, MK, D);
     CF_LAUNCH_CHECK();
     return 0;
 }

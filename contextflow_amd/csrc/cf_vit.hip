@@ -125,9 +125,12 @@ constexpr int WG_LS = WG_MAXF * 32;   // LDS row stride (floats): 48 KiB per wor
 
 // TPW = tiles per wave of this launch (1..WG_TPW): slots past the last tile recompute tile 0 and are not stored - a
 // branch around an MFMA would put a full LDS wait in front of every one of them.
-template <int TPW>
+// ldx / ldy: row strides of x / gy (a launch may cover a column block of wider matrices); XSQ: the B operand is x^2
+// (second-moment sums of the mixture backward).
+template <int TPW, bool XSQ = false>
 __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
-                                                      float* __restrict__ part, int rows, int K, int N, int NT, int KT, int ybase) {
+                                                      float* __restrict__ part, int rows, int K, int N, int NT, int KT, int ybase,
+                                                      int64_t ldx, int64_t ldy) {
     // one LDS row = the 32-feature blocks [gy (NT) | x, 1, 0.. (KT)] of one activation row at the FIXED stride WG_LS: the
     // operand reads of the MFMA loop are then base register + immediate offset (no address arithmetic between MFMAs)
     __shared__ float lds[WG_RC * WG_LS];
@@ -165,8 +168,9 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
             for (int cb = 0; cb < WG_MAXF; ++cb) {
                 const bool isg = cb < NT;                                         // uniform
                 const int col = cb * 32 + c32 - (isg ? 0 : NS);                   // n, or k
-                const float* src = isg ? gy + rc * N + min(col, N - 1) : x + rc * K + min(col, K - 1);
+                const float* src = isg ? gy + rc * ldy + min(col, N - 1) : x + rc * ldx + min(col, K - 1);
                 stg[i][cb] = *src;
+                if (XSQ && !isg) stg[i][cb] *= stg[i][cb];
             }
         }
 #pragma unroll
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
 // 64 output elements per workgroup, the G partials split over the 4 waves (every 4th partial each), then summed across
 // the waves in a fixed order
 __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gW,
-                                                             float* __restrict__ gb, int K, int N, int KT, int ntiles, int G) {
+                                                             float* __restrict__ gb, int K, int N, int KT, int ntiles, int G,
+                                                             int64_t ldw) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;                 // element of the padded tile storage
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __rest
         const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
         const int t = e >> 10, n = (t / KT) * 32 + ((e >> 5) & 31), k = (t % KT) * 32 + (e & 31);
         if (n < N) {
-            if (k < K) gW[(int64_t)n * K + k] = v;
+            if (k < K) gW[(int64_t)n * ldw + k] = v;
             else if (k == K && gb) gb[n] = v;
         }
     }
@@ -430,38 +435,71 @@ static int linear_wgrad_groups(int rows) {
     return chunks < 512 ? (chunks > 0 ? chunks : 1) : 512;      // two workgroups per CU
 }
 
+// Column blocking of wide problems: the LDS stage holds WG_MAXF 32-feature blocks of [gy | x, 1]; gy goes in blocks of at
+// most 4 (128 output rows), x in blocks of what is left.
+static void wgrad_blocks(int K, int N, int& nbs, int& kbs) {
+    nbs = N < 128 ? N : 128;
+    const int NTc = (nbs + 31) / 32;
+    kbs = (WG_MAXF - NTc) * 32 - 1;
+    if (kbs > K) kbs = K;
+}
+
 int64_t cf_linear_wgrad_ws_bytes(int rows, int K, int N) {
-    const int NT = (N + 31) / 32, KT = (K + 1 + 31) / 32;
+    int nbs, kbs;
+    wgrad_blocks(K, N, nbs, kbs);
+    const int NT = (nbs + 31) / 32, KT = (kbs + 1 + 31) / 32;
     return (int64_t)linear_wgrad_groups(rows) * NT * KT * 1024 * sizeof(float);
+}
+
+static int linear_wgrad_any(const float* x, const float* gy, float* gW, float* gb, void* ws, int rows, int K, int N,
+                            cf_stream_t stream, bool xsq) {
+    CF_REQUIRE(x && gy && gW && ws && rows >= 0 && K > 0 && N > 0);
+    int nbs, kbs;
+    wgrad_blocks(K, N, nbs, kbs);
+    const int G = linear_wgrad_groups(rows);
+    float* part = (float*)ws;
+    hipStream_t st = cf_s(stream);
+    for (int n0 = 0; n0 < N; n0 += nbs)
+        for (int k0 = 0; k0 < K; k0 += kbs) {
+            const int Nc = N - n0 < nbs ? N - n0 : nbs, Kc = K - k0 < kbs ? K - k0 : kbs;
+            const int NT = (Nc + 31) / 32, KT = (Kc + 1 + 31) / 32, ntiles = NT * KT;
+            const float* xp = x + k0;
+            const float* gp = gy + n0;
+            // full blocks of 4 WG_TPW tiles, then the remainder with exactly as many tile slots per wave as it needs
+            const int full = ntiles / (4 * WG_TPW), rem = ntiles - full * 4 * WG_TPW;
+            if (full > 0) {
+                if (xsq) k_linear_wgrad<WG_TPW, true><<<dim3(G, full), dim3(256), 0, st>>>(xp, gp, part, rows, Kc, Nc, NT, KT, 0, K, N);
+                else k_linear_wgrad<WG_TPW, false><<<dim3(G, full), dim3(256), 0, st>>>(xp, gp, part, rows, Kc, Nc, NT, KT, 0, K, N);
+            }
+#define CF_WG_TAIL(T) do { if (xsq) k_linear_wgrad<T, true><<<dim3(G), dim3(256), 0, st>>>(xp, gp, part, rows, Kc, Nc, NT, KT, full, K, N); \
+                           else k_linear_wgrad<T, false><<<dim3(G), dim3(256), 0, st>>>(xp, gp, part, rows, Kc, Nc, NT, KT, full, K, N); } while (0)
+            switch ((rem + 3) / 4) {
+                case 0: break;
+                case 1: CF_WG_TAIL(1); break;
+                case 2: CF_WG_TAIL(2); break;
+                case 3: CF_WG_TAIL(3); break;
+                case 4: CF_WG_TAIL(4); break;
+                case 5: CF_WG_TAIL(5); break;
+                case 6: CF_WG_TAIL(6); break;
+                case 7: CF_WG_TAIL(7); break;
+                default: CF_WG_TAIL(8); break;
+            }
+#undef CF_WG_TAIL
+            // the bias gradient (column sums of gy) rides along with the first x block only
+            k_linear_wgrad_reduce<<<dim3(ntiles * 16), dim3(256), 0, st>>>(part, gW + (int64_t)n0 * K + k0, (gb && k0 == 0) ? gb + n0 : nullptr,
+                                                                         Kc, Nc, KT, ntiles, G, K);
+        }
+    CF_LAUNCH_CHECK();
+    return 0;
 }
 
 int cf_linear_wgrad(const float* x, const float* gy, float* gW, float* gb, void* ws, int rows, int K, int N,
                     cf_stream_t stream) {
-    CF_REQUIRE(x && gy && gW && ws && rows >= 0 && K > 0 && N > 0);
-    const int NT = (N + 31) / 32, KT = (K + 1 + 31) / 32, ntiles = NT * KT;
-    if (NT + KT > WG_MAXF) { cf_set_error("cf_linear_wgrad: K=%d + N=%d wider than %d features", K, N, 32 * WG_MAXF - 1); return CF_ERR_UNSUPPORTED; }
-    const int G = linear_wgrad_groups(rows);
-    float* part = (float*)ws;
-    // full blocks of 4 WG_TPW tiles, then the remainder with exactly as many tile slots per wave as it needs
-    const int full = ntiles / (4 * WG_TPW), rem = ntiles - full * 4 * WG_TPW;
-    hipStream_t st = cf_s(stream);
-    if (full > 0) k_linear_wgrad<WG_TPW><<<dim3(G, full), dim3(256), 0, st>>>(x, gy, part, rows, K, N, NT, KT, 0);
-#define CF_WG_TAIL(T) k_linear_wgrad<T><<<dim3(G), dim3(256), 0, st>>>(x, gy, part, rows, K, N, NT, KT, full)
-    switch ((rem + 3) / 4) {
-        case 0: break;
-        case 1: CF_WG_TAIL(1); break;
-        case 2: CF_WG_TAIL(2); break;
-        case 3: CF_WG_TAIL(3); break;
-        case 4: CF_WG_TAIL(4); break;
-        case 5: CF_WG_TAIL(5); break;
-        case 6: CF_WG_TAIL(6); break;
-        case 7: CF_WG_TAIL(7); break;
-        default: CF_WG_TAIL(8); break;
-    }
-#undef CF_WG_TAIL
-    k_linear_wgrad_reduce<<<dim3(ntiles * 16), dim3(256), 0, cf_s(stream)>>>(part, gW, gb, K, N, KT, ntiles, G);
-    CF_LAUNCH_CHECK();
-    return 0;
+    return linear_wgrad_any(x, gy, gW, gb, ws, rows, K, N, stream, false);
+}
+
+int cf_linear_wgrad_x2(const float* x, const float* gy, float* gW, void* ws, int rows, int K, int N, cf_stream_t stream) {
+    return linear_wgrad_any(x, gy, gW, nullptr, ws, rows, K, N, stream, true);
 }
 
 int cf_layernorm(const float* x, const float* w, const float* b, const float* pos, float* y, int rows, int dim,

@@ -49,7 +49,7 @@ SIGNATURES = {
     "cf_flow_step_inv_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_inv_prepare": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_p]),
     "cf_flow_step_inv": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_p]),
-    "cf_gmm_bwd_coeffs": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_p]),
+    "cf_gmm_bwd_coeffs": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_int, _c_p]),
     "cf_gmm_bwd_gx": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_i64, _c_p]),
     "cf_gmm_bwd_params": (_c_int, [_c_p] * 8 + [_c_int, _c_int, _c_p]),
     "cf_gmm_resp_ws_bytes": (_c_i64, [_c_int] * 4),
@@ -65,6 +65,7 @@ SIGNATURES = {
     "cf_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
     "cf_linear_wgrad_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_linear_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_p]),
+    "cf_linear_wgrad_x2": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_p]),
     "cf_linear": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),
     "cf_layernorm": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_f, _c_p]),
     "cf_attention": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),

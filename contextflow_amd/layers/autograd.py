@@ -6,8 +6,9 @@ Backward walks the tape in reverse:
   * flow step  : ONE kernel (cf_flow_step_bwd) recomputes the step in LDS and runs the data-gradient chain on the
                  fp32 matrix cores; it also writes the operand planes of the weight gradients, which are split-K
                  MFMA GEMMs over (batch x pixels) with the 3x3 tap shifts (cf_wgrad);
-  * GMM priors : component responsibilities from the HIP quadratic-form kernel (cf_gmm_quad), the remaining
-                 contractions are (B x 80) x (80 x D) library GEMMs + small elementwise terms;
+  * GMM priors : component responsibilities from the HIP quadratic-form kernel (cf_gmm_resp), the remaining
+                 contractions ((B x 80)(80 x D) and (80 x B)(B x D)) on cf_linear / cf_linear_wgrad (fp32 MFMA) + small
+                 elementwise kernels;
   * Squeeze / SplitPrior / Augment : index maps (squeeze kernel with `inverse`, concatenation).
 Reference quirks carried into the gradients: ActNorm's ldj = +sum(logs) (d/dlogs gets sum_b g_ld), Conv1x1's
 ldj = H*W*log|det W| (d/dW gets sum_b g_ld * H*W * W^-T).  Layers that run layer by layer in the plan (TransCoupling + its ViT,
@@ -32,17 +33,22 @@ def gmm_backward(x, dist, prepared, g):
     dev, st, pp = xv.device, _hip.stream(), _hip.p
     MK = M * K
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-    # d/dx = -sum_mk r a (x a + bm) = -(x (r A2) + r AB): two library GEMMs (B x MK)(MK x D) and one combining kernel
-    A2, AB = new(MK, D), new(MK, D)
-    _hip.call("cf_gmm_bwd_coeffs", pp(a), pp(bm), pp(A2), pp(AB), MK, D, st)
+    # d/dx = -sum_mk r a (x a + bm) = -(x (r A2) + r AB): two (B x MK)(MK x D) products on cf_linear (fp32 MFMA; the
+    # coefficient kernel writes A2 / AB transposed, as cf_linear's weight operand) and one combining kernel
+    A2t, ABt = new(D, MK), new(D, MK)
+    _hip.call("cf_gmm_bwd_coeffs", pp(a), pp(bm), pp(A2t), pp(ABt), MK, D, 1, st)
+    G1, G2 = new(B, D), new(B, D)
+    _hip.call("cf_linear", pp(r), pp(A2t), None, None, pp(G1), B, MK, D, 0, st)
+    _hip.call("cf_linear", pp(r), pp(ABt), None, None, pp(G2), B, MK, D, 0, st)
     gx = new(B, D)
-    _hip.call("cf_gmm_bwd_gx", pp(xv), pp(r @ A2), pp(r @ AB), pp(gx), B, D, xbs, st)
-    # parameter sums over the batch: plain GEMMs (MK x B) x (B x D), then one kernel for the chain to mG / sG
+    _hip.call("cf_gmm_bwd_gx", pp(xv), pp(G1), pp(G2), pp(gx), B, D, xbs, st)
+    # parameter sums over the batch: S1 = r^T x, S2 = r^T x^2 (MK x D) and S0 = column sums of r, as split-K MFMA GEMMs
+    # over the samples (cf_linear_wgrad: the bias-gradient column gives S0; x is squared while it is staged for S2)
     xf = xv.reshape(B, -1) if xv.is_contiguous() else xv.contiguous().reshape(B, -1)
-    rt_ = r.t()
-    S0 = r.sum(0)
-    S1 = rt_ @ xf
-    S2 = rt_ @ (xf * xf)
+    S0, S1, S2 = new(MK), new(MK, D), new(MK, D)
+    wsw = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(B, D, MK), device=dev, dtype=torch.uint8)
+    _hip.call("cf_linear_wgrad", pp(xf), pp(r), pp(S1), pp(S0), pp(wsw), B, D, MK, st)
+    _hip.call("cf_linear_wgrad_x2", pp(xf), pp(r), pp(S2), pp(wsw), B, D, MK, st)
     g_mu, g_sigma = new(MK, D), new(MK, D)
     sG = _hip.f32(dist.sG.detach()).reshape(MK, D)
     _hip.call("cf_gmm_bwd_params", pp(a), pp(bm), pp(sG), pp(S0), pp(S1), pp(S2), pp(g_mu), pp(g_sigma), MK, D, st)

@@ -60,12 +60,9 @@ def _dense_bwd(x_in, W2d, gy, need_gx=True):
     N, K = W2d.shape
     rows = x_in.shape[0]
     gy, x_in, st = gy.contiguous(), x_in.contiguous(), _hip.stream()
-    if (N + 31) // 32 + (K + 32) // 32 > 12:                  # wider than cf_linear_wgrad's LDS stage: library GEMM
-        gW, gb = gy.t() @ x_in, gy.sum(0)
-    else:
-        gW, gb = _new(N, K, like=gy), _new(N, like=gy)
-        ws = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, K, N), device=gy.device, dtype=torch.uint8)
-        _hip.call("cf_linear_wgrad", _hip.p(x_in), _hip.p(gy), _hip.p(gW), _hip.p(gb), _hip.p(ws), rows, K, N, st)
+    gW, gb = _new(N, K, like=gy), _new(N, like=gy)
+    ws = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, K, N), device=gy.device, dtype=torch.uint8)
+    _hip.call("cf_linear_wgrad", _hip.p(x_in), _hip.p(gy), _hip.p(gW), _hip.p(gb), _hip.p(ws), rows, K, N, st)
     gx = None
     if need_gx:
         gx = _new(rows, K, like=gy)
@@ -179,9 +176,10 @@ def _embedding_grads(emb, context, gc, grads):
 
 
 def _linear_bwd(x_in, lin, gy, grads):
-    grads[lin.weight] = gy.t() @ x_in
-    grads[lin.bias] = gy.sum(0)
-    return gy @ _hip.f32(lin.weight.detach())
+    """nn.Linear of a CN net: weight / bias gradients and the data gradient through cf_linear_wgrad / cf_linear."""
+    gx, gW, gb = _dense_bwd(_hip.f32(x_in), _hip.f32(lin.weight.detach()), _hip.f32(gy))
+    grads[lin.weight], grads[lin.bias] = gW, gb
+    return gx
 
 
 def _relu_bwd(act, gy):
@@ -277,11 +275,14 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
     s1 = _new(B, HID, like=x)
     _hip.call("cf_sample_channel_sums", pp(s_gh1), pp(s1), B, HID, HW, st)
     wc = w1[:, D:, 0, 0]                                                  # (HID, O)
-    grads[c1.weight] = torch.cat([gw1[0], s1.t() @ rec["cn"]], dim=1).reshape(c1.weight.shape)
+    _, gwc, _ = _dense_bwd(_hip.f32(rec["cn"]), wc.contiguous(), s1, need_gx=False)      # (HID, O) = s1^T CN(c)
+    grads[c1.weight] = torch.cat([gw1[0], gwc], dim=1).reshape(c1.weight.shape)
     grads[c1.bias] = gb1
     grads[c2.weight], grads[c2.bias] = gw2.permute(1, 2, 0).reshape(c2.weight.shape), gb2
     grads[c3.weight], grads[c3.bias] = gw3[0].reshape(c3.weight.shape), gb3
-    _cn_chain_backward(m, rec, context, s1 @ wc, grads, f(gld) * float(HW))
+    gcn = _new(B, wc.shape[1], like=x)
+    _hip.call("cf_linear", pp(s1), pp(wc.t().contiguous()), None, None, pp(gcn), B, HID, wc.shape[1], 0, st)   # s1 wc
+    _cn_chain_backward(m, rec, context, gcn, grads, f(gld) * float(HW))
     return gx
 
 

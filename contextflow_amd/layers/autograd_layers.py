@@ -26,11 +26,7 @@ def _linear_bwd(x_in, lin, gy, grads, need_gx=True):
     rows = x_in.shape[0]
     gy = gy.contiguous()
     st = _hip.stream()
-    if grads is not None and (N + 31) // 32 + (K + 32) // 32 > 12:     # wider than cf_linear_wgrad's LDS stage: library GEMM
-        grads[lin.weight] = gy.t() @ x_in
-        if lin.bias is not None:
-            grads[lin.bias] = gy.sum(0)
-    elif grads is not None:
+    if grads is not None:
         x_in = x_in.contiguous()
         gW = _new(N, K, like=gy)
         gb = _new(N, like=gy) if lin.bias is not None else None
@@ -161,9 +157,15 @@ def conv1x1_backward(m, x_in, gz, gld):
     lad = _new(1, like=gzc)
     winv = _new(C, C, like=gzc)
     _hip.call("cf_slogdet_inverse", _hip.p(Wm), C, _hip.p(lad), _hip.p(winv), _hip.stream())
-    xs = x.permute(1, 0, 2, 3).reshape(C, -1)
-    gs = gzc.permute(1, 0, 2, 3).reshape(C, -1)
-    gW = gs @ xs.t() + (gld.sum() * (H * W)) * winv.t()
+    # gW[o][i] = sum over (b, pixel) of gz[b,o,p] x[b,i,p]: the split-K MFMA GEMM over rows = (sample, pixel) (cf_linear_wgrad)
+    # on channel-last copies (index ops)
+    rows = B * H * W
+    xs = x.permute(0, 2, 3, 1).reshape(rows, C).contiguous()
+    gs = gzc.permute(0, 2, 3, 1).reshape(rows, C).contiguous()
+    gW = _new(C, C, like=gzc)
+    ws = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, C, C), device=gzc.device, dtype=torch.uint8)
+    _hip.call("cf_linear_wgrad", _hip.p(xs), _hip.p(gs), _hip.p(gW), None, _hip.p(ws), rows, C, C, _hip.stream())
+    gW = gW + (gld.sum() * (H * W)) * winv.t()
     return gx, {m.NN: gW}
 
 

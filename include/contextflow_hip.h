@@ -125,7 +125,8 @@ int cf_gmm_quad(const float* x, const float* a, const float* bm, float* q, int B
 /* elementwise pieces of the mixture backward: A2 = a a, AB = a bm (M*K, D);  gx = -(x G1 + G2) with G1 = r A2, G2 = r AB
  * (B, D);  g_mu / g_sG (M*K, D) from the batch sums S0 = sum_b r (M*K), S1 = r^T x, S2 = r^T x^2 (M*K, D):
  * g_mu = a (a S1 + bm S0), g_sG = a (a^2 S2 + 2 a bm S1 + bm^2 S0 - S0) sigmoid(sG).                              */
-int cf_gmm_bwd_coeffs(const float* a, const float* bm, float* A2, float* AB, int MK, int D, cf_stream_t stream);
+int cf_gmm_bwd_coeffs(const float* a, const float* bm, float* A2, float* AB, int MK, int D, int transposed,
+                      cf_stream_t stream);      /* transposed != 0: A2, AB are written as (D, M*K): the Wt operand of cf_linear */
 int cf_gmm_bwd_gx(const float* x, const float* G1, const float* G2, float* gx, int B, int D, int64_t x_bstride,
                   cf_stream_t stream);
 int cf_gmm_bwd_params(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
@@ -221,11 +222,13 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
 int cf_linear(const float* x, const float* Wt, const float* bias, const float* res, float* y,
               int rows, int K, int N, int act, cf_stream_t stream);
 /* backward of cf_linear w.r.t. its parameters: gW (N,K) = gy^T x, gb (N) = column sums of gy (gb may be NULL); split-K
- * fp32-MFMA GEMM over the rows, partials in ws (cf_linear_wgrad_ws_bytes) summed in a fixed order.
- * ceil(N/32) + ceil((K+1)/32) <= 12 (the ViT widths of every preset); wider: CF_ERR_UNSUPPORTED.                */
+ * fp32-MFMA GEMM over the rows, partials in ws (cf_linear_wgrad_ws_bytes) summed in a fixed order.  Any K, N (wide
+ * problems run as column blocks of at most 128 outputs x 255 inputs).  cf_linear_wgrad_x2: the same with x squared
+ * element by element while it is staged (gW = gy^T x^2: second-moment sums of the mixture backward).                */
 int64_t cf_linear_wgrad_ws_bytes(int rows, int K, int N);
 int cf_linear_wgrad(const float* x, const float* gy, float* gW, float* gb, void* ws, int rows, int K, int N,
                     cf_stream_t stream);
+int cf_linear_wgrad_x2(const float* x, const float* gy, float* gW, void* ws, int rows, int K, int N, cf_stream_t stream);
 /* y[r,:] = LayerNorm(x[r,:])*w + b (+ pos[r % ntok,:] if pos != NULL); biased variance, eps.          */
 int cf_layernorm(const float* x, const float* w, const float* b, const float* pos, float* y,
                  int rows, int dim, int ntok, float eps, cf_stream_t stream);

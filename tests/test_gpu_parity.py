@@ -430,7 +430,6 @@ def test_abi_errors(L):
     assert lib.cf_attention(N, N, 0, 4, 64, 0.125, N) == 0
     # shapes outside a kernel's range are refused with a message, not launched
     assert lib.cf_slogdet_inverse(ctypes.c_void_p(16), 193, ctypes.c_void_p(16), N, N) == -2 and b"193" in lib.cf_last_error()
-    assert lib.cf_linear_wgrad(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), N, ctypes.c_void_p(16), 8, 300, 300, N) == -2
 
 
 @pytest.mark.parametrize("tag,indiv", [("spline_shared", False), ("spline_indiv", True)])
@@ -945,7 +944,10 @@ def test_layer_backward_kernels_against_torch(L):
         _hip.call("cf_linear", P(xl), P(wl), P(bl), P(rl) if use_res else None, _hip.p(yl), rows, K, N, act, st())
         assert (yl.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item()), (rows, K, N, act)
     # weight / bias gradient of a Linear: split-K over the rows (ragged last chunk, > 256 chunks, several tile blocks)
-    for rows, K, N in ((300, 152, 152), (36 * 300 + 5, 152, 192), (129, 7, 200), (64, 33, 5), (2000, 150, 200), (5, 64, 64)):
+    # wide problems run as column blocks (<= 128 outputs x <= 255 inputs): the mixture backward's (80 x B)(B x 1024) sums,
+    # 300 x 300, more than 128 outputs with more than 255 inputs
+    for rows, K, N in ((300, 152, 152), (36 * 300 + 5, 152, 192), (129, 7, 200), (64, 33, 5), (2000, 150, 200), (5, 64, 64),
+                       (700, 1024, 80), (8, 300, 300), (333, 513, 130)):
         xl = torch.randn(rows, K, generator=g); gl = torch.randn(rows, N, generator=g)
         gW, gb = torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV)
         wsb = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(rows, K, N), device=DEV, dtype=torch.uint8)
@@ -953,6 +955,11 @@ def test_layer_backward_kernels_against_torch(L):
         rW, rb = gl.double().t() @ xl.double(), gl.double().sum(0)
         assert (gW.cpu().double() - rW).abs().max() < 2e-5 * max(1.0, rW.abs().max().item()), (rows, K, N)
         assert (gb.cpu().double() - rb).abs().max() < 2e-5 * max(1.0, rb.abs().max().item()), (rows, K, N)
+        if K >= 300:                                      # x squared while staged (second-moment sums)
+            g2 = torch.full((N, K), float("nan"), device=DEV)
+            _hip.call("cf_linear_wgrad_x2", P(xl), P(gl), _hip.p(g2), _hip.p(wsb), rows, K, N, st())
+            r2 = gl.double().t() @ (xl.double() ** 2)
+            assert (g2.cpu().double() - r2).abs().max() < 2e-5 * max(1.0, r2.abs().max().item()), (rows, K, N)
     # GELU
     xg = torch.randn(1000, generator=g) * 2; gg = torch.randn(1000, generator=g)
     x64 = xg.double().requires_grad_(True)

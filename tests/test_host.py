@@ -303,3 +303,16 @@ def test_calls_run_on_the_device_that_owns_the_tensors(built, monkeypatch):
         _hip.require_device(cpu)
     with pytest.raises(RuntimeError, match="different devices"):
         _hip.require_device(cuda, types.SimpleNamespace(is_cuda=True, device=torch.device("cuda", 0)))
+
+
+def test_no_library_gemm_in_the_product():
+    """Every contraction of the product path is a hand-written kernel reached through the C ABI: no torch matmul."""
+    import glob
+    pat = re.compile(r"(\s@\s|torch\.(matmul|mm|bmm|einsum|addmm|baddbmm)\b|F\.linear\b|\.matmul\()")
+    offenders = []
+    for f in glob.glob(os.path.join(ROOT, "contextflow_amd", "**", "*.py"), recursive=True):
+        for i, line in enumerate(open(f), 1):
+            code = line.split("#", 1)[0]
+            if pat.search(code):
+                offenders.append("%s:%d: %s" % (os.path.relpath(f, ROOT), i, line.strip()))
+    assert not offenders, "\n".join(offenders)
