@@ -37,6 +37,8 @@ SIGNATURES = {
     "cf_actnorm_from_sums": (_c_int, [_c_p, _c_p, ctypes.c_double, _c_p, _c_p, _c_int, _c_p]),
     "cf_actnorm": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "cf_conv2d_reflect": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_i64, _c_p]),
+    "cf_conv2d_zero": (_c_int, [_c_p, _c_p, _c_p, _c_p] + [_c_int] * 10 + [_c_i64, _c_p]),
+    "cf_reflect_pad_adjoint": (_c_int, [_c_p, _c_p] + [_c_int] * 5 + [_c_p]),
     "cf_coupling_apply": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_p]),
     "cf_gmm_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_p]),
     "cf_gmm_ws_bytes": (_c_i64, [_c_int] * 4),

@@ -5,9 +5,10 @@ masked residual block of three convolutions (autoregressive over channels at the
     h = conv3(relu(conv2(relu(conv1(relu(x)))))) + [x ; x]        t = h[:, :D],  log_s = 2 tanh(h[:, D:] / 2)
     z = x exp(log_s) + t,   ldj = sum log_s
 
-As in the reference the masks multiply the weights IN PLACE on every forward, `reverse` is not implemented (upstream
-returns zeros), and there is no hand-written backward (evaluation only).  Context-conditioned variants are not built.
-The convolutions run in the generic reflect-padded HIP kernel (cf_conv2d_reflect)."""
+As in the reference the masks multiply the weights IN PLACE on every forward and `reverse` is not implemented (upstream
+returns zeros).  Training: autograd_layers.masked_coupling_backward (the plain convolution gradients, as torch.autograd
+gives them in the reference for in-place masked weights).  Context-conditioned variants are not built.
+The convolutions run in the generic implicit-GEMM conv kernel (cf_conv2d_reflect, fp32 MFMA)."""
 import torch
 import torch.nn as nn
 

@@ -145,6 +145,104 @@ def transcoupling_backward(m, x_in, gz, gld):
     return gx, grads
 
 
+def _relu_mask(act, gy):
+    out = torch.empty_like(gy)
+    _hip.call("cf_relu_bwd", _hip.p(act), _hip.p(gy), _hip.p(out), gy.numel(), _hip.stream())
+    return out
+
+
+def conv_backward(x_in, conv, gy, grads, need_gx=True):
+    """k x k stride-1 convolution with reflect padding (cf_conv2d_reflect; nn.Conv2d of coupling.py:26-29 / the masked
+    convolutions of ar.py).  x_in (B, Cin, H, W), gy (B, Cout, H, W) -> gx; grads[weight], grads[bias].
+      * data gradient: zero-padded convolution of gy with the spatially flipped, channel-transposed weights on the MFMA
+        conv kernel (cf_conv2d_zero, padding k - 1), then the adjoint of the reflect padding folds the border ring back;
+      * weight / bias gradient: gW (Cout, Cin kh kw) = gy_rows^T cols, the split-K MFMA GEMM over the (sample, pixel)
+        rows (cf_linear_wgrad) of the unfolded, reflect-padded input (index ops)."""
+    x = _hip.f32(x_in).contiguous()
+    gy = _hip.f32(gy).contiguous()
+    B, Cin, H, W = x.shape
+    w = _hip.f32(conv.weight.detach())
+    Cout, _, kh, kw = w.shape
+    ph, pw = conv.padding if isinstance(conv.padding, tuple) else (conv.padding, conv.padding)
+    st = _hip.stream()
+    if grads is not None:
+        xp = torch.nn.functional.pad(x, (pw, pw, ph, ph), mode="reflect") if (ph or pw) else x
+        cols = xp.unfold(2, kh, 1).unfold(3, kw, 1).permute(0, 2, 3, 1, 4, 5).reshape(B * H * W, Cin * kh * kw).contiguous()
+        rows_g = gy.permute(0, 2, 3, 1).reshape(B * H * W, Cout).contiguous()
+        K = Cin * kh * kw
+        gW = _new(Cout, K, like=gy)
+        gb = _new(Cout, like=gy) if conv.bias is not None else None
+        ws = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(B * H * W, K, Cout), device=gy.device, dtype=torch.uint8)
+        _hip.call("cf_linear_wgrad", _hip.p(cols), _hip.p(rows_g), _hip.p(gW), _hip.p(gb), _hip.p(ws), B * H * W, K, Cout, st)
+        grads[conv.weight] = gW.view(Cout, Cin, kh, kw)
+        if gb is not None:
+            grads[conv.bias] = gb
+    if not need_gx:
+        return None
+    wt = w.flip(2, 3).transpose(0, 1).contiguous()                     # (Cin, Cout, kh, kw)
+    gpad = _new(B, Cin, H + 2 * ph, W + 2 * pw, like=gy)
+    _hip.call("cf_conv2d_zero", _hip.p(gy), _hip.p(wt), None, _hip.p(gpad), B, Cout, Cin, H, W, kh, kw, kh - 1, kw - 1, 0,
+              Cout * H * W, st)
+    if not (ph or pw):
+        return gpad
+    gx = _new(B, Cin, H, W, like=gy)
+    _hip.call("cf_reflect_pad_adjoint", _hip.p(gpad), _hip.p(gx), B * Cin, H, W, ph, pw, st)
+    return gx
+
+
+def coupling_conv_backward(m, x_in, gz, gld):
+    """Coupling with a conv conditioner of any shape (coupling.py:39-66; the fused step kernels cover only the image
+    shapes): the conditioner is re-run layer by layer with its activations kept, then the chain back."""
+    from .coupling import conv2d_reflect
+    x, xbs = _hip.bview(x_in)
+    gzv, gzbs = _hip.bview(gz)
+    B, C, H, W = x.shape
+    half = C // 2
+    c1, c2, c3 = m.NN[0], m.NN[2], m.NN[4]
+    x0 = x[:, :half].contiguous()
+    a1 = conv2d_reflect(x0, c1, True)
+    a2 = conv2d_reflect(a1, c2, True)
+    h = conv2d_reflect(a2, c3, False)
+    gx, gh = _new(B, C, H, W, like=x), _new(B, C, H, W, like=x)
+    _hip.call("cf_coupling_apply_bwd", _hip.p(x), _hip.p(h), _hip.p(gzv), _hip.p(_hip.f32(gld)), _hip.p(gx), _hip.p(gh),
+              B, C, H * W, xbs, gzbs, _hip.stream())
+    grads = {}
+    g2 = _relu_mask(a2, conv_backward(a2, c3, gh, grads))
+    g1 = _relu_mask(a1, conv_backward(a1, c2, g2, grads))
+    gx[:, :half] += conv_backward(x0, c1, g1, grads)
+    return gx, grads
+
+
+def masked_coupling_backward(m, x_in, gz, gld):
+    """MaskedCoupling (ar.py:33-57): z = x exp(log_s) + t with [t ; raw] = conv3(relu(conv2(relu(conv1(relu x))))) + [x ; x].
+    The weights are masked in place by the forward (masked_conv_2d.py:22), so - as under torch.autograd in the reference -
+    the weight gradients are the plain convolution gradients (entries at masked positions are wiped by the next forward)."""
+    from .coupling import conv2d_reflect
+    x = _hip.f32(x_in).contiguous()
+    gzc = _hip.f32(gz).contiguous()
+    B, D, H, W = x.shape
+    nn_ = m.NN
+    for c in (nn_.conv1, nn_.conv2, nn_.conv3):
+        c.apply_mask_()
+    a0 = _relu_mask(x, x)                                               # relu(x)
+    a1 = conv2d_reflect(a0, nn_.conv1, True)
+    a2 = conv2d_reflect(a1, nn_.conv2, True)
+    h = conv2d_reflect(a2, nn_.conv3, False)
+    _hip.call("cf_add_repeat", _hip.p(h), _hip.p(x), B, 2 * D, D, H * W, _hip.stream())       # + [x ; x]
+    # the affine-map kernels transform the SECOND channel half of their input: feed them [0 ; x] / [0 ; gz]
+    zeros = torch.zeros_like(x)
+    xx, gzz = torch.cat([zeros, x], dim=1), torch.cat([zeros, gzc], dim=1)
+    gxx, gh = _new(B, 2 * D, H, W, like=x), _new(B, 2 * D, H, W, like=x)
+    _hip.call("cf_coupling_apply_bwd", _hip.p(xx), _hip.p(h), _hip.p(gzz), _hip.p(_hip.f32(gld)), _hip.p(gxx), _hip.p(gh),
+              B, 2 * D, H * W, 2 * D * H * W, 2 * D * H * W, _hip.stream())
+    grads = {}
+    g2 = _relu_mask(a2, conv_backward(a2, nn_.conv3, gh, grads))
+    g1 = _relu_mask(a1, conv_backward(a1, nn_.conv2, g2, grads))
+    g0 = _relu_mask(x, conv_backward(a0, nn_.conv1, g1, grads))
+    gx = gxx[:, D:] + g0 + gh[:, :D] + gh[:, D:]                       # through x * s, the residual block, and + [x ; x]
+    return gx.contiguous(), grads
+
+
 def conv1x1_backward(m, x_in, gz, gld):
     """Conv1x1 (conv1x1.py:52-57): z = W x per pixel, ldj = H W log|det W|."""
     x = _hip.f32(x_in)
@@ -190,10 +288,15 @@ def layer_backward(m, x_in, gz, gld):
     from .actnorm import ActNorm
     from .augment import Augment
     from .conv1x1 import Conv1x1
-    from .coupling import TransCoupling
+    from .ar import MaskedCoupling
+    from .coupling import Coupling, TransCoupling
     from .permute_axes import PermuteAxes
     if isinstance(m, TransCoupling):
         return transcoupling_backward(m, x_in, gz, gld)
+    if type(m) is Coupling and not m.context_net:
+        return coupling_conv_backward(m, x_in, gz, gld)
+    if isinstance(m, MaskedCoupling):
+        return masked_coupling_backward(m, x_in, gz, gld)
     if type(m) is Conv1x1:
         return conv1x1_backward(m, x_in, gz, gld)
     if type(m) is ActNorm:

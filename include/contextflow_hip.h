@@ -97,6 +97,13 @@ int cf_actnorm(const float* x, const float* t, const float* logs, float* z, floa
 /* generic k x k convolution, stride 1, reflect padding (ph,pw), optional ReLU; fp32 direct form.     */
 int cf_conv2d_reflect(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout,
                       int H, int W, int kh, int kw, int ph, int pw, int relu, int64_t x_bstride, cf_stream_t stream);
+/* same implicit-GEMM kernel with ZERO padding (ph, pw): y (B, Cout, Hi + 2 ph - kh + 1, Wi + 2 pw - kw + 1).  With the
+ * weights flipped in space and transposed in the channels and padding (kh-1, kw-1) this is the transposed convolution
+ * of the backward; cf_reflect_pad_adjoint then folds the padded border (B*C, H + 2 ph, W + 2 pw) back onto the pixels it
+ * was reflected from: together the data gradient of cf_conv2d_reflect.                                              */
+int cf_conv2d_zero(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int Hi, int Wi,
+                   int kh, int kw, int ph, int pw, int relu, int64_t x_bstride, cf_stream_t stream);
+int cf_reflect_pad_adjoint(const float* gpad, float* gx, int BC, int H, int W, int ph, int pw, cf_stream_t stream);
 /* affine map from the net output h (B,C,HW): t = h[:, :C/2], log_s = 2 tanh(h[:, C/2:]/2).
  * inverse=0: z = [x0 | x1*exp(log_s)+t], ldj[b] = sum log_s ;  inverse=1: z = [x0 | (x1-t)/exp(log_s)] */
 int cf_coupling_apply(const float* x, const float* h, float* z, float* ldj, int B, int C, int HW, int inverse,

@@ -868,6 +868,41 @@ def test_training_steps_reduce_the_loss(L):
     assert losses[-1] < losses[0] - 1e-3, losses
 
 
+@pytest.mark.parametrize("name,coupling", [("mnist", "maf"), ("smap", "conv"), ("smap", "maf")])
+def test_training_with_generic_conv_couplings(L, name, coupling):
+    """`--coupling maf` (MaskedCoupling, ar.py) and `--coupling conv` on a time-series topology ((3,1) kernels, model.py:114):
+    the conditioners run on the generic conv kernels; their training step goes through conv_backward.  The first grad-mode
+    call initialises the ActNorms; gradients of every parameter match torch.autograd through the fp64 oracle on the flow's
+    output; a few optimiser steps reduce the loss."""
+    import contextflow_amd as cfa
+    from oracle import params as op
+    torch.manual_seed(1)
+    cfg, ds, M = cfa.preset_config(name)
+    cfg = dict(cfg, coupling=coupling)
+    model = cfa.create_model(cfg, ds, M).to(DEV)
+    g = torch.Generator().manual_seed(8)
+    B = 24
+    x = torch.rand(B, *ds, generator=g) if name == "smap" else torch.randint(0, 256, (B, *ds), generator=g).float()
+    x = x.to(DEV)
+    gt = torch.randint(0, M, (B,), generator=g).to(DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    dim_inv = 1.0 / (ds[0] * ds[1] * ds[2])
+    losses = []
+    for it in range(8):
+        opt.zero_grad(set_to_none=True)
+        logp = dim_inv * model.log_prob(x)
+        assert logp.requires_grad
+        loss = -logp.mean() if M == 1 else torch.nn.functional.cross_entropy(logp, gt)
+        loss.backward()
+        if it == 0:
+            got = [p for p in model.parameters() if p.grad is not None]
+            assert len(got) >= 20 and all(torch.isfinite(p.grad).all() for p in got)
+        opt.step()
+        losses.append(float(loss))
+    assert all(math.isfinite(v) for v in losses), losses
+    assert min(losses[1:]) < losses[0], losses
+
+
 @pytest.mark.parametrize("H,MR,NR,taps,B", [(16, 32, 32, 9, 5), (16, 16, 16, 9, 3), (8, 64, 64, 9, 7), (8, 32, 32, 9, 6),
                                             (4, 128, 128, 9, 9), (4, 64, 64, 9, 6), (4, 64, 64, 9, 2), (16, 16, 32, 1, 4),
                                             (8, 64, 16, 1, 5), (4, 128, 32, 1, 7), (4, 24, 40, 1, 3)])
@@ -1193,6 +1228,88 @@ def test_masked_coupling_matches_reference(L, tag, D, krn, pad):
     assert (ldj.cpu() - torch.from_numpy(fx[tag + "/ldj"])).abs().max() < 2e-4
     with pytest.raises(NotImplementedError):
         m.reverse(z)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,krn", [(3, 5, 70, 7, 5, (3, 3)), (4, 13, 52, 8, 1, (3, 1)), (2, 32, 32, 16, 16, (3, 3)),
+                                                 (5, 8, 24, 6, 9, (1, 1)), (2, 128, 128, 4, 4, (3, 3)), (1, 3, 40, 2, 2, (3, 3))])
+def test_generic_conv_and_its_backward(L, B, Cin, Cout, H, W, krn):
+    """The shape-agnostic convolution (implicit GEMM on the fp32 matrix cores, reflect padding) against torch in fp64, and
+    its backward - zero-padded transposed convolution + adjoint of the reflect padding for the data, split-K GEMM over
+    the unfolded rows for the weights - against fp64 autograd."""
+    from contextflow_amd.layers.autograd_layers import conv_backward
+    from contextflow_amd.layers.coupling import conv2d_reflect
+    pad = (krn[0] // 2, krn[1] // 2)
+    g = torch.Generator().manual_seed(B * 100 + Cin)
+    conv = torch.nn.Conv2d(Cin, Cout, krn, padding=pad, padding_mode="reflect")
+    x = torch.randn(B, Cin, H, W, generator=g)
+    gy = torch.randn(B, Cout, H, W, generator=g)
+    c64 = torch.nn.Conv2d(Cin, Cout, krn, padding=pad, padding_mode="reflect").double()
+    c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    y64 = c64(x64)
+    y64.backward(gy.double())
+    conv = conv.to(DEV)
+    for relu in (False, True):
+        y = conv2d_reflect(x.to(DEV), conv, relu)
+        ref = torch.relu(y64) if relu else y64
+        close(y, ref.detach(), tol=2e-5)
+    grads = {}
+    gx = conv_backward(x.to(DEV), conv, gy.to(DEV), grads)
+    close(gx, x64.grad, tol=2e-5)
+    close(grads[conv.weight], c64.weight.grad, tol=2e-5)
+    close(grads[conv.bias], c64.bias.grad, tol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["maf_3x3", "maf_3x1", "coupling_3x1", "coupling_3x3"])
+def test_conv_coupling_backward_against_autograd_oracle(L, kind):
+    """Backward of the layers whose conditioner runs on the generic conv kernels - MaskedCoupling (--coupling maf, ar.py:15-57)
+    and Coupling with kernels / shapes outside the fused step kernels (--coupling conv on time series, model.py:114) -
+    against torch.autograd through the fp64 oracle.  MaskedCoupling: the weights are masked in place (masked_conv_2d.py:22),
+    so the reference's autograd returns the plain convolution gradient: the oracle runs on the pre-masked weights with the
+    masks set to one."""
+    from contextflow_amd.layers.autograd_layers import layer_backward
+    g = torch.Generator().manual_seed(11)
+    if kind.startswith("maf"):
+        D, krn, pad = (6, (3, 3), (1, 1)) if kind == "maf_3x3" else (8, (3, 1), (1, 0))
+        fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "unit_maf.npz"))
+        sd = {k[len(kind) + 4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(kind + "/sd:")}
+        m = L.MaskedCoupling(D, kernel_size=krn, padding=pad)
+        m.load_state_dict(sd, strict=True)
+        x = torch.from_numpy(fx[kind + "/x"])
+        p = {}
+        for k, v in sd.items():
+            p["0." + k] = v.double()
+        for c in ("conv1", "conv2", "conv3"):                       # pre-masked weights, masks of ones
+            p["0.NN.%s.weight" % c] = (sd["NN.%s.weight" % c] * sd["NN.%s.mask" % c]).double().requires_grad_(True)
+            p["0.NN.%s.bias" % c] = sd["NN.%s.bias" % c].double().requires_grad_(True)
+            p["0.NN.%s.mask" % c] = torch.ones_like(sd["NN.%s.mask" % c]).double()
+        x64 = x.double().requires_grad_(True)
+        z64, l64 = fo.masked_coupling_fwd(x64, p, "0.", pad)
+    else:
+        t, sd = unit(kind)
+        C = t["x"].shape[1]
+        krn, pad = tuple(int(v) for v in t["krn"]), tuple(int(v) for v in t["pad"])
+        m = L.Coupling(C, kernel_size=krn, padding=pad)
+        m.load_state_dict(sd)
+        x = t["x"]
+        p = {"0." + k: v.double().requires_grad_(True) for k, v in sd.items()}
+        x64 = x.double().requires_grad_(True)
+        z64, l64 = fo.coupling_fwd(x64, p, "0.", pad)
+    gz = torch.randn(z64.shape, generator=g)
+    gld = torch.randn(x.shape[0], generator=g)
+    ((z64 * gz.double()).sum() + (l64 * gld.double()).sum()).backward()
+    m = m.to(DEV)
+    gx, grads = layer_backward(m, x.to(DEV), gz.to(DEV), gld.to(DEV))
+    close(gx, x64.grad, tol=5e-5)
+    checked = 0
+    for name, prm in m.named_parameters():
+        ref = p["0." + name].grad
+        assert prm in grads, name
+        scale = max(ref.abs().max().item(), 1e-3)
+        err = (grads[prm].detach().cpu().double() - ref).abs().max().item() / scale
+        assert err < 1e-4, (name, err)
+        checked += 1
+    assert checked == 6
 
 
 def test_in_kernel_noise_statistics(L):
