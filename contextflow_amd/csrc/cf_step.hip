@@ -448,6 +448,158 @@ int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int
     return 0;
 }
 
+// ---- row-split forward step for SMALL batches (C = 32 on 8x8, C = 64 on 4x4) -------------------------------------------
+// At the reference's batch sizes (64 / 256, config.py:10) a launch has far fewer workgroups than the chip has CUs, and
+// the time of a step is the serial work of ONE workgroup: in k_flow_step a wave runs every row tile of its own pixel
+// columns (C = 64: 4 tiles x 576 k-steps in the 3x3 alone).  Here the 4 waves of a workgroup share PIXR = 32 NPT pixel
+// columns (2 samples at 4x4, 1 sample at 8x8) and split the OUTPUT ROWS: in phases 1 and 2 each wave owns one
+// (row tile, pixel tile) pair, in phase 3 the two halves of K go to two waves whose partial sums meet in the epilogue.
+// 4x the workgroups, a quarter of the serial MFMA chain per workgroup; the planes are exchanged through LDS with a
+// workgroup barrier per phase.  Same packed workspace as k_flow_step.  Used below ~2 workgroups per CU (cf_flow_step_fwd).
+template <class G, int NPT, bool SQ>
+__global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ x, float* __restrict__ z,
+                                                      float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                      int64_t xbs) {
+    constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, HALF = G::HALF, HID = G::HID, HP = G::HP;
+    constexpr int PIXR = 32 * NPT, SPWR = PIXR / HW, RT1 = G::RT1, RT03 = G::RT03;
+    static_assert(RT1 * NPT == 4 && RT03 * NPT == 2 && HP == HALF && PIXR % HW == 0, "row-split geometry");
+    __shared__ __align__(16) float lds[(2 * C + HID + 2 * C) * PIXR];
+    float* XP = lds;                         // [C][PIXR]    x plane
+    float* Y = XP + C * PIXR;                // [C][PIXR]    rows [0, HALF) = y0, [HALF, C) = y1
+    float* H1 = Y + C * PIXR;                // [HID][PIXR]  h1, then h2 in place
+    float* T = H1 + HID * PIXR;              // [2][C][PIXR] the two K-halves of [t | raw]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    const int b0 = blockIdx.x * SPWR;
+    const ws_rsrc_t rs = ws_rsrc(ws, G::WS_FLOATS);
+
+    // ---- x -> LDS (element-wise: small batches are not bandwidth-bound; Squeeze folded into the index)
+#pragma unroll
+    for (int i = 0; i < C * PIXR / 256; ++i) {
+        const int e = tid + 256 * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
+        const int64_t bb = min(b0 + sm, B - 1);
+        int src;
+        if constexpr (!SQ) src = ch * HW + pp;
+        else { const int yy = pp / W, xx = pp - yy * W; src = (ch >> 2) * 4 * HW + (2 * yy + ((ch >> 1) & 1)) * 2 * W + 2 * xx + (ch & 1); }
+        XP[e] = x[bb * xbs + src];
+    }
+    __syncthreads();
+    // ---- phase 0: [y0 | y1] = W' x + b'   (waves 0, 1: one (row tile, pixel tile) pair each)
+    if (wave < 2) {
+        const int rt = wave % RT03, q = wave / RT03, col = q * 32 + li;
+        f32x16 acc = bias_tile(ws + G::OFF_B0 + rt * 32, lk);
+#pragma unroll
+        for (int g = 0; g < G::NG0; ++g) {
+            const float4 a = ws_frag(rs, lane, G::OFF_A0 + (g * RT03 + rt) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e < G::KS0)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a, e), XP[(2 * (4 * g + e) + lk) * PIXR + col], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Y[(rt * 32 + tile_row(r, lk)) * PIXR + col] = acc[r];
+    }
+    __syncthreads();
+    // first half of the output = y0 (coupling.py:65)
+#pragma unroll
+    for (int i = 0; i < HALF * PIXR / 256; ++i) {
+        const int e = tid + 256 * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
+        if (b0 + sm < B) z[(int64_t)(b0 + sm) * C * HW + ch * HW + pp] = Y[e];
+    }
+    const int rt1 = wave % RT1, q1 = wave / RT1, col1 = q1 * 32 + li;          // this wave's pair in phases 1, 2
+    // ---- phase 1: h1 = relu(NN.0 y0 + b)
+    {
+        f32x16 acc = bias_tile(ws + G::OFF_B1 + rt1 * 32, lk);
+#pragma unroll
+        for (int g = 0; g < G::NG1; ++g) {
+            const float4 a = ws_frag(rs, lane, G::OFF_A1 + (g * RT1 + rt1) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * g + e < G::KS1)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a, e), Y[(2 * (4 * g + e) + lk) * PIXR + col1], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1[(rt1 * 32 + tile_row(r, lk)) * PIXR + col1] = cf_relu(acc[r]);
+    }
+    __syncthreads();
+    // ---- phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3 reflect: K = 9 taps x HID channels, fragments one group ahead
+    f32x16 acc2 = bias_tile(ws + G::OFF_B2 + rt1 * 32, lk);
+    {
+        const int sm = col1 / HW, pp = col1 - sm * HW, py = pp / W, px = pp - py * W;
+        float4 a = ws_frag(rs, lane, G::OFF_A2 + rt1 * 256);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+            yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+            xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+            const float* src = H1 + sm * HW + yy * W + xx + lk * PIXR;
+#pragma unroll
+            for (int cg = 0; cg < G::NCG; ++cg) {
+                const int g = tap * G::NCG + cg, gn = g + 1 < G::NG2 ? g + 1 : g;
+                const float4 an = ws_frag(rs, lane, G::OFF_A2 + (gn * RT1 + rt1) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a, e), src[(8 * cg + 2 * e) * PIXR], acc2, 0, 0, 0);
+                a = an;
+            }
+        }
+    }
+    __syncthreads();                 // every wave has finished reading h1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H1[(rt1 * 32 + tile_row(r, lk)) * PIXR + col1] = cf_relu(acc2[r]);
+    __syncthreads();
+    // ---- phase 3: [t | raw] = NN.4 h2 + b: pair = wave & 1, K half = wave >> 1 (the bias rides with half 0)
+    {
+        const int it = wave & 1, kh = wave >> 1, rt = it % RT03, q = it / RT03, col = q * 32 + li;
+        f32x16 acc = bias_tile(ws + G::OFF_B3 + rt * 32, lk);
+        if (kh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        }
+        constexpr int NGH = G::NG3 / 2;
+        static_assert(G::NG3 % 2 == 0 && G::KS3 % 8 == 0, "phase-3 K halves");
+#pragma unroll
+        for (int gg = 0; gg < NGH; ++gg) {
+            const int g = kh * NGH + gg;
+            const float4 a = ws_frag(rs, lane, G::OFF_A3 + (g * RT03 + rt) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a, e), H1[(2 * (4 * g + e) + lk) * PIXR + col], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[(kh * C + rt * 32 + tile_row(r, lk)) * PIXR + col] = acc[r];
+    }
+    __syncthreads();
+    // ---- affine map and log-det over all 256 threads: element e = (channel, column); a thread's column is fixed
+    float lsum = 0.f;
+    const int colE = tid % PIXR, smE = colE / HW, ppE = colE - smE * HW;
+#pragma unroll
+    for (int i = 0; i < HALF * PIXR / 256; ++i) {
+        const int ch = (tid + 256 * i) / PIXR;
+        const float tt = T[ch * PIXR + colE] + T[(C + ch) * PIXR + colE];
+        const float raw = T[(HP + ch) * PIXR + colE] + T[(C + HP + ch) * PIXR + colE];
+        const float ls = cf_log_scale(raw);
+        const float z1 = fmaf(Y[(HP + ch) * PIXR + colE], __expf(ls), tt);
+        lsum += ls;
+        if (b0 + smE < B) z[(int64_t)(b0 + smE) * C * HW + (HALF + ch) * HW + ppE] = z1;
+    }
+    // per-sample sum: the lanes of a sample inside the wave (columns are lane % PIXR), then across the waves through LDS
+    constexpr int LPS = HW < 64 ? HW : 64;            // consecutive lanes of one sample
+#pragma unroll
+    for (int o = 1; o < LPS; o <<= 1) lsum += __shfl_xor(lsum, o, 64);
+    if (PIXR < 64 && HW < 32) lsum += __shfl_xor(lsum, 32, 64);    // PIXR = 32: lanes l and l + 32 hold the same column
+    __syncthreads();                                  // T is dead: reuse its first words
+    if ((lane % LPS) == 0 && (PIXR >= 64 || lane < 32)) T[wave * 4 + (lane % PIXR) / HW] = lsum;
+    __syncthreads();
+    if (tid < SPWR && b0 + tid < B) ldj_acc[b0 + tid] += ws[0] + ((T[tid] + T[4 + tid]) + (T[8 + tid] + T[12 + tid]));
+}
+
+template <class G, int NPT, bool SQ>
+int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s) {
+    constexpr int SPWR = 32 * NPT / G::HW;
+    k_flow_step_rs<G, NPT, SQ><<<dim3((B + SPWR - 1) / SPWR), dim3(256), 0, s>>>(x, z, ldj, ws, B, xbs);
+    return 0;
+}
+
 template <class G>
 int launch_prepare(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* w3, const float* b3, float* ws, hipStream_t s) {
@@ -751,6 +903,18 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     const int sid = shape_id(C, H, W);
     if ((sid == 2 && B < 256 * G32::SPW) || (sid == 3 && B < 256 * G64::SPW)) flags = 2 << 16;
     if (sid == 0 || sid == 1) flags = 3 << 16;      // 16x16 images: k_flow_step_small
+    // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
+    if ((sid == 2 && B <= 512) || (sid == 3 && B <= 1024)) {
+        CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);
+        if (B == 0) return 0;
+        const float* w = (const float*)ws;
+        if (sid == 2) { if (in_squeeze) launch_step_rs<G32, 2, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream));
+                        else launch_step_rs<G32, 2, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); }
+        else          { if (in_squeeze) launch_step_rs<G64, 1, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream));
+                        else launch_step_rs<G64, 1, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); }
+        CF_LAUNCH_CHECK();
+        return 0;
+    }
     return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, flags, stream);
 }
 

@@ -11,6 +11,8 @@ dev = "cuda:0"
 torch.manual_seed(0)
 cfg, ds, M = cfa.preset_config(name)
 model = cfa.create_model(cfg, ds, M).to(dev)
+torch.set_grad_enabled(False)                       # evaluation (experiment_cl.py:163-185)
+model.auto_graph = False                            # "eager" = every kernel launched by the host; "graph" = explicit capture
 model(torch.randint(0, 256, (256, *ds), device=dev).float())
 for B in Bs:
     x = torch.randint(0, 256, (B, *ds), device=dev).float()
