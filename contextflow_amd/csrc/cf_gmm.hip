@@ -216,8 +216,18 @@ __global__ __launch_bounds__(256) void k_gmm_finish(const float* __restrict__ q,
     const int b = blockIdx.x * spb + sl;
     const bool live = b < B && sl < spb;
     float s = 0.f;
-    if (live)
-        for (int z = 0; z < nsplit; ++z) s += q[((int64_t)z * B + b) * MK + mk];
+    if (live) {
+        const float* qp = q + (int64_t)b * MK + mk;
+        const int64_t zs = (int64_t)B * MK;
+        int z = 0;
+        for (; z + 8 <= nsplit; z += 8) {              // 8 independent loads in flight (the partials sit 4 B MK bytes apart)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = qp[(z + j) * zs];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; z < nsplit; ++z) s += qp[z * zs];
+    }
     l[threadIdx.x] = live ? cst[mk] - 0.5f * s : 0.f;
     __syncthreads();
     if (live && mk % K == 0) {

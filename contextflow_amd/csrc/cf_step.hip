@@ -525,22 +525,41 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
     f32x16 acc2 = bias_tile(ws + G::OFF_B2 + rt1 * 32, lk);
     {
         const int sm = col1 / HW, pp = col1 - sm * HW, py = pp / W, px = pp - py * W;
-        float4 a = ws_frag(rs, lane, G::OFF_A2 + rt1 * 256);
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
+        // a wave has ONE row tile here: 4 MFMAs (256 cycles) per weight fragment, less than an L2 round trip under load -
+        // the fragments run in a ring of 4, fetched three groups ahead
+        static_assert(G::NCG % 4 == 0, "fragment ring");
+        float4 a[4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[j] = ws_frag(rs, lane, G::OFF_A2 + (j * RT1 + rt1) * 256);
+        // ... and the B operands (LDS) one group ahead: with a single accumulator chain per wave nothing else hides the
+        // LDS latency in front of each group's first MFMA
+        auto tap_src = [&](int tap) -> const float* {
             int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
             yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
             xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-            const float* src = H1 + sm * HW + yy * W + xx + lk * PIXR;
+            return H1 + sm * HW + yy * W + xx + lk * PIXR;
+        };
+        float bv[2][4];
+        const float* src = tap_src(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[0][e] = src[2 * e * PIXR];
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* nsrc = tap_src(tap < 8 ? tap + 1 : 8);
 #pragma unroll
             for (int cg = 0; cg < G::NCG; ++cg) {
-                const int g = tap * G::NCG + cg, gn = g + 1 < G::NG2 ? g + 1 : g;
-                const float4 an = ws_frag(rs, lane, G::OFF_A2 + (gn * RT1 + rt1) * 256);
+                const int g = tap * G::NCG + cg, gn = g + 3 < G::NG2 ? g + 3 : G::NG2 - 1;
+                a[(cg + 3) & 3] = ws_frag(rs, lane, G::OFF_A2 + (gn * RT1 + rt1) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)       // next group: same tap, next 8 channels - or the first 8 of the next tap
+                    bv[(cg + 1) & 1][e] = (cg + 1 < G::NCG) ? src[(8 * (cg + 1) + 2 * e) * PIXR] : nsrc[2 * e * PIXR];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a, e), src[(8 * cg + 2 * e) * PIXR], acc2, 0, 0, 0);
-                a = an;
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[cg & 3], e), bv[cg & 1][e], acc2, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            src = nsrc;
         }
     }
     __syncthreads();                 // every wave has finished reading h1
