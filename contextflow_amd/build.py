@@ -48,6 +48,8 @@ def build(force=False, verbose=True):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    for junk in glob.glob(OUT + ".*"):          # hipcc leaves the unbundled device / host images of the link step behind
+        os.remove(junk)
     if verbose:
         print("built %s (%d kernels files, %.1f KB)" % (OUT, len(objs), os.path.getsize(OUT) / 1024))
     return OUT

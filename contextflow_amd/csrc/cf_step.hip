@@ -278,10 +278,11 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
 // ~100 ds_read_b32 per wave, i.e. a few hundred LDS cycles against ~22 000 MFMA cycles.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <class G, bool SQ, bool DBG = false>
+// DUMP (training): y0 and the post-ReLU h1 / h2 planes also go to the tape `tp` (see k_flow_step).
+template <class G, bool SQ, bool DBG = false, bool DUMP = false>
 __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
                                                                   float* __restrict__ ldj_acc, const float* __restrict__ ws,
-                                                                  int B, int64_t xbs, float* __restrict__ dbg) {
+                                                                  int B, int64_t xbs, float* __restrict__ dbg, StepTape tp) {
     static_assert(G::SMALL, "16x16 images, one sample per workgroup, C <= 16");
     constexpr int C = G::C, W = 16, H = 16, PIX = 256, HALF = G::HALF, HID = G::HID, PTW = G::PTW;
     constexpr int XI = C * PTW / 8;
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
             if (2 * lg + j < HALF) Y0[(2 * lg + j) * PIX + colb + 16 * ct] = acc0[ct][j];
     cf_wave_sync();
     z_store<G>(z, Y0, tile, 0, B, wave, lane);
+    if constexpr (DUMP) rows_store_t<G, HALF, HALF>(tp.y0, Y0, tile, B, wave, lane);
     const int64_t dbg_cols = (int64_t)B * PIX;       // test-only dumps (DBG): planes as [rows][B * PIX], see k_flow_step
     auto dump = [&](const float* plane, int rows, int row0) {
         __syncthreads();
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
 #pragma unroll
         for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q]; }
         f32x16 unused[G::RT03][PTW];
-        conditioner_net<G, 0, false, 2>(unused, lds, ws, pix, pin, lane, tid, DBG ? dbg : nullptr, dbg_cols, tile);
+        conditioner_net<G, 0, DUMP, 2>(unused, lds, ws, pix, pin, lane, tid, DBG ? dbg : nullptr, dbg_cols, tile, nullptr, nullptr, tp, B);
     } else {
         f32x4 a1[4];
         {
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a1[ct][r]);
+            if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h1, H1, tile, B, wave, lane);
         }
         __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' image rows
         if constexpr (DBG) dump(H1, HID, C);
@@ -393,6 +396,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a2[ct][r]);
+        if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h2, H1, tile, B, wave, lane);
         if constexpr (DBG) dump(H1, HID, C + HID);
     }
     cf_wave_sync();                      // h2: every lane's rows in place before other lanes read them as operands
@@ -441,10 +445,10 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
     if (tid == 0 && tile < B) ldj_acc[tile] += ws[0] + ((Y0[0] + Y0[64]) + (Y0[128] + Y0[192]));
 }
 
-template <class G, bool SQ, bool DBG = false>
+template <class G, bool SQ, bool DBG = false, bool DUMP = false>
 int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s,
-                      float* dbg = nullptr) {
-    k_flow_step_small<G, SQ, DBG><<<dim3(B), dim3(256), (size_t)G::LDS_FLOATS * sizeof(float), s>>>(x, z, ldj, ws, B, xbs, dbg);
+                      float* dbg = nullptr, StepTape tp = StepTape{nullptr, nullptr, nullptr}) {
+    k_flow_step_small<G, SQ, DBG, DUMP><<<dim3(B), dim3(256), (size_t)G::LDS_FLOATS * sizeof(float), s>>>(x, z, ldj, ws, B, xbs, dbg, tp);
     return 0;
 }
 
@@ -954,8 +958,10 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
                                     : launch_step<G, false, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp)
     // small batches (the reference trains with 256 samples): the half-size workgroup geometry, as in cf_flow_step_fwd
     switch (shape_id(C, H, W)) {
-        case 0: CF_STEPT(G8); break;
-        case 1: CF_STEPT(G16); break;
+        case 0: rc = in_squeeze ? launch_step_small<G8s, true, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp)
+                                : launch_step_small<G8s, false, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp); break;
+        case 1: rc = in_squeeze ? launch_step_small<G16s, true, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp)
+                                : launch_step_small<G16s, false, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp); break;
         case 2: if (B < 256 * G32::SPW) CF_STEPT(G32v2); else CF_STEPT(G32); break;
         case 3: if (B < 256 * G64::SPW) CF_STEPT(G64v2); else CF_STEPT(G64); break;
         default: cf_set_error("cf_flow_step_fwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;

@@ -165,7 +165,8 @@ __device__ __forceinline__ void load_vec(f32x16 (&v)[2], const float* __restrict
 
 // acc[rt] += sum over k-steps A(ws frags at foff) * B, B operand = registers: k-step s -> bop(s).
 // Fragments of group g+1 are requested before the MFMAs of group g (pinned: hipcc otherwise sinks the loads).
-template <int RT, int NKS, class BOP>
+// ZERO: the accumulators start from zero - passed to the first MFMA as the inline constant instead of 16 v_mov per tile.
+template <int RT, int NKS, bool ZERO = false, class BOP>
 __device__ __forceinline__ void gemm_regs(f32x16 (&acc)[RT], rsrc_t rs, int lane, int foff, BOP bop) {
     constexpr int NG = (NKS + 3) / 4;
     float4 a[2][RT];
@@ -183,8 +184,14 @@ __device__ __forceinline__ void gemm_regs(f32x16 (&acc)[RT], rsrc_t rs, int lane
             if (4 * g + e < NKS) {
                 const float b = bop(4 * g + e);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[g & 1][rt], e), b, acc[rt], 0, 0, 0);
+                for (int rt = 0; rt < RT; ++rt) {
+                    if (ZERO && g == 0 && e == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[g & 1][rt], e), b, zero, 0, 0, 0);
+                    } else {
+                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[g & 1][rt], e), b, acc[rt], 0, 0, 0);
+                    }
+                }
             }
     }
 }
@@ -254,7 +261,7 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 
 template <int CTRL> __device__ __forceinline__ float quad(float v) {          // DPP quad permutation of the 4 tokens of a sample
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 template <int M> __device__ __forceinline__ float tok_xor(float v) {
     if constexpr (M == 0) return v;
@@ -313,11 +320,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
             f32x16 u[2];
             layernorm<V, 2>(X, u, ws + wl + V::L_LNA, lk, nullptr);
             f32x16 qkv[6];
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) qkv[t][r] = 0.f;
-            gemm_regs<6, V::KS_RES>(qkv, rs, lane, wl + V::L_WQKV, [&](int s) { return u[s / V::KPT][s % V::KPT]; });
+            gemm_regs<6, V::KS_RES, true>(qkv, rs, lane, wl + V::L_WQKV, [&](int s) { return u[s / V::KPT][s % V::KPT]; });
             // scores of this token against the 4 tokens of its sample (partner = token ^ m), exact softmax
             float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
