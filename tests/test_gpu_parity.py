@@ -840,6 +840,38 @@ def test_graph_capture_matches_eager(L, name):
     assert (lp2 - logp).abs().max().item() > 0.0          # it really is a different result (static buffer was overwritten)
 
 
+def test_auto_graph_replay_and_cache_invalidation(L):
+    """Evaluation under no_grad: the packed parameter tables are cached, and after two identical-shape calls the forward is
+    replayed from a captured HIP graph (FlowSequential.auto_graph).  Replays must keep drawing fresh noise, return tensors
+    the next call does not overwrite, and a parameter update (version counters) must drop both the graph and the tables."""
+    from tests.gpu_util import build_model
+    ops, _, M, params, fx = load_e2e("mnist")
+    model = build_model("mnist", params)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (48, 1, 32, 32), generator=g).float().to(DEV)
+    outs = []
+    with torch.no_grad():
+        for _ in range(5):
+            outs.append(model.log_prob(x))
+    st = list(model._graphs.values())
+    assert len(st) == 1 and st[0][2] is not None, "no graph captured after repeated identical calls"
+    assert len({o.data_ptr() for o in outs}) == 5                       # fresh output tensors
+    b = [bpd(o.cpu(), "mnist") for o in outs]
+    for i in range(1, 5):
+        assert not torch.equal(outs[i], outs[0])                        # fresh dequantisation noise every call / replay
+        assert (b[i] - b[0]).abs().max() < 0.4 and abs(float(b[i].mean() - b[0].mean())) < 0.03   # ... of the same distribution
+    # a parameter update: results must follow it (stale tables or a stale graph would not)
+    with torch.no_grad():
+        model.dist.mG.add_(0.5)
+        shifted = model.log_prob(x)
+        assert list(model._graphs.values())[0][2] is None               # graph dropped, re-armed
+        model.auto_graph = False
+        ref = model.log_prob(x)
+    bs, br = bpd(shifted.cpu(), "mnist"), bpd(ref.cpu(), "mnist")
+    assert abs(float(bs.mean() - br.mean())) < 0.03
+    assert abs(float(bs.mean() - b[0].mean())) > 0.1                    # the shift is visible
+
+
 def test_training_steps_reduce_the_loss(L):
     """A few AdamW steps with the reference's classification loss (experiment_cl.py:127-133) through the hand-written
     backward: the loss must go down and stay finite (end-to-end use of the gradients, squeeze-folded steps included)."""
