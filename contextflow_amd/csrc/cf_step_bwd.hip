@@ -81,10 +81,10 @@ __device__ __forceinline__ void tiles_to_plane(const f32x16 (&acc)[RT][G::PTW], 
 // every tap.  VALU work never overlaps the MFMAs of its SIMD (tools/micro/mfma_issue.hip), so the 0/1-weighted sums
 // run as ONE batch per 4-k-step group, and the LDS reads of group cg+1 are issued before the MFMAs of group cg.
 template <class G, int NS>
-__device__ __forceinline__ void adj_issue(float (&raw)[G::PTW][4][NS], float4 (&a)[G::RT1], const float4* __restrict__ fr,
+__device__ __forceinline__ void adj_issue(float (&raw)[G::PTW][4][NS], float4 (&a)[G::RT1], ws_rsrc_t rs, int fr,
                                           const float* __restrict__ lds, const int (&off)[G::PTW][NS], int cg, int lane) {
 #pragma unroll
-    for (int rt = 0; rt < G::RT1; ++rt) a[rt] = fr[(cg * G::RT1 + rt) * 64 + lane];
+    for (int rt = 0; rt < G::RT1; ++rt) a[rt] = ws_frag(rs, lane, fr + (cg * G::RT1 + rt) * 256);
 #pragma unroll
     for (int q = 0; q < G::PTW; ++q)
 #pragma unroll
@@ -113,17 +113,17 @@ __device__ __forceinline__ void adj_combine(GroupOps<G::RT1, G::PTW>& o, const f
 }
 
 template <class G, int NS>
-__device__ __forceinline__ void adj_tap(f32x16 (&acc)[G::RT1][G::PTW], const float4* __restrict__ fr,
+__device__ __forceinline__ void adj_tap(f32x16 (&acc)[G::RT1][G::PTW], ws_rsrc_t rs, int fr,
                                         const float* __restrict__ lds, const int (&off)[G::PTW][NS],
                                         const float (&wgt)[G::PTW][NS], int lane) {
     float raw[G::PTW][4][NS];
     float4 a[2][G::RT1];
-    adj_issue<G, NS>(raw, a[0], fr, lds, off, 0, lane);
+    adj_issue<G, NS>(raw, a[0], rs, fr, lds, off, 0, lane);
 #pragma unroll
     for (int cg = 0; cg < G::NCG; ++cg) {
         GroupOps<G::RT1, G::PTW> o;
         adj_combine<G, NS>(o, raw, a[cg & 1], wgt);
-        if (cg + 1 < G::NCG) adj_issue<G, NS>(raw, a[(cg + 1) & 1], fr, lds, off, cg + 1, lane);
+        if (cg + 1 < G::NCG) adj_issue<G, NS>(raw, a[(cg + 1) & 1], rs, fr, lds, off, cg + 1, lane);
         __builtin_amdgcn_sched_barrier(0);
         group_mma<G::RT1, G::PTW>(acc, o, 4);
         __builtin_amdgcn_sched_barrier(0);
@@ -165,6 +165,8 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
     int pix[PTW], pin[PTW];
 #pragma unroll
     for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q] % HW; }
+    // packed weights through buffer resources: fragment offsets are scalars (cf_step_common.h)
+    const ws_rsrc_t rsw = ws_rsrc(ws, G::WS_FLOATS), rsb = ws_rsrc(wsb, Bw::WS_FLOATS);
 
     // ---------------------------------------------------------------- forward recompute
     float y1[PTW][NR];
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
         for (int rt = 0; rt < RT03; ++rt)
 #pragma unroll
             for (int q = 0; q < PTW; ++q) acc0[rt][q] = bias_tile(ws + G::OFF_B0 + rt * 32, lk);
-        dense_phase<G, G::KS0, G::NG0, RT03>(acc0, reinterpret_cast<const float4*>(ws + G::OFF_A0), H1, pix, lane);
+        dense_phase<G, G::KS0, G::NG0, RT03>(acc0, rsw, G::OFF_A0, H1, pix, lane);
 #pragma unroll
         for (int q = 0; q < PTW; ++q)
 #pragma unroll
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
         for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
             for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B1 + rt * 32, lk);
-        dense_phase<G, G::KS1, G::NG1, RT1>(acc, reinterpret_cast<const float4*>(ws + G::OFF_A1), Y0, pix, lane);
+        dense_phase<G, G::KS1, G::NG1, RT1>(acc, rsw, G::OFF_A1, Y0, pix, lane);
 #pragma unroll
         for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
@@ -240,7 +242,6 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
         for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
             for (int q = 0; q < PTW; ++q) acc[rt][q] = bias_tile(ws + G::OFF_B2 + rt * 32, lk);
-        const float4* frags = reinterpret_cast<const float4*>(ws + G::OFF_A2);
         GroupOps<RT1, PTW> ops[2];
         auto tap_src = [&](int tap, int (&src)[PTW]) {
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -252,9 +253,9 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
             }
         };
-        auto load = [&](const float4* fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+        auto load = [&](int fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
 #pragma unroll
-            for (int rt = 0; rt < RT1; ++rt) o.a[rt] = fr[rt * 64 + lane];
+            for (int rt = 0; rt < RT1; ++rt) o.a[rt] = ws_frag(rsw, lane, fr + rt * 256);
 #pragma unroll
             for (int q = 0; q < PTW; ++q)
 #pragma unroll
@@ -262,14 +263,14 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
         };
         int src_cur[PTW], src_nxt[PTW];
         tap_src(0, src_cur);
-        load(frags, src_cur, 0, ops[0]);
+        load(G::OFF_A2, src_cur, 0, ops[0]);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             tap_src(min(tap + 1, 8), src_nxt);
-            const float4* fr = frags + (int64_t)tap * G::NCG * RT1 * 64;
+            const int fr = G::OFF_A2 + tap * G::NCG * RT1 * 256;
 #pragma unroll
             for (int cg = 0; cg < G::NCG; ++cg) {
-                const float4* fn = fr + (cg + 1) * RT1 * 64;
+                const int fn = fr + (cg + 1) * RT1 * 256;
                 if (cg + 1 < G::NCG) load(fn, src_cur, cg + 1, ops[(cg + 1) & 1]);
                 else load(tap < 8 ? fn : fr, src_nxt, 0, ops[0]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
         for (int rt = 0; rt < RT03; ++rt)
 #pragma unroll
             for (int q = 0; q < PTW; ++q) acc3[rt][q] = bias_tile(ws + G::OFF_B3 + rt * 32, lk);
-        dense_phase<G, G::KS3, G::NG3, RT03>(acc3, reinterpret_cast<const float4*>(ws + G::OFF_A3), H1, pix, lane);
+        dense_phase<G, G::KS3, G::NG3, RT03>(acc3, rsw, G::OFF_A3, H1, pix, lane);
 #pragma unroll
         for (int q = 0; q < PTW; ++q)
 #pragma unroll
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
             for (int q = 0; q < PTW; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][q][r] = 0.f;
-        dense_phase<G, G::KS0, G::NG0, RT1>(acc, reinterpret_cast<const float4*>(wsb + Bw::OFF_A3T), GH, pix, lane);
+        dense_phase<G, G::KS0, G::NG0, RT1>(acc, rsb, Bw::OFF_A3T, GH, pix, lane);
 #pragma unroll
         for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
@@ -372,8 +373,8 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
             for (int q = 0; q < PTW; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][q][r] = 0.f;
-        const float4* frags = reinterpret_cast<const float4*>(wsb + Bw::OFF_A2T);
-        constexpr int TAPF = G::NCG * RT1 * 64;              // float4 fragments per tap
+        constexpr int frags = Bw::OFF_A2T;
+        constexpr int TAPF = G::NCG * RT1 * 256;             // fragment floats per tap
         int py[PTW], px[PTW], base[PTW];
 #pragma unroll
         for (int q = 0; q < PTW; ++q) { py[q] = pin[q] / W; px[q] = pin[q] % W; base[q] = HALF * PIX + (pix[q] - pin[q]) + lk * PIX; }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
             float wgt[PTW][1];
 #pragma unroll
             for (int q = 0; q < PTW; ++q) { off[q][0] = base[q] + pin[q]; wgt[q][0] = 1.f; }
-            adj_tap<G, 1>(acc, frags + 4 * TAPF, lds, off, wgt, lane);
+            adj_tap<G, 1>(acc, rsb, frags + 4 * TAPF, lds, off, wgt, lane);
         }
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {                        // edge taps 1, 3, 5, 7: main + one reflected source
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                 off[q][1] = base[q] + (vert ? ys[1] : ys[0]) * W + (vert ? xs[0] : xs[1]);
                 wgt[q][1] = (vert ? (yv[1] && xv[0]) : (yv[0] && xv[1])) ? 1.f : 0.f;
             }
-            adj_tap<G, 2>(acc, frags + tap * TAPF, lds, off, wgt, lane);
+            adj_tap<G, 2>(acc, rsb, frags + tap * TAPF, lds, off, wgt, lane);
         }
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {                        // corner taps 0, 2, 6, 8: up to four sources
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                         wgt[q][2 * a + b] = (yv[a] && xv[b]) ? 1.f : 0.f;
                     }
             }
-            adj_tap<G, 4>(acc, frags + tap * TAPF, lds, off, wgt, lane);
+            adj_tap<G, 4>(acc, rsb, frags + tap * TAPF, lds, off, wgt, lane);
         }
         __syncthreads();                 // everyone done reading g_h2
 #pragma unroll
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
         for (int q = 0; q < PTW; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][q][r] = 0.f;
-        dense_phase<G, G::KS3, G::NG3, 1>(acc, reinterpret_cast<const float4*>(wsb + Bw::OFF_A1T), H1, pix, lane);
+        dense_phase<G, G::KS3, G::NG3, 1>(acc, rsb, Bw::OFF_A1T, H1, pix, lane);
         // rows of this single tile are channels 0..31 in natural order: row = tile_row(r, lk) for r = 0..15
         float* GY = H1;                                   // g_y plane rows [0,C) (g_h1 is dead for this wave now)
 #pragma unroll
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
             for (int q = 0; q < PTW; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ax[rt][q][r] = 0.f;
-        dense_phase<G, G::KS0, G::NG0, Bw::RTI>(ax, reinterpret_cast<const float4*>(wsb + Bw::OFF_A0T), GY, pix, lane);
+        dense_phase<G, G::KS0, G::NG0, Bw::RTI>(ax, rsb, Bw::OFF_A0T, GY, pix, lane);
         float* GX = H1 + C * PIX;
         tiles_to_plane<G, Bw::RTI>(ax, GX, C, pix, lk);
         rows_store_t<G, C, C>(gx, GX, b0, B, wave, lane);
