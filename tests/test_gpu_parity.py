@@ -551,23 +551,33 @@ def test_edge_batches_and_layouts(L, name):
 
 
 # ------------------------------------------------------------------------------------------ training step (backward)
-@pytest.mark.parametrize("name,B", [("mnist", 6), ("cifar10", 5), ("smap", 7), ("atm", 3)])
-def test_backward_against_autograd_oracle(L, name, B):
+@pytest.mark.parametrize("name,B,tag", [("mnist", 6, None), ("cifar10", 5, None), ("smap", 7, None), ("atm", 3, None),
+                                        ("mnist", 5, "stress"), ("cifar10", 4, "stress"), ("smap", 6, "stress")])
+def test_backward_against_autograd_oracle(L, name, B, tag):
     """d sum(w * logp) / d parameters: the hand-written backward (fused HIP step-backward kernel, the layer-by-layer
     backward of TransCoupling / SimpleViT for smap, library GEMMs) against torch.autograd run through the CPU oracle
     in fp64 on the same inputs, noise and parameters."""
     from tests.gpu_util import build_model, set_noise
-    ops, _, M, params, fx = load_e2e(name)
+    ops, _, M, params, fx = load_e2e(name, tag)           # tag "stress": trained-like parameters (saturated log-scales, ...)
     C, H, W = fo.CONFIGS[name][0]
     g = torch.Generator().manual_seed(21)
     x = torch.rand(B, C, H, W, generator=g) if name in ("smap", "atm") else torch.randint(0, 256, (B, C, H, W), generator=g).float()
     u = torch.rand(B, C, H, W, generator=g)
     eps = [torch.randn(B, 1, H, W, generator=g)]
+    if tag:                      # the fixture's own samples: the mixture components sit on THEIR latents (moderate |logp|)
+        fxx, fxu, fxe = e2e_inputs(name, fx)
+        x, eps = fxx[:B], [e[:B] for e in fxe]
+        u = fxu[:B] if fxu is not None else u
     wts = torch.randn(B, M, generator=g)
     # oracle, fp64, autograd
     p64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in params.items()}
     _, lp = fo.flow_forward(ops, p64, x.double(), u.double(), [e.double() for e in eps])
     (lp * wts.double()).sum().backward()
+    p32 = None
+    if tag:                      # stress regime: the fp32 noise floor of the gradients themselves (torch.autograd in fp32)
+        p32 = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in params.items()}
+        _, lp32 = fo.flow_forward(ops, p32, x, u, eps)
+        (lp32 * wts).sum().backward()
     # product
     model = build_model(name, params)
     set_noise(model, u, eps)
@@ -587,8 +597,12 @@ def test_backward_against_autograd_oracle(L, name, B):
         scale = max(ref.abs().max().item(), 1e-3)
         err = (got - ref).abs().max().item() / scale
         # measured (tools/dev/bwd_errors.py, profiles/r2_backward_errors.md): worst tensor 4.6e-5 (cifar10 split-prior
-        # means), every tensor below the error fp32 torch.autograd itself makes on the same graph (up to 1.8e-4)
-        assert err < 1e-4, "%s: relative grad error %.3e (scale %.3e)" % (k, err, scale)
+        # means), every tensor below the error fp32 torch.autograd itself makes on the same graph (up to 1.8e-4).
+        # Stress parameters (sigma down to 0.13, saturated log-scales): the bar is 3x that fp32 floor where it exceeds 1e-4
+        tol = 1e-4
+        if p32 is not None:
+            tol = max(tol, 3.0 * (p32[k].grad.double() - ref).abs().max().item() / scale)
+        assert err < tol, "%s: relative grad error %.3e (scale %.3e, bar %.1e)" % (k, err, scale, tol)
         checked += 1
     assert checked >= 30
 
