@@ -281,8 +281,11 @@ class FlowSequential(nn.Module):
                     if cache_ok:
                         self._prep[(key, "prior")] = (pver, prior)
 
-        ld1 = torch.zeros(B, device=dev, dtype=torch.float32)       # per-sample scalar log-dets
-        ldM = torch.zeros(B, M, device=dev, dtype=torch.float32)    # per-mixture terms (priors)
+        # running log-dets: per-sample scalar terms / per-mixture terms (priors).  The first writer ASSIGNS (no zero-fill
+        # launches): the pre-processing kernel for ld1, the first mixture kernel for ldM
+        ld1 = (torch.empty if plan and plan[0][0] == "pre" else torch.zeros)(B, device=dev, dtype=torch.float32)
+        ldM = torch.empty(B, M, device=dev, dtype=torch.float32)
+        ldM_set = False
         st = _hip.stream()
         for k, op in enumerate(plan):
             kind = op[0]
@@ -369,21 +372,26 @@ class FlowSequential(nn.Module):
                 if tape is not None:
                     tape.append(("split", x, op[1].dist, prep))
                 c = x.shape[1] // 2
-                gmm_logprob(x[:, c:], prep, out=ldM, accumulate=True)
+                gmm_logprob(x[:, c:], prep, out=ldM, accumulate=ldM_set)
+                ldM_set = True
                 x = x[:, :c]
             else:                        # any other layer: its own kernels
                 if tape is not None:
                     tape.append(("layer", op[1], x))
                 x, ldj = op[1](x, context)
                 if ldj.dim() == 2:
-                    ldM += ldj
+                    if ldM_set:
+                        ldM += ldj
+                    else:
+                        ldM.copy_(ldj.expand_as(ldM))
+                        ldM_set = True
                 else:
                     ld1 += ldj
         if ev_prior is not None:
             main.wait_event(ev_prior)
         if tape is not None:
             tape.append(("prior", x, self.dist, prior))
-        gmm_logprob(x, prior, out=ldM, accumulate=True)
+        gmm_logprob(x, prior, out=ldM, accumulate=ldM_set)
         logp = torch.empty(B, M, device=dev, dtype=torch.float32)
         _hip.call("cf_logdet_combine", _hip.p(ldM), _hip.p(ld1), _hip.p(logp), B, M, st)
         # buffers written on the side stream are consumed on the main stream: keep the allocator informed
