@@ -97,11 +97,15 @@ __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict_
     const int dlo = blockIdx.z * dsplit;
     const int dhi = min(D, dlo + dsplit);
 
-    float acc[SPT][MKT];
+    // packed along d: element .x sums the even, .y the odd feature columns - both v_pk_fma_f32 operands of a term are then
+    // natural register pairs (x[s][d, d+1], a[mk][d, d+1]) with no broadcast.  (Written with scalars, hipcc packs across
+    // samples / components instead and spends 140 v_mov per 160 v_pk_fma on building the broadcast pairs.)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[SPT][MKT];
 #pragma unroll
     for (int i = 0; i < SPT; ++i)
 #pragma unroll
-        for (int j = 0; j < MKT; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < MKT; ++j) acc2[i][j] = f32x2{0.f, 0.f};
 
     float4 px[XITEMS], pa[PITEMS], pb[PITEMS];
     // rows past B / past the last component are clamped to a valid row: their results are never written
@@ -146,24 +150,28 @@ __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict_
 #pragma unroll 2
         for (int dd = 0; dd < DC; dd += 2) {
             // 8-byte LDS reads: same bytes per LDS cycle as 16-byte ones, half the operand registers
-            float2 xv[SPT], av[MKT], bv[MKT];
+            f32x2 xv[SPT], av[MKT], bv[MKT];
 #pragma unroll
-            for (int i = 0; i < SPT; ++i) xv[i] = *reinterpret_cast<const float2*>(&xs[(ts + 16 * i) * LD + dd]);
+            for (int i = 0; i < SPT; ++i) xv[i] = *reinterpret_cast<const f32x2*>(&xs[(ts + 16 * i) * LD + dd]);
 #pragma unroll
             for (int j = 0; j < MKT; ++j) {
-                av[j] = *reinterpret_cast<const float2*>(&as_[(tm + 16 * j) * LD + dd]);
-                bv[j] = *reinterpret_cast<const float2*>(&bs[(tm + 16 * j) * LD + dd]);
+                av[j] = *reinterpret_cast<const f32x2*>(&as_[(tm + 16 * j) * LD + dd]);
+                bv[j] = *reinterpret_cast<const f32x2*>(&bs[(tm + 16 * j) * LD + dd]);
             }
 #pragma unroll
             for (int i = 0; i < SPT; ++i)
 #pragma unroll
                 for (int j = 0; j < MKT; ++j) {
-                    float t;
-                    t = fmaf(xv[i].x, av[j].x, bv[j].x); acc[i][j] = fmaf(t, t, acc[i][j]);
-                    t = fmaf(xv[i].y, av[j].y, bv[j].y); acc[i][j] = fmaf(t, t, acc[i][j]);
+                    const f32x2 t = __builtin_elementwise_fma(xv[i], av[j], bv[j]);
+                    acc2[i][j] = __builtin_elementwise_fma(t, t, acc2[i][j]);
                 }
         }
     }
+    float acc[SPT][MKT];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i)
+#pragma unroll
+        for (int j = 0; j < MKT; ++j) acc[i][j] = acc2[i][j].x + acc2[i][j].y;
 
     if (SPLIT) {
         float* qb = qout + (int64_t)blockIdx.z * B * MKtot;
