@@ -132,6 +132,7 @@ template <int RT>
 __device__ __forceinline__ void vgemm(f32x16 (&acc)[RT], const float* __restrict__ frags, int ng,
                                       const float* __restrict__ plane, int col, int lane) {
     const float4* fr = reinterpret_cast<const float4*>(frags);
+    cf_wave_sync();                      // the operand plane was written by other lanes of this wave (cf_common.h)
     VOps<RT> o0, o1;
     vload<RT>(o0, fr, 0, plane, col, lane);
 #pragma unroll 1
@@ -155,10 +156,12 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[RT], float* __re
             const int row = rt * 32 + trow(r, lk);
             if (row < rows) plane[row * VR + col] = acc[rt][r];
         }
+    cf_wave_sync();
 }
 // acc = plane (+ bias)
 __device__ __forceinline__ void load_tiles2(f32x16 (&acc)[2], const float* __restrict__ plane, const float* __restrict__ bias,
                                             int col, int lk) {
+    cf_wave_sync();
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -171,6 +174,7 @@ __device__ __forceinline__ void load_tiles2(f32x16 (&acc)[2], const float* __res
 // The two half-waves (lanes l and l+32 hold the same token) split the features.
 __device__ __forceinline__ void col_layernorm(const float* __restrict__ src, float* __restrict__ dst, int D,
                                               const float* __restrict__ ln, const float* __restrict__ extra, int col, int lk) {
+    cf_wave_sync();                      // src rows were written by the other lane half of this token
     float s = 0.f;
     for (int f = lk; f < D; f += 2) s += src[f * VR + col];
     s += __shfl_xor(s, 32, 64);
@@ -184,6 +188,7 @@ __device__ __forceinline__ void col_layernorm(const float* __restrict__ src, flo
         if (extra) o += extra[f];
         dst[f * VR + col] = o;
     }
+    cf_wave_sync();
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------
@@ -210,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_coupling(const float* __restrict
         const int c = f % cin, ii = f / cin;
         Y[f * VR + col] = xb[(int64_t)c * HW + (py0 + ii / p2) * W + px0 + ii % p2];
     }
+    cf_wave_sync();
     col_layernorm(Y, Y, pd, ws + L.ln0, nullptr, col, lk);                    // to_patch_embedding.1
     {
         f32x16 acc[2];
@@ -288,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_coupling(const float* __restrict
         }
     }
     col_layernorm(X, Y, dim, ws + L.lnO, nullptr, col, lk);                   // transformer.norm
+    cf_wave_sync();
 
     // ---- un-patchify (simple_vit.py:115) + affine coupling map (coupling.py:139-155) + log-det
     // net output channel ch of pixel (i1,i2) of this token = feature (i1*p2+i2)*C + ch; t = ch < C/2, raw = ch >= C/2

@@ -183,24 +183,42 @@ class FlowSequential(nn.Module):
             i += 1
         return ops
 
+    def _noise_epoch(self, dev):
+        """Detects `torch.manual_seed` - also with an unchanged seed value - since the last call: the seed itself, and the
+        Philox offset of torch's CUDA generator for `dev`, which a re-seed resets to 0 and which this class bumps by 4 per
+        check (nothing else needs it to stand still).  Returns (seed, epoch); the epoch counts the re-seeds seen."""
+        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        st = self._rng_latched.get(dev.index)
+        off = None
+        if not torch.cuda.is_current_stream_capturing():
+            gen = torch.cuda.default_generators[dev.index]
+            off = gen.get_offset()
+        if st is None:
+            st = self._rng_latched[dev.index] = [seed, -1, 0]           # [seed, last offset seen, epoch]
+        if st[0] != seed or (off is not None and off <= st[1]):
+            st[0], st[2] = seed, st[2] + 1
+        if off is not None:
+            gen.set_offset(off + 4)
+            st[1] = off
+        return seed, st[2]
+
     def _rng_state(self, dev):
         """Device-resident position of the in-kernel noise stream (one uint64 per device).  The Philox key follows
-        torch's seed: after `torch.manual_seed(s)` the stream restarts from position 0 under the new key, so reseeding
+        torch's seed: after `torch.manual_seed(s)` the stream restarts from position 0 under the key of s, so re-seeding
         reproduces the noise as it does in the reference (uniform.py:32, gaussian.py:69).  Data-parallel ranks fold their
         rank into the key: equal seeds on every rank still give every rank its own dequantisation / Augment noise."""
-        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        seed, epoch = self._noise_epoch(dev)
         st = self._rng.get(dev.index)
         if st is None:
-            st = self._rng[dev.index] = torch.zeros(1, device=dev, dtype=torch.int64)
-            self._rng_latched[dev.index] = seed
-        elif self._rng_latched.get(dev.index) != seed:
-            st.zero_()
-            self._rng_latched[dev.index] = seed
+            st = self._rng[dev.index] = [torch.zeros(1, device=dev, dtype=torch.int64), epoch]
+        elif st[1] != epoch:
+            st[0].zero_()
+            st[1] = epoch
         rank = 0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank = torch.distributed.get_rank()
         self._rng_seed = (seed ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
-        return st
+        return st[0]
 
     def _side_stream(self, dev):
         s = self._side.get(dev.index)
@@ -458,7 +476,8 @@ class FlowSequential(nn.Module):
             if d is not None and getattr(d, "fixed_noise", None) is not None:
                 return None
         gkey = (tuple(x.shape), x.dtype, x.device)
-        ver = self._versions()
+        ver = self._versions() + self._noise_epoch(x.device)   # the Philox key is a kernel argument baked into the graph,
+        #                                                        and a re-seed restarts the stream: both drop the graph
         st = self._graphs.get(gkey)
         if st is None or st[1] != ver:
             if len(self._graphs) >= 8:                   # bounded: each graph owns its intermediates

@@ -1186,6 +1186,49 @@ def test_specialist_backward_against_autograd_oracle(L, fxname):
     assert checked >= 20
 
 
+def test_encoder_noise_is_taped_per_forward(L):
+    """Flow-type context encoders (vardeq): the backward replays the Gaussian draw of ITS OWN forward.  Two forwards
+    (different injected noise), then the backward of the FIRST: gradients must equal the oracle's for the first forward -
+    a draw kept as module state would have been overwritten by the second call."""
+    import contextflow_amd as cfa
+    from tests.helpers import load_specialist
+    from tests.gpu_util import set_noise
+    name, ctx, ops, M, params, inp = load_specialist("cifar10_eye_vardeq_cf")
+    B = inp["x"].shape[0]
+    g = torch.Generator().manual_seed(5)
+    wts = torch.randn(B, M, generator=g)
+    p64 = {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in params.items()}
+    _, lp = fo.flow_forward(ops, p64, inp["x"].double(), inp["u"].double(), [e.double() for e in inp["eps"]], ctx=ctx,
+                            context=inp["context"], cnoise=[c.double() for c in inp["cnoise"]])
+    (lp * wts.double()).sum().backward()
+    cfg, ds, MM = cfa.preset_config(name)
+    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type=ctx["enc_type"], contextflow=ctx["contextflow"])
+    model = cfa.create_model(cfg, ds, MM, contexts=ctx["contexts"])
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).train()
+    set_noise(model, inp["u"], inp["eps"])
+    encs = [m for m in model.modules() if isinstance(m, cfa.layers.ConditionalGaussianDistribution)]
+    assert len(encs) == len(inp["cnoise"])
+    for e, c in zip(encs, inp["cnoise"]):
+        e.fixed_noise = c.to(DEV)
+    _, logp_a = model(inp["x"].to(DEV), inp["context"].to(DEV))
+    for e, c in zip(encs, inp["cnoise"]):                        # second forward: other noise
+        e.fixed_noise = (-c.flip(0)).to(DEV)
+    _, logp_b = model(inp["x"].to(DEV), inp["context"].to(DEV))
+    assert not torch.equal(logp_a, logp_b)
+    (logp_a * wts.to(DEV)).sum().backward()                      # backward of the FIRST forward
+    checked = 0
+    for k, p in model.named_parameters():
+        ref = p64[k].grad
+        if not p.requires_grad or ref is None or float(ref.abs().max()) == 0.0:
+            continue
+        scale = max(ref.abs().max().item(), 1e-3)
+        err = (p.grad.detach().cpu().double() - ref).abs().max().item() / scale
+        assert err < 2e-4, "%s: relative grad error %.3e" % (k, err)
+        checked += 1
+    assert checked >= 20
+
+
 @pytest.mark.parametrize("name,contexts,emb,typ,cflow", [
     ("mnist", [64], "eye", "uniform", False),            # README.md:56
     ("cifar10", [15, 5], "onehot", "vardeq", False),     # README.md:61
@@ -1356,6 +1399,28 @@ def test_conv_coupling_backward_against_autograd_oracle(L, kind):
         assert err < 1e-4, (name, err)
         checked += 1
     assert checked == 6
+
+
+def test_in_kernel_noise_follows_torch_seed(L):
+    """The in-kernel Philox stream is keyed by torch's seed: re-seeding reproduces the noise (as `torch.manual_seed` does
+    for the reference's torch.rand / randn draws), another seed gives other noise - eagerly and through the auto-captured
+    graph (whose kernel arguments hold the key: a re-seed must drop it)."""
+    from tests.gpu_util import build_model
+    ops, _, M, params, fx = load_e2e("mnist")
+    model = build_model("mnist", params)
+    x = torch.randint(0, 256, (32, 1, 32, 32), generator=torch.Generator().manual_seed(1)).float().to(DEV)
+
+    def run(seed, n):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            return [model.log_prob(x).clone() for _ in range(n)]
+    a = run(7, 5)            # calls 3.. replay a captured graph
+    b = run(7, 5)
+    c = run(8, 2)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert not torch.equal(a[0], a[1])                               # successive calls draw fresh noise
+    assert not torch.equal(a[0], c[0])
 
 
 def test_in_kernel_noise_statistics(L):
