@@ -53,8 +53,9 @@ __global__ __launch_bounds__(256) void k_step_pack_bwd(const float* __restrict__
     }
     for (int e = gtid; e < G::NG0 * Bw::RTI * 256; e += gsz) {               // A0T[k_in][c] = e^{-logs[c]} Wm[c][k_in]
         split(e, Bw::RTI, g, rt, lane, j);
-        const int row = rt * 32 + (lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
-        wsb[Bw::OFF_A0T + e] = (row < G::C && k < G::C) ? expf(-logs[k]) * Wm[k * G::C + row] : 0.f;
+        const int row = rt * 32 + (lane & 31), kk = 2 * (4 * g + j) + (lane >> 5);
+        const int k = kk < G::HALF ? kk + G::HALF : kk - G::HALF;          // the g_y plane sits in LDS as [g_y1 ; g_y0]
+        wsb[Bw::OFF_A0T + e] = (row < G::C && kk < G::C) ? expf(-logs[k]) * Wm[k * G::C + row] : 0.f;
     }
 }
 
@@ -147,7 +148,7 @@ __device__ __forceinline__ void adj_axis(int c, int d, int N, int (&src)[2], boo
 // TAPED: s_y0 / s_h1 / s_h2 are INPUTS written by the training forward (cf_flow_step_fwd_taped): h1 / h2 are loaded for
 // their ReLU masks and as the operand of phase 3, the two big contractions of the recompute (phases 1, 2) are skipped.
 template <class G, bool SQ, int CTX = 0, bool TAPED = false>
-__global__ __launch_bounds__(256) void k_flow_step_bwd(
+__global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
     const float* __restrict__ x, const float* __restrict__ gz, const float* __restrict__ gld,
     const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ gx,
     float* __restrict__ s_y0, float* __restrict__ s_h1, float* __restrict__ s_h2, float* __restrict__ s_gh,
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int idx = tile_row(r, lk);
-                if (idx < HALF) Y0[idx * PIX + pix[q]] = acc0[0][q][r];
+                if constexpr (!TAPED) { if (idx < HALF) Y0[idx * PIX + pix[q]] = acc0[0][q][r]; }   // operand of phase 1
                 y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
             }
         if constexpr (CTX == 0 && !TAPED) rows_store_t<G, HALF, HALF>(s_y0, Y0, b0, B, wave, lane);   // weight-gradient operand plane
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                         const int row = rt * 32 + tile_row(r, lk);
                         if (row < HID) b |= (H1[row * PIX + pix[q]] > 0.f ? 1u : 0u) << r;
                     }
+                    asm volatile("" : "+v"(b));   // opaque: or hipcc keeps the 16 compare results apart instead (spills)
                     m[rt][q] = b;
                 }
         };
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                     m |= (acc[rt][q][r] > 0.f ? 1u : 0u) << r;
                     acc[rt][q][r] = v;
                 }
+                asm volatile("" : "+v"(m));
                 m1[rt][q] = m;
             }
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
                     m |= (acc[rt][q][r] > 0.f ? 1u : 0u) << r;
                     acc[rt][q][r] = cf_relu(acc[rt][q][r]);
                 }
+                asm volatile("" : "+v"(m));
                 m2[rt][q] = m;
             }
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);
@@ -320,7 +324,8 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
 
     // ---------------------------------------------------------------- backward
     // upstream gradient g_z -> LDS plane (H rows [0,C), own columns: h2 there is dead for this wave)
-    float gz0[PTW][NR], gy1[PTW][NR];
+    // g_y1 = g_z1 e^{ls} is parked in the Y0 region (dead since phase 1) until the last phase; g_z0 is fetched again there:
+    // neither stays in registers across the transposed 3x3 (2 workgroups per CU need <= 256 registers per lane)
     {
         float4 gr[XI];
         x_load<G, false>(gr, gz, (int64_t)C * HW, tile, B, wave, lane);
@@ -333,17 +338,17 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
             for (int r = 0; r < NR; ++r) {
                 const int idx = tile_row(r, lk);
                 if (idx < HALF) {
-                    const float g0 = H1[idx * PIX + pix[q]], g1 = H1[(HALF + idx) * PIX + pix[q]];
+                    const float g1 = H1[(HALF + idx) * PIX + pix[q]];
                     const float e = __expf(ls[q][r]);
-                    gz0[q][r] = g0;
-                    gy1[q][r] = g1 * e;                                              // d z1 / d y1
+                    Y0[idx * PIX + pix[q]] = g1 * e;                                 // g_y1 = d z1 / d y1
                     const float gls = g1 * y1[q][r] * e + gl;                        // d/d log_s (+ the log-det path)
                     GH[idx * PIX + pix[q]] = g1;                                     // d z1 / d t
                     GH[(HALF + idx) * PIX + pix[q]] = gls * (1.0f - 0.25f * ls[q][r] * ls[q][r]);   // d log_s / d raw
-                } else { gz0[q][r] = 0.f; gy1[q][r] = 0.f; }
+                }
             }
         }
         rows_store_t<G, C, C>(s_gh, GH, b0, B, wave, lane);
+        if constexpr (CTX == 0) rows_store_t<G, HALF, C>(s_gy + HALF * HW, Y0, b0, B, wave, lane);   // g_y1 rows of the g_y plane
         // g_h2 = (NN.4^T g_h) * [h2 > 0]
         f32x16 acc[RT1][PTW];
 #pragma unroll
@@ -436,33 +441,30 @@ __global__ __launch_bounds__(256) void k_flow_step_bwd(
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);       // g_h1 plane
         if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_gh1, H1, b0, B, wave, lane);   // weight-gradient operand plane
     }
-    {   // g_y0 = NN.0^T g_h1 + g_z0 ;  g_y plane = [g_y0 | g_y1] -> Y0 (HALF rows) + ... stored as C rows in the H region
+    {   // g_y0 = NN.0^T g_h1 + g_z0: the accumulators start from g_z0 (rows of the single tile = channels 0..31 in
+        // natural order; read again from global memory, 128 contiguous bytes per row and half wave)
         f32x16 acc[1][PTW];
 #pragma unroll
-        for (int q = 0; q < PTW; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][q][r] = 0.f;
-        dense_phase<G, G::KS3, G::NG3, 1>(acc, rsb, Bw::OFF_A1T, H1, pix, lane);
-        // rows of this single tile are channels 0..31 in natural order: row = tile_row(r, lk) for r = 0..15
-        float* GY = H1;                                   // g_y plane rows [0,C) (g_h1 is dead for this wave now)
-#pragma unroll
         for (int q = 0; q < PTW; ++q) {
+            const float* gzp = gz + (int64_t)min(b0 + pix[q] / HW, B - 1) * C * HW + pin[q];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = tile_row(r, lk);
-                if (row < HALF) {
-                    // g_z0 lives in the packed-tile register layout: its register for channel `row` is r itself when
-                    // HALF <= 16 (rows 0..15 <-> regs 0..7) and r when HALF == 32 (regs 0..15)
-                    GY[row * PIX + pix[q]] = acc[0][q][r] + gz0[q][HALF <= 16 ? (r & 7) : r];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int idx = tile_row(r, lk);
-                if (idx < HALF) GY[(HALF + idx) * PIX + pix[q]] = gy1[q][r];
+                acc[0][q][r] = (HALF >= 32 || row < HALF) ? gzp[row * HW] : 0.f;
             }
         }
-        if constexpr (CTX == 0) rows_store_t<G, C, C>(s_gy, GY, b0, B, wave, lane);   // weight-gradient operand plane
+        dense_phase<G, G::KS3, G::NG3, 1>(acc, rsb, Bw::OFF_A1T, H1, pix, lane);
+        // g_y plane in LDS: rows [0, HALF) = g_y1 (the Y0 region, parked above), rows [HALF, C) = g_y0 (first rows of the H
+        // region: g_h1 is dead for this wave now); A0T is packed with its k in that order
+        float* GY = lds;
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tile_row(r, lk);
+                if (row < HALF) H1[row * PIX + pix[q]] = acc[0][q][r];
+            }
+        if constexpr (CTX == 0) rows_store_t<G, HALF, C>(s_gy, H1, b0, B, wave, lane);   // g_y0 rows (weight-gradient operand plane)
         // g_x = (e^{-logs} Wm)^T g_y
         f32x16 ax[Bw::RTI][PTW];
 #pragma unroll

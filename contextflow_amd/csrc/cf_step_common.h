@@ -240,37 +240,50 @@ __device__ __forceinline__ void z_store(float* __restrict__ z, const float* __re
     rows_store<G, G::HALF>(z, plane, tb0, ch0, B, wave, lane);
 }
 
-// rows_store for a target tensor with CT channels per sample, and its inverse (global -> this wave's columns of a plane)
+// rows_store for a target tensor with CT channels per sample, and its inverse (global -> this wave's columns of a plane).
+// Both go through a buffer resource that covers exactly the VALID samples of this workgroup's tile of the tensor: the
+// per-lane byte offset is one 32-bit register for every plane of that shape (item i adds a constant, which travels in the
+// scalar offset operand), there is no 64-bit address arithmetic and no `b < B` compare - an access beyond the last sample
+// is out of range for the resource: stores are dropped and loads return 0 by the hardware's range check.
+template <class G, int CT>
+__device__ __forceinline__ ws_rsrc_t tile_rsrc(const float* t, int tb0, int B) {
+    const int nb = min(B - tb0, G::SPW);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t + (int64_t)tb0 * CT * G::HW), 0, nb * CT * G::HW * 4, 0x00020000);
+}
 template <class G, int NROWS, int CT>
 __device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const float* __restrict__ plane, int tb0, int B,
                                              int wave, int lane) {
-    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX;
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, RPI = 256 / WPX;     // rows per item of 64 lanes x 16 bytes
+    const ws_rsrc_t rs = tile_rsrc<G, CT>(dst, tb0, B);
+    const int idx0 = lane / (WPX / 4), col = wave * WPX + 4 * (lane % (WPX / 4));
+    const int voff = ((col / HW) * CT * HW + idx0 * HW + col % HW) * 4;
     cf_wave_sync();
 #pragma unroll
-    for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
-        const int n = i * 64 + lane;
-        const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
-        const int b = tb0 + col / HW;
-        if (idx < NROWS && b < B)
-            *reinterpret_cast<float4*>(dst + (int64_t)b * CT * HW + (int64_t)idx * HW + col % HW) =
-                *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
+    for (int i = 0; i < (NROWS + RPI - 1) / RPI; ++i) {
+        if (NROWS % RPI == 0 || idx0 + i * RPI < NROWS) {
+            const float4 v = *reinterpret_cast<const float4*>(&plane[(idx0 + i * RPI) * PIX + col]);
+            const i32x4_t d = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, i * RPI * HW * 4, 0);
+        }
     }
     cf_wave_sync();
 }
 template <class G, int NROWS, int CT>
 __device__ __forceinline__ void rows_load_t(const float* __restrict__ src, float* __restrict__ plane, int tb0, int B,
                                             int wave, int lane) {
-    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX;
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, RPI = 256 / WPX;
+    const ws_rsrc_t rs = tile_rsrc<G, CT>(src, tb0, B);
+    const int idx0 = lane / (WPX / 4), col = wave * WPX + 4 * (lane % (WPX / 4));
+    const int voff = ((col / HW) * CT * HW + idx0 * HW + col % HW) * 4;
     cf_wave_sync();                      // earlier readers of these words (other lanes) are done
 #pragma unroll
-    for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
-        const int n = i * 64 + lane;
-        const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
-        const int b = tb0 + col / HW;
-        if (idx < NROWS) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b < B) v = *reinterpret_cast<const float4*>(src + (int64_t)b * CT * HW + (int64_t)idx * HW + col % HW);
-            *reinterpret_cast<float4*>(&plane[idx * PIX + col]) = v;
+    for (int i = 0; i < (NROWS + RPI - 1) / RPI; ++i) {
+        if (NROWS % RPI == 0 || idx0 + i * RPI < NROWS) {
+            const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, i * RPI * HW * 4, 0);
+            *reinterpret_cast<float4*>(&plane[(idx0 + i * RPI) * PIX + col]) =
+                make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
         }
     }
     cf_wave_sync();

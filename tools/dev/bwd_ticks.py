@@ -27,8 +27,13 @@ for (C, H) in [(16, 16), (32, 8), (64, 4)]:
     new = lambda rows: torch.empty(B, rows, HW, device=dev)
     gx = torch.empty(B, C, H, H, device=dev)
     bufs = [new(HALF), new(HID), new(HID), new(C), new(HID), new(HID), new(C)]
-    run = lambda: L.cf_flow_step_bwd(P(x), P(gz), P(gld), P(ws), P(wsb), P(gx), *[P(b) for b in bufs], I(B), I(C), I(H), I(H),
-                                     ctypes.c_int64(C * HW), I(0), st)
+    taped = os.environ.get("CF_TAPED", "1") != "0"
+    if taped:
+        for b in bufs[:3]:
+            b.normal_()                                   # stand-in tape: half the ReLU masks set
+    fn = L.cf_flow_step_bwd_taped if taped else L.cf_flow_step_bwd
+    run = lambda: fn(P(x), P(gz), P(gld), P(ws), P(wsb), P(gx), *[P(b) for b in bufs], I(B), I(C), I(H), I(H),
+                     ctypes.c_int64(C * HW), I(0), st)
     for _ in range(2):
         assert run() == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
