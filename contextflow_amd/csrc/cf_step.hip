@@ -210,6 +210,13 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
                     const float ls = cf_log_scale(raw);
                     Y0[idx * PIX + pix[q]] = fmaf(y1[q][r], __expf(ls), tt);      // coupling.py:63 (z1, staged in LDS)
                     lsum[q] += ls;
+                    if constexpr (DUMP) {           // tape: 128 contiguous bytes per row and half wave
+                        if (live[q]) {
+                            const int64_t o = ((int64_t)smp[q] * HALF + idx) * HW + pin[q];
+                            tp.ls[o] = ls;
+                            tp.y1[o] = y1[q][r];
+                        }
+                    }
                     if (dbg) {
                         float* d = dbg + (int64_t)(C + 2 * HID) * dbg_cols + (int64_t)tile * PIX + pix[q];
                         d[(int64_t)idx * dbg_cols] = tt;
@@ -334,6 +341,19 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
         __syncthreads();
     };
     if constexpr (DBG) dump(Y0, HALF, 0);
+    // C = 8 (16 hidden rows on 16x16x4 tiles): the tape's ReLU mask words are defined in the 32x32x2 accumulator layout
+    // (StepTape) - taken from the plane in LDS, this wave's own columns (rows_store_t before it ends with a wave fence)
+    auto plane_mask_store = [&](unsigned* __restrict__ m) {
+        const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) {
+            unsigned b = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) b |= (H1[tile_row(r, lk) * PIX + (wave * PTW + q) * 32 + li] > 0.f ? 1u : 0u) << r;
+            m[((int64_t)tile * G::NPT + wave * PTW + q) * 64 + lane] = b;
+        }
+    };
+    (void)plane_mask_store;
 
     // ================= phases 1, 2: h2 = relu(NN.2 (*) relu(NN.0 y0 + b) + b)   (coupling.py:26-27)
     if constexpr (!G::HID16) {
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a1[ct][r]);
-            if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h1, H1, tile, B, wave, lane);
+            if constexpr (DUMP) { rows_store_t<G, HID, HID>(tp.h1, H1, tile, B, wave, lane); plane_mask_store(tp.m1); }
         }
         __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' image rows
         if constexpr (DBG) dump(H1, HID, C);
@@ -396,7 +416,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a2[ct][r]);
-        if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h2, H1, tile, B, wave, lane);
+        if constexpr (DUMP) { rows_store_t<G, HID, HID>(tp.h2, H1, tile, B, wave, lane); plane_mask_store(tp.m2); }
         if constexpr (DBG) dump(H1, HID, C + HID);
     }
     cf_wave_sync();                      // h2: every lane's rows in place before other lanes read them as operands
@@ -430,6 +450,11 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
                 const float ls = cf_log_scale(acc3[ct][j + 2]);
                 Y0[(2 * lg + j) * PIX + colb + 16 * ct] = fmaf(acc0[ct][j + 2], __expf(ls), acc3[ct][j]);     // z1, staged in LDS
                 lsum += ls;
+                if constexpr (DUMP) {
+                    const int64_t o = ((int64_t)tile * HALF + 2 * lg + j) * PIX + colb + 16 * ct;
+                    tp.ls[o] = ls;
+                    tp.y1[o] = acc0[ct][j + 2];
+                }
                 if constexpr (DBG) {
                     float* d = dbg + (int64_t)(C + 2 * HID) * dbg_cols + (int64_t)tile * PIX + colb + 16 * ct;
                     d[(int64_t)(2 * lg + j) * dbg_cols] = acc3[ct][j];
@@ -447,7 +472,7 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
 
 template <class G, bool SQ, bool DBG = false, bool DUMP = false>
 int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s,
-                      float* dbg = nullptr, StepTape tp = StepTape{nullptr, nullptr, nullptr}) {
+                      float* dbg = nullptr, StepTape tp = kNoTape) {
     k_flow_step_small<G, SQ, DBG, DUMP><<<dim3(B), dim3(256), (size_t)G::LDS_FLOATS * sizeof(float), s>>>(x, z, ldj, ws, B, xbs, dbg, tp);
     return 0;
 }
@@ -636,7 +661,7 @@ int launch_prepare(const float* Wm, const float* t, const float* logs, const flo
 
 template <class G, bool SQ, int CTX = 0, bool DUMP = false, bool DBG = false>
 int launch_step(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, float* dbg, int flags,
-                hipStream_t s, const float* sb = nullptr, StepTape tp = StepTape{nullptr, nullptr, nullptr}) {
+                hipStream_t s, const float* sb = nullptr, StepTape tp = kNoTape) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {          // one-time opt-in to > 64 KiB of dynamic LDS (immutable afterwards)
         static std::atomic<uint64_t> raised{0};
@@ -944,15 +969,19 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
 // training forward: the same step, and the conditioner's intermediate planes y0 (B, C/2, H, W), h1, h2 (B, 2C, H, W;
 // post-ReLU) go to the caller's tape.  cf_flow_step_bwd_taped consumes them: it skips the recompute of the two big
 // contractions and uses the planes directly as the operands of the weight-gradient GEMMs.
+int64_t cf_flow_step_tape_aux_bytes(int B, int C, int H, int W) {
+    return shape_id(C, H, W) < 0 ? 0 : tape_aux_bytes(B, C, H, W);
+}
+
 int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* t_y0, float* t_h1, float* t_h2,
-                           int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
+                           void* t_aux, int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(x && z && ldj_acc && ws && t_y0 && t_h1 && t_h2 && x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0);
+    CF_REQUIRE(x && z && ldj_acc && ws && t_y0 && t_h1 && t_h2 && t_aux && x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0);
     CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(t_y0) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_h1) & 15) == 0 &&
-               (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0);
+               (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_aux) & 15) == 0);
     const float* w = (const float*)ws;
-    const StepTape tp{t_y0, t_h1, t_h2};
+    const StepTape tp = make_tape(t_y0, t_h1, t_h2, t_aux, B, C, H, W);
     int rc = 0;
 #define CF_STEPT(G) rc = in_squeeze ? launch_step<G, true, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp) \
                                     : launch_step<G, false, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp)
@@ -1002,14 +1031,15 @@ int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* w
 // parameter trains): cf_flow_step_fwd_ctx that also writes the tape planes of cf_flow_step_fwd_taped.  The per-sample
 // bias only shapes h1, which the backward loads - cf_flow_step_bwd_taped needs no context argument.
 int cf_flow_step_fwd_ctx_taped(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, float* t_y0,
-                               float* t_h1, float* t_h2, int B, int C, int H, int W, int64_t x_bstride, cf_stream_t stream) {
+                               float* t_h1, float* t_h2, void* t_aux, int B, int C, int H, int W, int64_t x_bstride,
+                               cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(x && z && ldj_acc && ws && sbias && t_y0 && t_h1 && t_h2 && x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0);
+    CF_REQUIRE(x && z && ldj_acc && ws && sbias && t_y0 && t_h1 && t_h2 && t_aux && x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0);
     CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(t_y0) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_h1) & 15) == 0 &&
-               (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0);
+               (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_aux) & 15) == 0);
     const float* w = (const float*)ws;
-    const StepTape tp{t_y0, t_h1, t_h2};
+    const StepTape tp = make_tape(t_y0, t_h1, t_h2, t_aux, B, C, H, W);
     int rc = 0;
 #define CF_STEPCT(G) rc = launch_step<G, false, 2, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), sbias, tp)
     switch (shape_id(C, H, W)) {

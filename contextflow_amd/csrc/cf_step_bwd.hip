@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
     const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ gx,
     float* __restrict__ s_y0, float* __restrict__ s_h1, float* __restrict__ s_h2, float* __restrict__ s_gh,
     float* __restrict__ s_gh2, float* __restrict__ s_gh1, float* __restrict__ s_gy, int B, int64_t xbs,
-    const float* __restrict__ sb) {
+    const float* __restrict__ sb, StepTape tp) {
     using Bw = GeoBwd<G>;
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1, NR = (HALF <= 16 ? 8 : 16);
@@ -169,8 +169,34 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
     // packed weights through buffer resources: fragment offsets are scalars (cf_step_common.h)
     const ws_rsrc_t rsw = ws_rsrc(ws, G::WS_FLOATS), rsb = ws_rsrc(wsb, Bw::WS_FLOATS);
 
-    // ---------------------------------------------------------------- forward recompute
-    float y1[PTW][NR];
+    // ---------------------------------------------------------------- what the data-gradient chain needs of the forward
+    // y1 (second half of the Conv1x1 + ActNorm output), ls (log-scale) in the packed-row register layout, and the ReLU
+    // masks of h1 / h2, one bit per accumulator register.  TAPED: all four were written by the training forward
+    // (StepTape: ls / y1 as (B, C/2, HW) planes read 128 contiguous bytes per row and half wave, the masks as words in
+    // exactly this layout) - no step input, no recompute.  Otherwise: the forward is re-run from x in LDS.
+    float y1[PTW][NR], ls[PTW][NR];
+    unsigned m1[RT1][PTW], m2[RT1][PTW];
+    if constexpr (TAPED) {
+#pragma unroll
+        for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                const int64_t w = ((int64_t)(tile * G::NPT + wave * PTW + q) * RT1 + rt) * 64 + lane;
+                m1[rt][q] = tp.m1[w];
+                m2[rt][q] = tp.m2[w];
+            }
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) {
+            const int64_t o = (int64_t)min(b0 + pix[q] / HW, B - 1) * HALF * HW + pin[q];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int idx = tile_row(r, lk);
+                const bool ok = HALF >= 16 || idx < HALF;
+                ls[q][r] = ok ? tp.ls[o + idx * HW] : 0.f;
+                y1[q][r] = ok ? tp.y1[o + idx * HW] : 0.f;
+            }
+        }
+    } else {
     {
         float4 xr[XI];
         x_load<G, SQ>(xr, x, xbs, tile, B, wave, lane);
@@ -191,29 +217,6 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
             }
         if constexpr (CTX == 0 && !TAPED) rows_store_t<G, HALF, HALF>(s_y0, Y0, b0, B, wave, lane);   // weight-gradient operand plane
     }
-    unsigned m1[RT1][PTW], m2[RT1][PTW];       // ReLU masks of h1 / h2, one bit per accumulator register
-    if constexpr (TAPED) {
-        // post-ReLU planes from the tape -> this wave's columns of the H region -> masks in the accumulator layout
-        auto plane_mask = [&](unsigned (&m)[RT1][PTW]) {
-#pragma unroll
-            for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-                for (int q = 0; q < PTW; ++q) {
-                    unsigned b = 0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = rt * 32 + tile_row(r, lk);
-                        if (row < HID) b |= (H1[row * PIX + pix[q]] > 0.f ? 1u : 0u) << r;
-                    }
-                    asm volatile("" : "+v"(b));   // opaque: or hipcc keeps the 16 compare results apart instead (spills)
-                    m[rt][q] = b;
-                }
-        };
-        rows_load_t<G, HID, HID>(s_h1, H1, b0, B, wave, lane);
-        plane_mask(m1);
-        rows_load_t<G, HID, HID>(s_h2, H1, b0, B, wave, lane);
-        plane_mask(m2);
-    } else {
     {   // phase 1
         f32x16 acc[RT1][PTW];
 #pragma unroll
@@ -299,9 +302,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);
         if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_h2, H1, b0, B, wave, lane);   // weight-gradient operand plane
     }
-    }
     // phase 3 -> t, raw
-    float ls[PTW][NR];
     {
         f32x16 acc3[RT03][PTW];
 #pragma unroll
@@ -320,6 +321,8 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
                 }
                 ls[q][r] = cf_log_scale(raw);
             }
+    }
+
     }
 
     // ---------------------------------------------------------------- backward
@@ -492,14 +495,14 @@ int launch_prepare_bwd(const float* Wm, const float* logs, const float* w1, cons
 template <class G, bool SQ, int CTX = 0, bool TAPED = false>
 int launch_step_bwd(const float* x, const float* gz, const float* gld, const float* ws, const float* wsb, float* gx,
                     float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy, int B,
-                    int64_t xbs, hipStream_t s, const float* sb = nullptr) {
+                    int64_t xbs, hipStream_t s, const float* sb = nullptr, StepTape tp = kNoTape) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {
         static std::atomic<uint64_t> raised{0};
         if (int rc_ = cf_raise_dynamic_lds((const void*)k_flow_step_bwd<G, SQ, CTX, TAPED>, 160 * 1024, raised, __func__)) return rc_;
     }
     k_flow_step_bwd<G, SQ, CTX, TAPED><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(
-        x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs, sb);
+        x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs, sb, tp);
     return 0;
 }
 
@@ -563,24 +566,20 @@ int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const vo
     return 0;
 }
 
-// backward of a step whose forward was cf_flow_step_fwd_taped: s_y0 / s_h1 / s_h2 are read, not written.
-int cf_flow_step_bwd_taped(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
-                           const float* t_y0, const float* t_h1, const float* t_h2, float* s_gh, float* s_gh2,
-                           float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, int in_squeeze,
-                           cf_stream_t stream) {
+// backward of a step whose forward was cf_flow_step_fwd_taped: the kernel reads ls / y1 / the two ReLU masks from the
+// tape's aux buffer - it needs neither the step input nor the forward's packed weights, and runs no recompute.  (The y0 /
+// h1 / h2 planes of the tape are operands of cf_wgrad only.)  gx comes out in the (B, C, H, W) layout of the step.
+int cf_flow_step_bwd_taped(const float* gz, const float* gld, const void* wsb, const void* t_aux, float* gx, float* s_gh,
+                           float* s_gh2, float* s_gh1, float* s_gy, int B, int C, int H, int W, cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(x && gz && gld && ws && wsb && gx && t_y0 && t_h1 && t_h2 && s_gh && s_gh2 && s_gh1 && s_gy);
-    CF_REQUIRE(x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-               (reinterpret_cast<uintptr_t>(gz) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0 &&
-               (reinterpret_cast<uintptr_t>(t_h1) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0);
-    const float* w = (const float*)ws;
+    CF_REQUIRE(gz && gld && wsb && t_aux && gx && s_gh && s_gh2 && s_gh1 && s_gy);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(gz) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(t_aux) & 15) == 0);
     const float* wb = (const float*)wsb;
-    float* y0 = const_cast<float*>(t_y0);
-    float* h1 = const_cast<float*>(t_h1);
-    float* h2 = const_cast<float*>(t_h2);
+    const StepTape tp = make_tape(nullptr, nullptr, nullptr, const_cast<void*>(t_aux), B, C, H, W);
     int rc = 0;
-#define CF_BWDT(G) rc = in_squeeze ? launch_step_bwd<G, true, 0, true>(x, gz, gld, w, wb, gx, y0, h1, h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream)) \
-                                   : launch_step_bwd<G, false, 0, true>(x, gz, gld, w, wb, gx, y0, h1, h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream))
+#define CF_BWDT(G) rc = launch_step_bwd<G, false, 0, true>(nullptr, gz, gld, nullptr, wb, gx, nullptr, nullptr, nullptr, s_gh, s_gh2, \
+                                                           s_gh1, s_gy, B, (int64_t)C * H * W, cf_s(stream), nullptr, tp)
     switch (shape_id(C, H, W)) {
         case 0: CF_BWDT(B8); break;
         case 1: CF_BWDT(B16); break;

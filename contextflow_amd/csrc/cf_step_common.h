@@ -289,13 +289,49 @@ __device__ __forceinline__ void rows_load_t(const float* __restrict__ src, float
     cf_wave_sync();
 }
 
-// training tape of a step (forward with DUMP writes, backward with TAPED reads): y0 (B, C/2, H, W), h1 / h2 (B, 2C, H, W),
-// the post-ReLU hidden planes of the conditioner
+// training tape of a step (forward with DUMP writes, backward with TAPED reads):
+//   y0 (B, C/2, HW), h1 / h2 (B, 2C, HW; post-ReLU hidden planes of the conditioner): operands of the weight-gradient GEMMs;
+//   ls, y1 (B, C/2, HW): log-scale and the second half of the step's Conv1x1+ActNorm output - with them the backward
+//   kernel needs neither the step input nor a recompute of the first and last 1x1;
+//   m1 / m2: the ReLU masks of h1 / h2 as bit words in the accumulator layout of the 32x32x2 tiles: word
+//   [(T * RT1 + rt) * 64 + lane], T = global 32-pixel tile (sample-major pixel index / 32), bit r = row rt*32 + tile_row(r, lane>>5)
+//   of pixel 32 T + (lane & 31).  Sized for the batch rounded up to 16 samples (cf_flow_step_tape_aux_bytes).
 struct StepTape {
     float* y0;
     float* h1;
     float* h2;
+    float* ls;
+    float* y1;
+    unsigned* m1;
+    unsigned* m2;
 };
+constexpr StepTape kNoTape{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+// host: the four small tape items live in ONE caller-provided buffer `aux` = [ls | y1 | m1 | m2]
+inline int64_t tape_mask_words(int B, int C, int H, int W) {
+    return (int64_t)((B + 15) & ~15) * H * W / 32 * ((2 * C + 31) / 32) * 64;
+}
+inline int64_t tape_aux_bytes(int B, int C, int H, int W) {
+    return (2 * (int64_t)B * (C / 2) * H * W + 2 * tape_mask_words(B, C, H, W)) * 4;
+}
+inline StepTape make_tape(float* y0, float* h1, float* h2, void* aux, int B, int C, int H, int W) {
+    const int64_t nh = (int64_t)B * (C / 2) * H * W, nm = tape_mask_words(B, C, H, W);
+    float* a = (float*)aux;
+    return StepTape{y0, h1, h2, a, a + nh, (unsigned*)(a + 2 * nh), (unsigned*)(a + 2 * nh) + nm};
+}
+
+// ReLU mask words of RT x PTW accumulator tiles (pre- or post-ReLU values: the bit is `value > 0` either way)
+template <class G, int RT>
+__device__ __forceinline__ void mask_store(unsigned* __restrict__ m, const f32x16 (&acc)[RT][G::PTW], int tile, int wave, int lane) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int q = 0; q < G::PTW; ++q) {
+            unsigned b = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) b |= (acc[rt][q][r] > 0.f ? 1u : 0u) << r;
+            m[((int64_t)(tile * G::NPT + wave * G::PTW + q) * RT + rt) * 64 + lane] = b;
+        }
+}
 
 // ---- the conditioner: phases 1-3 of a step (shared by the forward and the inverse kernel) --------------
 // In: Y0 = y0 plane (this wave's columns).  Out: acc3 = NN.4 output tiles (t rows / raw rows, packed-row
@@ -310,8 +346,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                                                 const float* __restrict__ wsl, const int (&pix)[G::PTW],
                                                 const int (&pin)[G::PTW], int lane, int tid, float* __restrict__ dbg,
                                                 int64_t dbg_cols, int tile, const float* __restrict__ sb = nullptr,
-                                                const int* soff = nullptr, StepTape tp = StepTape{nullptr, nullptr, nullptr},
-                                                int B = 0) {
+                                                const int* soff = nullptr, StepTape tp = kNoTape, int B = 0) {
     constexpr int C = G::C, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1;
     float* Y0 = lds;
@@ -346,7 +381,11 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     const int row = rt * 32 + tile_row(r, lk);
                     if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
                 }
-        if constexpr (DUMP) { cf_wave_sync(); rows_store_t<G, HID, HID>(tp.h1, H1, tile * G::SPW, B, tid >> 6, lane); }
+        if constexpr (DUMP) {
+            cf_wave_sync();
+            rows_store_t<G, HID, HID>(tp.h1, H1, tile * G::SPW, B, tid >> 6, lane);
+            mask_store<G, RT1>(tp.m1, acc, tile, tid >> 6, lane);
+        }
     }
     __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' columns
     if (dbg) {
@@ -502,7 +541,10 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
                 }
         cf_wave_sync();              // h2 rows of all lanes in place (read below by other lanes of this wave)
-        if constexpr (DUMP) rows_store_t<G, HID, HID>(tp.h2, H1, tile * G::SPW, B, tid >> 6, lane);
+        if constexpr (DUMP) {
+            rows_store_t<G, HID, HID>(tp.h2, H1, tile * G::SPW, B, tid >> 6, lane);
+            mask_store<G, RT1>(tp.m2, acc, tile, tid >> 6, lane);
+        }
     }
     // no workgroup barrier: phase 3 reads only this wave's own pixel columns of h2
     if (dbg) {

@@ -60,8 +60,9 @@ SIGNATURES = {
     "cf_flow_step_bwd_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_bwd_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_p]),
     "cf_flow_step_bwd": (_c_int, [_c_p] * 13 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
-    "cf_flow_step_bwd_taped": (_c_int, [_c_p] * 13 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
-    "cf_flow_step_fwd_taped": (_c_int, [_c_p] * 7 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
+    "cf_flow_step_tape_aux_bytes": (_c_i64, [_c_int] * 4),
+    "cf_flow_step_bwd_taped": (_c_int, [_c_p] * 9 + [_c_int] * 4 + [_c_p]),
+    "cf_flow_step_fwd_taped": (_c_int, [_c_p] * 8 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_step_param_grads": (_c_int, [_c_p] * 7 + [_c_int] + [_c_p] * 3 + [_c_int, _c_p]),
     "cf_wgrad_ws_bytes": (_c_i64, [_c_int] * 6),
     "cf_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
@@ -90,7 +91,7 @@ SIGNATURES = {
     "cf_gelu": (_c_int, [_c_p] * 3 + [_c_i64, _c_int, _c_p]),
     "cf_coupling_apply_bwd": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
     "cf_channel_sums": (_c_int, [_c_p] * 3 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
-    "cf_flow_step_fwd_ctx_taped": (_c_int, [_c_p] * 8 + [_c_int] * 4 + [_c_i64, _c_p]),
+    "cf_flow_step_fwd_ctx_taped": (_c_int, [_c_p] * 9 + [_c_int] * 4 + [_c_i64, _c_p]),
     "cf_flow_step_fwd_ctx": (_c_int, [_c_p] * 5 + [_c_int] * 5 + [_c_i64, _c_p]),
     "cf_flow_step_bwd_ctx": (_c_int, [_c_p] * 14 + [_c_int] * 4 + [_c_i64, _c_p]),
     "cf_conv1x1_ctx_bwd": (_c_int, [_c_p] * 7 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),

@@ -63,7 +63,7 @@ def gmm_backward(x, dist, prepared, g):
 # ------------------------------------------------------------------------------------------------ flow step
 def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
-    planes: (y0, h1, h2) written by cf_flow_step_fwd_taped, or None = recompute them from x.
+    planes: the step tape (y0, h1, h2, aux) written by cf_flow_step_fwd_taped, or None = recompute everything from x.
     gsum: 1-element tensor sum(gld) (the same for every step of a backward pass), or None.
     Returns (dL/dx in the layout of x, {param: grad})."""
     C, H, W = shape
@@ -83,12 +83,12 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
     gzc = f(gz)
     if planes is None:
         s_y0, s_h1, s_h2 = new(HALF), new(HID), new(HID)
-        entry = "cf_flow_step_bwd"
+        _hip.call("cf_flow_step_bwd", pp(xv), pp(gzc), pp(f(gld)), pp(ws), pp(wsb), pp(gx), pp(s_y0), pp(s_h1), pp(s_h2),
+                  pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, int(squeeze), st)
     else:
-        s_y0, s_h1, s_h2 = planes
-        entry = "cf_flow_step_bwd_taped"
-    _hip.call(entry, pp(xv), pp(gzc), pp(f(gld)), pp(ws), pp(wsb), pp(gx), pp(s_y0), pp(s_h1), pp(s_h2),
-              pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, int(squeeze), st)
+        s_y0, s_h1, s_h2, aux = planes
+        _hip.call("cf_flow_step_bwd_taped", pp(gzc), pp(f(gld)), pp(wsb), pp(aux), pp(gx), pp(s_gh), pp(s_gh2), pp(s_gh1),
+                  pp(s_gy), B, C, H, W, st)
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts (cf_wgrad)
     def wgrad(A, Bm, taps):
         """(gw (taps, MR, NR), gbias (MR,) = row sums of A)"""

@@ -255,10 +255,10 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
         _cn_chain_backward(m, rec, context, gcn, grads, f(gld) * float(HW))      # ldj += H W logp_c (coupling.py:43)
         return gx
     new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
-    y0, h1, h2 = rec["planes"]
+    y0, h1, h2, aux = rec["planes"]
     s_gh2, s_gh1, s_gy = new(HID), new(HID), new(C)
-    _hip.call("cf_flow_step_bwd_taped", pp(x), pp(gzc), pp(f(gld)), pp(rec["ws"]), pp(wsb), pp(gx), pp(y0), pp(h1), pp(h2),
-              pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, 0, st)
+    _hip.call("cf_flow_step_bwd_taped", pp(gzc), pp(f(gld)), pp(wsb), pp(aux), pp(gx), pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy),
+              B, C, H, W, st)
 
     def wgrad(A, Bm, taps):
         MR, NR = A.shape[1], Bm.shape[1]

@@ -142,10 +142,11 @@ class Coupling(_AffineCoupling):
         ldj = torch.zeros(B, device=dev, dtype=torch.float32)
         planes = None
         if tape is not None and mode == 2:
-            # every parameter trains: the forward kernel also writes y0 / h1 / h2 and the backward loads them
-            planes = tuple(torch.empty(B, r, H * W, device=dev, dtype=torch.float32) for r in (D, 2 * C, 2 * C))
+            # every parameter trains: the forward kernel also writes the step tape for the backward kernel and the weight gradients
+            from .flowsequential import step_tape
+            planes = step_tape(B, C, H, W, dev)
             _hip.call("cf_flow_step_fwd_ctx_taped", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), pp(planes[0]), pp(planes[1]),
-                      pp(planes[2]), B, C, H, W, xbs, st)
+                      pp(planes[2]), pp(planes[3]), B, C, H, W, xbs, st)
         else:
             _hip.call("cf_flow_step_fwd_ctx", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), mode, B, C, H, W, xbs, st)
         if tape is not None:

@@ -37,6 +37,15 @@ from .transforms import LogitTransform
 TAPE_PLANES = True
 
 
+def step_tape(B, C, H, W, dev):
+    """Buffers of one step's training tape (cf_flow_step_fwd_taped): y0 (B, C/2, HW), h1, h2 (B, 2C, HW) - the operands of
+    the weight-gradient GEMMs - and the opaque aux buffer (log-scales, second half of the Conv1x1+ActNorm output, ReLU
+    masks) that is all the step-backward kernel reads of the forward."""
+    planes = [torch.empty(B, r, H * W, device=dev, dtype=torch.float32) for r in (C // 2, 2 * C, 2 * C)]
+    planes.append(torch.empty(_hip.lib().cf_flow_step_tape_aux_bytes(B, C, H, W), device=dev, dtype=torch.uint8))
+    return tuple(planes)
+
+
 class FlowSequential(nn.Module):
     def __init__(self, dist, *modules):
         super().__init__()
@@ -347,16 +356,16 @@ class FlowSequential(nn.Module):
                 planes = None
                 if tape is not None:
                     ws, winv = ws
-                    # training: the forward kernel writes y0 / h1 / h2, the backward loads them - unless the planes of this
+                    # training: the forward kernel writes the tape, the backward kernel reads it - unless the planes of this
                     # step would take more than 1/64 of the device memory (huge batches: recompute form, 4.5x less tape)
                     if TAPE_PLANES and 18 * B * C * H * W <= torch.cuda.get_device_properties(dev).total_memory // 64:
-                        planes = tuple(torch.empty(B, r, H * W, device=dev, dtype=torch.float32) for r in (C // 2, 2 * C, 2 * C))
+                        planes = step_tape(B, C, H, W, dev)
                     tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws, winv, planes))
                 x, xbs = _hip.bview(x)
                 z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
                 if planes is not None:
                     _hip.call("cf_flow_step_fwd_taped", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), _hip.p(planes[0]),
-                              _hip.p(planes[1]), _hip.p(planes[2]), B, C, H, W, xbs, int(sq), st)
+                              _hip.p(planes[1]), _hip.p(planes[2]), _hip.p(planes[3]), B, C, H, W, xbs, int(sq), st)
                     x = z
                     continue
                 events = self.step_events

@@ -191,20 +191,24 @@ int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const vo
                      float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy,
                      int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 
-/* Taped training pair.  cf_flow_step_fwd_taped = cf_flow_step_fwd that also writes the conditioner's intermediate
- * planes t_y0 (B, C/2, H*W), t_h1, t_h2 (B, 2C, H*W; post-ReLU, Coupling.NN of coupling.py:26-27).
- * cf_flow_step_bwd_taped = cf_flow_step_bwd that READS those planes (masks of the two ReLUs, operand of the last 1x1)
- * instead of recomputing the two big contractions, and leaves them in place as operands of cf_wgrad. */
+/* Taped training pair (experiment_cl.py:130-136: forward + cost.backward()).
+ * cf_flow_step_fwd_taped = cf_flow_step_fwd that also writes the tape of the step:
+ *   t_y0 (B, C/2, H*W), t_h1, t_h2 (B, 2C, H*W; post-ReLU planes of Coupling.NN, coupling.py:26-27): operands of cf_wgrad;
+ *   t_aux (cf_flow_step_tape_aux_bytes(B, C, H, W) bytes, 16-byte aligned; opaque): log-scale and second output half of
+ *   Conv1x1+ActNorm per (sample, channel, pixel) and the two ReLU masks as bit words.
+ * cf_flow_step_bwd_taped = the data-gradient chain of the step from dL/dz (gz), dL/d ld1 (gld) and t_aux alone - no step
+ * input, no recompute; writes dL/dx (gx, in the step's (B, C, H, W) layout) and the gradient planes s_gh (B, C, H*W),
+ * s_gh2, s_gh1 (B, 2C, H*W), s_gy (B, C, H*W) that cf_wgrad contracts with t_h2 / t_h1 / t_y0 / the step input. */
+int64_t cf_flow_step_tape_aux_bytes(int B, int C, int H, int W);
 int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* t_y0, float* t_h1, float* t_h2,
-                           int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
+                           void* t_aux, int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 /* specialist coupling without contextflow (coupling.py:45-47: CN(c) concatenated to the conditioner input = per-sample
- * bias sbias (B, 2C) before the first ReLU): training forward with the tape planes; backward = cf_flow_step_bwd_taped. */
+ * bias sbias (B, 2C) before the first ReLU): training forward with the same tape; backward = cf_flow_step_bwd_taped. */
 int cf_flow_step_fwd_ctx_taped(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, float* t_y0,
-                               float* t_h1, float* t_h2, int B, int C, int H, int W, int64_t x_bstride, cf_stream_t stream);
-int cf_flow_step_bwd_taped(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
-                           const float* t_y0, const float* t_h1, const float* t_h2, float* s_gh, float* s_gh2,
-                           float* s_gh1, float* s_gy, int B, int C, int H, int W, int64_t x_bstride, int in_squeeze,
-                           cf_stream_t stream);
+                               float* t_h1, float* t_h2, void* t_aux, int B, int C, int H, int W, int64_t x_bstride,
+                               cf_stream_t stream);
+int cf_flow_step_bwd_taped(const float* gz, const float* gld, const void* wsb, const void* t_aux, float* gx, float* s_gh,
+                           float* s_gh2, float* s_gh1, float* s_gy, int B, int C, int H, int W, cf_stream_t stream);
 
 /* Conv1x1 / ActNorm parameter gradients of a fused step from the gradients of its folded matrix / bias (gWp (C,C) and
  * gbp (C) = the wgrad of the g_y plane against the step input): gNN = diag(s) gWp + G H W Wm^-T, gt = -s gbp,

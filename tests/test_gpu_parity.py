@@ -414,9 +414,9 @@ def test_abi_errors(L):
         L.Squeeze((2, 2))(torch.zeros(1, 1, 2, 2))           # CPU tensor: no fallback
     # empty batches: every batched entry point returns 0 without touching its (null) pointers
     N = None
-    assert lib.cf_flow_step_fwd_taped(N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, 0, N) == 0
-    assert lib.cf_flow_step_bwd_taped(N, N, N, N, N, N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, 0, N) == 0
-    assert lib.cf_flow_step_fwd_ctx_taped(N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, N) == 0
+    assert lib.cf_flow_step_fwd_taped(N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, 0, N) == 0
+    assert lib.cf_flow_step_bwd_taped(N, N, N, N, N, N, N, N, N, 0, 16, 16, 16, N) == 0
+    assert lib.cf_flow_step_fwd_ctx_taped(N, N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, N) == 0
     assert lib.cf_gmm_ctx_logprob(N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
     assert lib.cf_gmm_ctx_logprob_tab(N, N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
     assert lib.cf_gmm_ctx_bwd(N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, N) == 0
