@@ -69,7 +69,7 @@ __device__ __forceinline__ void tiles_to_plane(const f32x16 (&acc)[RT][G::PTW], 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + tile_row(r, lk);
-                if (row < nrows) plane[row * G::PIX + pix[q]] = acc[rt][q][r];
+                if (row < nrows) plane[row * G::RS + pix[q]] = acc[rt][q][r];
             }
     cf_wave_sync();                      // other lanes of this wave read these rows next
 }
@@ -91,7 +91,7 @@ __device__ __forceinline__ void adj_issue(float (&raw)[G::PTW][4][NS], float4 (&
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int j = 0; j < NS; ++j) raw[q][e][j] = lds[off[q][j] + (8 * cg + 2 * e) * G::PIX];
+            for (int j = 0; j < NS; ++j) raw[q][e][j] = lds[off[q][j] + (8 * cg + 2 * e) * G::RS];
 }
 
 template <class G, int NS>
@@ -131,6 +131,45 @@ __device__ __forceinline__ void adj_tap(f32x16 (&acc)[G::RT1][G::PTW], ws_rsrc_t
     }
 }
 
+// ---- PATCH geometries (16x16 and 8x8 images): the folds as precomputed SOURCES --------------------------------------
+// Along one axis of size N the adjoint of the reflected gather for shift d reads a PATCHED copy of g at s - d:
+//   d = -1:  G'[j] = g[j], except G'[2] = g[2] + g[0] and G'[N] = 0;    d = +1:  G'[N-3] = g[N-3] + g[N-1], G'[-1] = 0
+// (the border element whose reflection lands on s shares its output pixel with the regular source next to it).  In two
+// dimensions only one row (y = 2 / H-3), one column (x = 2 / W-3) and their crossing differ from g per direction, so every
+// plane row carries PP = 2W + 2H + 4 fold sums per sample behind its pixels (+ one zero for out-of-range sources), built
+// once per tile; the tap loop then reads ONE source per operand through a per-lane offset - no VALU between the MFMAs,
+// 9 instead of 25 LDS reads per k-step (the class-by-class weighted sums of adj_tap<NS> remain for 4x4 images, where
+// the fold slots would outgrow the planes).
+// Slot order per sample: [0,W) row y=2 (+ y=0), [W,2W) row H-3 (+ H-1), [2W,2W+H) column x=2 (+ x=0), [2W+H,2W+2H) column
+// W-3 (+ W-1), then the corners (dy<0,dx<0), (dy<0,dx>0), (dy>0,dx<0), (dy>0,dx>0).
+template <class G>
+__device__ __forceinline__ void patch_build(float* __restrict__ plane, int tid) {
+    constexpr int W = G::W, H = G::H, HW = G::HW, PP = G::PP, SLOTS = G::SPW * PP, GROUPS = 256 / SLOTS;
+    static_assert(GROUPS >= 1, "one thread per fold slot");
+    if (tid < G::HID) plane[tid * G::RS + G::PIX + SLOTS] = 0.f;              // the zero slot of every row
+    if (tid >= GROUPS * SLOTS) return;
+    const int j = tid % SLOTS, grp = tid / SLOTS, smp = j / PP, t = j % PP;
+    int ya, yb = -1, xa, xb = -1;
+    if (t < W) { ya = 2; yb = 0; xa = t; }
+    else if (t < 2 * W) { ya = H - 3; yb = H - 1; xa = t - W; }
+    else if (t < 2 * W + H) { ya = t - 2 * W; xa = 2; xb = 0; }
+    else if (t < 2 * W + 2 * H) { ya = t - 2 * W - H; xa = W - 3; xb = W - 1; }
+    else {
+        const int c = t - 2 * W - 2 * H;
+        ya = (c >> 1) ? H - 3 : 2; yb = (c >> 1) ? H - 1 : 0;
+        xa = (c & 1) ? W - 3 : 2;  xb = (c & 1) ? W - 1 : 0;
+    }
+    const int o0 = smp * HW + ya * W + xa;
+    const int o1 = xb >= 0 ? smp * HW + ya * W + xb : o0, o2 = yb >= 0 ? smp * HW + yb * W + xa : o0;
+    const int o3 = (xb >= 0 && yb >= 0) ? smp * HW + yb * W + xb : o0;
+    const float w1 = xb >= 0 ? 1.f : 0.f, w2 = yb >= 0 ? 1.f : 0.f, w3 = w1 * w2;
+#pragma unroll 4
+    for (int k = grp; k < G::HID; k += GROUPS) {
+        float* row = plane + k * G::RS;
+        row[G::PIX + j] = fmaf(w3, row[o3], fmaf(w2, row[o2], fmaf(w1, row[o1], row[o0])));
+    }
+}
+
 // candidate sources of output coordinate c along one axis of size N for tap shift d: [0] main, [1] reflected border
 __device__ __forceinline__ void adj_axis(int c, int d, int N, int (&src)[2], bool (&ok)[2]) {
     const int m = c - d;
@@ -155,12 +194,12 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
     float* __restrict__ s_gh2, float* __restrict__ s_gh1, float* __restrict__ s_gy, int B, int64_t xbs,
     const float* __restrict__ sb, StepTape tp) {
     using Bw = GeoBwd<G>;
-    constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, PIX = G::PIX, HALF = G::HALF, HID = G::HID;
+    constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, RS = G::RS, HALF = G::HALF, HID = G::HID;   // RS: row stride of the LDS planes
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1, NR = (HALF <= 16 ? 8 : 16);
     constexpr int XI = C * PTW / 8;
     extern __shared__ __align__(16) float lds[];
-    float* Y0 = lds;                    // [HALF][PIX]
-    float* H1 = lds + HALF * PIX;       // [HID][PIX]  (HID = 2C rows)
+    float* Y0 = lds;                    // [HALF][RS]
+    float* H1 = lds + HALF * RS;       // [HID][RS]  (HID = 2C rows)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
     const int tile = blockIdx.x, b0 = tile * G::SPW;
     int pix[PTW], pin[PTW];
@@ -212,7 +251,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int idx = tile_row(r, lk);
-                if constexpr (!TAPED) { if (idx < HALF) Y0[idx * PIX + pix[q]] = acc0[0][q][r]; }   // operand of phase 1
+                if constexpr (!TAPED) { if (idx < HALF) Y0[idx * RS + pix[q]] = acc0[0][q][r]; }   // operand of phase 1
                 y1[q][r] = (HALF <= 16) ? acc0[0][q][r + 8] : acc0[RT03 - 1][q][r];
             }
         if constexpr (CTX == 0 && !TAPED) rows_store_t<G, HALF, HALF>(s_y0, Y0, b0, B, wave, lane);   // weight-gradient operand plane
@@ -256,7 +295,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
                 int yy = pin[q] / W + dy, xx = pin[q] % W + dx;
                 yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
                 xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-                src[q] = HALF * PIX + (pix[q] - pin[q]) + yy * W + xx + lk * PIX;
+                src[q] = HALF * RS + (pix[q] - pin[q]) + yy * W + xx + lk * RS;
             }
         };
         auto load = [&](int fr, const int (&src)[PTW], int cg, GroupOps<RT1, PTW>& o) {
@@ -265,7 +304,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
 #pragma unroll
             for (int q = 0; q < PTW; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * PIX];
+                for (int e = 0; e < 4; ++e) o.b[e][q] = lds[src[q] + (8 * cg + 2 * e) * RS];
         };
         int src_cur[PTW], src_nxt[PTW];
         tap_src(0, src_cur);
@@ -333,7 +372,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
         float4 gr[XI];
         x_load<G, false>(gr, gz, (int64_t)C * HW, tile, B, wave, lane);
         x_to_lds<G, false>(gr, H1, wave, lane);
-        float* GH = H1 + C * PIX;                     // g_h plane: rows [0,HALF) = g_t, [HALF,C) = g_raw
+        float* GH = H1 + C * RS;                     // g_h plane: rows [0,HALF) = g_t, [HALF,C) = g_raw
 #pragma unroll
         for (int q = 0; q < PTW; ++q) {
             const float gl = gld[min(b0 + pix[q] / HW, B - 1)];
@@ -341,12 +380,12 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
             for (int r = 0; r < NR; ++r) {
                 const int idx = tile_row(r, lk);
                 if (idx < HALF) {
-                    const float g1 = H1[(HALF + idx) * PIX + pix[q]];
+                    const float g1 = H1[(HALF + idx) * RS + pix[q]];
                     const float e = __expf(ls[q][r]);
-                    Y0[idx * PIX + pix[q]] = g1 * e;                                 // g_y1 = d z1 / d y1
+                    Y0[idx * RS + pix[q]] = g1 * e;                                 // g_y1 = d z1 / d y1
                     const float gls = g1 * y1[q][r] * e + gl;                        // d/d log_s (+ the log-det path)
-                    GH[idx * PIX + pix[q]] = g1;                                     // d z1 / d t
-                    GH[(HALF + idx) * PIX + pix[q]] = gls * (1.0f - 0.25f * ls[q][r] * ls[q][r]);   // d log_s / d raw
+                    GH[idx * RS + pix[q]] = g1;                                     // d z1 / d t
+                    GH[(HALF + idx) * RS + pix[q]] = gls * (1.0f - 0.25f * ls[q][r] * ls[q][r]);   // d log_s / d raw
                 }
             }
         }
@@ -385,7 +424,59 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
         constexpr int TAPF = G::NCG * RT1 * 256;             // fragment floats per tap
         int py[PTW], px[PTW], base[PTW];
 #pragma unroll
-        for (int q = 0; q < PTW; ++q) { py[q] = pin[q] / W; px[q] = pin[q] % W; base[q] = HALF * PIX + (pix[q] - pin[q]) + lk * PIX; }
+        for (int q = 0; q < PTW; ++q) { py[q] = pin[q] / W; px[q] = pin[q] % W; base[q] = HALF * RS + (pix[q] - pin[q]) + lk * RS; }
+        if constexpr (G::PATCH) {
+            patch_build<G>(H1, tid);
+            __syncthreads();             // fold slots in place
+            constexpr int PP = G::PP;
+            // one source per operand: the same two-stage operand pipeline as the forward 3x3 (the first group of the next tap
+            // is requested before the last group of this tap runs; NCG is even: static ping-pong)
+            auto tap_off = [&](int tap, int (&off)[PTW]) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;                 // scalars
+                const int ysp = dy < 0 ? 2 : H - 3, xsp = dx < 0 ? 2 : W - 3;
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) {
+                    const int jy = py[q] - dy, jx = px[q] - dx;
+                    const bool oob = jy < 0 || jy >= H || jx < 0 || jx >= W;
+                    const bool fy = dy != 0 && jy == ysp, fx = dx != 0 && jx == xsp;
+                    const int slots = G::PIX + ((pix[q] - pin[q]) / HW) * PP;
+                    int o = (pix[q] - pin[q]) + jy * W + jx;
+                    if (fy) o = slots + (dy > 0 ? W : 0) + jx;
+                    if (fx) o = slots + 2 * W + (dx > 0 ? H : 0) + jy;
+                    if (fy && fx) o = slots + 2 * W + 2 * H + (dy > 0 ? 2 : 0) + (dx > 0 ? 1 : 0);
+                    if (oob) o = G::PIX + G::SPW * PP;
+                    off[q] = HALF * RS + lk * RS + o;
+                }
+            };
+            GroupOps<RT1, PTW> ops[2];
+            auto load = [&](int fr, const int (&off)[PTW], int cg, GroupOps<RT1, PTW>& o) {
+#pragma unroll
+                for (int rt = 0; rt < RT1; ++rt) o.a[rt] = ws_frag(rsb, lane, fr + rt * 256);
+#pragma unroll
+                for (int q = 0; q < PTW; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.b[e][q] = lds[off[q] + (8 * cg + 2 * e) * RS];
+            };
+            int off_cur[PTW], off_nxt[PTW];
+            tap_off(0, off_cur);
+            load(frags, off_cur, 0, ops[0]);
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                tap_off(min(tap + 1, 8), off_nxt);
+                const int fr = frags + tap * TAPF;
+#pragma unroll
+                for (int cg = 0; cg < G::NCG; ++cg) {
+                    const int fn = fr + (cg + 1) * RT1 * 256;
+                    if (cg + 1 < G::NCG) load(fn, off_cur, cg + 1, ops[(cg + 1) & 1]);
+                    else load(tap < 8 ? fn : fr, off_nxt, 0, ops[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    group_mma<RT1, PTW>(acc, ops[cg & 1], 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) off_cur[q] = off_nxt[q];
+            }
+        } else {
         {   // centre tap: the pixel itself
             int off[PTW][1];
             float wgt[PTW][1];
@@ -433,6 +524,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
             }
             adj_tap<G, 4>(acc, rsb, frags + tap * TAPF, lds, off, wgt, lane);
         }
+        }
         __syncthreads();                 // everyone done reading g_h2
 #pragma unroll
         for (int rt = 0; rt < RT1; ++rt)
@@ -465,7 +557,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = tile_row(r, lk);
-                if (row < HALF) H1[row * PIX + pix[q]] = acc[0][q][r];
+                if (row < HALF) H1[row * RS + pix[q]] = acc[0][q][r];
             }
         if constexpr (CTX == 0) rows_store_t<G, HALF, C>(s_gy, H1, b0, B, wave, lane);   // g_y0 rows (weight-gradient operand plane)
         // g_x = (e^{-logs} Wm)^T g_y
@@ -477,7 +569,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ax[rt][q][r] = 0.f;
         dense_phase<G, G::KS0, G::NG0, Bw::RTI>(ax, rsb, Bw::OFF_A0T, GY, pix, lane);
-        float* GX = H1 + C * PIX;
+        float* GX = H1 + C * RS;
         tiles_to_plane<G, Bw::RTI>(ax, GX, C, pix, lk);
         rows_store_t<G, C, C>(gx, GX, b0, B, wave, lane);
     }
@@ -507,9 +599,10 @@ int launch_step_bwd(const float* x, const float* gz, const float* gld, const flo
 }
 
 // the backward uses the smaller tiles (2 workgroups/CU at C = 64): its register footprint is larger than the forward's
-using B8 = Geo<8, 16, 16, 1, 1>;
-using B16 = Geo<16, 16, 16, 1, 1>;
-using B32 = Geo<32, 8, 8, 4, 1>;
+// 16x16 / 8x8: fold slots behind every plane row (PATCH); 8x8 with 2 samples per workgroup so that two workgroups share a CU
+using B8 = Geo<8, 16, 16, 1, 1, 0, 1>;
+using B16 = Geo<16, 16, 16, 1, 1, 0, 1>;
+using B32 = Geo<32, 8, 8, 2, 1, 0, 1>;
 using B64 = Geo<64, 4, 4, 8, 1>;
 
 }  // namespace

@@ -15,9 +15,11 @@ constexpr int kWaves = 4;
 // ---- compile-time geometry of one supported shape ------------------------------------------------
 // PIPE_: phase-2 loop form (1 = explicit two-stage operand pipeline, 0 = compiler-scheduled per-tap loop)
 // ABL_: timing-only ablations for tools/step_bench.py (1 = phase-2 operands are constants: no LDS / L2 loads there)
-template <int C_, int H_, int W_, int SPW_, int PIPE_ = 1, int ABL_ = 0>
+// PATCH_: (backward) every row of an LDS plane carries, behind its PIX pixel columns, the fold sums of the transposed
+// reflect-padded 3x3 (cf_step_bwd.hip): PP slots per sample + one zero slot; RS = row stride of all LDS planes.
+template <int C_, int H_, int W_, int SPW_, int PIPE_ = 1, int ABL_ = 0, int PATCH_ = 0>
 struct Geo {
-    static constexpr int C = C_, H = H_, W = W_, SPW = SPW_, PIPE = PIPE_, ABL = ABL_;
+    static constexpr int C = C_, H = H_, W = W_, SPW = SPW_, PIPE = PIPE_, ABL = ABL_, PATCH = PATCH_;
     static constexpr int HW = H * W;
     static constexpr int PIX = SPW * HW;              // pixels per workgroup
     static constexpr int HALF = C / 2;                // conditioner channels
@@ -55,7 +57,9 @@ struct Geo {
     static constexpr int OFF_SA1 = OFF_SA3 + (SMALL ? SG3 * 256 : 0);
     static constexpr int OFF_SA2 = OFF_SA1 + (HID16 ? SG1 * 256 : 0);
     static constexpr int WS_FLOATS = OFF_SA2 + (HID16 ? 9 * 256 : 0);
-    static constexpr int LDS_FLOATS = (HALF + HID) * PIX;
+    static constexpr int PP = 2 * W + 2 * H + 4;      // fold slots per sample: 2 patched rows, 2 patched columns, 4 corners
+    static constexpr int RS = PATCH ? ((PIX + SPW * PP + 1 + 3) & ~3) : PIX;
+    static constexpr int LDS_FLOATS = (HALF + HID) * RS;
     // waves per SIMD the register allocator must leave room for = workgroups per CU the LDS footprint admits
     static constexpr int MINW = (160 * 1024) / (LDS_FLOATS * 4) >= 4 ? 4 : ((160 * 1024) / (LDS_FLOATS * 4) >= 2 ? 2 : 1);
     static_assert(PIX % 128 == 0 && PTW >= 1, "workgroup must own a multiple of 128 pixels");
@@ -152,7 +156,7 @@ __device__ __forceinline__ void dense_phase_impl(f32x16 (&acc)[RT][G::PTW], FRAG
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int q = 0; q < G::PTW; ++q)
-                o.b[e][q] = (4 * g + e < KS) ? plane[(2 * (4 * g + e) + lk) * G::PIX + pix[q]] : 0.f;
+                o.b[e][q] = (4 * g + e < KS) ? plane[(2 * (4 * g + e) + lk) * G::RS + pix[q]] : 0.f;
     };
     load(0, ops[0]);
 #pragma unroll
@@ -200,7 +204,7 @@ __device__ __forceinline__ void x_load(float4 (&xr)[G::C * G::PTW / 8], const fl
 
 template <class G, bool SQ>
 __device__ __forceinline__ void x_to_lds(const float4 (&xr)[G::C * G::PTW / 8], float* __restrict__ plane, int wave, int lane) {
-    constexpr int WPX = 32 * G::PTW, PIX = G::PIX;
+    constexpr int WPX = 32 * G::PTW, PIX = G::RS;      // row stride of the plane
 #pragma unroll
     for (int i = 0; i < G::C * G::PTW / 8; ++i) {
         const int n = i * 64 + lane;
@@ -221,7 +225,7 @@ __device__ __forceinline__ void x_to_lds(const float4 (&xr)[G::C * G::PTW / 8], 
 template <class G, int NROWS>
 __device__ __forceinline__ void rows_store(float* __restrict__ z, const float* __restrict__ plane, int tb0, int ch0, int B,
                                            int wave, int lane) {
-    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, C = G::C;
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::RS, C = G::C;
     cf_wave_sync();                      // rows written by other lanes of this wave
 #pragma unroll
     for (int i = 0; i < (NROWS * G::PTW + 7) / 8; ++i) {
@@ -254,7 +258,7 @@ template <class G, int NROWS, int CT>
 __device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const float* __restrict__ plane, int tb0, int B,
                                              int wave, int lane) {
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
-    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, RPI = 256 / WPX;     // rows per item of 64 lanes x 16 bytes
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::RS, RPI = 256 / WPX;      // rows per item of 64 lanes x 16 bytes
     const ws_rsrc_t rs = tile_rsrc<G, CT>(dst, tb0, B);
     const int idx0 = lane / (WPX / 4), col = wave * WPX + 4 * (lane % (WPX / 4));
     const int voff = ((col / HW) * CT * HW + idx0 * HW + col % HW) * 4;
@@ -273,7 +277,7 @@ template <class G, int NROWS, int CT>
 __device__ __forceinline__ void rows_load_t(const float* __restrict__ src, float* __restrict__ plane, int tb0, int B,
                                             int wave, int lane) {
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
-    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::PIX, RPI = 256 / WPX;
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::RS, RPI = 256 / WPX;
     const ws_rsrc_t rs = tile_rsrc<G, CT>(src, tb0, B);
     const int idx0 = lane / (WPX / 4), col = wave * WPX + 4 * (lane % (WPX / 4));
     const int voff = ((col / HW) * CT * HW + idx0 * HW + col % HW) * 4;
