@@ -13,6 +13,14 @@ import torch
 import torch.distributed as dist
 
 
+def _active():
+    """Collectives run when a process group of more than one rank exists - or of ONE rank with CF_DIST_SINGLE_RANK=1
+    (tests on a one-GPU box: the same calls through a real RCCL communicator of size 1)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CF_DIST_SINGLE_RANK") == "1"
+
+
 def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -43,7 +51,7 @@ def allreduce_nll(local_sum_logp, local_count):
     buf = torch.zeros(2, dtype=torch.float64, device=dev)
     buf[0] = local_sum_logp.reshape(-1)[0].double() if torch.is_tensor(local_sum_logp) else float(local_sum_logp)
     buf[1] = float(local_count)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
@@ -57,7 +65,7 @@ def broadcast_parameters(module, src=0):
     """Replicate parameters and buffers from `src` (after rank `src` ran the ActNorm data-dependent init): ONE flat
     message per dtype (the cifar10 flow: 6 MB of fp32 + 12 int64 flags) instead of one tiny broadcast per tensor, written
     back with `copy_` so that every tensor's version counter moves (parameter-derived caches key on it)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return
     tensors = list(module.parameters()) + list(module.buffers())
     with torch.no_grad():
@@ -82,7 +90,7 @@ def allreduce_actnorm_sums(sums):
     [sum x (C) | sum x^2 (C) | elements per channel (1)] of this rank's shard, summed in place over the ranks - one
     (2C+1)-double message per ActNorm layer, after which every rank derives the same t / logs as a single process would
     from the whole batch (cf_actnorm_from_sums).  No-op for world size 1."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     return sums
 
@@ -107,7 +115,7 @@ def allreduce_gradients(module, bucket_bytes=32 << 20):
     """Average parameter gradients over the ranks (data-parallel training step).  Gradients are packed into flat
     fp32 buckets (default 32 MB; the whole cifar10 flow is 6 MB = one message) so that each RCCL all-reduce moves a
     bandwidth-relevant payload over the point-to-point xGMI links instead of 135 tiny latency-bound ones."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return
     world = dist.get_world_size()
     params = [p for p in module.parameters() if p.grad is not None]

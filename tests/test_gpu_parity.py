@@ -1481,3 +1481,71 @@ def test_large_launch_equals_chunked(L):
             _, part = model(x[c0:c0 + step])
             assert torch.equal(part, big[c0:c0 + step]), c0
     assert torch.isfinite(big).all()
+
+
+# ------------------------------------------------------------------------------------------ RCCL (one rank)
+_RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["CF_ROOT"])
+import torch, torch.distributed as dist
+import contextflow_amd as cfa
+from contextflow_amd import dist as cdist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)          # backend "nccl" is RCCL on ROCm
+assert dist.get_backend() == "nccl"
+dev = torch.device("cuda", 0)
+
+def build():
+    torch.manual_seed(0)                                         # also restarts the in-kernel noise stream: both runs draw the same noise
+    cfg, ds, M = cfa.preset_config("mnist")
+    return cfa.create_model(cfg, ds, M).to(dev), ds, M
+
+x = torch.randint(0, 256, (64, 1, 32, 32), generator=torch.Generator().manual_seed(1)).float().to(dev)
+gt = torch.randint(0, 10, (64,), generator=torch.Generator().manual_seed(2)).to(dev)
+
+def run(collectives):
+    os.environ["CF_DIST_SINGLE_RANK"] = "1" if collectives else "0"
+    model, ds, M = build()
+    with torch.no_grad():
+        if collectives:
+            with cdist.sharded_actnorm_init():                  # all-reduce of fp64 [sum x | sum x^2 | n] per ActNorm
+                model(x)
+        else:
+            model(x)
+    cdist.broadcast_parameters(model, src=0)                    # one flat broadcast per dtype (fp32, int64)
+    _, logp = model(x)
+    loss = torch.nn.functional.cross_entropy(logp / 1024.0, gt)
+    loss.backward()
+    cdist.allreduce_gradients(model)                            # bucketed fp32 all-reduce
+    red = cdist.allreduce_nll(torch.logsumexp(logp.detach(), -1).sum().double(), 64)     # fp64 [sum log p, count]
+    return red.cpu(), {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}, \
+        {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+r1, g1, s1 = run(True)
+r0, g0, s0 = run(False)
+assert torch.equal(r1, r0), (r1, r0)
+assert g1.keys() == g0.keys() and len(g1) > 20
+for k in s0:
+    assert torch.allclose(s1[k].double(), s0[k].double(), rtol=1e-6, atol=1e-7), k     # sums path vs two-pass init
+for k in g0:
+    assert torch.allclose(g1[k], g0[k], rtol=2e-4, atol=1e-7), k
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_OK", ".".join(str(v) for v in torch.cuda.nccl.version()))
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_runs_every_collective_of_the_data_parallel_path(tmp_path):
+    """No multi-GPU node is available to the build, so the RCCL calls of contextflow_amd.dist run here through a real
+    communicator of ONE rank on the one GPU (CF_DIST_SINGLE_RANK=1): the sharded ActNorm init (fp64 all-reduce), the flat
+    fp32 / int64 parameter broadcast, the bucketed gradient all-reduce and the fp64 NLL all-reduce - dtypes, reduce ops and
+    CUDA-tensor plumbing as in an N-rank job - and must leave the numbers of a run without collectives unchanged."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = dict(os.environ, CF_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
