@@ -215,6 +215,20 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
     // exactly this layout) - no step input, no recompute.  Otherwise: the forward is re-run from x in LDS.
     float y1[PTW][NR], ls[PTW][NR];
     unsigned m1[RT1][PTW], m2[RT1][PTW];
+    // the upstream gradient of the transformed half, g_z1, in the same register layout (128 contiguous bytes per row and
+    // half wave), and d L / d ld1 of this lane's samples - requested first, consumed after the tape / recompute below
+    float g1v[PTW][NR], glv[PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) {
+        const int smp = min(b0 + pix[q] / HW, B - 1);
+        const float* gzp = gz + ((int64_t)smp * C + HALF) * HW + pin[q];
+        glv[q] = gld[smp];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int idx = tile_row(r, lk);
+            g1v[q][r] = (HALF >= 16 || idx < HALF) ? gzp[idx * HW] : 0.f;
+        }
+    }
     if constexpr (TAPED) {
 #pragma unroll
         for (int rt = 0; rt < RT1; ++rt)
@@ -365,22 +379,18 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
     }
 
     // ---------------------------------------------------------------- backward
-    // upstream gradient g_z -> LDS plane (H rows [0,C), own columns: h2 there is dead for this wave)
-    // g_y1 = g_z1 e^{ls} is parked in the Y0 region (dead since phase 1) until the last phase; g_z0 is fetched again there:
-    // neither stays in registers across the transposed 3x3 (2 workgroups per CU need <= 256 registers per lane)
+    // g_y1 = g_z1 e^{ls} is parked in the Y0 region (dead since phase 1) until the last phase; g_z0 is fetched separately
+    // for the last phases: neither stays in registers across the transposed 3x3
     {
-        float4 gr[XI];
-        x_load<G, false>(gr, gz, (int64_t)C * HW, tile, B, wave, lane);
-        x_to_lds<G, false>(gr, H1, wave, lane);
         float* GH = H1 + C * RS;                     // g_h plane: rows [0,HALF) = g_t, [HALF,C) = g_raw
 #pragma unroll
         for (int q = 0; q < PTW; ++q) {
-            const float gl = gld[min(b0 + pix[q] / HW, B - 1)];
+            const float gl = glv[q];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int idx = tile_row(r, lk);
                 if (idx < HALF) {
-                    const float g1 = H1[(HALF + idx) * RS + pix[q]];
+                    const float g1 = g1v[q][r];
                     const float e = __expf(ls[q][r]);
                     Y0[idx * RS + pix[q]] = g1 * e;                                 // g_y1 = d z1 / d y1
                     const float gls = g1 * y1[q][r] * e + gl;                        // d/d log_s (+ the log-det path)
@@ -409,6 +419,18 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
                     if (!((m2[rt][q] >> r) & 1u)) acc[rt][q][r] = 0.f;
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);       // g_h2 plane over the whole H region (own columns)
         if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_gh2, H1, b0, B, wave, lane);   // weight-gradient operand plane
+    }
+    // g_z0, the start value of the g_y0 accumulators two phases on (rows of that single tile = channels 0..31 in natural
+    // order; 128 contiguous bytes per row and half wave): in flight during the transposed 3x3
+    f32x16 accy[1][PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) {
+        const float* gzp = gz + (int64_t)min(b0 + pix[q] / HW, B - 1) * C * HW + pin[q];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tile_row(r, lk);
+            accy[0][q][r] = (HALF >= 32 || row < HALF) ? gzp[row * HW] : 0.f;
+        }
     }
     __syncthreads();                     // g_h2 complete: the transposed 3x3 reads neighbouring waves' columns
     {   // g_h1 = (NN.2^T (*) g_h2) * [h1 > 0]: adjoint of the reflect-padded gather.  Output pixel p of tap (dy,dx)
@@ -536,18 +558,8 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
         tiles_to_plane<G, RT1>(acc, H1, HID, pix, lk);       // g_h1 plane
         if constexpr (CTX == 0) rows_store_t<G, HID, HID>(s_gh1, H1, b0, B, wave, lane);   // weight-gradient operand plane
     }
-    {   // g_y0 = NN.0^T g_h1 + g_z0: the accumulators start from g_z0 (rows of the single tile = channels 0..31 in
-        // natural order; read again from global memory, 128 contiguous bytes per row and half wave)
-        f32x16 acc[1][PTW];
-#pragma unroll
-        for (int q = 0; q < PTW; ++q) {
-            const float* gzp = gz + (int64_t)min(b0 + pix[q] / HW, B - 1) * C * HW + pin[q];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = tile_row(r, lk);
-                acc[0][q][r] = (HALF >= 32 || row < HALF) ? gzp[row * HW] : 0.f;
-            }
-        }
+    {   // g_y0 = NN.0^T g_h1 + g_z0: the accumulators start from g_z0 (requested before the transposed 3x3)
+        f32x16 (&acc)[1][PTW] = accy;
         dense_phase<G, G::KS3, G::NG3, 1>(acc, rsb, Bw::OFF_A1T, H1, pix, lane);
         // g_y plane in LDS: rows [0, HALF) = g_y1 (the Y0 region, parked above), rows [HALF, C) = g_y0 (first rows of the H
         // region: g_h1 is dead for this wave now); A0T is packed with its k in that order

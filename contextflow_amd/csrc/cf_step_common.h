@@ -263,6 +263,9 @@ __device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const floa
     const int idx0 = lane / (WPX / 4), col = wave * WPX + 4 * (lane % (WPX / 4));
     const int voff = ((col / HW) * CT * HW + idx0 * HW + col % HW) * 4;
     cf_wave_sync();
+#ifdef CF_ABL_NOSTORE                    // timing-only ablation (tools/dev/make_abl.py): no plane stores
+    if (tb0 >= 0) return;
+#endif
 #pragma unroll
     for (int i = 0; i < (NROWS + RPI - 1) / RPI; ++i) {
         if (NROWS % RPI == 0 || idx0 + i * RPI < NROWS) {

@@ -24,16 +24,16 @@ for (C, H) in [(16, 16), (32, 8), (64, 4)]:
     assert L.cf_flow_step_prepare(P(Wm), P(t), P(logs), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), P(ws), I(C), I(H), I(H), st) == 0
     assert L.cf_flow_step_bwd_prepare(P(Wm), P(logs), P(w1), P(w2), P(w3), P(wsb), I(C), I(H), I(H), st) == 0
     x, gz, gld = r(B, C, H, H), r(B, C, H, H), r(B)
+    L.cf_flow_step_tape_aux_bytes.restype = ctypes.c_int64
     new = lambda rows: torch.empty(B, rows, HW, device=dev)
     gx = torch.empty(B, C, H, H, device=dev)
-    bufs = [new(HALF), new(HID), new(HID), new(C), new(HID), new(HID), new(C)]
-    taped = os.environ.get("CF_TAPED", "1") != "0"
-    if taped:
-        for b in bufs[:3]:
-            b.normal_()                                   # stand-in tape: half the ReLU masks set
-    fn = L.cf_flow_step_bwd_taped if taped else L.cf_flow_step_bwd
-    run = lambda: fn(P(x), P(gz), P(gld), P(ws), P(wsb), P(gx), *[P(b) for b in bufs], I(B), I(C), I(H), I(H),
-                     ctypes.c_int64(C * HW), I(0), st)
+    z, ld = torch.empty_like(x), torch.zeros(B, device=dev)
+    y0, h1, h2 = new(HALF), new(HID), new(HID)
+    aux = torch.empty(L.cf_flow_step_tape_aux_bytes(I(B), I(C), I(H), I(H)), device=dev, dtype=torch.uint8)
+    assert L.cf_flow_step_fwd_taped(P(x), P(z), P(ld), P(ws), P(y0), P(h1), P(h2), P(aux), I(B), I(C), I(H), I(H),
+                                    ctypes.c_int64(C * HW), I(0), st) == 0
+    bufs = [new(C), new(HID), new(HID), new(C)]
+    run = lambda: L.cf_flow_step_bwd_taped(P(gz), P(gld), P(wsb), P(aux), P(gx), *[P(b) for b in bufs], I(B), I(C), I(H), I(H), st)
     for _ in range(2):
         assert run() == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

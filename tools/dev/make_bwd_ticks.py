@@ -6,29 +6,28 @@ import glob, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = open(os.path.join(root, "contextflow_amd/csrc/cf_step_bwd.hip")).read()
 marks = [
-    ("    // ---------------------------------------------------------------- forward recompute\n", None),
-    ("    unsigned m1[RT1][PTW], m2[RT1][PTW];", "p0"),
-    ("    __syncthreads();                     // h1 complete (taps cross waves)\n", "p1"),
-    ("    // phase 3 -> t, raw\n", "p2"),
-    ("    // ---------------------------------------------------------------- backward\n", "p3"),
+    ("    // ---------------------------------------------------------------- what the data-gradient chain needs of the forward\n", None),
+    ("    // ---------------------------------------------------------------- backward\n", "tape"),
     ("        // g_h2 = (NN.4^T g_h) * [h2 > 0]\n", "gz_gh"),
-    ("    __syncthreads();                     // g_h2 complete", "p3T"),
-    ("    {   // g_y0 = NN.0^T g_h1 + g_z0", "p2T"),
-    ("        // g_x = (e^{-logs} Wm)^T g_y\n", "p1T"),
+    ("    __syncthreads();                     // g_h2 complete", "a3t"),
+    ("            __syncthreads();             // fold slots in place\n", "bar+build"),
+    ("        __syncthreads();                 // everyone done reading g_h2\n", "bar+taps"),
+    ("    {   // g_y0 = NN.0^T g_h1 + g_z0", "bar+gh1"),
+    ("        // g_x = (e^{-logs} Wm)^T g_y\n", "a1t"),
 ]
 out = src
 names = []
 for k, (m, name) in enumerate(marks):
     assert m in out, m
     if name is None:
-        out = out.replace(m, m + "    long long tacc[12]; for (int k = 0; k < 12; ++k) tacc[k] = 0; long long tp = __builtin_readcyclecounter();\n"
-                          "#define TICK(k) { long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tp; tp = tn; }\n")
+        out = out.replace(m, m + "    long long tacc[12]; for (int k = 0; k < 12; ++k) tacc[k] = 0; long long tprev = __builtin_readcyclecounter();\n"
+                          "#define TICK(k) { long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; }\n")
     else:
         out = out.replace(m, "    TICK(%d);\n" % len(names) + m)
         names.append(name)
 tail = "        rows_store_t<G, C, C>(gx, GX, b0, B, wave, lane);\n    }\n}"
 assert tail in out
-names.append("p0T")
+names.append("a0t")
 out = out.replace(tail, "        rows_store_t<G, C, C>(gx, GX, b0, B, wave, lane);\n    }\n    TICK(%d);\n    __syncthreads();\n"
                   "    if (blockIdx.x == 0 && lane == 0) for (int k = 0; k < 12; ++k) gx[wave * 12 + k] = (float)tacc[k];\n}" % (len(names) - 1))
 tmp = os.path.join(root, "contextflow_amd/build/abl")
