@@ -211,6 +211,49 @@ def secondary_throughput(name, dev, G, chunk, steps, warmup, cpu):
     return out
 
 
+def secondary_training(name, dev, B, iters, graph):
+    """SURVEY.md 8(f)1, the caller right after the path (experiment_cl.py:123-136): one optimisation step = forward,
+    loss (cross-entropy over the M class mixtures of logp / D), hand-written backward, AdamW - eagerly launched at a
+    saturating batch, or as ONE captured HIP graph at the reference's batch of 256 (FlowSequential.capture_train_step)."""
+    model, cfg = build(name, dev)
+    x = synth(name, B, dev, seed=4000)
+    M = 10
+    gt = torch.randint(0, M, (B,), device=dev)
+    inv = 1.0 / DIMS[name]
+    loss_fn = lambda logp, y: torch.nn.functional.cross_entropy(logp * inv, y)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=graph)
+    if graph:
+        step = model.capture_train_step(x, loss_fn, opt)
+        run = lambda: step(x, gt)
+    else:
+        def run():
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(model.log_prob(x), gt)
+            loss.backward()
+            opt.step()
+            return loss
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    # algorithmic dense work of a step: forward + data gradients + weight gradients = 3x the forward contractions
+    tf = 3 * total_flop_per_sample(name) * B / dt / 1e12
+    out = {"metric": "samples/s training step (fwd + bwd + AdamW), %s" % LABEL[name], "value": round(B / dt, 1), "unit": "samples/s",
+           "config": {"workload": "%s --coupling %s" % (name, cfg["coupling"]), "batch": B, "iters": iters,
+                      "launch": "one captured HIP graph" if graph else "eager"},
+           "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss), 5),
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "basis": "whole step, 3x the forward's dense flop (forward, data gradients, weight gradients)"}}
+    del model, x, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary_small_batch(name, dev, B, cpu, iters=300):
     """The reference's operating point (config.py:10: batch 256; BASELINE config 1: 64): latency of ONE eval forward
     through the public API (`flow.log_prob(x)` under no_grad), eagerly launched and - the default once a shape repeats -
@@ -335,6 +378,8 @@ def main():
                 secondary_small_batch("cifar10", dev, 64, cpu),
                 secondary_small_batch("cifar10", dev, 256, cpu=False),     # its CPU baseline is the headline's (batch 256)
                 secondary_small_batch("mnist", dev, 64, cpu),
+                secondary_training("cifar10", dev, 8192, 10, graph=False),
+                secondary_training("cifar10", dev, 256, 50, graph=True),
             ]
         print(json.dumps(out))
     if world > 1:
