@@ -72,6 +72,20 @@ __global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm,
         const int ch = chan_of_row<G>(rt * 32 + (lane & 31)), k = 2 * (4 * g + j) + (lane >> 5);
         ws[G::OFF_A3 + e] = (ch >= 0 && k < G::HID) ? w3[ch * G::HID + k] : 0.f;
     }
+    {   // Winograd-domain weights of NN.2: U[xi][nu] = G w G^T (fp64, rounded once), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+        constexpr int HID = G::HID;
+        const double Gm[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+        for (int e = gtid; e < 16 * HID * HID; e += gsz) {
+            const int jj = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+            const int kg = q % G::KG4, rt16 = (q / G::KG4) % G::RT16, pos = q / (G::KG4 * G::RT16);
+            const int co = rt16 * 16 + (ln & 15), ci = 4 * (4 * kg + jj) + (ln >> 4), xi = pos >> 2, nu = pos & 3;
+            const float* wk = w2 + ((int64_t)co * HID + ci) * 9;
+            double u = 0.0;
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) u += Gm[xi][a] * Gm[nu][b] * (double)wk[a * 3 + b];
+            ws[G::OFF_AW + e] = (float)u;
+        }
+    }
     if constexpr (G::SMALL) {
         // operands of the 16x16x4 phases: A fragment of k-step s, lane l = A[row = l & 15][k = 4 s + (l >> 4)];
         // element e = (group * 64 + lane) * 4 + j holds k-step 4 group + j
@@ -918,23 +932,25 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
         CF_LAUNCH_CHECK();
         return 0;
     }
-    switch (shape_id(C, H, W) * 4 + variant) {
+    switch (shape_id(C, H, W) * 8 + variant) {
         case 0: CF_STEP(G8); break;
         case 3: rc = in_squeeze ? launch_step_small<G8s, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))
                                 : launch_step_small<G8s, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
-        case 4: CF_STEP(G16); break;
-        case 5: CF_STEP(G16v1); break;
-        case 6: CF_STEP(G16v2); break;
-        case 7: rc = in_squeeze ? launch_step_small<G16s, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))
+        case 8: CF_STEP(G16); break;
+        case 9: CF_STEP(G16v1); break;
+        case 10: CF_STEP(G16v2); break;
+        case 11: rc = in_squeeze ? launch_step_small<G16s, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))
                                 : launch_step_small<G16s, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
-        case 8: CF_STEP(G32); break;
-        case 9: CF_STEP(G32v1); break;
-        case 10: CF_STEP(G32v2); break;
-        case 11: CF_STEP(G32v3); break;
-        case 12: CF_STEP(G64); break;
-        case 13: CF_STEP(G64v1); break;
-        case 14: CF_STEP(G64v2); break;
-        case 15: CF_STEP(G64v3); break;
+        case 16: CF_STEP(G32); break;
+        case 17: CF_STEP(G32v1); break;
+        case 18: CF_STEP(G32v2); break;
+        case 19: CF_STEP(G32v3); break;
+        case 24: CF_STEP(G64); break;
+        case 25: CF_STEP(G64v1); break;
+        case 26: CF_STEP(G64v2); break;
+        case 27: CF_STEP(G64v3); break;
+        case 20: CF_STEP(G32w); break;            // variant 4: Winograd F(2x2,3x3) form of the 3x3
+        case 28: CF_STEP(G64w); break;
         default: cf_set_error("cf_flow_step_fwd: shape (%d,%d,%d) variant %d unsupported", C, H, W, variant); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEP

@@ -56,7 +56,12 @@ struct Geo {
     static constexpr int OFF_SA3 = OFF_SA0 + (SMALL ? SG0 * 256 : 0);
     static constexpr int OFF_SA1 = OFF_SA3 + (SMALL ? SG3 * 256 : 0);
     static constexpr int OFF_SA2 = OFF_SA1 + (HID16 ? SG1 * 256 : 0);
-    static constexpr int WS_FLOATS = OFF_SA2 + (HID16 ? 9 * 256 : 0);
+    // Winograd F(2x2,3x3) form of the 3x3 (PIPE == 3, winograd_phase2 below): U = G w G^T for the 16 positions, packed as
+    // 16x16x4 A fragments: [position][16-row tile][group of 4 k-steps][lane][4]
+    static constexpr bool WINO = (PIPE_ == 3);
+    static constexpr int RT16 = HID / 16, KG4 = HID / 16;         // row tiles / k-step groups of the 16x16x4 products over HID
+    static constexpr int OFF_AW = OFF_SA2 + (HID16 ? 9 * 256 : 0);
+    static constexpr int WS_FLOATS = OFF_AW + 16 * HID * HID;
     static constexpr int PP = 2 * W + 2 * H + 4;      // fold slots per sample: 2 patched rows, 2 patched columns, 4 corners
     static constexpr int RS = PATCH ? ((PIX + SPW * PP + 1 + 3) & ~3) : PIX;
     static constexpr int LDS_FLOATS = (HALF + HID) * RS;
@@ -340,6 +345,143 @@ __device__ __forceinline__ void mask_store(unsigned* __restrict__ m, const f32x1
         }
 }
 
+// ---- Winograd F(2x2,3x3) form of the reflect-padded 3x3 (phase 2 of PIPE == 3 geometries) ---------------------------
+// The 3x3 holds 72 of the 80 C^2 HW multiply-adds of a step and the exact-fp32 matrix pipe is the bound of the whole path,
+// so the way past it is fewer multiplications: per 2x2 output tile and channel pair, 16 products instead of 36,
+//     Y = A^T [ sum_ci U[ci] (.) (B^T d[ci] B) ] A,     U = G w G^T (packed once, fp64 -> fp32, k_step_pack),
+// d = the 4x4 input patch of the tile (reflect-padded), B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]],
+// A^T = [[1,1,1,0],[0,1,-1,-1]].  All entries are 0 / +-1 (the 1/2 of G lives in the packed weights): the transforms are
+// additions, the error of the fp32 result is ~1.6x that of the direct sum (tools/dev/winograd_numerics.py: bits/dim of
+// every end-to-end fixture unchanged to its last fp32 digit).
+// Mapping: the 16 "positions" (xi, nu) are 16 independent (HID x HID) x (HID x tiles) products on v_mfma_f32_16x16x4_f32;
+// a wave owns the 16 tiles (= 64 output pixels) of its own pixel columns and ALL output rows, so the B operand - one
+// Winograd-domain value per lane and k-step = 4 LDS reads + 3 additions - serves HID/16 MFMAs, and h2 goes straight back to
+// this wave's columns.  The output transform is folded position by position into the four Y accumulators (+-M).
+// h1 layout (written by phase 1 of the same geometry): pixel (s, y, x) of row k sits at
+//     k PIX + [ s HW + (y&1) HW/2 + (y>>1) W + (x&1) W/2 + (x>>1) ]  ^  (k&1) W/2
+// - rows and columns split by parity, so the stride-2 patch reads of neighbouring tiles are consecutive words, and the
+// XOR moves odd rows k to the other column-parity block: the 32 lanes of a half wave (16 tiles x 2 channels) hit 32 banks.
+template <class G> __device__ __forceinline__ int wino_pix(int sHW, int y, int x) {
+    int p = sHW + (y & 1) * (G::HW / 2) + (y >> 1) * G::W + (x & 1) * (G::W / 2) + (x >> 1);
+    if constexpr (G::HW == 16) p ^= ((p >> 5) & 1) << 3;       // 4x4: four samples per wave - fold the sample bit that would alias
+    return p;
+}
+
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+template <class G>
+__device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const float* __restrict__ wsl, ws_rsrc_t rs, int lane,
+                                                int wave) {
+    constexpr int W = G::W, H = G::H, HW = G::HW, PIX = G::PIX, HALF = G::HALF, HID = G::HID, RT16 = G::RT16, KG4 = G::KG4;
+    static_assert(G::PTW == 2 && HID % 16 == 0, "a wave owns 64 pixels = 16 output tiles");
+    float* H1 = lds + HALF * PIX;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int TPS = HW / 4;                              // tiles per sample
+    const int tg = wave * 16 + l15, smp = tg / TPS, ti = tg % TPS, ty = ti / (W / 2), tx = ti % (W / 2);
+    int off[4][4];                                            // the 4x4 patch of this lane's tile, row lg of a k-step
+    {
+        int ry[4], rx[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int yy = 2 * ty - 1 + a, xx = 2 * tx - 1 + a;
+            ry[a] = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+            rx[a] = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) off[a][b] = HALF * PIX + lg * PIX + (wino_pix<G>(smp * HW, ry[a], rx[b]) ^ ((lg & 1) * (W / 2)));
+    }
+    f32x4w Y[2][2][RT16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) Y[i][j][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    // Operands of one group of 4 k-steps: RT16 weight fragments + the 4 patch values behind each of the 4 Winograd-domain
+    // operands.  Two-stage pipeline as in dense_phase: the loads of group g+1 are issued, then the 3 additions per k-step and
+    // the MFMAs of group g run (sched_barrier keeps hipcc from sinking the loads to their first use or hoisting a whole
+    // position's worth of them: both were tried by the compiler, the second one spills).
+    struct WOps { float4 a[RT16]; float d[4][4]; };
+    constexpr int KGC = KG4 < 4 ? KG4 : 4, NCH = KG4 / KGC;       // k in chunks of <= 64 channels: addresses = patch offset + immediate
+    static_assert(KGC % 2 == 0, "static ping-pong");
+    constexpr int A1[4] = {0, 1, 1, 1}, A2[4] = {2, 2, 2, 3};           // the two patch rows / columns of B^T row xi
+    constexpr float S1[4] = {1.f, 1.f, -1.f, 1.f}, S2[4] = {-1.f, 1.f, 1.f, -1.f};
+    constexpr float AT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+        const int xi = pos >> 2, nu = pos & 3;
+        const int o11 = off[A1[xi]][A1[nu]], o12 = off[A1[xi]][A2[nu]], o21 = off[A2[xi]][A1[nu]], o22 = off[A2[xi]][A2[nu]];
+        f32x4w M[RT16];
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) M[rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+        const int fr = G::OFF_AW + pos * RT16 * KG4 * 256;
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch) {
+            const float* base = lds + ch * (16 * KGC) * PIX;
+            auto load = [&](int kk, WOps& o) {
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) o.a[rt] = ws_frag(rs, lane, fr + (rt * KG4 + ch * KGC + kk) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* row = base + (16 * kk + 4 * e) * PIX;
+                    o.d[e][0] = row[o11]; o.d[e][1] = row[o12]; o.d[e][2] = row[o21]; o.d[e][3] = row[o22];
+                }
+            };
+            WOps ops[2];
+            load(0, ops[0]);
+#pragma unroll
+            for (int kk = 0; kk < KGC; ++kk) {
+                if (kk + 1 < KGC) load(kk + 1, ops[(kk + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const WOps& o = ops[kk & 1];
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t1 = S1[nu] * o.d[e][0] + S2[nu] * o.d[e][1];
+                    const float t2 = S1[nu] * o.d[e][2] + S2[nu] * o.d[e][3];
+                    v[e] = S1[xi] * t1 + S2[xi] * t2;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int rt = 0; rt < RT16; ++rt) M[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(o.a[rt], e), v[e], M[rt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // output transform, folded: Y[i][j] += A^T[i][xi] A^T[j][nu] M
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float c = AT[i][xi] * AT[j][nu];
+                if (c != 0.f) {
+#pragma unroll
+                    for (int rt = 0; rt < RT16; ++rt) Y[i][j][rt] = c > 0.f ? Y[i][j][rt] + M[rt] : Y[i][j][rt] - M[rt];
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                 // every wave has finished reading h1
+    // h2 = relu(Y + b), natural [row][pixel] layout, this wave's own columns (phase 3 reads them as MFMA operands)
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) {
+        const float4 b = *reinterpret_cast<const float4*>(wsl + G::OFF_B2 + rt * 16 + 4 * lg);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float* dst = H1 + (rt * 16 + 4 * lg) * PIX + smp * HW + (2 * ty + i) * W + 2 * tx + j;
+                dst[0] = cf_relu(Y[i][j][rt][0] + b.x);
+                dst[PIX] = cf_relu(Y[i][j][rt][1] + b.y);
+                dst[2 * PIX] = cf_relu(Y[i][j][rt][2] + b.z);
+                dst[3 * PIX] = cf_relu(Y[i][j][rt][3] + b.w);
+            }
+    }
+    cf_wave_sync();
+}
+
 // ---- the conditioner: phases 1-3 of a step (shared by the forward and the inverse kernel) --------------
 // In: Y0 = y0 plane (this wave's columns).  Out: acc3 = NN.4 output tiles (t rows / raw rows, packed-row
 // layout of chan_of_row).  Uses the H region of LDS for h1 / h2; two workgroup barriers.
@@ -386,8 +528,14 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + tile_row(r, lk);
-                    if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
+                    if constexpr (G::WINO) {     // parity-split pixel order of winograd_phase2 (row & 1 = r & 1)
+                        const int pw = wino_pix<G>(pix[q] - pin[q], pin[q] / W, pin[q] % W) ^ ((r & 1) * (W / 2));
+                        if (row < HID) H1[row * PIX + pw] = cf_relu(acc[rt][q][r]);
+                    } else {
+                        if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
+                    }
                 }
+        static_assert(!(DUMP && G::WINO), "the training tape is written by the direct-form geometries");
         if constexpr (DUMP) {
             cf_wave_sync();
             rows_store_t<G, HID, HID>(tp.h1, H1, tile * G::SPW, B, tid >> 6, lane);
@@ -401,7 +549,9 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
     }
 
     // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
-    {
+    if constexpr (G::WINO) {
+        winograd_phase2<G>(lds, wsl, rs, lane, tid >> 6);
+    } else {
         f32x16 acc[RT1][PTW];
 #pragma unroll
         for (int rt = 0; rt < RT1; ++rt)
@@ -602,6 +752,8 @@ using G32v3 = Geo<32, 8, 8, 8, 0>;
 using G64v1 = Geo<64, 4, 4, 16, 1, 1>;
 using G64v2 = Geo<64, 4, 4, 8, 1>;
 using G64v3 = Geo<64, 4, 4, 16, 0>;
+using G32w = Geo<32, 8, 8, 4, 3>;        // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2)
+using G64w = Geo<64, 4, 4, 16, 3>;
 
 
 int shape_id(int C, int H, int W) {
