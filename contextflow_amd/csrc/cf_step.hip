@@ -301,7 +301,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // DUMP (training): y0 and the post-ReLU h1 / h2 planes also go to the tape `tp` (see k_flow_step).
 template <class G, bool SQ, bool DBG = false, bool DUMP = false>
-__global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
+__global__ __launch_bounds__(256, G::WINO ? 3 : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
                                                                   float* __restrict__ ldj_acc, const float* __restrict__ ws,
                                                                   int B, int64_t xbs, float* __restrict__ dbg, StepTape tp) {
     static_assert(G::SMALL, "16x16 images, one sample per workgroup, C <= 16");
@@ -376,6 +376,9 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* _
 #pragma unroll
         for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q]; }
         f32x16 unused[G::RT03][PTW];
+        // the parity-split h1 layout of the Winograd form scatters a wave's pixels over the whole plane of this (single)
+        // sample: every wave must be done with its columns of the x plane first
+        if constexpr (G::WINO) __syncthreads();
         conditioner_net<G, 0, DUMP, 2>(unused, lds, ws, pix, pin, lane, tid, DBG ? dbg : nullptr, dbg_cols, tile, nullptr, nullptr, tp, B);
     } else {
         f32x4 a1[4];
@@ -949,8 +952,14 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
         case 25: CF_STEP(G64v1); break;
         case 26: CF_STEP(G64v2); break;
         case 27: CF_STEP(G64v3); break;
+        case 12: rc = in_squeeze ? launch_step_small<G16w, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))
+                                : launch_step_small<G16w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
         case 20: CF_STEP(G32w); break;            // variant 4: Winograd F(2x2,3x3) form of the 3x3
         case 28: CF_STEP(G64w); break;
+        case 21: CF_STEP(G32wa); break;
+        case 29: CF_STEP(G64wa); break;
+        case 22: CF_STEP(G32wb); break;
+        case 23: CF_STEP(G32wc); break;
         default: cf_set_error("cf_flow_step_fwd: shape (%d,%d,%d) variant %d unsupported", C, H, W, variant); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEP

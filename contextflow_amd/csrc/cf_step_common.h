@@ -378,20 +378,18 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
     const int l15 = lane & 15, lg = lane >> 4;
     constexpr int TPS = HW / 4;                              // tiles per sample
     const int tg = wave * 16 + l15, smp = tg / TPS, ti = tg % TPS, ty = ti / (W / 2), tx = ti % (W / 2);
-    int off[4][4];                                            // the 4x4 patch of this lane's tile, row lg of a k-step
-    {
-        int ry[4], rx[4];
+    // patch offsets: the permuted pixel offset is a sum of a row part and a column part (disjoint bit fields; the XOR of odd
+    // k rows only touches the column-parity bit), so 4 + 4 registers describe the 4x4 patch of this lane's tile
+    int rpart[4], cpart[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            int yy = 2 * ty - 1 + a, xx = 2 * tx - 1 + a;
-            ry[a] = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
-            rx[a] = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) off[a][b] = HALF * PIX + lg * PIX + (wino_pix<G>(smp * HW, ry[a], rx[b]) ^ ((lg & 1) * (W / 2)));
+    for (int a = 0; a < 4; ++a) {
+        int yy = 2 * ty - 1 + a, xx = 2 * tx - 1 + a;
+        yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+        xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+        rpart[a] = HALF * PIX + lg * PIX + wino_pix<G>(smp * HW, yy, 0);
+        cpart[a] = (((xx ^ lg) & 1) * (W / 2)) + (xx >> 1);
     }
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
     f32x4w Y[2][2][RT16];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -400,68 +398,95 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
             for (int rt = 0; rt < RT16; ++rt) Y[i][j][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
     // Operands of one group of 4 k-steps: RT16 weight fragments + the 4 patch values behind each of the 4 Winograd-domain
-    // operands.  Two-stage pipeline as in dense_phase: the loads of group g+1 are issued, then the 3 additions per k-step and
-    // the MFMAs of group g run (sched_barrier keeps hipcc from sinking the loads to their first use or hoisting a whole
-    // position's worth of them: both were tried by the compiler, the second one spills).
-    struct WOps { float4 a[RT16]; float d[4][4]; };
-    constexpr int KGC = KG4 < 4 ? KG4 : 4, NCH = KG4 / KGC;       // k in chunks of <= 64 channels: addresses = patch offset + immediate
+    // operands (k-steps paired: the three additions per operand run as packed fp32 pairs).  Two-stage pipeline as in
+    // dense_phase: the loads of group g+1 - of the next position after a position's last group - are issued, then the
+    // additions and MFMAs of group g run (sched_barrier keeps hipcc from sinking the loads to their first use or hoisting a
+    // whole position's worth of them).  k runs in chunks of <= 64 channels (outer loop): inside a chunk every operand
+    // address is `patch offset + immediate`, and the output transform is linear, so each chunk's partial M is folded into Y.
+    struct WFrag { float4 a[RT16]; };
+    struct WPatch { f32x2w d[2][4]; };
+    constexpr int KGC = KG4 < 4 ? KG4 : 4, NCH = KG4 / KGC;
     static_assert(KGC % 2 == 0, "static ping-pong");
     constexpr int A1[4] = {0, 1, 1, 1}, A2[4] = {2, 2, 2, 3};           // the two patch rows / columns of B^T row xi
     constexpr float S1[4] = {1.f, 1.f, -1.f, 1.f}, S2[4] = {-1.f, 1.f, 1.f, -1.f};
     constexpr float AT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
-#pragma unroll
-    for (int pos = 0; pos < 16; ++pos) {
-        const int xi = pos >> 2, nu = pos & 3;
-        const int o11 = off[A1[xi]][A1[nu]], o12 = off[A1[xi]][A2[nu]], o21 = off[A2[xi]][A1[nu]], o22 = off[A2[xi]][A2[nu]];
-        f32x4w M[RT16];
-#pragma unroll
-        for (int rt = 0; rt < RT16; ++rt) M[rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
-        const int fr = G::OFF_AW + pos * RT16 * KG4 * 256;
 #pragma unroll 1
-        for (int ch = 0; ch < NCH; ++ch) {
-            const float* base = lds + ch * (16 * KGC) * PIX;
-            auto load = [&](int kk, WOps& o) {
+    for (int ch = 0; ch < NCH; ++ch) {
+        const float* base = lds + ch * (16 * KGC) * PIX;
+        const int frc = G::OFF_AW + ch * KGC * 256;
+        // group g = pos * KGC + kk of this chunk.  Weight fragments (L2) and patch values (LDS) are requested one group ahead,
+        // ping-pong (a ring of three fragment sets, two groups ahead, was tried: no gain at C = 32, spills at C = 64)
+        constexpr int NA = 2;
+        WFrag fa[NA];
+        WPatch pd[2];
+        auto load_a = [&](int g, WFrag& o) {
+            const int pos = g / KGC, kk = g % KGC;
 #pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) o.a[rt] = ws_frag(rs, lane, fr + (rt * KG4 + ch * KGC + kk) * 256);
+            for (int rt = 0; rt < RT16; ++rt)
+                o.a[rt] = ws_frag(rs, lane, G::ABL == 2 ? G::OFF_AW + rt * 256 : frc + ((pos * RT16 + rt) * KG4 + kk) * 256);   // ABL 2 (timing only): L1-resident fragments
+        };
+        auto load_d = [&](int g, WPatch& o) {
+            const int pos = g / KGC, kk = g % KGC, xi = pos >> 2, nu = pos & 3;
+            const int o11 = rpart[A1[xi]] + cpart[A1[nu]], o12 = rpart[A1[xi]] + cpart[A2[nu]];
+            const int o21 = rpart[A2[xi]] + cpart[A1[nu]], o22 = rpart[A2[xi]] + cpart[A2[nu]];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float* row = base + (16 * kk + 4 * e) * PIX;
-                    o.d[e][0] = row[o11]; o.d[e][1] = row[o12]; o.d[e][2] = row[o21]; o.d[e][3] = row[o22];
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const float* r0 = base + (16 * kk + 8 * e2) * PIX;
+                const float* r1 = r0 + 4 * PIX;
+                if constexpr (G::ABL == 4) {             // timing only: no patch reads
+                    o.d[e2][0] = f32x2w{0.001f * (o11 + e2), 0.002f * o12};
+                    continue;
                 }
-            };
-            WOps ops[2];
-            load(0, ops[0]);
+                o.d[e2][0] = f32x2w{r0[o11], r1[o11]}; o.d[e2][1] = f32x2w{r0[o12], r1[o12]};
+                o.d[e2][2] = f32x2w{r0[o21], r1[o21]}; o.d[e2][3] = f32x2w{r0[o22], r1[o22]};
+            }
+        };
+        constexpr int NGR = 16 * KGC;
+#pragma unroll
+        for (int g = 0; g < NA - 1; ++g) load_a(g, fa[g]);
+        load_d(0, pd[0]);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            const int xi = pos >> 2, nu = pos & 3;
+            f32x4w M[RT16];
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) M[rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < KGC; ++kk) {
-                if (kk + 1 < KGC) load(kk + 1, ops[(kk + 1) & 1]);
+                const int g = pos * KGC + kk;
+                if (g + NA - 1 < NGR) load_a(g + NA - 1, fa[(g + NA - 1) % NA]);
+                if (g + 1 < NGR) load_d(g + 1, pd[(g + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                const WOps& o = ops[kk & 1];
-                float v[4];
+                const WFrag& oa = fa[g % NA];
+                const WPatch& o = pd[g & 1];
+                f32x2w v[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t1 = S1[nu] * o.d[e][0] + S2[nu] * o.d[e][1];
-                    const float t2 = S1[nu] * o.d[e][2] + S2[nu] * o.d[e][3];
-                    v[e] = S1[xi] * t1 + S2[xi] * t2;
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const f32x2w t1 = S1[nu] * o.d[e2][0] + S2[nu] * o.d[e2][1];
+                    const f32x2w t2 = S1[nu] * o.d[e2][2] + S2[nu] * o.d[e2][3];
+                    v[e2] = S1[xi] * t1 + S2[xi] * t2;
+                    if constexpr (G::ABL == 3 || G::ABL == 4) v[e2] = o.d[e2][0];      // timing only: no transform additions
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int rt = 0; rt < RT16; ++rt) M[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(o.a[rt], e), v[e], M[rt], 0, 0, 0);
+                    for (int rt = 0; rt < RT16; ++rt)
+                        M[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[e >> 1][e & 1], M[rt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        // output transform, folded: Y[i][j] += A^T[i][xi] A^T[j][nu] M
+            // output transform, folded: Y[i][j] += A^T[i][xi] A^T[j][nu] M
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float c = AT[i][xi] * AT[j][nu];
-                if (c != 0.f) {
+                for (int j = 0; j < 2; ++j) {
+                    const float c = AT[i][xi] * AT[j][nu];
+                    if (c != 0.f) {
 #pragma unroll
-                    for (int rt = 0; rt < RT16; ++rt) Y[i][j][rt] = c > 0.f ? Y[i][j][rt] + M[rt] : Y[i][j][rt] - M[rt];
+                        for (int rt = 0; rt < RT16; ++rt) Y[i][j][rt] = c > 0.f ? Y[i][j][rt] + M[rt] : Y[i][j][rt] - M[rt];
+                    }
                 }
-            }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     __syncthreads();                 // every wave has finished reading h1
     // h2 = relu(Y + b), natural [row][pixel] layout, this wave's own columns (phase 3 reads them as MFMA operands)
@@ -754,6 +779,11 @@ using G64v2 = Geo<64, 4, 4, 8, 1>;
 using G64v3 = Geo<64, 4, 4, 16, 0>;
 using G32w = Geo<32, 8, 8, 4, 3>;        // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2)
 using G64w = Geo<64, 4, 4, 16, 3>;
+using G16w = Geo<16, 16, 16, 1, 3>;      // k_flow_step_small with the Winograd 3x3
+using G32wa = Geo<32, 8, 8, 4, 3, 2>;    // timing-only ablations of the Winograd form (tools/dev/wino_check.py)
+using G64wa = Geo<64, 4, 4, 16, 3, 2>;
+using G32wb = Geo<32, 8, 8, 4, 3, 3>;
+using G32wc = Geo<32, 8, 8, 4, 3, 4>;
 
 
 int shape_id(int C, int H, int W) {
