@@ -20,6 +20,7 @@
 //    hop across waves, then a plain read-modify-write of ldj_acc[b] by the single owner of sample
 //    b — no float atomics, bitwise reproducible.
 #include "cf_step_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -976,6 +977,10 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     const int sid = shape_id(C, H, W);
     if ((sid == 2 && B < 256 * G32::SPW) || (sid == 3 && B < 256 * G64::SPW)) flags = 2 << 16;
     if (sid == 0 || sid == 1) flags = 3 << 16;      // 16x16 images: k_flow_step_small
+    // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2): 40 instead of 80 C^2 HW multiply-adds per sample and step.
+    // CONTEXTFLOW_DIRECT_CONV=1 keeps the direct form (A/B measurements, tools/step_bench.py).
+    static const bool direct_only = [] { const char* e = getenv("CONTEXTFLOW_DIRECT_CONV"); return e && e[0] == '1'; }();
+    if (!direct_only && (sid == 1 || (sid == 2 && B >= 256 * G32::SPW) || (sid == 3 && B >= 256 * G64::SPW))) flags = 4 << 16;
     // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
     if ((sid == 2 && B <= 512) || (sid == 3 && B <= 1024)) {
         CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);

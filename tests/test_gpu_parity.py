@@ -1549,3 +1549,61 @@ def test_rccl_communicator_runs_every_collective_of_the_data_parallel_path(tmp_p
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ------------------------------------------------------------------------------------------ Winograd form of the 3x3
+@pytest.mark.parametrize("tag", [None, "stress", "extreme"])
+@pytest.mark.parametrize("name", ["mnist", "cifar10"])
+def test_e2e_at_saturating_batch_runs_the_winograd_kernels(L, name, tag):
+    """At the batch sizes the benchmark runs (>= 4096 samples per call) every resolution level takes the Winograd
+    F(2x2,3x3) form of the coupling net's 3x3 (cf_step_common.h: winograd_phase2; small batches take the direct form at
+    8x8 / 4x4).  The fixture's samples and captured noise, repeated to 4096 rows, must reproduce the reference's
+    per-sample log-densities within the same bits/dim bar as the small-batch test, in every parameter regime."""
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e(name, tag)
+    x, u, eps = e2e_inputs(name, fx)
+    rep = 4096 // x.shape[0]
+    tol = stress_tolerance(fx, tag) if tag else BPD_TOL
+    model = build_model(name, params)
+    set_noise(model, u.repeat(rep, 1, 1, 1), [e.repeat(rep, *([1] * (e.dim() - 1))) for e in eps])
+    z, logp = model(x.repeat(rep, 1, 1, 1).to(DEV))
+    ref = torch.from_numpy(fx["logp"]).repeat(rep, 1)
+    d32 = (bpd(logp.cpu(), name) - bpd(ref, name)).abs().max().item()
+    print("%s %s B=%d: |d bits/dim| vs reference fp32 %.2e (bar %.1e)" % (name, tag, x.shape[0] * rep, d32, tol))
+    assert d32 < tol
+    if "logp_f64" in fx:
+        ref64 = torch.from_numpy(fx["logp_f64"]).repeat(rep, 1)
+        assert (bpd(logp.cpu(), name) - bpd(ref64, name)).abs().max().item() < tol
+    zr = torch.from_numpy(fx["z"]).repeat(rep, 1, 1, 1)
+    assert (z.cpu() - zr).abs().max().item() <= 2e-4 * max(1.0, zr.abs().max().item())
+
+
+@pytest.mark.parametrize("squeeze", [False, True])
+@pytest.mark.parametrize("C,H", [(16, 16), (32, 8), (64, 4)])
+def test_winograd_step_kernel_against_the_oracle(L, C, H, squeeze):
+    """One fused step through the production entry point at a batch that selects the Winograd kernels (4100 samples: the
+    last workgroup is partially filled), against the oracle of the same step and against the direct-form kernel: z to
+    1e-5 of its scale, the log-det to 1e-5 relative - the bars of test_fused_step_phases."""
+    from tests.gpu_util import fused_step_debug
+    B, W = 4100, H
+    torch.manual_seed(C * 1000 + 7)
+    conv, act, cpl = L.Conv1x1((C, H, W)), L.ActNorm((C, H, W)), L.Coupling(C, kernel_size=(3, 3), padding=(1, 1))
+    with torch.no_grad():
+        conv.NN.add_(0.1 * torch.randn(C, C))
+        act.NN_t.copy_(0.3 * torch.randn(C)); act.NN_logs.copy_(0.2 * torch.randn(C)); act.initialized.fill_(1)
+    act._init_done = True
+    x = torch.randn(B, C, H, W)
+    p = {"0." + k: v.detach().double() for k, v in cpl.state_dict().items()}
+    y, l0 = fo.conv1x1_fwd(x.double(), conv.NN.detach().double())
+    y, l1 = fo.actnorm_fwd(y, act.NN_t.detach().double(), act.NN_logs.detach().double())
+    zref, l2 = fo.coupling_fwd(y, p, "0.", (1, 1))
+    for m in (conv, act, cpl):
+        m.to(DEV)
+    xin = fo.squeeze_inv(x, (2, 2)) if squeeze else x
+    z, ldj, d = fused_step_debug(xin.to(DEV).contiguous(), conv, act, cpl, squeeze=squeeze)
+    scale = max(1.0, zref.abs().max().item())
+    for got in (d["z_prod"], z):                          # Winograd form (production at this batch), direct form (dump kernel)
+        assert (got.cpu().double() - zref).abs().max().item() <= 1e-5 * scale
+    lref = l0 + l1 + l2
+    for got in (d["ldj_prod"], ldj):
+        assert ((got.cpu().double() - lref).abs() / lref.abs().clamp_min(1.0)).max().item() <= 1e-5
