@@ -58,7 +58,7 @@ struct Geo {
     static constexpr int OFF_SA2 = OFF_SA1 + (HID16 ? SG1 * 256 : 0);
     // Winograd F(2x2,3x3) form of the 3x3 (PIPE == 3, winograd_phase2 below): U = G w G^T for the 16 positions, packed as
     // 16x16x4 A fragments: [position][16-row tile][group of 4 k-steps][lane][4]
-    static constexpr bool WINO = (PIPE_ == 3);
+    static constexpr bool WINO = (PIPE_ == 3 || PIPE_ == 4);      // 4: the xi loop of winograd_phase2 stays a loop
     static constexpr int RT16 = HID / 16, KG4 = HID / 16;         // row tiles / k-step groups of the 16x16x4 products over HID
     static constexpr int OFF_AW = OFF_SA2 + (HID16 ? 9 * 256 : 0);
     static constexpr int WS_FLOATS = OFF_AW + 16 * HID * HID;
@@ -373,30 +373,40 @@ template <class G>
 __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const float* __restrict__ wsl, ws_rsrc_t rs, int lane,
                                                 int wave) {
     constexpr int W = G::W, H = G::H, HW = G::HW, PIX = G::PIX, HALF = G::HALF, HID = G::HID, RT16 = G::RT16, KG4 = G::KG4;
-    static_assert(G::PTW == 2 && HID % 16 == 0, "a wave owns 64 pixels = 16 output tiles");
+    static_assert(G::PTW % 2 == 0 && HID % 16 == 0, "a wave owns NT x 64 pixels = NT column tiles of 16 output tiles");
+    constexpr int NT = G::PTW / 2;                           // column tiles per wave: they share every weight fragment
     float* H1 = lds + HALF * PIX;
     const int l15 = lane & 15, lg = lane >> 4;
     constexpr int TPS = HW / 4;                              // tiles per sample
-    const int tg = wave * 16 + l15, smp = tg / TPS, ti = tg % TPS, ty = ti / (W / 2), tx = ti % (W / 2);
+    int smp[NT], ty[NT], tx[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const int tg = (wave * NT + ct) * 16 + l15, ti = tg % TPS;
+        smp[ct] = tg / TPS; ty[ct] = ti / (W / 2); tx[ct] = ti % (W / 2);
+    }
     // patch offsets: the permuted pixel offset is a sum of a row part and a column part (disjoint bit fields; the XOR of odd
     // k rows only touches the column-parity bit), so 4 + 4 registers describe the 4x4 patch of this lane's tile
-    int rpart[4], cpart[4];
+    int rpart[NT][4], cpart[NT][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        int yy = 2 * ty - 1 + a, xx = 2 * tx - 1 + a;
-        yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
-        xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-        rpart[a] = HALF * PIX + lg * PIX + wino_pix<G>(smp * HW, yy, 0);
-        cpart[a] = (((xx ^ lg) & 1) * (W / 2)) + (xx >> 1);
-    }
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int yy = 2 * ty[ct] - 1 + a, xx = 2 * tx[ct] - 1 + a;
+            yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+            xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+            rpart[ct][a] = HALF * PIX + lg * PIX + wino_pix<G>(smp[ct] * HW, yy, 0);
+            cpart[ct][a] = (((xx ^ lg) & 1) * (W / 2)) + (xx >> 1);
+        }
     typedef float f32x2w __attribute__((ext_vector_type(2)));
-    f32x4w Y[2][2][RT16];
+    f32x4w Y[NT][2][2][RT16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) Y[i][j][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) Y[ct][i][j][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
     // Operands of one group of 4 k-steps: RT16 weight fragments + the 4 patch values behind each of the 4 Winograd-domain
     // operands (k-steps paired: the three additions per operand run as packed fp32 pairs).  Two-stage pipeline as in
     // dense_phase: the loads of group g+1 - of the next position after a position's last group - are issued, then the
@@ -404,7 +414,7 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
     // whole position's worth of them).  k runs in chunks of <= 64 channels (outer loop): inside a chunk every operand
     // address is `patch offset + immediate`, and the output transform is linear, so each chunk's partial M is folded into Y.
     struct WFrag { float4 a[RT16]; };
-    struct WPatch { f32x2w d[2][4]; };
+    struct WPatch { f32x2w d[NT][2][4]; };
     constexpr int KGC = KG4 < 4 ? KG4 : 4, NCH = KG4 / KGC;
     static_assert(KGC % 2 == 0, "static ping-pong");
     constexpr int A1[4] = {0, 1, 1, 1}, A2[4] = {2, 2, 2, 3};           // the two patch rows / columns of B^T row xi
@@ -427,18 +437,21 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
         };
         auto load_d = [&](int g, WPatch& o) {
             const int pos = g / KGC, kk = g % KGC, xi = pos >> 2, nu = pos & 3;
-            const int o11 = rpart[A1[xi]] + cpart[A1[nu]], o12 = rpart[A1[xi]] + cpart[A2[nu]];
-            const int o21 = rpart[A2[xi]] + cpart[A1[nu]], o22 = rpart[A2[xi]] + cpart[A2[nu]];
 #pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-                const float* r0 = base + (16 * kk + 8 * e2) * PIX;
-                const float* r1 = r0 + 4 * PIX;
-                if constexpr (G::ABL == 4) {             // timing only: no patch reads
-                    o.d[e2][0] = f32x2w{0.001f * (o11 + e2), 0.002f * o12};
-                    continue;
+            for (int ct = 0; ct < NT; ++ct) {
+                const int o11 = rpart[ct][A1[xi]] + cpart[ct][A1[nu]], o12 = rpart[ct][A1[xi]] + cpart[ct][A2[nu]];
+                const int o21 = rpart[ct][A2[xi]] + cpart[ct][A1[nu]], o22 = rpart[ct][A2[xi]] + cpart[ct][A2[nu]];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const float* r0 = base + (16 * kk + 8 * e2) * PIX;
+                    const float* r1 = r0 + 4 * PIX;
+                    if constexpr (G::ABL == 4) {             // timing only: no patch reads
+                        o.d[ct][e2][0] = f32x2w{0.001f * (o11 + e2), 0.002f * o12};
+                        continue;
+                    }
+                    o.d[ct][e2][0] = f32x2w{r0[o11], r1[o11]}; o.d[ct][e2][1] = f32x2w{r0[o12], r1[o12]};
+                    o.d[ct][e2][2] = f32x2w{r0[o21], r1[o21]}; o.d[ct][e2][3] = f32x2w{r0[o22], r1[o22]};
                 }
-                o.d[e2][0] = f32x2w{r0[o11], r1[o11]}; o.d[e2][1] = f32x2w{r0[o12], r1[o12]};
-                o.d[e2][2] = f32x2w{r0[o21], r1[o21]}; o.d[e2][3] = f32x2w{r0[o22], r1[o22]};
             }
         };
         constexpr int NGR = 16 * KGC;
@@ -448,9 +461,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) {
             const int xi = pos >> 2, nu = pos & 3;
-            f32x4w M[RT16];
+            f32x4w M[NT][RT16];
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) M[rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) M[ct][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < KGC; ++kk) {
                 const int g = pos * KGC + kk;
@@ -459,19 +474,23 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                 __builtin_amdgcn_sched_barrier(0);
                 const WFrag& oa = fa[g % NA];
                 const WPatch& o = pd[g & 1];
-                f32x2w v[2];
+                f32x2w v[NT][2];
 #pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) {
-                    const f32x2w t1 = S1[nu] * o.d[e2][0] + S2[nu] * o.d[e2][1];
-                    const f32x2w t2 = S1[nu] * o.d[e2][2] + S2[nu] * o.d[e2][3];
-                    v[e2] = S1[xi] * t1 + S2[xi] * t2;
-                    if constexpr (G::ABL == 3 || G::ABL == 4) v[e2] = o.d[e2][0];      // timing only: no transform additions
-                }
+                for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const f32x2w t1 = S1[nu] * o.d[ct][e2][0] + S2[nu] * o.d[ct][e2][1];
+                        const f32x2w t2 = S1[nu] * o.d[ct][e2][2] + S2[nu] * o.d[ct][e2][3];
+                        v[ct][e2] = S1[xi] * t1 + S2[xi] * t2;
+                        if constexpr (G::ABL == 3 || G::ABL == 4) v[ct][e2] = o.d[ct][e2][0];      // timing only: no transform additions
+                    }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int rt = 0; rt < RT16; ++rt)
-                        M[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[e >> 1][e & 1], M[rt], 0, 0, 0);
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct)
+                            M[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[ct][e >> 1][e & 1], M[ct][rt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // output transform, folded: Y[i][j] += A^T[i][xi] A^T[j][nu] M
@@ -482,7 +501,10 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                     const float c = AT[i][xi] * AT[j][nu];
                     if (c != 0.f) {
 #pragma unroll
-                        for (int rt = 0; rt < RT16; ++rt) Y[i][j][rt] = c > 0.f ? Y[i][j][rt] + M[rt] : Y[i][j][rt] - M[rt];
+                        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                            for (int rt = 0; rt < RT16; ++rt)
+                                Y[ct][i][j][rt] = c > 0.f ? Y[ct][i][j][rt] + M[ct][rt] : Y[ct][i][j][rt] - M[ct][rt];
                     }
                 }
             __builtin_amdgcn_sched_barrier(0);
@@ -494,15 +516,173 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
     for (int rt = 0; rt < RT16; ++rt) {
         const float4 b = *reinterpret_cast<const float4*>(wsl + G::OFF_B2 + rt * 16 + 4 * lg);
 #pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float* dst = H1 + (rt * 16 + 4 * lg) * PIX + smp[ct] * HW + (2 * ty[ct] + i) * W + 2 * tx[ct] + j;
+                    dst[0] = cf_relu(Y[ct][i][j][rt][0] + b.x);
+                    dst[PIX] = cf_relu(Y[ct][i][j][rt][1] + b.y);
+                    dst[2 * PIX] = cf_relu(Y[ct][i][j][rt][2] + b.z);
+                    dst[3 * PIX] = cf_relu(Y[ct][i][j][rt][3] + b.w);
+                }
+    }
+    cf_wave_sync();
+}
+
+// Same product with the xi index (row of B^T / A^T on the vertical axis) as a RUNTIME loop: a quarter of the code, and
+// register lifetimes the allocator copes with (the fully unrolled form above spills at 2 workgroups / CU).  What depends on
+// xi becomes data: the two patch rows (xi = 2 takes them swapped, so that the vertical transform is t1 + sigma t2 with
+// sigma = +1 for xi = 1 and -1 otherwise), the fragment offset (a scalar), and the output coefficients A^T[i][xi].
+template <class G>
+__device__ __forceinline__ void winograd_phase2_loop(float* __restrict__ lds, const float* __restrict__ wsl, ws_rsrc_t rs, int lane,
+                                                     int wave) {
+    constexpr int W = G::W, H = G::H, HW = G::HW, PIX = G::PIX, HALF = G::HALF, HID = G::HID, RT16 = G::RT16, KG4 = G::KG4;
+    static_assert(G::PTW % 2 == 0 && HID % 16 == 0, "a wave owns NT x 64 pixels = NT column tiles of 16 output tiles");
+    constexpr int NT = G::PTW / 2;
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
+    float* H1 = lds + HALF * PIX;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int TPS = HW / 4;
+    int smp[NT], ty[NT], tx[NT], rpart[NT][4], cpart[NT][4];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) {
+        const int tg = (wave * NT + ct) * 16 + l15, ti = tg % TPS;
+        smp[ct] = tg / TPS; ty[ct] = ti / (W / 2); tx[ct] = ti % (W / 2);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int yy = 2 * ty[ct] - 1 + a, xx = 2 * tx[ct] - 1 + a;
+            yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+            xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+            rpart[ct][a] = HALF * PIX + lg * PIX + wino_pix<G>(smp[ct] * HW, yy, 0);
+            cpart[ct][a] = (((xx ^ lg) & 1) * (W / 2)) + (xx >> 1);
+        }
+    }
+    f32x4w Y[NT][2][2][RT16];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float* dst = H1 + (rt * 16 + 4 * lg) * PIX + smp * HW + (2 * ty + i) * W + 2 * tx + j;
-                dst[0] = cf_relu(Y[i][j][rt][0] + b.x);
-                dst[PIX] = cf_relu(Y[i][j][rt][1] + b.y);
-                dst[2 * PIX] = cf_relu(Y[i][j][rt][2] + b.z);
-                dst[3 * PIX] = cf_relu(Y[i][j][rt][3] + b.w);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt) Y[ct][i][j][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    struct WFrag { float4 a[RT16]; };
+    struct WPatch { f32x2w d[NT][2][4]; };
+    constexpr int KGC = KG4 < 4 ? KG4 : 4, NCH = KG4 / KGC, NGX = 4 * KGC;       // groups per xi
+    static_assert(KGC % 2 == 0, "static ping-pong");
+    constexpr int B1[4] = {0, 1, 1, 1}, B2[4] = {2, 2, 2, 3};                       // patch columns of B^T row nu
+    constexpr float S1[4] = {1.f, 1.f, -1.f, 1.f}, S2[4] = {-1.f, 1.f, 1.f, -1.f};
+    constexpr float AT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        const float* base = lds + ch * (16 * KGC) * PIX;
+        const int frc = G::OFF_AW + ch * KGC * 256;
+        WFrag fa[2];
+        WPatch pd[2];
+        auto rows_of = [&](int xi, int (&r1)[NT], int (&r2)[NT]) {          // xi is wave-uniform: selects, not branches
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                r1[ct] = xi == 0 ? rpart[ct][0] : (xi == 2 ? rpart[ct][2] : rpart[ct][1]);
+                r2[ct] = xi == 2 ? rpart[ct][1] : (xi == 3 ? rpart[ct][3] : rpart[ct][2]);
             }
+        };
+        auto load = [&](int xi, const int (&r1)[NT], const int (&r2)[NT], int g, WFrag& fo, WPatch& o) {    // g = nu * KGC + kk (static)
+            const int nu = g / KGC, kk = g % KGC;
+            const int fr = frc + ((xi * 4 + nu) * RT16 * KG4 + kk) * 256;
+#pragma unroll
+            for (int rt = 0; rt < RT16; ++rt) fo.a[rt] = ws_frag(rs, lane, fr + rt * KG4 * 256);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const int o11 = r1[ct] + cpart[ct][B1[nu]], o12 = r1[ct] + cpart[ct][B2[nu]];
+                const int o21 = r2[ct] + cpart[ct][B1[nu]], o22 = r2[ct] + cpart[ct][B2[nu]];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const float* q0 = base + (16 * kk + 8 * e2) * PIX;
+                    const float* q1 = q0 + 4 * PIX;
+                    o.d[ct][e2][0] = f32x2w{q0[o11], q1[o11]}; o.d[ct][e2][1] = f32x2w{q0[o12], q1[o12]};
+                    o.d[ct][e2][2] = f32x2w{q0[o21], q1[o21]}; o.d[ct][e2][3] = f32x2w{q0[o22], q1[o22]};
+                }
+            }
+        };
+        int r1[NT], r2[NT], r1n[NT], r2n[NT];
+        rows_of(0, r1, r2);
+        load(0, r1, r2, 0, fa[0], pd[0]);
+#pragma unroll 1
+        for (int xi = 0; xi < 4; ++xi) {
+            const int xn = xi < 3 ? xi + 1 : 3;
+            rows_of(xn, r1n, r2n);
+            const float sigma = xi == 1 ? 1.f : -1.f;
+            const float c0 = xi < 3 ? 1.f : 0.f, c1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);      // A^T[0][xi], A^T[1][xi]
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                f32x4w M[NT][RT16];
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < RT16; ++rt) M[ct][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KGC; ++kk) {
+                    const int g = nu * KGC + kk;
+                    if (g + 1 < NGX) load(xi, r1, r2, g + 1, fa[(g + 1) & 1], pd[(g + 1) & 1]);
+                    else load(xn, r1n, r2n, 0, fa[0], pd[0]);            // first group of the next xi (after the last xi: harmless)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const WFrag& oa = fa[g & 1];
+                    const WPatch& o = pd[g & 1];
+                    f32x2w v[NT][2];
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const f32x2w t1 = S1[nu] * o.d[ct][e2][0] + S2[nu] * o.d[ct][e2][1];
+                            const f32x2w t2 = S1[nu] * o.d[ct][e2][2] + S2[nu] * o.d[ct][e2][3];
+                            v[ct][e2] = t1 + sigma * t2;
+                        }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < NT; ++ct)
+                                M[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[ct][e >> 1][e & 1], M[ct][rt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // Y[i][j] += A^T[i][xi] A^T[j][nu] M
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (AT[j][nu] != 0.f) {
+                        const float k0 = c0 * AT[j][nu], k1 = c1 * AT[j][nu];
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                            for (int rt = 0; rt < RT16; ++rt) {
+                                Y[ct][0][j][rt] += k0 * M[ct][rt];
+                                Y[ct][1][j][rt] += k1 * M[ct][rt];
+                            }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) { r1[ct] = r1n[ct]; r2[ct] = r2n[ct]; }
+        }
+    }
+    __syncthreads();                 // every wave has finished reading h1
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) {
+        const float4 b = *reinterpret_cast<const float4*>(wsl + G::OFF_B2 + rt * 16 + 4 * lg);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float* dst = H1 + (rt * 16 + 4 * lg) * PIX + smp[ct] * HW + (2 * ty[ct] + i) * W + 2 * tx[ct] + j;
+                    dst[0] = cf_relu(Y[ct][i][j][rt][0] + b.x);
+                    dst[PIX] = cf_relu(Y[ct][i][j][rt][1] + b.y);
+                    dst[2 * PIX] = cf_relu(Y[ct][i][j][rt][2] + b.z);
+                    dst[3 * PIX] = cf_relu(Y[ct][i][j][rt][3] + b.w);
+                }
     }
     cf_wave_sync();
 }
@@ -575,7 +755,8 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
 
     // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
     if constexpr (G::WINO) {
-        winograd_phase2<G>(lds, wsl, rs, lane, tid >> 6);
+        if constexpr (G::PIPE == 4) winograd_phase2_loop<G>(lds, wsl, rs, lane, tid >> 6);
+        else winograd_phase2<G>(lds, wsl, rs, lane, tid >> 6);
     } else {
         f32x16 acc[RT1][PTW];
 #pragma unroll
@@ -780,10 +961,12 @@ using G64v3 = Geo<64, 4, 4, 16, 0>;
 using G32w = Geo<32, 8, 8, 4, 3>;        // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2)
 using G64w = Geo<64, 4, 4, 16, 3>;
 using G16w = Geo<16, 16, 16, 1, 3>;      // k_flow_step_small with the Winograd 3x3
+using G32w8 = Geo<32, 8, 8, 8, 4>;       // 8 samples per workgroup (the whole LDS, 1 workgroup / CU): a wave owns 2 column tiles
 using G32wa = Geo<32, 8, 8, 4, 3, 2>;    // timing-only ablations of the Winograd form (tools/dev/wino_check.py)
 using G64wa = Geo<64, 4, 4, 16, 3, 2>;
-using G32wb = Geo<32, 8, 8, 4, 3, 3>;
-using G32wc = Geo<32, 8, 8, 4, 3, 4>;
+using G32x = Geo<32, 8, 8, 4, 4>;        // xi loop kept as a loop
+using G64x = Geo<64, 4, 4, 16, 4>;
+using G16x = Geo<16, 16, 16, 1, 4>;
 
 
 int shape_id(int C, int H, int W) {
