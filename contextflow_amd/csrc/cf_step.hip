@@ -953,17 +953,10 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
         case 25: CF_STEP(G64v1); break;
         case 26: CF_STEP(G64v2); break;
         case 27: CF_STEP(G64v3); break;
-        case 12: rc = in_squeeze ? launch_step_small<G16w, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))
-                                : launch_step_small<G16w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
-        case 20: CF_STEP(G32w); break;            // variant 4: Winograd F(2x2,3x3) form of the 3x3
+        case 12: rc = in_squeeze ? launch_step_small<G16w, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))         // variant 4:
+                                : launch_step_small<G16w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;  // Winograd form of the 3x3
+        case 20: CF_STEP(G32w); break;
         case 28: CF_STEP(G64w); break;
-        case 21: CF_STEP(G32wa); break;
-        case 29: CF_STEP(G64wa); break;
-        case 23: CF_STEP(G32x); break;            // variant 7: Winograd with the xi loop kept
-        case 31: CF_STEP(G64x); break;
-        case 15: rc = in_squeeze ? launch_step_small<G16x, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))
-                                : launch_step_small<G16x, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
-        case 22: CF_STEP(G32w8); break;           // variant 6
         default: cf_set_error("cf_flow_step_fwd: shape (%d,%d,%d) variant %d unsupported", C, H, W, variant); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEP
@@ -983,7 +976,7 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2): 40 instead of 80 C^2 HW multiply-adds per sample and step.
     // CONTEXTFLOW_DIRECT_CONV=1 keeps the direct form (A/B measurements, tools/step_bench.py).
     static const bool direct_only = [] { const char* e = getenv("CONTEXTFLOW_DIRECT_CONV"); return e && e[0] == '1'; }();
-    if (!direct_only && (sid == 1 || (sid == 2 && B >= 256 * G32::SPW) || (sid == 3 && B >= 256 * G64::SPW))) flags = 7 << 16;
+    if (!direct_only && (sid == 1 || (sid == 2 && B >= 256 * G32::SPW) || (sid == 3 && B >= 256 * G64::SPW))) flags = 4 << 16;
     // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
     if ((sid == 2 && B <= 512) || (sid == 3 && B <= 1024)) {
         CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);

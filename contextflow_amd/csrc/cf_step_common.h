@@ -58,7 +58,7 @@ struct Geo {
     static constexpr int OFF_SA2 = OFF_SA1 + (HID16 ? SG1 * 256 : 0);
     // Winograd F(2x2,3x3) form of the 3x3 (PIPE == 3, winograd_phase2 below): U = G w G^T for the 16 positions, packed as
     // 16x16x4 A fragments: [position][16-row tile][group of 4 k-steps][lane][4]
-    static constexpr bool WINO = (PIPE_ == 3 || PIPE_ == 4);      // 4: the xi loop of winograd_phase2 stays a loop
+    static constexpr bool WINO = (PIPE_ == 3);
     static constexpr int RT16 = HID / 16, KG4 = HID / 16;         // row tiles / k-step groups of the 16x16x4 products over HID
     static constexpr int OFF_AW = OFF_SA2 + (HID16 ? 9 * 256 : 0);
     static constexpr int WS_FLOATS = OFF_AW + 16 * HID * HID;
@@ -369,174 +369,18 @@ template <class G> __device__ __forceinline__ int wino_pix(int sHW, int y, int x
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
+// Loop form: the 16 positions run as a RUNTIME loop over xi (row of B^T / A^T on the vertical axis) around the four nu,
+// unrolled.  (All 16 unrolled was measured first: 4x the code, and hipcc spilled 50-150 registers at 2-3 workgroups / CU:
+// 561 / 448 / 414 us per 16384 samples at C = 16 / 32 / 64 against 447 / 372 / 406 us in this form; direct 3x3: 640 / 618 /
+// 620 us.)  What depends on xi is data: the two patch rows (xi = 2 takes them swapped, so that the vertical transform is
+// t1 + sigma t2 with sigma = +1 for xi = 1 and -1 otherwise), the fragment offset (a scalar), the coefficients A^T[i][xi].
+// Operands of a group of 4 k-steps (RT16 weight fragments from L2, 4 patch values per Winograd-domain operand from LDS,
+// k-steps paired so that the additions run as packed fp32) are requested one group ahead - the first group of the next xi
+// during the last one of this xi - and sched_barrier keeps hipcc from sinking them to their first use.  k runs in chunks
+// of <= 64 channels (outer loop): inside a chunk every operand address is `patch offset + immediate`; the output
+// transform is linear, so each chunk's partial M is folded into Y.
 template <class G>
 __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const float* __restrict__ wsl, ws_rsrc_t rs, int lane,
-                                                int wave) {
-    constexpr int W = G::W, H = G::H, HW = G::HW, PIX = G::PIX, HALF = G::HALF, HID = G::HID, RT16 = G::RT16, KG4 = G::KG4;
-    static_assert(G::PTW % 2 == 0 && HID % 16 == 0, "a wave owns NT x 64 pixels = NT column tiles of 16 output tiles");
-    constexpr int NT = G::PTW / 2;                           // column tiles per wave: they share every weight fragment
-    float* H1 = lds + HALF * PIX;
-    const int l15 = lane & 15, lg = lane >> 4;
-    constexpr int TPS = HW / 4;                              // tiles per sample
-    int smp[NT], ty[NT], tx[NT];
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) {
-        const int tg = (wave * NT + ct) * 16 + l15, ti = tg % TPS;
-        smp[ct] = tg / TPS; ty[ct] = ti / (W / 2); tx[ct] = ti % (W / 2);
-    }
-    // patch offsets: the permuted pixel offset is a sum of a row part and a column part (disjoint bit fields; the XOR of odd
-    // k rows only touches the column-parity bit), so 4 + 4 registers describe the 4x4 patch of this lane's tile
-    int rpart[NT][4], cpart[NT][4];
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            int yy = 2 * ty[ct] - 1 + a, xx = 2 * tx[ct] - 1 + a;
-            yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
-            xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-            rpart[ct][a] = HALF * PIX + lg * PIX + wino_pix<G>(smp[ct] * HW, yy, 0);
-            cpart[ct][a] = (((xx ^ lg) & 1) * (W / 2)) + (xx >> 1);
-        }
-    typedef float f32x2w __attribute__((ext_vector_type(2)));
-    f32x4w Y[NT][2][2][RT16];
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) Y[ct][i][j][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
-    // Operands of one group of 4 k-steps: RT16 weight fragments + the 4 patch values behind each of the 4 Winograd-domain
-    // operands (k-steps paired: the three additions per operand run as packed fp32 pairs).  Two-stage pipeline as in
-    // dense_phase: the loads of group g+1 - of the next position after a position's last group - are issued, then the
-    // additions and MFMAs of group g run (sched_barrier keeps hipcc from sinking the loads to their first use or hoisting a
-    // whole position's worth of them).  k runs in chunks of <= 64 channels (outer loop): inside a chunk every operand
-    // address is `patch offset + immediate`, and the output transform is linear, so each chunk's partial M is folded into Y.
-    struct WFrag { float4 a[RT16]; };
-    struct WPatch { f32x2w d[NT][2][4]; };
-    constexpr int KGC = KG4 < 4 ? KG4 : 4, NCH = KG4 / KGC;
-    static_assert(KGC % 2 == 0, "static ping-pong");
-    constexpr int A1[4] = {0, 1, 1, 1}, A2[4] = {2, 2, 2, 3};           // the two patch rows / columns of B^T row xi
-    constexpr float S1[4] = {1.f, 1.f, -1.f, 1.f}, S2[4] = {-1.f, 1.f, 1.f, -1.f};
-    constexpr float AT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
-#pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-        const float* base = lds + ch * (16 * KGC) * PIX;
-        const int frc = G::OFF_AW + ch * KGC * 256;
-        // group g = pos * KGC + kk of this chunk.  Weight fragments (L2) and patch values (LDS) are requested one group ahead,
-        // ping-pong (a ring of three fragment sets, two groups ahead, was tried: no gain at C = 32, spills at C = 64)
-        constexpr int NA = 2;
-        WFrag fa[NA];
-        WPatch pd[2];
-        auto load_a = [&](int g, WFrag& o) {
-            const int pos = g / KGC, kk = g % KGC;
-#pragma unroll
-            for (int rt = 0; rt < RT16; ++rt)
-                o.a[rt] = ws_frag(rs, lane, G::ABL == 2 ? G::OFF_AW + rt * 256 : frc + ((pos * RT16 + rt) * KG4 + kk) * 256);   // ABL 2 (timing only): L1-resident fragments
-        };
-        auto load_d = [&](int g, WPatch& o) {
-            const int pos = g / KGC, kk = g % KGC, xi = pos >> 2, nu = pos & 3;
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct) {
-                const int o11 = rpart[ct][A1[xi]] + cpart[ct][A1[nu]], o12 = rpart[ct][A1[xi]] + cpart[ct][A2[nu]];
-                const int o21 = rpart[ct][A2[xi]] + cpart[ct][A1[nu]], o22 = rpart[ct][A2[xi]] + cpart[ct][A2[nu]];
-#pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) {
-                    const float* r0 = base + (16 * kk + 8 * e2) * PIX;
-                    const float* r1 = r0 + 4 * PIX;
-                    if constexpr (G::ABL == 4) {             // timing only: no patch reads
-                        o.d[ct][e2][0] = f32x2w{0.001f * (o11 + e2), 0.002f * o12};
-                        continue;
-                    }
-                    o.d[ct][e2][0] = f32x2w{r0[o11], r1[o11]}; o.d[ct][e2][1] = f32x2w{r0[o12], r1[o12]};
-                    o.d[ct][e2][2] = f32x2w{r0[o21], r1[o21]}; o.d[ct][e2][3] = f32x2w{r0[o22], r1[o22]};
-                }
-            }
-        };
-        constexpr int NGR = 16 * KGC;
-#pragma unroll
-        for (int g = 0; g < NA - 1; ++g) load_a(g, fa[g]);
-        load_d(0, pd[0]);
-#pragma unroll
-        for (int pos = 0; pos < 16; ++pos) {
-            const int xi = pos >> 2, nu = pos & 3;
-            f32x4w M[NT][RT16];
-#pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) M[ct][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KGC; ++kk) {
-                const int g = pos * KGC + kk;
-                if (g + NA - 1 < NGR) load_a(g + NA - 1, fa[(g + NA - 1) % NA]);
-                if (g + 1 < NGR) load_d(g + 1, pd[(g + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                const WFrag& oa = fa[g % NA];
-                const WPatch& o = pd[g & 1];
-                f32x2w v[NT][2];
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-                    for (int e2 = 0; e2 < 2; ++e2) {
-                        const f32x2w t1 = S1[nu] * o.d[ct][e2][0] + S2[nu] * o.d[ct][e2][1];
-                        const f32x2w t2 = S1[nu] * o.d[ct][e2][2] + S2[nu] * o.d[ct][e2][3];
-                        v[ct][e2] = S1[xi] * t1 + S2[xi] * t2;
-                        if constexpr (G::ABL == 3 || G::ABL == 4) v[ct][e2] = o.d[ct][e2][0];      // timing only: no transform additions
-                    }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-                        for (int ct = 0; ct < NT; ++ct)
-                            M[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[ct][e >> 1][e & 1], M[ct][rt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // output transform, folded: Y[i][j] += A^T[i][xi] A^T[j][nu] M
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float c = AT[i][xi] * AT[j][nu];
-                    if (c != 0.f) {
-#pragma unroll
-                        for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-                            for (int rt = 0; rt < RT16; ++rt)
-                                Y[ct][i][j][rt] = c > 0.f ? Y[ct][i][j][rt] + M[ct][rt] : Y[ct][i][j][rt] - M[ct][rt];
-                    }
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __syncthreads();                 // every wave has finished reading h1
-    // h2 = relu(Y + b), natural [row][pixel] layout, this wave's own columns (phase 3 reads them as MFMA operands)
-#pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) {
-        const float4 b = *reinterpret_cast<const float4*>(wsl + G::OFF_B2 + rt * 16 + 4 * lg);
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float* dst = H1 + (rt * 16 + 4 * lg) * PIX + smp[ct] * HW + (2 * ty[ct] + i) * W + 2 * tx[ct] + j;
-                    dst[0] = cf_relu(Y[ct][i][j][rt][0] + b.x);
-                    dst[PIX] = cf_relu(Y[ct][i][j][rt][1] + b.y);
-                    dst[2 * PIX] = cf_relu(Y[ct][i][j][rt][2] + b.z);
-                    dst[3 * PIX] = cf_relu(Y[ct][i][j][rt][3] + b.w);
-                }
-    }
-    cf_wave_sync();
-}
-
-// Same product with the xi index (row of B^T / A^T on the vertical axis) as a RUNTIME loop: a quarter of the code, and
-// register lifetimes the allocator copes with (the fully unrolled form above spills at 2 workgroups / CU).  What depends on
-// xi becomes data: the two patch rows (xi = 2 takes them swapped, so that the vertical transform is t1 + sigma t2 with
-// sigma = +1 for xi = 1 and -1 otherwise), the fragment offset (a scalar), and the output coefficients A^T[i][xi].
-template <class G>
-__device__ __forceinline__ void winograd_phase2_loop(float* __restrict__ lds, const float* __restrict__ wsl, ws_rsrc_t rs, int lane,
                                                      int wave) {
     constexpr int W = G::W, H = G::H, HW = G::HW, PIX = G::PIX, HALF = G::HALF, HID = G::HID, RT16 = G::RT16, KG4 = G::KG4;
     static_assert(G::PTW % 2 == 0 && HID % 16 == 0, "a wave owns NT x 64 pixels = NT column tiles of 16 output tiles");
@@ -755,8 +599,7 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
 
     // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
     if constexpr (G::WINO) {
-        if constexpr (G::PIPE == 4) winograd_phase2_loop<G>(lds, wsl, rs, lane, tid >> 6);
-        else winograd_phase2<G>(lds, wsl, rs, lane, tid >> 6);
+        winograd_phase2<G>(lds, wsl, rs, lane, tid >> 6);
     } else {
         f32x16 acc[RT1][PTW];
 #pragma unroll
@@ -958,15 +801,9 @@ using G32v3 = Geo<32, 8, 8, 8, 0>;
 using G64v1 = Geo<64, 4, 4, 16, 1, 1>;
 using G64v2 = Geo<64, 4, 4, 8, 1>;
 using G64v3 = Geo<64, 4, 4, 16, 0>;
-using G32w = Geo<32, 8, 8, 4, 3>;        // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2)
+using G16w = Geo<16, 16, 16, 1, 3>;      // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2); 16x16: in k_flow_step_small
+using G32w = Geo<32, 8, 8, 4, 3>;
 using G64w = Geo<64, 4, 4, 16, 3>;
-using G16w = Geo<16, 16, 16, 1, 3>;      // k_flow_step_small with the Winograd 3x3
-using G32w8 = Geo<32, 8, 8, 8, 4>;       // 8 samples per workgroup (the whole LDS, 1 workgroup / CU): a wave owns 2 column tiles
-using G32wa = Geo<32, 8, 8, 4, 3, 2>;    // timing-only ablations of the Winograd form (tools/dev/wino_check.py)
-using G64wa = Geo<64, 4, 4, 16, 3, 2>;
-using G32x = Geo<32, 8, 8, 4, 4>;        // xi loop kept as a loop
-using G64x = Geo<64, 4, 4, 16, 4>;
-using G16x = Geo<16, 16, 16, 1, 4>;
 
 
 int shape_id(int C, int H, int W) {
