@@ -302,7 +302,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // DUMP (training): y0 and the post-ReLU h1 / h2 planes also go to the tape `tp` (see k_flow_step).
 template <class G, bool SQ, bool DBG = false, bool DUMP = false>
-__global__ __launch_bounds__(256, G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
+__global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
                                                                   float* __restrict__ ldj_acc, const float* __restrict__ ws,
                                                                   int B, int64_t xbs, float* __restrict__ dbg, StepTape tp) {
     static_assert(G::SMALL, "16x16 images, one sample per workgroup, C <= 16");
@@ -965,6 +965,11 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
     return 0;
 }
 
+static bool direct_conv_only() {
+    static const bool v = [] { const char* e = getenv("CONTEXTFLOW_DIRECT_CONV"); return e && e[0] == '1'; }();
+    return v;
+}
+
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                      int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
     // Small batches are latency-bound by the serial work of ONE workgroup (a launch of < 256 workgroups leaves CUs
@@ -975,7 +980,7 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     if (sid == 0 || sid == 1) flags = 3 << 16;      // 16x16 images: k_flow_step_small
     // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2): 40 instead of 80 C^2 HW multiply-adds per sample and step.
     // CONTEXTFLOW_DIRECT_CONV=1 keeps the direct form (A/B measurements, tools/step_bench.py).
-    static const bool direct_only = [] { const char* e = getenv("CONTEXTFLOW_DIRECT_CONV"); return e && e[0] == '1'; }();
+    const bool direct_only = direct_conv_only();
     if (!direct_only && (sid == 1 || (sid == 2 && B >= 256 * G32::SPW) || (sid == 3 && B >= 256 * G64::SPW))) flags = 4 << 16;
     // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
     if ((sid == 2 && B <= 512) || (sid == 3 && B <= 1024)) {
@@ -1008,6 +1013,7 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
                (reinterpret_cast<uintptr_t>(t_h2) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_aux) & 15) == 0);
     const float* w = (const float*)ws;
     const StepTape tp = make_tape(t_y0, t_h1, t_h2, t_aux, B, C, H, W);
+    const bool direct_only = direct_conv_only();
     int rc = 0;
 #define CF_STEPT(G) rc = in_squeeze ? launch_step<G, true, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp) \
                                     : launch_step<G, false, 0, true>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), nullptr, tp)
@@ -1015,10 +1021,15 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
     switch (shape_id(C, H, W)) {
         case 0: rc = in_squeeze ? launch_step_small<G8s, true, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp)
                                 : launch_step_small<G8s, false, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp); break;
-        case 1: rc = in_squeeze ? launch_step_small<G16s, true, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp)
-                                : launch_step_small<G16s, false, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp); break;
-        case 2: if (B < 256 * G32::SPW) CF_STEPT(G32v2); else CF_STEPT(G32); break;
-        case 3: if (B < 256 * G64::SPW) CF_STEPT(G64v2); else CF_STEPT(G64); break;
+        // as in cf_flow_step_fwd: Winograd form of the 3x3 on 16x16 images and at saturating batches (h1 reaches the tape from
+        // the accumulators there, its LDS plane is in the parity-split order)
+        case 1: if (direct_only) rc = in_squeeze ? launch_step_small<G16s, true, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp)
+                                                 : launch_step_small<G16s, false, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp);
+                else rc = in_squeeze ? launch_step_small<G16w, true, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp)
+                                     : launch_step_small<G16w, false, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp);
+                break;
+        case 2: if (B < 256 * G32::SPW) CF_STEPT(G32v2); else if (direct_only) CF_STEPT(G32); else CF_STEPT(G32w); break;
+        case 3: if (B < 256 * G64::SPW) CF_STEPT(G64v2); else if (direct_only) CF_STEPT(G64); else CF_STEPT(G64w); break;
         default: cf_set_error("cf_flow_step_fwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEPT

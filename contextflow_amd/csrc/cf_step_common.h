@@ -259,12 +259,28 @@ __device__ __forceinline__ ws_rsrc_t tile_rsrc(const float* t, int tb0, int B) {
     const int nb = min(B - tb0, G::SPW);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t + (int64_t)tb0 * CT * G::HW), 0, nb * CT * G::HW * 4, 0x00020000);
 }
+// 16-byte store through a buffer resource with a SCALAR offset, as ONE unit with a wait state behind it.  Measured on
+// gfx950: the VGPRs holding the data of a `buffer_store_dwordx4 ... s_off offen` must not be written by the VALU
+// instruction right behind it (hipcc places one there when the registers become free - it treats a store with a
+// register soffset as hazard-free - and the stored rows then carry the new register contents in some lanes:
+// tools/dev/nan_hunt3.py found 64-bit addresses inside the g_h2 plane).  Inline asm: the compiler cannot slide anything
+// between the store and its s_nop.
+typedef int cf_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cf_i32x4 tile_rsrc_words(const float* base, int bytes) {
+    const uint64_t p = reinterpret_cast<uint64_t>(base);
+    return cf_i32x4{(int)(uint32_t)p, (int)((uint32_t)(p >> 32) & 0xffffu), bytes, 0x00020000};
+}
+__device__ __forceinline__ void tile_store_b128(const cf_i32x4 rs, int voff, int soff, const float4 v) {
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    const f32x4s d = {v.x, v.y, v.z, v.w};
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
 template <class G, int NROWS, int CT>
 __device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const float* __restrict__ plane, int tb0, int B,
                                              int wave, int lane) {
-    typedef int i32x4_t __attribute__((ext_vector_type(4)));
     constexpr int WPX = 32 * G::PTW, HW = G::HW, PIX = G::RS, RPI = 256 / WPX;      // rows per item of 64 lanes x 16 bytes
-    const ws_rsrc_t rs = tile_rsrc<G, CT>(dst, tb0, B);
+    const cf_i32x4 rs = tile_rsrc_words(dst + (int64_t)tb0 * CT * HW, min(B - tb0, G::SPW) * CT * HW * 4);
     const int idx0 = lane / (WPX / 4), col = wave * WPX + 4 * (lane % (WPX / 4));
     const int voff = ((col / HW) * CT * HW + idx0 * HW + col % HW) * 4;
     cf_wave_sync();
@@ -275,8 +291,7 @@ __device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const floa
     for (int i = 0; i < (NROWS + RPI - 1) / RPI; ++i) {
         if (NROWS % RPI == 0 || idx0 + i * RPI < NROWS) {
             const float4 v = *reinterpret_cast<const float4*>(&plane[(idx0 + i * RPI) * PIX + col]);
-            const i32x4_t d = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, i * RPI * HW * 4, 0);
+            tile_store_b128(rs, voff, i * RPI * HW * 4, v);
         }
     }
     cf_wave_sync();
@@ -584,8 +599,25 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                         if (row < HID) H1[row * PIX + pix[q]] = cf_relu(acc[rt][q][r]);
                     }
                 }
-        static_assert(!(DUMP && G::WINO), "the training tape is written by the direct-form geometries");
-        if constexpr (DUMP) {
+        if constexpr (DUMP && G::WINO) {
+            // the LDS plane is in the parity-split order: the tape's h1 (natural order, operand of the 3x3 weight gradient)
+            // goes out from the accumulators, 128 contiguous bytes per row and half wave
+#pragma unroll
+            for (int q = 0; q < PTW; ++q) {
+                const int b = tile * G::SPW + (pix[q] - pin[q]) / G::HW;
+                if (b < B) {
+                    float* dst = tp.h1 + (int64_t)b * HID * G::HW + pin[q];
+#pragma unroll
+                    for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = rt * 32 + tile_row(r, lk);
+                            if (row < HID) dst[row * G::HW] = cf_relu(acc[rt][q][r]);
+                        }
+                }
+            }
+            mask_store<G, RT1>(tp.m1, acc, tile, tid >> 6, lane);
+        } else if constexpr (DUMP) {
             cf_wave_sync();
             rows_store_t<G, HID, HID>(tp.h1, H1, tile * G::SPW, B, tid >> 6, lane);
             mask_store<G, RT1>(tp.m1, acc, tile, tid >> 6, lane);
@@ -600,6 +632,21 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
     // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
     if constexpr (G::WINO) {
         winograd_phase2<G>(lds, wsl, rs, lane, tid >> 6);
+        if constexpr (DUMP) {            // h2 sits in LDS in natural order (own columns): plane store + mask words from the plane
+            rows_store_t<G, HID, HID>(tp.h2, H1, tile * G::SPW, B, tid >> 6, lane);
+#pragma unroll
+            for (int rt = 0; rt < RT1; ++rt)
+#pragma unroll
+                for (int q = 0; q < PTW; ++q) {
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rt * 32 + tile_row(r, lk);
+                        if (row < HID) bits |= (H1[row * PIX + pix[q]] > 0.f ? 1u : 0u) << r;
+                    }
+                    tp.m2[((int64_t)(tile * G::NPT + (tid >> 6) * PTW + q) * RT1 + rt) * 64 + lane] = bits;
+                }
+        }
     } else {
         f32x16 acc[RT1][PTW];
 #pragma unroll

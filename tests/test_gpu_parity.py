@@ -1607,3 +1607,39 @@ def test_winograd_step_kernel_against_the_oracle(L, C, H, squeeze):
     lref = l0 + l1 + l2
     for got in (d["ldj_prod"], ldj):
         assert ((got.cpu().double() - lref).abs() / lref.abs().clamp_min(1.0)).max().item() <= 1e-5
+
+
+def test_taped_training_step_at_a_large_batch_is_clean(L):
+    """Regression (round 2): plane stores through a buffer resource with a scalar offset were followed by a VALU write of
+    their data registers; from ~9000 samples per launch a few rows of the gradient planes carried register garbage
+    (1e20-1e38) and the 3x3 weight gradients blew up, intermittently.  Six training backward passes at 9216 samples: all
+    gradients finite and within 1e-3 relative (ReLU-boundary flips between the two forward forms aside) of the recompute form."""
+    import contextflow_amd as cfa
+    from contextflow_amd.layers import flowsequential as fs
+    B = 9216
+    torch.manual_seed(0)
+    cfg, ds, M = cfa.preset_config("cifar10")
+    model = cfa.create_model(cfg, ds, M).to(DEV)
+    x = torch.randint(0, 256, (B, *ds), device=DEV).float()
+    gt = torch.randint(0, M, (B,), device=DEV)
+    with torch.no_grad():
+        model(x[:256])
+
+    def grads(tape):
+        prev, fs.TAPE_PLANES = fs.TAPE_PLANES, tape
+        try:
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(1)
+            _, lp = model(x)
+            torch.nn.functional.cross_entropy(lp / 3072.0, gt).backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        finally:
+            fs.TAPE_PLANES = prev
+    ref = grads(False)
+    for _ in range(6):
+        g = grads(True)
+        for k in ref:
+            assert torch.isfinite(g[k]).all(), k
+            scale = ref[k].abs().max().item() + 1e-12
+            assert (g[k] - ref[k]).abs().max().item() <= 1e-3 * scale, (k, (g[k] - ref[k]).abs().max().item() / scale)
