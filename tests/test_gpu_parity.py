@@ -1613,7 +1613,7 @@ def test_taped_training_step_at_a_large_batch_is_clean(L):
     """Regression (round 2): plane stores through a buffer resource with a scalar offset were followed by a VALU write of
     their data registers; from ~9000 samples per launch a few rows of the gradient planes carried register garbage
     (1e20-1e38) and the 3x3 weight gradients blew up, intermittently.  Six training backward passes at 9216 samples: all
-    gradients finite and within 5e-3 relative (ReLU-boundary flips between the two forward forms aside) of the recompute form."""
+    gradients finite and within 1e-2 of the recompute form's in the 2-norm, per tensor."""
     import contextflow_amd as cfa
     from contextflow_amd.layers import flowsequential as fs
     B = 9216
@@ -1641,5 +1641,6 @@ def test_taped_training_step_at_a_large_batch_is_clean(L):
         g = grads(True)
         for k in ref:
             assert torch.isfinite(g[k]).all(), k
-            scale = ref[k].abs().max().item() + 1e-12
-            assert (g[k] - ref[k]).abs().max().item() <= 5e-3 * scale, (k, (g[k] - ref[k]).abs().max().item() / scale)
+            # the two forms run different forward kernels (Winograd / direct 3x3): hidden units within rounding of 0 flip
+            # their ReLU mask and move single entries by ~1e-3..1e-2 of the tensor's scale; register garbage is 1e20+
+            assert (g[k] - ref[k]).norm().item() <= 1e-2 * ref[k].norm().item() + 1e-12, k
