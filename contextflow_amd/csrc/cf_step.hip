@@ -377,9 +377,6 @@ __global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : G::MINW) void k_flow_s
 #pragma unroll
         for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q]; }
         f32x16 unused[G::RT03][PTW];
-        // the parity-split h1 layout of the Winograd form scatters a wave's pixels over the whole plane of this (single)
-        // sample: every wave must be done with its columns of the x plane first
-        if constexpr (G::WINO) __syncthreads();
         conditioner_net<G, 0, DUMP, 2>(unused, lds, ws, pix, pin, lane, tid, DBG ? dbg : nullptr, dbg_cols, tile, nullptr, nullptr, tp, B);
     } else {
         f32x4 a1[4];
@@ -815,6 +812,11 @@ int launch_step_inv(const float* z, float* x, const float* ws, const float* wsi,
 
 }  // namespace
 
+static bool direct_conv_only() {
+    static const bool v = [] { const char* e = getenv("CONTEXTFLOW_DIRECT_CONV"); return e && e[0] == '1'; }();
+    return v;
+}
+
 extern "C" {
 
 int cf_flow_step_supported(int C, int H, int W, int kh, int kw) {
@@ -887,9 +889,13 @@ int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, 
     const float* wi = (const float*)wsi;
     switch (shape_id(C, H, W)) {
         case 0: rc = launch_step_inv<G8>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
-        case 1: rc = launch_step_inv<G16>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
-        case 2: rc = launch_step_inv<G32>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
-        case 3: rc = launch_step_inv<G64>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        // the conditioner is the forward's: Winograd form of its 3x3 unless CONTEXTFLOW_DIRECT_CONV=1
+        case 1: rc = direct_conv_only() ? launch_step_inv<G16>(z, x, w, wi, B, z_bstride, cf_s(stream))
+                                        : launch_step_inv<G16w>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        case 2: rc = direct_conv_only() ? launch_step_inv<G32>(z, x, w, wi, B, z_bstride, cf_s(stream))
+                                        : launch_step_inv<G32w>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        case 3: rc = direct_conv_only() ? launch_step_inv<G64>(z, x, w, wi, B, z_bstride, cf_s(stream))
+                                        : launch_step_inv<G64w>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
         default: cf_set_error("cf_flow_step_inv: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
@@ -963,11 +969,6 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
-}
-
-static bool direct_conv_only() {
-    static const bool v = [] { const char* e = getenv("CONTEXTFLOW_DIRECT_CONV"); return e && e[0] == '1'; }();
-    return v;
 }
 
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
@@ -1051,11 +1052,12 @@ int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* w
     int rc = 0;
 #define CF_STEPC(G) rc = mode == 1 ? launch_step<G, false, 1>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), sbias) \
                                    : launch_step<G, false, 2>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), sbias)
+    const bool wino = !direct_conv_only();      // as cf_flow_step_fwd: Winograd form of the 3x3 (16x16 always, 8x8 / 4x4 at saturating batches)
     switch (shape_id(C, H, W)) {
         case 0: CF_STEPC(G8); break;
-        case 1: CF_STEPC(G16); break;
-        case 2: CF_STEPC(G32); break;
-        case 3: CF_STEPC(G64); break;
+        case 1: if (wino) CF_STEPC(G16w); else CF_STEPC(G16); break;
+        case 2: if (wino && B >= 256 * G32::SPW) CF_STEPC(G32w); else CF_STEPC(G32); break;
+        case 3: if (wino && B >= 256 * G64::SPW) CF_STEPC(G64w); else CF_STEPC(G64); break;
         default: cf_set_error("cf_flow_step_fwd_ctx: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEPC

@@ -585,6 +585,9 @@ __device__ __forceinline__ void conditioner_net(f32x16 (&acc3)[G::RT03][G::PTW],
                     }
         }
         dense_phase<G, G::KS1, G::NG1, RT1>(acc, rs, G::OFF_A1, Y0, pix, lane);
+        // the parity-split h1 order of the Winograd form scatters a wave's pixels over its whole SAMPLE: where a sample spans
+        // several waves (16x16), every wave must be done with its columns of what the H region held before (x / z plane)
+        if constexpr (G::WINO && G::HW > 32 * PTW) __syncthreads();
 #pragma unroll
         for (int rt = 0; rt < RT1; ++rt)
 #pragma unroll
