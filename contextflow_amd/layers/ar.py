@@ -7,7 +7,9 @@ masked residual block of three convolutions (autoregressive over channels at the
 
 As in the reference the masks multiply the weights IN PLACE on every forward and `reverse` is not implemented (upstream
 returns zeros).  Training: autograd_layers.masked_coupling_backward (the plain convolution gradients, as torch.autograd
-gives them in the reference for in-place masked weights).  Context-conditioned variants are not built.
+gives them in the reference for in-place masked weights).  Context-conditioned variants are not built: upstream's cannot run
+(ar.py:23-30 - the 2D-input residual block adds a 4D-channel identity to a 2D-channel output, masked_conv_2d.py:93-98; the
+contextflow branch adds a (B, C) code to a (B, 2D) output, masked_linear.py:121-129).
 The convolutions run in the generic implicit-GEMM conv kernel (cf_conv2d_reflect, fp32 MFMA)."""
 import torch
 import torch.nn as nn
