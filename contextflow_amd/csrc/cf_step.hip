@@ -895,7 +895,7 @@ int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, 
         case 2: rc = direct_conv_only() ? launch_step_inv<G32>(z, x, w, wi, B, z_bstride, cf_s(stream))
                                         : launch_step_inv<G32w>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
         case 3: rc = direct_conv_only() ? launch_step_inv<G64>(z, x, w, wi, B, z_bstride, cf_s(stream))
-                                        : launch_step_inv<G64w>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+                                        : launch_step_inv<G64w2>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
         default: cf_set_error("cf_flow_step_inv: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
@@ -963,6 +963,7 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
                                 : launch_step_small<G16w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;  // Winograd form of the 3x3
         case 20: CF_STEP(G32w); break;
         case 28: CF_STEP(G64w); break;
+        case 29: CF_STEP(G64w2); break;           // variant 5: row-split Winograd at 128 pixels per workgroup
         default: cf_set_error("cf_flow_step_fwd: shape (%d,%d,%d) variant %d unsupported", C, H, W, variant); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEP
@@ -982,7 +983,8 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2): 40 instead of 80 C^2 HW multiply-adds per sample and step.
     // CONTEXTFLOW_DIRECT_CONV=1 keeps the direct form (A/B measurements, tools/step_bench.py).
     const bool direct_only = direct_conv_only();
-    if (!direct_only && (sid == 1 || (sid == 2 && B >= 256 * G32::SPW) || (sid == 3 && B >= 256 * G64::SPW))) flags = 4 << 16;
+    if (!direct_only && (sid == 1 || (sid == 2 && B >= 256 * G32::SPW))) flags = 4 << 16;
+    if (!direct_only && sid == 3 && B >= 256 * G64w2::SPW) flags = 5 << 16;      // 4x4: 8 samples per workgroup, rows split over wave pairs
     // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
     if ((sid == 2 && B <= 512) || (sid == 3 && B <= 1024)) {
         CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);
@@ -1030,7 +1032,7 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
                                      : launch_step_small<G16w, false, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp);
                 break;
         case 2: if (B < 256 * G32::SPW) CF_STEPT(G32v2); else if (direct_only) CF_STEPT(G32); else CF_STEPT(G32w); break;
-        case 3: if (B < 256 * G64::SPW) CF_STEPT(G64v2); else if (direct_only) CF_STEPT(G64); else CF_STEPT(G64w); break;
+        case 3: if (!direct_only && B >= 256 * G64w2::SPW) CF_STEPT(G64w2); else if (B < 256 * G64::SPW) CF_STEPT(G64v2); else CF_STEPT(G64); break;
         default: cf_set_error("cf_flow_step_fwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEPT
@@ -1057,7 +1059,7 @@ int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* w
         case 0: CF_STEPC(G8); break;
         case 1: if (wino) CF_STEPC(G16w); else CF_STEPC(G16); break;
         case 2: if (wino && B >= 256 * G32::SPW) CF_STEPC(G32w); else CF_STEPC(G32); break;
-        case 3: if (wino && B >= 256 * G64::SPW) CF_STEPC(G64w); else CF_STEPC(G64); break;
+        case 3: if (wino && B >= 256 * G64w2::SPW) CF_STEPC(G64w2); else CF_STEPC(G64); break;
         default: cf_set_error("cf_flow_step_fwd_ctx: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEPC

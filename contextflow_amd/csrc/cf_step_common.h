@@ -398,8 +398,14 @@ template <class G>
 __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const float* __restrict__ wsl, ws_rsrc_t rs, int lane,
                                                      int wave) {
     constexpr int W = G::W, H = G::H, HW = G::HW, PIX = G::PIX, HALF = G::HALF, HID = G::HID, RT16 = G::RT16, KG4 = G::KG4;
-    static_assert(G::PTW % 2 == 0 && HID % 16 == 0, "a wave owns NT x 64 pixels = NT column tiles of 16 output tiles");
-    constexpr int NT = G::PTW / 2;
+    // Ownership.  PTW even: a wave takes the NT = PTW / 2 column tiles (16 output tiles = 64 pixels each) of its own pixel
+    // columns and ALL output rows.  PTW = 1 (128 pixels per workgroup: half the LDS, two workgroups per CU): two waves share a
+    // column tile and split the output ROWS (RSPLIT = 2) - the Winograd-domain operands are formed twice, h2 needs a workgroup
+    // barrier before phase 3, but a second workgroup per CU covers the stalls of a lone wave per SIMD (C = 64: 406 -> see DESIGN).
+    constexpr int RSPLIT = G::PTW == 1 ? 2 : 1, NT = G::PTW * RSPLIT / 2, NCW = 4 / RSPLIT, RTW = RT16 / RSPLIT;
+    static_assert((G::PTW == 1 || G::PTW % 2 == 0) && HID % 16 == 0 && RT16 % RSPLIT == 0, "column tiles of 16 output tiles");
+    const int cw = RSPLIT == 1 ? wave : wave % NCW;           // this wave's column-tile group ...
+    const int rt0 = RSPLIT == 1 ? 0 : __builtin_amdgcn_readfirstlane((wave / NCW) * RTW);      // ... and first 16-row tile (a constant / a scalar)
     typedef float f32x2w __attribute__((ext_vector_type(2)));
     float* H1 = lds + HALF * PIX;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -407,7 +413,7 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
     int smp[NT], ty[NT], tx[NT], rpart[NT][4], cpart[NT][4];
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
-        const int tg = (wave * NT + ct) * 16 + l15, ti = tg % TPS;
+        const int tg = (cw * NT + ct) * 16 + l15, ti = tg % TPS;
         smp[ct] = tg / TPS; ty[ct] = ti / (W / 2); tx[ct] = ti % (W / 2);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -418,7 +424,7 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
             cpart[ct][a] = (((xx ^ lg) & 1) * (W / 2)) + (xx >> 1);
         }
     }
-    f32x4w Y[NT][2][2][RT16];
+    f32x4w Y[NT][2][2][RTW];
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -426,11 +432,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int rt = 0; rt < RT16; ++rt) Y[ct][i][j][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
-    struct WFrag { float4 a[RT16]; };
+                for (int rt = 0; rt < RTW; ++rt) Y[ct][i][j][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    struct WFrag { float4 a[RTW]; };
     struct WPatch { f32x2w d[NT][2][4]; };
     constexpr int KGC = KG4 < 4 ? KG4 : 4, NCH = KG4 / KGC, NGX = 4 * KGC;       // groups per xi
-    static_assert(KGC % 2 == 0, "static ping-pong");
+    static_assert(NGX % 2 == 0, "static ping-pong");
     constexpr int B1[4] = {0, 1, 1, 1}, B2[4] = {2, 2, 2, 3};                       // patch columns of B^T row nu
     constexpr float S1[4] = {1.f, 1.f, -1.f, 1.f}, S2[4] = {-1.f, 1.f, 1.f, -1.f};
     constexpr float AT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
@@ -451,7 +457,7 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
             const int nu = g / KGC, kk = g % KGC;
             const int fr = frc + ((xi * 4 + nu) * RT16 * KG4 + kk) * 256;
 #pragma unroll
-            for (int rt = 0; rt < RT16; ++rt) fo.a[rt] = ws_frag(rs, lane, fr + rt * KG4 * 256);
+            for (int rt = 0; rt < RTW; ++rt) fo.a[rt] = ws_frag(rs, lane, fr + (rt0 + rt) * KG4 * 256);
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const int o11 = r1[ct] + cpart[ct][B1[nu]], o12 = r1[ct] + cpart[ct][B2[nu]];
@@ -476,11 +482,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
             const float c0 = xi < 3 ? 1.f : 0.f, c1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);      // A^T[0][xi], A^T[1][xi]
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
-                f32x4w M[NT][RT16];
+                f32x4w M[NT][RTW];
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                    for (int rt = 0; rt < RT16; ++rt) M[ct][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+                    for (int rt = 0; rt < RTW; ++rt) M[ct][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < KGC; ++kk) {
                     const int g = nu * KGC + kk;
@@ -501,7 +507,7 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int rt = 0; rt < RT16; ++rt)
+                        for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
                             for (int ct = 0; ct < NT; ++ct)
                                 M[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[ct][e >> 1][e & 1], M[ct][rt], 0, 0, 0);
@@ -515,7 +521,7 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
                         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-                            for (int rt = 0; rt < RT16; ++rt) {
+                            for (int rt = 0; rt < RTW; ++rt) {
                                 Y[ct][0][j][rt] += k0 * M[ct][rt];
                                 Y[ct][1][j][rt] += k1 * M[ct][rt];
                             }
@@ -528,22 +534,23 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
     }
     __syncthreads();                 // every wave has finished reading h1
 #pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) {
-        const float4 b = *reinterpret_cast<const float4*>(wsl + G::OFF_B2 + rt * 16 + 4 * lg);
+    for (int rt = 0; rt < RTW; ++rt) {
+        const float4 b = *reinterpret_cast<const float4*>(wsl + G::OFF_B2 + (rt0 + rt) * 16 + 4 * lg);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float* dst = H1 + (rt * 16 + 4 * lg) * PIX + smp[ct] * HW + (2 * ty[ct] + i) * W + 2 * tx[ct] + j;
+                    float* dst = H1 + ((rt0 + rt) * 16 + 4 * lg) * PIX + smp[ct] * HW + (2 * ty[ct] + i) * W + 2 * tx[ct] + j;
                     dst[0] = cf_relu(Y[ct][i][j][rt][0] + b.x);
                     dst[PIX] = cf_relu(Y[ct][i][j][rt][1] + b.y);
                     dst[2 * PIX] = cf_relu(Y[ct][i][j][rt][2] + b.z);
                     dst[3 * PIX] = cf_relu(Y[ct][i][j][rt][3] + b.w);
                 }
     }
-    cf_wave_sync();
+    if constexpr (RSPLIT > 1) __syncthreads();      // phase 3 reads all rows of this wave's own columns: both row halves in place
+    else cf_wave_sync();
 }
 
 // ---- the conditioner: phases 1-3 of a step (shared by the forward and the inverse kernel) --------------
@@ -854,6 +861,7 @@ using G64v3 = Geo<64, 4, 4, 16, 0>;
 using G16w = Geo<16, 16, 16, 1, 3>;      // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2); 16x16: in k_flow_step_small
 using G32w = Geo<32, 8, 8, 4, 3>;
 using G64w = Geo<64, 4, 4, 16, 3>;
+using G64w2 = Geo<64, 4, 4, 8, 3>;       // 8 samples per workgroup, 2 workgroups / CU: two waves per column tile split the rows
 
 
 int shape_id(int C, int H, int W) {
