@@ -163,7 +163,7 @@ def roofline(events, name, dt):
         per[k][0] += e[0].elapsed_time(e[1])
         per[k][1] += e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4]))
     traffic = None
-    tp = os.path.join(ROOT, "profiles", {"cifar10": "traffic.json", "mnist": "r2_mnist2_traffic.json",
+    tp = os.path.join(ROOT, "profiles", {"cifar10": "traffic.json", "mnist": "r2_mnist3_traffic.json",
                                          "smap": "r2_smap1_traffic.json"}.get(name, "none"))
     if os.path.exists(tp):          # PMC-measured HBM bytes of the dominant kernel (profiles/, tools/profile.sh), scaled to this run's launch size
         tj = json.load(open(tp))

@@ -161,7 +161,7 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs,
  * in_squeeze != 0: x is the UN-squeezed (B, C/4, 2H, 2W) tensor and Squeeze((2,2)) (squeeze.py:10-11)
  * is folded into the kernel's operand addressing (no separate index kernel, no extra HBM pass).
  * The 3x3 of the coupling net runs in Winograd F(2x2,3x3) form (fp32; weights G w G^T packed by
- * cf_flow_step_prepare) on 16x16 images and from 1024 (8x8) / 4096 (4x4) samples per call, in direct form
+ * cf_flow_step_prepare) on 16x16 images and from 1024 (8x8) / 2048 (4x4) samples per call, in direct form
  * otherwise - same results to fp32 rounding; the environment variable CONTEXTFLOW_DIRECT_CONV=1 keeps
  * the direct form everywhere.  The same holds for _fwd_taped, _fwd_ctx and _inv below.                 */
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
