@@ -11,8 +11,10 @@
 //    puts t, log_s and x1 of one (channel, pixel) in the SAME lane for the affine epilogue;
 //  * a workgroup (4 waves) owns PIX = 128/256 pixels = SPW whole samples; activations never leave
 //    the CU between the five contractions: x -> [MFMA] y=W'x+b' (ActNorm folded into the 1x1
-//    matrix) -> LDS -> h1 -> LDS -> 3x3 implicit GEMM over 9 taps -> LDS -> h -> epilogue.
-//    HBM traffic per step = read x once + write z once;
+//    matrix) -> LDS -> h1 -> LDS -> 3x3 -> LDS -> h -> epilogue.  HBM traffic per step = read x once + write z once.
+//    The 3x3 - 72 of the 80 C^2 HW multiply-adds of a step - is an implicit GEMM over the 9 taps in the direct-form
+//    geometries, and Winograd F(2x2,3x3) on 16x16x4 tiles (16 of 36 products per output tile; cf_step_common.h:
+//    winograd_phase2) in the PIPE = 3 geometries that cf_flow_step_fwd dispatches at benchmark batch sizes;
 //  * weights are pre-packed per call by cf_flow_step_prepare into MFMA-fragment order (one 16-byte
 //    load per lane = A fragments of 4 k-steps, 1 KiB per wave-instruction, L2-resident) and
 //    software-prefetched one group ahead of the MFMAs that use them;

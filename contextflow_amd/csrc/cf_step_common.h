@@ -13,7 +13,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWaves = 4;
 
 // ---- compile-time geometry of one supported shape ------------------------------------------------
-// PIPE_: phase-2 loop form (1 = explicit two-stage operand pipeline, 0 = compiler-scheduled per-tap loop)
+// PIPE_: form of phase 2, the 3x3 (0 = compiler-scheduled per-tap loop, 1 = explicit two-stage operand pipeline, 2 = all nine
+// taps unrolled with precomputed row / column offset parts, 3 = Winograd F(2x2,3x3): winograd_phase2)
 // ABL_: timing-only ablations for tools/step_bench.py (1 = phase-2 operands are constants: no LDS / L2 loads there)
 // PATCH_: (backward) every row of an LDS plane carries, behind its PIX pixel columns, the fold sums of the transposed
 // reflect-padded 3x3 (cf_step_bwd.hip): PP slots per sample + one zero slot; RS = row stride of all LDS planes.
