@@ -1644,3 +1644,32 @@ def test_taped_training_step_at_a_large_batch_is_clean(L):
             # the two forms run different forward kernels (Winograd / direct 3x3): hidden units within rounding of 0 flip
             # their ReLU mask and move single entries by ~1e-3..1e-2 of the tensor's scale; register garbage is 1e20+
             assert (g[k] - ref[k]).norm().item() <= 1e-2 * ref[k].norm().item() + 1e-12, k
+
+
+@pytest.mark.parametrize("fxname", ["mnist_eye_cf", "cifar10_onehot_cf", "cifar10_eye"])
+def test_specialist_forward_at_saturating_batch_runs_the_winograd_kernels(L, fxname):
+    """The specialist step kernels (per-sample bias on the conditioner output / before its first ReLU) take the Winograd
+    form of the 3x3 at 8x8 / 4x4 only from 1024 / 2048 samples per call: the fixture's rows, noise and contexts repeated
+    to 4096 samples must give the reference's log-densities within the same bar as the small-batch test."""
+    import contextflow_amd as cfa
+    from tests.helpers import load_specialist
+    from tests.gpu_util import set_noise
+    name, ctx, ops, M, params, inp = load_specialist(fxname)
+    cfg, ds, MM = cfa.preset_config(name)
+    enc_type = ctx.get("enc_type", "uniform")
+    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type=enc_type, contextflow=ctx["contextflow"])
+    model = cfa.create_model(cfg, ds, MM, contexts=ctx["contexts"])
+    model.load_state_dict(params, strict=True)
+    model = model.to(DEV).eval()
+    rep = 4096 // inp["x"].shape[0]
+    tile = lambda t: t.repeat(rep, *([1] * (t.dim() - 1)))
+    set_noise(model, tile(inp["u"]), [tile(e) for e in inp["eps"]])
+    encs = [m for m in model.modules() if isinstance(m, cfa.layers.UniformCatDequantization)]
+    assert len(encs) == len(inp["cnoise"])
+    for e, c in zip(encs, inp["cnoise"]):
+        e.fixed_noise = tile(c).to(DEV)
+    z, logp = model(tile(inp["x"]).to(DEV), tile(inp["context"]).to(DEV))
+    ref = tile(inp["logp"])
+    tol = max(BPD_TOL, 1e-5 * bpd(inp["logp"], name).abs().max().item())
+    assert (bpd(logp.cpu(), name) - bpd(ref, name)).abs().max().item() < tol
+    assert (z.cpu() - tile(inp["z"])).abs().max().item() < 2e-3 * max(1.0, inp["z"].abs().max().item())
