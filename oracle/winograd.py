@@ -1,0 +1,37 @@
+"""TEST INFRASTRUCTURE (like the rest of oracle/): CPU restatement of the Winograd F(2x2,3x3) form in which the HIP step
+kernels evaluate the reflect-padded 3x3 convolution of the coupling nets (contextflow/layers/coupling.py:27; kernel side:
+contextflow_amd/csrc/cf_step_common.h: winograd_phase2).  fp32 arithmetic in the kernel's order of operations: weights
+transformed in fp64 and rounded once (k_step_pack), input transform B^T d B by additions, per-position channel contraction
+with fp32 accumulation, output transform A^T M A by additions.  Pinned by tests/test_oracle_golden.py against the direct
+convolution and, through the flow oracle, against the reference's end-to-end fixtures."""
+import torch
+import torch.nn.functional as F
+
+G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+
+
+def winograd3x3_reflect(h, w, b):
+    """h (B, Ci, H, W) fp32, w (Co, Ci, 3, 3), b (Co,) -> conv2d(reflect_pad(h, 1), w) + b as (B, Co, H, W); H, W even."""
+    B, Ci, H, W = h.shape
+    U = torch.einsum("xa,oiab,yb->xyoi", G, w.double(), G).float()                 # (4, 4, Co, Ci), rounded once
+    d = F.pad(h, (1, 1, 1, 1), mode="reflect").unfold(2, 4, 2).unfold(3, 4, 2)     # (B, Ci, H/2, W/2, 4, 4) input patches
+    V = torch.einsum("xa,ncijab->ncijxb", BT, d)
+    V = torch.einsum("ncijxb,yb->ncijxy", V, BT)
+    M = torch.einsum("xyoc,ncijxy->noijxy", U, V)
+    Y = torch.einsum("px,noijxy->noijpy", AT, M)
+    Y = torch.einsum("noijpy,qy->noijpq", Y, AT)                                   # (B, Co, H/2, W/2, 2, 2)
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(B, -1, H, W) + b.view(1, -1, 1, 1)
+
+
+def coupling_net_winograd(x0, p, prefix, pad):
+    """oracle.flow_oracle.coupling_net with the 3x3 in Winograd form (fp32 inputs, (1, 1) padding; otherwise the direct form)."""
+    h = F.relu(F.conv2d(x0, p[prefix + "NN.0.weight"], p[prefix + "NN.0.bias"]))
+    if h.dtype == torch.float32 and tuple(pad) == (1, 1) and h.shape[2] % 2 == 0 and h.shape[3] % 2 == 0:
+        h = F.relu(winograd3x3_reflect(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
+    else:
+        if pad[0] or pad[1]:
+            h = F.pad(h, (pad[1], pad[1], pad[0], pad[0]), mode="reflect")
+        h = F.relu(F.conv2d(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
+    return F.conv2d(h, p[prefix + "NN.4.weight"], p[prefix + "NN.4.bias"])

@@ -249,3 +249,36 @@ def test_activation_oracle(tag):
     assert (ldj - torch.from_numpy(fx[tag + "/ldj"])).abs().max() < 1e-4
     xr = fo.activation_inv(ACT_CASES[tag], torch.from_numpy(fx[tag + "/z"]), a, b, eps=1e-4)
     assert (xr - torch.from_numpy(fx[tag + "/xr"])).abs().max() < 1e-5
+
+
+def test_winograd_form_of_the_3x3_against_the_direct_convolution():
+    """The F(2x2,3x3) restatement (oracle/winograd.py = what winograd_phase2 computes) against the fp64 direct convolution:
+    same result to fp32 rounding, error within 3x the fp32 direct convolution's own."""
+    from oracle.winograd import winograd3x3_reflect
+    g = torch.Generator().manual_seed(0)
+    for (C, H) in [(32, 16), (64, 8), (128, 4)]:
+        h = torch.relu(torch.randn(3, C, H, H, generator=g))
+        w = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+        b = 0.1 * torch.randn(C, generator=g)
+        ref = torch.nn.functional.conv2d(torch.nn.functional.pad(h.double(), (1, 1, 1, 1), mode="reflect"), w.double(), b.double())
+        direct = torch.nn.functional.conv2d(torch.nn.functional.pad(h, (1, 1, 1, 1), mode="reflect"), w, b)
+        wino = winograd3x3_reflect(h, w, b)
+        e_direct = (direct.double() - ref).abs().max().item()
+        e_wino = (wino.double() - ref).abs().max().item()
+        assert e_wino <= 1e-5 * ref.abs().max().item()
+        assert e_wino <= 3.0 * e_direct + 1e-7, (C, H, e_wino, e_direct)
+
+
+@pytest.mark.parametrize("name,tag", [("cifar10", None), ("mnist", "stress"), ("cifar10", "extreme")])
+def test_e2e_with_the_winograd_form_keeps_the_bits_per_dim(name, tag, monkeypatch):
+    """The whole flow with every coupling net's 3x3 in Winograd form (fp32) against the reference's outputs: the bar of the
+    direct form (1e-5 bits/dim; "extreme": the fixture's own) holds - the evidence behind dispatching the Winograd kernels."""
+    from oracle import winograd
+    ops, _, M, params, fx = load_e2e(name, tag)
+    x, u, eps = e2e_inputs(name, fx)
+    tol = stress_tolerance(fx, tag) if tag else 1e-5
+    monkeypatch.setattr(fo, "coupling_net", winograd.coupling_net_winograd)
+    _, logp = fo.flow_forward(ops, params, x, u, eps)
+    assert (bpd(logp, name) - bpd(torch.from_numpy(fx["logp"]), name)).abs().max() < tol
+    if "logp_f64" in fx:
+        assert (bpd(logp, name) - bpd(torch.from_numpy(fx["logp_f64"]), name)).abs().max() < tol

@@ -9,36 +9,7 @@ import torch, torch.nn.functional as F
 from oracle import flow_oracle as fo
 from tests.helpers import load_e2e, e2e_inputs, bpd
 
-G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
-BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
-AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
-
-
-def winograd3x3(h, w, b):
-    """h (B,Ci,H,W) fp32 (reflect padded here), w (Co,Ci,3,3) -> (B,Co,H,W); F(2x2,3x3), fp32 arithmetic in the order a
-    kernel would use: input transform (adds), per-position channel contraction (fp32 accumulate), output transform."""
-    B, Ci, H, W = h.shape
-    U = torch.einsum("xa,oiab,yb->xyoi", G, w.double(), G).float()               # (4,4,Co,Ci), rounded once
-    hp = F.pad(h, (1, 1, 1, 1), mode="reflect")
-    d = hp.unfold(2, 4, 2).unfold(3, 4, 2)                                         # (B,Ci,H/2,W/2,4,4)
-    V = torch.einsum("xa,ncijab->ncijxb", BT, d)
-    V = torch.einsum("ncijxb,yb->ncijxy", V, BT)                                   # (B,Ci,th,tw,4,4)
-    M = torch.einsum("xyoc,ncijxy->noijxy", U, V)
-    Y = torch.einsum("px,noijxy->noijpy", AT, M)
-    Y = torch.einsum("noijpy,qy->noijpq", Y, AT)                                   # (B,Co,th,tw,2,2)
-    out = Y.permute(0, 1, 2, 4, 3, 5).reshape(B, -1, H, W)
-    return out + b.view(1, -1, 1, 1)
-
-
-def coupling_net_wino(x0, p, prefix, pad):
-    h = F.relu(F.conv2d(x0, p[prefix + "NN.0.weight"], p[prefix + "NN.0.bias"]))
-    if h.dtype == torch.float32 and pad == (1, 1):
-        h = F.relu(winograd3x3(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
-    else:
-        if pad[0] or pad[1]:
-            h = F.pad(h, (pad[1], pad[1], pad[0], pad[0]), mode="reflect")
-        h = F.relu(F.conv2d(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
-    return F.conv2d(h, p[prefix + "NN.4.weight"], p[prefix + "NN.4.bias"])
+from oracle.winograd import coupling_net_winograd as coupling_net_wino      # the restatement lives with the oracle
 
 
 direct = fo.coupling_net
