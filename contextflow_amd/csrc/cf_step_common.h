@@ -367,7 +367,7 @@ __device__ __forceinline__ void mask_store(unsigned* __restrict__ m, const f32x1
 //     Y = A^T [ sum_ci U[ci] (.) (B^T d[ci] B) ] A,     U = G w G^T (packed once, fp64 -> fp32, k_step_pack),
 // d = the 4x4 input patch of the tile (reflect-padded), B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]],
 // A^T = [[1,1,1,0],[0,1,-1,-1]].  All entries are 0 / +-1 (the 1/2 of G lives in the packed weights): the transforms are
-// additions, the error of the fp32 result is ~1.6x that of the direct sum (tools/dev/winograd_numerics.py: bits/dim of
+// additions, the error of the fp32 result is ~1.6x that of the direct sum (tests/dev_winograd_numerics.py: bits/dim of
 // every end-to-end fixture unchanged to its last fp32 digit).
 // Mapping: the 16 "positions" (xi, nu) are 16 independent (HID x HID) x (HID x tiles) products on v_mfma_f32_16x16x4_f32;
 // a wave owns the 16 tiles (= 64 output pixels) of its own pixel columns and ALL output rows, so the B operand - one

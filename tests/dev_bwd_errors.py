@@ -1,12 +1,12 @@
 """Per-tensor relative gradient error of the hand-written backward vs fp64 autograd through the oracle, next to the
 error of fp32 autograd through the same oracle (the fp32 noise floor of the gradient itself).  Developer tool:
-    python tools/dev/bwd_errors.py [mnist cifar10 smap atm]"""
+    python tests/dev_bwd_errors.py [mnist cifar10 smap atm]"""
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import flow_oracle as fo                      # noqa: E402
 from tests.gpu_util import build_model, set_noise         # noqa: E402

@@ -4,7 +4,7 @@ evaluated in fp32, still meet the 1e-5 bits/dim bar?  Runs the oracle's flow on 
 3x3 replaced by an fp32 Winograd restatement (weights transformed in fp64, rounded once) and prints the bits/dim error
 against the reference's fp32 and fp64 outputs, next to the direct fp32 convolution's."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 from oracle import flow_oracle as fo
 from tests.helpers import load_e2e, e2e_inputs, bpd

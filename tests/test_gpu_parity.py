@@ -596,7 +596,7 @@ def test_backward_against_autograd_oracle(L, name, B, tag):
         got = p.grad.detach().cpu().double()
         scale = max(ref.abs().max().item(), 1e-3)
         err = (got - ref).abs().max().item() / scale
-        # measured (tools/dev/bwd_errors.py, profiles/r2_backward_errors.md): worst tensor 4.6e-5 (cifar10 split-prior
+        # measured (tests/dev_bwd_errors.py, profiles/r2_backward_errors.md): worst tensor 4.6e-5 (cifar10 split-prior
         # means), every tensor below the error fp32 torch.autograd itself makes on the same graph (up to 1.8e-4).
         # Stress parameters (sigma down to 0.13, saturated log-scales): the bar is 3x that fp32 floor where it exceeds 1e-4
         tol = 1e-4
