@@ -90,7 +90,8 @@ SIGNATURES = {
     "cf_attention_bwd": (_c_int, [_c_p] * 3 + [_c_int] * 3 + [_c_f, _c_p]),
     "cf_gelu": (_c_int, [_c_p] * 3 + [_c_i64, _c_int, _c_p]),
     "cf_coupling_apply_bwd": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
-    "cf_channel_sums": (_c_int, [_c_p] * 3 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
+    "cf_channel_sums_ws_bytes": (_c_i64, [_c_int] * 2),
+    "cf_channel_sums": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_i64, _c_i64, _c_p]),
     "cf_flow_step_fwd_ctx_taped": (_c_int, [_c_p] * 9 + [_c_int] * 4 + [_c_i64, _c_p]),
     "cf_flow_step_fwd_ctx": (_c_int, [_c_p] * 5 + [_c_int] * 5 + [_c_i64, _c_p]),
     "cf_flow_step_bwd_ctx": (_c_int, [_c_p] * 14 + [_c_int] * 4 + [_c_i64, _c_p]),

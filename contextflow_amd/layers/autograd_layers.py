@@ -277,7 +277,8 @@ def actnorm_backward(m, x_in, gz, gld):
     z = _new(B, C, H, W, like=gzc)
     _hip.call("cf_actnorm", _hip.p(x), _hip.p(t), _hip.p(logs), _hip.p(z), None, B, C, H * W, 0, st)
     sums = _new(2 * C, like=gzc)
-    _hip.call("cf_channel_sums", _hip.p(gzc), _hip.p(z), _hip.p(sums), B, C, H * W, C * H * W, C * H * W, st)
+    wsum = torch.empty(_hip.lib().cf_channel_sums_ws_bytes(B, C), device=gzc.device, dtype=torch.uint8)
+    _hip.call("cf_channel_sums", _hip.p(gzc), _hip.p(z), _hip.p(sums), _hip.p(wsum), B, C, H * W, C * H * W, C * H * W, st)
     s = torch.exp(-logs)
     gx = gzc * s.view(1, C, 1, 1)
     return gx, {m.NN_t: -s * sums[:C], m.NN_logs: gld.sum() - sums[C:]}

@@ -313,8 +313,9 @@ int cf_gelu(const float* x, const float* gy, float* out, int64_t n, int backward
 int cf_coupling_apply_bwd(const float* x, const float* h, const float* gz, const float* gld, float* gx, float* gh, int B,
                           int C, int HW, int64_t x_bstride, int64_t gz_bstride, cf_stream_t stream);
 /* out[c] = sum_{b,p} a[b,c,p]; out[C+c] = sum_{b,p} a*b2 (b2 may be null): ActNorm's d/dt, d/dlogs reductions
- * (actnorm.py:53-60), one workgroup per channel, fixed order                                                  */
-int cf_channel_sums(const float* a, const float* b2, float* out, int B, int C, int HW, int64_t a_bstride,
+ * (actnorm.py:53-60); two passes over batch slices, fixed order; ws: cf_channel_sums_ws_bytes(B, C) bytes         */
+int64_t cf_channel_sums_ws_bytes(int B, int C);
+int cf_channel_sums(const float* a, const float* b2, float* out, void* ws, int B, int C, int HW, int64_t a_bstride,
                     int64_t b_bstride, cf_stream_t stream);
 
 /* ---- specialist (context-conditioned) branches: SURVEY 8(f) rank 2 ------------------------------------------

@@ -1062,8 +1062,14 @@ def test_layer_backward_kernels_against_torch(L):
     # channel sums
     a, b2 = torch.randn(B, C, HW, generator=g), torch.randn(B, C, HW, generator=g)
     out = torch.empty(2 * C, device=DEV)
-    _hip.call("cf_channel_sums", P(a.cpu()), P(b2.cpu()), _hip.p(out), B, C, HW, C * HW, C * HW, st())
+    wsum = torch.empty(_hip.lib().cf_channel_sums_ws_bytes(B, C), device=DEV, dtype=torch.uint8)
+    _hip.call("cf_channel_sums", P(a.cpu()), P(b2.cpu()), _hip.p(out), _hip.p(wsum), B, C, HW, C * HW, C * HW, st())
     assert (out[:C].cpu() - a.sum((0, 2))).abs().max() < 1e-4 and (out[C:].cpu() - (a * b2).sum((0, 2))).abs().max() < 1e-4
+    Bb = 1000                                                 # more samples than batch slices: ragged slices
+    a, b2 = torch.randn(Bb, C, HW, generator=g), torch.randn(Bb, C, HW, generator=g)
+    wsum = torch.empty(_hip.lib().cf_channel_sums_ws_bytes(Bb, C), device=DEV, dtype=torch.uint8)
+    _hip.call("cf_channel_sums", P(a.cpu()), P(b2.cpu()), _hip.p(out), _hip.p(wsum), Bb, C, HW, C * HW, C * HW, st())
+    assert (out[:C].cpu() - a.sum((0, 2))).abs().max() < 1e-3 and (out[C:].cpu() - (a * b2).sum((0, 2))).abs().max() < 1e-3
 
 
 def test_training_steps_reduce_the_loss_smap(L):
