@@ -1,17 +1,21 @@
 // Backward of one flow step (Conv1x1 -> ActNorm -> Coupling) for the training step that follows the density
 // path (contextflow/experiment_cl.py:130-136 `cost.backward()`), as ONE gfx950 kernel per step.
 //
-// Per tile the kernel re-runs the forward in LDS (same code as cf_step.hip: invertible flows make storing the
-// conv intermediates unnecessary), then walks the data-gradient chain on the fp32 matrix cores with
-// TRANSPOSED weight fragments:
+// What the data-gradient chain needs of the forward - y1, the log-scale and the two ReLU masks - comes from the tape the
+// training forward wrote (TAPED, the default: cf_flow_step_fwd_taped; no step input, no recompute), or is recomputed from
+// the step input in LDS with the forward's own code (invertible flow: nothing else stored).  Then, on the fp32 matrix
+// cores with TRANSPOSED weight fragments:
 //     g_h   = [ g_z1 ,  (g_z1 * y1 * e^{ls} + g_ld) * (1 - (ls/2)^2) ]           affine map + log-det
 //     g_h2  = (NN.4^T g_h)            * [h2 > 0]
 //     g_h1  = (NN.2^T (*) g_h2)       * [h1 > 0]     3x3 transposed conv = adjoint of the reflect-padded gather
 //     g_y0  =  NN.0^T g_h1 + g_z0 ;   g_y1 = g_z1 * e^{ls}
 //     g_x   = (e^{-logs} Wm)^T g_y
-// and writes, next to g_x, the operand planes the weight gradients contract over (y0, h1, h2, g_h, g_h2, g_h1,
-// g_y).  The weight gradients themselves are plain GEMMs over (batch x pixels) and are left to rocBLAS through
-// torch (contextflow_amd/layers/autograd.py).  ReLU masks are 16-bit lane masks in registers.
+// and writes, next to g_x, the gradient planes the weight gradients contract over (g_h, g_h2, g_h1, g_y; in the recompute
+// form also y0, h1, h2).  The weight gradients themselves are split-K MFMA GEMMs over (sample, pixel): cf_wgrad.hip,
+// called from contextflow_amd/layers/autograd.py.  ReLU masks are 16-bit lane masks in registers.
+// The adjoint of the reflected gather reads, per tap, ONE source per operand: every LDS plane row carries the fold sums of
+// its border rows / columns behind its pixels (PATCH geometries, see patch_build below); 4x4 images keep the class-by-class
+// weighted sums (adj_tap<NS>).
 #include "cf_step_common.h"
 
 namespace {
