@@ -2,8 +2,9 @@
 // what the training step (experiment_ad.py:207-213: loss.backward()) needs besides the fused conv-flow backward.
 //
 // All of them are small HBM- / latency-bound VALU kernels over token-major (rows, dim) or NCHW tensors; the dense
-// contractions of the Linear layers' backward (gX = gY W, gW = gY^T X) are plain GEMMs and stay with the library
-// (torch.matmul -> hipBLASLt), as the scope rules allow.  Parameter gradients that are reductions over rows are
+// contractions of the Linear layers' backward run on the repo's own MFMA kernels (gX = gY W: cf_linear with the
+// transposed weight; gW = gY^T X: cf_linear_wgrad, cf_vit.hip - no library GEMM anywhere in the product:
+// tests/test_host.py::test_no_library_gemm_in_the_product).  Parameter gradients that are reductions over rows are
 // produced as per-workgroup partial sums in a fixed order (no float atomics: reproducible); the host sums the few
 // hundred partial rows.
 #include "cf_common.h"
