@@ -176,7 +176,7 @@ def roofline(events, name, dt):
             "executed": round(ach_exec, 2), "executed_frac": round(ach_exec / PEAK_F32_MFMA_TFLOPS, 4),
             "algorithm": "direct" if abs(ach_exec - ach) < 1e-9 else "Winograd F(2x2,3x3) for the 3x3 of the coupling nets (fp32, 40 of 80 C^2 HW multiply-adds per sample-step executed)",
             "kernel": "k_vit_step (Conv1x1+ActNorm+TransCoupling fused, v_mfma_f32_32x32x2_f32)" if vit else
-                      "k_flow_step / k_flow_step_small (Conv1x1+ActNorm+Coupling fused, v_mfma_f32_32x32x2_f32 + 16x16x4_f32)",
+                      "k_flow_step / k_flow_step_small (Conv1x1+ActNorm+Coupling fused; v_mfma_f32_32x32x2_f32 / 16x16x4_f32, the 3x3 in Winograd F(2x2,3x3) form on 16x16x4 tiles)",
             "launches": len(events), "avg_launch_ms": round(ms / len(events), 4),
             "per_level_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
             "kernel_time_share": round(ms * 1e-3 / dt, 3)}
