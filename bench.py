@@ -153,7 +153,7 @@ def roofline(events, name, dt):
     # multiply-adds actually issued to the matrix pipe: the Winograd F(2x2,3x3) form of the 3x3 executes 32 of its 72 C^2 HW
     # (cf_flow_step_fwd: 16x16 images always, 8x8 / 4x4 from 1024 / 2048 samples per launch)
     wino = lambda e: (not vit) and os.environ.get("CONTEXTFLOW_DIRECT_CONV") != "1" and (
-        (e[3] == 16 and e[4] == 256) or (e[3] == 32 and e[2] >= 1024) or (e[3] == 64 and e[2] >= 2048))
+        (e[3] in (8, 16) and e[4] == 256) or (e[3] == 32 and e[2] >= 1024) or (e[3] == 64 and e[2] >= 2048))
     flop_exec = sum(e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4]) * (0.5 if wino(e) else 1.0)) for e in events)
     ach_exec = flop_exec / (ms * 1e-3) / 1e12
     per = {}

@@ -394,14 +394,30 @@ __global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : G::MINW) void k_flow_s
                     for (int ct = 0; ct < 4; ++ct)
                         a1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), Y0[(4 * e + lg) * PIX + colb + 16 * ct], a1[ct], 0, 0, 0);
                 }
+            if constexpr (G::WINO) {
+                // Winograd form of the 3x3 (cf_step_common.h: winograd_phase2): h1 goes to LDS in its parity-split pixel
+                // order, which scatters a wave's pixels over the whole sample - every wave must be done with the x plane
+                static_assert(!DUMP && !DBG, "the tape / the dumps are written by the direct-form geometry");
+                __syncthreads();
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int pw = wino_pix<G>(0, wave * 4 + ct, l15);      // a column tile is one image row
 #pragma unroll
-                for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a1[ct][r]);
+                    for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + (pw ^ ((r & 1) * (W / 2)))] = cf_relu(a1[ct][r]);
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a1[ct][r]);
+            }
             if constexpr (DUMP) { rows_store_t<G, HID, HID>(tp.h1, H1, tile, B, wave, lane); plane_mask_store(tp.m1); }
         }
         __syncthreads();                 // h1 complete: the 3x3 taps read neighbouring waves' image rows
         if constexpr (DBG) dump(H1, HID, C);
+        if constexpr (G::WINO) {
+            winograd_phase2<G>(lds, ws, rs, lane, wave);       // ends with h2 (ReLU, bias) in natural order, own columns
+        } else {
         f32x4 a2[4];
         {
             const float4 b = *reinterpret_cast<const float4*>(ws + G::OFF_B2 + 4 * lg);
@@ -435,6 +451,7 @@ __global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : G::MINW) void k_flow_s
             for (int r = 0; r < 4; ++r) H1[(4 * lg + r) * PIX + colb + 16 * ct] = cf_relu(a2[ct][r]);
         if constexpr (DUMP) { rows_store_t<G, HID, HID>(tp.h2, H1, tile, B, wave, lane); plane_mask_store(tp.m2); }
         if constexpr (DBG) dump(H1, HID, C + HID);
+        }
     }
     cf_wave_sync();                      // h2: every lane's rows in place before other lanes read them as operands
 
@@ -961,6 +978,8 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
         case 25: CF_STEP(G64v1); break;
         case 26: CF_STEP(G64v2); break;
         case 27: CF_STEP(G64v3); break;
+        case 4: rc = in_squeeze ? launch_step_small<G8w, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))           // variant 4 at C = 8
+                               : launch_step_small<G8w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
         case 12: rc = in_squeeze ? launch_step_small<G16w, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))         // variant 4:
                                 : launch_step_small<G16w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;  // Winograd form of the 3x3
         case 20: CF_STEP(G32w); break;
@@ -985,7 +1004,7 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2): 40 instead of 80 C^2 HW multiply-adds per sample and step.
     // CONTEXTFLOW_DIRECT_CONV=1 keeps the direct form (A/B measurements, tools/step_bench.py).
     const bool direct_only = direct_conv_only();
-    if (!direct_only && (sid == 1 || (sid == 2 && B >= 256 * G32::SPW))) flags = 4 << 16;
+    if (!direct_only && (sid == 0 || sid == 1 || (sid == 2 && B >= 256 * G32::SPW))) flags = 4 << 16;
     if (!direct_only && sid == 3 && B >= 256 * G64w2::SPW) flags = 5 << 16;      // 4x4: 8 samples per workgroup, rows split over wave pairs
     // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
     if ((sid == 2 && B <= 512) || (sid == 3 && B <= 1024)) {

@@ -859,6 +859,7 @@ using G32v3 = Geo<32, 8, 8, 8, 0>;
 using G64v1 = Geo<64, 4, 4, 16, 1, 1>;
 using G64v2 = Geo<64, 4, 4, 8, 1>;
 using G64v3 = Geo<64, 4, 4, 16, 0>;
+using G8w = Geo<8, 16, 16, 1, 3>;
 using G16w = Geo<16, 16, 16, 1, 3>;      // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2); 16x16: in k_flow_step_small
 using G32w = Geo<32, 8, 8, 4, 3>;
 using G64w = Geo<64, 4, 4, 16, 3>;

@@ -1585,7 +1585,7 @@ def test_e2e_at_saturating_batch_runs_the_winograd_kernels(L, name, tag):
 
 
 @pytest.mark.parametrize("squeeze", [False, True])
-@pytest.mark.parametrize("C,H", [(16, 16), (32, 8), (64, 4)])
+@pytest.mark.parametrize("C,H", [(8, 16), (16, 16), (32, 8), (64, 4)])
 def test_winograd_step_kernel_against_the_oracle(L, C, H, squeeze):
     """One fused step through the production entry point at a batch that selects the Winograd kernels (4100 samples: the
     last workgroup is partially filled), against the oracle of the same step and against the direct-form kernel: z to

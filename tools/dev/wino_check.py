@@ -13,7 +13,7 @@ L = _hip.lib()
 fn = L.cf_flow_step_fwd_debug
 fn.restype = ctypes.c_int
 P = _hip.p
-for (C, H) in [(32, 8), (64, 4), (16, 16)]:
+for (C, H) in [(32, 8), (64, 4), (16, 16), (8, 16)]:
     HID, HALF, HW = 2 * C, C // 2, H * H
     g = torch.Generator().manual_seed(C)
     r = lambda *s: (torch.randn(*s, generator=g)).to(dev)
