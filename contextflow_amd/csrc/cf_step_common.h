@@ -540,15 +540,14 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {            // the two pixels (j = 0, 1) of an output row of the tile: one 8-byte store
+                float* dst = H1 + ((rt0 + rt) * 16 + 4 * lg) * PIX + smp[ct] * HW + (2 * ty[ct] + i) * W + 2 * tx[ct];
+                const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float* dst = H1 + ((rt0 + rt) * 16 + 4 * lg) * PIX + smp[ct] * HW + (2 * ty[ct] + i) * W + 2 * tx[ct] + j;
-                    dst[0] = cf_relu(Y[ct][i][j][rt][0] + b.x);
-                    dst[PIX] = cf_relu(Y[ct][i][j][rt][1] + b.y);
-                    dst[2 * PIX] = cf_relu(Y[ct][i][j][rt][2] + b.z);
-                    dst[3 * PIX] = cf_relu(Y[ct][i][j][rt][3] + b.w);
-                }
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<float2*>(dst + r * PIX) =
+                        make_float2(cf_relu(Y[ct][i][0][rt][r] + bb[r]), cf_relu(Y[ct][i][1][rt][r] + bb[r]));
+            }
     }
     if constexpr (RSPLIT > 1) __syncthreads();      // phase 3 reads all rows of this wave's own columns: both row halves in place
     else cf_wave_sync();
