@@ -15,6 +15,7 @@
 // outputs are tiny and shared by every workgroup, and the result stays bitwise reproducible).  Output layout
 // [t][m][n]; the caller permutes to the reference's [m][n][kh][kw].
 #include "cf_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -131,8 +132,113 @@ __device__ __forceinline__ void wg_row_steps(f32x16 (&acc)[9], WgOps9& o0, WgOps
     }
 }
 
+// ---- 3x3 path, Winograd form F(3x3, 2x2) -----------------------------------------------------------------------
+// The weight gradient of a 3x3 convolution is itself a convolution with 3x3 outputs (the taps) and the 2x2 tiles of the
+// upstream gradient as filter:  gw = A^T [ sum_{sample, tile} (G dy G^T) . (B^T d B) ] A   with dy the 2x2 tile of A, d the
+// 4x4 reflect-padded patch of Bm around it.  The sum over tiles and samples runs in the Winograd domain: 16 positions,
+// each a rank-update of a 32x32 accumulator tile, i.e. 16 MFMAs per 2 tiles (= 8 pixels) where the direct form issues
+// 36.  The k axis of the MFMA is the TILE index: a lane (channel li, tile lk) reads its own 2x2 / 4x4 raw values from the
+// transposed LDS tiles (conflict-free as before), transforms them in registers (12 + 32 additions; G' = 2G is used
+// unscaled, the factors 1/2 are folded into the output transform) and feeds the 16 results straight into the MFMAs as
+// operands - no LDS round trip for the transformed data.  The 16 accumulator tiles (256 registers per lane) live in the
+// AGPR half of the register file: one wave per SIMD, which is all the MFMA pipe needs here (16 independent
+// accumulators back to back; the raw reads of the next step are issued in front of them).
+// Reflect: the patch column -1 of the leftmost tile is column 1 and the tile of the other lane half needs column
+// x0 - 1 = 1 as well - BOTH halves read column 1, so the border is an address without the lane-half term (same at the
+// right border with column W - 2): no selects.  Rows are scalar as in the direct form.
+// Bias gradient: position (1, 1) of G' dy G'^T is the plain sum of the tile.
+struct WwRow { int a[2], b[4], c[4]; };               // LDS byte offsets: rows of A; rows of Bm with / without the lane-half term
+struct WwRaw { float a[4], b[16]; };
+
+template <int H, int W, int SA, int SB>
+__device__ __forceinline__ void ww_row_addr(WwRow& r, int g, int offTBb, int laneA, int laneB, int laneC) {
+    constexpr int TR = H / 2;                          // tile rows per sample
+    const int smp = g / TR, ty = g - smp * TR, base = smp * (H * W);      // scalar
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r.a[i] = (base + (2 * ty + i) * W) * (SA * 4) + laneA;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int yy = 2 * ty - 1 + i; yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+        const int rb = offTBb + (base + yy * W) * (SB * 4);
+        r.b[i] = rb + laneB;
+        r.c[i] = rb + laneC;
+    }
+}
+
+// raw operands of k-step XS of a tile row: tiles 2 XS + lk, i.e. x0 = 4 XS + 2 lk (the 2 lk is in laneA / laneB)
+template <int W, int SA, int SB, int XS>
+__device__ __forceinline__ void ww_load(WwRaw& o, const char* ldsb, const WwRow& r) {
+    constexpr int x0 = 4 * XS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o.a[i * 2 + j] = wg_ldf(ldsb, r.a[i] + (x0 + j) * SA * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (XS == 0 && j == 0) o.b[i * 4 + j] = wg_ldf(ldsb, r.c[i] + 1 * SB * 4);
+            else if (XS == W / 4 - 1 && j == 3) o.b[i * 4 + j] = wg_ldf(ldsb, r.c[i] + (W - 2) * SB * 4);
+            else o.b[i * 4 + j] = wg_ldf(ldsb, r.b[i] + (x0 + j - 1) * SB * 4);
+        }
+}
+
+__device__ __forceinline__ void ww_transform(const WwRaw& o, float (&at)[16], float (&bt)[16]) {
+    {   // G' dy G'^T, G' = [[1,0],[1,1],[1,-1],[0,1]]
+        const float p[4] = {o.a[0], o.a[0] + o.a[2], o.a[0] - o.a[2], o.a[2]};
+        const float q[4] = {o.a[1], o.a[1] + o.a[3], o.a[1] - o.a[3], o.a[3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { at[4 * i] = p[i]; at[4 * i + 1] = p[i] + q[i]; at[4 * i + 2] = p[i] - q[i]; at[4 * i + 3] = q[i]; }
+    }
+    float t[16];                                       // B^T d
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[j] = o.b[j] - o.b[8 + j]; t[4 + j] = o.b[4 + j] + o.b[8 + j];
+        t[8 + j] = o.b[8 + j] - o.b[4 + j]; t[12 + j] = o.b[4 + j] - o.b[12 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                      // (B^T d) B
+        bt[4 * i] = t[4 * i] - t[4 * i + 2]; bt[4 * i + 1] = t[4 * i + 1] + t[4 * i + 2];
+        bt[4 * i + 2] = t[4 * i + 2] - t[4 * i + 1]; bt[4 * i + 3] = t[4 * i + 1] - t[4 * i + 3];
+    }
+}
+
+// the W/4 k-steps of one tile row; the raw reads of the next step (the last: of the next row) fly behind the MFMAs
+template <int W, int SA, int SB, int XS>
+__device__ __forceinline__ void ww_row_steps(f32x16 (&acc)[16], WwRaw& raw, const char* ldsb, const WwRow& cur, const WwRow& nxt,
+                                             float& bsum) {
+    if constexpr (XS < W / 4) {
+        float at[16], bt[16];
+        ww_transform(raw, at, bt);
+        bsum += at[5];
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (XS + 1 < W / 4) ww_load<W, SA, SB, XS + 1>(raw, ldsb, cur);
+        else ww_load<W, SA, SB, 0>(raw, ldsb, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[p], bt[p], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ww_row_steps<W, SA, SB, XS + 1>(acc, raw, ldsb, cur, nxt, bsum);
+    }
+}
+
+// output transform of one accumulator element: gw(3x3) = A^T (s M s) A, A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]], s = (1, 1/2, 1/2, 1)
+__device__ __forceinline__ void ww_output(const float (&m)[16], float (&o)[9]) {
+    float r[12];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const float p = 0.5f * (m[4 * x + 1] + m[4 * x + 2]), q = 0.5f * (m[4 * x + 1] - m[4 * x + 2]);
+        r[3 * x] = m[4 * x] + p; r[3 * x + 1] = q; r[3 * x + 2] = p - m[4 * x + 3];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float p = 0.5f * (r[3 + c] + r[6 + c]), q = 0.5f * (r[3 + c] - r[6 + c]);
+        o[c] = r[c] + p; o[3 + c] = q; o[6 + c] = p - r[9 + c];
+    }
+}
+
 // NT = 32-column tiles of Bm (1, 2 or 4); the 4 waves split (column tile) x (K quarter): KW = 4 / NT
-template <int H, int W, int TAPS, int NT>
+template <int H, int W, int TAPS, int NT, bool WINO = false>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, const float* __restrict__ Bm,
                                                float* __restrict__ part, int B, int MR, int NR) {
     constexpr int HW = H * W;
@@ -148,11 +254,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     const int nt = wave % NT, kq = __builtin_amdgcn_readfirstlane(wave / NT);
     const int m0 = blockIdx.x * 32;
 
+    static_assert(!WINO || TAPS == 9, "the Winograd form is the 3x3's");
     f32x16 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x16 wacc[WINO ? 16 : 1];                       // Winograd-domain accumulators (16 positions)
+#pragma unroll
+    for (int t = 0; t < (WINO ? 16 : 1); ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[t][r] = 0.f;
     float bsum = 0.f;                                 // row sum of A (= the bias gradient), lanes of column tile 0
 
     // global -> registers (lanes along pixels: coalesced); one chunk ahead of the MFMAs.  Element i of thread tid is
@@ -213,7 +325,24 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
         if (have) {
         constexpr int offTB = KC * SA;
         const int ncol = nt * 32 + li;
-        if constexpr (TAPS == 9) {
+        if constexpr (WINO) {
+            // this wave takes the TILE rows g = kq (mod KW) of the chunk's SPC samples
+            constexpr int TROWS = SPC * H / 2;
+            static_assert(TROWS % KW == 0 && W % 4 == 0, "tile rows split evenly; two tiles per k-step");
+            const char* ldsb = reinterpret_cast<const char*>(lds);
+            const int laneA = (2 * lk * SA + li) * 4, laneB = (2 * lk * SB + ncol) * 4, laneC = ncol * 4;
+            WwRaw raw;
+            WwRow cur, nxt;
+            ww_row_addr<H, W, SA, SB>(cur, kq, offTB * 4, laneA, laneB, laneC);
+            ww_load<W, SA, SB, 0>(raw, ldsb, cur);
+#pragma unroll 1
+            for (int g = kq; g < TROWS; g += KW) {
+                const int gn = g + KW < TROWS ? g + KW : kq;          // scalar select, no branch
+                ww_row_addr<H, W, SA, SB>(nxt, gn, offTB * 4, laneA, laneB, laneC);
+                ww_row_steps<W, SA, SB, 0>(wacc, raw, ldsb, cur, nxt, bsum);
+                cur = nxt;
+            }
+        } else if constexpr (TAPS == 9) {
             // this wave takes the image rows g = kq (mod KW) of the chunk's SPC samples
             constexpr int ROWS = SPC * H;
             static_assert(ROWS % KW == 0 && (W / 2) % 2 == 0, "rows split evenly; even number of k-steps per row");
@@ -268,6 +397,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
         for (int i = 0; i < IB; ++i) TB[pixl * SB + chw + i * CPI] = rb[i];
         __syncthreads();
         have = true;
+    }
+    if constexpr (WINO) {                              // back to the 9 taps, once
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float m[16], o[9];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = wacc[p][r];
+            ww_output(m, o);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t][r] = o[t];
+        }
     }
     // combine the KW K-quarters of this workgroup in LDS, in a fixed order (deterministic), into the kq == 0 waves
     if (KW > 1) {
@@ -337,15 +477,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
-inline int wgrad_splits(int B, int MR, int HW) {
+// wgs = workgroups to aim for: 512 (two per CU in flight) for the direct forms; the Winograd form runs one workgroup per
+// CU (512 registers per lane), so 256 - one round, one epilogue per CU
+inline int wgrad_splits(int B, int MR, int HW, int wgs = 512) {
     const int KC = HW >= 64 ? HW : 64, SPC = KC / HW;
     const int mtiles = (MR + 31) / 32, nchunks = (B + SPC - 1) / SPC;
-    int splits = 512 / mtiles;                        // ~2 workgroups per CU in flight
+    int splits = wgs / mtiles;
     if (splits > nchunks) splits = nchunks;
     return splits < 1 ? 1 : splits;
 }
 
-template <int H, int W, int TAPS, int NT>
+template <int H, int W, int TAPS, int NT, bool WINO>
 int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s) {
     constexpr int HW = H * W, KC = HW >= 64 ? HW : 64, KW = 4 / NT;
     constexpr size_t lds_main = (size_t)(KC * 33 + KC * (NT * 32 + 1)) * 4;
@@ -353,29 +495,44 @@ int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float
     constexpr size_t lds = lds_main > lds_comb ? lds_main : lds_comb;
     if (lds > 64 * 1024) {
         static std::atomic<uint64_t> raised{0};
-        if (int rc_ = cf_raise_dynamic_lds((const void*)k_wgrad<H, W, TAPS, NT>, 160 * 1024, raised, __func__)) return rc_;
+        if (int rc_ = cf_raise_dynamic_lds((const void*)k_wgrad<H, W, TAPS, NT, WINO>, 160 * 1024, raised, __func__)) return rc_;
     }
     const int mtiles = (MR + 31) / 32;
-    const int splits = wgrad_splits(B, MR, HW);
+    const int splits = wgrad_splits(B, MR, HW, WINO ? 256 : 512);
     const int S = splits, nw = TAPS * MR * NR;
     // partials: [S][TAPS*MR*NR + MR] (weights | bias of one split contiguous: ONE reduce launch)
-    k_wgrad<H, W, TAPS, NT><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, ws, B, MR, NR);
+    k_wgrad<H, W, TAPS, NT, WINO><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, ws, B, MR, NR);
     k_wgrad_reduce<<<dim3((nw + MR + 63) / 64), dim3(256), 0, s>>>(ws, gw, gbias, nw, nw + MR, S);
     return 0;
 }
 
+// the 3x3 takes the Winograd form unless CONTEXTFLOW_DIRECT_CONV=1 (same switch as the step kernels)
+static bool wgrad_direct_only() {
+    static const bool v = [] { const char* e = getenv("CONTEXTFLOW_DIRECT_CONV"); return e && e[0] == '1'; }();
+    return v;
+}
+
+template <int H, int W, int TAPS, int NT>
+int launch_form(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s) {
+    // (16x16 with 128 columns would stage 160 values per thread next to the 256 accumulators: it keeps the direct form)
+    if constexpr (TAPS == 9 && !(H * W == 256 && NT == 4)) {
+        if (!wgrad_direct_only()) return launch_wgrad<H, W, TAPS, NT, true>(A, Bm, gw, gbias, ws, B, MR, NR, s);
+    }
+    return launch_wgrad<H, W, TAPS, NT, false>(A, Bm, gw, gbias, ws, B, MR, NR, s);
+}
+
 template <int H, int W, int TAPS>
 int dispatch_nt(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s) {
-    if (NR <= 32) return launch_wgrad<H, W, TAPS, 1>(A, Bm, gw, gbias, ws, B, MR, NR, s);
-    if (NR <= 64) return launch_wgrad<H, W, TAPS, 2>(A, Bm, gw, gbias, ws, B, MR, NR, s);
-    return launch_wgrad<H, W, TAPS, 4>(A, Bm, gw, gbias, ws, B, MR, NR, s);
+    if (NR <= 32) return launch_form<H, W, TAPS, 1>(A, Bm, gw, gbias, ws, B, MR, NR, s);
+    if (NR <= 64) return launch_form<H, W, TAPS, 2>(A, Bm, gw, gbias, ws, B, MR, NR, s);
+    return launch_form<H, W, TAPS, 4>(A, Bm, gw, gbias, ws, B, MR, NR, s);
 }
 
 }  // namespace
 
 extern "C" {
 
-// workspace for the split-K partials: [splits][taps*MR*NR + MR] floats
+// workspace for the split-K partials: [splits][taps*MR*NR + MR] floats (sized for the larger split count of the two forms)
 int64_t cf_wgrad_ws_bytes(int B, int MR, int NR, int H, int W, int taps) {
     const int S = wgrad_splits(B, MR, H * W);
     return (int64_t)S * ((int64_t)taps * MR * NR + MR) * 4;

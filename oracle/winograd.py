@@ -35,3 +35,21 @@ def coupling_net_winograd(x0, p, prefix, pad):
             h = F.pad(h, (pad[1], pad[1], pad[0], pad[0]), mode="reflect")
         h = F.relu(F.conv2d(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
     return F.conv2d(h, p[prefix + "NN.4.weight"], p[prefix + "NN.4.bias"])
+
+
+# Weight gradient of the same convolution in the transposed form F(3x3, 2x2) (contextflow_amd/csrc/cf_wgrad.hip, k_wgrad
+# with WINO): the 2x2 tiles of the upstream gradient play the filter, the 4x4 reflect-padded input patches the data, and
+# the sum over tiles and samples runs in the Winograd domain (16 positions) before ONE output transform.  The kernel uses
+# the unscaled G' = 2G rows and folds the factors 1/2 into the output transform; this restatement keeps them in G.
+G32 = torch.tensor([[1, 0], [.5, .5], [.5, -.5], [0, 1]], dtype=torch.float32)
+AT32 = torch.tensor([[1, 1, 1, 0], [0, 1, -1, 0], [0, 1, 1, -1]], dtype=torch.float32)
+
+
+def winograd3x3_wgrad_reflect(g, h):
+    """g (B, Co, H, W) upstream gradient of conv2d(reflect_pad(h, 1), w), h (B, Ci, H, W) -> dL/dw as (Co, Ci, 3, 3); fp32."""
+    dy = g.unfold(2, 2, 2).unfold(3, 2, 2)                                          # (B, Co, H/2, W/2, 2, 2)
+    d = F.pad(h, (1, 1, 1, 1), mode="reflect").unfold(2, 4, 2).unfold(3, 4, 2)      # (B, Ci, H/2, W/2, 4, 4)
+    Gy = torch.einsum("xa,noijab,yb->noijxy", G32, dy, G32)
+    V = torch.einsum("xa,ncijab,yb->ncijxy", BT, d, BT)
+    M = torch.einsum("noijxy,ncijxy->ocxy", Gy, V)                                  # summed over samples and tiles
+    return torch.einsum("px,ocxy,qy->ocpq", AT32, M, AT32)
