@@ -389,7 +389,7 @@ def main():
                 secondary_small_batch("cifar10", dev, 256, cpu=False),     # its CPU baseline is the headline's (batch 256)
                 secondary_small_batch("mnist", dev, 64, cpu),
                 secondary_training("cifar10", dev, 16384, 10, graph=False),
-                secondary_training("cifar10", dev, 16384, 10, graph=True),
+                secondary_training("cifar10", dev, 8192, 20, graph=True),
                 secondary_training("cifar10", dev, 256, 50, graph=True),
             ]
         print(json.dumps(out))

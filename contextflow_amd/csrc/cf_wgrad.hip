@@ -14,6 +14,8 @@
 // plain coalesced stores and a small second kernel sums the partials in a fixed order (no float atomics: the
 // outputs are tiny and shared by every workgroup, and the result stays bitwise reproducible).  Output layout
 // [t][m][n]; the caller permutes to the reference's [m][n][kh][kw].
+// The 3x3 runs in the Winograd form F(3x3, 2x2) (further down: 16 MFMAs per 8 pixels instead of 36) unless
+// CONTEXTFLOW_DIRECT_CONV=1; the direct 3x3 path stays as the second implementation the tests compare it with.
 #include "cf_common.h"
 #include <cstdlib>
 
@@ -214,9 +216,16 @@ __device__ __forceinline__ void ww_row_steps(f32x16 (&acc)[16], WwRaw& raw, cons
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (XS + 1 < W / 4) ww_load<W, SA, SB, XS + 1>(raw, ldsb, cur);
         else ww_load<W, SA, SB, 0>(raw, ldsb, nxt);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 16; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[p], bt[p], acc[p], 0, 0, 0);
+        // with one wave per SIMD every instruction costs an issue slot of the wave: the LDS reads go into the shadow of
+        // the MFMAs (an MFMA occupies the pipe for 64 cycles; LDS / scalar instructions issue next to it)
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        // 2 DS reads
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
         __builtin_amdgcn_sched_barrier(0);
         ww_row_steps<W, SA, SB, XS + 1>(acc, raw, ldsb, cur, nxt, bsum);
     }
@@ -507,9 +516,10 @@ int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float
 }
 
 // the 3x3 takes the Winograd form unless CONTEXTFLOW_DIRECT_CONV=1 (same switch as the step kernels)
+static thread_local int g_wgrad_form = -1;            // test hook (cf_wgrad_form): 0 direct, 1 Winograd, -1 environment
 static bool wgrad_direct_only() {
     static const bool v = [] { const char* e = getenv("CONTEXTFLOW_DIRECT_CONV"); return e && e[0] == '1'; }();
-    return v;
+    return g_wgrad_form < 0 ? v : g_wgrad_form == 0;
 }
 
 template <int H, int W, int TAPS, int NT>
@@ -554,6 +564,15 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
+}
+
+// test hook (not part of the public header): cf_wgrad with the form of the 3x3 chosen by the caller (0 direct, 1 Winograd)
+int cf_wgrad_form(const float* A, const float* Bm, float* gw, float* gbias, void* ws, int B, int MR, int NR, int H, int W,
+                  int taps, int form, cf_stream_t stream) {
+    g_wgrad_form = form ? 1 : 0;
+    const int rc = cf_wgrad(A, Bm, gw, gbias, ws, B, MR, NR, H, W, taps, stream);
+    g_wgrad_form = -1;
+    return rc;
 }
 
 }  // extern "C"

@@ -974,6 +974,37 @@ def test_wgrad_gemm_against_torch(L, H, MR, NR, taps, B):
     assert (gb.cpu().double() - bias.grad).abs().max().item() < 1e-4 * bias.grad.abs().max().item() + 1e-4
 
 
+@pytest.mark.parametrize("H,MR,NR,B", [(16, 32, 32, 300), (16, 20, 24, 7), (8, 64, 64, 777), (8, 48, 40, 5), (4, 128, 128, 2050),
+                                         (4, 72, 100, 9), (4, 128, 128, 3)])
+def test_wgrad_3x3_winograd_form_equals_the_direct_form(L, H, MR, NR, B):
+    """The two implementations of the 3x3 weight gradient - k_wgrad's direct form (nine taps) and its Winograd form
+    F(3x3,2x2) - on the same planes: each within 2e-6 of the fp64 result's largest entry, bias sums equal to 1e-6 relative;
+    batches that give every workgroup several chunks, ragged row / column tiles, sample counts that leave the last
+    4x4 chunk (4 samples) partly empty."""
+    import ctypes
+    from contextflow_amd.layers import _hip
+    lib = _hip.lib()
+    fn = lib.cf_wgrad_form
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
+    g = torch.Generator().manual_seed(H * 7 + MR + NR + B)
+    A = torch.randn(B, MR, H * H, generator=g).to(DEV)
+    Bm = torch.relu(torch.randn(B, NR, H * H, generator=g)).to(DEV)
+    pad = torch.nn.functional.pad(Bm.double().view(B, NR, H, H), (1, 1, 1, 1), mode="reflect").unfold(2, H, 1).unfold(3, H, 1)
+    ref = torch.einsum("nmyx,nkabyx->abmk", A.double().view(B, MR, H, H), pad).reshape(9, MR, NR)
+    refb = A.double().sum((0, 2))
+    ws = torch.empty(lib.cf_wgrad_ws_bytes(B, MR, NR, H, H, 9), device=DEV, dtype=torch.uint8)
+    out = []
+    for form in (0, 1):
+        gw = torch.full((9, MR, NR), float("nan"), device=DEV)
+        gb = torch.full((MR,), float("nan"), device=DEV)
+        _hip.check(fn(_hip.p(A), _hip.p(Bm), _hip.p(gw), _hip.p(gb), _hip.p(ws), B, MR, NR, H, H, 9, form, _hip.stream()), "cf_wgrad_form")
+        assert (gw.double() - ref).abs().max().item() < 2e-6 * ref.abs().max().item(), form
+        assert (gb.double() - refb).abs().max().item() < 1e-6 * refb.abs().max().item() + 1e-4, form
+        out.append(gw)
+    assert (out[0] - out[1]).abs().max().item() < 2e-6 * ref.abs().max().item()
+
+
 def test_layer_backward_kernels_against_torch(L):
     """cf_layernorm_bwd / cf_attention_bwd / cf_gelu / cf_coupling_apply_bwd / cf_channel_sums against torch.autograd
     in fp64 (ragged row counts, the SMAP ViT geometry: dim 52, 4 tokens, head 64)."""

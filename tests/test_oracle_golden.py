@@ -269,6 +269,22 @@ def test_winograd_form_of_the_3x3_against_the_direct_convolution():
         assert e_wino <= 3.0 * e_direct + 1e-7, (C, H, e_wino, e_direct)
 
 
+def test_winograd_form_of_the_3x3_weight_gradient_against_autograd():
+    """The F(3x3,2x2) restatement of the weight gradient (oracle/winograd.py = what k_wgrad<..., WINO> computes) against
+    torch.autograd through the fp64 reflect-padded convolution: <= 2e-6 of the largest entry, at the three image sizes of
+    the cifar10 flow (reflect borders on every tile at 4x4) and with an odd batch."""
+    from oracle.winograd import winograd3x3_wgrad_reflect
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(11)
+    for (B, Co, Ci, H) in [(3, 8, 6, 16), (5, 16, 16, 8), (7, 12, 20, 4)]:
+        gy = torch.randn(B, Co, H, H, generator=g)
+        h = torch.randn(B, Ci, H, H, generator=g)
+        w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(F.pad(h.double(), (1, 1, 1, 1), mode="reflect"), w) * gy.double()).sum().backward()
+        got = winograd3x3_wgrad_reflect(gy, h)
+        assert (got.double() - w.grad).abs().max().item() < 2e-6 * w.grad.abs().max().item()
+
+
 @pytest.mark.parametrize("name,tag", [("cifar10", None), ("mnist", "stress"), ("cifar10", "extreme")])
 def test_e2e_with_the_winograd_form_keeps_the_bits_per_dim(name, tag, monkeypatch):
     """The whole flow with every coupling net's 3x3 in Winograd form (fp32) against the reference's outputs: the bar of the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Kernel-only timing of cf_wgrad (3x3) per level of the cifar10 flow + error against fp64 torch.  usage: wgrad_bench.py [B] [iters]"""
+"""Kernel-only timing of cf_wgrad (3x3) per level of the cifar10 flow + error against fp64 torch.  usage: wgrad3x3_bench.py [B] [iters]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from contextflow_amd.layers import _hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
