@@ -231,7 +231,10 @@ def secondary_training(name, dev, B, iters, graph):
     gt = torch.randint(0, M, (B,), device=dev)
     inv = 1.0 / DIMS[name]
     loss_fn = lambda logp, y: torch.nn.functional.cross_entropy(logp * inv, y)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=graph)
+    # the reference's optimizer (model.py:289: AdamW(params, lr)); under capture its fused implementation: ONE multi-tensor
+    # kernel per step (the foreach form falls back to two launches per parameter on the 0-dim step tensors of capturable mode)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True) if graph and os.environ.get("CF_BENCH_FOREACH_ADAMW") != "1" \
+        else torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=graph)
     if graph:
         step = model.capture_train_step(x, loss_fn, opt)
         run = lambda: step(x, gt)

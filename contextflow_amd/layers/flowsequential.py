@@ -596,7 +596,10 @@ class GraphedTrainStep:
         self.warmup = warmup
 
     def _step(self):
-        self.opt.zero_grad(set_to_none=False)
+        # grads start as None: the autograd engine then TAKES the gradient buffers the backward returns (allocated from
+        # the graph's private pool during capture, so their addresses are the ones every replay writes and the
+        # optimizer's captured kernels read) instead of a fill + an accumulate launch per parameter
+        self.opt.zero_grad(set_to_none=True)
         logp = self.flow.log_prob(self.static_in)
         loss = self.loss_fn(logp, *self.static_args)
         loss.backward()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Eager training steps of the cifar10 flow for `rocprofv3 --kernel-trace` (then: train_trace.py --summarize DIR).
-usage: train_trace.py [B] [steps]   |   train_trace.py --summarize DIR"""
+usage: train_trace.py [B] [steps] [graph]   |   train_trace.py --summarize DIR"""
 import csv, glob, os, sys
 if len(sys.argv) > 2 and sys.argv[1] == "--summarize":
     f = glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True)[0]
@@ -27,5 +27,5 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch, bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-r = bench.secondary_training("cifar10", torch.device("cuda:0"), B, steps, False)
+r = bench.secondary_training("cifar10", torch.device("cuda:0"), B, steps, len(sys.argv) > 3 and sys.argv[3] == "graph")
 print(r["value"], r["ms_per_step"])
