@@ -486,6 +486,38 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
+// the same sum for up to four problems in one launch (blockIdx.y = problem): the four weight gradients of a flow step
+struct WgReduce4 { const float* part[4]; float* out0[4]; float* out1[4]; int n0[4], n[4], S[4]; };
+__global__ __launch_bounds__(256) void k_wgrad_reduce4(WgReduce4 d) {
+    __shared__ float red[4][64];
+    const int q = blockIdx.y;
+    const float* __restrict__ part = d.part[q];
+    const int n = d.n[q], n0 = d.n0[q], S = d.S[q];
+    if ((int)blockIdx.x * 64 >= n) return;            // uniform per block
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        int i = w;
+        for (; i + 12 < S; i += 16) {
+            s0 += part[(int64_t)i * n + e]; s1 += part[(int64_t)(i + 4) * n + e];
+            s2 += part[(int64_t)(i + 8) * n + e]; s3 += part[(int64_t)(i + 12) * n + e];
+        }
+        for (; i < S; i += 4) s0 += part[(int64_t)i * n + e];
+    }
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0 && e < n) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (e < n0) d.out0[q][e] = v;
+        else if (d.out1[q] != nullptr) d.out1[q][e - n0] = v;
+    }
+}
+
+// cf_step_wgrads: the k_wgrad launches leave their partials in place and report their split count; one reduce follows
+static thread_local bool g_wgrad_defer = false;
+static thread_local int g_wgrad_last_S = 0;
+
 // wgs = workgroups to aim for: 512 (two per CU in flight) for the direct forms; the Winograd form runs one workgroup per
 // CU (512 registers per lane), so 256 - one round, one epilogue per CU
 inline int wgrad_splits(int B, int MR, int HW, int wgs = 512) {
@@ -511,7 +543,8 @@ int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float
     const int S = splits, nw = TAPS * MR * NR;
     // partials: [S][TAPS*MR*NR + MR] (weights | bias of one split contiguous: ONE reduce launch)
     k_wgrad<H, W, TAPS, NT, WINO><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, ws, B, MR, NR);
-    k_wgrad_reduce<<<dim3((nw + MR + 63) / 64), dim3(256), 0, s>>>(ws, gw, gbias, nw, nw + MR, S);
+    g_wgrad_last_S = S;
+    if (!g_wgrad_defer) k_wgrad_reduce<<<dim3((nw + MR + 63) / 64), dim3(256), 0, s>>>(ws, gw, gbias, nw, nw + MR, S);
     return 0;
 }
 
@@ -562,6 +595,46 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
     else { cf_set_error("cf_wgrad: image %dx%d unsupported", H, W); return CF_ERR_UNSUPPORTED; }
 #undef CF_W
     if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// The four weight gradients of one flow step - NN.4 (s_gh x t_h2), NN.2 (3x3: s_gh2 x t_h1), NN.0 (s_gh1 x t_y0), the
+// folded Conv1x1 / ActNorm matrix (s_gy x xs) - as four k_wgrad launches and ONE reduce launch (small batches: the step's
+// backward is a chain of launches of a few microseconds each).  Same results as four cf_wgrad calls, bit for bit.
+int64_t cf_step_wgrads_ws_bytes(int B, int C, int H, int W) {
+    const int HID = 2 * C, HALF = C / 2;
+    return cf_wgrad_ws_bytes(B, C, HID, H, W, 1) + cf_wgrad_ws_bytes(B, HID, HID, H, W, 9) +
+           cf_wgrad_ws_bytes(B, HID, HALF, H, W, 1) + cf_wgrad_ws_bytes(B, C, C, H, W, 1);
+}
+
+int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, const float* s_gy, const float* t_h2,
+                   const float* t_h1, const float* t_y0, const float* xs, float* gw3, float* gb3, float* gw2, float* gb2,
+                   float* gw1, float* gb1, float* gwp, float* gbp, void* ws, int B, int C, int H, int W, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(s_gh && s_gh2 && s_gh1 && s_gy && t_h2 && t_h1 && t_y0 && xs && gw3 && gb3 && gw2 && gb2 && gw1 && gb1 && gwp && gbp && ws);
+    CF_REQUIRE(C >= 2 && C % 2 == 0 && 2 * C <= 128);
+    const int HID = 2 * C, HALF = C / 2;
+    const float* As[4] = {s_gh, s_gh2, s_gh1, s_gy};
+    const float* Bs[4] = {t_h2, t_h1, t_y0, xs};
+    float* gws[4] = {gw3, gw2, gw1, gwp};
+    float* gbs[4] = {gb3, gb2, gb1, gbp};
+    const int MRs[4] = {C, HID, HID, C}, NRs[4] = {HID, HID, HALF, C}, tps[4] = {1, 9, 1, 1};
+    WgReduce4 d;
+    char* w = (char*)ws;
+    int nmax = 0;
+    for (int q = 0; q < 4; ++q) {
+        g_wgrad_defer = true;
+        const int rc = cf_wgrad(As[q], Bs[q], gws[q], gbs[q], w, B, MRs[q], NRs[q], H, W, tps[q], stream);
+        g_wgrad_defer = false;
+        if (rc) return rc;
+        const int nw = tps[q] * MRs[q] * NRs[q];
+        d.part[q] = (const float*)w; d.out0[q] = gws[q]; d.out1[q] = gbs[q];
+        d.n0[q] = nw; d.n[q] = nw + MRs[q]; d.S[q] = g_wgrad_last_S;
+        nmax = nw + MRs[q] > nmax ? nw + MRs[q] : nmax;
+        w += cf_wgrad_ws_bytes(B, MRs[q], NRs[q], H, W, tps[q]);
+    }
+    k_wgrad_reduce4<<<dim3((nmax + 63) / 64, 4), dim3(256), 0, cf_s(stream)>>>(d);
     CF_LAUNCH_CHECK();
     return 0;
 }

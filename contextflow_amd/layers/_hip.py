@@ -66,6 +66,8 @@ SIGNATURES = {
     "cf_step_param_grads": (_c_int, [_c_p] * 7 + [_c_int] + [_c_p] * 3 + [_c_int, _c_p]),
     "cf_wgrad_ws_bytes": (_c_i64, [_c_int] * 6),
     "cf_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),
+    "cf_step_wgrads_ws_bytes": (_c_i64, [_c_int] * 4),
+    "cf_step_wgrads": (_c_int, [_c_p] * 17 + [_c_int] * 4 + [_c_p]),
     "cf_linear_wgrad_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_linear_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_p]),
     "cf_linear_wgrad_x2": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_p]),

@@ -89,21 +89,15 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
         s_y0, s_h1, s_h2, aux = planes
         _hip.call("cf_flow_step_bwd_taped", pp(gzc), pp(f(gld)), pp(wsb), pp(aux), pp(gx), pp(s_gh), pp(s_gh2), pp(s_gh1),
                   pp(s_gy), B, C, H, W, st)
-    # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts (cf_wgrad)
-    def wgrad(A, Bm, taps):
-        """(gw (taps, MR, NR), gbias (MR,) = row sums of A)"""
-        MR, NR = A.shape[1], Bm.shape[1]
-        gw = torch.empty(taps, MR, NR, device=dev, dtype=torch.float32)
-        gb = torch.empty(MR, device=dev, dtype=torch.float32)
-        wsw = torch.empty(L.cf_wgrad_ws_bytes(B, MR, NR, H, W, taps), device=dev, dtype=torch.uint8)
-        _hip.call("cf_wgrad", pp(A), pp(Bm), pp(gw), pp(gb), pp(wsw), B, MR, NR, H, W, taps, st)
-        return gw, gb
-
-    gw3, gb3 = wgrad(s_gh, s_h2, 1)
-    gw2, gb2 = wgrad(s_gh2, s_h1, 9)
-    gw1, gb1 = wgrad(s_gh1, s_y0, 1)
+    # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts, the four of a step in one call
+    # (cf_step_wgrads: four k_wgrad launches, ONE reduce launch)
+    e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+    gw3, gb3, gw2, gb2 = e(1, C, HID), e(C), e(9, HID, HID), e(HID)
+    gw1, gb1, gWp, gbp = e(1, HID, HALF), e(HID), e(1, C, C), e(C)
     xs = squeeze_op(xv, (2, 2), False) if squeeze else xv.contiguous()
-    gWp, gbp = wgrad(s_gy, xs.reshape(B, C, HW), 1)
+    wsw = torch.empty(L.cf_step_wgrads_ws_bytes(B, C, H, W), device=dev, dtype=torch.uint8)
+    _hip.call("cf_step_wgrads", pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), pp(s_h2), pp(s_h1), pp(s_y0), pp(xs), pp(gw3), pp(gb3),
+              pp(gw2), pp(gb2), pp(gw1), pp(gb1), pp(gWp), pp(gbp), pp(wsw), B, C, H, W, st)
     gw3, gw1, gWp = gw3[0], gw1[0], gWp[0]
     gw2 = gw2.permute(1, 2, 0).reshape(HID, HID, 3, 3)
     # ---- chain to Conv1x1 / ActNorm parameters (W' = diag(s) Wm, b' = -t s, s = exp(-logs)): one small kernel

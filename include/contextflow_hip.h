@@ -231,6 +231,17 @@ int64_t cf_wgrad_ws_bytes(int B, int MR, int NR, int H, int W, int taps);
 int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws, int B, int MR, int NR, int H, int W,
              int taps, cf_stream_t stream);
 
+/* The four weight gradients of one flow step in one call (layers/autograd.py::step_backward; reference: autograd through
+ * Conv1x1 / ActNorm / Coupling.NN, coupling.py:26-28, conv1x1.py:52-57): NN.4 = s_gh x t_h2 -> gw3 (1, C, 2C), gb3 (C);
+ * NN.2 (3x3) = s_gh2 x t_h1 -> gw2 (9, 2C, 2C), gb2 (2C); NN.0 = s_gh1 x t_y0 -> gw1 (1, 2C, C/2), gb1 (2C); folded
+ * Conv1x1 / ActNorm matrix = s_gy x xs -> gwp (1, C, C), gbp (C).  Planes as written by cf_flow_step_bwd[_taped] /
+ * cf_flow_step_fwd_taped, xs = the (squeezed) step input (B, C, H*W).  Four split-K launches + ONE reduce launch; results
+ * bitwise equal to four cf_wgrad calls. */
+int64_t cf_step_wgrads_ws_bytes(int B, int C, int H, int W);
+int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, const float* s_gy, const float* t_h2,
+                   const float* t_h1, const float* t_y0, const float* xs, float* gw3, float* gb3, float* gw2, float* gb2,
+                   float* gw1, float* gb1, float* gwp, float* gbp, void* ws, int B, int C, int H, int W, cf_stream_t stream);
+
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; any K, N.
  * act: 0 none, 1 exact (erf) GELU, 2 ReLU.   nn.Linear of patch embedding / to_qkv / to_out / FeedForward; CN nets. */

@@ -1005,6 +1005,35 @@ def test_wgrad_3x3_winograd_form_equals_the_direct_form(L, H, MR, NR, B):
     assert (out[0] - out[1]).abs().max().item() < 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("C,H,B", [(16, 16, 37), (32, 8, 300), (64, 4, 1030), (8, 16, 5)])
+def test_step_wgrads_equals_four_wgrad_calls(L, C, H, B):
+    """cf_step_wgrads (four split-K launches + ONE reduce launch) against four cf_wgrad calls on the same planes:
+    bitwise equal (same partials, same summation order)."""
+    from contextflow_amd.layers import _hip
+    lib = _hip.lib()
+    HID, HALF, HW = 2 * C, C // 2, H * H
+    g = torch.Generator().manual_seed(C + H + B)
+    r = lambda rows: torch.randn(B, rows, HW, generator=g).to(DEV)
+    s_gh, s_gh2, s_gh1, s_gy, t_h2, t_h1, t_y0, xs = r(C), r(HID), r(HID), r(C), r(HID), r(HID), r(HALF), r(C)
+    probs = [(s_gh, t_h2, 1), (s_gh2, t_h1, 9), (s_gh1, t_y0, 1), (s_gy, xs, 1)]
+    ref = []
+    for A, Bm, taps in probs:
+        MR, NR = A.shape[1], Bm.shape[1]
+        gw, gb = torch.empty(taps, MR, NR, device=DEV), torch.empty(MR, device=DEV)
+        ws = torch.empty(lib.cf_wgrad_ws_bytes(B, MR, NR, H, H, taps), device=DEV, dtype=torch.uint8)
+        _hip.call("cf_wgrad", _hip.p(A), _hip.p(Bm), _hip.p(gw), _hip.p(gb), _hip.p(ws), B, MR, NR, H, H, taps, _hip.stream())
+        ref += [gw, gb]
+    out = []
+    for A, Bm, taps in probs:
+        out += [torch.full((taps, A.shape[1], Bm.shape[1]), float("nan"), device=DEV), torch.full((A.shape[1],), float("nan"), device=DEV)]
+    ws = torch.empty(lib.cf_step_wgrads_ws_bytes(B, C, H, H), device=DEV, dtype=torch.uint8)
+    P = _hip.p
+    _hip.call("cf_step_wgrads", P(s_gh), P(s_gh2), P(s_gh1), P(s_gy), P(t_h2), P(t_h1), P(t_y0), P(xs), *[P(o) for o in out], P(ws),
+              B, C, H, H, _hip.stream())
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+
+
 def test_layer_backward_kernels_against_torch(L):
     """cf_layernorm_bwd / cf_attention_bwd / cf_gelu / cf_coupling_apply_bwd / cf_channel_sums against torch.autograd
     in fp64 (ragged row counts, the SMAP ViT geometry: dim 52, 4 tokens, head 64)."""
