@@ -682,10 +682,12 @@ int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B,
     return 0;
 }
 
+static thread_local float* g_prepare_winv = nullptr;          // cf_flow_step_prepare_train: also write Wm^-1 here
+
 template <class G>
 int launch_prepare(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* w3, const float* b3, float* ws, hipStream_t s) {
-    int rc = cf_slogdet_inverse(Wm, G::C, ws + 1, nullptr, (cf_stream_t)s);
+    int rc = cf_slogdet_inverse(Wm, G::C, ws + 1, g_prepare_winv, (cf_stream_t)s);       // training: W^-1 from the same factorisation
     if (rc) return rc;
     int blocks = (G::WS_FLOATS + 255) / 256;
     if (blocks > 512) blocks = 512;
@@ -869,6 +871,17 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, con
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
+}
+
+// training: the same packing + Wm^-1 (C, C) for d log|det Wm| / d Wm = Wm^-T, from the ONE factorisation of the prepare step
+int cf_flow_step_prepare_train(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
+                               const float* w2, const float* b2, const float* w3, const float* b3, void* ws, float* winv,
+                               int C, int H, int W, cf_stream_t stream) {
+    CF_REQUIRE(winv);
+    g_prepare_winv = winv;
+    const int rc = cf_flow_step_prepare(Wm, t, logs, w1, b1, w2, b2, w3, b3, ws, C, H, W, stream);
+    g_prepare_winv = nullptr;
+    return rc;
 }
 
 int64_t cf_flow_step_inv_ws_bytes(int C, int H, int W) {

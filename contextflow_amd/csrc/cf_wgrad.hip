@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 // the same sum for up to four problems in one launch (blockIdx.y = problem): the four weight gradients of a flow step
-struct WgReduce4 { const float* part[4]; float* out0[4]; float* out1[4]; int n0[4], n[4], S[4]; };
+struct WgReduce4 { const float* part[4]; float* out0[4]; float* out1[4]; int n0[4], n[4], S[4], taps[4]; };   // taps > 1: out0 as [m][n][tap]
 __global__ __launch_bounds__(256) void k_wgrad_reduce4(WgReduce4 d) {
     __shared__ float red[4][64];
     const int q = blockIdx.y;
@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4(WgReduce4 d) {
     __syncthreads();
     if (w == 0 && e < n) {
         const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        if (e < n0) d.out0[q][e] = v;
+        const int tp = d.taps[q], mn = n0 / tp;       // partials are [tap][m][n]; the 3x3 leaves as the reference's [m][n][kh][kw]
+        if (e < n0) d.out0[q][tp > 1 ? (e % mn) * tp + e / mn : e] = v;
         else if (d.out1[q] != nullptr) d.out1[q][e - n0] = v;
     }
 }
@@ -601,7 +602,8 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
 
 // The four weight gradients of one flow step - NN.4 (s_gh x t_h2), NN.2 (3x3: s_gh2 x t_h1), NN.0 (s_gh1 x t_y0), the
 // folded Conv1x1 / ActNorm matrix (s_gy x xs) - as four k_wgrad launches and ONE reduce launch (small batches: the step's
-// backward is a chain of launches of a few microseconds each).  Same results as four cf_wgrad calls, bit for bit.
+// backward is a chain of launches of a few microseconds each).  Same results as four cf_wgrad calls, bit for bit; gw2
+// leaves in the reference's layout (2C, 2C, 3, 3) - no permute launch behind it.
 int64_t cf_step_wgrads_ws_bytes(int B, int C, int H, int W) {
     const int HID = 2 * C, HALF = C / 2;
     return cf_wgrad_ws_bytes(B, C, HID, H, W, 1) + cf_wgrad_ws_bytes(B, HID, HID, H, W, 9) +
@@ -630,7 +632,7 @@ int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, co
         if (rc) return rc;
         const int nw = tps[q] * MRs[q] * NRs[q];
         d.part[q] = (const float*)w; d.out0[q] = gws[q]; d.out1[q] = gbs[q];
-        d.n0[q] = nw; d.n[q] = nw + MRs[q]; d.S[q] = g_wgrad_last_S;
+        d.n0[q] = nw; d.n[q] = nw + MRs[q]; d.S[q] = g_wgrad_last_S; d.taps[q] = tps[q];
         nmax = nw + MRs[q] > nmax ? nw + MRs[q] : nmax;
         w += cf_wgrad_ws_bytes(B, MRs[q], NRs[q], H, W, tps[q]);
     }

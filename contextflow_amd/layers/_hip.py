@@ -47,6 +47,7 @@ SIGNATURES = {
     "cf_flow_step_supported": (_c_int, [_c_int] * 5),
     "cf_flow_step_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_prepare": (_c_int, [_c_p] * 10 + [_c_int] * 3 + [_c_p]),
+    "cf_flow_step_prepare_train": (_c_int, [_c_p] * 11 + [_c_int] * 3 + [_c_p]),
     "cf_flow_step_fwd": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_flow_step_inv_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_inv_prepare": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_p]),

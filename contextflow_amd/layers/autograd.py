@@ -92,14 +92,13 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts, the four of a step in one call
     # (cf_step_wgrads: four k_wgrad launches, ONE reduce launch)
     e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
-    gw3, gb3, gw2, gb2 = e(1, C, HID), e(C), e(9, HID, HID), e(HID)
+    gw3, gb3, gw2, gb2 = e(1, C, HID), e(C), e(HID, HID, 3, 3), e(HID)
     gw1, gb1, gWp, gbp = e(1, HID, HALF), e(HID), e(1, C, C), e(C)
     xs = squeeze_op(xv, (2, 2), False) if squeeze else xv.contiguous()
     wsw = torch.empty(L.cf_step_wgrads_ws_bytes(B, C, H, W), device=dev, dtype=torch.uint8)
     _hip.call("cf_step_wgrads", pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), pp(s_h2), pp(s_h1), pp(s_y0), pp(xs), pp(gw3), pp(gb3),
               pp(gw2), pp(gb2), pp(gw1), pp(gb1), pp(gWp), pp(gbp), pp(wsw), B, C, H, W, st)
     gw3, gw1, gWp = gw3[0], gw1[0], gWp[0]
-    gw2 = gw2.permute(1, 2, 0).reshape(HID, HID, 3, 3)
     # ---- chain to Conv1x1 / ActNorm parameters (W' = diag(s) Wm, b' = -t s, s = exp(-logs)): one small kernel
     if gsum is None:
         gsum = gld.sum().reshape(1)

@@ -236,14 +236,19 @@ class FlowSequential(nn.Module):
         return s
 
     @staticmethod
-    def _prepare_step(conv, act, cpl, shape, dev):
+    def _prepare_step(conv, act, cpl, shape, dev, winv=None):
+        """Packed weight tables of a flow step; winv (C, C): also Wm^-1 from the same factorisation (training)."""
         C, H, W = shape
         ws = torch.empty(_hip.lib().cf_flow_step_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
         f, pp = _hip.f32, _hip.p
         c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
-        _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
-                  pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
-                  pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, _hip.stream())
+        args = (pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
+                pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
+                pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws))
+        if winv is None:
+            _hip.call("cf_flow_step_prepare", *args, C, H, W, _hip.stream())
+        else:
+            _hip.call("cf_flow_step_prepare_train", *args, pp(winv), C, H, W, _hip.stream())
         return ws
 
     def _forward_fused(self, x, context, tape=None):
@@ -285,13 +290,12 @@ class FlowSequential(nn.Module):
             with torch.cuda.stream(side):
                 for k, op, ver in todo:
                     if op[0] == "step":
-                        buf = self._prepare_step(op[1], op[2], op[3], op[4], dev)
-                        if tape is not None:     # training: W^-1 for d(log|det W|)/dW, off the critical path
+                        if tape is not None:     # training: W^-1 for d(log|det W|)/dW from the prepare step's factorisation
                             Cc = op[4][0]
                             winv = torch.empty(Cc, Cc, device=dev, dtype=torch.float32)
-                            lad = torch.empty(1, device=dev, dtype=torch.float32)
-                            _hip.call("cf_slogdet_inverse", _hip.p(_hip.f32(op[1].NN.detach())), Cc, _hip.p(lad), _hip.p(winv), _hip.stream())
-                            buf = (buf, winv)
+                            buf = (self._prepare_step(op[1], op[2], op[3], op[4], dev, winv), winv)
+                        else:
+                            buf = self._prepare_step(op[1], op[2], op[3], op[4], dev)
                     elif op[0] == "vstep":
                         buf = op[3].step_prepare(op[1].NN, op[2].NN_t, op[2].NN_logs, dev)
                     else:

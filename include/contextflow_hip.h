@@ -157,6 +157,11 @@ int64_t cf_flow_step_ws_bytes(int C, int H, int W);
 int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs,
                          const float* w1, const float* b1, const float* w2, const float* b2,
                          const float* w3, const float* b3, void* ws, int C, int H, int W, cf_stream_t stream);
+/* training form: the same packing, and Wm^-1 (C, C; the gradient of log|det Wm| is Wm^-T, conv1x1.py:52-57) from the one
+ * factorisation the prepare step runs anyway */
+int cf_flow_step_prepare_train(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
+                               const float* w2, const float* b2, const float* w3, const float* b3, void* ws, float* winv,
+                               int C, int H, int W, cf_stream_t stream);
 /* z = step(x); ldj_acc[b] += ldj_const + sum log_s   (ldj_acc is the running per-sample log-det).
  * in_squeeze != 0: x is the UN-squeezed (B, C/4, 2H, 2W) tensor and Squeeze((2,2)) (squeeze.py:10-11)
  * is folded into the kernel's operand addressing (no separate index kernel, no extra HBM pass).
@@ -233,7 +238,7 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
 
 /* The four weight gradients of one flow step in one call (layers/autograd.py::step_backward; reference: autograd through
  * Conv1x1 / ActNorm / Coupling.NN, coupling.py:26-28, conv1x1.py:52-57): NN.4 = s_gh x t_h2 -> gw3 (1, C, 2C), gb3 (C);
- * NN.2 (3x3) = s_gh2 x t_h1 -> gw2 (9, 2C, 2C), gb2 (2C); NN.0 = s_gh1 x t_y0 -> gw1 (1, 2C, C/2), gb1 (2C); folded
+ * NN.2 (3x3) = s_gh2 x t_h1 -> gw2 (2C, 2C, 3, 3: the reference's weight layout), gb2 (2C); NN.0 = s_gh1 x t_y0 -> gw1 (1, 2C, C/2), gb1 (2C); folded
  * Conv1x1 / ActNorm matrix = s_gy x xs -> gwp (1, C, C), gbp (C).  Planes as written by cf_flow_step_bwd[_taped] /
  * cf_flow_step_fwd_taped, xs = the (squeezed) step input (B, C, H*W).  Four split-K launches + ONE reduce launch; results
  * bitwise equal to four cf_wgrad calls. */
