@@ -129,8 +129,12 @@ constexpr int WG_LS = WG_MAXF * 32;   // LDS row stride (floats): 48 KiB per wor
 // (second-moment sums of the mixture backward).
 template <int TPW, bool XSQ = false>
 __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
-                                                      float* __restrict__ part, int rows, int K, int N, int NT, int KT, int ybase,
-                                                      int64_t ldx, int64_t ldy) {
+                                                      float* __restrict__ part, int rows, int Ktot, int N, int NT, int kbs, int ybase,
+                                                      int64_t ldx, int64_t ldy, int64_t zstride) {
+    // blockIdx.z = column block of a wide x (kbs columns each; small batches run all blocks in one launch)
+    const int K = min(kbs, Ktot - (int)blockIdx.z * kbs), KT = (K + 1 + 31) / 32;
+    x += (int64_t)blockIdx.z * kbs;
+    part += (int64_t)blockIdx.z * zstride;
     // one LDS row = the 32-feature blocks [gy (NT) | x, 1, 0.. (KT)] of one activation row at the FIXED stride WG_LS: the
     // operand reads of the MFMA loop are then base register + immediate offset (no address arithmetic between MFMAs)
     __shared__ float lds[WG_RC * WG_LS];
@@ -219,12 +223,17 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
 // 64 output elements per workgroup, the G partials split over the 4 waves (every 4th partial each), then summed across
 // the waves in a fixed order
 __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gW,
-                                                             float* __restrict__ gb, int K, int N, int KT, int ntiles, int G,
-                                                             int64_t ldw) {
+                                                             float* __restrict__ gb, int Ktot, int N, int kbs, int NT, int G,
+                                                             int64_t ldw, int64_t zstride) {
     __shared__ float red[4][64];
+    const int z = blockIdx.y;                             // column block of x, as in k_linear_wgrad
+    const int K = min(kbs, Ktot - z * kbs), KT = (K + 1 + 31) / 32, ntiles = NT * KT;
+    if ((int)blockIdx.x * 64 >= ntiles * 1024) return;    // uniform: the last block may have fewer tiles
+    gW += (int64_t)z * kbs;
+    if (z != 0) gb = nullptr;                             // the bias column rides with the first block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;                 // element of the padded tile storage
-    const float* p = part + e;
+    const float* p = part + (int64_t)z * zstride + e;
     float s0 = 0.f, s1 = 0.f;
     int g = wave;
     for (; g + 4 < G; g += 8) { s0 += p[(int64_t)g * ntiles * 1024]; s1 += p[(int64_t)(g + 4) * ntiles * 1024]; }
@@ -444,11 +453,18 @@ static void wgrad_blocks(int K, int N, int& nbs, int& kbs) {
     if (kbs > K) kbs = K;
 }
 
+// column blocks of x that share one launch (blockIdx.z): all of them while the grid stays small (small batches, where a
+// launch costs more than its kernel), else one launch pair per block (the partials of one block at a time)
+static int wgrad_zblocks(int G, int K, int kbs) {
+    const int nkb = (K + kbs - 1) / kbs;
+    return G * nkb <= 512 ? nkb : 1;
+}
+
 int64_t cf_linear_wgrad_ws_bytes(int rows, int K, int N) {
     int nbs, kbs;
     wgrad_blocks(K, N, nbs, kbs);
-    const int NT = (nbs + 31) / 32, KT = (kbs + 1 + 31) / 32;
-    return (int64_t)linear_wgrad_groups(rows) * NT * KT * 1024 * sizeof(float);
+    const int NT = (nbs + 31) / 32, KT = (kbs + 1 + 31) / 32, G = linear_wgrad_groups(rows);
+    return (int64_t)G * NT * KT * 1024 * sizeof(float) * wgrad_zblocks(G, K, kbs);
 }
 
 static int linear_wgrad_any(const float* x, const float* gy, float* gW, float* gb, void* ws, int rows, int K, int N,
@@ -457,22 +473,26 @@ static int linear_wgrad_any(const float* x, const float* gy, float* gW, float* g
     int nbs, kbs;
     wgrad_blocks(K, N, nbs, kbs);
     const int G = linear_wgrad_groups(rows);
+    const int ZB = wgrad_zblocks(G, K, kbs);              // column blocks per launch: all, or 1
     float* part = (float*)ws;
     hipStream_t st = cf_s(stream);
     for (int n0 = 0; n0 < N; n0 += nbs)
-        for (int k0 = 0; k0 < K; k0 += kbs) {
-            const int Nc = N - n0 < nbs ? N - n0 : nbs, Kc = K - k0 < kbs ? K - k0 : kbs;
-            const int NT = (Nc + 31) / 32, KT = (Kc + 1 + 31) / 32, ntiles = NT * KT;
+        for (int k0 = 0; k0 < K; k0 += kbs * ZB) {
+            const int Nc = N - n0 < nbs ? N - n0 : nbs, Krem = K - k0, Kc = Krem < kbs ? Krem : kbs;
+            const int nz = ZB > 1 ? (Krem + kbs - 1) / kbs : 1;
+            const int Kl = ZB > 1 ? Krem : Kc;            // columns this launch covers
+            const int NT = (Nc + 31) / 32, KT = (Kc + 1 + 31) / 32, ntiles = NT * KT;       // of the widest (first) block
+            const int64_t zs = (int64_t)G * ntiles * 1024;
             const float* xp = x + k0;
             const float* gp = gy + n0;
             // full blocks of 4 WG_TPW tiles, then the remainder with exactly as many tile slots per wave as it needs
             const int full = ntiles / (4 * WG_TPW), rem = ntiles - full * 4 * WG_TPW;
             if (full > 0) {
-                if (xsq) k_linear_wgrad<WG_TPW, true><<<dim3(G, full), dim3(256), 0, st>>>(xp, gp, part, rows, Kc, Nc, NT, KT, 0, K, N);
-                else k_linear_wgrad<WG_TPW, false><<<dim3(G, full), dim3(256), 0, st>>>(xp, gp, part, rows, Kc, Nc, NT, KT, 0, K, N);
+                if (xsq) k_linear_wgrad<WG_TPW, true><<<dim3(G, full, nz), dim3(256), 0, st>>>(xp, gp, part, rows, Kl, Nc, NT, kbs, 0, K, N, zs);
+                else k_linear_wgrad<WG_TPW, false><<<dim3(G, full, nz), dim3(256), 0, st>>>(xp, gp, part, rows, Kl, Nc, NT, kbs, 0, K, N, zs);
             }
-#define CF_WG_TAIL(T) do { if (xsq) k_linear_wgrad<T, true><<<dim3(G), dim3(256), 0, st>>>(xp, gp, part, rows, Kc, Nc, NT, KT, full, K, N); \
-                           else k_linear_wgrad<T, false><<<dim3(G), dim3(256), 0, st>>>(xp, gp, part, rows, Kc, Nc, NT, KT, full, K, N); } while (0)
+#define CF_WG_TAIL(T) do { if (xsq) k_linear_wgrad<T, true><<<dim3(G, 1, nz), dim3(256), 0, st>>>(xp, gp, part, rows, Kl, Nc, NT, kbs, full, K, N, zs); \
+                           else k_linear_wgrad<T, false><<<dim3(G, 1, nz), dim3(256), 0, st>>>(xp, gp, part, rows, Kl, Nc, NT, kbs, full, K, N, zs); } while (0)
             switch ((rem + 3) / 4) {
                 case 0: break;
                 case 1: CF_WG_TAIL(1); break;
@@ -486,8 +506,8 @@ static int linear_wgrad_any(const float* x, const float* gy, float* gW, float* g
             }
 #undef CF_WG_TAIL
             // the bias gradient (column sums of gy) rides along with the first x block only
-            k_linear_wgrad_reduce<<<dim3(ntiles * 16), dim3(256), 0, st>>>(part, gW + (int64_t)n0 * K + k0, (gb && k0 == 0) ? gb + n0 : nullptr,
-                                                                         Kc, Nc, KT, ntiles, G, K);
+            k_linear_wgrad_reduce<<<dim3(ntiles * 16, nz), dim3(256), 0, st>>>(part, gW + (int64_t)n0 * K + k0, (gb && k0 == 0) ? gb + n0 : nullptr,
+                                                                             Kl, Nc, kbs, NT, G, K, zs);
         }
     CF_LAUNCH_CHECK();
     return 0;
