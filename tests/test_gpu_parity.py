@@ -1035,6 +1035,28 @@ def test_step_wgrads_equals_four_wgrad_calls(L, C, H, B):
         assert torch.equal(a.reshape(-1), b.reshape(-1))
 
 
+@pytest.mark.parametrize("C,H", [(16, 16), (32, 8), (64, 4)])
+def test_prepare_train_equals_prepare_plus_inverse(L, C, H):
+    """cf_flow_step_prepare_train: the packed tables are bitwise those of cf_flow_step_prepare, and the W^-1 it writes from
+    the same factorisation is the inverse (against fp64 torch; what d log|det W| / dW = W^-T needs)."""
+    from contextflow_amd.layers import _hip
+    lib, P = _hip.lib(), _hip.p
+    g = torch.Generator().manual_seed(C)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.2).to(DEV)
+    HID, HALF = 2 * C, C // 2
+    Wm = (torch.linalg.qr(torch.randn(C, C, generator=g))[0] + 0.05 * torch.randn(C, C, generator=g)).contiguous().to(DEV)
+    args = [Wm, r(C), r(C), r(HID, HALF), r(HID), r(HID, HID, 3, 3), r(HID), r(C, HID), r(C)]
+    n = lib.cf_flow_step_ws_bytes(C, H, H)
+    ws0 = torch.zeros(n, device=DEV, dtype=torch.uint8)
+    ws1 = torch.zeros(n, device=DEV, dtype=torch.uint8)
+    winv = torch.empty(C, C, device=DEV)
+    _hip.call("cf_flow_step_prepare", *[P(a) for a in args], P(ws0), C, H, H, _hip.stream())
+    _hip.call("cf_flow_step_prepare_train", *[P(a) for a in args], P(ws1), P(winv), C, H, H, _hip.stream())
+    assert torch.equal(ws0, ws1)
+    ref = torch.linalg.inv(Wm.double().cpu())
+    assert (winv.double().cpu() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+
+
 def test_layer_backward_kernels_against_torch(L):
     """cf_layernorm_bwd / cf_attention_bwd / cf_gelu / cf_coupling_apply_bwd / cf_channel_sums against torch.autograd
     in fp64 (ragged row counts, the SMAP ViT geometry: dim 52, 4 tokens, head 64)."""
