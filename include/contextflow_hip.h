@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 2
+#define CF_ABI_VERSION 3
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
