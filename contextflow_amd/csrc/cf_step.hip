@@ -519,10 +519,12 @@ int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int
 // (row tile, pixel tile) pair, in phase 3 the two halves of K go to two waves whose partial sums meet in the epilogue.
 // 4x the workgroups, a quarter of the serial MFMA chain per workgroup; the planes are exchanged through LDS with a
 // workgroup barrier per phase.  Same packed workspace as k_flow_step.  Used below ~2 workgroups per CU (cf_flow_step_fwd).
-template <class G, int NPT, bool SQ>
+// DUMP (training at small batches): the tape of cf_flow_step_fwd_taped - y0 / h1 / h2 planes, log-scale and y1, the ReLU
+// mask words of this wave's (row tile, pixel tile) pairs, in the layout k_flow_step writes.
+template <class G, int NPT, bool SQ, bool DUMP = false>
 __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ x, float* __restrict__ z,
                                                       float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                      int64_t xbs) {
+                                                      int64_t xbs, StepTape tp = kNoTape) {
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, HALF = G::HALF, HID = G::HID, HP = G::HP;
     constexpr int PIXR = 32 * NPT, SPWR = PIXR / HW, RT1 = G::RT1, RT03 = G::RT03;
     static_assert(RT1 * NPT == 4 && RT03 * NPT == 2 && HP == HALF && PIXR % HW == 0, "row-split geometry");
@@ -566,9 +568,27 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < HALF * PIXR / 256; ++i) {
         const int e = tid + 256 * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
-        if (b0 + sm < B) z[(int64_t)(b0 + sm) * C * HW + ch * HW + pp] = Y[e];
+        if (b0 + sm < B) {
+            z[(int64_t)(b0 + sm) * C * HW + ch * HW + pp] = Y[e];
+            if constexpr (DUMP) tp.y0[((int64_t)(b0 + sm) * HALF + ch) * HW + pp] = Y[e];
+        }
     }
     const int rt1 = wave % RT1, q1 = wave / RT1, col1 = q1 * 32 + li;          // this wave's pair in phases 1, 2
+    // tape helpers: the mask word of this wave's accumulator tile (global 32-column tile = blockIdx NPT + q1), and a
+    // cooperative copy of the [HID][PIXR] plane in LDS to its (B, HID, HW) place
+    auto mask_word = [&](unsigned* __restrict__ m, const f32x16& a) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= (a[r] > 0.f ? 1u : 0u) << r;
+        m[((int64_t)(blockIdx.x * NPT + q1) * RT1 + rt1) * 64 + lane] = bits;
+    };
+    auto plane_dump = [&](float* __restrict__ dst) {
+#pragma unroll
+        for (int i = 0; i < HID * PIXR / 256; ++i) {
+            const int e = tid + 256 * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
+            if (b0 + sm < B) dst[((int64_t)(b0 + sm) * HID + ch) * HW + pp] = H1[e];
+        }
+    };
     // ---- phase 1: h1 = relu(NN.0 y0 + b)
     {
         f32x16 acc = bias_tile(ws + G::OFF_B1 + rt1 * 32, lk);
@@ -582,8 +602,10 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) H1[(rt1 * 32 + tile_row(r, lk)) * PIXR + col1] = cf_relu(acc[r]);
+        if constexpr (DUMP) mask_word(tp.m1, acc);
     }
     __syncthreads();
+    if constexpr (DUMP) plane_dump(tp.h1);
     // ---- phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3 reflect: K = 9 taps x HID channels, fragments one group ahead
     f32x16 acc2 = bias_tile(ws + G::OFF_B2 + rt1 * 32, lk);
     {
@@ -628,7 +650,9 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
     __syncthreads();                 // every wave has finished reading h1
 #pragma unroll
     for (int r = 0; r < 16; ++r) H1[(rt1 * 32 + tile_row(r, lk)) * PIXR + col1] = cf_relu(acc2[r]);
+    if constexpr (DUMP) mask_word(tp.m2, acc2);
     __syncthreads();
+    if constexpr (DUMP) plane_dump(tp.h2);
     // ---- phase 3: [t | raw] = NN.4 h2 + b: pair = wave & 1, K half = wave >> 1 (the bias rides with half 0)
     {
         const int it = wave & 1, kh = wave >> 1, rt = it % RT03, q = it / RT03, col = q * 32 + li;
@@ -660,9 +684,17 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
         const float tt = T[ch * PIXR + colE] + T[(C + ch) * PIXR + colE];
         const float raw = T[(HP + ch) * PIXR + colE] + T[(C + HP + ch) * PIXR + colE];
         const float ls = cf_log_scale(raw);
-        const float z1 = fmaf(Y[(HP + ch) * PIXR + colE], __expf(ls), tt);
+        const float y1v = Y[(HP + ch) * PIXR + colE];
+        const float z1 = fmaf(y1v, __expf(ls), tt);
         lsum += ls;
-        if (b0 + smE < B) z[(int64_t)(b0 + smE) * C * HW + (HALF + ch) * HW + ppE] = z1;
+        if (b0 + smE < B) {
+            z[(int64_t)(b0 + smE) * C * HW + (HALF + ch) * HW + ppE] = z1;
+            if constexpr (DUMP) {
+                const int64_t o = ((int64_t)(b0 + smE) * HALF + ch) * HW + ppE;
+                tp.ls[o] = ls;
+                tp.y1[o] = y1v;
+            }
+        }
     }
     // per-sample sum: the lanes of a sample inside the wave (columns are lane % PIXR), then across the waves through LDS
     constexpr int LPS = HW < 64 ? HW : 64;            // consecutive lanes of one sample
@@ -675,10 +707,10 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
     if (tid < SPWR && b0 + tid < B) ldj_acc[b0 + tid] += ws[0] + ((T[tid] + T[4 + tid]) + (T[8 + tid] + T[12 + tid]));
 }
 
-template <class G, int NPT, bool SQ>
-int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s) {
+template <class G, int NPT, bool SQ, bool DUMP = false>
+int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s, StepTape tp = kNoTape) {
     constexpr int SPWR = 32 * NPT / G::HW;
-    k_flow_step_rs<G, NPT, SQ><<<dim3((B + SPWR - 1) / SPWR), dim3(256), 0, s>>>(x, z, ldj, ws, B, xbs);
+    k_flow_step_rs<G, NPT, SQ, DUMP><<<dim3((B + SPWR - 1) / SPWR), dim3(256), 0, s>>>(x, z, ldj, ws, B, xbs, tp);
     return 0;
 }
 
@@ -1065,8 +1097,13 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
                 else rc = in_squeeze ? launch_step_small<G16w, true, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp)
                                      : launch_step_small<G16w, false, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, tp);
                 break;
-        case 2: if (B < 256 * G32::SPW) CF_STEPT(G32v2); else if (direct_only) CF_STEPT(G32); else CF_STEPT(G32w); break;
-        case 3: if (!direct_only && B >= 256 * G64w2::SPW) CF_STEPT(G64w2); else if (B < 256 * G64::SPW) CF_STEPT(G64v2); else CF_STEPT(G64); break;
+        // very small batches: the row-split kernel, as in cf_flow_step_fwd (a quarter of the serial chain per workgroup)
+        case 2: if (B <= 512) rc = in_squeeze ? launch_step_rs<G32, 2, true, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), tp)
+                                              : launch_step_rs<G32, 2, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), tp);
+                else if (B < 256 * G32::SPW) CF_STEPT(G32v2); else if (direct_only) CF_STEPT(G32); else CF_STEPT(G32w); break;
+        case 3: if (B <= 1024) rc = in_squeeze ? launch_step_rs<G64, 1, true, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), tp)
+                                               : launch_step_rs<G64, 1, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), tp);
+                else if (!direct_only && B >= 256 * G64w2::SPW) CF_STEPT(G64w2); else if (B < 256 * G64::SPW) CF_STEPT(G64v2); else CF_STEPT(G64); break;
         default: cf_set_error("cf_flow_step_fwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_STEPT
