@@ -854,6 +854,46 @@ def test_graph_capture_matches_eager(L, name):
     assert (lp2 - logp).abs().max().item() > 0.0          # it really is a different result (static buffer was overwritten)
 
 
+@pytest.mark.parametrize("name", ["mnist", "cifar10"])
+def test_captured_train_step_matches_the_eager_loop(L, name):
+    """FlowSequential.capture_train_step (forward + loss + hand-written backward + fused AdamW as ONE HIP graph, gradients
+    taken from None) against the reference's loop as written (experiment_cl.py:127-136: zero_grad, loss, backward,
+    AdamW.step) from the same parameters, inputs and noise: same loss at every step and the same parameters after four
+    updates, to the rounding of the two AdamW implementations."""
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e(name)
+    x, u, eps = e2e_inputs(name, fx)
+    xd = x.to(DEV)
+    gt = (torch.arange(x.shape[0]) % M).to(DEV)
+    inv = 1.0 / x[0].numel()
+    loss_fn = lambda lp, y: torch.nn.functional.cross_entropy(lp * inv, y) if M > 1 else -(lp * inv).mean()
+    eager = build_model(name, params)
+    set_noise(eager, u, eps)
+    eager.train()
+    opt_e = torch.optim.AdamW(eager.parameters(), lr=1e-3)
+    losses_e = []
+    for _ in range(4):
+        opt_e.zero_grad(set_to_none=True)
+        loss = loss_fn(eager.log_prob(xd), gt)
+        loss.backward()
+        opt_e.step()
+        losses_e.append(float(loss.detach()))
+    cap = build_model(name, params)
+    set_noise(cap, u, eps)
+    cap.train()
+    opt_c = torch.optim.AdamW(cap.parameters(), lr=1e-3, fused=True, capturable=True)
+    step = cap.capture_train_step(xd, loss_fn, opt_c, warmup=1)
+    step(xd, gt)                                  # update 1 (the warm-up step, eager) + capture
+    losses_c = [float(step(xd, gt)) for _ in range(3)]           # updates 2-4: replays
+    for a, b in zip(losses_e[1:], losses_c):
+        assert abs(a - b) < 2e-6 * max(1.0, abs(a)), (losses_e, losses_c)
+    assert losses_c[-1] < losses_c[0]
+    pe, pc = dict(eager.named_parameters()), dict(cap.named_parameters())
+    for k in pe:
+        d = (pe[k].detach() - pc[k].detach()).abs().max().item()
+        assert d < 2e-5 * max(1.0, pe[k].detach().abs().max().item()), (k, d)
+
+
 def test_auto_graph_replay_and_cache_invalidation(L):
     """Evaluation under no_grad: the packed parameter tables are cached, and after two identical-shape calls the forward is
     replayed from a captured HIP graph (FlowSequential.auto_graph).  Replays must keep drawing fresh noise, return tensors
