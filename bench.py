@@ -392,6 +392,7 @@ def main():
                 secondary_small_batch("cifar10", dev, 64, cpu),
                 secondary_small_batch("cifar10", dev, 256, cpu=False),     # its CPU baseline is the headline's (batch 256)
                 secondary_small_batch("mnist", dev, 64, cpu),
+                secondary_small_batch("smap", dev, 256, cpu=False),        # BASELINE config 4 at the reference's default batch
                 secondary_training("cifar10", dev, 16384, 10, graph=True),
                 secondary_training("cifar10", dev, 16384, 10, graph=False),
                 secondary_training("cifar10", dev, 256, 50, graph=True),
