@@ -21,7 +21,9 @@ constexpr int LIN_KP = LIN_KC + 1;   // odd row stride: conflict-free operand re
 // K is walked in chunks of 16 through a 15 KiB LDS stage (any K; 5 workgroups per CU overlap each other's staging
 // and MFMA phases - 32- and 64-wide chunks measured slower); the next chunk's global loads are issued into registers
 // before the MFMAs of the current one.
-template <int ACT, int NTL, bool VEC>
+// WT: the weight is given as (K, N) row-major - element (n, k) = Wt[k N + n] - i.e. the nn.Linear weight of the layer whose
+// BACKWARD this is (gx = gy W): staged with lanes along n (coalesced), same LDS image, same summation order.
+template <int ACT, int NTL, bool VEC, bool WT = false>
 __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, const float* __restrict__ Wt,
                                                 const float* __restrict__ bias, const float* __restrict__ res,
                                                 float* __restrict__ y, int rows, int K, int N) {
@@ -38,7 +40,10 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
     constexpr int NXI = LIN_ROWS / RSTEP, NWI = (LIN_COLS + RSTEP - 1) / RSTEP;
     const int sk = (tid % (LIN_KC / EPL)) * EPL, sr = tid / (LIN_KC / EPL);
     const float* __restrict__ xb = x + (int64_t)r0 * K;
-    const float* __restrict__ wbp = Wt + (int64_t)n0 * K;
+    const float* __restrict__ wbp = WT ? Wt + n0 : Wt + (int64_t)n0 * K;
+    constexpr int NWT = LIN_COLS * LIN_KC / 256;         // WT: elements per thread (n fastest)
+    static_assert(!WT || (LIN_COLS * LIN_KC) % 256 == 0, "WT staging covers the tile exactly");
+    float wrt[WT ? NWT : 1];
     const int rmax = rows - 1 - r0, nmax = N - 1 - n0;
     int xo[NXI], wo[NWI];
 #pragma unroll
@@ -53,10 +58,18 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
             if constexpr (VEC) { const float4 v = *reinterpret_cast<const float4*>(xb + xo[i] + kc); xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w; }
             else xr[i][0] = xb[xo[i] + kc];
         }
+        if constexpr (WT) {
+#pragma unroll
+            for (int i = 0; i < NWT; ++i) {
+                const int e = tid + 256 * i, nl = e % LIN_COLS, kl = e / LIN_COLS;
+                wrt[i] = wbp[(int64_t)min(k0 + kl, K - 1) * N + min(nl, nmax)];
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             if constexpr (VEC) { const float4 v = *reinterpret_cast<const float4*>(wbp + wo[i] + kc); wr[i][0] = v.x; wr[i][1] = v.y; wr[i][2] = v.z; wr[i][3] = v.w; }
             else wr[i][0] = wbp[wo[i] + kc];
+        }
         }
     };
     f32x16 acc[NTL];
@@ -74,11 +87,19 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
         for (int i = 0; i < NXI; ++i)
 #pragma unroll
             for (int j = 0; j < EPL; ++j) xs[(sr + RSTEP * i) * LIN_KP + sk + j] = (kin && sr + RSTEP * i <= rmax) ? xr[i][j] : 0.f;
+        if constexpr (WT) {
+#pragma unroll
+            for (int i = 0; i < NWT; ++i) {
+                const int e = tid + 256 * i, nl = e % LIN_COLS, kl = e / LIN_COLS;
+                ws[nl * LIN_KP + kl] = (k0 + kl < K && nl <= nmax) ? wrt[i] : 0.f;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NWI; ++i)
 #pragma unroll
             for (int j = 0; j < EPL; ++j)
                 if (sr + RSTEP * i < LIN_COLS) ws[(sr + RSTEP * i) * LIN_KP + sk + j] = (kin && sr + RSTEP * i <= nmax) ? wr[i][j] : 0.f;
+        }
         __syncthreads();
         if (k0 + LIN_KC < K) fetch(k0 + LIN_KC);
 #pragma unroll
@@ -435,6 +456,21 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
     else CF_LIN_A(3, false);
 #undef CF_LIN_A
 #undef CF_LIN
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// gx = gy W for an nn.Linear weight W (N_out, K_in) as stored: y[r, n] = sum_k x[r, k] W[k, n] - the data gradient of
+// cf_linear without a transposed copy of the weight (K = the layer's N_out, N = its K_in)
+int cf_linear_tn(const float* x, const float* W, float* y, int rows, int K, int N, cf_stream_t stream) {
+    if (rows == 0) return 0;
+    CF_REQUIRE(x && W && y && rows >= 0 && K > 0 && N > 0);
+    constexpr int ntl = 3;
+    const int nt = (N + 31) / 32;
+    dim3 grid((rows + LIN_ROWS - 1) / LIN_ROWS, (nt + ntl - 1) / ntl);
+    const bool vec = K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) k_linear<0, 3, true, true><<<grid, dim3(256), 0, cf_s(stream)>>>(x, W, nullptr, nullptr, y, rows, K, N);
+    else k_linear<0, 3, false, true><<<grid, dim3(256), 0, cf_s(stream)>>>(x, W, nullptr, nullptr, y, rows, K, N);
     CF_LAUNCH_CHECK();
     return 0;
 }

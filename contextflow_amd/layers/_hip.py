@@ -73,6 +73,7 @@ SIGNATURES = {
     "cf_linear_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_p]),
     "cf_linear_wgrad_x2": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_p]),
     "cf_linear": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),
+    "cf_linear_tn": (_c_int, [_c_p] * 3 + [_c_int] * 3 + [_c_p]),
     "cf_layernorm": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_f, _c_p]),
     "cf_attention": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),
     "cf_patchify": (_c_int, [_c_p, _c_p] + [_c_int] * 6 + [_c_i64, _c_int, _c_p]),

@@ -38,8 +38,7 @@ def _linear_bwd(x_in, lin, gy, grads, need_gx=True):
     if not need_gx:
         return None
     gx = _new(rows, K, like=gy)
-    Wt = W.t().contiguous()
-    _hip.call("cf_linear", _hip.p(gy), _hip.p(Wt), None, None, _hip.p(gx), rows, N, K, 0, st)
+    _hip.call("cf_linear_tn", _hip.p(gy), _hip.p(W.contiguous()), _hip.p(gx), rows, N, K, st)      # gy W, the weight as stored
     return gx
 
 

@@ -252,6 +252,9 @@ int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, co
  * act: 0 none, 1 exact (erf) GELU, 2 ReLU.   nn.Linear of patch embedding / to_qkv / to_out / FeedForward; CN nets. */
 int cf_linear(const float* x, const float* Wt, const float* bias, const float* res, float* y,
               int rows, int K, int N, int act, cf_stream_t stream);
+/* data gradient of cf_linear: y[r,n] = sum_k x[r,k] W[k,n] with W the layer's weight as stored ((K, N) row-major here =
+ * nn.Linear's (out, in)): gx = gy W without a transposed copy of the weight. */
+int cf_linear_tn(const float* x, const float* W, float* y, int rows, int K, int N, cf_stream_t stream);
 /* backward of cf_linear w.r.t. its parameters: gW (N,K) = gy^T x, gb (N) = column sums of gy (gb may be NULL); split-K
  * fp32-MFMA GEMM over the rows, partials in ws (cf_linear_wgrad_ws_bytes) summed in a fixed order.  Any K, N (wide
  * problems run as column blocks of at most 128 outputs x 255 inputs).  cf_linear_wgrad_x2: the same with x squared

@@ -1097,6 +1097,22 @@ def test_prepare_train_equals_prepare_plus_inverse(L, C, H):
     assert (winv.double().cpu() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("rows,K,N", [(1000, 104, 52), (37, 52, 104), (513, 64, 192), (300, 30, 17), (128, 152, 152)])
+def test_linear_tn_equals_linear_with_a_transposed_copy(L, rows, K, N):
+    """cf_linear_tn (gx = gy W, the nn.Linear weight as stored) against cf_linear on W^T copied out: bitwise equal (same
+    LDS image, same summation order), ragged row / feature tiles, K not a multiple of 4."""
+    from contextflow_amd.layers import _hip
+    g = torch.Generator().manual_seed(rows + K + N)
+    gy = torch.randn(rows, K, generator=g).to(DEV)
+    W = torch.randn(K, N, generator=g).to(DEV)                # the layer's (out = K here, in = N) weight
+    a, b = torch.empty(rows, N, device=DEV), torch.empty(rows, N, device=DEV)
+    _hip.call("cf_linear", _hip.p(gy), _hip.p(W.t().contiguous()), None, None, _hip.p(a), rows, K, N, 0, _hip.stream())
+    _hip.call("cf_linear_tn", _hip.p(gy), _hip.p(W), _hip.p(b), rows, K, N, _hip.stream())
+    assert torch.equal(a, b)
+    ref = gy.double() @ W.double()
+    assert (b.double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+
+
 def test_layer_backward_kernels_against_torch(L):
     """cf_layernorm_bwd / cf_attention_bwd / cf_gelu / cf_coupling_apply_bwd / cf_channel_sums against torch.autograd
     in fp64 (ragged row counts, the SMAP ViT geometry: dim 52, 4 tokens, head 64)."""
