@@ -365,10 +365,24 @@ __global__ __launch_bounds__(256) void k_gmm_bwd_gx(const float* __restrict__ x,
 }
 // parameter gradients from the batch sums S0 (MK) = sum_b r, S1 = r^T x, S2 = r^T x^2 (MK x D):
 //   t = a x + bm;  g_mu = a sum_b r t;  g_sG = a (sum_b r t^2 - S0) sigmoid(sG)      (softplus' = sigmoid)
+// ... and, when gw is given, the mixture-weight gradient  g_wG[m][k] = S0[mk] - gcol[m] softmax_k(wG[m])[k]   (the log-weights
+// enter through log softmax; gcol[m] = sum_b g[b][m]): M K <= a few hundred values, the first workgroup's job
 __global__ __launch_bounds__(256) void k_gmm_bwd_params(const float* __restrict__ a, const float* __restrict__ bm,
                                                         const float* __restrict__ sG, const float* __restrict__ S0,
                                                         const float* __restrict__ S1, const float* __restrict__ S2,
-                                                        float* __restrict__ gmu, float* __restrict__ gsig, int D, int64_t n) {
+                                                        float* __restrict__ gmu, float* __restrict__ gsig, int D, int64_t n,
+                                                        const float* __restrict__ wG = nullptr, const float* __restrict__ gcol = nullptr,
+                                                        float* __restrict__ gw = nullptr, int M = 0, int K = 0) {
+    if (gw != nullptr && blockIdx.x == 0) {
+        for (int mk = threadIdx.x; mk < M * K; mk += 256) {
+            const int m = mk / K;
+            float mx = -INFINITY;
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, wG[m * K + k]);
+            float sum = 0.f;
+            for (int k = 0; k < K; ++k) sum += expf(wG[m * K + k] - mx);
+            gw[mk] = S0[mk] - gcol[m] * (expf(wG[mk] - mx) / sum);
+        }
+    }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const float av = a[e], bv = bm[e], s0 = S0[e / D], s1 = S1[e], s2 = S2[e];
         const float rt = av * s1 + bv * s0;
@@ -550,6 +564,18 @@ int cf_gmm_bwd_params(const float* a, const float* bm, const float* sG, const fl
     CF_REQUIRE(a && bm && sG && S0 && S1 && S2 && gmu && gsig && MK > 0 && D > 0);
     const int64_t n = (int64_t)MK * D;
     k_gmm_bwd_params<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, sG, S0, S1, S2, gmu, gsig, D, n);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same + the mixture-weight gradient gw (M, K) = S0 - gcol softmax(wG) in the same launch (gcol (M) = column sums of
+// the upstream gradient)
+int cf_gmm_bwd_params_w(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
+                        const float* wG, const float* gcol, float* gmu, float* gsig, float* gw, int M, int K, int D,
+                        cf_stream_t stream) {
+    CF_REQUIRE(a && bm && sG && S0 && S1 && S2 && wG && gcol && gmu && gsig && gw && M > 0 && K > 0 && D > 0);
+    const int64_t n = (int64_t)M * K * D;
+    k_gmm_bwd_params<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, sG, S0, S1, S2, gmu, gsig, D, n, wG, gcol, gw, M, K);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -55,6 +55,7 @@ SIGNATURES = {
     "cf_gmm_bwd_coeffs": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_int, _c_p]),
     "cf_gmm_bwd_gx": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_i64, _c_p]),
     "cf_gmm_bwd_params": (_c_int, [_c_p] * 8 + [_c_int, _c_int, _c_p]),
+    "cf_gmm_bwd_params_w": (_c_int, [_c_p] * 11 + [_c_int] * 3 + [_c_p]),
     "cf_gmm_resp_ws_bytes": (_c_i64, [_c_int] * 4),
     "cf_gmm_resp": (_c_int, [_c_p] * 7 + [_c_int] * 4 + [_c_i64, _c_p]),
     "cf_gmm_quad": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_p]),

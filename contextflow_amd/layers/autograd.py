@@ -21,8 +21,9 @@ from .squeeze import squeeze_op
 
 
 # ------------------------------------------------------------------------------------------------ GMM prior
-def gmm_backward(x, dist, prepared, g):
-    """x: (B, D...) possibly a channel slice; g: (B, M) upstream.  Returns (gx like x, {param: grad})."""
+def gmm_backward(x, dist, prepared, g, gcol=None):
+    """x: (B, D...) possibly a channel slice; g: (B, M) upstream; gcol: its column sums (M,) if the caller has them (the
+    priors of one backward pass share g).  Returns (gx like x, {param: grad})."""
     a, bm, cst, M, K, D = prepared
     xv, xbs = _hip.bview(x)
     B = xv.shape[0]
@@ -51,12 +52,13 @@ def gmm_backward(x, dist, prepared, g):
     _hip.call("cf_linear_wgrad_x2", pp(xf), pp(r), pp(S2), pp(wsw), B, D, MK, st)
     g_mu, g_sigma = new(MK, D), new(MK, D)
     sG = _hip.f32(dist.sG.detach()).reshape(MK, D)
-    _hip.call("cf_gmm_bwd_params", pp(a), pp(bm), pp(sG), pp(S0), pp(S1), pp(S2), pp(g_mu), pp(g_sigma), MK, D, st)
-    grads = {
-        dist.mG: g_mu.view_as(dist.mG),
-        dist.sG: g_sigma.view_as(dist.sG),
-        dist.wG: S0.view(M, K) - g.sum(0).unsqueeze(-1) * torch.softmax(dist.wG.detach(), dim=-1),
-    }
+    if gcol is None:
+        gcol = _hip.f32(g).sum(0)
+    g_w = new(M, K)
+    wG = _hip.f32(dist.wG.detach()).reshape(M, K)
+    _hip.call("cf_gmm_bwd_params_w", pp(a), pp(bm), pp(sG), pp(S0), pp(S1), pp(S2), pp(wG), pp(_hip.f32(gcol)), pp(g_mu), pp(g_sigma),
+              pp(g_w), M, K, D, st)
+    grads = {dist.mG: g_mu.view_as(dist.mG), dist.sG: g_sigma.view_as(dist.sG), dist.wG: g_w.view_as(dist.wG)}
     return gx.view(xv.shape), grads
 
 
@@ -142,6 +144,7 @@ class FlowLogProb(torch.autograd.Function):
         glogp = _hip.f32(glogp)
         gld = glogp.sum(1).contiguous()                     # d/d ld1[b]: logp = ldM + ld1[:, None]
         gsum = gld.sum().reshape(1)                         # shared by the parameter chains of all steps
+        gcol = glogp.sum(0)                                 # ... and by the mixture-weight gradients of all priors
         acc = {}
 
         def add(d):
@@ -153,12 +156,12 @@ class FlowLogProb(torch.autograd.Function):
             kind = rec[0]
             if kind == "prior":
                 _, xin, dist, prep = rec
-                gz, gp = gmm_backward(xin, dist, prep, glogp)
+                gz, gp = gmm_backward(xin, dist, prep, glogp, gcol)
                 add(gp)
             elif kind == "split":
                 _, xin, dist, prep = rec                      # xin: full tensor before the split
                 c = xin.shape[1] // 2
-                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp)
+                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp, gcol)
                 add(gp)
                 gz = torch.cat([gz, g2], dim=1)
             elif kind == "step":

@@ -138,6 +138,11 @@ int cf_gmm_bwd_gx(const float* x, const float* G1, const float* G2, float* gx, i
                   cf_stream_t stream);
 int cf_gmm_bwd_params(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
                       float* gmu, float* gsig, int MK, int D, cf_stream_t stream);
+/* the same + the mixture-weight gradient gw (M, K) = S0 - gcol softmax(wG) (gaussian.py:149-153: the log-weights enter through
+ * log_softmax; gcol (M) = column sums of the upstream gradient (B, M)) in the same launch */
+int cf_gmm_bwd_params_w(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
+                        const float* wG, const float* gcol, float* gmu, float* gsig, float* gw, int M, int K, int D,
+                        cf_stream_t stream);
 int64_t cf_gmm_resp_ws_bytes(int B, int M, int K, int D);
 int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cst, const float* g, float* r, void* ws, int B,
                 int M, int K, int D, int64_t x_bstride, cf_stream_t stream);
