@@ -123,8 +123,8 @@ int launch_sample(const float* x, const float* u, float* y, float* ldj, int B, i
 // through HBM): Philox4x32-10 keyed by `seed`, counter = (float4 index, kind, offset) - one call gives the four
 // uniforms of a float4 of pixels.  The augment channel (augment.py:14-18, gaussian.py:50-72) is filled with
 // Box-Muller normals from the same generator and contributes -log q(eps) = sum(eps^2/2 + log(2 pi)/2).
-// state[0] = offset, advanced by k_rng_advance on the same stream (so that a captured graph draws fresh noise on
-// every replay).
+// state[0] = offset: either a per-call value the caller draws from its own generator (FlowSequential: torch's CUDA
+// generator, graph-safe), or a self-advancing word (`advance` = 1: k_rng_advance on the same stream).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
                                               unsigned (&out)[4]) {
@@ -455,14 +455,14 @@ int cf_preprocess_fwd(const float* x, const float* u, float* y, float* ldj, int 
 
 int cf_preprocess_rng_fwd(const float* x, float* y, float* ldj, uint64_t* rng_state, uint64_t seed, int B, int N,
                           int aug_n, int64_t y_bstride, float t1, float s1, float t2, float s2, float ldj_const,
-                          cf_stream_t stream) {
+                          int advance, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(x && y && ldj && rng_state && B >= 0 && N > 0 && aug_n >= 0 && y_bstride >= N + aug_n);
     CF_REQUIRE(N % 4 == 0 && aug_n % 4 == 0 && y_bstride % 4 == 0 && aligned16(x) && aligned16(y));
     k_preprocess_rng<256><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, y, ldj, (const unsigned long long*)rng_state,
                                                                   (unsigned long long)seed, N / 4, aug_n / 4, N, y_bstride,
                                                                   t1, s1, t2, s2, ldj_const);
-    k_rng_advance<<<dim3(1), dim3(1), 0, cf_s(stream)>>>((unsigned long long*)rng_state);
+    if (advance) k_rng_advance<<<dim3(1), dim3(1), 0, cf_s(stream)>>>((unsigned long long*)rng_state);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -6,7 +6,7 @@
 // Work shape: a "GEMM with a square in the inner product" — (B samples) x (M*K components) x D.
 // VALU-bound (2 FMA per term) when operands are reused from registers, so the kernel is register
 // tiled: a 256-thread workgroup owns 128 samples x 80 components, each thread an 8 x 5 micro-tile;
-// x and the (a, bm) = (1/sigma, -mu/sigma) rows stream through LDS in 32-wide d-chunks with
+// x and the (a, nm) = (1/sigma, -mu) rows stream through LDS in 32-wide d-chunks with
 // 36-float row stride (every ds_read_b128 lane group hits distinct 4-bank groups), the next
 // chunk's global loads are issued before the current chunk's FMAs.  D can be split over
 // blockIdx.z (partials in a caller workspace + a small finishing kernel) to fill 256 CUs when
@@ -29,7 +29,7 @@ __device__ __forceinline__ float softplus_ref(float v) {      // torch softplus,
 // one block per component row mk
 __global__ __launch_bounds__(256) void k_gmm_prepare(const float* __restrict__ mG, const float* __restrict__ sG,
                                                      const float* __restrict__ wG, float* __restrict__ a,
-                                                     float* __restrict__ bm, float* __restrict__ cst, int K, int D) {
+                                                     float* __restrict__ nm, float* __restrict__ cst, int K, int D) {
     __shared__ float red[4];
     const int mk = blockIdx.x;
     const float* mu = mG + (int64_t)mk * D;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_gmm_prepare(const float* __restrict__ m
         const float s = softplus_ref(sg[d]);
         const float inv = 1.0f / s;
         a[(int64_t)mk * D + d] = inv;
-        bm[(int64_t)mk * D + d] = -mu[d] * inv;
+        nm[(int64_t)mk * D + d] = -mu[d];
         acc += logf(s);
     }
     acc = cf_block_sum<4>(acc, red);
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_gmm_prepare(const float* __restrict__ m
     }
 }
 
-// guarded 4-float load for ragged tails: elements at d >= dend read as 0 (a = bm = 0 makes the term vanish)
+// guarded 4-float load for ragged tails: elements at d >= dend read as 0 (a = nm = 0 makes the term vanish)
 template <bool VEC>
 __device__ __forceinline__ float4 ld4_tail(const float* row, int d, int dend) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -75,7 +75,7 @@ __device__ __forceinline__ float4 ld4_tail(const float* row, int d, int dend) {
 // otherwise the logsumexp epilogue runs here.
 template <int MKT, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict__ x, const float* __restrict__ a,
-                                                     const float* __restrict__ bm, const float* __restrict__ cst,
+                                                     const float* __restrict__ nm, const float* __restrict__ cst,
                                                      float* __restrict__ out, float* __restrict__ qout,
                                                      int B, int MKtot, int K, int D, int dsplit,
                                                      int64_t xbs, int accumulate, int Mtot) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict_
             const int e = q * 256 + tid, row = e >> 3, c4 = (e & 7) * 4;
             const int64_t off = (int64_t)min(mk0 + row, MKtot - 1) * D;
             pa[q] = full ? *reinterpret_cast<const float4*>(a + off + d0 + c4) : ld4_tail<VEC>(a + off, d0 + c4, dhi);
-            pb[q] = full ? *reinterpret_cast<const float4*>(bm + off + d0 + c4) : ld4_tail<VEC>(bm + off, d0 + c4, dhi);
+            pb[q] = full ? *reinterpret_cast<const float4*>(nm + off + d0 + c4) : ld4_tail<VEC>(nm + off, d0 + c4, dhi);
         }
     };
     auto lstore = [&]() {
@@ -162,7 +162,11 @@ __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict_
             for (int i = 0; i < SPT; ++i)
 #pragma unroll
                 for (int j = 0; j < MKT; ++j) {
-                    const f32x2 t = __builtin_elementwise_fma(xv[i], av[j], bv[j]);
+                    // the reference's form (x - mu) / sigma (gaussian.py:142-161): the difference of two close values is
+                    // exact, whereas fma(x, 1/sigma, -mu/sigma) carries the rounding of mu/sigma - an absolute error of
+                    // ulp(mu/sigma) on a term of size O(1) once a mixture is fitted with small sigma (SMAP "extreme"
+                    // fixtures: 1.7e-5 bits/dim).  One more packed VALU per term than the fma form.
+                    const f32x2 t = (xv[i] + bv[j]) * av[j];
                     acc2[i][j] = __builtin_elementwise_fma(t, t, acc2[i][j]);
                 }
         }
@@ -342,16 +346,16 @@ __global__ __launch_bounds__(256) void k_gmm_resp_finish(const float* __restrict
 
 // ---- elementwise pieces of the mixture backward (autograd.py gmm_backward), one launch each instead of a chain of
 // parameter-sized torch kernels ------------------------------------------------------------------------------------
-// A2 = a a, AB = a bm: right-hand sides of the two (B x MK) x (MK x D) products of d/dx
+// A2 = a a, AB = a a nm (nm = -mu): right-hand sides of the two (B x MK) x (MK x D) products of d/dx
 // TR: outputs transposed, (D, MK) - the Wt operand of cf_linear for G = r A  (coalesced writes, strided L2-resident reads)
 template <bool TR>
-__global__ __launch_bounds__(256) void k_gmm_bwd_coeffs(const float* __restrict__ a, const float* __restrict__ bm,
+__global__ __launch_bounds__(256) void k_gmm_bwd_coeffs(const float* __restrict__ a, const float* __restrict__ nm,
                                                         float* __restrict__ A2, float* __restrict__ AB, int64_t n, int MK, int D) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         const int64_t src = TR ? (e % MK) * D + e / MK : e;
         const float av = a[src];
         A2[e] = av * av;
-        AB[e] = av * bm[src];
+        AB[e] = av * av * nm[src];
     }
 }
 // gx[b, d] = -(x[b, d] G1[b, d] + G2[b, d]),  G1 = r A2, G2 = r AB
@@ -364,10 +368,10 @@ __global__ __launch_bounds__(256) void k_gmm_bwd_gx(const float* __restrict__ x,
     }
 }
 // parameter gradients from the batch sums S0 (MK) = sum_b r, S1 = r^T x, S2 = r^T x^2 (MK x D):
-//   t = a x + bm;  g_mu = a sum_b r t;  g_sG = a (sum_b r t^2 - S0) sigmoid(sG)      (softplus' = sigmoid)
+//   t = a (x + nm), nm = -mu;  g_mu = a sum_b r t;  g_sG = a (sum_b r t^2 - S0) sigmoid(sG)      (softplus' = sigmoid)
 // ... and, when gw is given, the mixture-weight gradient  g_wG[m][k] = S0[mk] - gcol[m] softmax_k(wG[m])[k]   (the log-weights
 // enter through log softmax; gcol[m] = sum_b g[b][m]): M K <= a few hundred values, the first workgroup's job
-__global__ __launch_bounds__(256) void k_gmm_bwd_params(const float* __restrict__ a, const float* __restrict__ bm,
+__global__ __launch_bounds__(256) void k_gmm_bwd_params(const float* __restrict__ a, const float* __restrict__ nm,
                                                         const float* __restrict__ sG, const float* __restrict__ S0,
                                                         const float* __restrict__ S1, const float* __restrict__ S2,
                                                         float* __restrict__ gmu, float* __restrict__ gsig, int D, int64_t n,
@@ -384,9 +388,9 @@ __global__ __launch_bounds__(256) void k_gmm_bwd_params(const float* __restrict_
         }
     }
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-        const float av = a[e], bv = bm[e], s0 = S0[e / D], s1 = S1[e], s2 = S2[e];
-        const float rt = av * s1 + bv * s0;
-        const float rt2 = av * av * s2 + 2.0f * av * bv * s1 + bv * bv * s0;
+        const float av = a[e], bv = nm[e], s0 = S0[e / D], s1 = S1[e], s2 = S2[e];
+        const float rt = av * (s1 + bv * s0);
+        const float rt2 = av * av * (s2 + 2.0f * bv * s1 + bv * bv * s0);
         gmu[e] = av * rt;
         gsig[e] = av * (rt2 - s0) / (1.0f + expf(-sG[e]));
     }
@@ -417,27 +421,27 @@ int choose_nsplit(int B, int MK, int D) {
 
 extern "C" {
 
-int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, float* bm, float* cst, int M, int K,
+int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, float* nm, float* cst, int M, int K,
                    int D, cf_stream_t stream) {
-    CF_REQUIRE(mG && sG && wG && a && bm && cst && M > 0 && K > 0 && D > 0);
-    k_gmm_prepare<<<dim3(M * K), dim3(256), 0, cf_s(stream)>>>(mG, sG, wG, a, bm, cst, K, D);
+    CF_REQUIRE(mG && sG && wG && a && nm && cst && M > 0 && K > 0 && D > 0);
+    k_gmm_prepare<<<dim3(M * K), dim3(256), 0, cf_s(stream)>>>(mG, sG, wG, a, nm, cst, K, D);
     CF_LAUNCH_CHECK();
     return 0;
 }
 
-// q[b, mk] = sum_d (x[b,d]*a[mk,d] + bm[mk,d])^2 — the quadratic forms alone (used by the backward pass to rebuild
+// q[b, mk] = sum_d ((x[b,d] + nm[mk,d]) * a[mk,d])^2 — the quadratic forms alone (used by the backward pass to rebuild
 // the component responsibilities)
-int cf_gmm_quad(const float* x, const float* a, const float* bm, float* q, int B, int M, int K, int D, int64_t x_bstride,
+int cf_gmm_quad(const float* x, const float* a, const float* nm, float* q, int B, int M, int K, int D, int64_t x_bstride,
                 cf_stream_t stream) {
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
-    CF_REQUIRE(x && a && bm && q && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
+    CF_REQUIRE(x && a && nm && q && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
     const int MK = M * K;
     const bool small = MK <= 16;
     const bool vec = (D % 4 == 0) && (x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(bm) & 15) == 0);
+                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(nm) & 15) == 0);
     const int mkb = small ? 16 : 80;
     dim3 grid((B + TB - 1) / TB, (MK + mkb - 1) / mkb, 1);
-#define CF_GO(MKT, V) k_gmm_logprob<MKT, V, true><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, bm, nullptr, nullptr, q, B, MK, K, D, D, x_bstride, 0, M)
+#define CF_GO(MKT, V) k_gmm_logprob<MKT, V, true><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, nm, nullptr, nullptr, q, B, MK, K, D, D, x_bstride, 0, M)
     if (small) { if (vec) CF_GO(1, true); else CF_GO(1, false); }
     else       { if (vec) CF_GO(5, true); else CF_GO(5, false); }
 #undef CF_GO
@@ -463,10 +467,10 @@ int64_t cf_gmm_ws_bytes(int B, int M, int K, int D) {
     return ns > 1 ? (int64_t)ns * B * M * K * sizeof(float) : 0;
 }
 
-int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float* cst, float* out, void* ws,
+int cf_gmm_logprob(const float* x, const float* a, const float* nm, const float* cst, float* out, void* ws,
                    int B, int M, int K, int D, int64_t x_bstride, int accumulate, cf_stream_t stream) {
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
-    CF_REQUIRE(x && a && bm && cst && out && B >= 0 && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
+    CF_REQUIRE(x && a && nm && cst && out && B >= 0 && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
     if (B == 0) return 0;
     const int MK = M * K;
     const bool small = MK <= 16;
@@ -475,12 +479,12 @@ int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float*
     int dsplit = D;
     if (ns > 1) { dsplit = ((D + ns - 1) / ns + DC - 1) / DC * DC; ns = (D + dsplit - 1) / dsplit; }
     const bool vec = (D % 4 == 0) && (x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(bm) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(nm) & 15) == 0) &&
                      (dsplit % 4 == 0);
     const int mkb = small ? 16 : 80;
     dim3 grid((B + TB - 1) / TB, (MK + mkb - 1) / mkb, ns);
     float* q = (float*)ws;
-#define CF_GO(MKT, V, S) k_gmm_logprob<MKT, V, S><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, bm, cst, out, q, B, MK, K, D, dsplit, x_bstride, accumulate, M)
+#define CF_GO(MKT, V, S) k_gmm_logprob<MKT, V, S><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, nm, cst, out, q, B, MK, K, D, dsplit, x_bstride, accumulate, M)
     if (ns > 1) {
         if (small) { if (vec) CF_GO(1, true, true); else CF_GO(1, false, true); }
         else       { if (vec) CF_GO(5, true, true); else CF_GO(5, false, true); }
@@ -507,22 +511,22 @@ int64_t cf_gmm_resp_ws_bytes(int B, int M, int K, int D) {
     return (int64_t)ns * B * M * K * sizeof(float);
 }
 
-int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cst, const float* g, float* r, void* ws, int B,
+int cf_gmm_resp(const float* x, const float* a, const float* nm, const float* cst, const float* g, float* r, void* ws, int B,
                 int M, int K, int D, int64_t x_bstride, cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(x && a && bm && cst && g && r && ws && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
+    CF_REQUIRE(x && a && nm && cst && g && r && ws && M > 0 && K > 0 && K <= 16 && D > 0 && x_bstride >= D);
     const int MK = M * K;
     const bool small = MK <= 16;
     int ns = choose_nsplit(B, MK, D);
     int dsplit = D;
     if (ns > 1) { dsplit = ((D + ns - 1) / ns + DC - 1) / DC * DC; ns = (D + dsplit - 1) / dsplit; }
     const bool vec = (D % 4 == 0) && (x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(bm) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(nm) & 15) == 0) &&
                      (dsplit % 4 == 0);
     const int mkb = small ? 16 : 80;
     dim3 grid((B + TB - 1) / TB, (MK + mkb - 1) / mkb, ns);
     float* q = (float*)ws;
-#define CF_GO(MKT, V) k_gmm_logprob<MKT, V, true><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, bm, nullptr, nullptr, q, B, MK, K, D, dsplit, x_bstride, 0, M)
+#define CF_GO(MKT, V) k_gmm_logprob<MKT, V, true><<<grid, dim3(256), 0, cf_s(stream)>>>(x, a, nm, nullptr, nullptr, q, B, MK, K, D, dsplit, x_bstride, 0, M)
     if (small) { if (vec) CF_GO(1, true); else CF_GO(1, false); }
     else       { if (vec) CF_GO(5, true); else CF_GO(5, false); }
 #undef CF_GO
@@ -539,12 +543,12 @@ int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cs
 
 static unsigned gmm_ew_blocks(int64_t n) { const int64_t b = (n + 255) / 256; return (unsigned)(b > 8192 ? 8192 : (b > 0 ? b : 1)); }
 
-int cf_gmm_bwd_coeffs(const float* a, const float* bm, float* A2, float* AB, int MK, int D, int transposed,
+int cf_gmm_bwd_coeffs(const float* a, const float* nm, float* A2, float* AB, int MK, int D, int transposed,
                       cf_stream_t stream) {
-    CF_REQUIRE(a && bm && A2 && AB && MK > 0 && D > 0);
+    CF_REQUIRE(a && nm && A2 && AB && MK > 0 && D > 0);
     const int64_t n = (int64_t)MK * D;
-    if (transposed) k_gmm_bwd_coeffs<true><<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, A2, AB, n, MK, D);
-    else k_gmm_bwd_coeffs<false><<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, A2, AB, n, MK, D);
+    if (transposed) k_gmm_bwd_coeffs<true><<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, nm, A2, AB, n, MK, D);
+    else k_gmm_bwd_coeffs<false><<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, nm, A2, AB, n, MK, D);
     CF_LAUNCH_CHECK();
     return 0;
 }
@@ -559,23 +563,23 @@ int cf_gmm_bwd_gx(const float* x, const float* G1, const float* G2, float* gx, i
     return 0;
 }
 
-int cf_gmm_bwd_params(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
+int cf_gmm_bwd_params(const float* a, const float* nm, const float* sG, const float* S0, const float* S1, const float* S2,
                       float* gmu, float* gsig, int MK, int D, cf_stream_t stream) {
-    CF_REQUIRE(a && bm && sG && S0 && S1 && S2 && gmu && gsig && MK > 0 && D > 0);
+    CF_REQUIRE(a && nm && sG && S0 && S1 && S2 && gmu && gsig && MK > 0 && D > 0);
     const int64_t n = (int64_t)MK * D;
-    k_gmm_bwd_params<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, sG, S0, S1, S2, gmu, gsig, D, n);
+    k_gmm_bwd_params<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, nm, sG, S0, S1, S2, gmu, gsig, D, n);
     CF_LAUNCH_CHECK();
     return 0;
 }
 
 // the same + the mixture-weight gradient gw (M, K) = S0 - gcol softmax(wG) in the same launch (gcol (M) = column sums of
 // the upstream gradient)
-int cf_gmm_bwd_params_w(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
+int cf_gmm_bwd_params_w(const float* a, const float* nm, const float* sG, const float* S0, const float* S1, const float* S2,
                         const float* wG, const float* gcol, float* gmu, float* gsig, float* gw, int M, int K, int D,
                         cf_stream_t stream) {
-    CF_REQUIRE(a && bm && sG && S0 && S1 && S2 && wG && gcol && gmu && gsig && gw && M > 0 && K > 0 && D > 0);
+    CF_REQUIRE(a && nm && sG && S0 && S1 && S2 && wG && gcol && gmu && gsig && gw && M > 0 && K > 0 && D > 0);
     const int64_t n = (int64_t)M * K * D;
-    k_gmm_bwd_params<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, bm, sG, S0, S1, S2, gmu, gsig, D, n, wG, gcol, gw, M, K);
+    k_gmm_bwd_params<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, nm, sG, S0, S1, S2, gmu, gsig, D, n, wG, gcol, gw, M, K);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -650,31 +650,6 @@ int cf_flow_step_bwd_prepare(const float* Wm, const float* logs, const float* w1
     return 0;
 }
 
-int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
-                     float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy,
-                     int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
-    if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
-    CF_REQUIRE(x && gz && gld && ws && wsb && gx && s_y0 && s_h1 && s_h2 && s_gh && s_gh2 && s_gh1 && s_gy);
-    CF_REQUIRE(x_bstride >= (int64_t)C * H * W && x_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-               (reinterpret_cast<uintptr_t>(gz) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0);
-    const float* w = (const float*)ws;
-    const float* wb = (const float*)wsb;
-    int rc = 0;
-#define CF_BWD(G) rc = in_squeeze ? launch_step_bwd<G, true>(x, gz, gld, w, wb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream)) \
-                                  : launch_step_bwd<G, false>(x, gz, gld, w, wb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, x_bstride, cf_s(stream))
-    switch (shape_id(C, H, W)) {
-        case 0: CF_BWD(B8); break;
-        case 1: CF_BWD(B16); break;
-        case 2: CF_BWD(B32); break;
-        case 3: CF_BWD(B64); break;
-        default: cf_set_error("cf_flow_step_bwd: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
-    }
-#undef CF_BWD
-    if (rc) return rc;
-    CF_LAUNCH_CHECK();
-    return 0;
-}
-
 // backward of a step whose forward was cf_flow_step_fwd_taped: the kernel reads ls / y1 / the two ReLU masks from the
 // tape's aux buffer - it needs neither the step input nor the forward's packed weights, and runs no recompute.  (The y0 /
 // h1 / h2 planes of the tape are operands of cf_wgrad only.)  gx comes out in the (B, C, H, W) layout of the step.

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CONTEXTFLOW_HIP_LIB: developer override (A/B builds, probe builds of tools/dev); the default is the in-tree library
 LIB_PATH = os.environ.get("CONTEXTFLOW_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libcontextflow_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -26,7 +26,7 @@ SIGNATURES = {
     "cf_sigmoid": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "cf_floor": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "cf_preprocess_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
-    "cf_preprocess_rng_fwd": (_c_int, [_c_p] * 4 + [ctypes.c_uint64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
+    "cf_preprocess_rng_fwd": (_c_int, [_c_p] * 4 + [ctypes.c_uint64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int, _c_p]),
     "cf_std_normal_nll": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_i64, _c_p]),
     "cf_squeeze": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_int, _c_p]),
     "cf_conv1x1_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_p]),
@@ -61,7 +61,6 @@ SIGNATURES = {
     "cf_gmm_quad": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_p]),
     "cf_flow_step_bwd_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_bwd_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_p]),
-    "cf_flow_step_bwd": (_c_int, [_c_p] * 13 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_flow_step_tape_aux_bytes": (_c_i64, [_c_int] * 4),
     "cf_flow_step_bwd_taped": (_c_int, [_c_p] * 9 + [_c_int] * 4 + [_c_p]),
     "cf_flow_step_fwd_taped": (_c_int, [_c_p] * 8 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),

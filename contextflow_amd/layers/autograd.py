@@ -3,9 +3,10 @@
 
 Forward = the fused plan of FlowSequential (same kernels, same numbers) with a tape of each group's input.
 Backward walks the tape in reverse:
-  * flow step  : ONE kernel (cf_flow_step_bwd) recomputes the step in LDS and runs the data-gradient chain on the
-                 fp32 matrix cores; it also writes the operand planes of the weight gradients, which are split-K
-                 MFMA GEMMs over (batch x pixels) with the 3x3 tap shifts (cf_wgrad);
+  * flow step  : ONE kernel (cf_flow_step_bwd_taped) reads the lean tape of the taping forward kernel and runs the
+                 data-gradient chain on the fp32 matrix cores; it also writes the operand planes of the weight gradients,
+                 which are split-K MFMA GEMMs over (batch x pixels) with the 3x3 tap shifts (cf_wgrad).  Without a kept
+                 tape (TAPE_PLANES = False / huge batches) the taping forward kernel is re-run per step at backward time;
   * GMM priors : component responsibilities from the HIP quadratic-form kernel (cf_gmm_resp), the remaining
                  contractions ((B x 80)(80 x D) and (80 x B)(B x D)) on cf_linear / cf_linear_wgrad (fp32 MFMA) + small
                  elementwise kernels;
@@ -24,20 +25,20 @@ from .squeeze import squeeze_op
 def gmm_backward(x, dist, prepared, g, gcol=None):
     """x: (B, D...) possibly a channel slice; g: (B, M) upstream; gcol: its column sums (M,) if the caller has them (the
     priors of one backward pass share g).  Returns (gx like x, {param: grad})."""
-    a, bm, cst, M, K, D = prepared
+    a, nm, cst, M, K, D = prepared
     xv, xbs = _hip.bview(x)
     B = xv.shape[0]
     r = torch.empty(B, M * K, device=xv.device, dtype=torch.float32)          # responsibilities x upstream
     ws = torch.empty(_hip.lib().cf_gmm_resp_ws_bytes(B, M, K, D), device=xv.device, dtype=torch.uint8)
-    _hip.call("cf_gmm_resp", _hip.p(xv), _hip.p(a), _hip.p(bm), _hip.p(cst), _hip.p(_hip.f32(g)), _hip.p(r), _hip.p(ws), B, M, K,
+    _hip.call("cf_gmm_resp", _hip.p(xv), _hip.p(a), _hip.p(nm), _hip.p(cst), _hip.p(_hip.f32(g)), _hip.p(r), _hip.p(ws), B, M, K,
               D, xbs, _hip.stream())
     dev, st, pp = xv.device, _hip.stream(), _hip.p
     MK = M * K
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-    # d/dx = -sum_mk r a (x a + bm) = -(x (r A2) + r AB): two (B x MK)(MK x D) products on cf_linear (fp32 MFMA; the
+    # d/dx = -sum_mk r a^2 (x + nm) = -(x (r A2) + r AB), nm = -mu: two (B x MK)(MK x D) products on cf_linear (fp32 MFMA; the
     # coefficient kernel writes A2 / AB transposed, as cf_linear's weight operand) and one combining kernel
     A2t, ABt = new(D, MK), new(D, MK)
-    _hip.call("cf_gmm_bwd_coeffs", pp(a), pp(bm), pp(A2t), pp(ABt), MK, D, 1, st)
+    _hip.call("cf_gmm_bwd_coeffs", pp(a), pp(nm), pp(A2t), pp(ABt), MK, D, 1, st)
     G1, G2 = new(B, D), new(B, D)
     _hip.call("cf_linear", pp(r), pp(A2t), None, None, pp(G1), B, MK, D, 0, st)
     _hip.call("cf_linear", pp(r), pp(ABt), None, None, pp(G2), B, MK, D, 0, st)
@@ -56,7 +57,7 @@ def gmm_backward(x, dist, prepared, g, gcol=None):
         gcol = _hip.f32(g).sum(0)
     g_w = new(M, K)
     wG = _hip.f32(dist.wG.detach()).reshape(M, K)
-    _hip.call("cf_gmm_bwd_params_w", pp(a), pp(bm), pp(sG), pp(S0), pp(S1), pp(S2), pp(wG), pp(_hip.f32(gcol)), pp(g_mu), pp(g_sigma),
+    _hip.call("cf_gmm_bwd_params_w", pp(a), pp(nm), pp(sG), pp(S0), pp(S1), pp(S2), pp(wG), pp(_hip.f32(gcol)), pp(g_mu), pp(g_sigma),
               pp(g_w), M, K, D, st)
     grads = {dist.mG: g_mu.view_as(dist.mG), dist.sG: g_sigma.view_as(dist.sG), dist.wG: g_w.view_as(dist.wG)}
     return gx.view(xv.shape), grads
@@ -65,7 +66,7 @@ def gmm_backward(x, dist, prepared, g, gcol=None):
 # ------------------------------------------------------------------------------------------------ flow step
 def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
-    planes: the step tape (y0, h1, h2, aux) written by cf_flow_step_fwd_taped, or None = recompute everything from x.
+    planes: the step tape (y0, h1, h2, aux) written by cf_flow_step_fwd_taped, or None = rebuild it from x with the same kernel.
     gsum: 1-element tensor sum(gld) (the same for every step of a backward pass), or None.
     Returns (dL/dx in the layout of x, {param: grad})."""
     C, H, W = shape
@@ -84,13 +85,21 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
     s_gh, s_gh2, s_gh1, s_gy = new(C), new(HID), new(HID), new(C)
     gzc = f(gz)
     if planes is None:
-        s_y0, s_h1, s_h2 = new(HALF), new(HID), new(HID)
-        _hip.call("cf_flow_step_bwd", pp(xv), pp(gzc), pp(f(gld)), pp(ws), pp(wsb), pp(gx), pp(s_y0), pp(s_h1), pp(s_h2),
-                  pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), B, C, H, W, xbs, int(squeeze), st)
-    else:
-        s_y0, s_h1, s_h2, aux = planes
-        _hip.call("cf_flow_step_bwd_taped", pp(gzc), pp(f(gld)), pp(wsb), pp(aux), pp(gx), pp(s_gh), pp(s_gh2), pp(s_gh1),
-                  pp(s_gy), B, C, H, W, st)
+        # recompute form (the forward kept only the step input): run the SAME taping forward kernel again into a scratch
+        # tape that lives for this step only - the ReLU masks and log-scales are then bit for bit the ones of the forward
+        # that produced the loss, whichever form (Winograd / direct, by batch size) the dispatch chose for the 3x3.
+        # (Round 2 rebuilt h2 inside the backward kernel in the direct form: under the Winograd forward, units within
+        # rounding of zero got another mask bit and a tensor's gradient could differ by 1e-3..1e-2 of its largest entry.)
+        from .flowsequential import step_tape
+        planes = step_tape(B, C, H, W, dev)
+        zs = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+        lds = torch.zeros(B, device=dev, dtype=torch.float32)
+        _hip.call("cf_flow_step_fwd_taped", pp(xv), pp(zs), pp(lds), pp(ws), pp(planes[0]), pp(planes[1]), pp(planes[2]),
+                  pp(planes[3]), B, C, H, W, xbs, int(squeeze), st)
+        del zs, lds
+    s_y0, s_h1, s_h2, aux = planes
+    _hip.call("cf_flow_step_bwd_taped", pp(gzc), pp(f(gld)), pp(wsb), pp(aux), pp(gx), pp(s_gh), pp(s_gh2), pp(s_gh1),
+              pp(s_gy), B, C, H, W, st)
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts, the four of a step in one call
     # (cf_step_wgrads: four k_wgrad launches, ONE reduce launch)
     e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)

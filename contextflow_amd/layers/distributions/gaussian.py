@@ -48,20 +48,20 @@ class StandardNormal(nn.Module):
 
 
 def gmm_prepare(mG, sG, wG):
-    """Per-call parameter transform on the device: a = 1/softplus(sG), bm = -mG*a, cst (M,K)."""
+    """Per-call parameter transform on the device: a = 1/softplus(sG), nm = -mG, cst (M,K)."""
     M, K = wG.shape
     D = mG.numel() // (M * K)
     dev = mG.device
     a = torch.empty(M * K, D, device=dev, dtype=torch.float32)
-    bm = torch.empty(M * K, D, device=dev, dtype=torch.float32)
+    nm = torch.empty(M * K, D, device=dev, dtype=torch.float32)
     cst = torch.empty(M * K, device=dev, dtype=torch.float32)
     _hip.call("cf_gmm_prepare", _hip.p(_hip.f32(mG)), _hip.p(_hip.f32(sG)), _hip.p(_hip.f32(wG)),
-              _hip.p(a), _hip.p(bm), _hip.p(cst), M, K, D, _hip.stream())
-    return a, bm, cst, M, K, D
+              _hip.p(a), _hip.p(nm), _hip.p(cst), M, K, D, _hip.stream())
+    return a, nm, cst, M, K, D
 
 
 def gmm_logprob(x, prepared, out=None, accumulate=False):
-    a, bm, cst, M, K, D = prepared
+    a, nm, cst, M, K, D = prepared
     x, xbs = _hip.bview(x)
     B = x.shape[0]
     assert x.numel() // max(B, 1) == D or B == 0
@@ -70,7 +70,7 @@ def gmm_logprob(x, prepared, out=None, accumulate=False):
         accumulate = False
     nbytes = _hip.lib().cf_gmm_ws_bytes(B, M, K, D)
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
-    _hip.call("cf_gmm_logprob", _hip.p(x), _hip.p(a), _hip.p(bm), _hip.p(cst), _hip.p(out), _hip.p(ws),
+    _hip.call("cf_gmm_logprob", _hip.p(x), _hip.p(a), _hip.p(nm), _hip.p(cst), _hip.p(out), _hip.p(ws),
               B, M, K, D, xbs, int(accumulate), _hip.stream())
     return out
 

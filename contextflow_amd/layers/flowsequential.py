@@ -33,7 +33,8 @@ from .squeeze import Squeeze, squeeze_op
 from .transforms import LogitTransform
 
 # training: the forward step kernel tapes y0 / h1 / h2 and the backward kernel loads them (no recompute of the two big
-# contractions).  False = the backward recomputes everything from the step input (4.5x less tape memory per step).
+# contractions).  False = the tape is dropped after the forward and rebuilt per step at backward time by the same kernel
+# (4.5x less tape memory per step, one more forward pass of kernel time; bitwise the same gradients).
 TAPE_PLANES = True
 
 
@@ -65,14 +66,14 @@ class FlowSequential(nn.Module):
         # forward is captured into a HIP graph and replayed (batches up to AUTO_GRAPH_MAX_BATCH); set False to disable
         self.auto_graph = True
         self._graphs = {}            # (shape, device) -> [stable calls, versions, GraphedFlow | None]
-        self._rng, self._rng_seed, self._rng_latched = {}, 0, {}   # device index -> position of the in-kernel noise stream / seed it was started under
+        self._rng_key = 0            # Philox key of the in-kernel noise (rank folded in); the stream position is drawn per call
 
     def __iter__(self):
         yield from self.sequence_modules
 
     def __getstate__(self):              # streams / cached plans are per-process runtime state
         d = self.__dict__.copy()
-        d["_plans"], d["_side"], d["step_events"], d["_rng"], d["_rng_latched"] = {}, {}, None, {}, {}
+        d["_plans"], d["_side"], d["step_events"] = {}, {}, None
         d["_prep"], d["_graphs"] = {}, {}
         return d
 
@@ -192,42 +193,18 @@ class FlowSequential(nn.Module):
             i += 1
         return ops
 
-    def _noise_epoch(self, dev):
-        """Detects `torch.manual_seed` - also with an unchanged seed value - since the last call: the seed itself, and the
-        Philox offset of torch's CUDA generator for `dev`, which a re-seed resets to 0 and which this class bumps by 4 per
-        check (nothing else needs it to stand still).  Returns (seed, epoch); the epoch counts the re-seeds seen."""
-        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        st = self._rng_latched.get(dev.index)
-        off = None
-        if not torch.cuda.is_current_stream_capturing():
-            gen = torch.cuda.default_generators[dev.index]
-            off = gen.get_offset()
-        if st is None:
-            st = self._rng_latched[dev.index] = [seed, -1, 0]           # [seed, last offset seen, epoch]
-        if st[0] != seed or (off is not None and off <= st[1]):
-            st[0], st[2] = seed, st[2] + 1
-        if off is not None:
-            gen.set_offset(off + 4)
-            st[1] = off
-        return seed, st[2]
-
-    def _rng_state(self, dev):
-        """Device-resident position of the in-kernel noise stream (one uint64 per device).  The Philox key follows
-        torch's seed: after `torch.manual_seed(s)` the stream restarts from position 0 under the key of s, so re-seeding
-        reproduces the noise as it does in the reference (uniform.py:32, gaussian.py:69).  Data-parallel ranks fold their
-        rank into the key: equal seeds on every rank still give every rank its own dequantisation / Augment noise."""
-        seed, epoch = self._noise_epoch(dev)
-        st = self._rng.get(dev.index)
-        if st is None:
-            st = self._rng[dev.index] = [torch.zeros(1, device=dev, dtype=torch.int64), epoch]
-        elif st[1] != epoch:
-            st[0].zero_()
-            st[1] = epoch
+    def _noise_nonce(self, dev):
+        """Per-call position of the in-kernel noise stream: one 63-bit draw from torch's CUDA generator of `dev`, consumed
+        the way torch's own random ops consume it.  So the noise follows `torch.manual_seed` (re-seeding reproduces it,
+        as it does for the reference's torch.rand / randn draws: uniform.py:32, gaussian.py:69), the generator moves on
+        by one draw per forward whatever the user does with it in between, and under graph capture torch registers the
+        generator with the graph: every replay reads a fresh value.  Data-parallel ranks fold their rank into the Philox
+        KEY: equal seeds on every rank still give every rank its own dequantisation / Augment noise."""
         rank = 0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank = torch.distributed.get_rank()
-        self._rng_seed = (seed ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
-        return st[0]
+        self._rng_key = (0x243F6A8885A308D3 ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+        return torch.empty(1, device=dev, dtype=torch.int64).random_()
 
     def _side_stream(self, dev):
         s = self._side.get(dev.index)
@@ -265,6 +242,9 @@ class FlowSequential(nn.Module):
         prepared = {}
         cache_ok = tape is None
         todo = []
+        # a capturing stream must not wait on an event recorded outside the capture - and need not: torch.cuda.graph
+        # synchronises the device before the capture begins, so cached tables are complete by then
+        capturing = torch.cuda.is_current_stream_capturing()
         for k, op in enumerate(plan):
             if op[0] == "step":
                 srcs = (op[1].NN, op[2].NN_t, op[2].NN_logs) + tuple(p for c in (op[3].NN[0], op[3].NN[2], op[3].NN[4]) for p in (c.weight, c.bias))
@@ -279,12 +259,13 @@ class FlowSequential(nn.Module):
             ver = tuple(t._version for t in srcs) + (dev.index,)
             hit = self._prep.get((key, k)) if cache_ok else None
             if hit is not None and hit[0] == ver:
-                prepared[k] = (hit[1], None)
-            else:
+                prepared[k] = (hit[1], None if capturing else hit[2])      # the producer's event stays with the entry: a later call on ANOTHER
+            else:                                    # stream is ordered against the side stream that wrote the buffers
                 todo.append((k, op, ver))
         pver = tuple(t._version for t in (self.dist.mG, self.dist.sG, self.dist.wG)) + (dev.index,)
         hit = self._prep.get((key, "prior")) if cache_ok else None
-        prior, ev_prior = (hit[1], None) if (hit is not None and hit[0] == pver) else (None, None)
+        prior, ev_prior = (hit[1], None if capturing else hit[2]) if (hit is not None and hit[0] == pver) else (None, None)
+        fresh = set()                # entries built by THIS call (their buffers get a record_stream below)
         if todo or prior is None:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -303,14 +284,16 @@ class FlowSequential(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(side)
                     prepared[k] = (buf, ev)
+                    fresh.add(k)
                     if cache_ok:
-                        self._prep[(key, k)] = (ver, buf)
+                        self._prep[(key, k)] = (ver, buf, ev)
                 if prior is None:
                     prior = self.dist.prepared()
                     ev_prior = torch.cuda.Event()
                     ev_prior.record(side)
+                    fresh.add("prior")
                     if cache_ok:
-                        self._prep[(key, "prior")] = (pver, prior)
+                        self._prep[(key, "prior")] = (pver, prior, ev_prior)
 
         # running log-dets: per-sample scalar terms / per-mixture terms (priors).  The first writer ASSIGNS (no zero-fill
         # launches): the pre-processing kernel for ld1, the first mixture kernel for ldM
@@ -335,9 +318,9 @@ class FlowSequential(nn.Module):
                         and N % 4 == 0 and (ca * H * W) % 4 == 0):
                     # noise drawn inside the kernel (Philox, keyed by torch's seed): dequantisation uniforms and the
                     # Augment channel's normals never travel through HBM as tensors of their own
-                    state = self._rng_state(dev)
-                    _hip.call("cf_preprocess_rng_fwd", _hip.p(xin), _hip.p(y), _hip.p(ldp), _hip.p(state), self._rng_seed, B, N,
-                              ca * H * W, (C + ca) * H * W, n1._t, n1._s, n2._t, n2._s, cst, st)
+                    nonce = self._noise_nonce(dev)
+                    _hip.call("cf_preprocess_rng_fwd", _hip.p(xin), _hip.p(y), _hip.p(ldp), _hip.p(nonce), self._rng_key, B, N,
+                              ca * H * W, (C + ca) * H * W, n1._t, n1._s, n2._t, n2._s, cst, 0, st)
                     if ldp is not ld1:
                         ld1 += ldp
                     x = y
@@ -357,21 +340,25 @@ class FlowSequential(nn.Module):
                 ws, ev = prepared[k]
                 if ev is not None:
                     main.wait_event(ev)
-                planes = None
                 if tape is not None:
                     ws, winv = ws
-                    # training: the forward kernel writes the tape, the backward kernel reads it - unless the planes of this
-                    # step would take more than 1/64 of the device memory (huge batches: recompute form, 4.5x less tape)
-                    if TAPE_PLANES and 18 * B * C * H * W <= torch.cuda.get_device_properties(dev).total_memory // 64:
-                        planes = step_tape(B, C, H, W, dev)
-                    tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws, winv, planes))
-                x, xbs = _hip.bview(x)
-                z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
-                if planes is not None:
+                    # training: the taping forward kernel writes the step tape and the backward kernel reads it.  If the
+                    # planes of this step would take more than 1/64 of the device memory (huge batches), or with
+                    # TAPE_PLANES = False, the tape is NOT kept (4.5x less memory per step): the backward then re-runs this
+                    # very kernel from the step input.  The forward is the taping kernel in both cases, so the masks the
+                    # backward uses are bit for bit those of the forward that produced the loss.
+                    keep = TAPE_PLANES and 18 * B * C * H * W <= torch.cuda.get_device_properties(dev).total_memory // 64
+                    planes = step_tape(B, C, H, W, dev)
+                    tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws, winv, planes if keep else None))
+                    x, xbs = _hip.bview(x)
+                    z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
                     _hip.call("cf_flow_step_fwd_taped", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), _hip.p(planes[0]),
                               _hip.p(planes[1]), _hip.p(planes[2]), _hip.p(planes[3]), B, C, H, W, xbs, int(sq), st)
+                    del planes
                     x = z
                     continue
+                x, xbs = _hip.bview(x)
+                z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
                 events = self.step_events
                 if events is not None:       # HIP events on the launch stream, bracketing exactly this kernel
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -433,11 +420,11 @@ class FlowSequential(nn.Module):
                 for u in t:
                     yield from _bufs(u)
 
-        for v in prepared.values():
-            if v[1] is not None:
+        for k, v in prepared.items():
+            if k in fresh:
                 for buf in _bufs(v[0]):
                     buf.record_stream(main)
-        if ev_prior is not None:
+        if "prior" in fresh:
             for buf in prior:
                 if torch.is_tensor(buf):
                     buf.record_stream(main)
@@ -481,7 +468,8 @@ class FlowSequential(nn.Module):
         ~20 launches of a few microseconds of work each).  Conditions: same shape / dtype / device as the previous calls,
         parameters unchanged since (version counters), in-kernel noise (no injected test noise), no event probes, not
         already capturing.  Anything else runs eagerly, and a parameter update drops the graph."""
-        if (not self.auto_graph or self.step_events is not None or x.dim() != 4 or x.shape[0] == 0
+        from . import coupling as _cpl
+        if (not self.auto_graph or self.step_events is not None or _cpl.VIT_EVENTS is not None or x.dim() != 4 or x.shape[0] == 0
                 or x.shape[0] > self.AUTO_GRAPH_MAX_BATCH or torch.cuda.is_current_stream_capturing()):
             return None
         for m in self.sequence_modules:
@@ -489,8 +477,7 @@ class FlowSequential(nn.Module):
             if d is not None and getattr(d, "fixed_noise", None) is not None:
                 return None
         gkey = (tuple(x.shape), x.dtype, x.device)
-        ver = self._versions() + self._noise_epoch(x.device)   # the Philox key is a kernel argument baked into the graph,
-        #                                                        and a re-seed restarts the stream: both drop the graph
+        ver = self._versions()
         st = self._graphs.get(gkey)
         if st is None or st[1] != ver:
             if len(self._graphs) >= 8:                   # bounded: each graph owns its intermediates
@@ -504,12 +491,13 @@ class FlowSequential(nn.Module):
             st[2] = GraphedFlow(self, x, warmup=1)
         return st[2]
 
-    def capture_train_step(self, example_input, loss_fn, optimizer, warmup=3):
+    def capture_train_step(self, example_input, loss_fn, optimizer, warmup=1):
         """One whole training step - forward, loss, hand-written backward, optimizer update - captured into ONE HIP graph
         (at the reference's batch of 256 a step is ~330 launches of a few microseconds each: launch-bound).  Returns
         `step(x, *loss_args) -> loss` that copies its arguments into static buffers and replays; `loss_fn(logp, *loss_args)`
         maps the (B, M) log-densities to a scalar.  The optimizer must be capturable (`torch.optim.AdamW(..., capturable=
-        True)`); ActNorm layers must be initialised (run one forward first)."""
+        True)`); ActNorm layers must be initialised (run one forward first).  The first call runs `warmup` eager steps
+        (real updates; default 1) and captures; see GraphedTrainStep."""
         return GraphedTrainStep(self, example_input, loss_fn, optimizer, warmup)
 
     def log_prob(self, input, context=None):
@@ -572,10 +560,13 @@ class GraphedFlow:
         with torch.no_grad():
             s = torch.cuda.Stream(device=example.device)
             s.wait_stream(torch.cuda.current_stream(example.device))
-            with torch.cuda.stream(s):                 # warm-up off the default stream: first-use attribute calls,
-                for _ in range(warmup):               # allocator pools, plan construction
-                    flow._forward_fused(self.static_in, None)
-            torch.cuda.current_stream(example.device).wait_stream(s)
+            gen = torch.cuda.default_generators[example.device.index]
+            gstate = gen.get_state()                   # the warm-up passes draw noise positions nobody sees: hand the
+            with torch.cuda.stream(s):                 # generator back as it was, so that capturing is invisible in the
+                for _ in range(warmup):               # noise sequence (same seed => same noise, captured or not)
+                    flow._forward_fused(self.static_in, None)       # warm-up off the default stream: first-use attribute
+            torch.cuda.current_stream(example.device).wait_stream(s)   # calls, allocator pools, plan construction
+            gen.set_state(gstate)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.static_z, self.static_logp = flow._forward_fused(self.static_in, None)
@@ -587,17 +578,28 @@ class GraphedFlow:
 
 
 class GraphedTrainStep:
-    """See FlowSequential.capture_train_step."""
+    """See FlowSequential.capture_train_step.
 
-    def __init__(self, flow, example, loss_fn, optimizer, warmup=3, loss_args=()):
+    First call: `warmup` (default 1) EAGER training steps on the given batch - real optimizer updates, off the default
+    stream - then the capture of one more step (a capture records, it does not execute: no update).  It returns the loss
+    of the last eager step, so with the default warmup the first call is exactly one update, like every later call.
+    Later calls replay.  A replay changes the parameters on the device without moving their version counters, which
+    the evaluation caches of the flow key on (packed step tables, mixture tables, auto-captured forward graphs): every
+    call therefore ends with `flow.invalidate_caches()`, and a `log_prob` between training steps sees the current
+    parameters."""
+
+    def __init__(self, flow, example, loss_fn, optimizer, warmup=1, loss_args=()):
         _hip.require_device(example)
         if not flow._fusable() and not flow._specialist():
             raise RuntimeError("capture_train_step needs initialised ActNorms: run one forward first")
+        if warmup < 1:
+            raise ValueError("capture_train_step: warmup must be >= 1 (the first call returns the loss of its last eager step)")
         self.flow, self.loss_fn, self.opt = flow, loss_fn, optimizer
         self.static_in = example.detach().clone()
         self.static_args = None
         self.graph = None
         self.warmup = warmup
+        self.updates = 0             # optimizer updates performed through this object
 
     def _step(self):
         # grads start as None: the autograd engine then TAKES the gradient buffers the backward returns (allocated from
@@ -619,17 +621,21 @@ class GraphedTrainStep:
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):                   # warm-up steps are real optimizer steps
                 for _ in range(self.warmup):
-                    self._step()
+                    first = self._step().detach().clone()
             torch.cuda.current_stream(dev).wait_stream(s)
+            self.updates += self.warmup
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.static_loss = self._step()
-            return self.static_loss
+            self.flow.invalidate_caches()
+            return first
         self.static_in.copy_(x)
         for dst, src in zip(self.static_args, loss_args):
             if torch.is_tensor(dst):
                 dst.copy_(src)
         self.graph.replay()
+        self.updates += 1
+        self.flow.invalidate_caches()
         return self.static_loss
 
 

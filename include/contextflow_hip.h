@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 3
+#define CF_ABI_VERSION 4
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -52,11 +52,13 @@ int cf_preprocess_fwd(const float* x, const float* u, float* y, float* ldj, int 
                       float t1, float s1, float t2, float s2, float ldj_const, cf_stream_t stream);
 /* the same fused pre-processing with the noise drawn inside the kernel (Philox4x32-10; u ~ U[0,1) per element,
  * eps ~ N(0,1) for the `aug_n` elements of the Augment channel appended after the N image elements, whose
- * -log q(eps) is added to ldj).  rng_state: one uint64 on the device (the stream position, advanced by the call -
- * graph replays therefore draw fresh noise); seed: the generator key.  N, aug_n, y_bstride multiples of 4.     */
+ * -log q(eps) is added to ldj).  rng_state: one uint64 on the device = the stream position of THIS call (the Philox
+ * counter's high half); seed: the Philox key.  advance != 0: the call also increments rng_state[0] on the stream (a
+ * self-advancing stream; graph replays then draw fresh noise); advance == 0: the caller supplies a fresh position per
+ * call (FlowSequential draws it from torch's CUDA generator).  N, aug_n, y_bstride multiples of 4.              */
 int cf_preprocess_rng_fwd(const float* x, float* y, float* ldj, uint64_t* rng_state, uint64_t seed, int B, int N,
                           int aug_n, int64_t y_bstride, float t1, float s1, float t2, float s2, float ldj_const,
-                          cf_stream_t stream);
+                          int advance, cf_stream_t stream);
 /* out[b] = 0.5*sum(eps^2) + 0.5*N*log(2 pi)  = -log N(eps;0,I)  Augment ldj (augment.py:14-18,
  * distributions/gaussian.py:50-54); eps rows have stride eps_bstride.                              */
 int cf_std_normal_nll(const float* eps, float* out, int B, int N, int64_t eps_bstride, cf_stream_t stream);
@@ -110,41 +112,42 @@ int cf_coupling_apply(const float* x, const float* h, float* z, float* ldj, int 
                       cf_stream_t stream);
 
 /* ---- GaussianMixtureDistribution.log_prob (layers/distributions/gaussian.py:138-161) ------------ */
-/* parameter transform, once per call: a = 1/softplus(sG), bm = -mG*a (both (M*K, D)),
+/* parameter transform, once per call: a = 1/softplus(sG), nm = -mG (both (M*K, D)),
  * cst[m,k] = log_softmax(wG[m])[k] - sum_d log softplus(sG) - D/2 log(2 pi).                         */
-int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, float* bm, float* cst,
+int cf_gmm_prepare(const float* mG, const float* sG, const float* wG, float* a, float* nm, float* cst,
                    int M, int K, int D, cf_stream_t stream);
-/* out[b,m] (+)= logsumexp_k( cst[m,k] - 0.5 * sum_d (x[b,d]*a + bm)^2 );  K <= 16.
+/* out[b,m] (+)= logsumexp_k( cst[m,k] - 0.5 * sum_d ((x[b,d] + nm)*a)^2 );  K <= 16.  (x - mu first, as the reference does:
+ * the difference is exact for fitted means; gaussian.py:142-161.)
  * accumulate != 0 adds into out (used to fold SplitPrior's ldj into the running (B,M) log-det).
  * ws: optional workspace of cf_gmm_ws_bytes(B,M,K,D) bytes; when given (and non-zero sized) the
  * D axis is split over workgroups to fill the chip at small B; NULL = single pass.                  */
 int64_t cf_gmm_ws_bytes(int B, int M, int K, int D);
-int cf_gmm_logprob(const float* x, const float* a, const float* bm, const float* cst, float* out, void* ws,
+int cf_gmm_logprob(const float* x, const float* a, const float* nm, const float* cst, float* out, void* ws,
                    int B, int M, int K, int D, int64_t x_bstride, int accumulate, cf_stream_t stream);
 
-/* q[b, m*K+k] = sum_d (x[b,d]*a + bm)^2 only (B x M*K, dense): the backward pass rebuilds the responsibilities
+/* q[b, m*K+k] = sum_d ((x[b,d] + nm)*a)^2 only (B x M*K, dense): the backward pass rebuilds the responsibilities
  * softmax_k(cst - q/2) from it.                                                                        */
-int cf_gmm_quad(const float* x, const float* a, const float* bm, float* q, int B, int M, int K, int D,
+int cf_gmm_quad(const float* x, const float* a, const float* nm, float* q, int B, int M, int K, int D,
                 int64_t x_bstride, cf_stream_t stream);
 /* backward, first half in one call: r (B, M*K) = softmax_k(cst - q/2) * g[b, m] - the component responsibilities times the
  * upstream gradient g (B, M); the reduction over D is split over workgroups when B alone does not fill the chip.
  * ws: cf_gmm_resp_ws_bytes(...) bytes.                                                                          */
-/* elementwise pieces of the mixture backward: A2 = a a, AB = a bm (M*K, D);  gx = -(x G1 + G2) with G1 = r A2, G2 = r AB
+/* elementwise pieces of the mixture backward: A2 = a a, AB = a a nm (M*K, D);  gx = -(x G1 + G2) with G1 = r A2, G2 = r AB
  * (B, D);  g_mu / g_sG (M*K, D) from the batch sums S0 = sum_b r (M*K), S1 = r^T x, S2 = r^T x^2 (M*K, D):
- * g_mu = a (a S1 + bm S0), g_sG = a (a^2 S2 + 2 a bm S1 + bm^2 S0 - S0) sigmoid(sG).                              */
-int cf_gmm_bwd_coeffs(const float* a, const float* bm, float* A2, float* AB, int MK, int D, int transposed,
+ * g_mu = a^2 (S1 + nm S0), g_sG = a (a^2 (S2 + 2 nm S1 + nm^2 S0) - S0) sigmoid(sG).                              */
+int cf_gmm_bwd_coeffs(const float* a, const float* nm, float* A2, float* AB, int MK, int D, int transposed,
                       cf_stream_t stream);      /* transposed != 0: A2, AB are written as (D, M*K): the Wt operand of cf_linear */
 int cf_gmm_bwd_gx(const float* x, const float* G1, const float* G2, float* gx, int B, int D, int64_t x_bstride,
                   cf_stream_t stream);
-int cf_gmm_bwd_params(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
+int cf_gmm_bwd_params(const float* a, const float* nm, const float* sG, const float* S0, const float* S1, const float* S2,
                       float* gmu, float* gsig, int MK, int D, cf_stream_t stream);
 /* the same + the mixture-weight gradient gw (M, K) = S0 - gcol softmax(wG) (gaussian.py:149-153: the log-weights enter through
  * log_softmax; gcol (M) = column sums of the upstream gradient (B, M)) in the same launch */
-int cf_gmm_bwd_params_w(const float* a, const float* bm, const float* sG, const float* S0, const float* S1, const float* S2,
+int cf_gmm_bwd_params_w(const float* a, const float* nm, const float* sG, const float* S0, const float* S1, const float* S2,
                         const float* wG, const float* gcol, float* gmu, float* gsig, float* gw, int M, int K, int D,
                         cf_stream_t stream);
 int64_t cf_gmm_resp_ws_bytes(int B, int M, int K, int D);
-int cf_gmm_resp(const float* x, const float* a, const float* bm, const float* cst, const float* g, float* r, void* ws, int B,
+int cf_gmm_resp(const float* x, const float* a, const float* nm, const float* cst, const float* g, float* r, void* ws, int B,
                 int M, int K, int D, int64_t x_bstride, cf_stream_t stream);
 /* prior sampling (gaussian.py:163-169): out[n,:] = mG[rows[n],:] + softplus(sG[rows[n],:]) * eps[n,:];
  * rows[n] = m*K + k_n (int64, component drawn by the caller), eps ~ N(0,1) supplied by the caller.      */
@@ -193,17 +196,13 @@ int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, 
                      int64_t z_bstride, cf_stream_t stream);
 
 /* ---- backward of the fused step (training: experiment_cl.py:130-136) ------------------------------
- * One kernel per step: recomputes the forward in LDS, then the data-gradient chain on fp32 MFMA with
- * transposed weight fragments (cf_flow_step_bwd_prepare), writes g_x (B,C,H,W; squeezed layout when
- * in_squeeze) and the operand planes the weight gradients contract over, each (B, rows, H*W) dense:
- * s_y0 (C/2), s_h1, s_h2, s_gh2, s_gh1 (2C), s_gh, s_gy (C).  gz: dL/dz (B,C,H,W) dense; gld: dL/d(log-det) (B,).
- * The weight gradients are plain GEMMs over (batch x pixels) left to the caller (rocBLAS).              */
+ * cf_flow_step_bwd_prepare packs the TRANSPOSED weight fragments of the data-gradient chain (workspace of
+ * cf_flow_step_bwd_ws_bytes bytes).  The generalist's backward is the taped pair below; a caller that kept only the step
+ * input re-runs cf_flow_step_fwd_taped into a scratch tape at backward time (same kernel => the very masks of the
+ * forward).  gz: dL/dz (B,C,H,W) dense; gld: dL/d(log-det) (B,).                                               */
 int64_t cf_flow_step_bwd_ws_bytes(int C, int H, int W);
 int cf_flow_step_bwd_prepare(const float* Wm, const float* logs, const float* w1, const float* w2, const float* w3,
                              void* wsb, int C, int H, int W, cf_stream_t stream);
-int cf_flow_step_bwd(const float* x, const float* gz, const float* gld, const void* ws, const void* wsb, float* gx,
-                     float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy,
-                     int B, int C, int H, int W, int64_t x_bstride, int in_squeeze, cf_stream_t stream);
 
 /* Taped training pair (experiment_cl.py:130-136: forward + cost.backward()).
  * cf_flow_step_fwd_taped = cf_flow_step_fwd that also writes the tape of the step:
@@ -234,7 +233,7 @@ int cf_step_param_grads(const float* gWp, const float* gbp, const float* Wm, con
 /* weight gradient as a split-K MFMA GEMM over (sample, pixel):
  *   gw[t][m][n] = sum_{b,p} A[b][m][p] * Bm[b][n][src_t(p)],  t < taps (1, or 9 = 3x3 reflect-shifted pixels)
  *   gbias[m]    = sum_{b,p} A[b][m][p]                         (optional)
- * A: (B, MR, H*W), Bm: (B, NR, H*W) dense (planes written by cf_flow_step_bwd); gw: (taps, MR, NR) fp32.
+ * A: (B, MR, H*W), Bm: (B, NR, H*W) dense (planes written by cf_flow_step_bwd_taped / the step tape); gw: (taps, MR, NR) fp32.
  * ws: cf_wgrad_ws_bytes(...) bytes for the split-K partials, summed in a fixed order (reproducible).
  * H x W in {16x16, 8x8, 4x4}, NR <= 128.                                                               */
 int64_t cf_wgrad_ws_bytes(int B, int MR, int NR, int H, int W, int taps);
