@@ -31,6 +31,9 @@ LABEL = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap":
 #              = 2 * 40 C^2 HW flop  (cifar10: 5 242 880 at every level; mnist: 1 310 720 at C = 8, 5 242 880 at C = 32);
 #  smap: k_vit_step = Conv1x1 26x26x8 + SimpleViT linears 454 688 + attention QK^T / PV 12 288 MAC = 944 768 flop.
 VIT_FLOP_PER_SAMPLE = {"smap": 2 * (26 * 26 * 8 + 454688 + 12288)}
+# what k_vit_step's MFMAs execute per sample (2 148 v_mfma_f32_32x32x2_f32 of 4 096 flop per wave of 8 samples)
+VIT_MFMA_FLOP_PER_SAMPLE = {"smap": 2148 * 4096 // 8}
+TRAFFIC_JSON = {"cifar10": "r2_prof3_traffic.json", "mnist": "r2_mnist3_traffic.json", "smap": "r2_smap1_traffic.json"}
 
 
 def step_flop(C, HW):
@@ -143,42 +146,46 @@ def kernel_events(model, name):
 
 
 def roofline(events, name, dt):
-    """Roofline of the dominant kernel (fp32 MFMA): algorithmic flop of the launches / their measured durations."""
+    """Roofline of the dominant kernel (fp32 MFMA) from the HIP events around its launches.  `achieved` / `frac` count the
+    multiply-adds the matrix pipe EXECUTED (the library reports them per launch: cf_flow_step_macs - the Winograd
+    F(2x2,3x3) form of the 3x3 runs 16 of its 36 C^2 HW), so frac <= 1 by construction; `algorithmic_tflops` is the
+    reference's direct-convolution flop over the same time and `algorithmic_speedup` their ratio."""
     if not events:
         return None
+    from contextflow_amd.layers import _hip
+    L = _hip.lib()
     vit = name in VIT_FLOP_PER_SAMPLE
     ms = sum(e[0].elapsed_time(e[1]) for e in events)
-    flop = sum(e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4])) for e in events)
-    ach = flop / (ms * 1e-3) / 1e12
-    # multiply-adds actually issued to the matrix pipe: the Winograd F(2x2,3x3) form of the 3x3 executes 32 of its 72 C^2 HW
-    # (cf_flow_step_fwd: 16x16 images always, 8x8 / 4x4 from 1024 / 2048 samples per launch)
-    wino = lambda e: (not vit) and os.environ.get("CONTEXTFLOW_DIRECT_CONV") != "1" and (
-        (e[3] in (8, 16) and e[4] == 256) or (e[3] == 32 and e[2] >= 1024) or (e[3] == 64 and e[2] >= 2048))
-    flop_exec = sum(e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4]) * (0.5 if wino(e) else 1.0)) for e in events)
-    ach_exec = flop_exec / (ms * 1e-3) / 1e12
+    alg = lambda e: e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4]))
+    hw = lambda e: int(round(math.sqrt(e[4])))
+    exe = lambda e: e[2] * (VIT_MFMA_FLOP_PER_SAMPLE[name] if vit else 2 * L.cf_flow_step_macs(e[2], e[3], hw(e), hw(e), 0))
+    flop, flop_exec = sum(alg(e) for e in events), sum(exe(e) for e in events)
+    ach, ach_exec = flop / (ms * 1e-3) / 1e12, flop_exec / (ms * 1e-3) / 1e12
     per = {}
     for e in events:
         k = "vit" if vit else "C%d" % e[3]
-        per.setdefault(k, [0.0, 0.0])
+        per.setdefault(k, [0.0, 0.0, 0.0])
         per[k][0] += e[0].elapsed_time(e[1])
-        per[k][1] += e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4]))
+        per[k][1] += alg(e)
+        per[k][2] += exe(e)
     traffic = None
-    tp = os.path.join(ROOT, "profiles", {"cifar10": "traffic.json", "mnist": "r2_mnist3_traffic.json",
-                                         "smap": "r2_smap1_traffic.json"}.get(name, "none"))
+    tp = os.path.join(ROOT, "profiles", TRAFFIC_JSON.get(name, "none"))
     if os.path.exists(tp):          # PMC-measured HBM bytes of the dominant kernel (profiles/, tools/profile.sh), scaled to this run's launch size
         tj = json.load(open(tp))
         avg_b = sum(e[2] for e in events) / len(events)
         traffic = int(tj["k_flow_step_bytes_per_launch"] / tj["batch_per_launch"] * avg_b)
-    return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-            # `achieved` counts the ALGORITHMIC flop of the reference's direct convolutions (SURVEY.md 8d); `executed` is what
-            # the matrix pipe really ran (Winograd form of the 3x3: half of it) - frac > 1 is the algorithm, not the hardware
-            "executed": round(ach_exec, 2), "executed_frac": round(ach_exec / PEAK_F32_MFMA_TFLOPS, 4),
-            "algorithm": "direct" if abs(ach_exec - ach) < 1e-9 else "Winograd F(2x2,3x3) for the 3x3 of the coupling nets (fp32, 40 of 80 C^2 HW multiply-adds per sample-step executed)",
+    return {"bound": "mfma", "achieved": round(ach_exec, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach_exec / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "basis": "multiply-adds executed by the matrix pipe (x2) / HIP-event time of the launches",
+            "algorithmic_tflops": round(ach, 2), "algorithmic_speedup": round(ach / ach_exec, 3),
+            "algorithm": ("as the reference computes it" if abs(ach_exec - ach) < 1e-9 * ach else
+                          "Winograd F(2x2,3x3) for the 3x3 of the coupling nets where dispatched (fp32; 20 of 40 C^2 HW multiply-adds per sample-step executed)")
+                         if not vit else "52-wide features in 64-row MFMA tiles, K 52 -> 56 (executed > algorithmic: padding)",
             "kernel": "k_vit_step (Conv1x1+ActNorm+TransCoupling fused, v_mfma_f32_32x32x2_f32)" if vit else
                       "k_flow_step / k_flow_step_small (Conv1x1+ActNorm+Coupling fused; v_mfma_f32_32x32x2_f32 / 16x16x4_f32, the 3x3 in Winograd F(2x2,3x3) form on 16x16x4 tiles)",
             "launches": len(events), "avg_launch_ms": round(ms / len(events), 4),
-            "per_level_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
+            "per_level_executed_tflops": {k: round(v[2] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
+            "per_level_algorithmic_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
             "kernel_time_share": round(ms * 1e-3 / dt, 3)}
 
 
@@ -221,17 +228,87 @@ def secondary_throughput(name, dev, G, chunk, steps, warmup, cpu):
     return out
 
 
-def secondary_training(name, dev, B, iters, graph):
-    """SURVEY.md 8(f)1, the caller right after the path (experiment_cl.py:123-136): one optimisation step = forward,
-    loss (cross-entropy over the M class mixtures of logp / D), hand-written backward, AdamW - as ONE captured HIP graph (FlowSequential.capture_train_step) at a saturating
-    batch and at the reference's batch of 256, and eagerly launched (the reference's loop as written; host-bound when the
-    box's cores are busy)."""
+def reference_loss(name):
+    """The reference's training loss on logp = dim_inv * log_prob (NaN scrubbed first: `logp[logp != logp] = 0`, written
+    as a select so that it can be captured in a graph).  Classification flows (experiment_cl.py:127-133, alpha = 1e-3):
+    CE(logp, gt) + alpha * mean(-logsigmoid(logsumexp_m logp)); anomaly detection without labels (experiment_ad.py:61,
+    204-210, alpha = 1e2): alpha * mean(-logsigmoid(logp))."""
+    inv = 1.0 / DIMS[name]
+    F = torch.nn.functional
+
+    def scrub(logp):
+        logp = logp * inv
+        return torch.where(logp != logp, torch.zeros_like(logp), logp)
+    if name in ("smap", "atm"):
+        return lambda logp, y: 1e2 * (-F.logsigmoid(scrub(logp))).mean()
+
+    def cl(logp, y):
+        logp = scrub(logp)
+        return F.cross_entropy(logp, y) + 1e-3 * (-F.logsigmoid(torch.logsumexp(logp, -1))).mean()
+    return cl
+
+
+def train_flop_per_sample(name, B):
+    """(algorithmic, executed) dense flop per sample of one training step.  Conv flows: per flow step forward + data
+    gradients + weight gradients = 3 x 80 C^2 HW algorithmic; executed as the library reports for the kernels dispatched
+    at this batch size (Winograd form in the taping forward and in the 3x3 weight gradient, direct transposed 3x3 in the
+    data-gradient chain).  Transformer flow: 3 x the forward's Linear / attention flop (the backward re-runs the
+    conditioner on top of that; not counted)."""
+    from contextflow_amd.layers import _hip
+    L = _hip.lib()
+    if name in VIT_FLOP_PER_SAMPLE:
+        f = 3 * total_flop_per_sample(name)
+        return f, f
+    levels = {"cifar10": [(16, 16, 4), (32, 8, 4), (64, 4, 4)], "mnist": [(8, 16, 2), (32, 8, 2)]}[name]
+    alg = sum(3 * step_flop(C, H * H) * n for C, H, n in levels)
+    exe = sum(2 * n * (L.cf_flow_step_macs(B, C, H, H, 1) + L.cf_flow_step_macs(B, C, H, H, 2) + L.cf_step_wgrads_macs(B, C, H, H))
+              for C, H, n in levels)
+    return alg, exe
+
+
+def cpu_train_baseline(name, B=256, iters=5, warmups=1):
+    """The oracle's forward under torch.autograd + AdamW on the host cores: one training step of the same loss on one
+    batch (`kind: "port"`), median of `iters`."""
+    from oracle import flow_oracle as fo, params as op
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ops, prior, M = fo.program(name)
+    params = op.gen_params(op.param_spec(ops, prior, M), seed=0)
+    g = torch.Generator().manual_seed(0)
+    C, H, W = fo.CONFIGS[name][0]
+    x = torch.rand(B, C, H, W, generator=g) if name in ("smap", "atm") else torch.randint(0, 256, (B, C, H, W), generator=g).float()
+    u = torch.rand(B, C, H, W, generator=g)
+    eps = [torch.randn(B, 1, H, W, generator=g)]
+    gt = torch.randint(0, M, (B,), generator=g)
+    with torch.no_grad():
+        fo.flow_forward(ops, params, x, u, eps, init_actnorm=True)
+    leaves = [v.requires_grad_(True) for v in params.values() if v.is_floating_point()]
+    opt = torch.optim.AdamW(leaves, lr=1e-4)
+    loss_fn = reference_loss(name)
+    times = []
+    for i in range(warmups + iters):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss_fn(fo.flow_forward(ops, params, x, u, eps)[1], gt).backward()
+        opt.step()
+        if i >= warmups:
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(B / med, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "median of %d training steps (oracle forward under torch.autograd, the reference's loss, AdamW) on one batch of "
+                      "%d %s-shaped samples after %d warm-up, torch %d threads" % (iters, B, name, warmups, cores)}
+
+
+def secondary_training(name, dev, B, iters, graph, cpu=False):
+    """SURVEY.md 8(f)1, the caller right after the path (experiment_cl.py:123-136 / experiment_ad.py:199-213): one
+    optimisation step = forward, the reference's loss, hand-written backward, AdamW - as ONE captured HIP graph
+    (FlowSequential.capture_train_step) at a saturating batch and at the reference's batch of 256, and eagerly launched
+    (the reference's loop as written; host-bound when the box's cores are busy)."""
     model, cfg = build(name, dev)
     x = synth(name, B, dev, seed=4000)
-    M = 10
+    M = model.mixtures
     gt = torch.randint(0, M, (B,), device=dev)
-    inv = 1.0 / DIMS[name]
-    loss_fn = lambda logp, y: torch.nn.functional.cross_entropy(logp * inv, y)
+    loss_fn = reference_loss(name)
     # the reference's optimizer (model.py:289: AdamW(params, lr)); under capture its fused implementation: ONE multi-tensor
     # kernel per step (the foreach form falls back to two launches per parameter on the 0-dim step tensors of capturable mode)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True) if graph and os.environ.get("CF_BENCH_FOREACH_ADAMW") != "1" \
@@ -254,16 +331,103 @@ def secondary_training(name, dev, B, iters, graph):
         loss = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    # algorithmic dense work of a step: forward + data gradients + weight gradients = 3x the forward contractions
-    tf = 3 * total_flop_per_sample(name) * B / dt / 1e12
+    alg, exe = train_flop_per_sample(name, B)
+    tf_alg, tf_exe = alg * B / dt / 1e12, exe * B / dt / 1e12
     out = {"metric": "samples/s training step (fwd + bwd + AdamW), %s" % LABEL[name], "value": round(B / dt, 1), "unit": "samples/s",
            "config": {"workload": "%s --coupling %s" % (name, cfg["coupling"]), "batch": B, "iters": iters,
-                      "launch": "one captured HIP graph" if graph else "eager"},
+                      "launch": "one captured HIP graph" if graph else "eager",
+                      "loss": "experiment_ad.py:207 (1e2 * -logsigmoid(logp / D), NaN scrubbed)" if M == 1 else
+                              "experiment_cl.py:128-133 (NaN scrub, CE + 1e-3 * -logsigmoid(logsumexp))"},
            "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss), 5),
-           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                        "basis": "whole step, 3x the forward's dense flop (forward, data gradients, weight gradients)"}}
+           "roofline": {"bound": "mfma", "achieved": round(tf_exe, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf_exe / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "algorithmic_tflops": round(tf_alg, 2), "algorithmic_speedup": round(tf_alg / tf_exe, 3),
+                        "basis": "whole step: dense multiply-adds executed by the matrix pipe (forward, data gradients, weight gradients) / wall time"}}
+    if cpu:
+        out["cpu_baseline"] = cpu_train_baseline(name)
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     del model, x, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+SPECIALIST_CTX = {"cifar10": dict(contexts=[15, 5], enc_emb="onehot", enc_type="uniform", contextflow=True)}
+
+
+def cpu_specialist_baseline(name, B=256, iters=5, warmups=1):
+    """The oracle's specialist forward (context encoders, per-sample Conv1x1 / ActNorm, CN(c) branches, context-shifted
+    mixtures) on the host cores, one batch."""
+    from oracle import flow_oracle as fo, params as op
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ctx = SPECIALIST_CTX[name]
+    ops, prior, M = fo.program(name)
+    params = op.gen_params(op.param_spec(ops, prior, M, ctx), seed=0)
+    g = torch.Generator().manual_seed(0)
+    C, H, W = fo.CONFIGS[name][0]
+    x = torch.randint(0, 256, (B, C, H, W), generator=g).float()
+    u = torch.rand(B, C, H, W, generator=g)
+    eps = [torch.randn(B, 1, H, W, generator=g)]
+    context = torch.stack([torch.randint(0, k, (B,), generator=g) for k in ctx["contexts"]], 1)
+    n_enc = sum(1 for o in ops if o[0] in ("conv1x1", "actnorm", "coupling", "transcoupling"))
+    cn = lambda: [torch.rand(B, fo.ctx_width(ctx), generator=g) for _ in range(n_enc)]
+    times = []
+    with torch.no_grad():
+        fo.flow_forward(ops, params, x, u, eps, init_actnorm=True, ctx=ctx, context=context, cnoise=cn())
+        for i in range(warmups + iters):
+            noise = cn()
+            t0 = time.perf_counter()
+            fo.flow_forward(ops, params, x, u, eps, ctx=ctx, context=context, cnoise=noise)
+            if i >= warmups:
+                times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(B / med, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "median of %d specialist forward passes (oracle/flow_oracle.py, contexts %s, %s + %s, contextflow) over one batch of %d "
+                      "after %d warm-up, torch %d threads" % (iters, ctx["contexts"], ctx["enc_emb"], ctx["enc_type"], B, warmups, cores)}
+
+
+def secondary_specialist(name, dev, B, iters, cpu):
+    """the context-conditioned (specialist) forward under --contextflow (README: generalist frozen, one
+    context encoder + CN net per layer => per-sample Conv1x1 / ActNorm / conditioner bias, context-shifted mixtures)."""
+    import contextflow_amd as cfa
+    ctx = SPECIALIST_CTX[name]
+    torch.manual_seed(0)
+    cfg, ds, M = cfa.preset_config(name)
+    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type=ctx["enc_type"], contextflow=ctx["contextflow"])
+    model = cfa.create_model(cfg, ds, M, contexts=ctx["contexts"]).to(dev).eval()
+    for p in model.parameters():                       # CN nets are zero-initialised (model.py): perturb so that they do something
+        if p.abs().max() == 0:
+            p.data.normal_(0, 0.02)
+    x = synth(name, B, dev, seed=5000)
+    context = torch.stack([torch.randint(0, k, (B,), device=dev) for k in ctx["contexts"]], 1)
+    ev = []
+    with torch.no_grad():
+        for _ in range(2):
+            model(x, context)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            _, logp = model(x, context)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    from contextflow_amd.layers import _hip
+    L = _hip.lib()
+    levels = [(16, 16, 4), (32, 8, 4), (64, 4, 4)]
+    alg = total_flop_per_sample(name)
+    exe = sum(2 * n * L.cf_flow_step_macs(B, C, H, H, 0) for C, H, n in levels)
+    tf_alg, tf_exe = alg * B / dt / 1e12, exe * B / dt / 1e12
+    out = {"metric": "samples/s specialist fwd+logdet (--contextflow), %s" % LABEL[name], "value": round(B / dt, 1), "unit": "samples/s",
+           "config": {"workload": "%s --coupling %s --contextflow, enc %s + %s, contexts %s" % (name, cfg["coupling"], ctx["enc_emb"], ctx["enc_type"], ctx["contexts"]),
+                      "batch": B, "iters": iters},
+           "ms_per_step": round(dt * 1e3, 3), "finite": bool(torch.isfinite(logp).all()),
+           "roofline": {"bound": "mfma", "achieved": round(tf_exe, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf_exe / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "algorithmic_tflops": round(tf_alg, 2), "algorithmic_speedup": round(tf_alg / tf_exe, 3),
+                        "basis": "whole call: dense multiply-adds executed by the matrix pipe / wall time"}}
+    if cpu:
+        out["cpu_baseline"] = cpu_specialist_baseline(name)
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    del model, x
     torch.cuda.empty_cache()
     return out
 
@@ -309,6 +473,7 @@ def main():
     from contextflow_amd.layers import _hip
     import torch.distributed as dist
 
+    t_start = time.perf_counter()
     rank, local_rank, world = cdist.env_world()
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
@@ -331,6 +496,8 @@ def main():
     lo, hi = cdist.shard_bounds(G, rank, world)
     x = synth(name, hi - lo, dev, seed=1000 + rank)
     nll_acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    ar_events = []                                      # (start, end) HIP events around the all-reduce of every timed step
+
     @torch.no_grad()                                   # density evaluation (experiment_cl.py:163-185 runs it under no_grad):
     def step(timed):                                   # no autograd tape, no W^-1 for the backward
         nll_acc.zero_()
@@ -338,7 +505,14 @@ def main():
             xb = x[c0:c0 + a.chunk]
             _, logp = model(xb)
             _hip.call("cf_nll_sum", _hip.p(logp), _hip.p(nll_acc), logp.shape[0], logp.shape[1], _hip.stream())
-        return cdist.allreduce_nll(nll_acc, hi - lo)           # RCCL all-reduce of [sum log p, count]
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        red = cdist.allreduce_nll(nll_acc, hi - lo)            # RCCL all-reduce of [sum log p, count]
+        if timed:
+            e1.record()
+            ar_events.append((e0, e1))
+        return red
 
     def fence():
         torch.cuda.synchronize()
@@ -355,17 +529,39 @@ def main():
         red = step(True)
     fence()
     dt = time.perf_counter() - t0
+    torch.cuda.synchronize()
     from contextflow_amd.layers import coupling as _cpl
     model.step_events, _cpl.VIT_EVENTS = None, None
+    # per-rank breakdown (the first multi-GPU run should be diagnosable from its one JSON line): wall time of the timed
+    # region, time inside the dominant kernel, time between "my last kernel is done" and "the all-reduce is done" (RCCL
+    # latency + waiting for the slowest rank), gathered on rank 0
+    kern_s = sum(e[0].elapsed_time(e[1]) for e in events) * 1e-3
+    ar_ms = [e[0].elapsed_time(e[1]) for e in ar_events]
+    mine = torch.tensor([dt, kern_s, sum(ar_ms) * 1e-3, max(ar_ms) * 1e-3 if ar_ms else 0.0, float(hi - lo), float(local_rank)],
+                        dtype=torch.float64, device=dev)
+    table = torch.zeros(world, mine.numel(), dtype=torch.float64, device=dev)
+    table[rank] = mine
+    if world > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)          # a gather written as a sum of one-hot rows (works on RCCL and gloo)
+    allr = list(table)
+    per_rank = [{"rank": r, "local_rank": int(v[5]), "samples_per_step": int(v[4]), "wall_s": round(float(v[0]), 4),
+                 "kernel_s": round(float(v[1]), 4), "allreduce_s": round(float(v[2]), 5), "allreduce_max_ms": round(float(v[3]) * 1e3, 3)}
+                for r, v in enumerate(t.cpu() for t in allr)]
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     bpd = cdist.mean_bits_per_dim(red.cpu(), DIMS[name])
     roof = roofline(events, name, dt)
-    comm = {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
+    walls, kerns, ars = [p["wall_s"] for p in per_rank], [p["kernel_s"] for p in per_rank], [p["allreduce_s"] for p in per_rank]
+    comm = {"backend": dist.get_backend() if dist.is_initialized() else None, "world_size": world,
+            "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "visible_devices": torch.cuda.device_count(),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
-            "rehearsal_gloo_on_one_device": rehearsal}
+            "rehearsal_gloo_on_one_device": rehearsal,
+            "wall_s_min_max": [min(walls), max(walls)], "kernel_s_min_max": [min(kerns), max(kerns)],
+            "allreduce_s_min_max": [min(ars), max(ars)], "allreduce_share_of_step": round(max(ars) / dt, 5),
+            "per_rank": per_rank}
 
     if rank == 0:
         out = {"metric": "samples/s fwd+logdet (log p(x) (B,M)), %s" % LABEL[name],
@@ -393,10 +589,14 @@ def main():
                 secondary_small_batch("cifar10", dev, 256, cpu=False),     # its CPU baseline is the headline's (batch 256)
                 secondary_small_batch("mnist", dev, 64, cpu),
                 secondary_small_batch("smap", dev, 256, cpu=False),        # BASELINE config 4 at the reference's default batch
-                secondary_training("cifar10", dev, 16384, 10, graph=True),
+                secondary_training("cifar10", dev, 16384, 10, graph=True, cpu=cpu),
                 secondary_training("cifar10", dev, 16384, 10, graph=False),
                 secondary_training("cifar10", dev, 256, 50, graph=True),
+                secondary_training("smap", dev, 32768, 10, graph=True, cpu=cpu),       # BASELINE config 4's training step
+                secondary_training("smap", dev, 256, 50, graph=True),                  # ... at the reference's batch (config.py:10)
+                secondary_specialist("cifar10", dev, 32768, 5, cpu),                   # --contextflow specialist forward
             ]
+        out["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

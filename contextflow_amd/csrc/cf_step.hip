@@ -1066,6 +1066,23 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     return cf_flow_step_fwd_debug(x, z, ldj_acc, ws, B, C, H, W, x_bstride, in_squeeze, nullptr, flags, stream);
 }
 
+// Multiply-adds per sample the matrix pipe EXECUTES for one step at this batch size (bench.py's executed-flop roofline):
+// pass 0 = cf_flow_step_fwd, 1 = cf_flow_step_fwd_taped, 2 = cf_flow_step_bwd_taped (direct transposed 3x3).  The direct
+// form runs C^2 (Conv1x1) + C^2 + 36 C^2 + 2 C^2 = 40 C^2 per pixel; the Winograd form of the 3x3 runs 16 instead of 36
+// C^2.  The conditions below restate the dispatch of the two entry points above / below - change them together.
+int64_t cf_flow_step_macs(int B, int C, int H, int W, int pass) {
+    const int sid = shape_id(C, H, W);
+    if (sid < 0 || pass < 0 || pass > 2) return 0;
+    const int64_t direct = 40ll * C * C * H * W, wino = 20ll * C * C * H * W;
+    if (pass == 2 || direct_conv_only()) return direct;
+    bool w;
+    if (sid == 0) w = pass == 0;                                  // mnist's C = 8 level: evaluation only
+    else if (sid == 1) w = true;                                  // 16x16, C = 16: every batch size
+    else if (sid == 2) w = B >= 256 * G32::SPW;
+    else w = B >= 256 * G64w2::SPW;
+    return w ? wino : direct;
+}
+
 // training forward: the same step, and the conditioner's intermediate planes y0 (B, C/2, H, W), h1, h2 (B, 2C, H, W;
 // post-ReLU) go to the caller's tape.  cf_flow_step_bwd_taped consumes them: it skips the recompute of the two big
 // contractions and uses the planes directly as the operands of the weight-gradient GEMMs.

@@ -641,6 +641,14 @@ int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, co
     return 0;
 }
 
+// multiply-adds per sample the matrix pipe executes for the four weight gradients of a step (bench.py): direct 40 C^2 HW;
+// the Winograd form F(3x3, 2x2) of the 3x3 (launch_form: every shape but 16x16 with 128 columns) runs 16 instead of 36 C^2
+int64_t cf_step_wgrads_macs(int B, int C, int H, int W) {
+    (void)B;
+    const bool wino = !wgrad_direct_only() && !(H * W == 256 && 2 * C > 64);
+    return (wino ? 20ll : 40ll) * C * C * H * W;
+}
+
 // test hook (not part of the public header): cf_wgrad with the form of the 3x3 chosen by the caller (0 direct, 1 Winograd)
 int cf_wgrad_form(const float* A, const float* Bm, float* gw, float* gbias, void* ws, int B, int MR, int NR, int H, int W,
                   int taps, int form, cf_stream_t stream) {

@@ -33,7 +33,15 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            # one process per GPU: every local rank needs its own device (RCCL deadlocks or fails obscurely otherwise)
+            n = torch.cuda.device_count()
+            if local_rank >= n:
+                raise RuntimeError("contextflow_amd.dist: LOCAL_RANK %d but only %d visible GPU(s) (WORLD_SIZE %d): launch one "
+                                   "process per GPU, e.g. torch.distributed.run --nproc-per-node <= %d" % (local_rank, n, world, n))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if dist.get_world_size() != world:
+            raise RuntimeError("contextflow_amd.dist: process group of %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), world))
     return rank, local_rank, world
 
 

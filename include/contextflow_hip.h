@@ -204,6 +204,13 @@ int64_t cf_flow_step_bwd_ws_bytes(int C, int H, int W);
 int cf_flow_step_bwd_prepare(const float* Wm, const float* logs, const float* w1, const float* w2, const float* w3,
                              void* wsb, int C, int H, int W, cf_stream_t stream);
 
+/* Multiply-adds per sample that the matrix pipe EXECUTES for one step at batch size B (the dispatch picks the Winograd
+ * form of the 3x3 - 16 instead of 36 C^2 HW - by shape and batch size): pass 0 = cf_flow_step_fwd, 1 = cf_flow_step_fwd_taped,
+ * 2 = cf_flow_step_bwd_taped; cf_step_wgrads_macs: the four weight gradients of cf_step_wgrads.  The ALGORITHMIC count
+ * (the reference's direct convolutions) is 40 C^2 HW for each of them.  Host-only, no stream.           */
+int64_t cf_flow_step_macs(int B, int C, int H, int W, int pass);
+int64_t cf_step_wgrads_macs(int B, int C, int H, int W);
+
 /* Taped training pair (experiment_cl.py:130-136: forward + cost.backward()).
  * cf_flow_step_fwd_taped = cf_flow_step_fwd that also writes the tape of the step:
  *   t_y0 (B, C/2, H*W), t_h1, t_h2 (B, 2C, H*W; post-ReLU planes of Coupling.NN, coupling.py:26-27): operands of cf_wgrad;
