@@ -15,6 +15,7 @@ OUT = os.path.join(PKG, "libcontextflow_hip.so")
 OBJ = os.path.join(PKG, "build")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wno-comment"]
+EXTRA_FLAGS = {}          # per-file extras: {"file.hip": [flags]} (A/B builds: tools/dev/make_abl.py)
 
 
 def sources():
@@ -31,7 +32,7 @@ def up_to_date():
 
 def _compile(src):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-    cmd = ["hipcc"] + FLAGS + ["-c", src, "-o", obj]
+    cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

@@ -303,8 +303,12 @@ __global__ __launch_bounds__(256, G::MINW) void k_flow_step(const float* __restr
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // DUMP (training): y0 and the post-ReLU h1 / h2 planes also go to the tape `tp` (see k_flow_step).
+// CF_G16W_MINW: waves per SIMD the C = 16 Winograd geometry is compiled for (A/B builds of tools/dev/make_abl.py)
+#ifndef CF_G16W_MINW
+#define CF_G16W_MINW 4
+#endif
 template <class G, bool SQ, bool DBG = false, bool DUMP = false>
-__global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
+__global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
                                                                   float* __restrict__ ldj_acc, const float* __restrict__ ws,
                                                                   int B, int64_t xbs, float* __restrict__ dbg, StepTape tp) {
     static_assert(G::SMALL, "16x16 images, one sample per workgroup, C <= 16");

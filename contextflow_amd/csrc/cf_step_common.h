@@ -441,6 +441,131 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
     constexpr int B1[4] = {0, 1, 1, 1}, B2[4] = {2, 2, 2, 3};                       // patch columns of B^T row nu
     constexpr float S1[4] = {1.f, 1.f, -1.f, 1.f}, S2[4] = {-1.f, 1.f, 1.f, -1.f};
     constexpr float AT[2][4] = {{1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -1.f}};
+    // ---- column-shared form (HID <= 64: one k-chunk, no row split) ------------------------------------------------------
+    // B^T d B for one vertical index xi: A[c] = d[r1][c] + sigma d[r2][c] for the four patch columns c, and the four
+    // horizontal positions are  nu 0: A0 - A2,  1: A1 + A2,  2: A2 - A1,  3: A1 - A3.  A1 / A2 of every k-group are kept for
+    // the whole xi (2 x 4 values per k-group), A0 / A3 are formed where nu = 0 / 3 uses them: 8 LDS reads + 8 VALU per
+    // channel and xi instead of 16 + 12 in the per-position form below, same register footprint (no extra accumulators).
+    // At HID = 32 / 16 a transformed operand feeds only 2 / 1 MFMAs: the per-position form kept the CU's LDS pipe 50 / 100 %
+    // busy with patch reads (round 2 PMC: SQ_WAIT_INST_LDS 7x the C = 32 level's) and spilled 5-7 registers at 4 workgroups
+    // per CU.  Measured (tools/dev/ab_step.py, 65536 samples): C = 8  0.73 -> 0.68 ms, C = 16  1.76 -> 1.64 ms (no spills),
+    // C = 32  1.50 -> 1.47 ms.  (Also measured: the same arithmetic on scalar floats with -fno-slp-vectorize, as the
+    // micro-architecture guide suggests for VALU beside bf16 MFMAs - no gain at C = 16, 2 % slower at C = 32 / 64: the fp32
+    // MFMA shares the fp32 lanes with the VALU, so what counts here is the NUMBER of vector instructions, and packed ones
+    // halve it.)
+#ifndef CF_WINO_VF_MAXRT
+#define CF_WINO_VF_MAXRT 4
+#endif
+    constexpr bool VF = RT16 <= CF_WINO_VF_MAXRT && NCH == 1 && RSPLIT == 1;
+    if constexpr (VF) {
+        const float* base = lds;
+        constexpr int frc = G::OFF_AW;
+        auto rows_of = [&](int xi, int (&r1)[NT], int (&r2)[NT]) {
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                r1[ct] = xi == 0 ? rpart[ct][0] : (xi == 2 ? rpart[ct][2] : rpart[ct][1]);
+                r2[ct] = xi == 2 ? rpart[ct][1] : (xi == 3 ? rpart[ct][3] : rpart[ct][2]);
+            }
+        };
+        // operands of group g = nu KGC + kk: the weight fragments and the raw patch columns the group has to fold
+        // (nu 0: columns 0 and 2, nu 1: column 1, nu 2: none, nu 3: column 3); k-steps paired for packed arithmetic
+        struct WRaw { f32x2w d[NT][2][2][2]; };               // [ct][slot][row r1 / r2][k-step pair]
+        WFrag fa[2];
+        WRaw raw[2];
+        auto load = [&](int xi, const int (&r1)[NT], const int (&r2)[NT], int g, WFrag& fo, WRaw& o) {
+            const int nu = g / KGC, kk = g % KGC;
+            const int fr = frc + ((xi * 4 + nu) * RT16 * KG4 + kk) * 256;
+#pragma unroll
+            for (int rt = 0; rt < RTW; ++rt) fo.a[rt] = ws_frag(rs, lane, fr + (rt0 + rt) * KG4 * 256);
+            constexpr int NC[4] = {2, 1, 0, 1}, C0[4] = {0, 1, 0, 3}, C1[4] = {2, 0, 0, 0};
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+                    if (sl < NC[nu]) {
+                        const int c = sl == 0 ? C0[nu] : C1[nu];
+                        const int o1 = r1[ct] + cpart[ct][c], o2 = r2[ct] + cpart[ct][c];
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const float* q0 = base + (16 * kk + 8 * e2) * PIX;
+                            const float* q1 = q0 + 4 * PIX;
+                            o.d[ct][sl][0][e2] = f32x2w{q0[o1], q1[o1]};
+                            o.d[ct][sl][1][e2] = f32x2w{q0[o2], q1[o2]};
+                        }
+                    }
+        };
+        f32x2w A1[KGC][NT][2], A2[KGC][NT][2];
+        int r1[NT], r2[NT], r1n[NT], r2n[NT];
+        rows_of(0, r1, r2);
+        load(0, r1, r2, 0, fa[0], raw[0]);
+#pragma unroll 1
+        for (int xi = 0; xi < 4; ++xi) {
+            const int xn = xi < 3 ? xi + 1 : 3;
+            rows_of(xn, r1n, r2n);
+            const float sigma = xi == 1 ? 1.f : -1.f;
+            const float c0 = xi < 3 ? 1.f : 0.f, c1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);      // A^T[0][xi], A^T[1][xi]
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                f32x4w M[NT][RTW];
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                    for (int rt = 0; rt < RTW; ++rt) M[ct][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KGC; ++kk) {
+                    const int g = nu * KGC + kk;
+                    if (g + 1 < NGX) load(xi, r1, r2, g + 1, fa[(g + 1) & 1], raw[(g + 1) & 1]);
+                    else load(xn, r1n, r2n, 0, fa[0], raw[0]);           // first group of the next xi (after the last xi: harmless)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const WFrag& oa = fa[g & 1];
+                    const WRaw& o = raw[g & 1];
+                    f32x2w v[NT][2];
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            if (nu == 0) {
+                                const f32x2w a0 = o.d[ct][0][0][e2] + sigma * o.d[ct][0][1][e2];
+                                A2[kk][ct][e2] = o.d[ct][1][0][e2] + sigma * o.d[ct][1][1][e2];
+                                v[ct][e2] = a0 - A2[kk][ct][e2];
+                            } else if (nu == 1) {
+                                A1[kk][ct][e2] = o.d[ct][0][0][e2] + sigma * o.d[ct][0][1][e2];
+                                v[ct][e2] = A1[kk][ct][e2] + A2[kk][ct][e2];
+                            } else if (nu == 2) {
+                                v[ct][e2] = A2[kk][ct][e2] - A1[kk][ct][e2];
+                            } else {
+                                const f32x2w a3 = o.d[ct][0][0][e2] + sigma * o.d[ct][0][1][e2];
+                                v[ct][e2] = A1[kk][ct][e2] - a3;
+                            }
+                        }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < NT; ++ct)
+                                M[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[ct][e >> 1][e & 1], M[ct][rt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // Y[i][j] += A^T[i][xi] A^T[j][nu] M
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (AT[j][nu] != 0.f) {
+                        const float k0 = c0 * AT[j][nu], k1 = c1 * AT[j][nu];
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                            for (int rt = 0; rt < RTW; ++rt) {
+                                Y[ct][0][j][rt] += k0 * M[ct][rt];
+                                Y[ct][1][j][rt] += k1 * M[ct][rt];
+                            }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) { r1[ct] = r1n[ct]; r2[ct] = r2n[ct]; }
+        }
+    } else {
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
         const float* base = lds + ch * (16 * KGC) * PIX;
@@ -533,6 +658,7 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
             for (int ct = 0; ct < NT; ++ct) { r1[ct] = r1n[ct]; r2[ct] = r2n[ct]; }
         }
     }
+    }       // per-position form
     __syncthreads();                 // every wave has finished reading h1
 #pragma unroll
     for (int rt = 0; rt < RTW; ++rt) {
