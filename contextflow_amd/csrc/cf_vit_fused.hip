@@ -269,9 +269,14 @@ __global__ __launch_bounds__(256, 2) void k_vit_coupling(const float* __restrict
         }
         store_tiles<2>(o, Y, 64, col, lk);
         {
-            f32x16 acc[2];
-            load_tiles2(acc, X, nullptr, col, lk);                             // residual
+            // product first, ONE addition into the residual stream afterwards (as the reference: simple_vit.py:84).  Summing
+            // the k-steps on top of X rounds every partial sum at the residual's magnitude: 2-3x the reference's fp32 error
+            f32x16 acc[2], res[2];
+            load_tiles2(acc, nullptr, nullptr, col, lk);
             vgemm<2>(acc, wl + L.wout, ngroups(64), Y, col, lane);
+            load_tiles2(res, X, nullptr, col, lk);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] += res[t];
             store_tiles<2>(acc, X, dim, col, lk);
         }
         // ---- MLP block: x = W2 gelu(W1 LN(x) + b1) + b2 + x                   (simple_vit.py:30-40,86)
@@ -287,9 +292,12 @@ __global__ __launch_bounds__(256, 2) void k_vit_coupling(const float* __restrict
             store_tiles<2>(acc, Y, dim, col, lk);
         }
         {
-            f32x16 acc[2];
-            load_tiles2(acc, X, wl + L.b2, col, lk);
+            f32x16 acc[2], res[2];
+            load_tiles2(acc, nullptr, wl + L.b2, col, lk);
             vgemm<2>(acc, wl + L.w2, ngroups(dim), Y, col, lane);
+            load_tiles2(res, X, nullptr, col, lk);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] += res[t];
             store_tiles<2>(acc, X, dim, col, lk);
         }
     }

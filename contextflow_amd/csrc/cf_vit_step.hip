@@ -349,7 +349,17 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
                     o[t][r] = fmaf(p3, tok_xor<3>(v), fmaf(p2, tok_xor<2>(v), fmaf(p1, tok_xor<1>(v), p0 * v)));
                 }
         }
-        gemm_regs<2, V::KS_HEAD>(X, rs, lane, wl + V::L_WOUT, [&](int s) { return o[s >> 4][s & 15]; });   // + residual, in place
+        {
+            // the product is summed on its own and meets the residual stream in ONE addition per element, as in the
+            // reference (x = to_out(...) + x, simple_vit.py:84).  Accumulating the k-steps on top of X rounds every partial
+            // sum at the magnitude of the residual stream (|X| ~ 5 against |product| < 1): 56-64 roundings of ulp(X) per
+            // element and block, which was 2-3x the reference's own fp32 error on the layer's output and - amplified by
+            // 1 / sigma of a fitted prior - the whole distance of the SMAP "extreme" fixtures (tools/attribute_vit.py)
+            f32x16 a[2];
+            gemm_regs<2, V::KS_HEAD, true>(a, rs, lane, wl + V::L_WOUT, [&](int s) { return o[s >> 4][s & 15]; });
+#pragma unroll
+            for (int t = 0; t < 2; ++t) X[t] += a[t];
+        }
         {
             f32x16 u[2], h[2];
             layernorm<V, 2>(X, u, ws + wl + V::L_LNF, lk, nullptr);
@@ -359,11 +369,11 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[t][r] = (r < V::KPT) ? gelu_erf(h[t][r]) : 0.f;     // gelu(0) = 0 on padded rows anyway
-            f32x16 b2[2];
-            load_vec(b2, ws + wl + V::L_B2, lk);
+            f32x16 a[2];
+            load_vec(a, ws + wl + V::L_B2, lk);                                   // W2 h + b2 on its own, then one add into the residual
+            gemm_regs<2, V::KS_RES>(a, rs, lane, wl + V::L_W2, [&](int s) { return h[s / V::KPT][s % V::KPT]; });
 #pragma unroll
-            for (int t = 0; t < 2; ++t) X[t] += b2[t];
-            gemm_regs<2, V::KS_RES>(X, rs, lane, wl + V::L_W2, [&](int s) { return h[s / V::KPT][s % V::KPT]; });   // + residual
+            for (int t = 0; t < 2; ++t) X[t] += a[t];
         }
     }
     f32x16 hn[2];

@@ -42,12 +42,14 @@ def pre_init_params(name, fx):
 def stress_tolerance(fx, tag):
     """bits/dim bar of a stress fixture: 1e-5 (BASELINE.json) where the reference's own fp32 answer sits well inside it
     ("stress": measured 2.6e-6 .. 3.0e-6 from its fp64 run); for "extreme" the reference's fp32 result is itself up to
-    7.5e-6 from its fp64 run, so no fp32 implementation can be held to 1e-5 of it: the bar is max(1e-5, 3 x that floor)."""
+    7.5e-6 from its fp64 run, so the bar is max(1e-5, 1.5 x that floor).  (Round 2 needed 3 x: the fused transformer kernels
+    summed every residual product on top of the residual stream and lost 2-3x the reference's accuracy per layer; measured
+    now: smap extreme 8.8e-6 from the reference's fp32 and 3.0e-6 from its fp64 answer.)"""
     floor = float(fx["floor_bpd"])
     if tag == "stress":
         assert floor < 3.5e-6
         return 1e-5
-    return max(1e-5, 3.0 * floor)
+    return max(1e-5, 1.5 * floor)
 
 
 def e2e_inputs(name, fx):
