@@ -148,19 +148,19 @@ constexpr int WG_LS = WG_MAXF * 32;   // LDS row stride (floats): 48 KiB per wor
 // branch around an MFMA would put a full LDS wait in front of every one of them.
 // ldx / ldy: row strides of x / gy (a launch may cover a column block of wider matrices); XSQ: the B operand is x^2
 // (second-moment sums of the mixture backward).
-template <int TPW, bool XSQ = false>
-__global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
-                                                      float* __restrict__ part, int rows, int Ktot, int N, int NT, int kbs, int ybase,
-                                                      int64_t ldx, int64_t ldy, int64_t zstride) {
-    // blockIdx.z = column block of a wide x (kbs columns each; small batches run all blocks in one launch)
-    const int K = min(kbs, Ktot - (int)blockIdx.z * kbs), KT = (K + 1 + 31) / 32;
-    x += (int64_t)blockIdx.z * kbs;
-    part += (int64_t)blockIdx.z * zstride;
+template <int TPW, bool XSQ>
+__device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ x, const float* __restrict__ gy,
+                                                  float* __restrict__ part, int rows, int Ktot, int N, int NT, int kbs, int ybase,
+                                                  int64_t ldx, int64_t ldy, int64_t zstride, int bx, int by, int bz, int gdx) {
+    // bz = column block of a wide x (kbs columns each; small batches run all blocks in one launch)
+    const int K = min(kbs, Ktot - bz * kbs), KT = (K + 1 + 31) / 32;
+    x += (int64_t)bz * kbs;
+    part += (int64_t)bz * zstride;
     // one LDS row = the 32-feature blocks [gy (NT) | x, 1, 0.. (KT)] of one activation row at the FIXED stride WG_LS: the
     // operand reads of the MFMA loop are then base register + immediate offset (no address arithmetic between MFMAs)
     __shared__ float lds[WG_RC * WG_LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
-    const int NS = NT * 32, ntiles = NT * KT, t0 = (ybase + blockIdx.y) * 4 * WG_TPW;
+    const int NS = NT * 32, ntiles = NT * KT, t0 = (ybase + by) * 4 * WG_TPW;
     int aoff[TPW], boff[TPW];
     bool live[TPW];
 #pragma unroll
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
     // other's staging and MFMA phases.
     const int nchunks = (rows + WG_RC - 1) / WG_RC;
     const int c32 = tid & 31, rs = tid >> 5;
-    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (int c = bx; c < nchunks; c += gdx) {
         const int r0 = c * WG_RC;
         // branch-free batch: all 4 x WG_MAXF loads of a thread are in flight together (clamped addresses; the values of
         // padding positions are replaced afterwards), then the LDS writes
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
         __syncthreads();
     }
     // partial of this workgroup: full 32 x 32 tiles, [tile][i = n][j = kcol]
-    float* pw = part + (int64_t)blockIdx.x * ntiles * 1024;
+    float* pw = part + (int64_t)bx * ntiles * 1024;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         if (!live[i]) continue;
@@ -241,19 +241,40 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
     }
 }
 
+template <int TPW, bool XSQ = false>
+__global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      float* __restrict__ part, int rows, int Ktot, int N, int NT, int kbs, int ybase,
+                                                      int64_t ldx, int64_t ldy, int64_t zstride) {
+    linear_wgrad_body<TPW, XSQ>(x, gy, part, rows, Ktot, N, NT, kbs, ybase, ldx, ldy, zstride, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// A GROUP of weight gradients in one launch (blockIdx.z = member): the Linears of a transformer flow step share their row
+// count and are far too small to fill the chip one by one - 26 launch pairs per step became one (cf_linear_wgrad_group).
+// Every member is one column block (K + 1 <= (WG_MAXF - NT) * 32); TPW covers the member with the most tiles.
+constexpr int WG_GROUP_MAX = 32;
+struct WgMember { const float* x; const float* gy; float* part; float* gW; float* gb; int rows, K, N, NT, G; int64_t ldx, ldy; };
+struct WgGroup { WgMember m[WG_GROUP_MAX]; };
+template <int TPW>
+__global__ __launch_bounds__(256) void k_linear_wgrad_group(const WgGroup grp) {
+    const WgMember& d = grp.m[blockIdx.z];
+    if ((int)blockIdx.x >= d.G) return;                          // uniform: this member has fewer row groups
+    const int KT = (d.K + 1 + 31) / 32;
+    if ((int)blockIdx.y * 4 * TPW >= d.NT * KT) return;
+    linear_wgrad_body<TPW, false>(d.x, d.gy, d.part, d.rows, d.K, d.N, d.NT, d.K, 0, d.ldx, d.ldy, 0, blockIdx.x, blockIdx.y, 0, d.G);
+}
 // 64 output elements per workgroup, the G partials split over the 4 waves (every 4th partial each), then summed across
 // the waves in a fixed order
-__global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gW,
-                                                             float* __restrict__ gb, int Ktot, int N, int kbs, int NT, int G,
-                                                             int64_t ldw, int64_t zstride) {
+__device__ __forceinline__ void linear_wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ gW,
+                                                         float* __restrict__ gb, int Ktot, int N, int kbs, int NT, int G,
+                                                         int64_t ldw, int64_t zstride, int bx, int z) {
     __shared__ float red[4][64];
-    const int z = blockIdx.y;                             // column block of x, as in k_linear_wgrad
+    // z: column block of x, as in k_linear_wgrad
     const int K = min(kbs, Ktot - z * kbs), KT = (K + 1 + 31) / 32, ntiles = NT * KT;
-    if ((int)blockIdx.x * 64 >= ntiles * 1024) return;    // uniform: the last block may have fewer tiles
+    if (bx * 64 >= ntiles * 1024) return;    // uniform: the last block may have fewer tiles
     gW += (int64_t)z * kbs;
     if (z != 0) gb = nullptr;                             // the bias column rides with the first block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;                 // element of the padded tile storage
+    const int e = bx * 64 + lane;                 // element of the padded tile storage
     const float* p = part + (int64_t)z * zstride + e;
     float s0 = 0.f, s1 = 0.f;
     int g = wave;
@@ -269,6 +290,16 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __rest
             else if (k == K && gb) gb[n] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __restrict__ part, float* __restrict__ gW,
+                                                             float* __restrict__ gb, int Ktot, int N, int kbs, int NT, int G,
+                                                             int64_t ldw, int64_t zstride) {
+    linear_wgrad_reduce_body(part, gW, gb, Ktot, N, kbs, NT, G, ldw, zstride, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(256) void k_linear_wgrad_reduce_group(const WgGroup grp) {
+    const WgMember& d = grp.m[blockIdx.y];
+    linear_wgrad_reduce_body(d.part, d.gW, d.gb, d.K, d.N, d.K, d.NT, d.G, d.K, 0, blockIdx.x, 0);
 }
 
 // LayerNorm over the last dim (biased variance, eps) + optional positional embedding add:
@@ -545,6 +576,49 @@ static int linear_wgrad_any(const float* x, const float* gy, float* gW, float* g
             k_linear_wgrad_reduce<<<dim3(ntiles * 16, nz), dim3(256), 0, st>>>(part, gW + (int64_t)n0 * K + k0, (gb && k0 == 0) ? gb + n0 : nullptr,
                                                                              Kl, Nc, kbs, NT, G, K, zs);
         }
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- a group of weight gradients: one k_linear_wgrad_group launch + one reduce launch ---------------------------------
+// member i: gW_i (N_i x K_i) = gy_i^T x_i over rows_i rows, gb_i (N_i, optional) = column sums of gy_i; x_i: (rows_i, K_i)
+// dense, gy_i: (rows_i, N_i) dense.  N_i <= 192, K_i + 1 <= (12 - ceil(N_i / 32)) * 32, at most 32 members.
+static int64_t wgrad_member_part_floats(int rows, int K, int N) {
+    const int NT = (N + 31) / 32, KT = (K + 1 + 31) / 32;
+    return (int64_t)linear_wgrad_groups(rows) * NT * KT * 1024;
+}
+int64_t cf_linear_wgrad_group_ws_bytes(const int* rows, const int* K, const int* N, int n) {
+    int64_t f = 0;
+    for (int i = 0; i < n; ++i) f += wgrad_member_part_floats(rows[i], K[i], N[i]);
+    return f * (int64_t)sizeof(float);
+}
+int cf_linear_wgrad_group(const float* const* x, const float* const* gy, float* const* gW, float* const* gb, const int* rows,
+                          const int* K, const int* N, int n, void* ws, cf_stream_t stream) {
+    CF_REQUIRE(x && gy && gW && gb && rows && K && N && ws && n >= 1 && n <= WG_GROUP_MAX);
+    WgGroup grp;
+    float* part = (float*)ws;
+    int gmax = 1, tmax = 1;
+    for (int i = 0; i < n; ++i) {
+        const int NT = (N[i] + 31) / 32, KT = (K[i] + 1 + 31) / 32;
+        CF_REQUIRE(x[i] && gy[i] && gW[i] && rows[i] >= 0 && K[i] > 0 && N[i] > 0 && NT <= 6 && NT + KT <= WG_MAXF && NT * KT <= 4 * WG_TPW);
+        WgMember& m = grp.m[i];
+        m.x = x[i]; m.gy = gy[i]; m.part = part; m.gW = gW[i]; m.gb = gb[i];
+        m.rows = rows[i]; m.K = K[i]; m.N = N[i]; m.NT = NT; m.G = linear_wgrad_groups(rows[i]); m.ldx = K[i]; m.ldy = N[i];
+        part += wgrad_member_part_floats(rows[i], K[i], N[i]);
+        gmax = m.G > gmax ? m.G : gmax;
+        tmax = NT * KT > tmax ? NT * KT : tmax;
+    }
+    for (int i = n; i < WG_GROUP_MAX; ++i) grp.m[i] = grp.m[0];
+    hipStream_t st = cf_s(stream);
+    const int tpw = (tmax + 3) / 4;
+    switch (tpw) {
+        case 1: k_linear_wgrad_group<1><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
+        case 2: k_linear_wgrad_group<2><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
+        case 3: k_linear_wgrad_group<3><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
+        case 4: k_linear_wgrad_group<4><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
+        default: k_linear_wgrad_group<WG_TPW><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
+    }
+    k_linear_wgrad_reduce_group<<<dim3(tmax * 16, n), dim3(256), 0, st>>>(grp);
     CF_LAUNCH_CHECK();
     return 0;
 }

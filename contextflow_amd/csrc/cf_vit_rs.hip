@@ -1,0 +1,284 @@
+// Row-split transformer-coupling flow step for SMALL batches: Conv1x1 -> ActNorm -> TransCoupling (patchify, SimpleViT,
+// un-patchify, affine map, log-det) of the time-series topologies (H x 1 windows, patch (2,1), 4 tokens per sample: SMAP)
+// with the four waves of a workgroup SHARING 16 token columns (4 samples) and splitting the OUTPUT ROWS of every Linear.
+// Reference: contextflow/model.py:129-147, layers/conv1x1.py:52-57, layers/actnorm.py:53-60, layers/coupling.py:100-159,
+// layers/simple_vit.py:18-127.
+//
+// Why a second kernel.  k_vit_step (cf_vit_step.hip) keeps a sample's whole step inside ONE wave (8 samples per wave, all
+// 2 148 MFMAs + 12 K vector instructions in series): the right shape at saturating batches, but at the reference's batch of
+// 256 (config.py:10) a launch is 32 waves on 8 CUs and a step takes the ~90 us of one wave's serial chain.  Here a step's
+// chain is cut eight-fold: v_mfma_f32_16x16x4_f32 tiles (16 token columns = 4 samples instead of 32 = 8) and one 16-row
+// tile of every 64-row result per wave.  Planes [feature][16 tokens] go through LDS (26 KB per workgroup), five
+// workgroup barriers per transformer layer.
+//  * LayerNorm + Linear: the 13 values a lane reads for the token statistics (features g, g + 4, ...; lane group g) ARE its
+//    B operands of the following product (k-step s needs feature 4 s + g): one LDS read per MFMA, normalisation as one FMA,
+//    gamma folded into the packed weights and beta into the bias (k_vit_rs_pack, fp64);
+//  * residual products are summed on their own and meet the residual stream in one addition (as the reference does);
+//    single-tile products run as two interleaved accumulation chains (even / odd k-steps: a dependent 16x16x4 needs 40
+//    cycles, an independent one 32);
+//  * attention: a sample's 4 tokens are 4 consecutive lanes - q.k^T and p.v by DPP quad permutations on the wave's own 16
+//    head features, the partial scores of the four waves meet in LDS, the softmax over 4 scores is exact;
+//  * weight fragments of a product are requested right after the same product of the PREVIOUS layer has used its registers:
+//    a whole layer of lead time, no copies.
+#include "cf_vit_rs_common.h"
+
+extern "C" int cf_slogdet_inverse(const float* W, int C, float* logabsdet, float* Winv, cf_stream_t stream);
+
+namespace {
+
+// ---- the forward kernel ---------------------------------------------------------------------------------------------------
+// x, z: (B, C, 8, 1).  ldj_acc[b] += H*W*log|det W| + sum logs + sum log_s.  hout (optional, tests): the conditioner's
+// output un-patchified, (B, C, 8, 1) = [t | raw].
+template <class V>
+__global__ __launch_bounds__(256) void k_vit_step_rs(const float* __restrict__ x, float* __restrict__ z,
+                                                     float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                     int64_t xbs, int depth, float* __restrict__ hout) {
+    constexpr int C = V::C, CIN = V::CIN, HW = V::HW, DIM = V::DIM, PD = V::PD, TOK = V::TOK, POSC = V::POSC;
+    __shared__ __align__(16) float lds[V::LDS_FLOATS];
+    float* XIN = lds + V::P_XIN;     // [4 KS_C][32 positions]   step input, channel-major
+    float* YP = lds + V::P_Y;        // [32][32]                 Conv1x1 + ActNorm output
+    float* XA = lds + V::P_X1;       // [64][16]                 residual stream at layer boundaries
+    float* XB = lds + V::P_X0;       // [64][16]                 ... after the attention block (and the embedding before its norm)
+    float* OP = lds + V::P_O;        // [64][16]                 attention output
+    float* HP = lds + V::P_H;        // [64][16]                 MLP hidden layer / final conditioner output
+    float* SC = lds + V::P_SC;       // [4 waves][4][16]         partial scores
+    float* LS = lds + V::P_LS;       // [CIN * 2][16]            log-scales of the epilogue
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction: fragment offsets stay scalar
+    const int s0 = blockIdx.x * V::SPW;
+    const rsrc_t rs = make_rsrc(ws, ws_floats<V>(depth));
+
+    // weight fragments of the first layer and of the front end: requested before anything else
+    float4 fqkv[3][V::NG_D], fout[V::NG_H], ffc1[V::NG_D], ffc2[V::NG_D], fconv[V::NG_C], femb[V::NG_PD];
+    load_frags(fconv, rs, lane, V::OFF_A0 + (w & 1) * V::NG_C * 256);
+    load_frags(femb, rs, lane, V::OFF_WE + w * V::NG_PD * 256);
+    auto load_layer_qkv = [&](int l) {
+        const int wl = V::OFF_LAYER + l * V::L_STRIDE;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) load_frags(fqkv[t], rs, lane, wl + V::L_WQKV + (4 * t + w) * V::NG_D * 256);
+    };
+    load_layer_qkv(0);
+    load_frags(fout, rs, lane, V::OFF_LAYER + V::L_WOUT + w * V::NG_H * 256);
+    load_frags(ffc1, rs, lane, V::OFF_LAYER + V::L_W1 + w * V::NG_D * 256);
+    load_frags(ffc2, rs, lane, V::OFF_LAYER + V::L_W2 + w * V::NG_D * 256);
+
+    for (int i = tid; i < 4 * V::KS_C * POSC; i += 256) {
+        const int c = i / POSC, pc = i % POSC, b = s0 + pc / HW;
+        XIN[i] = (c < C && b < B) ? x[(int64_t)b * xbs + c * HW + pc % HW] : 0.f;
+    }
+    __syncthreads();
+    // ================= Conv1x1 + ActNorm: one (16 channels x 16 positions) tile per wave
+    {
+        const int rt = w & 1, ct = w >> 1;
+        const f32x4 y = gemm1<V::KS_C>(to4(*reinterpret_cast<const float4*>(ws + V::OFF_B0 + 16 * rt + 4 * g)), fconv,
+                                       [&](int s) { return XIN[(4 * s + g) * POSC + 16 * ct + col]; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) YP[(16 * rt + 4 * g + r) * POSC + 16 * ct + col] = y[r];
+    }
+    __syncthreads();
+    // ================= patch embedding: LN(pd) -> Linear -> LN(dim) + pos          (simple_vit.py:100-105,122)
+    // token column col = 4 * (sample in workgroup) + n; patch feature f = ii * CIN + c = y[c][position 2 n + ii]
+    const int n = col & 3, pcol = (col >> 2) * HW + 2 * n;
+    f32x4 X;                                                                   // this wave's rows 16 w + 4 g + r of the residual stream
+    {
+        float pv[V::KS_PD];
+#pragma unroll
+        for (int i = 0; i < V::KS_PD; ++i) {
+            const int f = g + 4 * i, ii = f / CIN, c = f - ii * CIN;
+            pv[i] = f < PD ? YP[c * POSC + pcol + ii] : 0.f;
+        }
+        float mean, rstd;
+        token_stats(pv, PD, g, mean, rstd);
+        const float mr = -mean * rstd;
+        const f32x4 e = gemm1<V::KS_PD>(vec4(ws + V::OFF_BE, w, g), femb, [&](int s) { return (g + 4 * s < PD) ? fmaf(pv[s], rstd, mr) : 0.f; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) XB[(16 * w + 4 * g + r) * TOK + col] = e[r];
+        __syncthreads();
+        float ev[V::KS_D];
+#pragma unroll
+        for (int i = 0; i < V::KS_D; ++i) ev[i] = XB[(g + 4 * i) * TOK + col];
+        token_stats(ev, DIM, g, mean, rstd);
+        const f32x4 g1 = vec4(ws + V::OFF_LN1, w, g), b1 = vec4(ws + V::OFF_LN1 + 64, w, g), pe = vec4(ws + V::OFF_POS + 64 * n, w, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            X[r] = fmaf((e[r] - mean) * rstd, g1[r], b1[r]) + pe[r];
+            XA[(16 * w + 4 * g + r) * TOK + col] = X[r];
+        }
+        __syncthreads();
+    }
+    // ================= transformer                                                 (simple_vit.py:56-88)
+#pragma unroll 1
+    for (int l = 0; l < depth; ++l) {
+        const int wl = V::OFF_LAYER + l * V::L_STRIDE, ln = (l + 1 < depth ? l + 1 : l), wn = V::OFF_LAYER + ln * V::L_STRIDE;
+        float mean, rstd;
+        f32x4 o;
+        {
+            float xv[V::KS_D];
+#pragma unroll
+            for (int i = 0; i < V::KS_D; ++i) xv[i] = XA[(g + 4 * i) * TOK + col];
+            token_stats(xv, DIM, g, mean, rstd);
+            const float mr = -mean * rstd;
+            f32x4 q = vec4(ws + wl + V::L_CQKV, w, g), k = vec4(ws + wl + V::L_CQKV + 64, w, g), v = vec4(ws + wl + V::L_CQKV + 128, w, g);
+#pragma unroll
+            for (int s = 0; s < V::KS_D; ++s) {
+                const float b = (g + 4 * s < DIM) ? fmaf(xv[s], rstd, mr) : 0.f;
+                q = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(fqkv[0][s >> 2], s & 3), b, q, 0, 0, 0);
+                k = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(fqkv[1][s >> 2], s & 3), b, k, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(fqkv[2][s >> 2], s & 3), b, v, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_layer_qkv(ln);                                                // next layer's fragments: a whole layer of lead time
+            __builtin_amdgcn_sched_barrier(0);
+            // scores of this token against the 4 tokens of its sample (partner = token ^ m): own 16 head features, then the
+            // lane groups, then the four waves
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d0 = fmaf(q[r], k[r], d0);
+                d1 = fmaf(q[r], tok_xor<1>(k[r]), d1);
+                d2 = fmaf(q[r], tok_xor<2>(k[r]), d2);
+                d3 = fmaf(q[r], tok_xor<3>(k[r]), d3);
+            }
+            d0 = group_sum(d0); d1 = group_sum(d1); d2 = group_sum(d2); d3 = group_sum(d3);
+            if (g == 0) {
+                SC[(w * 4 + 0) * TOK + col] = d0; SC[(w * 4 + 1) * TOK + col] = d1;
+                SC[(w * 4 + 2) * TOK + col] = d2; SC[(w * 4 + 3) * TOK + col] = d3;
+            }
+            __syncthreads();
+            auto score = [&](int m) {
+                return ((SC[(0 * 4 + m) * TOK + col] + SC[(1 * 4 + m) * TOK + col]) + (SC[(2 * 4 + m) * TOK + col] + SC[(3 * 4 + m) * TOK + col])) * 0.125f;
+            };                                                                 // dim_head ** -0.5, dim_head = 64
+            d0 = score(0); d1 = score(1); d2 = score(2); d3 = score(3);
+            const float mx = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
+            float p0 = expf(d0 - mx), p1 = expf(d1 - mx), p2 = expf(d2 - mx), p3 = expf(d3 - mx);
+            const float inv = 1.0f / ((p0 + p1) + (p2 + p3));
+            p0 *= inv; p1 *= inv; p2 *= inv; p3 *= inv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = fmaf(p3, tok_xor<3>(v[r]), fmaf(p2, tok_xor<2>(v[r]), fmaf(p1, tok_xor<1>(v[r]), p0 * v[r])));
+                OP[(16 * w + 4 * g + r) * TOK + col] = o[r];
+            }
+        }
+        __syncthreads();
+        {   // x = to_out(attention) + x                                              (simple_vit.py:66-68,84)
+            const f32x4 a = gemm1<V::KS_H>(f32x4{0.f, 0.f, 0.f, 0.f}, fout, [&](int s) { return OP[(4 * s + g) * TOK + col]; });
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(fout, rs, lane, wn + V::L_WOUT + w * V::NG_H * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            X += a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) XB[(16 * w + 4 * g + r) * TOK + col] = X[r];
+        }
+        __syncthreads();
+        {   // x = W2 gelu(W1 LN(x) + b1) + b2 + x                                    (simple_vit.py:30-40,86)
+            float xv[V::KS_D];
+#pragma unroll
+            for (int i = 0; i < V::KS_D; ++i) xv[i] = XB[(g + 4 * i) * TOK + col];
+            token_stats(xv, DIM, g, mean, rstd);
+            const float mr = -mean * rstd;
+            f32x4 h = gemm1<V::KS_D>(vec4(ws + wl + V::L_B1, w, g), ffc1, [&](int s) { return (g + 4 * s < DIM) ? fmaf(xv[s], rstd, mr) : 0.f; });
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(ffc1, rs, lane, wn + V::L_W1 + w * V::NG_D * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                h[r] = 0.5f * h[r] * (1.0f + erff(h[r] * 0.70710678118654752f));
+                HP[(16 * w + 4 * g + r) * TOK + col] = h[r];
+            }
+        }
+        __syncthreads();
+        {
+            const f32x4 a = gemm1<V::KS_D>(vec4(ws + wl + V::L_B2, w, g), ffc2, [&](int s) { return HP[(4 * s + g) * TOK + col]; });
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(ffc2, rs, lane, wn + V::L_W2 + w * V::NG_D * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            X += a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) XA[(16 * w + 4 * g + r) * TOK + col] = X[r];
+        }
+        __syncthreads();
+    }
+    // ================= transformer.norm -> conditioner output plane [feature ii * C + ch][token]
+    {
+        float xv[V::KS_D];
+#pragma unroll
+        for (int i = 0; i < V::KS_D; ++i) xv[i] = XA[(g + 4 * i) * TOK + col];
+        float mean, rstd;
+        token_stats(xv, DIM, g, mean, rstd);
+        const f32x4 gn = vec4(ws + off_lno<V>(depth), w, g), bn = vec4(ws + off_lno<V>(depth) + 64, w, g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) HP[(16 * w + 4 * g + r) * TOK + col] = fmaf((X[r] - mean) * rstd, gn[r], bn[r]);
+    }
+    __syncthreads();
+    // ================= un-patchify, affine map, log-det, stores                    (coupling.py:139-155)
+    // item (c, ii, token): t = h[ii C + c], raw = h[ii C + CIN + c], x1 = y[CIN + c][position 2 n + ii]
+    for (int it = tid; it < CIN * 2 * TOK; it += 256) {
+        const int tc = it % TOK, ci = it / TOK, ii = ci / CIN, c = ci - ii * CIN;
+        const int sl = tc >> 2, pos = 2 * (tc & 3) + ii, b = s0 + sl;
+        const float tt = HP[(ii * C + c) * TOK + tc], raw = HP[(ii * C + CIN + c) * TOK + tc];
+        const float y1 = YP[(CIN + c) * POSC + sl * HW + pos], y0 = YP[c * POSC + sl * HW + pos];
+        const float ls = 2.0f * tanhf(0.5f * raw);
+        LS[it] = ls;
+        if (b < B) {
+            float* zb = z + (int64_t)b * C * HW;
+            zb[c * HW + pos] = y0;                                             // first half passes through (coupling.py:154)
+            zb[(CIN + c) * HW + pos] = fmaf(y1, expf(ls), tt);
+            if (hout) {
+                float* hb = hout + (int64_t)b * C * HW;
+                hb[c * HW + pos] = tt;
+                hb[(CIN + c) * HW + pos] = raw;
+            }
+        }
+    }
+    __syncthreads();
+    {   // wave w sums the log-scales of sample w in a fixed order (no float atomics: bitwise reproducible)
+        float s = 0.f;
+        for (int it = lane; it < CIN * 2 * 4; it += 64) {                      // the sample's items: (c, ii) x its 4 tokens
+            const int ci = it >> 2, tc = 4 * w + (it & 3);
+            s += LS[ci * TOK + tc];
+        }
+        s = cf_wave_sum(s);
+        if (lane == 0 && s0 + w < B) ldj_acc[s0 + w] += ws[0] + s;
+    }
+}
+
+using RS26 = RS<26>;
+
+bool rs_ok(int C, int H, int W, int p1, int p2, int dim, int dim_head, int heads) {
+    return C == 26 && H == 8 && W == 1 && p1 == 2 && p2 == 1 && dim == 2 * C && dim_head == 64 && heads == 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cf_vit_step_rs_supported(int C, int H, int W, int p1, int p2, int dim, int dim_head, int heads) {
+    return rs_ok(C, H, W, p1, p2, dim, dim_head, heads) ? 1 : 0;
+}
+
+int64_t cf_vit_step_rs_ws_bytes(int C, int depth) { return C == 26 ? (int64_t)ws_floats<RS26>(depth) * 4 : 0; }
+
+int cf_vit_step_rs_prepare(const float* Wm, const float* t, const float* logs, const float* flat_vit_params, const float* pos,
+                           void* ws, int C, int depth, cf_stream_t stream) {
+    CF_REQUIRE(Wm && t && logs && flat_vit_params && pos && ws && depth >= 1 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+    if (C != 26) { cf_set_error("cf_vit_step_rs_prepare: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
+    float* w = (float*)ws;
+    int rc = cf_slogdet_inverse(Wm, C, w + 1, nullptr, stream);
+    if (rc) return rc;
+    k_vit_rs_pack<RS26><<<dim3(64), dim3(256), 0, cf_s(stream)>>>(Wm, t, logs, flat_vit_params, pos, w, depth);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_vit_step_rs_fwd(const float* x, float* z, float* ldj_acc, const void* ws, float* h_out, int B, int C, int depth,
+                       int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && z && ldj_acc && ws && B > 0 && depth >= 1 && x_bstride >= (int64_t)C * 8);
+    if (C != 26) { cf_set_error("cf_vit_step_rs_fwd: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
+    k_vit_step_rs<RS26><<<dim3((unsigned)((B + 3) / 4)), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, (const float*)ws, B,
+                                                                                   x_bstride, depth, h_out);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

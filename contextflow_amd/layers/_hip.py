@@ -88,6 +88,17 @@ SIGNATURES = {
     "cf_vit_step_ws_bytes": (_c_i64, [_c_int] * 2),
     "cf_vit_step_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 2 + [_c_p]),
     "cf_vit_step_fwd": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
+    "cf_vit_step_rs_supported": (_c_int, [_c_int] * 8),
+    "cf_vit_step_rs_ws_bytes": (_c_i64, [_c_int] * 2),
+    "cf_vit_step_rs_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 2 + [_c_p]),
+    "cf_vit_step_rs_fwd": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
+    "cf_vit_step_bwd_ws_bytes": (_c_i64, [_c_int] * 2),
+    "cf_vit_step_bwd_plane_floats": (_c_i64, [_c_int] * 3),
+    "cf_vit_step_bwd_ln_floats": (_c_i64, [_c_int] * 3),
+    "cf_vit_step_bwd_prepare": (_c_int, [_c_p] * 4 + [_c_int] * 2 + [_c_p]),
+    "cf_vit_step_bwd": (_c_int, [_c_p] * 8 + [_c_int] * 3 + [_c_i64, _c_p]),
+    "cf_linear_wgrad_group_ws_bytes": (_c_i64, [_c_p] * 3 + [_c_int]),
+    "cf_linear_wgrad_group": (_c_int, [_c_p] * 7 + [_c_int, _c_p, _c_p]),
     "cf_spline_table_floats": (_c_i64, [_c_int, _c_int]),
     "cf_spline_prepare": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_f, _c_p]),
     "cf_spline": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_f, _c_int, _c_p]),

@@ -134,6 +134,106 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
     return gx, grads
 
 
+# ------------------------------------------------------------------------------------------------ transformer flow step
+def wgrad_group(members, dev):
+    """members: [(x (rows, K), gy (rows, N), has_bias)], all dense fp32 on `dev`.  One cf_linear_wgrad_group launch pair;
+    returns [(gW (N, K), gb (N,) | None)]."""
+    import ctypes
+    L = _hip.lib()
+    n = len(members)
+    rows = [m[0].shape[0] for m in members]
+    Ks = [m[0].shape[1] for m in members]
+    Ns = [m[1].shape[1] for m in members]
+    tot = sum(N * K + (N if m[2] else 0) for m, K, N in zip(members, Ks, Ns))
+    out = torch.empty(tot, device=dev, dtype=torch.float32)
+    res, o = [], 0
+    for m, K, N in zip(members, Ks, Ns):
+        gW = out[o:o + N * K].view(N, K); o += N * K
+        gb = None
+        if m[2]:
+            gb = out[o:o + N]; o += N
+        res.append((gW, gb))
+    iarr = lambda v: (ctypes.c_int * n)(*v)
+    parr = lambda ts: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
+    r_, k_, n_ = iarr(rows), iarr(Ks), iarr(Ns)
+    ws = torch.empty(L.cf_linear_wgrad_group_ws_bytes(r_, k_, n_, n), device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _hip.check(L.cf_linear_wgrad_group(parr([m[0] for m in members]), parr([m[1] for m in members]), parr([r[0] for r in res]),
+                                           parr([r[1] for r in res]), r_, k_, n_, n, _hip.p(ws), _hip.stream(dev)), "cf_linear_wgrad_group")
+    return res
+
+
+def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None):
+    """Conv1x1 -> ActNorm -> TransCoupling (one fused step of the transformer flows) backwards: ONE kernel re-runs the step
+    from its input and walks back (cf_vit_step_bwd), ONE grouped launch contracts the 26 weight-gradient operand pairs it
+    leaves (cf_linear_wgrad_group), the LayerNorm gradients are column sums of its per-workgroup partials, and the Conv1x1 /
+    ActNorm chain is cf_step_param_grads - as for the conv flows.  Returns (dL/dx, {param: grad})."""
+    xv, xbs = _hip.bview(x)
+    B, C = xv.shape[0], xv.shape[1]
+    dev = xv.device
+    vit = cpl.NN[0]
+    depth = len(vit.transformer.layers)
+    L = _hip.lib()
+    f, pp, st = _hip.f32, _hip.p, _hip.stream()
+    Wm, t, logs = f(conv.NN.detach()), f(act.NN_t.detach()), f(act.NN_logs.detach())
+    ws = cpl.step_prepare(conv.NN, act.NN_t, act.NN_logs, dev, "rs")
+    flat = cpl._flat_params()
+    wsb = torch.empty(L.cf_vit_step_bwd_ws_bytes(C, depth), device=dev, dtype=torch.uint8)
+    _hip.call("cf_vit_step_bwd_prepare", pp(Wm), pp(logs), pp(flat), pp(wsb), C, depth, st)
+    nwg = (B + 3) // 4
+    planes = torch.empty(L.cf_vit_step_bwd_plane_floats(B, C, depth), device=dev, dtype=torch.float32)
+    lnp = torch.empty(nwg, L.cf_vit_step_bwd_ln_floats(B, C, depth) // nwg, device=dev, dtype=torch.float32)
+    gx = torch.empty(B, C, xv.shape[2], xv.shape[3], device=dev, dtype=torch.float32)
+    _hip.call("cf_vit_step_bwd", pp(xv), pp(f(gz).contiguous()), pp(f(gld)), pp(gx), pp(ws), pp(wsb), pp(planes), pp(lnp), B, C,
+              depth, xbs, st)
+    # ---- weight gradients: the planes as (rows, width) matrices (layout: include/contextflow_hip.h, cf_vit_step_bwd)
+    Bp = nwg * 4
+    R4, P8, PD, DIM = 4 * Bp, 8 * Bp, C, 2 * C
+    o = [0]
+
+    def take(rows, width):
+        v = planes[o[0]:o[0] + rows * width].view(rows, width)
+        o[0] += rows * width
+        return v
+    xT, gyT, u0, ge = take(P8, C), take(P8, C), take(R4, PD), take(R4, DIM)
+    members = [(xT, gyT, True), (u0, ge, True)]
+    for _ in range(depth):
+        u1, gqkv, oo, gxm, u2, ghp, h, gxo = (take(R4, DIM), take(R4, 192), take(R4, 64), take(R4, DIM), take(R4, DIM), take(R4, DIM),
+                                               take(R4, DIM), take(R4, DIM))
+        members += [(u1, gqkv, False), (oo, gxm, False), (u2, ghp, True), (h, gxo, True)]
+    wg = wgrad_group(members, dev)
+    ln = lnp.sum(0)                                       # fixed-order column sums of the per-workgroup partials
+    grads = {}
+    tpe = vit.to_patch_embedding
+    grads[tpe[1].weight], grads[tpe[1].bias] = ln[0:PD], ln[32:32 + PD]
+    grads[tpe[2].weight], grads[tpe[2].bias] = wg[1]
+    grads[tpe[3].weight], grads[tpe[3].bias] = ln[64:64 + DIM], ln[128:128 + DIM]
+    for l, (attn, ff) in enumerate(vit.transformer.layers):
+        b = 192 + 256 * l
+        grads[attn.norm.weight], grads[attn.norm.bias] = ln[b:b + DIM], ln[b + 64:b + 64 + DIM]
+        grads[ff.net[0].weight], grads[ff.net[0].bias] = ln[b + 128:b + 128 + DIM], ln[b + 192:b + 192 + DIM]
+        q = 2 + 4 * l
+        grads[attn.to_qkv.weight] = wg[q][0]
+        grads[attn.to_out.weight] = wg[q + 1][0]
+        grads[ff.net[1].weight], grads[ff.net[1].bias] = wg[q + 2]
+        grads[ff.net[3].weight], grads[ff.net[3].bias] = wg[q + 3]
+    b = 192 + 256 * depth
+    grads[vit.transformer.norm.weight], grads[vit.transformer.norm.bias] = ln[b:b + DIM], ln[b + 64:b + 64 + DIM]
+    # ---- Conv1x1 / ActNorm chain from the folded matrix / bias gradient (W' = diag(s) Wm, b' = -t s)
+    gWp, gbp = wg[0]
+    if gsum is None:
+        gsum = gld.sum().reshape(1)
+    lad = torch.empty(1, device=dev, dtype=torch.float32)
+    winv = torch.empty(C, C, device=dev, dtype=torch.float32)
+    _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
+    gNN, gt, glogs = torch.empty(C, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    _hip.call("cf_step_param_grads", pp(gWp.contiguous()), pp(gbp.contiguous()), pp(Wm), pp(t), pp(logs), pp(winv), pp(f(gsum)),
+              xv.shape[2] * xv.shape[3], pp(gNN), pp(gt), pp(glogs), C, st)
+    grads[conv.NN] = gNN.view_as(conv.NN)
+    grads[act.NN_t], grads[act.NN_logs] = gt.view_as(act.NN_t), glogs.view_as(act.NN_logs)
+    return gx, grads
+
+
 # ------------------------------------------------------------------------------------------------ the Function
 class FlowLogProb(torch.autograd.Function):
     """logp (B,M) of a FlowSequential with parameter gradients.  `params` are passed positionally only so that autograd
@@ -176,6 +276,10 @@ class FlowLogProb(torch.autograd.Function):
             elif kind == "step":
                 _, xin, sq, conv, act, cpl, shape, ws, winv, planes = rec
                 gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum)
+                add(gp)
+            elif kind == "vstep":
+                _, xin, conv, act, cpl = rec
+                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum)
                 add(gp)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)

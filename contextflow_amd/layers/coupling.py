@@ -261,19 +261,30 @@ class TransCoupling(_AffineCoupling):
         """Parameters the packed step workspace derives from (cache key of FlowSequential)."""
         return tuple(self.NN[0].parameters())
 
-    def step_prepare(self, Wm, t, logs, dev):
+    # batches up to this size take the row-split step kernel (cf_vit_step_rs_fwd: 4 samples per workgroup, an eighth of the
+    # serial chain); larger ones the one-wave-per-8-samples kernel (cf_vit_step_fwd)
+    STEP_RS_MAX_BATCH = 2048
+
+    def step_variant(self, B):
+        """'rs' | 'wave': which one-kernel form of the step a batch of B samples takes (FlowSequential keys its packed
+        workspaces on it: the two kernels have their own fragment layouts)."""
+        return "rs" if B <= self.STEP_RS_MAX_BATCH else "wave"
+
+    def step_prepare(self, Wm, t, logs, dev, variant="wave"):
         """Pack Conv1x1 / ActNorm / ViT parameters into the fragment order of the one-kernel step."""
         vit = self.NN[0]
         C, depth = self.in_sz[0], len(vit.transformer.layers)
-        ws = torch.empty(_hip.lib().cf_vit_step_ws_bytes(C, depth), device=dev, dtype=torch.uint8)
+        rs = variant == "rs"
+        L = _hip.lib()
+        ws = torch.empty((L.cf_vit_step_rs_ws_bytes if rs else L.cf_vit_step_ws_bytes)(C, depth), device=dev, dtype=torch.uint8)
         if vit.pos_embedding.device != dev:
             vit.pos_embedding = vit.pos_embedding.to(dev).contiguous()
         flat = self._flat_params()
-        _hip.call("cf_vit_step_prepare", _hip.p(_hip.f32(Wm.detach())), _hip.p(_hip.f32(t.detach())), _hip.p(_hip.f32(logs.detach())),
-                  _hip.p(flat), _hip.p(_hip.f32(vit.pos_embedding)), _hip.p(ws), C, depth, _hip.stream())
+        _hip.call("cf_vit_step_rs_prepare" if rs else "cf_vit_step_prepare", _hip.p(_hip.f32(Wm.detach())), _hip.p(_hip.f32(t.detach())),
+                  _hip.p(_hip.f32(logs.detach())), _hip.p(flat), _hip.p(_hip.f32(vit.pos_embedding)), _hip.p(ws), C, depth, _hip.stream())
         return ws
 
-    def step_forward(self, x, ws, ld1, h_out=None):
+    def step_forward(self, x, ws, ld1, h_out=None, variant="wave"):
         """z = TransCoupling(ActNorm(Conv1x1(x))) and ld1 += the step's log-det, one launch."""
         x, xbs = _hip.bview(x)
         B, C = x.shape[0], x.shape[1]
@@ -283,7 +294,8 @@ class TransCoupling(_AffineCoupling):
         if events is not None:               # bench.py: HIP events on the launch stream around exactly this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(x.device))
-        _hip.call("cf_vit_step_fwd", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), _hip.p(h_out), B, C, depth, xbs, _hip.stream())
+        _hip.call("cf_vit_step_rs_fwd" if variant == "rs" else "cf_vit_step_fwd", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws),
+                  _hip.p(h_out), B, C, depth, xbs, _hip.stream())
         if events is not None:
             e1.record(torch.cuda.current_stream(x.device))
             events.append((e0, e1, B))

@@ -66,6 +66,7 @@ class FlowSequential(nn.Module):
         # forward is captured into a HIP graph and replayed (batches up to AUTO_GRAPH_MAX_BATCH); set False to disable
         self.auto_graph = True
         self._graphs = {}            # (shape, device) -> [stable calls, versions, GraphedFlow | None]
+        self._graph_policy = {}      # (shape, device) -> replaying beat eager launches when it was measured (else: stay eager)
         self._rng_key = 0            # Philox key of the in-kernel noise (rank folded in); the stream position is drawn per call
 
     def __iter__(self):
@@ -74,7 +75,7 @@ class FlowSequential(nn.Module):
     def __getstate__(self):              # streams / cached plans are per-process runtime state
         d = self.__dict__.copy()
         d["_plans"], d["_side"], d["step_events"] = {}, {}, None
-        d["_prep"], d["_graphs"] = {}, {}
+        d["_prep"], d["_graphs"], d["_graph_policy"] = {}, {}, {}
         return d
 
     def invalidate_caches(self):
@@ -242,6 +243,7 @@ class FlowSequential(nn.Module):
         prepared = {}
         cache_ok = tape is None
         todo = []
+        vkey = {}
         # a capturing stream must not wait on an event recorded outside the capture - and need not: torch.cuda.graph
         # synchronises the device before the capture begins, so cached tables are complete by then
         capturing = torch.cuda.is_current_stream_capturing()
@@ -249,15 +251,14 @@ class FlowSequential(nn.Module):
             if op[0] == "step":
                 srcs = (op[1].NN, op[2].NN_t, op[2].NN_logs) + tuple(p for c in (op[3].NN[0], op[3].NN[2], op[3].NN[4]) for p in (c.weight, c.bias))
             elif op[0] == "vstep":
-                if tape is not None:
-                    continue                 # training runs the three layers with their own backward kernels
                 srcs = (op[1].NN, op[2].NN_t, op[2].NN_logs) + op[3].step_sources()
+                vkey[k] = op[3].step_variant(B)      # small / saturating batches: two kernels, two fragment layouts
             elif op[0] == "split":
                 srcs = (op[1].dist.mG, op[1].dist.sG, op[1].dist.wG)
             else:
                 continue
             ver = tuple(t._version for t in srcs) + (dev.index,)
-            hit = self._prep.get((key, k)) if cache_ok else None
+            hit = self._prep.get((key, k, vkey.get(k))) if cache_ok else None
             if hit is not None and hit[0] == ver:
                 prepared[k] = (hit[1], None if capturing else hit[2])      # the producer's event stays with the entry: a later call on ANOTHER
             else:                                    # stream is ordered against the side stream that wrote the buffers
@@ -278,7 +279,7 @@ class FlowSequential(nn.Module):
                         else:
                             buf = self._prepare_step(op[1], op[2], op[3], op[4], dev)
                     elif op[0] == "vstep":
-                        buf = op[3].step_prepare(op[1].NN, op[2].NN_t, op[2].NN_logs, dev)
+                        buf = op[3].step_prepare(op[1].NN, op[2].NN_t, op[2].NN_logs, dev, vkey[k])
                     else:
                         buf = op[1].dist.prepared()
                     ev = torch.cuda.Event()
@@ -286,7 +287,7 @@ class FlowSequential(nn.Module):
                     prepared[k] = (buf, ev)
                     fresh.add(k)
                     if cache_ok:
-                        self._prep[(key, k)] = (ver, buf, ev)
+                        self._prep[(key, k, vkey.get(k))] = (ver, buf, ev)
                 if prior is None:
                     prior = self.dist.prepared()
                     ev_prior = torch.cuda.Event()
@@ -369,16 +370,12 @@ class FlowSequential(nn.Module):
                     events.append((e0, e1, B, C, H * W))
                 x = z
             elif kind == "vstep":
-                if tape is not None:
-                    for m in op[1:4]:
-                        tape.append(("layer", m, x))
-                        x, ldj = m(x, context)
-                        ld1 += ldj
-                    continue
+                if tape is not None:         # training: the same one-kernel forward; the backward re-runs the step from its input
+                    tape.append(("vstep", x, op[1], op[2], op[3]))
                 ws, ev = prepared[k]
                 if ev is not None:
                     main.wait_event(ev)
-                x = op[3].step_forward(x, ws, ld1)
+                x = op[3].step_forward(x, ws, ld1, variant=vkey[k])
             elif kind == "squeeze":
                 if tape is not None:
                     tape.append(("squeeze", tuple(op[1].p)))
@@ -485,11 +482,39 @@ class FlowSequential(nn.Module):
             self._graphs[gkey] = [1, ver, None]
             return None
         if st[2] is None:
+            if self._graph_policy.get(gkey) is False:    # measured before for this shape: eager launches are faster
+                return None
             st[0] += 1
             if st[0] <= self.AUTO_GRAPH_AFTER:
                 return None
             st[2] = GraphedFlow(self, x, warmup=1)
+            if gkey not in self._graph_policy:
+                self._graph_policy[gkey] = self._replay_wins(st[2], x)
+                if not self._graph_policy[gkey]:
+                    st[2] = None
+                    return None
         return st[2]
+
+    def _replay_wins(self, g, x, n=3):
+        """A replayed node costs ~7-12 us whatever its kernel does, eager launches are queued ahead of the running kernel:
+        with kernels longer than that (the transformer steps: ~90 us each at a batch of 256) the eager forward is the faster
+        one.  Measured once per input shape (the answer does not depend on parameter values): n eager forwards against n
+        replays, wall time; the generator is handed back as it was, so the noise sequence does not see the probe."""
+        import time
+        dev = x.device
+        gen = torch.cuda.default_generators[dev.index]
+        gstate = gen.get_state()
+        t = []
+        for run in (lambda: self._forward_fused(x, None), lambda: g(x)):
+            run()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                run()
+            torch.cuda.synchronize(dev)
+            t.append(time.perf_counter() - t0)
+        gen.set_state(gstate)
+        return t[1] < t[0]
 
     def capture_train_step(self, example_input, loss_fn, optimizer, warmup=1):
         """One whole training step - forward, loss, hand-written backward, optimizer update - captured into ONE HIP graph

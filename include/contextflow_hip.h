@@ -274,6 +274,13 @@ int64_t cf_linear_wgrad_ws_bytes(int rows, int K, int N);
 int cf_linear_wgrad(const float* x, const float* gy, float* gW, float* gb, void* ws, int rows, int K, int N,
                     cf_stream_t stream);
 int cf_linear_wgrad_x2(const float* x, const float* gy, float* gW, void* ws, int rows, int K, int N, cf_stream_t stream);
+/* A group of up to 32 such weight gradients in ONE launch pair (the Linears of a transformer flow step are far too small
+ * to fill the chip one by one): member i: gW[i] (N[i], K[i]) = gy[i]^T x[i] over rows[i] rows, gb[i] (N[i]; may be NULL) =
+ * column sums of gy[i]; x[i] (rows[i], K[i]) and gy[i] (rows[i], N[i]) dense.  N <= 192, K + 1 <= (12 - ceil(N/32)) * 32.
+ * The pointer / size arrays live on the HOST; ws: cf_linear_wgrad_group_ws_bytes bytes on the device.                  */
+int64_t cf_linear_wgrad_group_ws_bytes(const int* rows, const int* K, const int* N, int n);
+int cf_linear_wgrad_group(const float* const* x, const float* const* gy, float* const* gW, float* const* gb, const int* rows,
+                          const int* K, const int* N, int n, void* ws, cf_stream_t stream);
 /* y[r,:] = LayerNorm(x[r,:])*w + b (+ pos[r % ntok,:] if pos != NULL); biased variance, eps.          */
 int cf_layernorm(const float* x, const float* w, const float* b, const float* pos, float* y,
                  int rows, int dim, int ntok, float eps, cf_stream_t stream);
@@ -313,6 +320,38 @@ int cf_vit_step_prepare(const float* Wm, const float* t, const float* logs, cons
                         void* ws, int C, int depth, cf_stream_t stream);
 int cf_vit_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, float* h_out, int B, int C, int depth,
                     int64_t x_bstride, cf_stream_t stream);
+
+/* The same step for SMALL batches (the reference's operating point is 256 samples, config.py:10), row-split: the four waves
+ * of a workgroup share 16 token columns (4 samples) and split the output rows of every Linear (v_mfma_f32_16x16x4_f32,
+ * planes through LDS; csrc/cf_vit_rs.hip) - an eighth of the serial chain of cf_vit_step_fwd per workgroup, at 8x the
+ * workgroups.  Its own workspace layout (LayerNorm weights folded into the packed Linears); same arguments and results. */
+int cf_vit_step_rs_supported(int C, int H, int W, int p1, int p2, int dim, int dim_head, int heads);
+int64_t cf_vit_step_rs_ws_bytes(int C, int depth);
+int cf_vit_step_rs_prepare(const float* Wm, const float* t, const float* logs, const float* flat_vit_params, const float* pos,
+                           void* ws, int C, int depth, cf_stream_t stream);
+int cf_vit_step_rs_fwd(const float* x, float* z, float* ldj_acc, const void* ws, float* h_out, int B, int C, int depth,
+                       int64_t x_bstride, cf_stream_t stream);
+
+/* Backward of that step as ONE kernel (training step of the anomaly-detection flows, experiment_ad.py:204-213;
+ * csrc/cf_vit_rs_bwd.hip): from the step INPUT x, dL/dz (gz, dense (B,C,8,1)) and dL/d(log-det) (gld (B,)) it re-runs the
+ * step in the row-split form, walks back and writes dL/dx (gx, dense) plus
+ *   planes: the operands of every weight gradient as token-major matrices, Bp = B rounded up to 4, R = 4 Bp token rows,
+ *           P = 8 Bp position rows, in floats from the start:
+ *             [ x^T (P,26) | g_y (P,26) | u0 (R,26) | g_e (R,52) | per layer l: u1 (R,52) | g_qkv (R,192) | o (R,64) | g_xmid (R,52) |
+ *               u2 (R,52) | g_hpre (R,52) | h (R,52) | g_xout (R,52) ]
+ *           i.e. gW(Conv1x1+ActNorm folded) = g_y^T x^T, gW(embed) = g_e^T u0, gW(qkv) = g_qkv^T u1, gW(out) = g_xmid^T o,
+ *           gW(fc1) = g_hpre^T u2, gW(fc2) = g_xout^T h (cf_linear_wgrad_group contracts them in one launch);
+ *   ln_partials: ceil(B/4) rows of cf_vit_step_bwd_ln_floats / ceil(B/4) floats: per-workgroup sums of the LayerNorm
+ *           weight / bias gradients: [LN(pd): g 32 | b 32][LN(dim) of the embedding: g 64 | b 64][per layer: attention norm
+ *           g 64 | b 64 | feed-forward norm g 64 | b 64][transformer.norm: g 64 | b 64]; the column sums are the gradients.
+ * ws: cf_vit_step_rs_prepare; wsb: cf_vit_step_bwd_prepare (cf_vit_step_bwd_ws_bytes).  depth <= 6.                    */
+int64_t cf_vit_step_bwd_ws_bytes(int C, int depth);
+int64_t cf_vit_step_bwd_plane_floats(int B, int C, int depth);
+int64_t cf_vit_step_bwd_ln_floats(int B, int C, int depth);
+int cf_vit_step_bwd_prepare(const float* Wm, const float* logs, const float* flat_vit_params, void* wsb, int C, int depth,
+                            cf_stream_t stream);
+int cf_vit_step_bwd(const float* x, const float* gz, const float* gld, float* gx, const void* ws, const void* wsb, float* planes,
+                    float* ln_partials, int B, int C, int depth, int64_t x_bstride, cf_stream_t stream);
 
 /* ---- SplineActivation: monotone rational-quadratic spline, linear tails (layers/activations.py:120-211,
  * layers/splines/rational_quadratic.py:21-176) ----------------------------------------------------- */
