@@ -194,7 +194,7 @@ __device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ x, c
                 const bool isg = cb < NT;                                         // uniform
                 const int col = cb * 32 + c32 - (isg ? 0 : NS);                   // n, or k
                 const float* src = isg ? gy + rc * ldy + min(col, N - 1) : x + rc * ldx + min(col, K - 1);
-                stg[i][cb] = *src;
+                stg[i][cb] = cb < NT + KT ? *src : 0.f;                           // (uniform) blocks past [gy | x, 1] are never read
                 if (XSQ && !isg) stg[i][cb] *= stg[i][cb];
             }
         }
@@ -208,7 +208,7 @@ __device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ x, c
                 const int col = cb * 32 + c32 - (isg ? 0 : NS);
                 const float v = isg ? ((ok && col < N) ? stg[i][cb] : 0.f)        // rows past the end contribute nothing
                                     : (col < K ? stg[i][cb] : (col == K ? 1.f : 0.f));
-                lds[r * WG_LS + cb * 32 + c32] = v;
+                if (cb < NT + KT) lds[r * WG_LS + cb * 32 + c32] = v;
             }
         }
         __syncthreads();

@@ -150,11 +150,18 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
 #pragma unroll
         for (int i = 0; i < V::KS_D; ++i) xv[i] = P[(g + 4 * i) * TS + col];
     };
-    // plane [nrows][TS] -> token-major rows of `dst` (row stride ld): lane = feature, coalesced
+    // plane [nrows][TS] -> token-major rows of `dst` (row stride ld): lane = feature (coalesced, conflict-free LDS reads),
+    // wave w takes tokens w, w + 4, ..; no integer divisions
     auto store_T = [&](const float* P, int nrows, float* dst, int ld) {
-        for (int it = tid; it < nrows * V::TOK; it += 256) {
-            const int f = it % nrows, t = it / nrows;
-            dst[(int64_t)(tok0 + t) * ld + f] = P[f * TS + t];
+        for (int f0 = 0; f0 < nrows; f0 += 64) {
+            const int f = f0 + lane;
+            if (f < nrows) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = w + 4 * j;
+                    dst[(int64_t)(tok0 + t) * ld + f] = P[f * TS + t];
+                }
+            }
         }
     };
     auto masked = [&](const f32x4& v) {

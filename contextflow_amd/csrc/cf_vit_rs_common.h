@@ -49,12 +49,16 @@ __global__ __launch_bounds__(256) void k_vit_rs_pack(const float* __restrict__ W
             dst[i] = (row < N && k < K) ? W[row * K + k] * (gamma ? gamma[k] : 1.0f) : 0.f;
         }
     };
-    // bias'[row] = bias[row] + sum_k W[row][k] beta[k]  (beta: the preceding LayerNorm's bias), rows >= N: 0
+    // bias'[row] = bias[row] + sum_k W[row][k] beta[k]  (beta: the preceding LayerNorm's bias), rows >= N: 0.  A wave per
+    // row, lanes along k (coalesced), fp64 partial sums combined in a fixed order
     auto fold_bias = [&](float* dst, const float* W, const float* bias, const float* beta, int N, int K, int rows) {
-        for (int r = gtid; r < rows; r += gsz) {
-            double s = (r < N && bias) ? (double)bias[r] : 0.0;
-            if (r < N && beta) for (int k = 0; k < K; ++k) s += (double)W[r * K + k] * (double)beta[k];
-            dst[r] = (float)s;
+        const int lane = threadIdx.x & 63, gw = gtid >> 6, nw = gsz >> 6;
+        for (int r = gw; r < rows; r += nw) {
+            double s = 0.0;
+            if (r < N && beta) for (int k = lane; k < K; k += 64) s += (double)W[r * K + k] * (double)beta[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) dst[r] = (float)(s + ((r < N && bias) ? (double)bias[r] : 0.0));
         }
     };
     auto vec = [&](float* dst, const float* src, int n, int rows) {

@@ -163,7 +163,7 @@ def wgrad_group(members, dev):
     return res
 
 
-def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None):
+def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None):
     """Conv1x1 -> ActNorm -> TransCoupling (one fused step of the transformer flows) backwards: ONE kernel re-runs the step
     from its input and walks back (cf_vit_step_bwd), ONE grouped launch contracts the 26 weight-gradient operand pairs it
     leaves (cf_linear_wgrad_group), the LayerNorm gradients are column sums of its per-workgroup partials, and the Conv1x1 /
@@ -176,7 +176,8 @@ def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None):
     L = _hip.lib()
     f, pp, st = _hip.f32, _hip.p, _hip.stream()
     Wm, t, logs = f(conv.NN.detach()), f(act.NN_t.detach()), f(act.NN_logs.detach())
-    ws = cpl.step_prepare(conv.NN, act.NN_t, act.NN_logs, dev, "rs")
+    if ws is None:                                        # the forward ran the wave form: pack the row-split table now
+        ws = cpl.step_prepare(conv.NN, act.NN_t, act.NN_logs, dev, "rs")
     flat = cpl._flat_params()
     wsb = torch.empty(L.cf_vit_step_bwd_ws_bytes(C, depth), device=dev, dtype=torch.uint8)
     _hip.call("cf_vit_step_bwd_prepare", pp(Wm), pp(logs), pp(flat), pp(wsb), C, depth, st)
@@ -278,8 +279,8 @@ class FlowLogProb(torch.autograd.Function):
                 gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum)
                 add(gp)
             elif kind == "vstep":
-                _, xin, conv, act, cpl = rec
-                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum)
+                _, xin, conv, act, cpl, ws_rs = rec
+                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs)
                 add(gp)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)

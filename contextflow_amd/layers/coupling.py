@@ -263,7 +263,7 @@ class TransCoupling(_AffineCoupling):
 
     # batches up to this size take the row-split step kernel (cf_vit_step_rs_fwd: 4 samples per workgroup, an eighth of the
     # serial chain); larger ones the one-wave-per-8-samples kernel (cf_vit_step_fwd)
-    STEP_RS_MAX_BATCH = 2048
+    STEP_RS_MAX_BATCH = 4096          # measured cross-over (tools/dev/vit_variants.py): 77 vs 89 us at 4096, 132 vs 91 at 8192
 
     def step_variant(self, B):
         """'rs' | 'wave': which one-kernel form of the step a batch of B samples takes (FlowSequential keys its packed
@@ -302,6 +302,18 @@ class TransCoupling(_AffineCoupling):
         return z
 
     def _flat_params(self):
+        """The ViT parameters as one flat fp32 tensor in the order the pack kernels read them; kept until a parameter's
+        version counter moves (a training step asks for it twice: forward and backward)."""
+        vit = self.NN[0]
+        ver = tuple(p._version for p in vit.parameters()) + tuple(p.data_ptr() for p in vit.parameters())
+        hit = getattr(self, "_flat_cache", None)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        flat = self._flat_params_build()
+        self._flat_cache = (ver, flat)
+        return flat
+
+    def _flat_params_build(self):
         vit = self.NN[0]
         tpe = vit.to_patch_embedding
         parts = [tpe[1].weight, tpe[1].bias, tpe[2].weight, tpe[2].bias, tpe[3].weight, tpe[3].bias]

@@ -87,6 +87,8 @@ class FlowSequential(nn.Module):
         for m in self.modules():
             if hasattr(m, "_tab_cache"):
                 m._tab_cache = None
+            if hasattr(m, "_flat_cache"):
+                m._flat_cache = None
 
     def _apply(self, fn, *a, **k):         # .to() / .cuda() / .float(): new storages, same version counters
         self._prep, self._graphs, self._plans = {}, {}, {}
@@ -370,9 +372,10 @@ class FlowSequential(nn.Module):
                     events.append((e0, e1, B, C, H * W))
                 x = z
             elif kind == "vstep":
-                if tape is not None:         # training: the same one-kernel forward; the backward re-runs the step from its input
-                    tape.append(("vstep", x, op[1], op[2], op[3]))
                 ws, ev = prepared[k]
+                if tape is not None:         # training: the same one-kernel forward; the backward re-runs the step from its input
+                    #                          (and reuses the packed forward table when it is the row-split one)
+                    tape.append(("vstep", x, op[1], op[2], op[3], ws if vkey[k] == "rs" else None))
                 if ev is not None:
                     main.wait_event(ev)
                 x = op[3].step_forward(x, ws, ld1, variant=vkey[k])
