@@ -258,8 +258,12 @@ class TransCoupling(_AffineCoupling):
         return bool(_hip.lib().cf_vit_step_supported(C, H, W, self.p_sz[0], self.p_sz[1], vit.dim, att.dim_head, att.heads))
 
     def step_sources(self):
-        """Parameters the packed step workspace derives from (cache key of FlowSequential)."""
-        return tuple(self.NN[0].parameters())
+        """Parameters the packed step workspace derives from (cache key of FlowSequential).  The tuple is built once: walking
+        the module tree costs more host time per call than the whole step kernel takes at a batch of 256."""
+        src = getattr(self, "_step_src", None)
+        if src is None:
+            src = self._step_src = tuple(self.NN[0].parameters())
+        return src
 
     # batches up to this size take the row-split step kernel (cf_vit_step_rs_fwd: 4 samples per workgroup, an eighth of the
     # serial chain); larger ones the one-wave-per-8-samples kernel (cf_vit_step_fwd)
@@ -304,8 +308,8 @@ class TransCoupling(_AffineCoupling):
     def _flat_params(self):
         """The ViT parameters as one flat fp32 tensor in the order the pack kernels read them; kept until a parameter's
         version counter moves (a training step asks for it twice: forward and backward)."""
-        vit = self.NN[0]
-        ver = tuple(p._version for p in vit.parameters()) + tuple(p.data_ptr() for p in vit.parameters())
+        src = self.step_sources()
+        ver = tuple(p._version for p in src) + tuple(p.data_ptr() for p in src)
         hit = getattr(self, "_flat_cache", None)
         if hit is not None and hit[0] == ver:
             return hit[1]

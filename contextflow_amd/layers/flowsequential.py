@@ -67,6 +67,7 @@ class FlowSequential(nn.Module):
         self.auto_graph = True
         self._graphs = {}            # (shape, device) -> [stable calls, versions, GraphedFlow | None]
         self._graph_policy = {}      # (shape, device) -> replaying beat eager launches when it was measured (else: stay eager)
+        self._tensors = None         # parameters + buffers, collected once (_versions)
         self._rng_key = 0            # Philox key of the in-kernel noise (rank folded in); the stream position is drawn per call
 
     def __iter__(self):
@@ -75,7 +76,7 @@ class FlowSequential(nn.Module):
     def __getstate__(self):              # streams / cached plans are per-process runtime state
         d = self.__dict__.copy()
         d["_plans"], d["_side"], d["step_events"] = {}, {}, None
-        d["_prep"], d["_graphs"], d["_graph_policy"] = {}, {}, {}
+        d["_prep"], d["_graphs"], d["_graph_policy"], d["_tensors"] = {}, {}, {}, None
         return d
 
     def invalidate_caches(self):
@@ -91,11 +92,14 @@ class FlowSequential(nn.Module):
                 m._flat_cache = None
 
     def _apply(self, fn, *a, **k):         # .to() / .cuda() / .float(): new storages, same version counters
-        self._prep, self._graphs, self._plans = {}, {}, {}
+        self._prep, self._graphs, self._plans, self._tensors = {}, {}, {}, None
         return super()._apply(fn, *a, **k)
 
     def _versions(self):
-        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        ts = self._tensors
+        if ts is None:                       # the module tree is walked once (580 tensors in ~300 modules for the smap flow: per call
+            ts = self._tensors = tuple(self.parameters()) + tuple(self.buffers())    # that walk cost more than the replayed forward)
+        return tuple(t._version for t in ts)
 
     # ------------------------------------------------------------------ layer-by-layer mode
     def _forward_layers(self, input, context):
