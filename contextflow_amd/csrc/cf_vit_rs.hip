@@ -29,8 +29,11 @@ namespace {
 // ---- the forward kernel ---------------------------------------------------------------------------------------------------
 // x, z: (B, C, 8, 1).  ldj_acc[b] += H*W*log|det W| + sum logs + sum log_s.  hout (optional, tests): the conditioner's
 // output un-patchified, (B, C, 8, 1) = [t | raw].
+#ifndef CF_VIT_RS_MINW
+#define CF_VIT_RS_MINW 1
+#endif
 template <class V>
-__global__ __launch_bounds__(256) void k_vit_step_rs(const float* __restrict__ x, float* __restrict__ z,
+__global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float* __restrict__ x, float* __restrict__ z,
                                                      float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
                                                      int64_t xbs, int depth, float* __restrict__ hout) {
     constexpr int C = V::C, CIN = V::CIN, HW = V::HW, DIM = V::DIM, PD = V::PD, TOK = V::TOK, POSC = V::POSC;

@@ -4,7 +4,7 @@
 // layers/conv1x1.py:52-57, layers/actnorm.py:53-60).  Round 2 trained these flows layer by layer: ~260 launches per step.
 //
 // Shape: the row-split workgroup of cf_vit_rs.hip - four waves share 16 token columns (4 samples) and split the output
-// rows of every product, planes [feature][16 tokens] in LDS (78 KB: two workgroups per CU).  Nothing but the step INPUT is
+// rows of every product, planes [feature][16 tokens] in LDS (52.7 KB: three workgroups per CU).  Nothing but the step INPUT is
 // kept from the forward:
 //   phase A  re-runs the step (the forward kernel's arithmetic) and parks the residual stream at every layer boundary in
 //            LDS (the owner wave's tile only: 16 B per lane and layer);
@@ -34,10 +34,16 @@ template <class V> struct RSB {
     static constexpr int LB_W2T = LB_W1T + 4 * V::NG_D * 256, LB_STRIDE = LB_W2T + 4 * V::NG_D * 256;
     // LDS (floats).  Planes [feature][TS] with TS = 17: the transposed (lane = feature) global stores read them conflict-free
     static constexpr int TS = 17, PS = 33, PL = 64 * TS;
-    static constexpr int P_XIN = 0, P_Y = P_XIN + 4 * V::KS_C * PS, P_GY = P_Y + 32 * PS;
-    static constexpr int P_A = P_GY + 32 * PS, P_B = P_A + PL, P_O = P_B + PL, P_H = P_O + PL, P_G = P_H + PL, P_Q = P_G + PL;
-    static constexpr int P_SC = P_Q + 192 * TS, P_XS = (P_SC + 2 * 256 + 3) & ~3;      // SC: two halves of [4 waves][4][16]
-    static constexpr int LDS_FLOATS = P_XS + (MAXD + 1) * 1024;
+    // 52.7 KB: three workgroups per CU.  The gradient plane of q | k | v (192 rows) lives on the three planes that are dead by
+    // then (layer input / LayerNorm output / MLP hidden layer), the step input on the attention-output plane (dead after
+    // the Conv1x1 product); the residual stream is parked for the layer boundaries 1 .. depth - 1 only (boundary 0 is
+    // rebuilt from the embedding, the last one is consumed where it is produced).
+    static constexpr int P_Y = 0, P_GY = P_Y + 32 * PS;
+    static constexpr int P_A = P_GY + 32 * PS, P_B = P_A + PL, P_H = P_B + PL, P_O = P_H + PL, P_G = P_O + PL;
+    static constexpr int P_Q = P_A, P_XIN = P_O;
+    static constexpr int P_SC = P_G + PL, P_XS = (P_SC + 2 * 256 + 3) & ~3;            // SC: two halves of [4 waves][4][16]
+    static constexpr int LDS_FLOATS = P_XS + (MAXD - 1) * 1024;
+    static_assert(4 * V::KS_C * PS <= PL && 192 * TS <= 3 * PL, "aliased planes fit");
     // LayerNorm partial sums of one workgroup (floats): [gamma | beta] per LayerNorm
     static constexpr int LN_0 = 0, LN_1 = 64, LN_L = 192, LN_LSTRIDE = 256;       // per layer: [ga | ba | gf | bf]
     __host__ __device__ static constexpr int ln_final(int depth) { return LN_L + depth * LN_LSTRIDE; }
@@ -99,7 +105,7 @@ __device__ __forceinline__ float gelu_d(float x) {                    // d/dx of
 // ws: forward workspace of cf_vit_step_rs_prepare; wsb: k_vit_rs_pack_bwd.  tp: token-major planes (layout: RSB::TL_*,
 // see cf_vit_step_bwd_plane_floats); lnp: one row of LayerNorm partial sums per workgroup.
 template <class V>
-__global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restrict__ x, const float* __restrict__ gz,
+__global__ __launch_bounds__(256, 3) void k_vit_step_bwd_rs(const float* __restrict__ x, const float* __restrict__ gz,
                                                             const float* __restrict__ gld, float* __restrict__ gx,
                                                             const float* __restrict__ ws, const float* __restrict__ wsb,
                                                             float* __restrict__ tp, float* __restrict__ lnp, int B, int Bp,
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
     float* PG = lds + R::P_G;      // gradient of the residual stream
     float* PQ = lds + R::P_Q;      // [192][TS] gradient of q | k | v
     float* SC = lds + R::P_SC;     // [2][4 waves][2 .. 4][16] exchange between the waves (ping-pong)
-    float* XS = lds + R::P_XS;     // [depth + 1][256 threads][4] the owner's tile of the residual stream per layer boundary
+    float* XS = lds + R::P_XS;     // [depth - 1][256 threads][4] the owner's tile of the residual stream at the layer boundaries 1 ..
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s0 = blockIdx.x * V::SPW, tok0 = blockIdx.x * V::TOK, pos0 = blockIdx.x * V::POSC;
@@ -207,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         for (int r = 0; r < 4; ++r) o[r] = valid[r] ? (X[r] - mean) * rstd : 0.f;
         return o;
     };
-    auto xs_put = [&](int l, const f32x4& v) { *reinterpret_cast<float4*>(&XS[(l * 256 + tid) * 4]) = make_float4(v[0], v[1], v[2], v[3]); };
-    auto xs_get = [&](int l) { return to4(*reinterpret_cast<const float4*>(&XS[(l * 256 + tid) * 4])); };
+    auto xs_put = [&](int l, const f32x4& v) { *reinterpret_cast<float4*>(&XS[((l - 1) * 256 + tid) * 4]) = make_float4(v[0], v[1], v[2], v[3]); };
+    auto xs_get = [&](int l) { return to4(*reinterpret_cast<const float4*>(&XS[((l - 1) * 256 + tid) * 4])); };   // l >= 1
 
     // fragments of one layer's forward products (for the recompute) - requested one product ahead
     float4 fqkv[3][V::NG_D], fout[V::NG_H], ffc1[V::NG_D], ffc2[V::NG_D];
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         XIN[c * PS + pc] = (c < C && b < B) ? x[(int64_t)b * xbs + c * HW + pc % HW] : 0.f;
     }
     for (int i = tid; i < 6 * PS; i += 256) GYP[26 * PS + i] = 0.f;            // channel rows past C: zero operands
-    for (int i = tid; i < 12 * TS; i += 256) { PG[52 * TS + i] = 0.f; PO[52 * TS + i] = 0.f; }
+    for (int i = tid; i < 12 * TS; i += 256) PG[52 * TS + i] = 0.f;
     __syncthreads();
     for (int it = tid; it < V::POSC * C; it += 256) {                          // x, position-major (operand of the Conv1x1 weight gradient)
         const int c = it % C, pc = it / C;
@@ -306,9 +312,15 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) X[r] = fmaf((e_own[r] - mean_e) * rstd_e, g1[r], b1[r]) + pe[r];
         put(PA, X);
-        xs_put(0, X);
         __syncthreads();
     }
+    auto embed_out = [&]() {                                                   // the residual stream at layer boundary 0, owner's rows
+        const f32x4 g1 = vec4(ws + V::OFF_LN1, w, g), b1 = vec4(ws + V::OFF_LN1 + 64, w, g), pe = vec4(ws + V::OFF_POS + 64 * n, w, g);
+        f32x4 X;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[r] = fmaf((e_own[r] - mean_e) * rstd_e, g1[r], b1[r]) + pe[r];
+        return X;
+    };
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
         const int wl = V::OFF_LAYER + l * V::L_STRIDE, ln = (l + 1 < depth ? l + 1 : l), wn = V::OFF_LAYER + ln * V::L_STRIDE;
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         __builtin_amdgcn_sched_barrier(0);
         put(PO, o);
         __syncthreads();
-        f32x4 X = xs_get(l);
+        f32x4 X = l > 0 ? xs_get(l) : embed_out();
         {
             const f32x4 a = gemm1<V::KS_H>(f32x4{0.f, 0.f, 0.f, 0.f}, fout, [&](int s) { return PO[(4 * s + g) * TS + col]; });
             __builtin_amdgcn_sched_barrier(0);
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
             __builtin_amdgcn_sched_barrier(0);
             X += a;
             put(PA, X);
-            xs_put(l + 1, X);
+            if (l + 1 < depth) xs_put(l + 1, X);
         }
         __syncthreads();
     }
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         float xv[V::KS_D];
         rows13(PA, xv);
         token_stats(xv, DIM, g, mean_n, rstd_n);
-        un = normalised(xs_get(depth), mean_n, rstd_n);
+        un = normalised(get(PA), mean_n, rstd_n);                              // the last boundary: still in the plane, owner's rows
         const f32x4 gn = vec4(ws + off_lno<V>(depth), w, g), bn = vec4(ws + off_lno<V>(depth) + 64, w, g);
         f32x4 hn;
 #pragma unroll
@@ -405,16 +417,13 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         const int wl = V::OFF_LAYER + l * V::L_STRIDE, bl = R::OFF_LAYER + l * R::LB_STRIDE, lp = l > 0 ? l - 1 : 0;
         float* tl = tL + (int64_t)l * R4 * R::TL;
         // ---- recompute the layer from its parked input
-        const f32x4 Xin = xs_get(l);
+        const f32x4 Xin = l > 0 ? xs_get(l) : embed_out();
         put(PA, Xin);
         load_frags(ffc1, rs, lane, wl + V::L_W1 + w * V::NG_D * 256);
         __syncthreads();
         float mean1, rstd1, mean2, rstd2, p[4];
         f32x4 q, k, v, o;
         layer_front(l, mean1, rstd1, q, k, v, p, o);
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(f2T, rb, lane, bl + R::LB_W2T + w * V::NG_D * 256);
-        __builtin_amdgcn_sched_barrier(0);
         const f32x4 u1h = normalised(Xin, mean1, rstd1);
         {
             const f32x4 ga = vec4(wsb + bl + R::LB_GA, w, g), ba = vec4(wsb + bl + R::LB_BA, w, g);
@@ -430,9 +439,6 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         f32x4 Xm;
         {
             const f32x4 a = gemm1<V::KS_H>(f32x4{0.f, 0.f, 0.f, 0.f}, fout, [&](int s) { return PO[(4 * s + g) * TS + col]; });
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(f1T, rb, lane, bl + R::LB_W1T + w * V::NG_D * 256);
-            __builtin_amdgcn_sched_barrier(0);
             Xm = Xin + a;
         }
         __syncthreads();                                                       // everyone is done with PA (qkv operands), PB / PO (stores, out-proj)
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
             const float mr = -mean2 * rstd2;
             hp = gemm1<V::KS_D>(vec4(ws + wl + V::L_B1, w, g), ffc1, [&](int s) { return fmaf(xv[s], rstd2, mr); });
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(foT, rb, lane, bl + R::LB_WOUTT + w * V::NG_D * 256);
+            load_frags(f2T, rb, lane, bl + R::LB_W2T + w * V::NG_D * 256);          // transposed fragments: one product ahead
             __builtin_amdgcn_sched_barrier(0);
             u2h = normalised(Xm, mean2, rstd2);
             const f32x4 gf = vec4(wsb + bl + R::LB_GF, w, g), bf = vec4(wsb + bl + R::LB_BF, w, g);
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         {
             const f32x4 gh = gemm1<V::KS_D>(f32x4{0.f, 0.f, 0.f, 0.f}, f2T, [&](int s) { return PG[(4 * s + g) * TS + col]; });
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(fqT, rb, lane, bl + R::LB_WQKVT + w * R::NG_Q * 256);
+            load_frags(f1T, rb, lane, bl + R::LB_W1T + w * V::NG_D * 256);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 ghp;
 #pragma unroll
@@ -476,6 +482,9 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         f32x4 gXm;
         {
             const f32x4 gu2 = gemm1<V::KS_D>(f32x4{0.f, 0.f, 0.f, 0.f}, f1T, [&](int s) { return PO[(4 * s + g) * TS + col]; });
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(foT, rb, lane, bl + R::LB_WOUTT + w * V::NG_D * 256);
+            __builtin_amdgcn_sched_barrier(0);
             ln_partial(R::LN_L + l * R::LN_LSTRIDE + 128, gu2, u2h);
             const f32x4 gf = vec4(wsb + bl + R::LB_GF, w, g);
             gXm = gX + ln_bwd(gu2 * gf, u2h, rstd2, DIM);                      // (its exchange is a workgroup barrier: fc2^T has read PG)
@@ -487,8 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         {
             const f32x4 go = gemm1<V::KS_D>(f32x4{0.f, 0.f, 0.f, 0.f}, foT, [&](int s) { return PG[(4 * s + g) * TS + col]; });
             __builtin_amdgcn_sched_barrier(0);
-            load_qkv(lp);                                                      // next iteration's recompute
-            load_frags(fout, rs, lane, V::OFF_LAYER + lp * V::L_STRIDE + V::L_WOUT + w * V::NG_H * 256);
+            load_frags(fqT, rb, lane, bl + R::LB_WQKVT + w * R::NG_Q * 256);
             __builtin_amdgcn_sched_barrier(0);
             float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;                      // d / d p[m]: go . v(token ^ m), own rows, then everyone's
 #pragma unroll
@@ -528,6 +536,10 @@ __global__ __launch_bounds__(256, 2) void k_vit_step_bwd_rs(const float* __restr
         store_T(PQ, 192, tl + R4 * R::TL_GQKV, 192);
         {
             const f32x4 gu1 = gemm1<48>(f32x4{0.f, 0.f, 0.f, 0.f}, fqT, [&](int s) { return PQ[(4 * s + g) * TS + col]; });
+            __builtin_amdgcn_sched_barrier(0);
+            load_qkv(lp);                                                      // the next iteration's recompute (three workgroups per CU cover the rest of the latency)
+            load_frags(fout, rs, lane, V::OFF_LAYER + lp * V::L_STRIDE + V::L_WOUT + w * V::NG_H * 256);
+            __builtin_amdgcn_sched_barrier(0);
             ln_partial(R::LN_L + l * R::LN_LSTRIDE, gu1, u1h);
             const f32x4 ga = vec4(wsb + bl + R::LB_GA, w, g);
             gX = gXm + ln_bwd(gu1 * ga, u1h, rstd1, DIM);                      // (exchange = barrier: out^T has read PG)

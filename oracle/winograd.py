@@ -25,6 +25,43 @@ def winograd3x3_reflect(h, w, b):
     return Y.permute(0, 1, 2, 4, 3, 5).reshape(B, -1, H, W) + b.view(1, -1, 1, 1)
 
 
+# F(4x4, 3x3) (Lavin & Gray): 36 multiplications per 16 outputs (2.25 / output against 4 for F(2x2, 3x3) and 9 direct), but
+# transform entries up to 8 (output) / 5 (input) instead of +-1: restated here ONLY to measure what fp32 would cost in bits/dim
+# (tests/dev_winograd_numerics.py f4) before anyone writes a kernel for it - see DESIGN.md section 8.
+G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                  dtype=torch.float64)
+BT4 = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                    [0, 4, 0, -5, 0, 1]], dtype=torch.float32)
+AT4 = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float32)
+
+
+def winograd3x3_reflect_f4(h, w, b):
+    """The same convolution in the F(4x4, 3x3) form, fp32 (weights transformed in fp64, rounded once); H, W multiples of 4."""
+    B, Ci, H, W = h.shape
+    U = torch.einsum("xa,oiab,yb->xyoi", G4, w.double(), G4).float()               # (6, 6, Co, Ci)
+    d = F.pad(h, (1, 1, 1, 1), mode="reflect").unfold(2, 6, 4).unfold(3, 6, 4)     # (B, Ci, H/4, W/4, 6, 6)
+    V = torch.einsum("xa,ncijab->ncijxb", BT4, d)
+    V = torch.einsum("ncijxb,yb->ncijxy", V, BT4)
+    M = torch.einsum("xyoc,ncijxy->noijxy", U, V)
+    Y = torch.einsum("px,noijxy->noijpy", AT4, M)
+    Y = torch.einsum("noijpy,qy->noijpq", Y, AT4)                                  # (B, Co, H/4, W/4, 4, 4)
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(B, -1, H, W) + b.view(1, -1, 1, 1)
+
+
+def coupling_net_winograd_f4(x0, p, prefix, pad, min_hw=8):
+    """coupling_net with the 3x3 in the F(4x4, 3x3) form on images of at least min_hw x min_hw (else F(2x2, 3x3))."""
+    h = F.relu(F.conv2d(x0, p[prefix + "NN.0.weight"], p[prefix + "NN.0.bias"]))
+    if h.dtype == torch.float32 and tuple(pad) == (1, 1) and h.shape[2] % 4 == 0 and h.shape[3] % 4 == 0 and h.shape[2] >= min_hw:
+        h = F.relu(winograd3x3_reflect_f4(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
+    elif h.dtype == torch.float32 and tuple(pad) == (1, 1) and h.shape[2] % 2 == 0 and h.shape[3] % 2 == 0:
+        h = F.relu(winograd3x3_reflect(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
+    else:
+        if pad[0] or pad[1]:
+            h = F.pad(h, (pad[1], pad[1], pad[0], pad[0]), mode="reflect")
+        h = F.relu(F.conv2d(h, p[prefix + "NN.2.weight"], p[prefix + "NN.2.bias"]))
+    return F.conv2d(h, p[prefix + "NN.4.weight"], p[prefix + "NN.4.bias"])
+
+
 def coupling_net_winograd(x0, p, prefix, pad):
     """oracle.flow_oracle.coupling_net with the 3x3 in Winograd form (fp32 inputs, (1, 1) padding; otherwise the direct form)."""
     h = F.relu(F.conv2d(x0, p[prefix + "NN.0.weight"], p[prefix + "NN.0.bias"]))

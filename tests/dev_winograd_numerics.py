@@ -10,6 +10,7 @@ from oracle import flow_oracle as fo
 from tests.helpers import load_e2e, e2e_inputs, bpd
 
 from oracle.winograd import coupling_net_winograd as coupling_net_wino      # the restatement lives with the oracle
+from oracle.winograd import coupling_net_winograd_f4                         # F(4x4,3x3) on the 16x16 / 8x8 levels (argument "f4")
 
 
 direct = fo.coupling_net
@@ -20,7 +21,8 @@ for name in ("mnist", "cifar10"):
         ref = torch.from_numpy(fx["logp"])
         ref64 = torch.from_numpy(fx["logp_f64"]) if "logp_f64" in fx else None
         res = {}
-        for label, fn in (("direct", direct), ("winograd", coupling_net_wino)):
+        forms = (("direct", direct), ("winograd", coupling_net_wino)) + ((("f4", coupling_net_winograd_f4),) if "f4" in sys.argv else ())
+        for label, fn in forms:
             fo.coupling_net = fn
             _, logp = fo.flow_forward(ops, params, x, u, eps)
             e32 = (bpd(logp, name) - bpd(ref, name)).abs().max().item()
@@ -29,4 +31,5 @@ for name in ("mnist", "cifar10"):
         fo.coupling_net = direct
         floor = (bpd(ref, name) - bpd(ref64, name)).abs().max().item() if ref64 is not None else float("nan")
         print("%-8s %-8s B=%d  |bpd err| vs ref fp32 / vs ref fp64:  direct %.2e / %.2e   winograd %.2e / %.2e   (reference fp32 vs its fp64: %.2e)" % (
-            name, tag or "-", x.shape[0], res["direct"][0], res["direct"][1], res["winograd"][0], res["winograd"][1], floor))
+            name, tag or "-", x.shape[0], res["direct"][0], res["direct"][1], res["winograd"][0], res["winograd"][1], floor)
+              + ("   F(4x4,3x3) on 16x16 / 8x8: %.2e / %.2e" % res["f4"] if "f4" in res else ""))
