@@ -180,8 +180,36 @@ __device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ x, c
     // other's staging and MFMA phases.
     const int nchunks = (rows + WG_RC - 1) / WG_RC;
     const int c32 = tid & 31, rs = tid >> 5;
+    // 16-byte staging when every row of both operands is a whole number of aligned float4 (the planes of the transformer
+    // step backward: 52 / 64 / 192 floats per row): a thread takes 4 consecutive features of ONE row per 32-feature block -
+    // a quarter of the load instructions, the same LDS image.  (wave-uniform; x^2 sums keep the scalar form)
+    const bool vec4 = !XSQ && (N & 3) == 0 && (K & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0;
     for (int c = bx; c < nchunks; c += gdx) {
         const int r0 = c * WG_RC;
+        if (vec4) {
+            const int row = tid >> 3, c4 = (tid & 7) * 4;
+            const bool ok = r0 + row < rows;
+            const int64_t rc = ok ? r0 + row : rows - 1;
+            float4 st4[WG_MAXF];
+#pragma unroll
+            for (int cb = 0; cb < WG_MAXF; ++cb) {
+                const bool isg = cb < NT;                                         // uniform
+                const int col = cb * 32 + c4 - (isg ? 0 : NS);
+                const int lim = isg ? N : K;
+                st4[cb] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cb < NT + KT && col < lim) st4[cb] = *reinterpret_cast<const float4*>((isg ? gy + rc * ldy : x + rc * ldx) + col);
+            }
+#pragma unroll
+            for (int cb = 0; cb < WG_MAXF; ++cb) {
+                const bool isg = cb < NT;
+                const int col = cb * 32 + c4 - (isg ? 0 : NS);
+                float4 v = st4[cb];
+                if (isg) { if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f); }        // rows past the end contribute nothing
+                else if (col == K) v.x = 1.f;                                     // the bias column (K is a multiple of 4)
+                if (cb < NT + KT) *reinterpret_cast<float4*>(&lds[row * WG_LS + cb * 32 + c4]) = v;
+            }
+        } else {
         // branch-free batch: all 4 x WG_MAXF loads of a thread are in flight together (clamped addresses; the values of
         // padding positions are replaced afterwards), then the LDS writes
         float stg[WG_RC / 8][WG_MAXF];
@@ -210,6 +238,7 @@ __device__ __forceinline__ void linear_wgrad_body(const float* __restrict__ x, c
                                     : (col < K ? stg[i][cb] : (col == K ? 1.f : 0.f));
                 if (cb < NT + KT) lds[r * WG_LS + cb * 32 + c32] = v;
             }
+        }
         }
         __syncthreads();
         // operands of row pair rr + 2 are requested before the MFMAs of row pair rr (two register sets)
@@ -583,13 +612,19 @@ static int linear_wgrad_any(const float* x, const float* gy, float* gW, float* g
 // ---- a group of weight gradients: one k_linear_wgrad_group launch + one reduce launch ---------------------------------
 // member i: gW_i (N_i x K_i) = gy_i^T x_i over rows_i rows, gb_i (N_i, optional) = column sums of gy_i; x_i: (rows_i, K_i)
 // dense, gy_i: (rows_i, N_i) dense.  N_i <= 192, K_i + 1 <= (12 - ceil(N_i / 32)) * 32, at most 32 members.
-static int64_t wgrad_member_part_floats(int rows, int K, int N) {
+// row groups (= partials) per member: the members run side by side, so the chip is full with ~1536 workgroups in ALL -
+// 512 groups per member (the single-product launch's choice) would write and re-read 13x the partial sums
+static int group_row_groups(int rows, int n) {
+    const int g = linear_wgrad_groups(rows), cap = 1536 / n > 16 ? 1536 / n : 16;
+    return g < cap ? g : cap;
+}
+static int64_t wgrad_member_part_floats(int rows, int K, int N, int n) {
     const int NT = (N + 31) / 32, KT = (K + 1 + 31) / 32;
-    return (int64_t)linear_wgrad_groups(rows) * NT * KT * 1024;
+    return (int64_t)group_row_groups(rows, n) * NT * KT * 1024;
 }
 int64_t cf_linear_wgrad_group_ws_bytes(const int* rows, const int* K, const int* N, int n) {
     int64_t f = 0;
-    for (int i = 0; i < n; ++i) f += wgrad_member_part_floats(rows[i], K[i], N[i]);
+    for (int i = 0; i < n; ++i) f += wgrad_member_part_floats(rows[i], K[i], N[i], n);
     return f * (int64_t)sizeof(float);
 }
 int cf_linear_wgrad_group(const float* const* x, const float* const* gy, float* const* gW, float* const* gb, const int* rows,
@@ -603,8 +638,8 @@ int cf_linear_wgrad_group(const float* const* x, const float* const* gy, float* 
         CF_REQUIRE(x[i] && gy[i] && gW[i] && rows[i] >= 0 && K[i] > 0 && N[i] > 0 && NT <= 6 && NT + KT <= WG_MAXF && NT * KT <= 4 * WG_TPW);
         WgMember& m = grp.m[i];
         m.x = x[i]; m.gy = gy[i]; m.part = part; m.gW = gW[i]; m.gb = gb[i];
-        m.rows = rows[i]; m.K = K[i]; m.N = N[i]; m.NT = NT; m.G = linear_wgrad_groups(rows[i]); m.ldx = K[i]; m.ldy = N[i];
-        part += wgrad_member_part_floats(rows[i], K[i], N[i]);
+        m.rows = rows[i]; m.K = K[i]; m.N = N[i]; m.NT = NT; m.G = group_row_groups(rows[i], n); m.ldx = K[i]; m.ldy = N[i];
+        part += wgrad_member_part_floats(rows[i], K[i], N[i], n);
         gmax = m.G > gmax ? m.G : gmax;
         tmax = NT * KT > tmax ? NT * KT : tmax;
     }
