@@ -264,7 +264,7 @@ __device__ __forceinline__ ws_rsrc_t tile_rsrc(const float* t, int tb0, int B) {
 // gfx950: the VGPRs holding the data of a `buffer_store_dwordx4 ... s_off offen` must not be written by the VALU
 // instruction right behind it (hipcc places one there when the registers become free - it treats a store with a
 // register soffset as hazard-free - and the stored rows then carry the new register contents in some lanes:
-// tools/dev/nan_hunt3.py found 64-bit addresses inside the g_h2 plane).  Inline asm: the compiler cannot slide anything
+// per-call checks of the weight-gradient inputs found 64-bit addresses inside the g_h2 plane; reproducer: tools/micro/store_hazard.hip).  Inline asm: the compiler cannot slide anything
 // between the store and its s_nop.
 typedef int cf_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ cf_i32x4 tile_rsrc_words(const float* base, int bytes) {

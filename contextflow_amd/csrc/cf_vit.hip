@@ -504,7 +504,7 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
     CF_REQUIRE(x && Wt && y && rows >= 0 && K > 0 && N > 0 && act >= 0 && act <= 2);
     // column tiles per workgroup: 3 (96 features).  5 / 6 tiles (N = 152 / 192 in one pass, no padded MFMA work) were
     // measured: faster at 65 K rows, slower at 147 K rows and in the ATM forward end to end - fewer, longer workgroups
-    // quantise worse over the 256 CUs (tools/dev/lin_sweep.py)
+    // quantise worse over the 256 CUs (a sweep over sizes)
     constexpr int ntl = 3;
     const int nt = (N + 31) / 32;
     dim3 grid((rows + LIN_ROWS - 1) / LIN_ROWS, (nt + ntl - 1) / ntl);
