@@ -41,6 +41,36 @@ def test_library_exports_every_declared_symbol(built):
     assert _hip.lib().cf_actnorm_stats_ws_bytes(16) == 16 * 65 * 2 * 8
 
 
+def test_host_side_size_queries_of_round_3(built):
+    """Host-only entry points (no GPU call): executed multiply-adds of the step kernels as dispatched, the plane / partial
+    buffer sizes of the transformer step backward (the Python side slices the plane buffer by the layout of the header),
+    the grouped weight gradient's workspace."""
+    import ctypes
+    from contextflow_amd.layers import _hip
+    L = _hip.lib()
+    direct = lambda C, H: 40 * C * C * H * H
+    # evaluation forward: Winograd at 16x16 always, at 8x8 / 4x4 from 1024 / 2048 samples; backward: direct; weight gradients: Winograd
+    assert L.cf_flow_step_macs(256, 16, 16, 16, 0) == direct(16, 16) // 2
+    assert L.cf_flow_step_macs(256, 32, 8, 8, 0) == direct(32, 8) and L.cf_flow_step_macs(1024, 32, 8, 8, 0) == direct(32, 8) // 2
+    assert L.cf_flow_step_macs(2047, 64, 4, 4, 1) == direct(64, 4) and L.cf_flow_step_macs(2048, 64, 4, 4, 1) == direct(64, 4) // 2
+    assert L.cf_flow_step_macs(256, 8, 16, 16, 0) == direct(8, 16) // 2 and L.cf_flow_step_macs(256, 8, 16, 16, 1) == direct(8, 16)
+    assert L.cf_flow_step_macs(4096, 16, 16, 16, 2) == direct(16, 16)
+    assert L.cf_step_wgrads_macs(4096, 32, 8, 8) == direct(32, 8) // 2
+    assert L.cf_flow_step_macs(4096, 26, 8, 1, 0) == 0                     # not a conv-step shape
+    # transformer step backward: B = 10 -> Bp = 12: planes [x^T, g_y (8 Bp, 26)] [u0 (4 Bp, 26), g_e (4 Bp, 52)] + depth x 4 Bp x 568
+    B, C, depth = 10, 26, 6
+    Bp = 12
+    assert L.cf_vit_step_bwd_plane_floats(B, C, depth) == 2 * 8 * Bp * 26 + 4 * Bp * (26 + 52) + depth * 4 * Bp * 568
+    assert L.cf_vit_step_bwd_ln_floats(B, C, depth) == 3 * (64 + 128 + depth * 256 + 128)
+    assert L.cf_vit_step_bwd_ws_bytes(C, depth) > 4 * depth * (192 * 52 + 52 * 64 + 2 * 52 * 52)
+    assert L.cf_vit_step_rs_supported(26, 8, 1, 2, 1, 52, 64, 1) == 1 and L.cf_vit_step_rs_supported(38, 144, 1, 2, 1, 76, 64, 1) == 0
+    arr = lambda v: (ctypes.c_int * len(v))(*v)
+    one = L.cf_linear_wgrad_group_ws_bytes(arr([4096]), arr([52]), arr([192]), 1)
+    assert one == 128 * 6 * 2 * 1024 * 4                                   # 128 row groups x (6 x 2) tiles of 32 x 32 floats
+    many = L.cf_linear_wgrad_group_ws_bytes(arr([4096] * 26), arr([52] * 26), arr([192] * 26), 26)
+    assert many == 26 * 59 * 6 * 2 * 1024 * 4                              # the group caps the row groups per member (1536 / 26)
+
+
 def test_gfx950_code_object(built):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built], capture_output=True, text=True)
     blob = out.stdout + out.stderr
