@@ -1140,13 +1140,15 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
 int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, int mode, int B, int C,
                          int H, int W, int64_t x_bstride, cf_stream_t stream) {
     if (B == 0) return 0;
+    const bool keep_direct = (mode & 4) != 0;   // mode | 4: the direct form of the 3x3 whatever the batch size - the TRAINING forward under
+    mode &= 3;                                  // contextflow, whose backward (cf_flow_step_bwd_ctx) rebuilds the conditioner in that form
     CF_REQUIRE(x && z && ldj_acc && ws && sbias && (mode == 1 || mode == 2) && B >= 0 && x_bstride >= (int64_t)C * H * W);
     CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && x_bstride % 4 == 0);
     const float* w = (const float*)ws;
     int rc = 0;
 #define CF_STEPC(G) rc = mode == 1 ? launch_step<G, false, 1>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), sbias) \
                                    : launch_step<G, false, 2>(x, z, ldj_acc, w, B, x_bstride, nullptr, 0, cf_s(stream), sbias)
-    const bool wino = !direct_conv_only();      // as cf_flow_step_fwd: Winograd form of the 3x3 (16x16 always, 8x8 / 4x4 at saturating batches)
+    const bool wino = !direct_conv_only() && !keep_direct;      // as cf_flow_step_fwd: Winograd form of the 3x3 (16x16 always, 8x8 / 4x4 at saturating batches)
     switch (shape_id(C, H, W)) {
         case 0: CF_STEPC(G8); break;
         case 1: if (wino) CF_STEPC(G16w); else CF_STEPC(G16); break;

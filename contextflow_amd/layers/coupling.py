@@ -148,7 +148,10 @@ class Coupling(_AffineCoupling):
             _hip.call("cf_flow_step_fwd_ctx_taped", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), pp(planes[0]), pp(planes[1]),
                       pp(planes[2]), pp(planes[3]), B, C, H, W, xbs, st)
         else:
-            _hip.call("cf_flow_step_fwd_ctx", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), mode, B, C, H, W, xbs, st)
+            # training under contextflow (tape, mode 1): the backward kernel rebuilds the conditioner in the direct form of the 3x3,
+            # so the forward that produces the loss keeps that form too (flag 4) - same ReLU masks on both sides
+            _hip.call("cf_flow_step_fwd_ctx", pp(x), pp(z), pp(ldj), pp(ws), pp(sbias), mode | (4 if tape is not None else 0), B, C, H, W,
+                      xbs, st)
         if tape is not None:
             tape.append(dict(x=x, c=c, a1=a1, a2=a2, cn=cn, ws=ws, mode=mode, planes=planes, eps=encoder_noise(self.context_net)))
         return z, ldj + logp_c * float(H * W)

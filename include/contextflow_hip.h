@@ -182,7 +182,8 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
 
 /* the fused step with a per-sample bias from the specialist coupling's CN net (coupling.py:39-47):
  * mode 1: sbias (B,C) added to the conditioner output (contextflow); mode 2: sbias (B,2C) added before the
- * first ReLU (CN(c) concatenated to the conditioner input).                                                   */
+ * first ReLU (CN(c) concatenated to the conditioner input).  mode | 4: keep the direct form of the 3x3 at every batch
+ * size (the training forward under contextflow: cf_flow_step_bwd_ctx rebuilds the conditioner in that form).       */
 int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, int mode, int B, int C,
                          int H, int W, int64_t x_bstride, cf_stream_t stream);
 
