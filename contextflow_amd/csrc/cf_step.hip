@@ -525,8 +525,11 @@ int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int
 // workgroup barrier per phase.  Same packed workspace as k_flow_step.  Used below ~2 workgroups per CU (cf_flow_step_fwd).
 // DUMP (training at small batches): the tape of cf_flow_step_fwd_taped - y0 / h1 / h2 planes, log-scale and y1, the ReLU
 // mask words of this wave's (row tile, pixel tile) pairs, in the layout k_flow_step writes.
-template <class G, int NPT, bool SQ, bool DUMP = false>
-__global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ x, float* __restrict__ z,
+// KS = 2 (round 3): eight waves - waves 4..7 take the second half of the input channels of every tap of the 3x3 (the
+// phase that is 85 % of the chain), their partial sums meet waves 0..3's through the (then idle) T region: at a batch of 256
+// a launch has 128 (C = 64) / 256 (C = 32) workgroups, i.e. half / all of the chip's SIMDs held one wave each.
+template <class G, int NPT, bool SQ, bool DUMP = false, int KS = 2>
+__global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restrict__ x, float* __restrict__ z,
                                                       float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
                                                       int64_t xbs, StepTape tp = kNoTape) {
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, HALF = G::HALF, HID = G::HID, HP = G::HP;
@@ -537,14 +540,16 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
     float* Y = XP + C * PIXR;                // [C][PIXR]    rows [0, HALF) = y0, [HALF, C) = y1
     float* H1 = Y + C * PIXR;                // [HID][PIXR]  h1, then h2 in place
     float* T = H1 + HID * PIXR;              // [2][C][PIXR] the two K-halves of [t | raw]
+    constexpr int NTH = 256 * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
+    const int w4 = wave & 3, kh2 = wave >> 2;          // phase 2: (row tile, pixel tile) pair of waves w4 and w4 + 4, channel half
     const int b0 = blockIdx.x * SPWR;
     const ws_rsrc_t rs = ws_rsrc(ws, G::WS_FLOATS);
 
     // ---- x -> LDS (element-wise: small batches are not bandwidth-bound; Squeeze folded into the index)
 #pragma unroll
-    for (int i = 0; i < C * PIXR / 256; ++i) {
-        const int e = tid + 256 * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
+    for (int i = 0; i < C * PIXR / NTH; ++i) {
+        const int e = tid + NTH * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
         const int64_t bb = min(b0 + sm, B - 1);
         int src;
         if constexpr (!SQ) src = ch * HW + pp;
@@ -570,14 +575,14 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
     __syncthreads();
     // first half of the output = y0 (coupling.py:65)
 #pragma unroll
-    for (int i = 0; i < HALF * PIXR / 256; ++i) {
-        const int e = tid + 256 * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
+    for (int i = 0; i < HALF * PIXR / NTH; ++i) {
+        const int e = tid + NTH * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
         if (b0 + sm < B) {
             z[(int64_t)(b0 + sm) * C * HW + ch * HW + pp] = Y[e];
             if constexpr (DUMP) tp.y0[((int64_t)(b0 + sm) * HALF + ch) * HW + pp] = Y[e];
         }
     }
-    const int rt1 = wave % RT1, q1 = wave / RT1, col1 = q1 * 32 + li;          // this wave's pair in phases 1, 2
+    const int rt1 = w4 % RT1, q1 = w4 / RT1, col1 = q1 * 32 + li;              // this wave's pair in phases 1, 2
     // tape helpers: the mask word of this wave's accumulator tile (global 32-column tile = blockIdx NPT + q1), and a
     // cooperative copy of the [HID][PIXR] plane in LDS to its (B, HID, HW) place
     auto mask_word = [&](unsigned* __restrict__ m, const f32x16& a) {
@@ -588,13 +593,13 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
     };
     auto plane_dump = [&](float* __restrict__ dst) {
 #pragma unroll
-        for (int i = 0; i < HID * PIXR / 256; ++i) {
-            const int e = tid + 256 * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
+        for (int i = 0; i < HID * PIXR / NTH; ++i) {
+            const int e = tid + NTH * i, ch = e / PIXR, col = e - ch * PIXR, sm = col / HW, pp = col - sm * HW;
             if (b0 + sm < B) dst[((int64_t)(b0 + sm) * HID + ch) * HW + pp] = H1[e];
         }
     };
     // ---- phase 1: h1 = relu(NN.0 y0 + b)
-    {
+    if (wave < 4) {
         f32x16 acc = bias_tile(ws + G::OFF_B1 + rt1 * 32, lk);
 #pragma unroll
         for (int g = 0; g < G::NG1; ++g) {
@@ -612,21 +617,33 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
     if constexpr (DUMP) plane_dump(tp.h1);
     // ---- phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3 reflect: K = 9 taps x HID channels, fragments one group ahead
     f32x16 acc2 = bias_tile(ws + G::OFF_B2 + rt1 * 32, lk);
+    if (kh2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    }
     {
         const int sm = col1 / HW, pp = col1 - sm * HW, py = pp / W, px = pp - py * W;
         // a wave has ONE row tile here: 4 MFMAs (256 cycles) per weight fragment, less than an L2 round trip under load -
-        // the fragments run in a ring of 4, fetched three groups ahead
-        static_assert(G::NCG % 4 == 0, "fragment ring");
+        // the fragments run in a ring of 4, fetched three groups ahead.  This wave's sequence of groups: for every tap the NH
+        // channel groups of its half, cg0 .. cg0 + NH - 1
+        constexpr int NH = G::NCG / KS;
+        static_assert(NH % 4 == 0, "fragment ring");
+        const int cg0 = kh2 * NH;
+        auto seq_frag = [&](int tap, int c) {              // fragment offset of group (tap, cg0 + c); c may run past NH into the next tap
+            const int t2 = tap + c / NH, c2 = c % NH;
+            const int g = (t2 < 9 ? t2 : 8) * G::NCG + cg0 + (t2 < 9 ? c2 : NH - 1);
+            return G::OFF_A2 + (g * RT1 + rt1) * 256;
+        };
         float4 a[4];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) a[j] = ws_frag(rs, lane, G::OFF_A2 + (j * RT1 + rt1) * 256);
+        for (int j = 0; j < 3; ++j) a[j] = ws_frag(rs, lane, seq_frag(0, j));
         // ... and the B operands (LDS) one group ahead: with a single accumulator chain per wave nothing else hides the
         // LDS latency in front of each group's first MFMA
         auto tap_src = [&](int tap) -> const float* {
             int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
             yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
             xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-            return H1 + sm * HW + yy * W + xx + lk * PIXR;
+            return H1 + sm * HW + yy * W + xx + (lk + 8 * cg0) * PIXR;      // channel 8 cg0 + lk of the source pixel
         };
         float bv[2][4];
         const float* src = tap_src(0);
@@ -636,29 +653,41 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
         for (int tap = 0; tap < 9; ++tap) {
             const float* nsrc = tap_src(tap < 8 ? tap + 1 : 8);
 #pragma unroll
-            for (int cg = 0; cg < G::NCG; ++cg) {
-                const int g = tap * G::NCG + cg, gn = g + 3 < G::NG2 ? g + 3 : G::NG2 - 1;
-                a[(cg + 3) & 3] = ws_frag(rs, lane, G::OFF_A2 + (gn * RT1 + rt1) * 256);
+            for (int c = 0; c < NH; ++c) {
+                a[(c + 3) & 3] = ws_frag(rs, lane, seq_frag(tap, c + 3));
 #pragma unroll
                 for (int e = 0; e < 4; ++e)       // next group: same tap, next 8 channels - or the first 8 of the next tap
-                    bv[(cg + 1) & 1][e] = (cg + 1 < G::NCG) ? src[(8 * (cg + 1) + 2 * e) * PIXR] : nsrc[2 * e * PIXR];
+                    bv[(c + 1) & 1][e] = (c + 1 < NH) ? src[(8 * (c + 1) + 2 * e) * PIXR] : nsrc[2 * e * PIXR];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[cg & 3], e), bv[cg & 1][e], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[c & 3], e), bv[c & 1][e], acc2, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             src = nsrc;
         }
     }
     __syncthreads();                 // every wave has finished reading h1
+    if constexpr (KS > 1) {          // the two channel halves meet (T is idle until phase 3)
+        if (kh2) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) H1[(rt1 * 32 + tile_row(r, lk)) * PIXR + col1] = cf_relu(acc2[r]);
-    if constexpr (DUMP) mask_word(tp.m2, acc2);
+            for (int r = 0; r < 16; ++r) T[(rt1 * 32 + tile_row(r, lk)) * PIXR + col1] = acc2[r];
+        }
+        __syncthreads();
+        if (!kh2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] += T[(rt1 * 32 + tile_row(r, lk)) * PIXR + col1];
+        }
+    }
+    if (!kh2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1[(rt1 * 32 + tile_row(r, lk)) * PIXR + col1] = cf_relu(acc2[r]);
+        if constexpr (DUMP) mask_word(tp.m2, acc2);
+    }
     __syncthreads();
     if constexpr (DUMP) plane_dump(tp.h2);
     // ---- phase 3: [t | raw] = NN.4 h2 + b: pair = wave & 1, K half = wave >> 1 (the bias rides with half 0)
-    {
+    if (wave < 4) {
         const int it = wave & 1, kh = wave >> 1, rt = it % RT03, q = it / RT03, col = q * 32 + li;
         f32x16 acc = bias_tile(ws + G::OFF_B3 + rt * 32, lk);
         if (kh) {
@@ -679,8 +708,9 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
         for (int r = 0; r < 16; ++r) T[(kh * C + rt * 32 + tile_row(r, lk)) * PIXR + col] = acc[r];
     }
     __syncthreads();
-    // ---- affine map and log-det over all 256 threads: element e = (channel, column); a thread's column is fixed
+    // ---- affine map and log-det over the first 256 threads: element e = (channel, column); a thread's column is fixed
     float lsum = 0.f;
+    if (wave < 4) {
     const int colE = tid % PIXR, smE = colE / HW, ppE = colE - smE * HW;
 #pragma unroll
     for (int i = 0; i < HALF * PIXR / 256; ++i) {
@@ -705,16 +735,21 @@ __global__ __launch_bounds__(256) void k_flow_step_rs(const float* __restrict__ 
 #pragma unroll
     for (int o = 1; o < LPS; o <<= 1) lsum += __shfl_xor(lsum, o, 64);
     if (PIXR < 64 && HW < 32) lsum += __shfl_xor(lsum, 32, 64);    // PIXR = 32: lanes l and l + 32 hold the same column
+    }
     __syncthreads();                                  // T is dead: reuse its first words
-    if ((lane % LPS) == 0 && (PIXR >= 64 || lane < 32)) T[wave * 4 + (lane % PIXR) / HW] = lsum;
+    constexpr int LPS2 = HW < 64 ? HW : 64;
+    if (wave < 4 && (lane % LPS2) == 0 && (PIXR >= 64 || lane < 32)) T[wave * 4 + (lane % PIXR) / HW] = lsum;
     __syncthreads();
     if (tid < SPWR && b0 + tid < B) ldj_acc[b0 + tid] += ws[0] + ((T[tid] + T[4 + tid]) + (T[8 + tid] + T[12 + tid]));
 }
 
+#ifndef CF_RS_KSPLIT
+#define CF_RS_KSPLIT 2
+#endif
 template <class G, int NPT, bool SQ, bool DUMP = false>
 int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s, StepTape tp = kNoTape) {
     constexpr int SPWR = 32 * NPT / G::HW;
-    k_flow_step_rs<G, NPT, SQ, DUMP><<<dim3((B + SPWR - 1) / SPWR), dim3(256), 0, s>>>(x, z, ldj, ws, B, xbs, tp);
+    k_flow_step_rs<G, NPT, SQ, DUMP, CF_RS_KSPLIT><<<dim3((B + SPWR - 1) / SPWR), dim3(256 * CF_RS_KSPLIT), 0, s>>>(x, z, ldj, ws, B, xbs, tp);
     return 0;
 }
 
