@@ -525,9 +525,23 @@ int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int
 // workgroup barrier per phase.  Same packed workspace as k_flow_step.  Used below ~2 workgroups per CU (cf_flow_step_fwd).
 // DUMP (training at small batches): the tape of cf_flow_step_fwd_taped - y0 / h1 / h2 planes, log-scale and y1, the ReLU
 // mask words of this wave's (row tile, pixel tile) pairs, in the layout k_flow_step writes.
-// KS = 2 (round 3): eight waves - waves 4..7 take the second half of the input channels of every tap of the 3x3 (the
-// phase that is 85 % of the chain), their partial sums meet waves 0..3's through the (then idle) T region: at a batch of 256
-// a launch has 128 (C = 64) / 256 (C = 32) workgroups, i.e. half / all of the chip's SIMDs held one wave each.
+// KS = 2 (round 3): eight waves - waves 4..7 take the second half of the input channels of every tap of the 3x3, their
+// partial sums meet waves 0..3's through the (then idle) T region.  What it buys is a second wave per SIMD to cover the
+// first one's waits (35.0 -> 32.3 us at C = 64, 20.1 -> 19.1 at C = 32, batch of 256), NOT a shorter chain: the 2 304 MFMAs of a
+// workgroup's 3x3 share the four matrix pipes of ONE CU whoever issues them (tools/dev/rs_ticks.py: phase 2 = 45.6 K of the
+// 65 K cycles of a C = 64 step against 36.9 K of pure MFMA time).  Going below that needs more CUs per sample, i.e. 16-column
+// tiles (one sample per workgroup at 4x4).
+// timing-only probe build (tools/dev/make_abl.py ticks -DCF_RS_TICKS; read with tools/dev/rs_ticks.py): workgroup 0 leaves the
+// cycles between the phase boundaries of k_flow_step_rs in z[wave * 16 + k] (the results of that build are garbage)
+#ifdef CF_RS_TICKS
+#define RS_TICK_INIT long long tacc_[12]; for (int k_ = 0; k_ < 12; ++k_) tacc_[k_] = 0; long long tprev_ = __builtin_readcyclecounter();
+#define RS_TICK(k) { const long long tn_ = __builtin_readcyclecounter(); tacc_[k] += tn_ - tprev_; tprev_ = tn_; }
+#define RS_TICK_DUMP if (blockIdx.x == 0 && lane == 0) for (int k_ = 0; k_ < 12; ++k_) z[wave * 16 + k_] = (float)tacc_[k_];
+#else
+#define RS_TICK_INIT
+#define RS_TICK(k)
+#define RS_TICK_DUMP
+#endif
 template <class G, int NPT, bool SQ, bool DUMP = false, int KS = 2>
 __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restrict__ x, float* __restrict__ z,
                                                       float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
@@ -540,11 +554,28 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
     float* Y = XP + C * PIXR;                // [C][PIXR]    rows [0, HALF) = y0, [HALF, C) = y1
     float* H1 = Y + C * PIXR;                // [HID][PIXR]  h1, then h2 in place
     float* T = H1 + HID * PIXR;              // [2][C][PIXR] the two K-halves of [t | raw]
+    static_assert(KS == 2, "eight waves: the only form that is instantiated and tested");
     constexpr int NTH = 256 * KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
     const int w4 = wave & 3, kh2 = wave >> 2;          // phase 2: (row tile, pixel tile) pair of waves w4 and w4 + 4, channel half
     const int b0 = blockIdx.x * SPWR;
     const ws_rsrc_t rs = ws_rsrc(ws, G::WS_FLOATS);
+    RS_TICK_INIT
+    // the weight fragments of the three small products, requested before anything else (same reason as the ring of phase 2)
+    const int rt1_ = (wave & 3) % RT1, it3_ = wave & 1, kh3_ = (wave >> 1) & 1, rt3_ = it3_ % RT03;
+    constexpr int NGH3 = G::NG3 / 2;
+    float4 f0[G::NG0], f1[G::NG1], f3[NGH3];
+    if (wave < 2) {
+#pragma unroll
+        for (int g = 0; g < G::NG0; ++g) f0[g] = ws_frag(rs, lane, G::OFF_A0 + (g * RT03 + wave % RT03) * 256);
+    }
+    if (wave < 4) {
+#pragma unroll
+        for (int g = 0; g < G::NG1; ++g) f1[g] = ws_frag(rs, lane, G::OFF_A1 + (g * RT1 + rt1_) * 256);
+#pragma unroll
+        for (int g = 0; g < NGH3; ++g) f3[g] = ws_frag(rs, lane, G::OFF_A3 + ((kh3_ * NGH3 + g) * RT03 + rt3_) * 256);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- x -> LDS (element-wise: small batches are not bandwidth-bound; Squeeze folded into the index)
 #pragma unroll
@@ -557,13 +588,14 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
         XP[e] = x[bb * xbs + src];
     }
     __syncthreads();
+    RS_TICK(0)
     // ---- phase 0: [y0 | y1] = W' x + b'   (waves 0, 1: one (row tile, pixel tile) pair each)
     if (wave < 2) {
         const int rt = wave % RT03, q = wave / RT03, col = q * 32 + li;
         f32x16 acc = bias_tile(ws + G::OFF_B0 + rt * 32, lk);
 #pragma unroll
         for (int g = 0; g < G::NG0; ++g) {
-            const float4 a = ws_frag(rs, lane, G::OFF_A0 + (g * RT03 + rt) * 256);
+            const float4 a = f0[g];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (4 * g + e < G::KS0)
@@ -573,6 +605,7 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
         for (int r = 0; r < 16; ++r) Y[(rt * 32 + tile_row(r, lk)) * PIXR + col] = acc[r];
     }
     __syncthreads();
+    RS_TICK(1)
     // first half of the output = y0 (coupling.py:65)
 #pragma unroll
     for (int i = 0; i < HALF * PIXR / NTH; ++i) {
@@ -598,12 +631,13 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
             if (b0 + sm < B) dst[((int64_t)(b0 + sm) * HID + ch) * HW + pp] = H1[e];
         }
     };
+    RS_TICK(2)
     // ---- phase 1: h1 = relu(NN.0 y0 + b)
     if (wave < 4) {
         f32x16 acc = bias_tile(ws + G::OFF_B1 + rt1 * 32, lk);
 #pragma unroll
         for (int g = 0; g < G::NG1; ++g) {
-            const float4 a = ws_frag(rs, lane, G::OFF_A1 + (g * RT1 + rt1) * 256);
+            const float4 a = f1[g];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (4 * g + e < G::KS1)
@@ -614,6 +648,7 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
         if constexpr (DUMP) mask_word(tp.m1, acc);
     }
     __syncthreads();
+    RS_TICK(3)
     if constexpr (DUMP) plane_dump(tp.h1);
     // ---- phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3 reflect: K = 9 taps x HID channels, fragments one group ahead
     f32x16 acc2 = bias_tile(ws + G::OFF_B2 + rt1 * 32, lk);
@@ -627,16 +662,21 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
         // the fragments run in a ring of 4, fetched three groups ahead.  This wave's sequence of groups: for every tap the NH
         // channel groups of its half, cg0 .. cg0 + NH - 1
         constexpr int NH = G::NCG / KS;
-        static_assert(NH % 4 == 0, "fragment ring");
+        // ring depth: at a batch of 256 the packed weights of a step (0.16-0.66 MB, 6 MB over the twelve steps of a forward)
+        // come from the Infinity Cache, not from L2 - measured ~1900 cycles per fragment under the load of 128 workgroups
+        // streaming the same 590 KB (tools/dev/rs_ticks.py: 634 cycles per 256-cycle MFMA group with three loads in
+        // flight).  Seven in flight cover it.
+        constexpr int RD = NH % 8 == 0 ? 8 : 4;
+        static_assert(NH % RD == 0, "fragment ring");
         const int cg0 = kh2 * NH;
         auto seq_frag = [&](int tap, int c) {              // fragment offset of group (tap, cg0 + c); c may run past NH into the next tap
             const int t2 = tap + c / NH, c2 = c % NH;
             const int g = (t2 < 9 ? t2 : 8) * G::NCG + cg0 + (t2 < 9 ? c2 : NH - 1);
             return G::OFF_A2 + (g * RT1 + rt1) * 256;
         };
-        float4 a[4];
+        float4 a[RD];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) a[j] = ws_frag(rs, lane, seq_frag(0, j));
+        for (int j = 0; j < RD - 1; ++j) a[j] = ws_frag(rs, lane, seq_frag(0, j));
         // ... and the B operands (LDS) one group ahead: with a single accumulator chain per wave nothing else hides the
         // LDS latency in front of each group's first MFMA
         auto tap_src = [&](int tap) -> const float* {
@@ -654,20 +694,22 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
             const float* nsrc = tap_src(tap < 8 ? tap + 1 : 8);
 #pragma unroll
             for (int c = 0; c < NH; ++c) {
-                a[(c + 3) & 3] = ws_frag(rs, lane, seq_frag(tap, c + 3));
+                a[(c + RD - 1) & (RD - 1)] = ws_frag(rs, lane, seq_frag(tap, c + RD - 1));
 #pragma unroll
                 for (int e = 0; e < 4; ++e)       // next group: same tap, next 8 channels - or the first 8 of the next tap
                     bv[(c + 1) & 1][e] = (c + 1 < NH) ? src[(8 * (c + 1) + 2 * e) * PIXR] : nsrc[2 * e * PIXR];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[c & 3], e), bv[c & 1][e], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[c & (RD - 1)], e), bv[c & 1][e], acc2, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             src = nsrc;
         }
     }
+    RS_TICK(4)
     __syncthreads();                 // every wave has finished reading h1
+    RS_TICK(5)
     if constexpr (KS > 1) {          // the two channel halves meet (T is idle until phase 3)
         if (kh2) {
 #pragma unroll
@@ -685,6 +727,7 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
         if constexpr (DUMP) mask_word(tp.m2, acc2);
     }
     __syncthreads();
+    RS_TICK(6)
     if constexpr (DUMP) plane_dump(tp.h2);
     // ---- phase 3: [t | raw] = NN.4 h2 + b: pair = wave & 1, K half = wave >> 1 (the bias rides with half 0)
     if (wave < 4) {
@@ -699,7 +742,7 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
 #pragma unroll
         for (int gg = 0; gg < NGH; ++gg) {
             const int g = kh * NGH + gg;
-            const float4 a = ws_frag(rs, lane, G::OFF_A3 + (g * RT03 + rt) * 256);
+            const float4 a = f3[gg];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a, e), H1[(2 * (4 * g + e) + lk) * PIXR + col], acc, 0, 0, 0);
@@ -708,6 +751,7 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
         for (int r = 0; r < 16; ++r) T[(kh * C + rt * 32 + tile_row(r, lk)) * PIXR + col] = acc[r];
     }
     __syncthreads();
+    RS_TICK(7)
     // ---- affine map and log-det over the first 256 threads: element e = (channel, column); a thread's column is fixed
     float lsum = 0.f;
     if (wave < 4) {
@@ -741,15 +785,15 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
     if (wave < 4 && (lane % LPS2) == 0 && (PIXR >= 64 || lane < 32)) T[wave * 4 + (lane % PIXR) / HW] = lsum;
     __syncthreads();
     if (tid < SPWR && b0 + tid < B) ldj_acc[b0 + tid] += ws[0] + ((T[tid] + T[4 + tid]) + (T[8 + tid] + T[12 + tid]));
+    RS_TICK(8)
+    RS_TICK_DUMP
 }
 
-#ifndef CF_RS_KSPLIT
-#define CF_RS_KSPLIT 2
-#endif
 template <class G, int NPT, bool SQ, bool DUMP = false>
 int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s, StepTape tp = kNoTape) {
     constexpr int SPWR = 32 * NPT / G::HW;
-    k_flow_step_rs<G, NPT, SQ, DUMP, CF_RS_KSPLIT><<<dim3((B + SPWR - 1) / SPWR), dim3(256 * CF_RS_KSPLIT), 0, s>>>(x, z, ldj, ws, B, xbs, tp);
+    constexpr int KS = 2;
+    k_flow_step_rs<G, NPT, SQ, DUMP, KS><<<dim3((B + SPWR - 1) / SPWR), dim3(256 * KS), 0, s>>>(x, z, ldj, ws, B, xbs, tp);
     return 0;
 }
 
