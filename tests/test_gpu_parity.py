@@ -654,6 +654,38 @@ def test_taped_backward_equals_recompute(L, name, B):
         assert torch.equal(ga, out[False][1][k]), k
 
 
+def test_smap_backward_is_additive_over_the_batch(L):
+    """Size-independent property of the one-kernel transformer-step backward at a batch the oracle cannot reach: with a loss
+    that is a SUM over samples, the gradients of a ragged batch of 5003 (forward in the 8-samples-per-wave form, backward in
+    the row-split form, last workgroup three quarters full) equal the sum of the gradients of its two parts (2049 + 2954:
+    forward row-split form) - per tensor, to fp32 summation noise - and the input gradient rows are the parts' rows."""
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e("smap")
+    g = torch.Generator().manual_seed(17)
+    B, cut = 5003, 2049
+    x = torch.rand(B, 25, 8, 1, generator=g)
+    eps = torch.randn(B, 1, 8, 1, generator=g)
+    wts = torch.randn(B, 1, generator=g).to(DEV)
+
+    def grads(sl):
+        model = build_model("smap", params)
+        set_noise(model, None, [eps[sl]])
+        model.train()
+        xin = x[sl].to(DEV).requires_grad_(False)
+        _, logp = model(xin)
+        (logp * wts[sl]).sum().backward()
+        return {k: p.grad.detach().double() for k, p in model.named_parameters() if p.grad is not None}
+    whole, a, b = grads(slice(0, B)), grads(slice(0, cut)), grads(slice(cut, B))
+    assert whole.keys() == a.keys() == b.keys() and len(whole) >= 500
+    worst = 0.0
+    for k in whole:
+        s = a[k] + b[k]
+        scale = max(s.abs().max().item(), 1e-12)
+        worst = max(worst, (whole[k] - s).abs().max().item() / scale)
+        assert (whole[k] - s).abs().max().item() <= 2e-4 * scale, (k, (whole[k] - s).abs().max().item(), scale)
+    print("additivity of the smap backward over 5003 = 2049 + 2954 samples: worst relative difference %.2e" % worst)
+
+
 @pytest.mark.parametrize("D,H,W,M,K,B", [(8, 16, 16, 10, 5, 7), (16, 8, 8, 10, 5, 9), (64, 4, 4, 10, 5, 6), (8, 7, 7, 3, 2, 5),
                                            (4, 14, 14, 2, 3, 3), (2, 40, 32, 2, 2, 5), (3, 1, 1, 4, 1, 2)])
 def test_gmm_ctx_kernels_against_torch(L, D, H, W, M, K, B):
