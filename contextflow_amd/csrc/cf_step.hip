@@ -89,6 +89,34 @@ __global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm,
             ws[G::OFF_AW + e] = (float)u;
         }
     }
+    if constexpr (G::RS16) {
+        // k_flow_step_rs16: natural row order, element ((rt * NG + gi) * 64 + lane) * 4 + j = A[16 rt + (lane & 15)][4 (4 gi + j) + (lane >> 4)]
+        constexpr int C = G::C, HID = G::HID, HALF = G::HALF;
+        for (int p = gtid; p < C; p += gsz) { ws[G::OFF_RB0 + p] = -t[p] * expf(-logs[p]); ws[G::OFF_RB3 + p] = b3[p]; }
+        for (int p = gtid; p < HID; p += gsz) { ws[G::OFF_RB1 + p] = b1[p]; ws[G::OFF_RB2 + p] = b2[p]; }
+        auto split16 = [](int e, int NG, int& rt, int& gi, int& row, int& kk, int& j) {
+            j = e & 3; const int ln = (e >> 2) & 63, q = e >> 8; gi = q % NG; rt = q / NG; row = 16 * rt + (ln & 15); kk = ln >> 4;
+        };
+        int rt, gi, row, kk, j;
+        for (int e = gtid; e < (C / 16) * (C / 16) * 256; e += gsz) {                     // e^{-logs} Wm
+            split16(e, C / 16, rt, gi, row, kk, j);
+            const int k = 4 * (4 * gi + j) + kk;
+            ws[G::OFF_RA0 + e] = expf(-logs[row]) * Wm[row * C + k];
+        }
+        for (int e = gtid; e < (HID / 16) * (HALF / 16) * 256; e += gsz) {                // NN.0
+            split16(e, HALF / 16, rt, gi, row, kk, j);
+            ws[G::OFF_RA1 + e] = w1[row * HALF + 4 * (4 * gi + j) + kk];
+        }
+        for (int e = gtid; e < (HID / 16) * 9 * (HID / 16) * 256; e += gsz) {             // NN.2: group = tap * (HID / 16) + channel group
+            split16(e, 9 * (HID / 16), rt, gi, row, kk, j);
+            const int tap = gi / (HID / 16), ci = 4 * (4 * (gi % (HID / 16)) + j) + kk;
+            ws[G::OFF_RA2 + e] = w2[(row * HID + ci) * 9 + tap];
+        }
+        for (int e = gtid; e < (C / 16) * (HID / 16) * 256; e += gsz) {                   // NN.4
+            split16(e, HID / 16, rt, gi, row, kk, j);
+            ws[G::OFF_RA3 + e] = w3[row * HID + 4 * (4 * gi + j) + kk];
+        }
+    }
     if constexpr (G::SMALL) {
         // operands of the 16x16x4 phases: A fragment of k-step s, lane l = A[row = l & 15][k = 4 s + (l >> 4)];
         // element e = (group * 64 + lane) * 4 + j holds k-step 4 group + j
@@ -797,6 +825,169 @@ int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B,
     return 0;
 }
 
+#ifndef CF_RS_MAXB_C64
+#define CF_RS_MAXB_C64 1024          // evaluation forward of the 4x4 level: row-split / one-sample kernels up to here, Winograd above
+#endif
+#ifndef CF_RS16_MAXB
+#define CF_RS16_MAXB 1024
+#endif
+// ---- the 4x4 level at small batches: ONE sample per workgroup on 16-column tiles -------------------------------------------
+// tools/dev/rs_ticks.py: at a batch of 256 the row-split kernel above spends 45.6 K of its 65 K cycles in the 3x3 - against
+// 36.9 K of pure MFMA time: the 2 304 MFMAs of a workgroup's 3x3 (2 samples = 32 pixel columns of a 32x32x2 tile) share the
+// four matrix pipes of ONE CU, and the launch has 128 workgroups for 256 CUs.  v_mfma_f32_16x16x4_f32 tiles hold exactly one
+// 4x4 sample in their 16 columns: twice the workgroups, half the matrix work each.  The four waves split the output rows
+// (16-row tiles: 1 / 2 / 2 / 1 per wave in the four products), planes [channel][16 pixels] in LDS (20 KB), natural row
+// order (t / raw / y1 of a channel meet in the LDS epilogue), the fragments of the three small products requested at
+// kernel start, those of the 3x3 through a ring of four groups.
+template <class G, bool SQ>
+__global__ __launch_bounds__(256) void k_flow_step_rs16(const float* __restrict__ x, float* __restrict__ z,
+                                                        float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                        int64_t xbs) {
+    static_assert(G::RS16, "C = 64 on 4x4 images");
+    constexpr int C = G::C, HW = 16, W = 4, H = 4, HALF = G::HALF, HID = G::HID, P = 16;
+    constexpr int NG0 = C / 16, NG1 = HALF / 16, NGT = HID / 16, NG3 = HID / 16;            // groups of 4 k-steps: per product / per tap
+    __shared__ __align__(16) float lds[(C + C + HID + C) * P + 4];
+    float* XP = lds;                 // [C][16]    x
+    float* YP = XP + C * P;          // [C][16]    y0 | y1
+    float* H1 = YP + C * P;          // [HID][16]  h1, then h2 in place
+    float* TP = H1 + HID * P;        // [C][16]    t | raw
+    float* red = TP + C * P;         // [4]
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const ws_rsrc_t rs = ws_rsrc(ws, G::WS_FLOATS);
+    float4 f0[NG0], f1[2][NG1], f3[NG3];
+#pragma unroll
+    for (int gi = 0; gi < NG0; ++gi) f0[gi] = ws_frag(rs, lane, G::OFF_RA0 + (w * NG0 + gi) * 256);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int gi = 0; gi < NG1; ++gi) f1[t][gi] = ws_frag(rs, lane, G::OFF_RA1 + ((2 * w + t) * NG1 + gi) * 256);
+#pragma unroll
+    for (int gi = 0; gi < NG3; ++gi) f3[gi] = ws_frag(rs, lane, G::OFF_RA3 + (w * NG3 + gi) * 256);
+    // the 3x3: group sequence j = tap * NGT + channel group, two row tiles per group, ring of four groups
+    auto frag2 = [&](int j, float4 (&o)[2]) {
+        const int jj = j < 9 * NGT ? j : 9 * NGT - 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o[t] = ws_frag(rs, lane, G::OFF_RA2 + ((2 * w + t) * 9 * NGT + jj) * 256);
+    };
+    float4 ring[4][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) frag2(j, ring[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* xb = x + (int64_t)b * xbs;
+#pragma unroll
+    for (int i = 0; i < C * P / 256; ++i) {
+        const int e = tid + 256 * i, ch = e / P, pp = e - ch * P;
+        int src;
+        if constexpr (!SQ) src = ch * HW + pp;
+        else { const int yy = pp / W, xx = pp - yy * W; src = (ch >> 2) * 4 * HW + (2 * yy + ((ch >> 1) & 1)) * 2 * W + 2 * xx + (ch & 1); }
+        XP[e] = xb[src];
+    }
+    __syncthreads();
+    auto mma = [](float a, float bv, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0); };
+    auto bias4 = [&](int off, int rt) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + off + 16 * rt + 4 * g);
+        return f32x4{v.x, v.y, v.z, v.w};
+    };
+    // ---- phase 0: [y0 | y1] = e^{-logs} (Wm x - t), rows 16 w ..
+    {
+        f32x4 a0 = bias4(G::OFF_RB0, w), a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4 * NG0; ++s) {
+            const float bv = XP[(4 * s + g) * P + col];
+            if (s & 1) a1 = mma(f4e(f0[s >> 2], s & 3), bv, a1); else a0 = mma(f4e(f0[s >> 2], s & 3), bv, a0);
+        }
+        a0 += a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) YP[(16 * w + 4 * g + r) * P + col] = a0[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < HALF * P / 256; ++i) {                                 // first half of the output = y0 (coupling.py:65)
+        const int e = tid + 256 * i;
+        z[(int64_t)b * C * HW + e] = YP[e];
+    }
+    // ---- phase 1: h1 = relu(NN.0 y0 + b), row tiles 2 w, 2 w + 1
+    {
+        f32x4 a[2] = {bias4(G::OFF_RB1, 2 * w), bias4(G::OFF_RB1, 2 * w + 1)};
+#pragma unroll
+        for (int s = 0; s < 4 * NG1; ++s) {
+            const float bv = YP[(4 * s + g) * P + col];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = mma(f4e(f1[t][s >> 2], s & 3), bv, a[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H1[(16 * (2 * w + t) + 4 * g + r) * P + col] = cf_relu(a[t][r]);
+    }
+    __syncthreads();
+    // ---- phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3 with reflect padding: 9 taps x HID channels
+    f32x4 a2[2] = {bias4(G::OFF_RB2, 2 * w), bias4(G::OFF_RB2, 2 * w + 1)};
+    {
+        const int py = col / W, px = col - py * W;
+        auto tap_src = [&](int tap) {
+            int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+            yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
+            xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
+            return g * P + yy * W + xx;                                        // + 4 s P per k-step
+        };
+        float bv[2][4];
+        int src = tap_src(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[0][e] = H1[src + 4 * e * P];
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int nsrc = tap_src(tap < 8 ? tap + 1 : 8);
+#pragma unroll
+            for (int c = 0; c < NGT; ++c) {                                    // NGT = 8: static ring slots
+                frag2(tap * NGT + c + 3, ring[(c + 3) & 3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    bv[(c + 1) & 1][e] = (c + 1 < NGT) ? H1[src + (16 * (c + 1) + 4 * e) * P] : H1[nsrc + 4 * e * P];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) a2[t] = mma(f4e(ring[c & 3][t], e), bv[c & 1][e], a2[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            src = nsrc;
+        }
+    }
+    __syncthreads();                 // every wave has finished reading h1
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H1[(16 * (2 * w + t) + 4 * g + r) * P + col] = cf_relu(a2[t][r]);
+    __syncthreads();
+    // ---- phase 3: [t | raw] = NN.4 h2 + b, rows 16 w ..
+    {
+        f32x4 a0 = bias4(G::OFF_RB3, w), a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4 * NG3; ++s) {
+            const float bv = H1[(4 * s + g) * P + col];
+            if (s & 1) a1 = mma(f4e(f3[s >> 2], s & 3), bv, a1); else a0 = mma(f4e(f3[s >> 2], s & 3), bv, a0);
+        }
+        a0 += a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) TP[(16 * w + 4 * g + r) * P + col] = a0[r];
+    }
+    __syncthreads();
+    // ---- affine map and log-det (coupling.py:52-66): element (channel, pixel), two per thread
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < HALF * P / 256; ++i) {
+        const int e = tid + 256 * i;
+        const float ls = cf_log_scale(TP[HALF * P + e]);
+        z[(int64_t)b * C * HW + HALF * HW + e] = fmaf(YP[HALF * P + e], __expf(ls), TP[e]);
+        lsum += ls;
+    }
+    lsum = cf_block_sum<4>(lsum, red);
+    if (tid == 0) ldj_acc[b] += ws[0] + lsum;
+}
+
 static thread_local float* g_prepare_winv = nullptr;          // cf_flow_step_prepare_train: also write Wm^-1 here
 
 template <class G>
@@ -1135,10 +1326,16 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     if (!direct_only && (sid == 0 || sid == 1 || (sid == 2 && B >= 256 * G32::SPW))) flags = 4 << 16;
     if (!direct_only && sid == 3 && B >= 256 * G64w2::SPW) flags = 5 << 16;      // 4x4: 8 samples per workgroup, rows split over wave pairs
     // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
-    if ((sid == 2 && B <= 512) || (sid == 3 && B <= 1024)) {
+    if ((sid == 2 && B <= 512) || (sid == 3 && B <= CF_RS_MAXB_C64)) {
         CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);
         if (B == 0) return 0;
         const float* w = (const float*)ws;
+        if (sid == 3 && B <= CF_RS16_MAXB) {   // 4x4: one sample per workgroup on 16-column tiles (twice the workgroups of the row-split kernel)
+            if (in_squeeze) k_flow_step_rs16<G64, true><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, w, B, x_bstride);
+            else k_flow_step_rs16<G64, false><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, w, B, x_bstride);
+            CF_LAUNCH_CHECK();
+            return 0;
+        }
         if (sid == 2) { if (in_squeeze) launch_step_rs<G32, 2, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream));
                         else launch_step_rs<G32, 2, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); }
         else          { if (in_squeeze) launch_step_rs<G64, 1, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream));

@@ -62,7 +62,14 @@ struct Geo {
     static constexpr bool WINO = (PIPE_ == 3);
     static constexpr int RT16 = HID / 16, KG4 = HID / 16;         // row tiles / k-step groups of the 16x16x4 products over HID
     static constexpr int OFF_AW = OFF_SA2 + (HID16 ? 9 * 256 : 0);
-    static constexpr int WS_FLOATS = OFF_AW + 16 * HID * HID;
+    // one-sample-per-workgroup form of the 4x4 level for small batches (k_flow_step_rs16, cf_step.hip): 16x16x4 A fragments
+    // of all four products in NATURAL row order, [row tile][group of 4 k-steps][lane][4], + their biases
+    static constexpr bool RS16 = (C == 64 && H == 4 && W == 4);
+    static constexpr int OFF_RB0 = OFF_AW + 16 * HID * HID, OFF_RB1 = OFF_RB0 + C, OFF_RB2 = OFF_RB1 + HID, OFF_RB3 = OFF_RB2 + HID;
+    static constexpr int OFF_RA0 = OFF_RB3 + C, OFF_RA1 = OFF_RA0 + (C / 16) * (C / 16) * 256;
+    static constexpr int OFF_RA2 = OFF_RA1 + (HID / 16) * (HALF / 16) * 256, OFF_RA3 = OFF_RA2 + (HID / 16) * 9 * (HID / 16) * 256;
+    static constexpr int R16_END = OFF_RA3 + (C / 16) * (HID / 16) * 256;
+    static constexpr int WS_FLOATS = RS16 ? R16_END : OFF_AW + 16 * HID * HID;
     static constexpr int PP = 2 * W + 2 * H + 4;      // fold slots per sample: 2 patched rows, 2 patched columns, 4 corners
     static constexpr int RS = PATCH ? ((PIX + SPW * PP + 1 + 3) & ~3) : PIX;
     static constexpr int LDS_FLOATS = (HALF + HID) * RS;
