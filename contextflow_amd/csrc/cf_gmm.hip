@@ -73,12 +73,13 @@ __device__ __forceinline__ float4 ld4_tail(const float* row, int d, int dend) {
 // MKT = components per thread; the workgroup covers MKB = 16*MKT components starting at blockIdx.y*MKB.
 // Partial sums q[b, mk] over d in [dlo, dhi) go to qout (workspace, [nsplit][B][MKtot]) when SPLIT,
 // otherwise the logsumexp epilogue runs here.
+// dlo, dhi: this workgroup's range of d; qb: its slot of partial sums [B][MKtot] (SPLIT)
 template <int MKT, bool VEC, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict__ x, const float* __restrict__ a,
-                                                     const float* __restrict__ nm, const float* __restrict__ cst,
-                                                     float* __restrict__ out, float* __restrict__ qout,
-                                                     int B, int MKtot, int K, int D, int dsplit,
-                                                     int64_t xbs, int accumulate, int Mtot) {
+__device__ __forceinline__ void gmm_logprob_body(const float* __restrict__ x, const float* __restrict__ a,
+                                                 const float* __restrict__ nm, const float* __restrict__ cst,
+                                                 float* __restrict__ out, float* __restrict__ qb,
+                                                 int B, int MKtot, int K, int D, int dlo, int dhi,
+                                                 int64_t xbs, int accumulate, int Mtot) {
     constexpr int MKB = 16 * MKT;
     constexpr int XITEMS = TB * (DC / 4) / 256;                    // float4 per thread for the x chunk (4)
     constexpr int PITEMS = (MKB * (DC / 4) + 255) / 256;           // float4 per thread per parameter array
@@ -94,8 +95,6 @@ __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict_
     const int tm = tid & 15, ts = tid >> 4;
     const int b0 = blockIdx.x * TB;
     const int mk0 = blockIdx.y * MKB;
-    const int dlo = blockIdx.z * dsplit;
-    const int dhi = min(D, dlo + dsplit);
 
     // packed along d: element .x sums the even, .y the odd feature columns - both v_pk_fma_f32 operands of a term are then
     // natural register pairs (x[s][d, d+1], a[mk][d, d+1]) with no broadcast.  (Written with scalars, hipcc packs across
@@ -178,7 +177,6 @@ __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict_
         for (int j = 0; j < MKT; ++j) acc[i][j] = acc2[i][j].x + acc2[i][j].y;
 
     if (SPLIT) {
-        float* qb = qout + (int64_t)blockIdx.z * B * MKtot;
 #pragma unroll
         for (int i = 0; i < SPT; ++i) {
             const int b = b0 + ts + 16 * i;
@@ -213,6 +211,86 @@ __global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict_
         float* o = out + (int64_t)b * Mtot + (mk / K);
         *o = accumulate ? *o + r : r;
     }
+}
+
+template <int MKT, bool VEC, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_gmm_logprob(const float* __restrict__ x, const float* __restrict__ a,
+                                                     const float* __restrict__ nm, const float* __restrict__ cst,
+                                                     float* __restrict__ out, float* __restrict__ qout,
+                                                     int B, int MKtot, int K, int D, int dsplit,
+                                                     int64_t xbs, int accumulate, int Mtot) {
+    const int dlo = blockIdx.z * dsplit;
+    gmm_logprob_body<MKT, VEC, SPLIT>(x, a, nm, cst, out, qout + (int64_t)blockIdx.z * B * MKtot, B, MKtot, K, D, dlo,
+                                      min(D, dlo + dsplit), xbs, accumulate, Mtot);
+}
+
+// Small batches (the launch, not the arithmetic, is what a mixture costs there - 10.5 + 5.8 us per level at a batch of
+// 256): the mixtures of ALL levels of a flow (the Split priors + the final prior) in one launch of the D-split form.
+// blockIdx.z runs over the d-slices of level 0, then level 1, ...; one finishing kernel sums each level's partials,
+// takes its logsumexp, adds the levels in order and the per-sample log-det (cf_logdet_combine folded in).
+constexpr int GMM_MAX_LEVELS = 4;
+struct GmmLevels {
+    const float* x[GMM_MAX_LEVELS]; const float* a[GMM_MAX_LEVELS]; const float* nm[GMM_MAX_LEVELS];
+    const float* cst[GMM_MAX_LEVELS];
+    int64_t xbs[GMM_MAX_LEVELS];
+    int D[GMM_MAX_LEVELS], dsplit[GMM_MAX_LEVELS], z0[GMM_MAX_LEVELS + 1];
+    int n;
+};
+
+template <int MKT>
+__global__ __launch_bounds__(256, 2) void k_gmm_logprob_levels(GmmLevels L, float* __restrict__ qout, int B, int MKtot, int K,
+                                                            int Mtot) {
+    int l = 0;
+    while (l + 1 < L.n && (int)blockIdx.z >= L.z0[l + 1]) ++l;      // uniform
+    const int dlo = ((int)blockIdx.z - L.z0[l]) * L.dsplit[l];
+    gmm_logprob_body<MKT, true, true>(L.x[l], L.a[l], L.nm[l], nullptr, nullptr, qout + (int64_t)blockIdx.z * B * MKtot, B,
+                                      MKtot, K, L.D[l], dlo, min(L.D[l], dlo + L.dsplit[l]), L.xbs[l], 0, Mtot);
+}
+
+// one thread per (b, component) as in k_gmm_finish; out[b, m] = (ldM[b, m] +) sum_levels logsumexp_k(...) (+ ld1[b])
+__global__ __launch_bounds__(256) void k_gmm_finish_levels(const float* __restrict__ q, GmmLevels L,
+                                                           const float* __restrict__ ldM, const float* __restrict__ ld1,
+                                                           float* __restrict__ out, int B, int M, int K) {
+    __shared__ float l[256];
+    const int MK = M * K, spb = blockDim.x / MK;
+    const int sl = threadIdx.x / MK, mk = threadIdx.x - sl * MK;
+    const int b = blockIdx.x * spb + sl;
+    const bool live = b < B && sl < spb;
+    const bool head = live && mk % K == 0;
+    const int64_t e = (int64_t)b * M + mk / K;
+    float r = 0.f;
+    bool first = true;
+    if (head && ldM) { r = ldM[e]; first = false; }
+    for (int lev = 0; lev < L.n; ++lev) {
+        float s = 0.f;
+        if (live) {
+            const float* qp = q + (int64_t)b * MK + mk;
+            const int64_t zs = (int64_t)B * MK;
+            int z = L.z0[lev];
+            const int zend = L.z0[lev + 1];
+            for (; z + 8 <= zend; z += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = qp[(z + j) * zs];
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            for (; z < zend; ++z) s += qp[z * zs];
+        }
+        __syncthreads();
+        l[threadIdx.x] = live ? L.cst[lev][mk] - 0.5f * s : 0.f;
+        __syncthreads();
+        if (head) {
+            const float* lp = l + threadIdx.x;
+            float mx = -INFINITY;
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[k]);
+            float sum = 0.f;
+            for (int k = 0; k < K; ++k) sum += expf(lp[k] - mx);
+            const float v = mx + logf(sum);
+            r = first ? v : r + v;
+            first = false;
+        }
+    }
+    if (head) out[e] = ld1 ? r + ld1[b] : r;
 }
 
 // finishing kernel for the D-split form: sum partials, logsumexp.  One thread per (b, component): the partial sums of
@@ -500,6 +578,58 @@ int cf_gmm_logprob(const float* x, const float* a, const float* nm, const float*
         else       { if (vec) CF_GO(5, true, false); else CF_GO(5, false, false); }
     }
 #undef CF_GO
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// all mixtures of a flow in two launches (small batches).  Level l: x[l] (B rows of D[l] floats, row stride x_bstride[l]),
+// its prepared tables a[l], nm[l] (M*K, D[l]) and cst[l] (M*K).  out[b, m] = (ldM[b, m] +) sum_l log p_l(x_l[b] | m) (+ ld1[b]);
+// ldM and ld1 may be null.  The levels are summed in order, each with the D split cf_gmm_logprob would choose: the result
+// equals the chain of cf_gmm_logprob(..., accumulate) calls + cf_logdet_combine bit for bit.
+// Requires n <= 4, M*K <= 256, D[l] % 4 == 0, x_bstride[l] % 4 == 0, 16-byte aligned x[l] / a[l] / nm[l].
+int64_t cf_gmm_levels_ws_bytes(int n, const int* D, int B, int M, int K) {
+    if (n < 1 || n > GMM_MAX_LEVELS || !D) return -1;
+    int64_t z = 0;
+    for (int l = 0; l < n; ++l) {
+        int ns = choose_nsplit(B, M * K, D[l]);
+        if (ns > 1) { const int ds = ((D[l] + ns - 1) / ns + DC - 1) / DC * DC; ns = (D[l] + ds - 1) / ds; }
+        z += ns;
+    }
+    return z * B * M * K * (int64_t)sizeof(float);
+}
+
+int cf_gmm_logprob_levels(int n, const float* const* x, const float* const* a, const float* const* nm,
+                          const float* const* cst, const int* D, const int64_t* x_bstride, const float* ldM,
+                          const float* ld1, float* out, void* ws, int B, int M, int K, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(n >= 1 && n <= GMM_MAX_LEVELS && x && a && nm && cst && D && x_bstride && out && ws && B >= 0 && M > 0 &&
+               K > 0 && K <= 16 && M * K <= 256);
+    const int MK = M * K;
+    const bool small = MK <= 16;
+    CF_REQUIRE(small ? (16 % K == 0 || M == 1) : (80 % K == 0));
+    GmmLevels L;
+    L.n = n;
+    int z = 0;
+    for (int l = 0; l < GMM_MAX_LEVELS; ++l) {
+        const int s = l < n ? l : n - 1;
+        CF_REQUIRE(x[s] && a[s] && nm[s] && cst[s] && D[s] > 0 && D[s] % 4 == 0 && x_bstride[s] >= D[s] && x_bstride[s] % 4 == 0);
+        CF_REQUIRE(((reinterpret_cast<uintptr_t>(x[s]) | reinterpret_cast<uintptr_t>(a[s]) | reinterpret_cast<uintptr_t>(nm[s])) & 15) == 0);
+        L.x[l] = x[s]; L.a[l] = a[s]; L.nm[l] = nm[s]; L.cst[l] = cst[s]; L.xbs[l] = x_bstride[s]; L.D[l] = D[s];
+        int ns = choose_nsplit(B, MK, D[s]), ds = D[s];
+        if (ns > 1) { ds = ((D[s] + ns - 1) / ns + DC - 1) / DC * DC; ns = (D[s] + ds - 1) / ds; }
+        L.dsplit[l] = ds;
+        L.z0[l] = z;
+        if (l < n) z += ns;
+    }
+    L.z0[GMM_MAX_LEVELS] = z;
+    for (int l = n; l < GMM_MAX_LEVELS; ++l) L.z0[l] = z;
+    const int mkb = small ? 16 : 80;
+    dim3 grid((B + TB - 1) / TB, (MK + mkb - 1) / mkb, z);
+    float* q = (float*)ws;
+    if (small) k_gmm_logprob_levels<1><<<grid, dim3(256), 0, cf_s(stream)>>>(L, q, B, MK, K, M);
+    else k_gmm_logprob_levels<5><<<grid, dim3(256), 0, cf_s(stream)>>>(L, q, B, MK, K, M);
+    const int spb = 256 / MK;
+    k_gmm_finish_levels<<<dim3((unsigned)((B + spb - 1) / spb)), dim3(spb * MK), 0, cf_s(stream)>>>(q, L, ldM, ld1, out, B, M, K);
     CF_LAUNCH_CHECK();
     return 0;
 }

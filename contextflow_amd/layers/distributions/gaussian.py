@@ -75,6 +75,44 @@ def gmm_logprob(x, prepared, out=None, accumulate=False):
     return out
 
 
+GMM_LEVELS_MAX_BATCH = 1024       # below: all mixtures of a flow in one launch pair (the launches are what they cost there)
+
+
+def gmm_levels_ok(levels):
+    """levels: [(x, prepared)].  True when cf_gmm_logprob_levels takes them as they are (no copies made here)."""
+    if not 1 <= len(levels) <= 4:
+        return False
+    M, K = levels[0][1][3], levels[0][1][4]
+    if M * K > 256 or not ((16 % K == 0 or M == 1) if M * K <= 16 else 80 % K == 0):
+        return False
+    for x, (a, nm, cst, m, k, D) in levels:
+        xv, xbs = _hip.bview(x)
+        if (m, k) != (M, K) or xv is not x or D % 4 or xbs % 4 or (x.data_ptr() | a.data_ptr() | nm.data_ptr()) & 15:
+            return False
+    return True
+
+
+def gmm_logprob_levels(levels, ldM=None, ld1=None):
+    """logp (B, M) = (ldM +) sum over the levels' mixture log-probs (+ ld1[:, None]) in one launch pair; equals the chain of
+    gmm_logprob(..., accumulate=True) + cf_logdet_combine bit for bit.  levels as for gmm_levels_ok (which must hold)."""
+    import ctypes
+    n = len(levels)
+    a0, _, _, M, K, _ = levels[0][1]
+    B, dev = levels[0][0].shape[0], levels[0][0].device
+    parr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    Ds = (ctypes.c_int * n)(*[lv[1][5] for lv in levels])
+    xbs = (ctypes.c_int64 * n)(*[_hip.bview(lv[0])[1] for lv in levels])
+    L = _hip.lib()
+    ws = torch.empty(max(L.cf_gmm_levels_ws_bytes(n, Ds, B, M, K), 1), device=dev, dtype=torch.uint8)
+    out = torch.empty(B, M, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _hip.check(L.cf_gmm_logprob_levels(n, parr([lv[0] for lv in levels]), parr([lv[1][0] for lv in levels]),
+                                           parr([lv[1][1] for lv in levels]), parr([lv[1][2] for lv in levels]), Ds, xbs,
+                                           _hip.p(ldM), _hip.p(ld1), _hip.p(out), _hip.p(ws), B, M, K, _hip.stream(dev)),
+                   "cf_gmm_logprob_levels")
+    return out
+
+
 class GaussianDistribution(nn.Module):
     """gaussian.py:75-115: diagonal Gaussian with one (frozen) mean / pre-softplus scale per channel; log_prob (B,) sums
     over (C, H, W).  Evaluated by the mixture kernel with M = K = 1 (the parameters broadcast over the pixels)."""

@@ -24,7 +24,8 @@ from .augment import Augment
 from .conv1x1 import Conv1x1
 from .coupling import Coupling, TransCoupling
 from .dequantize import Dequantization
-from .distributions.gaussian import GaussianMixtureDistribution, StandardNormal, gmm_logprob
+from .distributions.gaussian import (GaussianMixtureDistribution, StandardNormal, gmm_logprob, gmm_levels_ok,
+                                     gmm_logprob_levels, GMM_LEVELS_MAX_BATCH)
 from .distributions.uniform import UniformDistribution
 from .normalize import Normalization
 from .permute_axes import PermuteAxes
@@ -307,6 +308,7 @@ class FlowSequential(nn.Module):
         ld1 = (torch.empty if plan and plan[0][0] == "pre" else torch.zeros)(B, device=dev, dtype=torch.float32)
         ldM = torch.empty(B, M, device=dev, dtype=torch.float32)
         ldM_set = False
+        levels = [] if tape is None and B <= GMM_LEVELS_MAX_BATCH else None
         st = _hip.stream()
         for k, op in enumerate(plan):
             kind = op[0]
@@ -394,8 +396,11 @@ class FlowSequential(nn.Module):
                 if tape is not None:
                     tape.append(("split", x, op[1].dist, prep))
                 c = x.shape[1] // 2
-                gmm_logprob(x[:, c:], prep, out=ldM, accumulate=ldM_set)
-                ldM_set = True
+                if levels is not None:       # small batch: every mixture of the flow in one launch pair at the end
+                    levels.append((x[:, c:], prep))
+                else:
+                    gmm_logprob(x[:, c:], prep, out=ldM, accumulate=ldM_set)
+                    ldM_set = True
                 x = x[:, :c]
             else:                        # any other layer: its own kernels
                 if tape is not None:
@@ -413,9 +418,15 @@ class FlowSequential(nn.Module):
             main.wait_event(ev_prior)
         if tape is not None:
             tape.append(("prior", x, self.dist, prior))
-        gmm_logprob(x, prior, out=ldM, accumulate=ldM_set)
-        logp = torch.empty(B, M, device=dev, dtype=torch.float32)
-        _hip.call("cf_logdet_combine", _hip.p(ldM), _hip.p(ld1), _hip.p(logp), B, M, st)
+        if levels is not None and gmm_levels_ok(levels + [(x, prior)]):
+            logp = gmm_logprob_levels(levels + [(x, prior)], ldM if ldM_set else None, ld1)
+        else:
+            for xl, prep in levels or ():
+                gmm_logprob(xl, prep, out=ldM, accumulate=ldM_set)
+                ldM_set = True
+            gmm_logprob(x, prior, out=ldM, accumulate=ldM_set)
+            logp = torch.empty(B, M, device=dev, dtype=torch.float32)
+            _hip.call("cf_logdet_combine", _hip.p(ldM), _hip.p(ld1), _hip.p(logp), B, M, st)
         # buffers written on the side stream are consumed on the main stream: keep the allocator informed
         def _bufs(t):
             if torch.is_tensor(t):

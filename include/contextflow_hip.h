@@ -125,6 +125,18 @@ int64_t cf_gmm_ws_bytes(int B, int M, int K, int D);
 int cf_gmm_logprob(const float* x, const float* a, const float* nm, const float* cst, float* out, void* ws,
                    int B, int M, int K, int D, int64_t x_bstride, int accumulate, cf_stream_t stream);
 
+/* All mixtures of one flow in two launches (small batches, where a launch costs more than the arithmetic: the Split priors
+ * of flowsequential.py:18-27 + the final prior).  Level l < n <= 4: x[l] (B rows of D[l] floats, row stride x_bstride[l])
+ * with its prepared tables a[l], nm[l] (M*K, D[l]) and cst[l] (M*K).
+ *   out[b,m] = (ldM[b,m] +) sum_l log p_l(x_l[b] | m) (+ ld1[b])        ldM, ld1: optional (NULL)
+ * - the chain of cf_gmm_logprob(..., accumulate) calls followed by cf_logdet_combine, bit for bit (same D splits, same
+ * order of sums).  Requires M*K <= 256, D[l] % 4 == 0, x_bstride[l] % 4 == 0, 16-byte aligned x / a / nm.
+ * ws: cf_gmm_levels_ws_bytes(n, D, B, M, K) bytes (always > 0; -1 for n outside 1..4).                                     */
+int64_t cf_gmm_levels_ws_bytes(int n, const int* D, int B, int M, int K);
+int cf_gmm_logprob_levels(int n, const float* const* x, const float* const* a, const float* const* nm,
+                          const float* const* cst, const int* D, const int64_t* x_bstride, const float* ldM,
+                          const float* ld1, float* out, void* ws, int B, int M, int K, cf_stream_t stream);
+
 /* q[b, m*K+k] = sum_d ((x[b,d] + nm)*a)^2 only (B x M*K, dense): the backward pass rebuilds the responsibilities
  * softmax_k(cst - q/2) from it.                                                                        */
 int cf_gmm_quad(const float* x, const float* a, const float* nm, float* q, int B, int M, int K, int D,

@@ -149,6 +149,36 @@ def test_gmm_split_d_matches_single_pass(L):
     close(out2, out1, tol=1e-6)
 
 
+@pytest.mark.parametrize("B,with_ldM", [(1, False), (70, True), (256, False), (1000, True)])
+def test_gmm_levels_entry_equals_the_chain_of_calls(L, B, with_ldM):
+    """cf_gmm_logprob_levels (all mixtures of a flow in one launch pair, small batches) = the chain of accumulating
+    cf_gmm_logprob calls + cf_logdet_combine, bit for bit; levels are channel slices of wider tensors as in the flow."""
+    from contextflow_amd.layers.distributions.gaussian import gmm_prepare, gmm_logprob, gmm_levels_ok, gmm_logprob_levels
+    from contextflow_amd.layers import _hip
+    g = torch.Generator().manual_seed(11 + B)
+    M, K = 10, 8
+    levels, ref = [], []
+    for D, wide in ((1536, 3072), (768, 1536), (768, 768)):
+        mG, sG, wG = torch.randn(M, K, D, generator=g), 1 + 0.2 * torch.randn(M, K, D, generator=g), torch.randn(M, K, generator=g)
+        xw = torch.randn(B, wide, generator=g).to(DEV)
+        x = xw[:, wide - D:]
+        levels.append((x, gmm_prepare(mG.to(DEV), sG.to(DEV), wG.to(DEV))))
+        ref.append(fo.gmm_logprob(x.cpu(), mG, sG, wG))
+    ld1 = torch.randn(B, generator=g).to(DEV)
+    ldM0 = torch.randn(B, M, generator=g).to(DEV) if with_ldM else None
+    assert gmm_levels_ok(levels)
+    got = gmm_logprob_levels(levels, ldM0, ld1)
+    ldM = ldM0.clone() if with_ldM else torch.empty(B, M, device=DEV)
+    for i, (x, prep) in enumerate(levels):
+        gmm_logprob(x, prep, out=ldM, accumulate=with_ldM or i > 0)
+    want = torch.empty(B, M, device=DEV)
+    _hip.call("cf_logdet_combine", _hip.p(ldM), _hip.p(ld1), _hip.p(want), B, M, _hip.stream())
+    assert torch.equal(got, want)
+    tot = sum(ref) + ld1.cpu()[:, None] + (ldM0.cpu() if with_ldM else 0)
+    close(got, tot, tol=3e-6)
+    assert not gmm_levels_ok([(levels[0][0][:, 1:], levels[0][1])])          # misaligned / wrong width: refused, not copied
+
+
 def test_preprocessing(L):
     t, _ = unit("normalize")
     n = L.Normalization(translation=1e-4, scale=1 / (1 - 2e-4)).to(DEV)
@@ -927,11 +957,11 @@ def test_captured_train_step_matches_the_eager_loop(L, name):
     cap.train()
     opt_c = torch.optim.AdamW(cap.parameters(), lr=1e-3, fused=True, capturable=True)
     step = cap.capture_train_step(xd, loss_fn, opt_c)
-    l0 = float(step(xd, gt))                      # update 1 (the warm-up step, eager) + capture: returns that step's loss
+    l0 = float(step(xd, gt).detach())                      # update 1 (the warm-up step, eager) + capture: returns that step's loss
     assert abs(l0 - losses_e[0]) < 2e-6 * max(1.0, abs(losses_e[0])), (l0, losses_e[0])
     with torch.no_grad():                         # an evaluation between the training steps fills the table caches ...
         cap.log_prob(xd)
-    losses_c = [float(step(xd, gt)) for _ in range(3)]           # updates 2-4: replays
+    losses_c = [float(step(xd, gt).detach()) for _ in range(3)]           # updates 2-4: replays
     assert step.updates == 4
     for a, b in zip(losses_e[1:], losses_c):
         assert abs(a - b) < 2e-6 * max(1.0, abs(a)), (losses_e, losses_c)
