@@ -74,12 +74,15 @@ __device__ __forceinline__ float4 ld4_tail(const float* row, int d, int dend) {
 // Partial sums q[b, mk] over d in [dlo, dhi) go to qout (workspace, [nsplit][B][MKtot]) when SPLIT,
 // otherwise the logsumexp epilogue runs here.
 // dlo, dhi: this workgroup's range of d; qb: its slot of partial sums [B][MKtot] (SPLIT)
-template <int MKT, bool VEC, bool SPLIT>
+// KEYED: the samples of this workgroup are rows[0 .. nvalid) (indices into x and qb) instead of b0 .. b0 + TB
+template <int MKT, bool VEC, bool SPLIT, bool KEYED = false>
 __device__ __forceinline__ void gmm_logprob_body(const float* __restrict__ x, const float* __restrict__ a,
                                                  const float* __restrict__ nm, const float* __restrict__ cst,
                                                  float* __restrict__ out, float* __restrict__ qb,
                                                  int B, int MKtot, int K, int D, int dlo, int dhi,
-                                                 int64_t xbs, int accumulate, int Mtot) {
+                                                 int64_t xbs, int accumulate, int Mtot,
+                                                 const int* __restrict__ rows = nullptr, int nvalid = 0) {
+    static_assert(!KEYED || SPLIT, "the keyed form writes partial sums");
     constexpr int MKB = 16 * MKT;
     constexpr int XITEMS = TB * (DC / 4) / 256;                    // float4 per thread for the x chunk (4)
     constexpr int PITEMS = (MKB * (DC / 4) + 255) / 256;           // float4 per thread per parameter array
@@ -113,7 +116,7 @@ __device__ __forceinline__ void gmm_logprob_body(const float* __restrict__ x, co
 #pragma unroll
         for (int q = 0; q < XITEMS; ++q) {
             const int e = q * 256 + tid, row = e >> 3, c4 = (e & 7) * 4;
-            const float* rp = x + (int64_t)min(b0 + row, B - 1) * xbs;
+            const float* rp = x + (int64_t)(KEYED ? rows[min(row, nvalid - 1)] : min(b0 + row, B - 1)) * xbs;
             px[q] = full ? *reinterpret_cast<const float4*>(rp + d0 + c4) : ld4_tail<VEC>(rp, d0 + c4, dhi);
         }
 #pragma unroll
@@ -179,11 +182,12 @@ __device__ __forceinline__ void gmm_logprob_body(const float* __restrict__ x, co
     if (SPLIT) {
 #pragma unroll
         for (int i = 0; i < SPT; ++i) {
-            const int b = b0 + ts + 16 * i;
+            const bool live = KEYED ? ts + 16 * i < nvalid : b0 + ts + 16 * i < B;
+            const int b = KEYED ? (live ? rows[ts + 16 * i] : 0) : b0 + ts + 16 * i;
 #pragma unroll
             for (int j = 0; j < MKT; ++j) {
                 const int mk = mk0 + tm + 16 * j;
-                if (b < B && mk < MKtot) qb[(int64_t)b * MKtot + mk] = acc[i][j];
+                if (live && mk < MKtot) qb[(int64_t)b * MKtot + mk] = acc[i][j];
             }
         }
         return;
@@ -291,6 +295,55 @@ __global__ __launch_bounds__(256) void k_gmm_finish_levels(const float* __restri
         }
     }
     if (head) out[e] = ld1 ? r + ld1[b] : r;
+}
+
+// Context-shifted mixtures whose shifts are embedding lookups (model.py:157,162: CatEmbeddings + EyeSampling): a sample's
+// mixture is one of Um x Us parameter sets - means mu + cm[km], scales softplus(sG + cs[ks]) - chosen by its context.
+// With the samples bucketed by (km, ks) a workgroup's 128 samples share their parameter rows, i.e. the register-tiled
+// kernel above applies with its x rows gathered through an index list and its tables chosen per tile (the per-sample
+// kernel of cf_context.hip reads one 1/sigma per term per sample from L2: 7x slower at saturating batches).
+// tiles (T, 4) int32: [ks, km, first position in `order`, number of samples (0: unused tile)].
+template <int MKT>
+__global__ __launch_bounds__(256, 2) void k_gmm_logprob_keyed(const float* __restrict__ x, const float* __restrict__ a_tab,
+                                                           const float* __restrict__ nm_tab, const int* __restrict__ tiles,
+                                                           const int* __restrict__ order, float* __restrict__ qout, int B,
+                                                           int MKtot, int K, int D, int dsplit, int64_t xbs, int Mtot) {
+    const int4 tl = *reinterpret_cast<const int4*>(tiles + 4 * blockIdx.x);
+    if (tl.w <= 0) return;                                           // uniform
+    const int dlo = blockIdx.z * dsplit;
+    const int64_t tab = (int64_t)MKtot * D;
+    gmm_logprob_body<MKT, true, true, true>(x, a_tab + tl.x * tab, nm_tab + tl.y * tab, nullptr, nullptr,
+                                            qout + (int64_t)blockIdx.z * B * MKtot, B, MKtot, K, D, dlo, min(D, dlo + dsplit),
+                                            xbs, 0, Mtot, order + tl.z, tl.w);
+}
+
+// k_gmm_finish with the constant row chosen by the sample's scale key
+__global__ __launch_bounds__(256) void k_gmm_finish_keyed(const float* __restrict__ q, const float* __restrict__ cst_tab,
+                                                          const int* __restrict__ key, float* __restrict__ out, int B, int M,
+                                                          int K, int nsplit, int accumulate) {
+    __shared__ float l[256];
+    const int MK = M * K, spb = blockDim.x / MK;
+    const int sl = threadIdx.x / MK, mk = threadIdx.x - sl * MK;
+    const int b = blockIdx.x * spb + sl;
+    const bool live = b < B && sl < spb;
+    float s = 0.f;
+    if (live) {
+        const float* qp = q + (int64_t)b * MK + mk;
+        const int64_t zs = (int64_t)B * MK;
+        for (int z = 0; z < nsplit; ++z) s += qp[z * zs];
+    }
+    l[threadIdx.x] = live ? cst_tab[(int64_t)key[b] * MK + mk] - 0.5f * s : 0.f;
+    __syncthreads();
+    if (live && mk % K == 0) {
+        const float* lp = l + threadIdx.x;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[k]);
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += expf(lp[k] - mx);
+        const float r = mx + logf(sum);
+        const int64_t e = (int64_t)b * M + mk / K;
+        out[e] = accumulate ? out[e] + r : r;
+    }
 }
 
 // finishing kernel for the D-split form: sum partials, logsumexp.  One thread per (b, component): the partial sums of
@@ -630,6 +683,44 @@ int cf_gmm_logprob_levels(int n, const float* const* x, const float* const* a, c
     else k_gmm_logprob_levels<5><<<grid, dim3(256), 0, cf_s(stream)>>>(L, q, B, MK, K, M);
     const int spb = 256 / MK;
     k_gmm_finish_levels<<<dim3((unsigned)((B + spb - 1) / spb)), dim3(spb * MK), 0, cf_s(stream)>>>(q, L, ldM, ld1, out, B, M, K);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Mixtures with keyed parameter sets (the embedding-lookup context nets of the specialist flows).  x (B rows of D floats -
+// D counts every feature, channels x pixels), a_tab (Us, M*K, D) = 1/sigma per scale key, nm_tab (Um, M*K, D) = -(mu + shift)
+// per mean key, cst_tab (Us, M*K), key_s (B): every sample's scale key.  order (B): the sample indices grouped by
+// (scale key, mean key); tiles (T, 4) int32 rows [ks, km, first position in order, count <= 128 (0 = unused tile)].
+// out[b, m] (+)= logsumexp_k(cst_tab[key_s[b]] - 1/2 sum_d ((x + nm) a)^2).  M*K <= 256 and a multiple of 80 / K as for
+// cf_gmm_logprob with M*K > 16; D % 4 == 0, x_bstride % 4 == 0, 16-byte aligned x and tables.
+static int keyed_nsplit(int T, int MK, int D) {
+    const int64_t base = (int64_t)T * ((MK + 79) / 80);
+    int ns = 1;
+    while (base * ns < 512 && ns < 64 && D / (ns * 2) >= DC) ns *= 2;
+    return ns;
+}
+
+int64_t cf_gmm_keyed_ws_bytes(int T, int B, int M, int K, int D) {
+    return (int64_t)keyed_nsplit(T, M * K, D) * B * M * K * (int64_t)sizeof(float);
+}
+
+int cf_gmm_logprob_keyed(const float* x, const float* a_tab, const float* nm_tab, const float* cst_tab, const int* key_s,
+                         const int* tiles, const int* order, float* out, void* ws, int T, int B, int M, int K, int D,
+                         int64_t x_bstride, int accumulate, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && a_tab && nm_tab && cst_tab && key_s && tiles && order && out && ws && T > 0 && B > 0 && M > 0 && K > 0 &&
+               K <= 16 && M * K > 16 && M * K <= 256 && 80 % K == 0 && D > 0 && D % 4 == 0 && x_bstride >= D && x_bstride % 4 == 0);
+    CF_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(a_tab) | reinterpret_cast<uintptr_t>(nm_tab) |
+                 reinterpret_cast<uintptr_t>(tiles)) & 15) == 0);
+    const int MK = M * K;
+    int ns = keyed_nsplit(T, MK, D), dsplit = D;
+    if (ns > 1) { dsplit = ((D + ns - 1) / ns + DC - 1) / DC * DC; ns = (D + dsplit - 1) / dsplit; }
+    float* q = (float*)ws;
+    k_gmm_logprob_keyed<5><<<dim3(T, (MK + 79) / 80, ns), dim3(256), 0, cf_s(stream)>>>(x, a_tab, nm_tab, tiles, order, q, B, MK,
+                                                                                       K, D, dsplit, x_bstride, M);
+    const int spb = 256 / MK;
+    k_gmm_finish_keyed<<<dim3((unsigned)((B + spb - 1) / spb)), dim3(spb * MK), 0, cf_s(stream)>>>(q, cst_tab, key_s, out, B, M, K,
+                                                                                                 ns, accumulate);
     CF_LAUNCH_CHECK();
     return 0;
 }

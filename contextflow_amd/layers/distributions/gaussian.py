@@ -113,6 +113,37 @@ def gmm_logprob_levels(levels, ldM=None, ld1=None):
     return out
 
 
+KEYED_MIN_PER_KEY = 16             # cf_gmm_logprob_keyed from 16 samples per (mean key, scale key) value on average
+_bucket_cache = [None, None]
+
+
+def _key_buckets(context, key_s, key_m, Us, Um, tag=None, TB=128):
+    """Samples grouped by (scale key, mean key) for cf_gmm_logprob_keyed, all on the device (no host sync):
+    order (B) int32 = sample indices sorted by key, tiles (T, 4) int32 = [ks, km, first position in order, count] with
+    T = ceil(B / TB) + Us Um (an upper bound; unused tiles have count 0).  The last result is kept with the context tensor
+    it was made from (the object itself, so its storage cannot be recycled under the cache; in-place writes bump its
+    version): the mixtures of all levels of a flow see the same context."""
+    sig = (context._version, Us, Um, tag)       # tag: what the keys were formed from (equal tag => equal keys)
+    if _bucket_cache[0] is not None and _bucket_cache[0][0] is context and _bucket_cache[0][1] == sig:
+        return _bucket_cache[1]
+    B, U, dev = key_s.shape[0], Us * Um, key_s.device
+    kc = key_s.long() * Um + key_m.long()
+    order = torch.argsort(kc).to(torch.int32)
+    counts = torch.bincount(kc, minlength=U)
+    per = (counts + TB - 1) // TB
+    tile_end = torch.cumsum(per, 0)
+    row_start = torch.cumsum(counts, 0) - counts
+    T = (B + TB - 1) // TB + U
+    t = torch.arange(T, device=dev)
+    u = torch.searchsorted(tile_end, t, right=True)
+    uc = u.clamp(max=U - 1)
+    j = t - (tile_end[uc] - per[uc])
+    n = torch.where(u < U, (counts[uc] - j * TB).clamp(max=TB), torch.zeros_like(j))
+    tiles = torch.stack([uc // Um, uc % Um, row_start[uc] + j * TB, n], 1).to(torch.int32).contiguous()
+    _bucket_cache[0], _bucket_cache[1] = (context, sig), (order, tiles)
+    return order, tiles
+
+
 class GaussianDistribution(nn.Module):
     """gaussian.py:75-115: diagonal Gaussian with one (frozen) mean / pre-softplus scale per channel; log_prob (B,) sums
     over (C, H, W).  Evaluated by the mixture kernel with M = K = 1 (the parameters broadcast over the pixels)."""
@@ -224,6 +255,18 @@ class GaussianMixtureDistribution(nn.Module):
             return key.to(torch.int32)
         return (key_of(rel_s, st_s),) + cache[1:4] + (key_of(rel_m, st_m), cache[4])
 
+    def _keyed_tables(self, tab, logw):
+        """Per-key parameter rows of cf_gmm_logprob_keyed, cached with the scale tables: nm (Um, M*K*N) = -(mG + mean shift)
+        - the reference's `self.mG + cond_mean` rounded once (gaussian.py:143) - and cst (Us, M*K)."""
+        cache = self._tab_cache
+        if len(cache) == 5 or cache[5][0] is not tab[1]:
+            D, H, W = self.size
+            MK = self.M * self.K
+            nm = -(_hip.f32(self.mG.detach()).view(1, MK, D, H * W) + tab[5].view(-1, MK, D, 1))
+            cst = logw.reshape(1, MK) - tab[3] - 0.5 * D * H * W * math.log(2 * math.pi)
+            cache = self._tab_cache = cache[:5] + ((tab[1], nm.reshape(nm.shape[0], -1).contiguous(), cst.contiguous()),)
+        return cache[5][1:]
+
     def _log_prob_ctx(self, input, context, tape=None):
         """gaussian.py:146-158: per-sample shifts (B, 2, M, K, D) of the component means / pre-softplus scales."""
         if isinstance(context, list):
@@ -238,6 +281,19 @@ class GaussianMixtureDistribution(nn.Module):
             # evaluation with the embedding-lookup context net: both halves of the shift come from tables indexed by a
             # key per sample - the (B, 2 M K D) rows of embeddings are never gathered (logp_c of the lookup is 0)
             key, inv, _, lsum, ckey, cm_tab = tab
+            Um, Us = cm_tab.shape[0], inv.shape[0]
+            N = D * H * W
+            if (B >= KEYED_MIN_PER_KEY * Um * Us and 16 < M * K <= 256 and 80 % K == 0 and N % 4 == 0 and xbs % 4 == 0
+                    and x.data_ptr() % 16 == 0):
+                # saturating batches: samples bucketed by (scale key, mean key) - a workgroup's 128 samples then share their
+                # parameter rows and the register-tiled mixture kernel applies (cf_gmm_logprob_keyed)
+                nm_tab, cst_tab = self._keyed_tables(tab, logw)
+                order, tiles = _key_buckets(context, key, ckey, Us, Um, tuple(e.num_embeddings for e in self.context_net[0]._embeddings))
+                T = tiles.shape[0]
+                ws = torch.empty(_hip.lib().cf_gmm_keyed_ws_bytes(T, B, M, K, N), device=x.device, dtype=torch.uint8)
+                _hip.call("cf_gmm_logprob_keyed", _hip.p(x), _hip.p(inv), _hip.p(nm_tab), _hip.p(cst_tab), _hip.p(key),
+                          _hip.p(tiles), _hip.p(order), _hip.p(out), _hip.p(ws), T, B, M, K, N, xbs, 0, _hip.stream())
+                return out
             _hip.call("cf_gmm_ctx_logprob_tab", _hip.p(x), _hip.p(_hip.f32(self.mG.detach())), _hip.p(inv), _hip.p(lsum),
                       _hip.p(logw), _hip.p(cm_tab), _hip.p(ckey), _hip.p(key), _hip.p(out), None, B, M, K, D, H * W, xbs, 0,
                       _hip.stream())

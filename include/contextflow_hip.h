@@ -137,6 +137,20 @@ int cf_gmm_logprob_levels(int n, const float* const* x, const float* const* a, c
                           const float* const* cst, const int* D, const int64_t* x_bstride, const float* ldM,
                           const float* ld1, float* out, void* ws, int B, int M, int K, cf_stream_t stream);
 
+/* Mixtures whose context shifts are embedding lookups (model.py:157,162; gaussian.py:142-158): a sample's parameters are
+ * one of Um x Us sets - means mG + shift[km] (rounded once, as `self.mG + cond_mean`), scales softplus(sG + shift[ks]).
+ * With the samples bucketed by (ks, km) the 128 samples of a workgroup share their rows: the register-tiled kernel of
+ * cf_gmm_logprob with gathered x rows (7x the per-sample form of cf_gmm_ctx_logprob_tab at saturating batches).
+ * x: B rows of D floats (D = channels x pixels); a_tab (Us, M*K, D) = 1/sigma; nm_tab (Um, M*K, D) = -(mu + shift);
+ * cst_tab (Us, M*K); key_s (B) int32: scale key per sample; order (B) int32: sample indices grouped by (ks, km);
+ * tiles (T, 4) int32 rows [ks, km, first position in order, count <= 128 (0 = unused tile)].
+ * out[b,m] (+)= logsumexp_k(cst_tab[key_s[b]] - 0.5 sum_d ((x + nm) a)^2).  16 < M*K <= 256, 80 % K == 0, D % 4 == 0,
+ * x_bstride % 4 == 0, 16-byte aligned x / tables / tiles.  ws: cf_gmm_keyed_ws_bytes(T, B, M, K, D) bytes.              */
+int64_t cf_gmm_keyed_ws_bytes(int T, int B, int M, int K, int D);
+int cf_gmm_logprob_keyed(const float* x, const float* a_tab, const float* nm_tab, const float* cst_tab, const int* key_s,
+                         const int* tiles, const int* order, float* out, void* ws, int T, int B, int M, int K, int D,
+                         int64_t x_bstride, int accumulate, cf_stream_t stream);
+
 /* q[b, m*K+k] = sum_d ((x[b,d] + nm)*a)^2 only (B x M*K, dense): the backward pass rebuilds the responsibilities
  * softmax_k(cst - q/2) from it.                                                                        */
 int cf_gmm_quad(const float* x, const float* a, const float* nm, float* q, int B, int M, int K, int D,

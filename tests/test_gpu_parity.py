@@ -179,6 +179,53 @@ def test_gmm_levels_entry_equals_the_chain_of_calls(L, B, with_ldM):
     assert not gmm_levels_ok([(levels[0][0][:, 1:], levels[0][1])])          # misaligned / wrong width: refused, not copied
 
 
+@pytest.mark.parametrize("B,contexts", [(5000, [15, 5]), (700, [3, 2]), (129, [1, 1])])
+def test_keyed_mixture_kernel_against_the_formula_and_the_per_sample_kernel(L, B, contexts):
+    """Context-shifted mixtures with embedding-lookup shifts at batches with many samples per context value run the
+    register-tiled kernel over samples bucketed by key (cf_gmm_logprob_keyed): against gaussian.py:142-158 in fp64 and
+    against the per-sample table kernel it replaces there; empty buckets, ragged tiles, one bucket only."""
+    from contextflow_amd.layers.distributions import gaussian as G
+    from contextflow_amd.layers.context import CatEmbeddings, EyeSampling
+    torch.manual_seed(B)
+    D, H, W, M, K = 6, 8, 8, 10, 8
+    half = M * K * D
+    cn = torch.nn.Sequential(CatEmbeddings(contexts, 2 * half // len(contexts), stack=False, init="zeros"), EyeSampling())
+    cn.C = 2 * half
+    dist = G.GaussianMixtureDistribution((D, H, W), mixtures=M, components=K, contextflow=True, context_net=cn)
+    with torch.no_grad():
+        dist.mG.mul_(0.5); dist.sG.copy_(0.5 * torch.randn_like(dist.sG) + 0.5)
+        for e in dist.context_net[0]._embeddings:
+            e.weight.copy_(0.3 * torch.randn_like(e.weight))
+    dist = dist.to(DEV)
+    x = torch.randn(B, D, H, W, device=DEV)
+    context = torch.stack([torch.randint(0, k, (B,)) for k in contexts], 1)
+    if contexts[0] > 3:
+        context[context[:, 0] == 2, 0] = 3                                   # an empty bucket
+    context = context.to(DEV)
+    with torch.no_grad():
+        got = dist.log_prob(x, context)
+        assert G._bucket_cache[0] is not None and G._bucket_cache[0][0] is context, "the keyed path did not run"
+        keep, G.KEYED_MIN_PER_KEY = G.KEYED_MIN_PER_KEY, 1 << 30
+        try:
+            per_sample = dist.log_prob(x, context)
+        finally:
+            G.KEYED_MIN_PER_KEY = keep
+        c, _ = dist.context_net(context)
+    c = c.double().cpu().view(B, 2, M, K, D, 1, 1)
+    mu = dist.mG.double().cpu().unsqueeze(0) + c[:, 0]
+    sig = torch.nn.functional.softplus(dist.sG.double().cpu().unsqueeze(0) + c[:, 1])
+    lp = (-0.5 * ((x.double().cpu().view(B, 1, 1, D, H, W) - mu) / sig) ** 2 - torch.log(sig) - 0.5 * math.log(2 * math.pi)).flatten(3).sum(-1)
+    ref = torch.logsumexp(lp + torch.log_softmax(dist.wG.double().cpu(), -1), -1)
+    scale = ref.abs().max().item()
+    assert (got.cpu().double() - ref).abs().max().item() < 2e-6 * scale
+    assert (got - per_sample).abs().max().item() < 2e-6 * scale
+    # a new context tensor (other values, possibly the recycled storage) is bucketed afresh
+    context2 = context.flip(0).clone()
+    with torch.no_grad():
+        got2 = dist.log_prob(x.flip(0).contiguous(), context2)
+    assert torch.equal(got2, got.flip(0)) or (got2 - got.flip(0)).abs().max().item() < 2e-6 * scale
+
+
 def test_preprocessing(L):
     t, _ = unit("normalize")
     n = L.Normalization(translation=1e-4, scale=1 / (1 - 2e-4)).to(DEV)
