@@ -164,6 +164,100 @@ __global__ __launch_bounds__(256) void k_actnorm_ctx(const float* __restrict__ x
     for (int e = tid; e < C * HW; e += 256) { const int c = e / HW; zb[e] = (xb[e] - tb[c]) * sb[c]; }
 }
 
+// Conv1x1 and ActNorm of a specialist step in ONE pass over the sample (evaluation): z = (W_b x - t_b) exp(-logs_b) with
+// W_b as in k_conv1x1_ctx (m1 = Conv1x1.CN(c), (B, C*C)) and t_b / logs_b as in k_actnorm_ctx (m2 = ActNorm.CN(c'), (B, 2C)).
+// SQ: x is the un-squeezed (C/4, 2H, 2W) sample and Squeeze((2,2)) (squeeze.py:10-11) is folded into the staging reads.
+//   ldj[b] (+)= H W (sum diag m1 + lad[0]) + sum_c logs_b + cadd       lad: log|det NN| (device scalar) or NULL
+// One workgroup per sample, as the two kernels it replaces: one read of x, one write of z instead of two of each (+ the
+// Squeeze copy), no intermediate tensor.
+template <bool SQ>
+__global__ __launch_bounds__(256) void k_affine_ctx(const float* __restrict__ x, const float* __restrict__ m1,
+                                                    const float* __restrict__ Wm, const float* __restrict__ m2,
+                                                    const float* __restrict__ t, const float* __restrict__ logs,
+                                                    const float* __restrict__ lad, float cadd, float* __restrict__ z,
+                                                    float* __restrict__ ldj, int C, int H, int W, int64_t xbs, int accumulate) {
+    extern __shared__ __align__(16) float dyn[];
+    const int CP = conv1x1_ctx_cp(C), HW = H * W;
+    float* Wt = dyn;                                  // Wt[i][o] = W_b[o][i], row stride CP
+    float* xs = dyn + C * CP;                         // [C][HW]
+    float* scr = xs + C * HW;                         // [4]
+    float* tb = scr + 4;                              // [C]  t_b
+    float* sb = tb + C;                               // [C]  exp(-logs_b)
+    float* ms = sb + C;                               // [C*C] this sample's Conv1x1.CN(c), staged before the transposed read
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (int64_t)b * xbs;
+    stage_copy(ms, m1 + (int64_t)b * C * C, C * C, tid);
+    float dsum = 0.f;
+    if (tid < C) {
+        float tv = m2[(int64_t)b * 2 * C + tid], lv = m2[(int64_t)b * 2 * C + C + tid];
+        if (t != nullptr) { tv += t[tid]; lv += logs[tid]; }
+        tb[tid] = tv; sb[tid] = expf(-lv);
+        dsum = lv;                                    // joins the block sum below with weight 1 (the diagonal gets H W)
+    }
+    if constexpr (!SQ) {
+        stage_copy(xs, xb, C * HW, tid);              // xs is 16-byte aligned: C * CP is a multiple of 4
+    } else {
+        for (int e0 = tid; e0 < C * HW; e0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = min(e0 + k * 256, C * HW - 1), c = e / HW, p = e - c * HW, yy = p / W, xx = p - yy * W;
+                v[k] = xb[(c >> 2) * 4 * HW + (2 * yy + ((c >> 1) & 1)) * 2 * W + 2 * xx + (c & 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (e0 + k * 256 < C * HW) xs[e0 + k * 256] = v[k];
+        }
+    }
+    __syncthreads();
+    const float hw = (float)HW;
+    for (int e0 = tid; e0 < CP * C; e0 += 8 * 256) {
+        float wm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wm[k] = Wm != nullptr ? Wm[min(e0 + k * 256, C * C - 1)] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + k * 256;
+            if (e < CP * C) {
+                const int o = e / C, i = e - o * C;
+                float w = 0.f;
+                if (o < C) {
+                    const float v = ms[e];
+                    w = o > i ? v : (o == i ? expf(v) : 0.f);
+                    if (o == i) dsum = fmaf(hw, v, dsum);
+                    if (Wm != nullptr) w += wm[k] - (o == i ? 1.f : 0.f);
+                }
+                Wt[i * CP + o] = w;
+            }
+        }
+    }
+    dsum = cf_block_sum<4>(dsum, scr);                // also the barrier that publishes Wt
+    if (tid == 0) {
+        const float v = dsum + (lad != nullptr ? hw * lad[0] : 0.f) + cadd;
+        ldj[b] = accumulate ? ldj[b] + v : v;
+    }
+    float* zb = z + (int64_t)b * C * HW;
+    const int nob = CP >> 3;
+    for (int e = tid; e < nob * HW; e += 256) {
+        const int ob = e / HW, p = e - ob * HW, o0 = ob * 8;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int i = 0; i < C; ++i) {
+            const float xv = xs[i * HW + p];
+            const float4 w0 = *reinterpret_cast<const float4*>(&Wt[i * CP + o0]);
+            const float4 w1 = *reinterpret_cast<const float4*>(&Wt[i * CP + o0 + 4]);
+            acc[0] = fmaf(w0.x, xv, acc[0]); acc[1] = fmaf(w0.y, xv, acc[1]);
+            acc[2] = fmaf(w0.z, xv, acc[2]); acc[3] = fmaf(w0.w, xv, acc[3]);
+            acc[4] = fmaf(w1.x, xv, acc[4]); acc[5] = fmaf(w1.y, xv, acc[5]);
+            acc[6] = fmaf(w1.z, xv, acc[6]); acc[7] = fmaf(w1.w, xv, acc[7]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (o0 + k < C) zb[(int64_t)(o0 + k) * HW + p] = (acc[k] - tb[o0 + k]) * sb[o0 + k];
+    }
+}
+
 // h[b, c, p] = act(h[b, c, p] + bias[b, c])      (the CN(c) term of the coupling net, coupling.py:44-47)
 __global__ __launch_bounds__(256) void k_add_sample_bias(float* __restrict__ h, const float* __restrict__ bias,
                                                          int HW, int64_t total, int relu) {
@@ -732,6 +826,25 @@ int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, fl
         if (int rc_ = cf_raise_dynamic_lds((const void*)k_conv1x1_ctx, 160 * 1024, raised, __func__)) return rc_;
     }
     k_conv1x1_ctx<<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, m, Wm, z, ldj, C, HW, x_bstride);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_affine_ctx_fwd(const float* x, const float* m1, const float* Wm, const float* m2, const float* t, const float* logs,
+                      const float* lad, float cadd, float* z, float* ldj, int B, int C, int H, int W, int64_t x_bstride,
+                      int in_squeeze, int accumulate, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && m1 && m2 && z && ldj && B >= 0 && C > 0 && C <= 256 && H > 0 && W > 0 && ((t == nullptr) == (logs == nullptr)) &&
+               x_bstride >= (int64_t)C * H * W && (!in_squeeze || C % 4 == 0));
+    const size_t lds = (size_t)(C * conv1x1_ctx_cp(C) + C * H * W + 4 + 2 * C + C * C) * sizeof(float);
+    if (lds > 160 * 1024) { cf_set_error("cf_affine_ctx_fwd: C=%d, H*W=%d need %zu B of LDS", C, H * W, lds); return CF_ERR_UNSUPPORTED; }
+    if (lds > 64 * 1024) {
+        static std::atomic<uint64_t> raised0{0}, raised1{0};
+        if (int rc_ = in_squeeze ? cf_raise_dynamic_lds((const void*)k_affine_ctx<true>, 160 * 1024, raised1, __func__)
+                                 : cf_raise_dynamic_lds((const void*)k_affine_ctx<false>, 160 * 1024, raised0, __func__)) return rc_;
+    }
+    if (in_squeeze) k_affine_ctx<true><<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, m1, Wm, m2, t, logs, lad, cadd, z, ldj, C, H, W, x_bstride, accumulate);
+    else k_affine_ctx<false><<<dim3(B), dim3(256), lds, cf_s(stream)>>>(x, m1, Wm, m2, t, logs, lad, cadd, z, ldj, C, H, W, x_bstride, accumulate);
     CF_LAUNCH_CHECK();
     return 0;
 }

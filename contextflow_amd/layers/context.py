@@ -82,6 +82,31 @@ class UniformCatDequantization(nn.Module):
         ldj = (self.ldj_per_dim * width).sum(-1).repeat(B)           # dequantize.py:62 (num_dims = width)
         return z, ldj
 
+    def encode(self, context, card=None):
+        """OneHotEncoder / EyeEncoder + this layer in one launch from the integer context (B, n): the one-hot code
+        (card: the cardinalities, int64 on the device) or the context itself (card None) never exists as a tensor.
+        Returns (z, ldj) as forward does - ldj as a stride-0 view of the constant (`const_logp` is its host value).
+        An out-of-range code gives an all-zero one-hot block (torch's one_hot would raise)."""
+        dev = self.qbins.device
+        B, width = context.shape[0], self.D
+        u = self.fixed_noise if self.fixed_noise is not None else torch.rand((B, width), device=dev, dtype=torch.float32)
+        z = torch.empty(B, width, device=dev, dtype=torch.float32)
+        code = context.to(device=dev, dtype=torch.int64).contiguous()
+        _hip.call("cf_ctx_encode", _hip.p(code), _hip.p(_hip.f32(u)), _hip.p(self.qbins), _hip.p(card), _hip.p(z), B,
+                  code.shape[1], width, 0 if card is None else 1, _hip.stream())
+        lc = getattr(self, "_lc", None)
+        if lc is None or lc.device != dev:
+            lc = self._lc = (self.ldj_per_dim * width).sum(-1).reshape(1)
+        return z, lc.expand(B)
+
+    @property
+    def const_logp(self):
+        """Host value of the (sample-independent) log-density term, dequantize.py:62."""
+        v = getattr(self, "_lc_host", None)
+        if v is None:
+            v = self._lc_host = float((self.ldj_per_dim.detach().cpu() * self.D).sum())
+        return v
+
     def reverse(self, z, context=None):
         return (z * self.qbins).floor().clamp(min=0).minimum(self.qbins - 1).long()
 
@@ -255,3 +280,17 @@ class ContextEncoder(nn.Sequential):
         super().__init__(emb, encoder)
         self.C = sz
         self.contexts = contexts
+
+    @property
+    def const_logp(self):
+        """The encoder's log-density when it is the same constant for every sample (uniform dequantisation), else None."""
+        return self[1].const_logp if isinstance(self[1], UniformCatDequantization) else None
+
+    def forward(self, input):
+        emb, enc = self[0], self[1]
+        if isinstance(enc, UniformCatDequantization) and input.ndim == 2:
+            if isinstance(emb, OneHotEncoder):
+                return enc.encode(input, emb.cardinalities)
+            if isinstance(emb, EyeEncoder):
+                return enc.encode(input)
+        return super().forward(input)

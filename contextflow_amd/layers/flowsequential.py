@@ -473,6 +473,10 @@ class FlowSequential(nn.Module):
                     z, logp = g(input)
                     return z.clone(), logp.clone()       # the graph's static outputs are overwritten by the next replay
                 return self._forward_fused(input, context)
+            if self.fused and self._specialist():
+                from . import specialist
+                if specialist.supported(self):       # grouped evaluation plan of the specialist conv flows
+                    return specialist.forward_eval(self, input, context)
             return self._forward_layers(input, context)
 
     AUTO_GRAPH_AFTER = 2

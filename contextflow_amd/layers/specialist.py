@@ -1,0 +1,205 @@
+"""Evaluation plan of the specialist (context-conditioned) conv flows: `create_model(generalist=False)`, model.py:117-162.
+
+Layer by layer, a specialist step costs three context encoders, five CN Linears, the per-sample Conv1x1, the per-sample
+ActNorm, the coupling step and a dozen tiny bookkeeping kernels (`profiles/r3_spec_fwd_b32768_kstats.txt`).  Here the
+layer list is grouped the way `FlowSequential._build_plan` groups the generalist's:
+
+  pre-processing          Dequantization -> Normalization x2 -> LogitTransform [-> Augment]: cf_preprocess_rng_fwd
+  [Squeeze ->] Conv1x1(c) -> ActNorm(c')    one pass over the sample: cf_affine_ctx_fwd (Squeeze folded into its reads)
+  Coupling(c'')           the fused step kernel with the CN(c'') bias, its packed weights kept while the parameters are
+                          unchanged, the log-det accumulated in place
+  everything else         the layer's own forward
+
+and the per-sample log-dets accumulate in ONE (B,) buffer inside the kernels instead of a (B, M) add per layer.
+Evaluation only (no tape); `FlowSequential.forward` uses it under no_grad and falls back to the layer loop when a
+model does not have this shape."""
+import math
+
+import torch
+
+from . import _hip
+from .actnorm import ActNorm
+from .conv1x1 import Conv1x1, slogdet_inverse
+from .coupling import Coupling
+from .dequantize import Dequantization
+from .distributions.gaussian import StandardNormal
+from .distributions.uniform import UniformDistribution
+from .augment import Augment
+from .normalize import Normalization
+from .squeeze import Squeeze
+from .transforms import LogitTransform
+
+
+def _const_logp(net):
+    """Host constant of an encoder's log-density, or None when it depends on the sample."""
+    return getattr(net, "const_logp", None)
+
+
+class _Acc:
+    """Running log-dets: ld1 (B,) per-sample terms, ldM (B, M) per-mixture terms; kernels accumulate into ld1 in place."""
+
+    def __init__(self, B, dev):
+        self.B, self.dev, self.ld1, self.ldM, self.cadd = B, dev, None, None, 0.0
+
+    def add(self, ldj):
+        if ldj.dim() == 2:
+            self.ldM = ldj if self.ldM is None else self.ldM + ldj
+            return
+        if ldj.dim() == 0:
+            ldj = ldj.reshape(1)
+        if self.ld1 is None:         # the first term becomes the buffer the kernels accumulate into: never a view / a broadcast
+            self.ld1 = ldj.expand(self.B).clone() if (ldj.shape[0] != self.B or ldj.stride(0) == 0 or ldj._base is not None) else ldj
+        else:
+            self.ld1 += ldj
+
+    def buffer(self):
+        """(ld1 buffer, accumulate flag) for a kernel that assigns or accumulates its per-sample log-det."""
+        if self.ld1 is None:
+            self.ld1 = torch.empty(self.B, device=self.dev, dtype=torch.float32)
+            return self.ld1, 0
+        return self.ld1, 1
+
+    def zeroed(self):
+        if self.ld1 is None:
+            self.ld1 = torch.zeros(self.B, device=self.dev, dtype=torch.float32)
+        return self.ld1
+
+
+def _affine_ok(conv, act, shape):
+    return (isinstance(conv, Conv1x1) and isinstance(act, ActNorm) and bool(conv.context_net) and bool(act.context_net)
+            and len(shape) == 3 and conv.D == shape[0] and act.D == shape[0] and shape[0] <= 128
+            and (not act.contextflow or act.is_initialized()))
+
+
+def _coupling_ws(flow, cpl, C, H, W, dev):
+    """Packed weights of the coupling step (identity 1x1 / ActNorm in front), kept while the conditioner is unchanged."""
+    convs = (cpl.NN[0], cpl.NN[2], cpl.NN[4])
+    srcs = tuple(p for c in convs for p in (c.weight, c.bias))
+    ver = tuple(t._version for t in srcs) + tuple(t.data_ptr() for t in srcs) + (C, H, W, str(dev))
+    cache = flow.__dict__.setdefault("_spec_ws", {})
+    hit = cache.get(id(cpl))
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    f, pp = _hip.f32, _hip.p
+    eye = torch.eye(C, device=dev, dtype=torch.float32)
+    zero = torch.zeros(C, device=dev, dtype=torch.float32)
+    ws = torch.empty(_hip.lib().cf_flow_step_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+    _hip.call("cf_flow_step_prepare", pp(eye), pp(zero), pp(zero), pp(f(convs[0].weight.detach())), pp(f(convs[0].bias.detach())),
+              pp(f(convs[1].weight.detach())), pp(f(convs[1].bias.detach())), pp(f(convs[2].weight.detach())),
+              pp(f(convs[2].bias.detach())), pp(ws), C, H, W, _hip.stream())
+    cache[id(cpl)] = (ver, ws)
+    return ws
+
+
+def _lad(flow, conv, dev):
+    """log|det NN| of a frozen Conv1x1 (device scalar), kept while NN is unchanged."""
+    cache = flow.__dict__.setdefault("_spec_lad", {})
+    ver = (conv.NN._version, conv.NN.data_ptr(), str(dev))
+    hit = cache.get(id(conv))
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    lad, _ = slogdet_inverse(_hip.f32(conv.NN.detach()), False)
+    cache[id(conv)] = (ver, lad)
+    return lad
+
+
+def supported(flow):
+    """True when the plan below has something to fuse: a specialist model with at least one Conv1x1(c) -> ActNorm(c') pair."""
+    mods = flow.sequence_modules
+    return any(isinstance(m, Conv1x1) and m.context_net and i + 1 < len(mods) and isinstance(mods[i + 1], ActNorm)
+               and mods[i + 1].context_net for i, m in enumerate(mods))
+
+
+def forward_eval(flow, x, context):
+    """(z, logp (B, M)) of a specialist flow, evaluation.  Same results as FlowSequential._forward_layers to fp32 rounding
+    (the per-sample log-dets are summed in another order)."""
+    from .simple_vit import _linear
+    mods, n = flow.sequence_modules, len(flow.sequence_modules)
+    B, dev = x.shape[0], x.device
+    acc = _Acc(B, dev)
+    st, pp, f = _hip.stream(), _hip.p, _hip.f32
+    i = 0
+    while i < n:
+        m = mods[i]
+        shape = tuple(x.shape[1:])
+        # ---- pre-processing in one kernel, noise drawn inside it (as the generalist's plan does)
+        if (isinstance(m, Dequantization) and isinstance(m.dist, UniformDistribution) and i + 3 < n and len(shape) == 3
+                and isinstance(mods[i + 1], Normalization) and isinstance(mods[i + 2], Normalization)
+                and isinstance(mods[i + 3], LogitTransform) and m.dist.fixed_noise is None):
+            aug = mods[i + 4] if (i + 4 < n and isinstance(mods[i + 4], Augment) and isinstance(mods[i + 4].distribution, StandardNormal)
+                                  and mods[i + 4].split_dim == 1) else None
+            C, H, W = shape
+            N, ca = C * H * W, (aug.aug_size if aug is not None else 0)
+            if (aug is None or aug.distribution.fixed_noise is None) and N % 4 == 0 and (ca * H * W) % 4 == 0:
+                n1, n2 = mods[i + 1], mods[i + 2]
+                xin = f(x)
+                y = torch.empty(B, C + ca, H, W, device=dev, dtype=torch.float32)
+                cst = -N * math.log(n1._s) - N * math.log(n2._s)
+                ldp = torch.empty(B, device=dev, dtype=torch.float32)
+                nonce = flow._noise_nonce(dev)
+                _hip.call("cf_preprocess_rng_fwd", pp(xin), pp(y), pp(ldp), pp(nonce), flow._rng_key, B, N, ca * H * W,
+                          (C + ca) * H * W, n1._t, n1._s, n2._t, n2._s, cst, 0, st)
+                acc.add(ldp)
+                x = y
+                i += 5 if aug is not None else 4
+                continue
+        # ---- [Squeeze ->] Conv1x1(c) -> ActNorm(c')
+        sq = (isinstance(m, Squeeze) and tuple(m.p) == (2, 2) and len(shape) == 3 and shape[1] % 2 == 0 and shape[2] % 2 == 0)
+        j = i + 1 if sq else i
+        sshape = (shape[0] * 4, shape[1] // 2, shape[2] // 2) if sq else shape
+        if j + 1 < n and _affine_ok(mods[j], mods[j + 1], sshape):
+            conv, act = mods[j], mods[j + 1]
+            C, H, W = sshape
+            xv, xbs = _hip.bview(x)
+            c1, lp1 = conv.context_net(context)
+            c2, lp2 = act.context_net(context)
+            m1 = _linear(f(c1), conv.CN)                       # (B, C*C)
+            m2 = _linear(f(c2), act.CN)                        # (B, 2C)
+            cadd = 0.0
+            for net, lp in ((conv.context_net, lp1), (act.context_net, lp2)):
+                k = _const_logp(net)
+                if k is not None:
+                    cadd += k * float(H * W)
+                else:
+                    acc.add(lp * float(H * W))
+            Wm = f(conv.NN.detach()) if conv.contextflow else None
+            t = f(act.NN_t.detach()) if act.contextflow else None
+            logs = f(act.NN_logs.detach()) if act.contextflow else None
+            lad = _lad(flow, conv, dev) if conv.contextflow else None
+            z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+            buf, accum = acc.buffer()
+            _hip.call("cf_affine_ctx_fwd", pp(xv), pp(m1), pp(Wm), pp(m2), pp(t), pp(logs), pp(lad), cadd, pp(z), pp(buf), B, C, H, W,
+                      xbs, int(sq), accum, st)
+            x = z
+            i = j + 2
+            continue
+        # ---- Coupling(c''): the fused step kernel, CN bias on the conditioner output (contextflow)
+        if (type(m) is Coupling and m.context_net and m.contextflow and len(shape) == 3 and m._fused_ctx_ok(x)):
+            C, H, W = shape
+            c, lp = m.context_net(context)
+            a1 = _linear(f(c), m.CN[0], act=2)
+            a2 = _linear(a1, m.CN[2], act=2)
+            cn = _linear(a2, m.CN[4])
+            xv, xbs = _hip.bview(x)
+            ws = _coupling_ws(flow, m, C, H, W, dev)
+            z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+            _hip.call("cf_flow_step_fwd_ctx", pp(xv), pp(z), pp(acc.zeroed()), pp(ws), pp(cn), 1, B, C, H, W, xbs, st)
+            k = _const_logp(m.context_net)
+            if k is not None:
+                acc.cadd += k * float(H * W)
+            else:
+                acc.add(lp * float(H * W))
+            x = z
+            i += 1
+            continue
+        x, ldj = m(x, context)
+        acc.add(ldj)
+        i += 1
+    logp = flow.dist.log_prob(x, context)
+    if acc.ldM is not None:
+        logp = logp + acc.ldM
+    if acc.ld1 is not None:
+        logp = logp + (acc.ld1 + acc.cadd if acc.cadd else acc.ld1).unsqueeze(-1)
+    elif acc.cadd:
+        logp = logp + acc.cadd
+    return x, logp

@@ -425,6 +425,15 @@ int cf_ctx_encode(const int64_t* ctx, const float* u, const float* qbins, const 
  * [+ Wm - I when Wm != NULL: contextflow]; z[b] = W_b x[b]; ldj[b] = H*W*sum(diag m).  C <= 64.                */
 int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, float* ldj, int B, int C, int HW,
                    int64_t x_bstride, cf_stream_t stream);
+/* Conv1x1 + ActNorm of a specialist step in one pass (evaluation; conv1x1.py:34-50, actnorm.py:40-60): m1 (B, C*C) =
+ * Conv1x1.CN(c), m2 (B, 2C) = ActNorm.CN(c'); Wm (C, C) / t, logs (C): the shared parameters under contextflow, else NULL.
+ *   z[b] = (W_b x[b] - t_b) exp(-logs_b);   ldj[b] (+)= H W (sum diag m1[b] + lad[0]) + sum_c logs_b + cadd
+ * (the two layers' own log-dets, reference quirks included: H W log|det NN| for Conv1x1, no H W factor for ActNorm).
+ * lad: device scalar log|det NN| or NULL; cadd: a host constant (the encoders' constant log-densities).
+ * in_squeeze != 0: x is the un-squeezed (B, C/4, 2H, 2W) tensor, Squeeze((2,2)) folded into the reads.                */
+int cf_affine_ctx_fwd(const float* x, const float* m1, const float* Wm, const float* m2, const float* t, const float* logs,
+                      const float* lad, float cadd, float* z, float* ldj, int B, int C, int H, int W, int64_t x_bstride,
+                      int in_squeeze, int accumulate, cf_stream_t stream);
 /* ActNorm with a context net (actnorm.py:40-60): m (B, 2C) = CN(c) = [t_b | logs_b] (+ t, logs when non-NULL:
  * contextflow); z = (x - t_b) exp(-logs_b); ldj[b] = sum_c logs_b.                                             */
 int cf_actnorm_ctx(const float* x, const float* m, const float* t, const float* logs, float* z, float* ldj, int B, int C,
