@@ -335,11 +335,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CF_G16W_MINW
 #define CF_G16W_MINW 4
 #endif
-template <class G, bool SQ, bool DBG = false, bool DUMP = false>
+// CTX: per-sample bias of the specialist coupling (see conditioner_net): 1 sb (B, C) on the conditioner output, 2 sb (B, 2C)
+// before the first ReLU.
+template <class G, bool SQ, bool DBG = false, bool DUMP = false, int CTX = 0>
 __global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
                                                                   float* __restrict__ ldj_acc, const float* __restrict__ ws,
-                                                                  int B, int64_t xbs, float* __restrict__ dbg, StepTape tp) {
+                                                                  int B, int64_t xbs, float* __restrict__ dbg, StepTape tp,
+                                                                  const float* __restrict__ sb = nullptr) {
     static_assert(G::SMALL, "16x16 images, one sample per workgroup, C <= 16");
+    static_assert(CTX == 0 || !G::HID16, "the per-sample bias is wired into the 32-row conditioner phases (C = 16)");
     constexpr int C = G::C, W = 16, H = 16, PIX = 256, HALF = G::HALF, HID = G::HID, PTW = G::PTW;
     constexpr int XI = C * PTW / 8;
     extern __shared__ __align__(16) float lds[];
@@ -411,7 +415,11 @@ __global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16
 #pragma unroll
         for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q]; }
         f32x16 unused[G::RT03][PTW];
-        conditioner_net<G, 0, DUMP, 2>(unused, lds, ws, pix, pin, lane, tid, DBG ? dbg : nullptr, dbg_cols, tile, nullptr, nullptr, tp, B);
+        int soff[PTW];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) soff[q] = tile * HID;
+        conditioner_net<G, CTX == 2 ? 2 : 0, DUMP, 2>(unused, lds, ws, pix, pin, lane, tid, DBG ? dbg : nullptr, dbg_cols, tile,
+                                                      CTX == 2 ? sb : nullptr, soff, tp, B);
     } else {
         f32x4 a1[4];
         {
@@ -506,6 +514,15 @@ __global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16
                 }
         }
     }
+    if constexpr (CTX == 1) {            // h = NN(x0) + CN(c): the sample's bias per packed row (coupling.py:39-42)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = chan_of_row16<G>(4 * lg + r);
+            const float add = ch >= 0 ? sb[(int64_t)tile * C + ch] : 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc3[ct][r] += add;
+        }
+    }
     // ================= affine map and log-det   (coupling.py:52-66)
     float lsum = 0.f;
 #pragma unroll
@@ -536,10 +553,10 @@ __global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16
     if (tid == 0 && tile < B) ldj_acc[tile] += ws[0] + ((Y0[0] + Y0[64]) + (Y0[128] + Y0[192]));
 }
 
-template <class G, bool SQ, bool DBG = false, bool DUMP = false>
+template <class G, bool SQ, bool DBG = false, bool DUMP = false, int CTX = 0>
 int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s,
-                      float* dbg = nullptr, StepTape tp = kNoTape) {
-    k_flow_step_small<G, SQ, DBG, DUMP><<<dim3(B), dim3(256), (size_t)G::LDS_FLOATS * sizeof(float), s>>>(x, z, ldj, ws, B, xbs, dbg, tp);
+                      float* dbg = nullptr, StepTape tp = kNoTape, const float* sb = nullptr) {
+    k_flow_step_small<G, SQ, DBG, DUMP, CTX><<<dim3(B), dim3(256), (size_t)G::LDS_FLOATS * sizeof(float), s>>>(x, z, ldj, ws, B, xbs, dbg, tp, sb);
     return 0;
 }
 
@@ -1427,7 +1444,10 @@ int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* w
     const bool wino = !direct_conv_only() && !keep_direct;      // as cf_flow_step_fwd: Winograd form of the 3x3 (16x16 always, 8x8 / 4x4 at saturating batches)
     switch (shape_id(C, H, W)) {
         case 0: CF_STEPC(G8); break;
-        case 1: if (wino) CF_STEPC(G16w); else CF_STEPC(G16); break;
+        case 1: if (!wino) CF_STEPC(G16);      // one sample per workgroup, as the generalist's 16x16 level (k_flow_step_small)
+                else rc = mode == 1 ? launch_step_small<G16w, false, false, false, 1>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, kNoTape, sbias)
+                                    : launch_step_small<G16w, false, false, false, 2>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), nullptr, kNoTape, sbias);
+                break;
         case 2: if (wino && B >= 256 * G32::SPW) CF_STEPC(G32w); else CF_STEPC(G32); break;
         case 3: if (wino && B >= 256 * G64w2::SPW) CF_STEPC(G64w2); else CF_STEPC(G64); break;
         default: cf_set_error("cf_flow_step_fwd_ctx: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
