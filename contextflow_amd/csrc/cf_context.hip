@@ -258,6 +258,150 @@ __global__ __launch_bounds__(256) void k_affine_ctx(const float* __restrict__ x,
     }
 }
 
+// The same on the matrix pipe for the three levels of the image flows, ONE WAVE per sample and no LDS: per sample the
+// product is (C x C) (C x HW) = 64 v_mfma_f32_16x16x4_f32 whatever the level, and every operand is read from global memory
+// exactly once, in the MFMA's own register layout:
+//   A (W_b, 16 rows x 4 k per instruction): lane (n = lane & 15, kk = lane >> 4) loads the float4 m1[o = 16 rt + n][16 g + 4 kk ..]
+//     and uses its 4 values for 4 successive k-steps - the k order of a product is free as long as A and B agree;
+//   B (x): for those k-steps lane (n, kk) needs x[i = 16 g + 4 kk + e][pixel of column n].  With 64 pixels or more, column n of
+//     column tile j IS pixel 4 n + j: one float4 of x serves the four column tiles, and the four results of a row come
+//     back as one float4 store.  On 4x4 images (16 pixels) the column is the pixel: dword loads, 64-byte runs.
+//   SQ: i = 4 q + 2 dy + dx with q = 4 g + kk, e = 2 dy + dx - the four k-steps of a lane are the four phases of ONE channel
+//     of the un-squeezed tensor: rows 2 y, 2 y + 1, 8 (2) consecutive floats each.
+// tril / exp(diag) / + NN - I are applied to the A fragments in registers; t_b, logs_b come as float4 per (row tile, kk).
+template <int C, int W, bool SQ>
+__global__ __launch_bounds__(256) void k_affine_ctx_wave(const float* __restrict__ x, const float* __restrict__ m1,
+                                                         const float* __restrict__ Wm, const float* __restrict__ m2,
+                                                         const float* __restrict__ t, const float* __restrict__ logs,
+                                                         const float* __restrict__ lad, float cadd, float* __restrict__ z,
+                                                         float* __restrict__ ldj, int B, int64_t xbs, int accumulate) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int HW = W * W, RT = C / 16, NG = C / 16, WIDE = HW >= 64, NT = WIDE ? HW / 64 : 1;
+    const int lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;                                // a whole wave: the kernel has no barrier
+    const float* mb = m1 + (int64_t)b * C * C;
+    const float* xb = x + (int64_t)b * xbs;
+    // ---- A fragments.  W_b is block lower triangular on the 16 x 16 grid of fragments: blocks above the diagonal hold NN alone
+    // (never read from m1), blocks below m1 + NN, the diagonal blocks the element-wise tril / exp(diag) / - I.
+    float4 a[RT][NG];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            a[rt][g] = g <= rt ? *reinterpret_cast<const float4*>(mb + (16 * rt + n) * C + 16 * g + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float dsum = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int o = 16 * rt + n, i0 = 16 * g + 4 * kk;
+            float v[4] = {a[rt][g].x, a[rt][g].y, a[rt][g].z, a[rt][g].w};
+            if (g == rt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e;
+                    const float ex = expf(v[e]) - (Wm != nullptr ? 1.f : 0.f);
+                    if (o == i) dsum += v[e];
+                    v[e] = o > i ? v[e] : (o == i ? ex : 0.f);
+                }
+            }
+            if (Wm != nullptr) {
+                const float4 wv = *reinterpret_cast<const float4*>(Wm + o * C + i0);
+                v[0] += wv.x; v[1] += wv.y; v[2] += wv.z; v[3] += wv.w;
+            }
+            a[rt][g] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    // ---- the product
+    f32x4 acc[RT][NT][WIDE ? 4 : 1];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int j = 0; j < (WIDE ? 4 : 1); ++j) acc[rt][T][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float xv[4][WIDE ? 4 : 1];                 // [k-step e][column tile j]
+            if constexpr (WIDE) {
+                if constexpr (!SQ) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 v = *reinterpret_cast<const float4*>(xb + (16 * g + 4 * kk + e) * HW + 64 * T + 4 * n);
+                        xv[e][0] = v.x; xv[e][1] = v.y; xv[e][2] = v.z; xv[e][3] = v.w;
+                    }
+                } else {
+                    const int p0 = 64 * T + 4 * n, yy = p0 / W, xx = p0 - yy * W;       // 4 pixels of one image row (W >= 4)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const float* row = xb + (4 * g + kk) * 4 * HW + (2 * yy + dy) * 2 * W + 2 * xx;
+                        const float4 u0 = *reinterpret_cast<const float4*>(row), u1 = *reinterpret_cast<const float4*>(row + 4);
+                        xv[2 * dy][0] = u0.x; xv[2 * dy][1] = u0.z; xv[2 * dy][2] = u1.x; xv[2 * dy][3] = u1.z;
+                        xv[2 * dy + 1][0] = u0.y; xv[2 * dy + 1][1] = u0.w; xv[2 * dy + 1][2] = u1.y; xv[2 * dy + 1][3] = u1.w;
+                    }
+                }
+            } else {
+                if constexpr (!SQ) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[e][0] = xb[(16 * g + 4 * kk + e) * HW + n];
+                } else {
+                    const int yy = n / W, xx = n - yy * W;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const float2 u = *reinterpret_cast<const float2*>(xb + (4 * g + kk) * 4 * HW + (2 * yy + dy) * 2 * W + 2 * xx);
+                        xv[2 * dy][0] = u.x; xv[2 * dy + 1][0] = u.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float av[4] = {a[rt][g].x, a[rt][g].y, a[rt][g].z, a[rt][g].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < (WIDE ? 4 : 1); ++j)
+                        acc[rt][T][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], xv[e][j], acc[rt][T][j], 0, 0, 0);
+            }
+        }
+    // ---- ActNorm epilogue: rows o = 16 rt + 4 kk + r of this lane
+    float* zb = z + (int64_t)b * C * HW;
+    float lsum = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int o0 = 16 * rt + 4 * kk;
+        float4 tv = *reinterpret_cast<const float4*>(m2 + (int64_t)b * 2 * C + o0);
+        float4 lv = *reinterpret_cast<const float4*>(m2 + (int64_t)b * 2 * C + C + o0);
+        if (t != nullptr) {
+            const float4 t0 = *reinterpret_cast<const float4*>(t + o0), l0 = *reinterpret_cast<const float4*>(logs + o0);
+            tv.x += t0.x; tv.y += t0.y; tv.z += t0.z; tv.w += t0.w;
+            lv.x += l0.x; lv.y += l0.y; lv.z += l0.z; lv.w += l0.w;
+        }
+        if (n == 0) lsum += (lv.x + lv.y) + (lv.z + lv.w);
+        const float tt[4] = {tv.x, tv.y, tv.z, tv.w};
+        const float ss[4] = {expf(-lv.x), expf(-lv.y), expf(-lv.z), expf(-lv.w)};
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (WIDE) {
+                    float4 o4;
+                    o4.x = (acc[rt][T][0][r] - tt[r]) * ss[r]; o4.y = (acc[rt][T][1][r] - tt[r]) * ss[r];
+                    o4.z = (acc[rt][T][2][r] - tt[r]) * ss[r]; o4.w = (acc[rt][T][3][r] - tt[r]) * ss[r];
+                    *reinterpret_cast<float4*>(zb + (o0 + r) * HW + 64 * T + 4 * n) = o4;
+                } else {
+                    zb[(o0 + r) * HW + n] = (acc[rt][T][0][r] - tt[r]) * ss[r];
+                }
+            }
+    }
+    const float tot = cf_wave_sum(fmaf((float)HW, dsum, lsum));
+    if (lane == 0) {
+        const float v = tot + (lad != nullptr ? (float)HW * lad[0] : 0.f) + cadd;
+        ldj[b] = accumulate ? ldj[b] + v : v;
+    }
+}
+
 // h[b, c, p] = act(h[b, c, p] + bias[b, c])      (the CN(c) term of the coupling net, coupling.py:44-47)
 __global__ __launch_bounds__(256) void k_add_sample_bias(float* __restrict__ h, const float* __restrict__ bias,
                                                          int HW, int64_t total, int relu) {
@@ -836,6 +980,19 @@ int cf_affine_ctx_fwd(const float* x, const float* m1, const float* Wm, const fl
     if (B == 0) return 0;
     CF_REQUIRE(x && m1 && m2 && z && ldj && B >= 0 && C > 0 && C <= 256 && H > 0 && W > 0 && ((t == nullptr) == (logs == nullptr)) &&
                x_bstride >= (int64_t)C * H * W && (!in_squeeze || C % 4 == 0));
+    // the image flows' three levels: one wave per sample on the matrix pipe, operands straight from global memory
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(m1) | reinterpret_cast<uintptr_t>(m2) |
+                      reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(Wm) | reinterpret_cast<uintptr_t>(t) |
+                      reinterpret_cast<uintptr_t>(logs)) & 15) == 0 && x_bstride % 4 == 0;
+    if (al && H == W && ((C == 16 && W == 16) || (C == 32 && W == 8) || (C == 64 && W == 4))) {
+        const dim3 grid((B + 3) / 4), blk(256);
+#define CF_AFF(CC, WW) do { if (in_squeeze) k_affine_ctx_wave<CC, WW, true><<<grid, blk, 0, cf_s(stream)>>>(x, m1, Wm, m2, t, logs, lad, cadd, z, ldj, B, x_bstride, accumulate); \
+                            else k_affine_ctx_wave<CC, WW, false><<<grid, blk, 0, cf_s(stream)>>>(x, m1, Wm, m2, t, logs, lad, cadd, z, ldj, B, x_bstride, accumulate); } while (0)
+        if (C == 16) CF_AFF(16, 16); else if (C == 32) CF_AFF(32, 8); else CF_AFF(64, 4);
+#undef CF_AFF
+        CF_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = (size_t)(C * conv1x1_ctx_cp(C) + C * H * W + 4 + 2 * C + C * C) * sizeof(float);
     if (lds > 160 * 1024) { cf_set_error("cf_affine_ctx_fwd: C=%d, H*W=%d need %zu B of LDS", C, H * W, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {
