@@ -540,6 +540,125 @@ __global__ __launch_bounds__(256) void k_gmm_sample(const float* __restrict__ mG
 }
 
 // D-split heuristic: enough workgroups to cover the chip (~2 per CU), chunks stay multiples of DC
+// ---- parameter sums of the mixture backward: S0[mk] = sum_b r[b][mk], S1[mk][d] = sum_b r[b][mk] x[b][d],
+// S2[mk][d] = sum_b r[b][mk] x[b][d]^2 - one (MK x B)(B x D) product with two right-hand sides.  MK = 80 rows are five
+// 16-row tiles of v_mfma_f32_16x16x4_f32 exactly (no padding rows); a WAVE owns 32 columns of d and one slice of the batch:
+// 20 accumulator tiles (5 row tiles x 2 column tiles x {x, x^2}) in 80 registers, per k-step (4 samples) 5 A and 2 B
+// dword loads straight from global memory in the MFMA layout for 20 MFMAs - no LDS, no barrier.  Partials per batch slice
+// are summed in slice order by k_gmm_sums_reduce (no float atomics).  (cf_linear_wgrad, built for K, N <= a few hundred,
+// took 13 launches over the 1536 columns and re-read r in each: 1.45 ms per training step for the three priors.)
+constexpr int GS_RT = 5;             // row tiles: MK = 80
+template <int RT>
+__global__ __launch_bounds__(256) void k_gmm_sums(const float* __restrict__ x, const float* __restrict__ r,
+                                                  float* __restrict__ part, int B, int D, int64_t xbs, int nsp, int spb) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int MK = 16 * RT;
+    const int lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);           // (column block of 32, batch slice)
+    const int nct = D / 32;
+    if (unit >= nct * nsp) return;                                   // whole wave
+    const int cb = unit % nct, sp = unit / nct;
+    const int b0 = sp * spb, b1 = min(B, b0 + spb);
+    f32x4 acc[RT][2][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[rt][c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s0[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) s0[rt] = 0.f;
+    // uniform slice bases + 32-bit lane offsets that advance by a constant per k-step (4 samples): the loop's address
+    // arithmetic is two v_add - every VALU instruction here is time taken from the matrix pipe
+    const float* xs = x + (int64_t)b0 * xbs + 32 * cb;
+    const float* rsl = r + (int64_t)b0 * MK;
+    const int nb = b1 - b0, xstep = 4 * (int)xbs;
+    int xo = kk * (int)xbs + n, ro = kk * MK + n;
+    auto load = [&](float (&av)[RT], float (&bv)[2]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) av[rt] = rsl[ro + 16 * rt];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bv[c] = xs[xo + 16 * c];
+        xo += xstep; ro += 4 * MK;
+    };
+    auto mma = [&](const float (&av)[RT], const float (&bv)[2]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            s0[rt] += av[rt];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[rt][c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[c], acc[rt][c][0], 0, 0, 0);
+                acc[rt][c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[c] * bv[c], acc[rt][c][1], 0, 0, 0);
+            }
+        }
+    };
+    float a0[RT], x0[2], a1[RT], x1[2];
+    const int full = nb / 8;                                         // trips of two whole k-steps
+    if (full > 0) {
+        load(a0, x0);
+        for (int it = 0; it < full; ++it) {
+            load(a1, x1);
+            mma(a0, x0);
+            if (it + 1 < full) load(a0, x0);
+            mma(a1, x1);
+        }
+    }
+    for (int bb = 8 * full; bb < nb; bb += 4) {                      // ragged tail: samples past the slice contribute r = 0
+        const bool ok = bb + kk < nb;
+        const int rr = ok ? ro : n, xx = ok ? xo : n;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) { const float v = rsl[rr + 16 * rt]; a0[rt] = ok ? v : 0.f; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) x0[c] = xs[xx + 16 * c];
+        xo += xstep; ro += 4 * MK;
+        mma(a0, x0);
+    }
+    // partial layout per slice: [S1 (MK, D) | S2 (MK, D) | S0 (MK)]
+    float* ps = part + (int64_t)sp * (2 * (int64_t)MK * D + MK);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ps[(int64_t)q * MK * D + (int64_t)(16 * rt + 4 * kk + j) * D + 32 * cb + 16 * c + n] = acc[rt][c][q][j];
+    if (cb == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float v = s0[rt];                                        // lanes (n, kk): sum over the 4 kk groups
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kk == 0) ps[2 * (int64_t)MK * D + 16 * rt + n] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gmm_sums_reduce(const float* __restrict__ part, float* __restrict__ S0,
+                                                         float* __restrict__ S1, float* __restrict__ S2, int MK, int D, int nsp) {
+    const int64_t per = 2 * (int64_t)MK * D + MK;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    float v = 0.f;
+    for (int sp = 0; sp < nsp; ++sp) v += part[sp * per + e];
+    if (e < (int64_t)MK * D) S1[e] = v;
+    else if (e < 2 * (int64_t)MK * D) S2[e - (int64_t)MK * D] = v;
+    else S0[e - 2 * (int64_t)MK * D] = v;
+}
+
+// batch slices: about two waves per SIMD over the chip, at least 64 samples each, a multiple of 8
+void gmm_sums_split(int B, int D, int& nsp, int& spb) {
+    const int nct = D / 32;
+    int want = (2048 + nct - 1) / nct;
+    if (want < 1) want = 1;
+    spb = (B + want - 1) / want;
+    if (spb < 64) spb = 64;
+    spb = (spb + 7) / 8 * 8;
+    nsp = (B + spb - 1) / spb;
+}
+
 int choose_nsplit(int B, int MK, int D) {
     const int mkb = MK <= 16 ? 16 : 80;
     const int64_t base = (int64_t)((B + TB - 1) / TB) * ((MK + mkb - 1) / mkb);
@@ -789,6 +908,30 @@ int cf_gmm_bwd_params(const float* a, const float* nm, const float* sG, const fl
     CF_REQUIRE(a && nm && sG && S0 && S1 && S2 && gmu && gsig && MK > 0 && D > 0);
     const int64_t n = (int64_t)MK * D;
     k_gmm_bwd_params<<<dim3(gmm_ew_blocks(n)), dim3(256), 0, cf_s(stream)>>>(a, nm, sG, S0, S1, S2, gmu, gsig, D, n);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// S0 (MK), S1, S2 (MK, D) of the mixture backward from the responsibilities r (B, MK) and x (B rows of D floats, row stride
+// x_bstride): see k_gmm_sums.  MK = 80, D % 32 == 0 (cf_gmm_bwd_sums_supported); ws: cf_gmm_bwd_sums_ws_bytes(B, MK, D).
+int cf_gmm_bwd_sums_supported(int MK, int D) { return MK == 16 * GS_RT && D > 0 && D % 32 == 0; }
+
+int64_t cf_gmm_bwd_sums_ws_bytes(int B, int MK, int D) {
+    if (!cf_gmm_bwd_sums_supported(MK, D) || B <= 0) return 0;
+    int nsp, spb;
+    gmm_sums_split(B, D, nsp, spb);
+    return (int64_t)nsp * (2 * (int64_t)MK * D + MK) * (int64_t)sizeof(float);
+}
+
+int cf_gmm_bwd_sums(const float* x, const float* r, float* S0, float* S1, float* S2, void* ws, int B, int MK, int D,
+                    int64_t x_bstride, cf_stream_t stream) {
+    CF_REQUIRE(x && r && S0 && S1 && S2 && ws && B > 0 && cf_gmm_bwd_sums_supported(MK, D) && x_bstride >= D && x_bstride < (1 << 20));
+    int nsp, spb;
+    gmm_sums_split(B, D, nsp, spb);
+    const int units = (D / 32) * nsp;
+    k_gmm_sums<GS_RT><<<dim3((units + 3) / 4), dim3(256), 0, cf_s(stream)>>>(x, r, (float*)ws, B, D, x_bstride, nsp, spb);
+    const int64_t per = 2 * (int64_t)MK * D + MK;
+    k_gmm_sums_reduce<<<dim3((unsigned)((per + 255) / 256)), dim3(256), 0, cf_s(stream)>>>((const float*)ws, S0, S1, S2, MK, D, nsp);
     CF_LAUNCH_CHECK();
     return 0;
 }

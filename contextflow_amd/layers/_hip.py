@@ -43,6 +43,9 @@ SIGNATURES = {
     "cf_gmm_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_p]),
     "cf_gmm_ws_bytes": (_c_i64, [_c_int] * 4),
     "cf_gmm_logprob": (_c_int, [_c_p] * 6 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
+    "cf_gmm_bwd_sums_supported": (_c_int, [_c_int] * 2),
+    "cf_gmm_bwd_sums_ws_bytes": (_c_i64, [_c_int] * 3),
+    "cf_gmm_bwd_sums": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_i64, _c_p]),
     "cf_gmm_keyed_ws_bytes": (_c_i64, [_c_int] * 5),
     "cf_gmm_logprob_keyed": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
     "cf_gmm_levels_ws_bytes": (_c_i64, [_c_int, _c_p] + [_c_int] * 3),

@@ -46,11 +46,17 @@ def gmm_backward(x, dist, prepared, g, gcol=None):
     _hip.call("cf_gmm_bwd_gx", pp(xv), pp(G1), pp(G2), pp(gx), B, D, xbs, st)
     # parameter sums over the batch: S1 = r^T x, S2 = r^T x^2 (MK x D) and S0 = column sums of r, as split-K MFMA GEMMs
     # over the samples (cf_linear_wgrad: the bias-gradient column gives S0; x is squared while it is staged for S2)
-    xf = xv.reshape(B, -1) if xv.is_contiguous() else xv.contiguous().reshape(B, -1)
     S0, S1, S2 = new(MK), new(MK, D), new(MK, D)
-    wsw = torch.empty(_hip.lib().cf_linear_wgrad_ws_bytes(B, D, MK), device=dev, dtype=torch.uint8)
-    _hip.call("cf_linear_wgrad", pp(xf), pp(r), pp(S1), pp(S0), pp(wsw), B, D, MK, st)
-    _hip.call("cf_linear_wgrad_x2", pp(xf), pp(r), pp(S2), pp(wsw), B, D, MK, st)
+    L = _hip.lib()
+    if L.cf_gmm_bwd_sums_supported(MK, D) and xbs < (1 << 20):
+        # one product with two right-hand sides (x, x^2) on 16-row MFMA tiles, x read in place through its batch stride
+        wsw = torch.empty(L.cf_gmm_bwd_sums_ws_bytes(B, MK, D), device=dev, dtype=torch.uint8)
+        _hip.call("cf_gmm_bwd_sums", pp(xv), pp(r), pp(S0), pp(S1), pp(S2), pp(wsw), B, MK, D, xbs, st)
+    else:
+        xf = xv.reshape(B, -1) if xv.is_contiguous() else xv.contiguous().reshape(B, -1)
+        wsw = torch.empty(L.cf_linear_wgrad_ws_bytes(B, D, MK), device=dev, dtype=torch.uint8)
+        _hip.call("cf_linear_wgrad", pp(xf), pp(r), pp(S1), pp(S0), pp(wsw), B, D, MK, st)
+        _hip.call("cf_linear_wgrad_x2", pp(xf), pp(r), pp(S2), pp(wsw), B, D, MK, st)
     g_mu, g_sigma = new(MK, D), new(MK, D)
     sG = _hip.f32(dist.sG.detach()).reshape(MK, D)
     if gcol is None:

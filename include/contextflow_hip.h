@@ -167,6 +167,14 @@ int cf_gmm_bwd_gx(const float* x, const float* G1, const float* G2, float* gx, i
                   cf_stream_t stream);
 int cf_gmm_bwd_params(const float* a, const float* nm, const float* sG, const float* S0, const float* S1, const float* S2,
                       float* gmu, float* gsig, int MK, int D, cf_stream_t stream);
+/* Parameter sums of the mixture backward in one product: S0[mk] = sum_b r[b,mk], S1[mk,d] = sum_b r[b,mk] x[b,d],
+ * S2[mk,d] = sum_b r[b,mk] x[b,d]^2 (r (B, MK) dense from cf_gmm_resp; x: B rows of D floats, row stride x_bstride < 2^20).
+ * MK = 80 and D % 32 == 0 (cf_gmm_bwd_sums_supported; other shapes: cf_linear_wgrad / cf_linear_wgrad_x2).  Batch slices
+ * are summed in slice order - no float atomics.  ws: cf_gmm_bwd_sums_ws_bytes(B, MK, D) bytes.                            */
+int cf_gmm_bwd_sums_supported(int MK, int D);
+int64_t cf_gmm_bwd_sums_ws_bytes(int B, int MK, int D);
+int cf_gmm_bwd_sums(const float* x, const float* r, float* S0, float* S1, float* S2, void* ws, int B, int MK, int D,
+                    int64_t x_bstride, cf_stream_t stream);
 /* the same + the mixture-weight gradient gw (M, K) = S0 - gcol softmax(wG) (gaussian.py:149-153: the log-weights enter through
  * log_softmax; gcol (M) = column sums of the upstream gradient (B, M)) in the same launch */
 int cf_gmm_bwd_params_w(const float* a, const float* nm, const float* sG, const float* S0, const float* S1, const float* S2,

@@ -226,6 +226,26 @@ def test_keyed_mixture_kernel_against_the_formula_and_the_per_sample_kernel(L, B
     assert torch.equal(got2, got.flip(0)) or (got2 - got.flip(0)).abs().max().item() < 2e-6 * scale
 
 
+@pytest.mark.parametrize("B,D,wide", [(1003, 768, 1536), (70, 1536, 1536), (4, 96, 128), (16384, 768, 768)])
+def test_gmm_backward_sums_kernel(L, B, D, wide):
+    """cf_gmm_bwd_sums (S0, S1, S2 of the mixture backward as one MFMA product over the batch, x read through its batch
+    stride) against fp64 matmuls; ragged batch slices, a batch smaller than one k-step."""
+    from contextflow_amd.layers import _hip
+    g = torch.Generator().manual_seed(B + D)
+    MK = 80
+    xw = torch.randn(B, wide, generator=g).to(DEV)
+    x = xw[:, wide - D:]
+    r = torch.randn(B, MK, generator=g).to(DEV)
+    lib = _hip.lib()
+    assert lib.cf_gmm_bwd_sums_supported(MK, D) and not lib.cf_gmm_bwd_sums_supported(MK, D + 4) and not lib.cf_gmm_bwd_sums_supported(64, D)
+    S0, S1, S2 = torch.empty(MK, device=DEV), torch.empty(MK, D, device=DEV), torch.empty(MK, D, device=DEV)
+    ws = torch.empty(lib.cf_gmm_bwd_sums_ws_bytes(B, MK, D), device=DEV, dtype=torch.uint8)
+    _hip.call("cf_gmm_bwd_sums", _hip.p(x), _hip.p(r), _hip.p(S0), _hip.p(S1), _hip.p(S2), _hip.p(ws), B, MK, D, wide, _hip.stream())
+    rd, xd = r.double().cpu(), x.double().cpu()
+    for got, want in ((S0, rd.sum(0)), (S1, rd.t() @ xd), (S2, rd.t() @ (xd * xd))):
+        assert (got.cpu().double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()) * max(1.0, (B / 1000) ** 0.5)
+
+
 def test_preprocessing(L):
     t, _ = unit("normalize")
     n = L.Normalization(translation=1e-4, scale=1 / (1 - 2e-4)).to(DEV)
