@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
     const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ gx,
     float* __restrict__ s_y0, float* __restrict__ s_h1, float* __restrict__ s_h2, float* __restrict__ s_gh,
     float* __restrict__ s_gh2, float* __restrict__ s_gh1, float* __restrict__ s_gy, int B, int64_t xbs,
-    const float* __restrict__ sb, StepTape tp) {
+    const float* __restrict__ sb, StepTape tp, int gx_unsq) {
     using Bw = GeoBwd<G>;
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, RS = G::RS, HALF = G::HALF, HID = G::HID;   // RS: row stride of the LDS planes
     constexpr int PTW = G::PTW, RT03 = G::RT03, RT1 = G::RT1, NR = (HALF <= 16 ? 8 : 16);
@@ -587,7 +587,8 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
         dense_phase<G, G::KS0, G::NG0, Bw::RTI>(ax, rsb, Bw::OFF_A0T, GY, pix, lane);
         float* GX = H1 + C * RS;
         tiles_to_plane<G, Bw::RTI>(ax, GX, C, pix, lk);
-        rows_store_t<G, C, C>(gx, GX, b0, B, wave, lane);
+        if (gx_unsq) rows_store_unsq<G>(gx, GX, b0, B, wave, lane);      // d/dx in the layout of the tensor BEFORE Squeeze((2,2))
+        else rows_store_t<G, C, C>(gx, GX, b0, B, wave, lane);
     }
 }
 
@@ -603,14 +604,14 @@ int launch_prepare_bwd(const float* Wm, const float* logs, const float* w1, cons
 template <class G, bool SQ, int CTX = 0, bool TAPED = false>
 int launch_step_bwd(const float* x, const float* gz, const float* gld, const float* ws, const float* wsb, float* gx,
                     float* s_y0, float* s_h1, float* s_h2, float* s_gh, float* s_gh2, float* s_gh1, float* s_gy, int B,
-                    int64_t xbs, hipStream_t s, const float* sb = nullptr, StepTape tp = kNoTape) {
+                    int64_t xbs, hipStream_t s, const float* sb = nullptr, StepTape tp = kNoTape, int gx_unsq = 0) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {
         static std::atomic<uint64_t> raised{0};
         if (int rc_ = cf_raise_dynamic_lds((const void*)k_flow_step_bwd<G, SQ, CTX, TAPED>, 160 * 1024, raised, __func__)) return rc_;
     }
     k_flow_step_bwd<G, SQ, CTX, TAPED><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(
-        x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs, sb, tp);
+        x, gz, gld, ws, wsb, gx, s_y0, s_h1, s_h2, s_gh, s_gh2, s_gh1, s_gy, B, xbs, sb, tp, gx_unsq);
     return 0;
 }
 
@@ -654,16 +655,17 @@ int cf_flow_step_bwd_prepare(const float* Wm, const float* logs, const float* w1
 // tape's aux buffer - it needs neither the step input nor the forward's packed weights, and runs no recompute.  (The y0 /
 // h1 / h2 planes of the tape are operands of cf_wgrad only.)  gx comes out in the (B, C, H, W) layout of the step.
 int cf_flow_step_bwd_taped(const float* gz, const float* gld, const void* wsb, const void* t_aux, float* gx, float* s_gh,
-                           float* s_gh2, float* s_gh1, float* s_gy, int B, int C, int H, int W, cf_stream_t stream) {
+                           float* s_gh2, float* s_gh1, float* s_gy, int B, int C, int H, int W, int gx_unsqueezed,
+                           cf_stream_t stream) {
     if (B == 0) return 0;
-    CF_REQUIRE(gz && gld && wsb && t_aux && gx && s_gh && s_gh2 && s_gh1 && s_gy);
+    CF_REQUIRE(gz && gld && wsb && t_aux && gx && s_gh && s_gh2 && s_gh1 && s_gy && (!gx_unsqueezed || C % 4 == 0));
     CF_REQUIRE((reinterpret_cast<uintptr_t>(gz) & 15) == 0 && (reinterpret_cast<uintptr_t>(gx) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(t_aux) & 15) == 0);
     const float* wb = (const float*)wsb;
     const StepTape tp = make_tape(nullptr, nullptr, nullptr, const_cast<void*>(t_aux), B, C, H, W);
     int rc = 0;
 #define CF_BWDT(G) rc = launch_step_bwd<G, false, 0, true>(nullptr, gz, gld, nullptr, wb, gx, nullptr, nullptr, nullptr, s_gh, s_gh2, \
-                                                           s_gh1, s_gy, B, (int64_t)C * H * W, cf_s(stream), nullptr, tp)
+                                                           s_gh1, s_gy, B, (int64_t)C * H * W, cf_s(stream), nullptr, tp, gx_unsqueezed != 0)
     switch (shape_id(C, H, W)) {
         case 0: CF_BWDT(B8); break;
         case 1: CF_BWDT(B16); break;

@@ -304,6 +304,29 @@ __device__ __forceinline__ void rows_store_t(float* __restrict__ dst, const floa
     }
     cf_wave_sync();
 }
+// the C rows of `plane` (this wave's own columns) to dst in the layout of the tensor BEFORE Squeeze((2,2)) (squeeze.py:10-11):
+// squeezed channel c = 4 q + 2 dy + dx at pixel (y, x) is element (q, 2 y + dy, 2 x + dx) of the (C/4, 2H, 2W) sample.  A
+// lane takes the channel pair (2 j, 2 j + 1) = (dx 0, 1) of q = j >> 1, dy = j & 1 at 4 pixels of one image row: 8
+// consecutive floats of the destination, two 16-byte stores.
+template <class G>
+__device__ __forceinline__ void rows_store_unsq(float* __restrict__ dst, const float* __restrict__ plane, int tb0, int B,
+                                                int wave, int lane) {
+    constexpr int WPX = 32 * G::PTW, HW = G::HW, W = G::W, PIX = G::RS, C = G::C, Q4 = WPX / 4;
+    static_assert(C % 4 == 0 && W % 4 == 0, "channel quadruples, 4 pixels of one image row");
+    cf_wave_sync();
+    for (int it = lane; it < (C / 2) * Q4; it += 64) {
+        const int j = it / Q4, col = wave * WPX + 4 * (it - j * Q4);
+        const int smp = tb0 + col / HW, p = col % HW, yy = p / W, xx = p - yy * W;
+        if (smp < B) {
+            const float4 a = *reinterpret_cast<const float4*>(&plane[(2 * j) * PIX + col]);
+            const float4 b = *reinterpret_cast<const float4*>(&plane[(2 * j + 1) * PIX + col]);
+            float* d = dst + (int64_t)smp * C * HW + (j >> 1) * 4 * HW + (2 * yy + (j & 1)) * 2 * W + 2 * xx;
+            *reinterpret_cast<float4*>(d) = make_float4(a.x, b.x, a.y, b.y);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(a.z, b.z, a.w, b.w);
+        }
+    }
+    cf_wave_sync();
+}
 template <class G, int NROWS, int CT>
 __device__ __forceinline__ void rows_load_t(const float* __restrict__ src, float* __restrict__ plane, int tb0, int B,
                                             int wave, int lane) {

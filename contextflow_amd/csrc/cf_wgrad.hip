@@ -249,7 +249,7 @@ __device__ __forceinline__ void ww_output(const float (&m)[16], float (&o)[9]) {
 // NT = 32-column tiles of Bm (1, 2 or 4); the 4 waves split (column tile) x (K quarter): KW = 4 / NT
 template <int H, int W, int TAPS, int NT, bool WINO = false>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, const float* __restrict__ Bm,
-                                               float* __restrict__ part, int B, int MR, int NR) {
+                                               float* __restrict__ part, int B, int MR, int NR, int64_t bsB, int sqB) {
     constexpr int HW = H * W;
     constexpr int KC = HW >= 64 ? HW : 64;            // pixels per chunk (whole samples)
     constexpr int SPC = KC / HW;                      // samples per chunk
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
         const int s0 = c * SPC;
         int sjc = sj;
         if constexpr (SPC > 1) sjc = min(sj, B - 1 - s0);
-        const unsigned offA = sjc * MR * HW + pl, offB = sjc * NR * HW + pl;
+        const unsigned offA = sjc * MR * HW + pl, offB = sjc * (unsigned)bsB + pl;
         if (fullA) {                                  // whole 32-row tile: one vector base, immediate row offsets
             const float* pa = A + ((int64_t)s0 * MR + m0 + chw) * HW + offA;
 #pragma unroll
@@ -305,8 +305,25 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
                 ra[i] = rowp[offA];
             }
         }
-        if (fullB) {
-            const float* pb = Bm + ((int64_t)s0 * NR + chw) * HW + offB;
+        bool doneB = false;
+        if constexpr (TAPS == 1 && !WINO) {
+            if (sqB) {               // Bm is the tensor BEFORE Squeeze((2,2)) (squeeze.py:10-11), (NR/4, 2H, 2W) per sample with batch
+                //                      stride bsB: channel c = 4 q + 2 dy + dx at (y, x) is element (q, 2 y + dy, 2 x + dx)
+                const int yy = pl / W, xx = pl - yy * W;
+                const float* pb = Bm + (int64_t)s0 * bsB + sjc * (unsigned)bsB + 4 * yy * W + 2 * xx;
+                int nrv = NR;
+                asm volatile("" : "+s"(nrv));
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    const int c = min(i * CPI + chw, nrv - 1);
+                    rb[i] = pb[(c >> 2) * 4 * HW + ((c >> 1) & 1) * 2 * W + (c & 1)];
+                }
+                doneB = true;
+            }
+        }
+        if (doneB) {
+        } else if (fullB) {
+            const float* pb = Bm + (int64_t)s0 * bsB + chw * HW + offB;
 #pragma unroll
             for (int i = 0; i < IB; ++i) rb[i] = pb[i * CPI * HW];
         } else {
@@ -314,7 +331,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
             asm volatile("" : "+s"(nrv));
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
-                const float* rowp = Bm + ((int64_t)s0 * NR + min(i * CPI + chw, nrv - 1)) * HW;
+                const float* rowp = Bm + (int64_t)s0 * bsB + min(i * CPI + chw, nrv - 1) * HW;
                 rb[i] = rowp[offB];
             }
         }
@@ -530,7 +547,8 @@ inline int wgrad_splits(int B, int MR, int HW, int wgs = 512) {
 }
 
 template <int H, int W, int TAPS, int NT, bool WINO>
-int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s) {
+int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s,
+                 int64_t bsB, int sqB) {
     constexpr int HW = H * W, KC = HW >= 64 ? HW : 64, KW = 4 / NT;
     constexpr size_t lds_main = (size_t)(KC * 33 + KC * (NT * 32 + 1)) * 4;
     constexpr size_t lds_comb = KW > 1 ? (size_t)(NT * TAPS * 1024 + NT * 64) * 4 : 0;
@@ -543,7 +561,7 @@ int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float
     const int splits = wgrad_splits(B, MR, HW, WINO ? 256 : 512);
     const int S = splits, nw = TAPS * MR * NR;
     // partials: [S][TAPS*MR*NR + MR] (weights | bias of one split contiguous: ONE reduce launch)
-    k_wgrad<H, W, TAPS, NT, WINO><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, ws, B, MR, NR);
+    k_wgrad<H, W, TAPS, NT, WINO><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, ws, B, MR, NR, bsB, sqB);
     g_wgrad_last_S = S;
     if (!g_wgrad_defer) k_wgrad_reduce<<<dim3((nw + MR + 63) / 64), dim3(256), 0, s>>>(ws, gw, gbias, nw, nw + MR, S);
     return 0;
@@ -557,19 +575,21 @@ static bool wgrad_direct_only() {
 }
 
 template <int H, int W, int TAPS, int NT>
-int launch_form(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s) {
+int launch_form(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s,
+                int64_t bsB, int sqB) {
     // (16x16 with 128 columns would stage 160 values per thread next to the 256 accumulators: it keeps the direct form)
     if constexpr (TAPS == 9 && !(H * W == 256 && NT == 4)) {
-        if (!wgrad_direct_only()) return launch_wgrad<H, W, TAPS, NT, true>(A, Bm, gw, gbias, ws, B, MR, NR, s);
+        if (!wgrad_direct_only()) return launch_wgrad<H, W, TAPS, NT, true>(A, Bm, gw, gbias, ws, B, MR, NR, s, bsB, sqB);
     }
-    return launch_wgrad<H, W, TAPS, NT, false>(A, Bm, gw, gbias, ws, B, MR, NR, s);
+    return launch_wgrad<H, W, TAPS, NT, false>(A, Bm, gw, gbias, ws, B, MR, NR, s, bsB, sqB);
 }
 
 template <int H, int W, int TAPS>
-int dispatch_nt(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s) {
-    if (NR <= 32) return launch_form<H, W, TAPS, 1>(A, Bm, gw, gbias, ws, B, MR, NR, s);
-    if (NR <= 64) return launch_form<H, W, TAPS, 2>(A, Bm, gw, gbias, ws, B, MR, NR, s);
-    return launch_form<H, W, TAPS, 4>(A, Bm, gw, gbias, ws, B, MR, NR, s);
+int dispatch_nt(const float* A, const float* Bm, float* gw, float* gbias, float* ws, int B, int MR, int NR, hipStream_t s,
+                int64_t bsB, int sqB) {
+    if (NR <= 32) return launch_form<H, W, TAPS, 1>(A, Bm, gw, gbias, ws, B, MR, NR, s, bsB, sqB);
+    if (NR <= 64) return launch_form<H, W, TAPS, 2>(A, Bm, gw, gbias, ws, B, MR, NR, s, bsB, sqB);
+    return launch_form<H, W, TAPS, 4>(A, Bm, gw, gbias, ws, B, MR, NR, s, bsB, sqB);
 }
 
 }  // namespace
@@ -582,14 +602,16 @@ int64_t cf_wgrad_ws_bytes(int B, int MR, int NR, int H, int W, int taps) {
     return (int64_t)S * ((int64_t)taps * MR * NR + MR) * 4;
 }
 
-int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws, int B, int MR, int NR, int H, int W,
-             int taps, cf_stream_t stream) {
+// bsB: batch stride of Bm in floats; sqB (taps == 1 only): Bm is the tensor before Squeeze((2,2)), read through the index map
+static int wgrad_impl(const float* A, const float* Bm, float* gw, float* gbias, void* ws, int B, int MR, int NR, int H, int W,
+                      int taps, int64_t bsB, int sqB, cf_stream_t stream) {
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(A && Bm && gw && ws && MR > 0 && NR > 0 && NR <= 128 && (taps == 1 || taps == 9));
+    CF_REQUIRE(bsB >= (int64_t)NR * H * W && bsB < (1 << 24) && (!sqB || (taps == 1 && NR % 4 == 0)));
     int rc;
     hipStream_t s = cf_s(stream);
     float* w = (float*)ws;
-#define CF_W(HH, WW) rc = taps == 9 ? dispatch_nt<HH, WW, 9>(A, Bm, gw, gbias, w, B, MR, NR, s) : dispatch_nt<HH, WW, 1>(A, Bm, gw, gbias, w, B, MR, NR, s)
+#define CF_W(HH, WW) rc = taps == 9 ? dispatch_nt<HH, WW, 9>(A, Bm, gw, gbias, w, B, MR, NR, s, bsB, sqB) : dispatch_nt<HH, WW, 1>(A, Bm, gw, gbias, w, B, MR, NR, s, bsB, sqB)
     if (H == 16 && W == 16) CF_W(16, 16);
     else if (H == 8 && W == 8) CF_W(8, 8);
     else if (H == 4 && W == 4) CF_W(4, 4);
@@ -598,6 +620,11 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
     if (rc) return rc;
     CF_LAUNCH_CHECK();
     return 0;
+}
+
+int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws, int B, int MR, int NR, int H, int W,
+             int taps, cf_stream_t stream) {
+    return wgrad_impl(A, Bm, gw, gbias, ws, B, MR, NR, H, W, taps, (int64_t)NR * H * W, 0, stream);
 }
 
 // The four weight gradients of one flow step - NN.4 (s_gh x t_h2), NN.2 (3x3: s_gh2 x t_h1), NN.0 (s_gh1 x t_y0), the
@@ -612,7 +639,8 @@ int64_t cf_step_wgrads_ws_bytes(int B, int C, int H, int W) {
 
 int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, const float* s_gy, const float* t_h2,
                    const float* t_h1, const float* t_y0, const float* xs, float* gw3, float* gb3, float* gw2, float* gb2,
-                   float* gw1, float* gb1, float* gwp, float* gbp, void* ws, int B, int C, int H, int W, cf_stream_t stream) {
+                   float* gw1, float* gb1, float* gwp, float* gbp, void* ws, int B, int C, int H, int W, int64_t xs_bstride,
+                   int xs_unsqueezed, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(s_gh && s_gh2 && s_gh1 && s_gy && t_h2 && t_h1 && t_y0 && xs && gw3 && gb3 && gw2 && gb2 && gw1 && gb1 && gwp && gbp && ws);
     CF_REQUIRE(C >= 2 && C % 2 == 0 && 2 * C <= 128);
@@ -627,7 +655,8 @@ int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, co
     int nmax = 0;
     for (int q = 0; q < 4; ++q) {
         g_wgrad_defer = true;
-        const int rc = cf_wgrad(As[q], Bs[q], gws[q], gbs[q], w, B, MRs[q], NRs[q], H, W, tps[q], stream);
+        const int rc = q == 3 ? wgrad_impl(As[q], Bs[q], gws[q], gbs[q], w, B, MRs[q], NRs[q], H, W, tps[q], xs_bstride, xs_unsqueezed != 0, stream)
+                              : cf_wgrad(As[q], Bs[q], gws[q], gbs[q], w, B, MRs[q], NRs[q], H, W, tps[q], stream);
         g_wgrad_defer = false;
         if (rc) return rc;
         const int nw = tps[q] * MRs[q] * NRs[q];

@@ -87,7 +87,8 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
     _hip.call("cf_flow_step_bwd_prepare", pp(Wm), pp(logs), pp(f(c1.weight.detach())), pp(f(c2.weight.detach())),
               pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
     new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
-    gx = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+    # with a Squeeze in front of the step, dL/dx leaves the kernel in the un-squeezed layout of x (index map folded into its stores)
+    gx = torch.empty((B, C // 4, 2 * H, 2 * W) if squeeze else (B, C, H, W), device=dev, dtype=torch.float32)
     s_gh, s_gh2, s_gh1, s_gy = new(C), new(HID), new(HID), new(C)
     gzc = f(gz)
     if planes is None:
@@ -105,16 +106,17 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
         del zs, lds
     s_y0, s_h1, s_h2, aux = planes
     _hip.call("cf_flow_step_bwd_taped", pp(gzc), pp(f(gld)), pp(wsb), pp(aux), pp(gx), pp(s_gh), pp(s_gh2), pp(s_gh1),
-              pp(s_gy), B, C, H, W, st)
+              pp(s_gy), B, C, H, W, int(bool(squeeze)), st)
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts, the four of a step in one call
     # (cf_step_wgrads: four k_wgrad launches, ONE reduce launch)
     e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
     gw3, gb3, gw2, gb2 = e(1, C, HID), e(C), e(HID, HID, 3, 3), e(HID)
     gw1, gb1, gWp, gbp = e(1, HID, HALF), e(HID), e(1, C, C), e(C)
-    xs = squeeze_op(xv, (2, 2), False) if squeeze else xv.contiguous()
+    # the step input is read in place by the Conv1x1 weight gradient: through its batch stride (a channel slice after a
+    # SplitPrior) and, behind a Squeeze, through the squeeze index map - no squeezed / contiguous copy
     wsw = torch.empty(L.cf_step_wgrads_ws_bytes(B, C, H, W), device=dev, dtype=torch.uint8)
-    _hip.call("cf_step_wgrads", pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), pp(s_h2), pp(s_h1), pp(s_y0), pp(xs), pp(gw3), pp(gb3),
-              pp(gw2), pp(gb2), pp(gw1), pp(gb1), pp(gWp), pp(gbp), pp(wsw), B, C, H, W, st)
+    _hip.call("cf_step_wgrads", pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy), pp(s_h2), pp(s_h1), pp(s_y0), pp(xv), pp(gw3), pp(gb3),
+              pp(gw2), pp(gb2), pp(gw1), pp(gb1), pp(gWp), pp(gbp), pp(wsw), B, C, H, W, xbs, int(bool(squeeze)), st)
     gw3, gw1, gWp = gw3[0], gw1[0], gWp[0]
     # ---- chain to Conv1x1 / ActNorm parameters (W' = diag(s) Wm, b' = -t s, s = exp(-logs)): one small kernel
     if gsum is None:
@@ -135,8 +137,6 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
         c2.weight: gw2, c2.bias: gb2,
         c3.weight: gw3.reshape(c3.weight.shape), c3.bias: gb3,
     }
-    if squeeze:
-        gx = squeeze_op(gx, (2, 2), True)
     return gx, grads
 
 

@@ -258,7 +258,7 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
     y0, h1, h2, aux = rec["planes"]
     s_gh2, s_gh1, s_gy = new(HID), new(HID), new(C)
     _hip.call("cf_flow_step_bwd_taped", pp(gzc), pp(f(gld)), pp(wsb), pp(aux), pp(gx), pp(s_gh), pp(s_gh2), pp(s_gh1), pp(s_gy),
-              B, C, H, W, st)
+              B, C, H, W, 0, st)
 
     def wgrad(A, Bm, taps):
         MR, NR = A.shape[1], Bm.shape[1]

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 4
+#define CF_ABI_VERSION 5
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -262,8 +262,11 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
 int cf_flow_step_fwd_ctx_taped(const float* x, float* z, float* ldj_acc, const void* ws, const float* sbias, float* t_y0,
                                float* t_h1, float* t_h2, void* t_aux, int B, int C, int H, int W, int64_t x_bstride,
                                cf_stream_t stream);
+/* gx_unsqueezed != 0: dL/dx is written in the layout of the tensor BEFORE the Squeeze((2,2)) in front of the step,
+ * (B, C/4, 2H, 2W) - the index map of squeeze.py:10-11 folded into the kernel's stores (C % 4 == 0).                       */
 int cf_flow_step_bwd_taped(const float* gz, const float* gld, const void* wsb, const void* t_aux, float* gx, float* s_gh,
-                           float* s_gh2, float* s_gh1, float* s_gy, int B, int C, int H, int W, cf_stream_t stream);
+                           float* s_gh2, float* s_gh1, float* s_gy, int B, int C, int H, int W, int gx_unsqueezed,
+                           cf_stream_t stream);
 
 /* Conv1x1 / ActNorm parameter gradients of a fused step from the gradients of its folded matrix / bias (gWp (C,C) and
  * gbp (C) = the wgrad of the g_y plane against the step input): gNN = diag(s) gWp + G H W Wm^-T, gt = -s gbp,
@@ -286,12 +289,15 @@ int cf_wgrad(const float* A, const float* Bm, float* gw, float* gbias, void* ws,
  * Conv1x1 / ActNorm / Coupling.NN, coupling.py:26-28, conv1x1.py:52-57): NN.4 = s_gh x t_h2 -> gw3 (1, C, 2C), gb3 (C);
  * NN.2 (3x3) = s_gh2 x t_h1 -> gw2 (2C, 2C, 3, 3: the reference's weight layout), gb2 (2C); NN.0 = s_gh1 x t_y0 -> gw1 (1, 2C, C/2), gb1 (2C); folded
  * Conv1x1 / ActNorm matrix = s_gy x xs -> gwp (1, C, C), gbp (C).  Planes as written by cf_flow_step_bwd[_taped] /
- * cf_flow_step_fwd_taped, xs = the (squeezed) step input (B, C, H*W).  Four split-K launches + ONE reduce launch; results
- * bitwise equal to four cf_wgrad calls. */
+ * cf_flow_step_fwd_taped.  xs = the step input, read in place: B samples at a stride of xs_bstride floats, each
+ * (C, H*W) - or, with xs_unsqueezed != 0, the (C/4, 2H, 2W) tensor in front of the step's Squeeze((2,2)), read through the
+ * index map of squeeze.py:10-11 (no squeezed / contiguous copy is made).  Four split-K launches + ONE reduce launch; results
+ * bitwise equal to four cf_wgrad calls on dense planes. */
 int64_t cf_step_wgrads_ws_bytes(int B, int C, int H, int W);
 int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, const float* s_gy, const float* t_h2,
                    const float* t_h1, const float* t_y0, const float* xs, float* gw3, float* gb3, float* gw2, float* gb2,
-                   float* gw1, float* gb1, float* gwp, float* gbp, void* ws, int B, int C, int H, int W, cf_stream_t stream);
+                   float* gw1, float* gb1, float* gwp, float* gbp, void* ws, int B, int C, int H, int W, int64_t xs_bstride,
+                   int xs_unsqueezed, cf_stream_t stream);
 
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; any K, N.

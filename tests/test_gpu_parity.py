@@ -526,7 +526,7 @@ def test_abi_errors(L):
     # empty batches: every batched entry point returns 0 without touching its (null) pointers
     N = None
     assert lib.cf_flow_step_fwd_taped(N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, 0, N) == 0
-    assert lib.cf_flow_step_bwd_taped(N, N, N, N, N, N, N, N, N, 0, 16, 16, 16, N) == 0
+    assert lib.cf_flow_step_bwd_taped(N, N, N, N, N, N, N, N, N, 0, 16, 16, 16, 0, N) == 0
     assert lib.cf_flow_step_fwd_ctx_taped(N, N, N, N, N, N, N, N, N, 0, 16, 16, 16, 4096, N) == 0
     assert lib.cf_gmm_ctx_logprob(N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
     assert lib.cf_gmm_ctx_logprob_tab(N, N, N, N, N, N, N, N, N, N, 0, 2, 2, 4, 16, 64, 0, N) == 0
@@ -1248,10 +1248,61 @@ def test_step_wgrads_equals_four_wgrad_calls(L, C, H, B):
     ws = torch.empty(lib.cf_step_wgrads_ws_bytes(B, C, H, H), device=DEV, dtype=torch.uint8)
     P = _hip.p
     _hip.call("cf_step_wgrads", P(s_gh), P(s_gh2), P(s_gh1), P(s_gy), P(t_h2), P(t_h1), P(t_y0), P(xs), *[P(o) for o in out], P(ws),
-              B, C, H, H, _hip.stream())
+              B, C, H, H, C * H * H, 0, _hip.stream())
     ref[2] = ref[2].permute(1, 2, 0).contiguous()            # the 3x3 leaves cf_step_wgrads as (2C, 2C, 3, 3)
     for a, b in zip(ref, out):
         assert torch.equal(a.reshape(-1), b.reshape(-1))
+    # the step input read in place: the un-squeezed tensor in front of the step's Squeeze((2,2)), as the first half of the
+    # channels of a wider tensor (a SplitPrior's view) - same bits as the squeezed dense copy
+    from contextflow_amd.layers.squeeze import squeeze_op
+    wide = torch.randn(B, C // 2, 2 * H, 2 * H, generator=g).to(DEV)
+    view = wide[:, : C // 4]
+    xs2 = squeeze_op(view, (2, 2), False).reshape(B, C, HW).contiguous()
+    outs = []
+    for xsrc, bst, unsq in ((xs2, C * HW, 0), (view, wide.stride(0), 1)):
+        o = [torch.full_like(t, float("nan")) for t in out]
+        _hip.call("cf_step_wgrads", P(s_gh), P(s_gh2), P(s_gh1), P(s_gy), P(t_h2), P(t_h1), P(t_y0), P(xsrc), *[P(t) for t in o], P(ws),
+                  B, C, H, H, bst, unsq, _hip.stream())
+        outs.append(o)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[0][6], out[6])               # (another input: the comparison above is not vacuous)
+
+
+@pytest.mark.parametrize("C,H,B", [(16, 16, 5), (32, 8, 37), (64, 4, 300), (8, 16, 3)])
+def test_step_backward_writes_the_unsqueezed_gradient(L, C, H, B):
+    """cf_flow_step_bwd_taped with gx_unsqueezed: dL/dx in the layout of the tensor in front of the step's Squeeze((2,2)) =
+    squeeze_op(inverse) of the squeezed-layout result, bit for bit (ragged last workgroup included)."""
+    from contextflow_amd.layers import _hip
+    from contextflow_amd.layers.squeeze import squeeze_op
+    from contextflow_amd.layers.flowsequential import step_tape
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(C * 7 + B)
+    HID, HALF, HW = 2 * C, C // 2, H * H
+    r = lambda *sh: torch.randn(*sh, generator=g).to(DEV)
+    Wm = torch.linalg.qr(torch.randn(C, C, generator=g))[0].contiguous().to(DEV)
+    t, logs = 0.1 * r(C), 0.1 * r(C)
+    w1, b1, w2, b2, w3, b3 = 0.2 * r(HID, HALF, 1, 1), 0.1 * r(HID), 0.05 * r(HID, HID, 3, 3), 0.1 * r(HID), 0.05 * r(C, HID, 1, 1), 0.1 * r(C)
+    P, st = _hip.p, _hip.stream()
+    ws = torch.empty(lib.cf_flow_step_ws_bytes(C, H, H), device=DEV, dtype=torch.uint8)
+    _hip.call("cf_flow_step_prepare", P(Wm), P(t), P(logs), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), P(ws), C, H, H, st)
+    wsb = torch.empty(lib.cf_flow_step_bwd_ws_bytes(C, H, H), device=DEV, dtype=torch.uint8)
+    _hip.call("cf_flow_step_bwd_prepare", P(Wm), P(logs), P(w1), P(w2), P(w3), P(wsb), C, H, H, st)
+    x = r(B, C, H, H)
+    z, ld = torch.empty_like(x), torch.zeros(B, device=DEV)
+    planes = step_tape(B, C, H, H, DEV)
+    _hip.call("cf_flow_step_fwd_taped", P(x), P(z), P(ld), P(ws), P(planes[0]), P(planes[1]), P(planes[2]), P(planes[3]), B, C, H, H,
+              C * HW, 0, st)
+    gz, gld = r(B, C, H, H), r(B)
+    res = []
+    for unsq in (0, 1):
+        gx = torch.full((B, C, H, H), float("nan"), device=DEV)
+        pl = [torch.empty(B, rows, HW, device=DEV) for rows in (C, HID, HID, C)]
+        _hip.call("cf_flow_step_bwd_taped", P(gz), P(gld), P(wsb), P(planes[3]), P(gx), *[P(p_) for p_ in pl], B, C, H, H, unsq, st)
+        res.append(gx)
+    want = squeeze_op(res[0], (2, 2), True)
+    assert torch.isfinite(res[1]).all()
+    assert torch.equal(res[1].view_as(want), want)
 
 
 @pytest.mark.parametrize("C,H", [(16, 16), (32, 8), (64, 4)])

@@ -33,7 +33,7 @@ for (C, H) in [(16, 16), (32, 8), (64, 4)]:
     gx = torch.empty(B, C, H, H, device=dev)
     s_gh, s_gh2, s_gh1, s_gy = new(C), new(HID), new(HID), new(C)
     run = lambda: _hip.call("cf_flow_step_bwd_taped", P(gz), P(gld), P(wsb), P(aux), P(gx), P(s_gh), P(s_gh2), P(s_gh1), P(s_gy),
-                            B, C, H, H, st)
+                            B, C, H, H, 0, st)
     for _ in range(30):                     # clocks up
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

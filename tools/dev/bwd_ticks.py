@@ -33,7 +33,7 @@ for (C, H) in [(16, 16), (32, 8), (64, 4)]:
     assert L.cf_flow_step_fwd_taped(P(x), P(z), P(ld), P(ws), P(y0), P(h1), P(h2), P(aux), I(B), I(C), I(H), I(H),
                                     ctypes.c_int64(C * HW), I(0), st) == 0
     bufs = [new(C), new(HID), new(HID), new(C)]
-    run = lambda: L.cf_flow_step_bwd_taped(P(gz), P(gld), P(wsb), P(aux), P(gx), *[P(b) for b in bufs], I(B), I(C), I(H), I(H), st)
+    run = lambda: L.cf_flow_step_bwd_taped(P(gz), P(gld), P(wsb), P(aux), P(gx), *[P(b) for b in bufs], I(B), I(C), I(H), I(H), I(0), st)
     for _ in range(2):
         assert run() == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
