@@ -478,6 +478,150 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
     }
 }
 
+// ---- 1x1 weight gradients without LDS ---------------------------------------------------------------------------------
+// gw[m][n] = sum_{b, p} A[b][m][p] Bm[b][n][p] with 8..128 rows on either side: a skinny product whose cost is reading the
+// two planes once (C = 16 on 16x16: 48 rows x 16.8 MB = 100 us at HBM speed; the staged 32x32x2 kernel above took 171 us,
+// loading 32-row tiles for 16 / 8 rows and going through LDS transposes).  Here a WAVE owns all RT x CT 16x16 output
+// tiles and a contiguous range of (sample, 16-pixel group) units, and reads both operands from global memory directly in
+// the layout of v_mfma_f32_16x16x4_f32: lane (n = lane & 15, kk = lane >> 4) loads the float4 A[b][16 rt + n][16 g + 4 kk ..]
+// and the float4 Bm[b][16 ct + n][16 g + 4 kk ..] - its four values are the operands of four successive k-steps whose k
+// index (the lane group kk) stands for pixel 16 g + 4 kk + e on BOTH sides; the order in which a sum visits its pixels is
+// free.  No LDS, no barrier; the row sums of A (bias gradient) are four adds per load.  Partials per wave in the layout of
+// k_wgrad ([MR][NR] | [MR]), summed in order by the same reduce kernels.
+// SQB: Bm is the tensor BEFORE Squeeze((2,2)) - channel c = 4 q + 2 dy + dx at (y, x) is element (q, 2 y + dy, 2 x + dx):
+// the 4 pixels of a lane are 8 consecutive floats of row 2 y + dy, of which it keeps those of its dx.
+__device__ __forceinline__ float wg_f4e(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+template <int RT, int CT, bool SQB, int NF>
+__global__ __launch_bounds__(256) void k_wgrad1x1(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                  float* __restrict__ part, int MR, int NR, int HW, int W, int64_t bsB,
+                                                  int Q, int qper, int nsplit) {
+    // NF = float4 per lane, row and unit: a unit is 16 NF pixels, of which lane group kk takes the 4 NF consecutive ones from
+    // 4 NF kk - with NF = 2 the four lane groups of a row read 128 contiguous bytes (whole cache lines; 16x16 / 8x8 images)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sp = blockIdx.x * 4 + wave;              // wave-uniform: the unit index and everything derived from it (sample,
+    //                                                    group, base pointers) live on the SALU
+    const int q0 = min(Q, sp * qper), q1 = min(Q, q0 + qper);       // (a wave past the end has an empty range: it still joins the barriers)
+    const int gps = HW / (16 * NF);                    // units per sample
+    f32x4 acc[RT][CT];
+    float bs[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        bs[rt] = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int arow[RT], brow[CT];                            // row offsets inside a sample (clamped: results of rows past MR / NR are not stored)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) arow[rt] = min(16 * rt + n, MR - 1) * HW + 4 * NF * kk;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = min(16 * ct + n, NR - 1);
+        brow[ct] = SQB ? (c >> 2) * 4 * HW + ((c >> 1) & 1) * 2 * W + (c & 1) : c * HW + 4 * NF * kk;
+    }
+    auto load = [&](int q, float4 (&av)[RT][NF], float4 (&bv)[CT][NF]) {
+        const int b = q / gps, g = q - b * gps;
+        const float* ab = A + (int64_t)b * MR * HW + 16 * NF * g;
+        const float* bb = Bm + (int64_t)b * bsB;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) av[rt][f] = *reinterpret_cast<const float4*>(ab + arow[rt] + 4 * f);
+        if constexpr (!SQB) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) bv[ct][f] = *reinterpret_cast<const float4*>(bb + 16 * NF * g + brow[ct] + 4 * f);
+        } else {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int p0 = 16 * NF * g + 4 * NF * kk + 4 * f, yy = p0 / W, xx = p0 - yy * W;     // 4 pixels of one image row (W >= 4)
+                const float* src = bb + 4 * yy * W + 2 * xx;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float* r = src + (brow[ct] & ~1);
+                    const float4 u0 = *reinterpret_cast<const float4*>(r), u1 = *reinterpret_cast<const float4*>(r + 4);
+                    bv[ct][f] = (brow[ct] & 1) ? make_float4(u0.y, u0.w, u1.y, u1.w) : make_float4(u0.x, u0.z, u1.x, u1.z);
+                }
+            }
+        }
+    };
+    auto mma = [&](const float4 (&av)[RT][NF], const float4 (&bv)[CT][NF]) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) bs[rt] += (av[rt][f].x + av[rt][f].y) + (av[rt][f].z + av[rt][f].w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)              // k-step outermost: successive MFMAs go to different accumulators
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wg_f4e(av[rt][f], e), wg_f4e(bv[ct][f], e), acc[rt][ct], 0, 0, 0);
+        }
+    };
+    // two units in flight behind the one being multiplied
+    float4 a0[RT][NF], b0[CT][NF], a1[RT][NF], b1[CT][NF], a2[RT][NF], b2[CT][NF];
+    int q = q0;
+    if (q < q1) load(q, a0, b0);
+    if (q + 1 < q1) load(q + 1, a1, b1);
+    for (; q + 2 < q1; q += 3) {
+        load(q + 2, a2, b2);
+        mma(a0, b0);
+        if (q + 3 < q1) load(q + 3, a0, b0);
+        mma(a1, b1);
+        if (q + 4 < q1) load(q + 4, a1, b1);
+        mma(a2, b2);
+    }
+    if (q < q1) mma(a0, b0);
+    if (q + 1 < q1) mma(a1, b1);
+    // the four waves of the workgroup meet in LDS (waves 3, 2, 1 in that order onto wave 0): one partial per WORKGROUP
+    extern __shared__ __align__(16) float xch[];       // [RT * CT * 4 + RT][64]
+#pragma unroll 1
+    for (int src = 3; src >= 1; --src) {
+        if (wave == src) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xch[((rt * CT + ct) * 4 + j) * 64 + lane] = acc[rt][ct][j];
+                xch[(RT * CT * 4 + rt) * 64 + lane] = bs[rt];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[rt][ct][j] += xch[((rt * CT + ct) * 4 + j) * 64 + lane];
+                bs[rt] += xch[(RT * CT * 4 + rt) * 64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    float* pw = part + (int64_t)blockIdx.x * ((int64_t)MR * NR + MR);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = 16 * rt + 4 * kk + j, c = 16 * ct + n;
+                if (m < MR && c < NR) pw[m * NR + c] = acc[rt][ct][j];
+            }
+        float v = bs[rt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (kk == 0 && 16 * rt + n < MR) pw[MR * NR + 16 * rt + n] = v;
+    }
+}
+
 // out[e] = sum_s part[s][e] in a fixed order: a wave covers 64 consecutive outputs, the 4 waves of a block split S.
 // The first n0 outputs go to out0 (weights), the rest to out1 (bias; may be null).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ out0,
@@ -488,6 +632,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < n) {
         int i = w;
+        for (; i + 60 < S; i += 64) {                 // the same sums in the same order as the loop below, 16 loads in flight
+            float v[16];                               // (one partial per WAVE of k_wgrad1x1: a thread walks up to 512 of them)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = part[(int64_t)(i + 4 * j) * n + e];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+        }
         for (; i + 12 < S; i += 16) {
             s0 += part[(int64_t)i * n + e]; s1 += part[(int64_t)(i + 4) * n + e];
             s2 += part[(int64_t)(i + 8) * n + e]; s3 += part[(int64_t)(i + 12) * n + e];
@@ -516,6 +667,13 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4(WgReduce4 d) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < n) {
         int i = w;
+        for (; i + 60 < S; i += 64) {                 // the same sums in the same order as the loop below, 16 loads in flight
+            float v[16];                               // (one partial per WAVE of k_wgrad1x1: a thread walks up to 512 of them)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = part[(int64_t)(i + 4 * j) * n + e];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+        }
         for (; i + 12 < S; i += 16) {
             s0 += part[(int64_t)i * n + e]; s1 += part[(int64_t)(i + 4) * n + e];
             s2 += part[(int64_t)(i + 8) * n + e]; s3 += part[(int64_t)(i + 12) * n + e];
@@ -544,6 +702,33 @@ inline int wgrad_splits(int B, int MR, int HW, int wgs = 512) {
     int splits = wgs / mtiles;
     if (splits > nchunks) splits = nchunks;
     return splits < 1 ? 1 : splits;
+}
+
+// k_wgrad1x1: one partial per wave; about two waves per SIMD, at least 8 units each.  A unit is 32 pixels on 16x16 / 8x8
+// images (NF = 2), 16 on 4x4
+inline int wgrad1x1_nf(int HW) { return HW >= 64 ? 2 : 1; }
+// nsplit = number of PARTIALS = workgroups of four waves; waves: about 4 per SIMD for the small tiles (<= 128 registers), 2 otherwise
+inline void wgrad1x1_split(int B, int MR, int NR, int HW, int& Q, int& qper, int& nsplit) {
+    const int rt = (MR + 15) / 16, ct = (NR + 15) / 16;
+    const int waves = rt * ct <= 2 ? 4096 : 2048;
+    Q = B * (HW / (16 * wgrad1x1_nf(HW)));
+    qper = (Q + waves - 1) / waves;
+    if (qper < 8) qper = 8;
+    nsplit = ((Q + qper - 1) / qper + 3) / 4;
+}
+inline bool wgrad1x1_ok(int MR, int NR, int HW) {
+    const int rt = (MR + 15) / 16, ct = (NR + 15) / 16;
+    return HW % 16 == 0 && rt <= 8 && ct <= 8 && rt * ct <= (wgrad1x1_nf(HW) == 2 ? 8 : 32);
+}
+
+template <int RT, int CT, int NF>
+int launch_wgrad1x1(const float* A, const float* Bm, float* ws, int MR, int NR, int HW, int W, int64_t bsB, int sqB, int Q,
+                    int qper, int nsplit, hipStream_t s) {
+    const dim3 grid(nsplit), blk(256);
+    const size_t lds = (size_t)(RT * CT * 4 + RT) * 64 * sizeof(float);          // <= 33 KB
+    if (sqB) k_wgrad1x1<RT, CT, true, NF><<<grid, blk, lds, s>>>(A, Bm, ws, MR, NR, HW, W, bsB, Q, qper, nsplit);
+    else k_wgrad1x1<RT, CT, false, NF><<<grid, blk, lds, s>>>(A, Bm, ws, MR, NR, HW, W, bsB, Q, qper, nsplit);
+    return 0;
 }
 
 template <int H, int W, int TAPS, int NT, bool WINO>
@@ -598,7 +783,12 @@ extern "C" {
 
 // workspace for the split-K partials: [splits][taps*MR*NR + MR] floats (sized for the larger split count of the two forms)
 int64_t cf_wgrad_ws_bytes(int B, int MR, int NR, int H, int W, int taps) {
-    const int S = wgrad_splits(B, MR, H * W);
+    int S = wgrad_splits(B, MR, H * W);
+    if (taps == 1 && wgrad1x1_ok(MR, NR, H * W)) {        // k_wgrad1x1: one partial per wave
+        int Q, qper, nsplit;
+        wgrad1x1_split(B, MR, NR, H * W, Q, qper, nsplit);
+        if (nsplit > S) S = nsplit;
+    }
     return (int64_t)S * ((int64_t)taps * MR * NR + MR) * 4;
 }
 
@@ -611,6 +801,27 @@ static int wgrad_impl(const float* A, const float* Bm, float* gw, float* gbias, 
     int rc;
     hipStream_t s = cf_s(stream);
     float* w = (float*)ws;
+    if (taps == 1 && wgrad1x1_ok(MR, NR, H * W) && (H == W) && (H == 16 || H == 8 || H == 4) &&
+        ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15) == 0 && bsB % 4 == 0) {
+        // the skinny 1x1 gradients: operands straight from global memory in MFMA layout (k_wgrad1x1)
+        int Q, qper, nsplit;
+        wgrad1x1_split(B, MR, NR, H * W, Q, qper, nsplit);
+        const int rt = (MR + 15) / 16, ct = (NR + 15) / 16;
+        rc = -1;
+#define CF_W1(R, Cc, F) if (rt == R && ct == Cc && nf == F) rc = launch_wgrad1x1<R, Cc, F>(A, Bm, w, MR, NR, H * W, W, bsB, sqB, Q, qper, nsplit, s)
+        const int nf = wgrad1x1_nf(H * W);
+        CF_W1(1, 1, 2); CF_W1(1, 2, 2); CF_W1(2, 1, 2); CF_W1(2, 2, 2); CF_W1(2, 4, 2); CF_W1(4, 1, 2); CF_W1(4, 2, 2);
+        CF_W1(1, 1, 1); CF_W1(1, 2, 1); CF_W1(2, 1, 1); CF_W1(2, 2, 1); CF_W1(2, 4, 1); CF_W1(4, 1, 1); CF_W1(4, 2, 1); CF_W1(4, 4, 1);
+        CF_W1(4, 8, 1); CF_W1(8, 2, 1);
+#undef CF_W1
+        if (rc == 0) {
+            g_wgrad_last_S = nsplit;
+            const int nw = MR * NR;
+            if (!g_wgrad_defer) k_wgrad_reduce<<<dim3((nw + MR + 63) / 64), dim3(256), 0, s>>>(w, gw, gbias, nw, nw + MR, nsplit);
+            CF_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define CF_W(HH, WW) rc = taps == 9 ? dispatch_nt<HH, WW, 9>(A, Bm, gw, gbias, w, B, MR, NR, s, bsB, sqB) : dispatch_nt<HH, WW, 1>(A, Bm, gw, gbias, w, B, MR, NR, s, bsB, sqB)
     if (H == 16 && W == 16) CF_W(16, 16);
     else if (H == 8 && W == 8) CF_W(8, 8);
