@@ -277,20 +277,6 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
     linear_wgrad_body<TPW, XSQ>(x, gy, part, rows, Ktot, N, NT, kbs, ybase, ldx, ldy, zstride, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
-// A GROUP of weight gradients in one launch (blockIdx.z = member): the Linears of a transformer flow step share their row
-// count and are far too small to fill the chip one by one - 26 launch pairs per step became one (cf_linear_wgrad_group).
-// Every member is one column block (K + 1 <= (WG_MAXF - NT) * 32); TPW covers the member with the most tiles.
-constexpr int WG_GROUP_MAX = 32;
-struct WgMember { const float* x; const float* gy; float* part; float* gW; float* gb; int rows, K, N, NT, G; int64_t ldx, ldy; };
-struct WgGroup { WgMember m[WG_GROUP_MAX]; };
-template <int TPW>
-__global__ __launch_bounds__(256) void k_linear_wgrad_group(const WgGroup grp) {
-    const WgMember& d = grp.m[blockIdx.z];
-    if ((int)blockIdx.x >= d.G) return;                          // uniform: this member has fewer row groups
-    const int KT = (d.K + 1 + 31) / 32;
-    if ((int)blockIdx.y * 4 * TPW >= d.NT * KT) return;
-    linear_wgrad_body<TPW, false>(d.x, d.gy, d.part, d.rows, d.K, d.N, d.NT, d.K, 0, d.ldx, d.ldy, 0, blockIdx.x, blockIdx.y, 0, d.G);
-}
 // 64 output elements per workgroup, the G partials split over the 4 waves (every 4th partial each), then summed across
 // the waves in a fixed order
 __device__ __forceinline__ void linear_wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ gW,
@@ -326,11 +312,6 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(const float* __rest
                                                              int64_t ldw, int64_t zstride) {
     linear_wgrad_reduce_body(part, gW, gb, Ktot, N, kbs, NT, G, ldw, zstride, blockIdx.x, blockIdx.y);
 }
-__global__ __launch_bounds__(256) void k_linear_wgrad_reduce_group(const WgGroup grp) {
-    const WgMember& d = grp.m[blockIdx.y];
-    linear_wgrad_reduce_body(d.part, d.gW, d.gb, d.K, d.N, d.K, d.NT, d.G, d.K, 0, blockIdx.x, 0);
-}
-
 // LayerNorm over the last dim (biased variance, eps) + optional positional embedding add:
 // y[r, :] = LN(x[r, :]) * w + b (+ pe[r % ntok, :]).  16 lanes per row.   simple_vit.py:33,50,74,104-106,122
 // CACHED (dim <= 256): the row is read once into registers (16 values per lane, all loads in flight together).
@@ -609,55 +590,7 @@ static int linear_wgrad_any(const float* x, const float* gy, float* gW, float* g
     return 0;
 }
 
-// ---- a group of weight gradients: one k_linear_wgrad_group launch + one reduce launch ---------------------------------
-// member i: gW_i (N_i x K_i) = gy_i^T x_i over rows_i rows, gb_i (N_i, optional) = column sums of gy_i; x_i: (rows_i, K_i)
-// dense, gy_i: (rows_i, N_i) dense.  N_i <= 192, K_i + 1 <= (12 - ceil(N_i / 32)) * 32, at most 32 members.
-// row groups (= partials) per member: the members run side by side, so the chip is full with ~1536 workgroups in ALL -
-// 512 groups per member (the single-product launch's choice) would write and re-read 13x the partial sums
-static int group_row_groups(int rows, int n) {
-    const int g = linear_wgrad_groups(rows), cap = 1536 / n > 16 ? 1536 / n : 16;
-    return g < cap ? g : cap;
-}
-static int64_t wgrad_member_part_floats(int rows, int K, int N, int n) {
-    const int NT = (N + 31) / 32, KT = (K + 1 + 31) / 32;
-    return (int64_t)group_row_groups(rows, n) * NT * KT * 1024;
-}
-int64_t cf_linear_wgrad_group_ws_bytes(const int* rows, const int* K, const int* N, int n) {
-    int64_t f = 0;
-    for (int i = 0; i < n; ++i) f += wgrad_member_part_floats(rows[i], K[i], N[i], n);
-    return f * (int64_t)sizeof(float);
-}
-int cf_linear_wgrad_group(const float* const* x, const float* const* gy, float* const* gW, float* const* gb, const int* rows,
-                          const int* K, const int* N, int n, void* ws, cf_stream_t stream) {
-    CF_REQUIRE(x && gy && gW && gb && rows && K && N && ws && n >= 1 && n <= WG_GROUP_MAX);
-    WgGroup grp;
-    float* part = (float*)ws;
-    int gmax = 1, tmax = 1;
-    for (int i = 0; i < n; ++i) {
-        const int NT = (N[i] + 31) / 32, KT = (K[i] + 1 + 31) / 32;
-        CF_REQUIRE(x[i] && gy[i] && gW[i] && rows[i] >= 0 && K[i] > 0 && N[i] > 0 && NT <= 6 && NT + KT <= WG_MAXF && NT * KT <= 4 * WG_TPW);
-        WgMember& m = grp.m[i];
-        m.x = x[i]; m.gy = gy[i]; m.part = part; m.gW = gW[i]; m.gb = gb[i];
-        m.rows = rows[i]; m.K = K[i]; m.N = N[i]; m.NT = NT; m.G = group_row_groups(rows[i], n); m.ldx = K[i]; m.ldy = N[i];
-        part += wgrad_member_part_floats(rows[i], K[i], N[i], n);
-        gmax = m.G > gmax ? m.G : gmax;
-        tmax = NT * KT > tmax ? NT * KT : tmax;
-    }
-    for (int i = n; i < WG_GROUP_MAX; ++i) grp.m[i] = grp.m[0];
-    hipStream_t st = cf_s(stream);
-    const int tpw = (tmax + 3) / 4;
-    switch (tpw) {
-        case 1: k_linear_wgrad_group<1><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
-        case 2: k_linear_wgrad_group<2><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
-        case 3: k_linear_wgrad_group<3><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
-        case 4: k_linear_wgrad_group<4><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
-        default: k_linear_wgrad_group<WG_TPW><<<dim3(gmax, 1, n), dim3(256), 0, st>>>(grp); break;
-    }
-    k_linear_wgrad_reduce_group<<<dim3(tmax * 16, n), dim3(256), 0, st>>>(grp);
-    CF_LAUNCH_CHECK();
-    return 0;
-}
-
+// (a GROUP of weight gradients in one launch pair - cf_linear_wgrad_group - lives in cf_rowgemm.hip)
 int cf_linear_wgrad(const float* x, const float* gy, float* gW, float* gb, void* ws, int rows, int K, int N,
                     cf_stream_t stream) {
     return linear_wgrad_any(x, gy, gW, gb, ws, rows, K, N, stream, false);

@@ -65,10 +65,12 @@ def test_host_side_size_queries_of_round_3(built):
     assert L.cf_vit_step_bwd_ws_bytes(C, depth) > 4 * depth * (192 * 52 + 52 * 64 + 2 * 52 * 52)
     assert L.cf_vit_step_rs_supported(26, 8, 1, 2, 1, 52, 64, 1) == 1 and L.cf_vit_step_rs_supported(38, 144, 1, 2, 1, 76, 64, 1) == 0
     arr = lambda v: (ctypes.c_int * len(v))(*v)
+    # grouped weight gradients: partials [N][K] | [N] per row range; about 4096 waves per group, >= 64 rows per range
     one = L.cf_linear_wgrad_group_ws_bytes(arr([4096]), arr([52]), arr([192]), 1)
-    assert one == 128 * 6 * 2 * 1024 * 4                                   # 128 row groups x (6 x 2) tiles of 32 x 32 floats
-    many = L.cf_linear_wgrad_group_ws_bytes(arr([4096] * 26), arr([52] * 26), arr([192] * 26), 26)
-    assert many == 26 * 59 * 6 * 2 * 1024 * 4                              # the group caps the row groups per member (1536 / 26)
+    assert one == 64 * (192 * 52 + 192) * 4                                # 4096 rows in ranges of 64
+    many = L.cf_linear_wgrad_group_ws_bytes(arr([131072] * 26), arr([52] * 26), arr([192] * 26), 26)
+    assert many == 26 * 79 * (192 * 52 + 192) * 4                          # 52 tile groups -> 79 ranges (of 1664 rows) per member
+    assert L.cf_linear_wgrad_group_ws_bytes(arr([1]), arr([1]), arr([1]), 0) == -1
 
 
 def test_gfx950_code_object(built):
