@@ -712,8 +712,8 @@ inline void wgrad1x1_split(int B, int MR, int NR, int HW, int& Q, int& qper, int
     const int rt = (MR + 15) / 16, ct = (NR + 15) / 16;
     const int waves = rt * ct <= 2 ? 4096 : 2048;
     Q = B * (HW / (16 * wgrad1x1_nf(HW)));
-    qper = (Q + waves - 1) / waves;
-    if (qper < 8) qper = 8;
+    qper = (Q + waves - 1) / waves;                    // (small batches: one unit per wave - the units are what fills the chip)
+    if (qper < 1) qper = 1;
     nsplit = ((Q + qper - 1) / qper + 3) / 4;
 }
 inline bool wgrad1x1_ok(int MR, int NR, int HW) {

@@ -1130,7 +1130,7 @@ def test_training_steps_reduce_the_loss(L):
         loss = torch.nn.functional.cross_entropy(logp, gt) + 1e-3 * (-torch.nn.functional.logsigmoid(torch.logsumexp(logp, -1))).mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(math.isfinite(v) for v in losses), losses
     assert losses[-1] < losses[0] - 1e-3, losses
 
