@@ -246,6 +246,79 @@ def test_gmm_backward_sums_kernel(L, B, D, wide):
         assert (got.cpu().double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()) * max(1.0, (B / 1000) ** 0.5)
 
 
+@pytest.mark.parametrize("C,H,W,B,cf,sq", [(16, 16, 16, 5, True, False), (16, 16, 16, 3, True, True), (32, 8, 8, 37, False, False),
+                                            (32, 8, 8, 9, True, True), (64, 4, 4, 130, True, False), (64, 4, 4, 6, False, True),
+                                            (8, 6, 6, 7, True, False), (12, 4, 4, 5, False, True)])
+def test_fused_specialist_affine_equals_its_two_layers(L, C, H, W, B, cf, sq):
+    """cf_affine_ctx_fwd (per-sample Conv1x1 + per-sample ActNorm [+ Squeeze] in one pass; the one-wave-per-sample MFMA form at
+    the three image-flow levels, the LDS form elsewhere) against Squeeze -> cf_conv1x1_ctx -> cf_actnorm_ctx and against
+    conv1x1.py:34-50 / actnorm.py:40-60 in fp64; the log-det accumulates into a running buffer or assigns."""
+    from contextflow_amd.layers import _hip
+    from contextflow_amd.layers.squeeze import squeeze_op
+    g = torch.Generator().manual_seed(C * 131 + H + B)
+    r = lambda *sh: torch.randn(*sh, generator=g)
+    HW = H * W
+    xin = r(B, C // 4, 2 * H, 2 * W) if sq else r(B, C, H, W)
+    wide = torch.cat([xin, r(*xin.shape)], 1).to(DEV)                        # the step input as a channel slice (SplitPrior view)
+    xv = wide[:, : xin.shape[1]]
+    m1, m2 = 0.3 * r(B, C * C), 0.3 * r(B, 2 * C)
+    Wm = torch.linalg.qr(r(C, C))[0].contiguous() if cf else None
+    t, logs = (0.2 * r(C), 0.2 * r(C)) if cf else (None, None)
+    lad, cadd = (r(1) if cf else None), 0.375
+    d = lambda v: None if v is None else v.to(DEV).contiguous()
+    P, st = _hip.p, _hip.stream()
+    # reference chain on the GPU
+    xs = squeeze_op(xv, (2, 2), False) if sq else xv
+    xs, xbs = _hip.bview(xs)
+    z1, l1 = torch.empty(B, C, H, W, device=DEV), torch.empty(B, device=DEV)
+    _hip.call("cf_conv1x1_ctx", P(xs), P(d(m1)), P(d(Wm)), P(z1), P(l1), B, C, HW, xbs, st)
+    z2, l2 = torch.empty_like(z1), torch.empty(B, device=DEV)
+    _hip.call("cf_actnorm_ctx", P(z1), P(d(m2)), P(d(t)), P(d(logs)), P(z2), P(l2), B, C, HW, C * HW, st)
+    want_l = l1 + l2 + cadd + (HW * lad.item() if cf else 0.0)
+    for accumulate in (0, 1):
+        z = torch.full((B, C, H, W), float("nan"), device=DEV)
+        ldj = torch.full((B,), 2.5, device=DEV)
+        _hip.call("cf_affine_ctx_fwd", P(xv), P(d(m1)), P(d(Wm)), P(d(m2)), P(d(t)), P(d(logs)), P(d(lad)), cadd, P(z), P(ldj), B, C, H, W,
+                  wide.stride(0), int(sq), accumulate, st)
+        assert (z - z2).abs().max().item() <= 2e-5 * max(1.0, z2.abs().max().item())
+        assert (ldj - (want_l + (2.5 if accumulate else 0.0))).abs().max().item() <= 2e-5 * max(1.0, want_l.abs().max().item())
+    # fp64 formula
+    xd = (squeeze_op(xv, (2, 2), False) if sq else xv).double().cpu().reshape(B, C, HW)
+    M1 = m1.double().view(B, C, C)
+    Wb = torch.tril(M1, -1) + torch.diag_embed(torch.exp(torch.diagonal(M1, dim1=1, dim2=2)))
+    if cf:
+        Wb = Wb + Wm.double() - torch.eye(C, dtype=torch.float64)
+    tb = m2[:, :C].double() + (t.double() if cf else 0.0)
+    lb = m2[:, C:].double() + (logs.double() if cf else 0.0)
+    ref = (torch.bmm(Wb, xd) - tb[:, :, None]) * torch.exp(-lb)[:, :, None]
+    assert (z.double().cpu().reshape(B, C, HW) - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("rows", [1, 37, 1000, 20000])
+def test_grouped_linear_weight_gradients_against_matmul(L, rows):
+    """cf_linear_wgrad_group (cf_rowgemm.hip: 16x16 MFMA tiles fed from global memory, one wave per tile group and row range)
+    against fp64 matmuls: widths that are not multiples of 16, more than 6 x 4 tiles per member, a ragged last k-step, members
+    with and without bias."""
+    from contextflow_amd.layers.autograd import wgrad_group
+    g = torch.Generator().manual_seed(rows)
+    shapes = [(26, 26), (26, 52), (52, 192), (64, 52), (52, 52), (5, 7), (130, 100), (1, 200)]        # (K, N)
+    members, refs = [], []
+    for i, (K, N) in enumerate(shapes):
+        x, gy = torch.randn(rows, K, generator=g), torch.randn(rows, N, generator=g)
+        members.append((x.to(DEV), gy.to(DEV), i % 2 == 0))
+        refs.append((gy.double().t() @ x.double(), gy.double().sum(0)))
+    res = wgrad_group(members, torch.device(DEV))
+    tol = 3e-6 * max(1.0, (rows / 100) ** 0.5)
+    for (gW, gb), (rW, rb), m in zip(res, refs, members):
+        assert (gW.double().cpu() - rW).abs().max().item() <= tol * max(1.0, rW.abs().max().item())
+        assert (gb is not None) == m[2]
+        if gb is not None:
+            assert (gb.double().cpu() - rb).abs().max().item() <= tol * max(1.0, rb.abs().max().item())
+    again = wgrad_group(members, torch.device(DEV))                          # fixed summation order: bitwise repeatable
+    for (a, _), (b, _) in zip(res, again):
+        assert torch.equal(a, b)
+
+
 def test_preprocessing(L):
     t, _ = unit("normalize")
     n = L.Normalization(translation=1e-4, scale=1 / (1 - 2e-4)).to(DEV)
