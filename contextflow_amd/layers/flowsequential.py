@@ -86,6 +86,8 @@ class FlowSequential(nn.Module):
         `.to()` are noticed without it."""
         self._prep.clear()
         self._graphs.clear()
+        self.__dict__.pop("_spec_ws", None)          # layers/specialist.py: packed coupling tables, log|det NN| of frozen Conv1x1
+        self.__dict__.pop("_spec_lad", None)
         for m in self.modules():
             if hasattr(m, "_tab_cache"):
                 m._tab_cache = None
@@ -94,6 +96,8 @@ class FlowSequential(nn.Module):
 
     def _apply(self, fn, *a, **k):         # .to() / .cuda() / .float(): new storages, same version counters
         self._prep, self._graphs, self._plans, self._tensors = {}, {}, {}, None
+        self.__dict__.pop("_spec_ws", None)
+        self.__dict__.pop("_spec_lad", None)
         return super()._apply(fn, *a, **k)
 
     def _versions(self):
