@@ -104,12 +104,16 @@ __device__ __forceinline__ float gelu_d(float x) {                    // d/dx of
 // x: step input (B, C, 8, 1), batch stride xbs; gz: dL/dz (B, C, 8, 1) dense; gld: dL/d(log-det) (B,); gx: dL/dx dense.
 // ws: forward workspace of cf_vit_step_rs_prepare; wsb: k_vit_rs_pack_bwd.  tp: token-major planes (layout: RSB::TL_*,
 // see cf_vit_step_bwd_plane_floats); lnp: one row of LayerNorm partial sums per workgroup.
-template <class V>
+// TAPED: the residual stream at the layer boundaries comes from the training forward (cf_vit_step_fwd_taped: xtape
+// [depth + 1][DIM][T], feature-major) - phase A then runs the Conv1x1 / ActNorm / patch embedding only (their statistics and
+// planes are needed on the way back) and skips the six layers, a quarter of this kernel's work.
+template <class V, bool TAPED = false>
 __global__ __launch_bounds__(256, 3) void k_vit_step_bwd_rs(const float* __restrict__ x, const float* __restrict__ gz,
                                                             const float* __restrict__ gld, float* __restrict__ gx,
                                                             const float* __restrict__ ws, const float* __restrict__ wsb,
                                                             float* __restrict__ tp, float* __restrict__ lnp, int B, int Bp,
-                                                            int64_t xbs, int depth) {
+                                                            int64_t xbs, int depth, const float* __restrict__ xtape = nullptr,
+                                                            int64_t T = 0) {
     using R = RSB<V>;
     constexpr int C = V::C, CIN = V::CIN, HW = V::HW, DIM = V::DIM, PD = V::PD, TS = R::TS, PS = R::PS;
     extern __shared__ __align__(16) float lds[];
@@ -321,6 +325,22 @@ __global__ __launch_bounds__(256, 3) void k_vit_step_bwd_rs(const float* __restr
         for (int r = 0; r < 4; ++r) X[r] = fmaf((e_own[r] - mean_e) * rstd_e, g1[r], b1[r]) + pe[r];
         return X;
     };
+    if constexpr (TAPED) {
+        // the owner's tile of boundary b: rows 16 w + 4 g + r of column tok0 + col
+        auto tile = [&](int b) {
+            f32x4 X;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * w + 4 * g + r;
+                X[r] = f < DIM ? xtape[((int64_t)b * DIM + f) * T + tok0 + col] : 0.f;
+            }
+            return X;
+        };
+#pragma unroll 1
+        for (int l = 1; l < depth; ++l) xs_put(l, tile(l));
+        put(PA, tile(depth));
+        __syncthreads();
+    } else
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
         const int wl = V::OFF_LAYER + l * V::L_STRIDE, ln = (l + 1 < depth ? l + 1 : l), wn = V::OFF_LAYER + ln * V::L_STRIDE;
@@ -650,6 +670,27 @@ int cf_vit_step_bwd(const float* x, const float* gz, const float* gld, float* gx
     const int nwg = (B + 3) / 4;
     k_vit_step_bwd_rs<RS26><<<dim3((unsigned)nwg), dim3(256), lds_bytes, cf_s(stream)>>>(
         x, gz, gld, gx, (const float*)ws, (const float*)wsb, planes, ln_partials, B, nwg * 4, x_bstride, depth);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same from the residual-stream tape of cf_vit_step_fwd_taped (xtape: cf_vit_step_tape_floats(B, C, depth) floats): the
+// six layers are not run a second time before the way back.  Same outputs to fp32 rounding (the tape holds the forward's own
+// residual stream, the recompute form rebuilds it in the row-split kernel's summation order).
+int cf_vit_step_bwd_taped(const float* x, const float* gz, const float* gld, float* gx, const void* ws, const void* wsb,
+                          float* planes, float* ln_partials, const float* xtape, int B, int C, int depth, int64_t x_bstride,
+                          cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && gz && gld && gx && ws && wsb && planes && ln_partials && xtape && B > 0 && depth >= 1 && depth <= RB26::MAXD &&
+               x_bstride >= (int64_t)C * 8);
+    if (C != 26) { cf_set_error("cf_vit_step_bwd_taped: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
+    constexpr size_t lds_bytes = (size_t)RB26::LDS_FLOATS * sizeof(float);
+    static std::atomic<uint64_t> raised{0};
+    if (int rc_ = cf_raise_dynamic_lds((const void*)k_vit_step_bwd_rs<RS26, true>, 160 * 1024, raised, __func__)) return rc_;
+    const int nwg = (B + 3) / 4;
+    k_vit_step_bwd_rs<RS26, true><<<dim3((unsigned)nwg), dim3(256), lds_bytes, cf_s(stream)>>>(
+        x, gz, gld, gx, (const float*)ws, (const float*)wsb, planes, ln_partials, B, nwg * 4, x_bstride, depth, xtape,
+        4ll * ((B + 31) / 32 * 32));
     CF_LAUNCH_CHECK();
     return 0;
 }

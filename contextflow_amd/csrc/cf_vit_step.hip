@@ -273,10 +273,14 @@ template <int M> __device__ __forceinline__ float tok_xor(float v) {
 // ---- the kernel ---------------------------------------------------------------------------------------------------------
 // x, z: (B, C, 8, 1).  ldj_acc[b] += H*W*log|det W| + sum logs + sum log_s.  hout (optional, tests): the conditioner's
 // output un-patchified, (B, C, 8, 1) = [t | raw].
-template <class V>
+// DUMP (training forward at saturating batches): the residual stream at the depth + 1 layer boundaries goes to `xtape`,
+// feature-major [boundary][feature < DIM][token < T] (token = 4 sample + n: 128 contiguous bytes per feature and half wave) -
+// cf_vit_step_bwd_taped then walks back from these instead of running the six layers again.
+template <class V, bool DUMP = false>
 __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x, float* __restrict__ z,
                                                      float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                     int64_t xbs, int depth, float* __restrict__ hout) {
+                                                     int64_t xbs, int depth, float* __restrict__ hout,
+                                                     float* __restrict__ xtape = nullptr, int64_t T = 0) {
     constexpr int C = V::C, CIN = V::CIN, HW = V::HW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
     const int n = li & 3;                                   // token of the sample: positions 2n, 2n + 1
@@ -311,6 +315,19 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
         gemm_regs<2, V::KS_IN>(X, rs, lane, V::OFF_WE, [&](int s) { return u[0][s]; });
         layernorm<V, 2>(X, X, ws + V::OFF_LN1, lk, ws + V::OFF_POS + 64 * n);
     }
+    auto dump = [&](int bnd) {
+        if constexpr (DUMP) {
+            float* tb = xtape + (int64_t)bnd * V::DIM * T + (int64_t)(blockIdx.x * 4 + wave) * 32 + li;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < V::KPT; ++r) {
+                    const int f = feat_of_phys<V>(trow(r, lk) + 32 * t);
+                    if (f >= 0) tb[(int64_t)f * T] = X[t][r];
+                }
+        }
+    };
+    dump(0);
     // ================= transformer                                                 (simple_vit.py:56-88)
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
@@ -375,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
 #pragma unroll
             for (int t = 0; t < 2; ++t) X[t] += a[t];
         }
+        dump(l + 1);
     }
     f32x16 hn[2];
     layernorm<V, 2>(X, hn, ws + off_lno<V>(depth), lk, nullptr);                  // transformer.norm: tile 0 = t, tile 1 = raw
@@ -440,6 +458,23 @@ int cf_vit_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, fl
     if (C != 26) { cf_set_error("cf_vit_step_fwd: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
     k_vit_step<VS26><<<dim3((unsigned)((B + 31) / 32)), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, (const float*)ws, B,
                                                                                     x_bstride, depth, h_out);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// training forward at saturating batches: cf_vit_step_fwd that also writes the residual stream at the layer boundaries -
+// xtape: cf_vit_step_tape_floats(B, C, depth) floats, [depth + 1][2C][T] with T = 4 * (B rounded up to 32) tokens.
+int64_t cf_vit_step_tape_tokens(int B) { return 4ll * ((B + 31) / 32 * 32); }
+int64_t cf_vit_step_tape_floats(int B, int C, int depth) { return C == 26 ? (int64_t)(depth + 1) * 2 * C * cf_vit_step_tape_tokens(B) : 0; }
+
+int cf_vit_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* xtape, int B, int C, int depth,
+                          int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && z && ldj_acc && ws && xtape && B > 0 && x_bstride >= (int64_t)C * 8);
+    if (C != 26) { cf_set_error("cf_vit_step_fwd_taped: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
+    k_vit_step<VS26, true><<<dim3((unsigned)((B + 31) / 32)), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, (const float*)ws, B,
+                                                                                          x_bstride, depth, nullptr, xtape,
+                                                                                          cf_vit_step_tape_tokens(B));
     CF_LAUNCH_CHECK();
     return 0;
 }

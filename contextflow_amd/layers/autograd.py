@@ -169,7 +169,7 @@ def wgrad_group(members, dev):
     return res
 
 
-def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None):
+def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None):
     """Conv1x1 -> ActNorm -> TransCoupling (one fused step of the transformer flows) backwards: ONE kernel re-runs the step
     from its input and walks back (cf_vit_step_bwd), ONE grouped launch contracts the 26 weight-gradient operand pairs it
     leaves (cf_linear_wgrad_group), the LayerNorm gradients are column sums of its per-workgroup partials, and the Conv1x1 /
@@ -191,8 +191,12 @@ def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None):
     planes = torch.empty(L.cf_vit_step_bwd_plane_floats(B, C, depth), device=dev, dtype=torch.float32)
     lnp = torch.empty(nwg, L.cf_vit_step_bwd_ln_floats(B, C, depth) // nwg, device=dev, dtype=torch.float32)
     gx = torch.empty(B, C, xv.shape[2], xv.shape[3], device=dev, dtype=torch.float32)
-    _hip.call("cf_vit_step_bwd", pp(xv), pp(f(gz).contiguous()), pp(f(gld)), pp(gx), pp(ws), pp(wsb), pp(planes), pp(lnp), B, C,
-              depth, xbs, st)
+    if xtape is not None:        # the forward taped the residual stream at the layer boundaries: the layers are not run again
+        _hip.call("cf_vit_step_bwd_taped", pp(xv), pp(f(gz).contiguous()), pp(f(gld)), pp(gx), pp(ws), pp(wsb), pp(planes), pp(lnp),
+                  pp(xtape), B, C, depth, xbs, st)
+    else:
+        _hip.call("cf_vit_step_bwd", pp(xv), pp(f(gz).contiguous()), pp(f(gld)), pp(gx), pp(ws), pp(wsb), pp(planes), pp(lnp), B, C,
+                  depth, xbs, st)
     # ---- weight gradients: the planes as (rows, width) matrices (layout: include/contextflow_hip.h, cf_vit_step_bwd)
     Bp = nwg * 4
     R4, P8, PD, DIM = 4 * Bp, 8 * Bp, C, 2 * C
@@ -285,8 +289,8 @@ class FlowLogProb(torch.autograd.Function):
                 gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum)
                 add(gp)
             elif kind == "vstep":
-                _, xin, conv, act, cpl, ws_rs = rec
-                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs)
+                _, xin, conv, act, cpl, ws_rs, xtape = rec
+                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape)
                 add(gp)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)

@@ -291,12 +291,18 @@ class TransCoupling(_AffineCoupling):
                   _hip.p(_hip.f32(logs.detach())), _hip.p(flat), _hip.p(_hip.f32(vit.pos_embedding)), _hip.p(ws), C, depth, _hip.stream())
         return ws
 
-    def step_forward(self, x, ws, ld1, h_out=None, variant="wave"):
-        """z = TransCoupling(ActNorm(Conv1x1(x))) and ld1 += the step's log-det, one launch."""
+    def step_forward(self, x, ws, ld1, h_out=None, variant="wave", xtape=None):
+        """z = TransCoupling(ActNorm(Conv1x1(x))) and ld1 += the step's log-det, one launch.  xtape (training, wave form):
+        receives the residual stream at the layer boundaries (cf_vit_step_fwd_taped) for cf_vit_step_bwd_taped."""
         x, xbs = _hip.bview(x)
         B, C = x.shape[0], x.shape[1]
         depth = len(self.NN[0].transformer.layers)
         z = torch.empty(B, C, x.shape[2], x.shape[3], device=x.device, dtype=torch.float32)
+        if xtape is not None:
+            assert variant == "wave" and h_out is None
+            _hip.call("cf_vit_step_fwd_taped", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), _hip.p(xtape), B, C, depth, xbs,
+                      _hip.stream())
+            return z
         events = VIT_EVENTS
         if events is not None:               # bench.py: HIP events on the launch stream around exactly this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

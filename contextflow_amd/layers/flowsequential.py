@@ -39,6 +39,9 @@ from .transforms import LogitTransform
 TAPE_PLANES = True
 
 
+VSTEP_TAPE = True        # transformer steps at saturating batches: keep the residual-stream tape (False: the backward recomputes)
+
+
 def step_tape(B, C, H, W, dev):
     """Buffers of one step's training tape (cf_flow_step_fwd_taped): y0 (B, C/2, HW), h1, h2 (B, 2C, HW) - the operands of
     the weight-gradient GEMMs - and the opaque aux buffer (log-scales, second half of the Conv1x1+ActNorm output, ReLU
@@ -385,7 +388,17 @@ class FlowSequential(nn.Module):
                 ws, ev = prepared[k]
                 if tape is not None:         # training: the same one-kernel forward; the backward re-runs the step from its input
                     #                          (and reuses the packed forward table when it is the row-split one)
-                    tape.append(("vstep", x, op[1], op[2], op[3], ws if vkey[k] == "rs" else None))
+                    # saturating batches (the register-resident forward): the residual stream at the layer boundaries goes to a
+                    # tape (5.8 KB per sample and step) and the backward kernel does not run the six layers a second time
+                    xt = None
+                    if vkey[k] == "wave" and VSTEP_TAPE:
+                        depth = len(op[3].NN[0].transformer.layers)
+                        xt = torch.empty(_hip.lib().cf_vit_step_tape_floats(B, x.shape[1], depth), device=dev, dtype=torch.float32)
+                    tape.append(("vstep", x, op[1], op[2], op[3], ws if vkey[k] == "rs" else None, xt))
+                    if ev is not None:
+                        main.wait_event(ev)
+                    x = op[3].step_forward(x, ws, ld1, variant=vkey[k], xtape=xt)
+                    continue
                 if ev is not None:
                     main.wait_event(ev)
                 x = op[3].step_forward(x, ws, ld1, variant=vkey[k])

@@ -394,6 +394,20 @@ int cf_vit_step_bwd_prepare(const float* Wm, const float* logs, const float* fla
 int cf_vit_step_bwd(const float* x, const float* gz, const float* gld, float* gx, const void* ws, const void* wsb, float* planes,
                     float* ln_partials, int B, int C, int depth, int64_t x_bstride, cf_stream_t stream);
 
+/* Taped pair for saturating batches (the register-resident forward): cf_vit_step_fwd_taped = cf_vit_step_fwd that also writes
+ * the residual stream of the conditioner at its depth + 1 layer boundaries to xtape - cf_vit_step_tape_floats(B, C, depth)
+ * floats, feature-major [boundary][2C][T], T = cf_vit_step_tape_tokens(B) = 4 x (B rounded up to 32), token = 4 sample + n
+ * (5.8 KB per sample at C = 26, depth 6).  cf_vit_step_bwd_taped = cf_vit_step_bwd that starts from that tape: the Conv1x1 /
+ * ActNorm / patch embedding are re-run (their statistics are needed on the way back), the transformer layers are not - a
+ * quarter of the kernel's work.  Same outputs to fp32 rounding.                                                          */
+int64_t cf_vit_step_tape_tokens(int B);
+int64_t cf_vit_step_tape_floats(int B, int C, int depth);
+int cf_vit_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* xtape, int B, int C, int depth,
+                          int64_t x_bstride, cf_stream_t stream);
+int cf_vit_step_bwd_taped(const float* x, const float* gz, const float* gld, float* gx, const void* ws, const void* wsb,
+                          float* planes, float* ln_partials, const float* xtape, int B, int C, int depth, int64_t x_bstride,
+                          cf_stream_t stream);
+
 /* ---- SplineActivation: monotone rational-quadratic spline, linear tails (layers/activations.py:120-211,
  * layers/splines/rational_quadratic.py:21-176) ----------------------------------------------------- */
 /* knot tables: P parameter sets (1 = shared weights, C*H*W = individual_weights) of K bins;

@@ -856,6 +856,43 @@ def test_smap_backward_is_additive_over_the_batch(L):
     print("additivity of the smap backward over 5003 = 2049 + 2954 samples: worst relative difference %.2e" % worst)
 
 
+@pytest.mark.parametrize("B", [3, 37, 70])
+def test_smap_taped_backward_equals_the_recompute_form(L, B):
+    """Transformer steps at saturating batches keep the residual stream of the forward (cf_vit_step_fwd_taped) and the backward
+    kernel starts from it (cf_vit_step_bwd_taped) instead of running the layers again: forced at small, ragged batches
+    (the 8-samples-per-wave forward), its gradients equal those of the recompute form to fp32 rounding - the forward's
+    residual stream and the row-split kernel's differ by summation order only - and the log-densities are the same bits."""
+    import contextflow_amd.layers.flowsequential as fs
+    from contextflow_amd.layers.coupling import TransCoupling
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e("smap")
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, 25, 8, 1, generator=g)
+    eps = torch.randn(B, 1, 8, 1, generator=g)
+    wts = torch.randn(B, 1, generator=g).to(DEV)
+
+    def run(taped):
+        keep, keep_t = TransCoupling.STEP_RS_MAX_BATCH, fs.VSTEP_TAPE
+        TransCoupling.STEP_RS_MAX_BATCH, fs.VSTEP_TAPE = 0, taped
+        try:
+            model = build_model("smap", params)
+            set_noise(model, None, [eps])
+            model.train()
+            _, logp = model(x.to(DEV))
+            (logp * wts).sum().backward()
+            return logp.detach(), {k: p.grad.detach().double() for k, p in model.named_parameters() if p.grad is not None}
+        finally:
+            TransCoupling.STEP_RS_MAX_BATCH, fs.VSTEP_TAPE = keep, keep_t
+    lp_t, gt_ = run(True)
+    lp_r, gr_ = run(False)
+    assert torch.equal(lp_t, lp_r)
+    assert gt_.keys() == gr_.keys() and len(gt_) >= 500
+    for k in gt_:
+        scale = max(gr_[k].abs().max().item(), 1e-12)
+        assert torch.isfinite(gt_[k]).all(), k
+        assert (gt_[k] - gr_[k]).abs().max().item() <= 2e-5 * scale, (k, (gt_[k] - gr_[k]).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("D,H,W,M,K,B", [(8, 16, 16, 10, 5, 7), (16, 8, 8, 10, 5, 9), (64, 4, 4, 10, 5, 6), (8, 7, 7, 3, 2, 5),
                                            (4, 14, 14, 2, 3, 3), (2, 40, 32, 2, 2, 5), (3, 1, 1, 4, 1, 2)])
 def test_gmm_ctx_kernels_against_torch(L, D, H, W, M, K, B):
