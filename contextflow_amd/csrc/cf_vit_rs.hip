@@ -32,10 +32,13 @@ namespace {
 #ifndef CF_VIT_RS_MINW
 #define CF_VIT_RS_MINW 1
 #endif
-template <class V>
+// DUMP (training forward): the residual stream at the depth + 1 layer boundaries also goes to xtape ([boundary][DIM][T],
+// as cf_vit_step_fwd_taped writes it) - the owner's tile, 64 contiguous bytes per feature row.
+template <class V, bool DUMP = false>
 __global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float* __restrict__ x, float* __restrict__ z,
                                                      float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                     int64_t xbs, int depth, float* __restrict__ hout) {
+                                                     int64_t xbs, int depth, float* __restrict__ hout,
+                                                     float* __restrict__ xtape = nullptr, int64_t T = 0) {
     constexpr int C = V::C, CIN = V::CIN, HW = V::HW, DIM = V::DIM, PD = V::PD, TOK = V::TOK, POSC = V::POSC;
     __shared__ __align__(16) float lds[V::LDS_FLOATS];
     float* XIN = lds + V::P_XIN;     // [4 KS_C][32 positions]   step input, channel-major
@@ -109,6 +112,16 @@ __global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float
         }
         __syncthreads();
     }
+    auto dump = [&](int bnd) {
+        if constexpr (DUMP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * w + 4 * g + r;
+                if (f < DIM) xtape[((int64_t)bnd * DIM + f) * T + blockIdx.x * TOK + col] = X[r];
+            }
+        }
+    };
+    dump(0);
     // ================= transformer                                                 (simple_vit.py:56-88)
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
@@ -198,6 +211,7 @@ __global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float
             X += a;
 #pragma unroll
             for (int r = 0; r < 4; ++r) XA[(16 * w + 4 * g + r) * TOK + col] = X[r];
+            dump(l + 1);
         }
         __syncthreads();
     }
@@ -280,6 +294,19 @@ int cf_vit_step_rs_fwd(const float* x, float* z, float* ldj_acc, const void* ws,
     if (C != 26) { cf_set_error("cf_vit_step_rs_fwd: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
     k_vit_step_rs<RS26><<<dim3((unsigned)((B + 3) / 4)), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, (const float*)ws, B,
                                                                                    x_bstride, depth, h_out);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// training forward: cf_vit_step_rs_fwd that also writes the residual-stream tape of cf_vit_step_fwd_taped (same layout and size)
+int cf_vit_step_rs_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* xtape, int B, int C, int depth,
+                             int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0) return 0;
+    CF_REQUIRE(x && z && ldj_acc && ws && xtape && B > 0 && depth >= 1 && x_bstride >= (int64_t)C * 8);
+    if (C != 26) { cf_set_error("cf_vit_step_rs_fwd_taped: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
+    k_vit_step_rs<RS26, true><<<dim3((unsigned)((B + 3) / 4)), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, (const float*)ws, B,
+                                                                                         x_bstride, depth, nullptr, xtape,
+                                                                                         4ll * ((B + 31) / 32 * 32));
     CF_LAUNCH_CHECK();
     return 0;
 }

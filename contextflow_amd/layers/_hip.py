@@ -108,6 +108,7 @@ SIGNATURES = {
     "cf_vit_step_tape_tokens": (_c_i64, [_c_int]),
     "cf_vit_step_tape_floats": (_c_i64, [_c_int] * 3),
     "cf_vit_step_fwd_taped": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
+    "cf_vit_step_rs_fwd_taped": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
     "cf_linear_wgrad_group_ws_bytes": (_c_i64, [_c_p] * 3 + [_c_int]),
     "cf_linear_wgrad_group": (_c_int, [_c_p] * 7 + [_c_int, _c_p, _c_p]),
     "cf_spline_table_floats": (_c_i64, [_c_int, _c_int]),

@@ -299,8 +299,8 @@ class TransCoupling(_AffineCoupling):
         depth = len(self.NN[0].transformer.layers)
         z = torch.empty(B, C, x.shape[2], x.shape[3], device=x.device, dtype=torch.float32)
         if xtape is not None:
-            assert variant == "wave" and h_out is None
-            _hip.call("cf_vit_step_fwd_taped", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), _hip.p(xtape), B, C, depth, xbs,
+            assert h_out is None
+            _hip.call("cf_vit_step_rs_fwd_taped" if variant == "rs" else "cf_vit_step_fwd_taped", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), _hip.p(xtape), B, C, depth, xbs,
                       _hip.stream())
             return z
         events = VIT_EVENTS

@@ -39,7 +39,7 @@ from .transforms import LogitTransform
 TAPE_PLANES = True
 
 
-VSTEP_TAPE = True        # transformer steps at saturating batches: keep the residual-stream tape (False: the backward recomputes)
+VSTEP_TAPE = True        # transformer steps in training: keep the residual-stream tape (False: the backward kernel recomputes it)
 
 
 def step_tape(B, C, H, W, dev):
@@ -388,10 +388,10 @@ class FlowSequential(nn.Module):
                 ws, ev = prepared[k]
                 if tape is not None:         # training: the same one-kernel forward; the backward re-runs the step from its input
                     #                          (and reuses the packed forward table when it is the row-split one)
-                    # saturating batches (the register-resident forward): the residual stream at the layer boundaries goes to a
-                    # tape (5.8 KB per sample and step) and the backward kernel does not run the six layers a second time
+                    # the residual stream at the layer boundaries goes to a tape (5.8 KB per sample and step) and the backward
+                    # kernel does not run the six layers a second time
                     xt = None
-                    if vkey[k] == "wave" and VSTEP_TAPE:
+                    if VSTEP_TAPE:
                         depth = len(op[3].NN[0].transformer.layers)
                         xt = torch.empty(_hip.lib().cf_vit_step_tape_floats(B, x.shape[1], depth), device=dev, dtype=torch.float32)
                     tape.append(("vstep", x, op[1], op[2], op[3], ws if vkey[k] == "rs" else None, xt))

@@ -404,6 +404,8 @@ int64_t cf_vit_step_tape_tokens(int B);
 int64_t cf_vit_step_tape_floats(int B, int C, int depth);
 int cf_vit_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* xtape, int B, int C, int depth,
                           int64_t x_bstride, cf_stream_t stream);
+int cf_vit_step_rs_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* xtape, int B, int C, int depth,
+                             int64_t x_bstride, cf_stream_t stream);       /* the row-split (small-batch) forward, same tape */
 int cf_vit_step_bwd_taped(const float* x, const float* gz, const float* gld, float* gx, const void* ws, const void* wsb,
                           float* planes, float* ln_partials, const float* xtape, int B, int C, int depth, int64_t x_bstride,
                           cf_stream_t stream);

@@ -886,6 +886,16 @@ def test_smap_taped_backward_equals_the_recompute_form(L, B):
     lp_t, gt_ = run(True)
     lp_r, gr_ = run(False)
     assert torch.equal(lp_t, lp_r)
+    # the row-split forward (the default at these batch sizes) tapes the same stream
+    model = build_model("smap", params)
+    set_noise(model, None, [eps])
+    model.train()
+    _, logp = model(x.to(DEV))
+    (logp * wts).sum().backward()
+    for k, p_ in model.named_parameters():
+        if p_.grad is not None:
+            scale = max(gr_[k].abs().max().item(), 1e-12)
+            assert (p_.grad.double() - gr_[k]).abs().max().item() <= 2e-5 * scale, k
     assert gt_.keys() == gr_.keys() and len(gt_) >= 500
     for k in gt_:
         scale = max(gr_[k].abs().max().item(), 1e-12)
