@@ -160,17 +160,24 @@ __device__ __forceinline__ void gmm_logprob_body(const float* __restrict__ x, co
                 av[j] = *reinterpret_cast<const f32x2*>(&as_[(tm + 16 * j) * LD + dd]);
                 bv[j] = *reinterpret_cast<const f32x2*>(&bs[(tm + 16 * j) * LD + dd]);
             }
+            // the reference's form (x - mu) / sigma (gaussian.py:142-161): the difference of two close values is exact,
+            // whereas fma(x, 1/sigma, -mu/sigma) carries the rounding of mu/sigma - an absolute error of ulp(mu/sigma) on a
+            // term of size O(1) once a mixture is fitted with small sigma (SMAP "extreme" fixtures: 1.7e-5 bits/dim).  One
+            // more packed VALU per term than the fma form.  Written stage by stage over the MKT components of a sample: left
+            // to itself hipcc chains add -> mul -> fma of ONE term through one temporary, with a wait state between every
+            // pair of dependent packed instructions (118 s_nop per 240 v_pk in the loop, two waves per SIMD to cover them):
+            // 1.70 -> 1.47 ms per 262 144 samples.  (The 2-way LDS bank conflict of the parameter reads - lanes tm and tm + 8
+            // lie 9 x 32 banks apart - was removed by rotating the column order per lane half and measured: no gain.)
 #pragma unroll
-            for (int i = 0; i < SPT; ++i)
+            for (int i = 0; i < SPT; ++i) {
+                f32x2 t[MKT];
 #pragma unroll
-                for (int j = 0; j < MKT; ++j) {
-                    // the reference's form (x - mu) / sigma (gaussian.py:142-161): the difference of two close values is
-                    // exact, whereas fma(x, 1/sigma, -mu/sigma) carries the rounding of mu/sigma - an absolute error of
-                    // ulp(mu/sigma) on a term of size O(1) once a mixture is fitted with small sigma (SMAP "extreme"
-                    // fixtures: 1.7e-5 bits/dim).  One more packed VALU per term than the fma form.
-                    const f32x2 t = (xv[i] + bv[j]) * av[j];
-                    acc2[i][j] = __builtin_elementwise_fma(t, t, acc2[i][j]);
-                }
+                for (int j = 0; j < MKT; ++j) t[j] = xv[i] + bv[j];
+#pragma unroll
+                for (int j = 0; j < MKT; ++j) t[j] = t[j] * av[j];
+#pragma unroll
+                for (int j = 0; j < MKT; ++j) acc2[i][j] = __builtin_elementwise_fma(t[j], t[j], acc2[i][j]);
+            }
         }
     }
     float acc[SPT][MKT];
