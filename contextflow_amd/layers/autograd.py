@@ -70,10 +70,17 @@ def gmm_backward(x, dist, prepared, g, gcol=None):
 
 
 # ------------------------------------------------------------------------------------------------ flow step
-def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None):
+WGRAD_SIDE_MAX_BATCH = 1024      # below: the weight gradients of a step run on a side stream, next to the data-gradient chain
+
+
+def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None, side=None, keep=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
     planes: the step tape (y0, h1, h2, aux) written by cf_flow_step_fwd_taped, or None = rebuild it from x with the same kernel.
     gsum: 1-element tensor sum(gld) (the same for every step of a backward pass), or None.
+    side / keep (small batches): the weight gradients and the parameter chain - which the data-gradient chain of the steps
+    before does not wait for - are launched on the stream `side` once the backward kernel has written its planes; what they
+    read is appended to `keep` (the caller holds it until it has joined the streams: a block handed back to the allocator could
+    be given out again on the main stream while the side stream still reads it).
     Returns (dL/dx in the layout of x, {param: grad})."""
     C, H, W = shape
     HW, HALF, HID = H * W, C // 2, 2 * C
@@ -109,6 +116,23 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
               pp(s_gy), B, C, H, W, int(bool(squeeze)), st)
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts, the four of a step in one call
     # (cf_step_wgrads: four k_wgrad launches, ONE reduce launch)
+    import contextlib
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(dev))
+        keep.append((s_gh, s_gh2, s_gh1, s_gy, planes, xv, wsb, gzc, winv, gsum))
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        return gx, _step_param_part(conv, act, cpl, (C, H, W), xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1, s_y0,
+                                    Wm, t, logs, winv, gsum, gld, B, dev)
+
+
+def _step_param_part(conv, act, cpl, shape, xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1, s_y0, Wm, t, logs, winv, gsum,
+                     gld, B, dev):
+    """Second half of step_backward: the four weight gradients of the step and the Conv1x1 / ActNorm parameter chain."""
+    C, H, W = shape
+    HW, HALF, HID = H * W, C // 2, 2 * C
+    L = _hip.lib()
+    f, pp, st = _hip.f32, _hip.p, _hip.stream()
+    c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
     e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
     gw3, gb3, gw2, gb2 = e(1, C, HID), e(C), e(HID, HID, 3, 3), e(HID)
     gw1, gb1, gWp, gbp = e(1, HID, HALF), e(HID), e(1, C, C), e(C)
@@ -137,7 +161,7 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
         c2.weight: gw2, c2.bias: gb2,
         c3.weight: gw3.reshape(c3.weight.shape), c3.bias: gb3,
     }
-    return gx, grads
+    return grads
 
 
 # ------------------------------------------------------------------------------------------------ transformer flow step
@@ -271,6 +295,12 @@ class FlowLogProb(torch.autograd.Function):
             for p, g in d.items():
                 acc[p] = g if p not in acc else acc[p] + g
 
+        # small batches: the kernels of a step fill a fraction of the chip, and the weight gradients of step k are off the chain
+        # that leads to step k - 1 - they run on the flow's side stream and meet the main stream once, at the end
+        B0 = glogp.shape[0]
+        dev = glogp.device
+        side = flow._side_stream(dev) if (glogp.is_cuda and B0 <= WGRAD_SIDE_MAX_BATCH) else None
+        keep = []
         gz = None
         for rec in reversed(tape):
             kind = rec[0]
@@ -286,8 +316,12 @@ class FlowLogProb(torch.autograd.Function):
                 gz = torch.cat([gz, g2], dim=1)
             elif kind == "step":
                 _, xin, sq, conv, act, cpl, shape, ws, winv, planes = rec
-                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum)
-                add(gp)
+                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, side, keep)
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        add(gp)
+                else:
+                    add(gp)
             elif kind == "vstep":
                 _, xin, conv, act, cpl, ws_rs, xtape = rec
                 gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape)
@@ -302,4 +336,10 @@ class FlowLogProb(torch.autograd.Function):
                 add(gp)
             else:
                 raise NotImplementedError("no backward for tape record %r" % (kind,))
+        if side is not None:
+            main = torch.cuda.current_stream(dev)
+            main.wait_stream(side)
+            for g in acc.values():
+                g.record_stream(main)
+            del keep
         return (None, None) + tuple(acc.get(p) for p in params)
