@@ -193,7 +193,7 @@ def wgrad_group(members, dev):
     return res
 
 
-def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None):
+def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, side=None, keep=None):
     """Conv1x1 -> ActNorm -> TransCoupling (one fused step of the transformer flows) backwards: ONE kernel re-runs the step
     from its input and walks back (cf_vit_step_bwd), ONE grouped launch contracts the 26 weight-gradient operand pairs it
     leaves (cf_linear_wgrad_group), the LayerNorm gradients are column sums of its per-workgroup partials, and the Conv1x1 /
@@ -222,6 +222,19 @@ def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None):
         _hip.call("cf_vit_step_bwd", pp(xv), pp(f(gz).contiguous()), pp(f(gld)), pp(gx), pp(ws), pp(wsb), pp(planes), pp(lnp), B, C,
                   depth, xbs, st)
     # ---- weight gradients: the planes as (rows, width) matrices (layout: include/contextflow_hip.h, cf_vit_step_bwd)
+    # (small batches: on the side stream, as in step_backward)
+    import contextlib
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(dev))
+        keep.append((planes, lnp, xv, ws, wsb, gsum))
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        return gx, _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, xv.shape[2] * xv.shape[3], Wm, t, logs, gsum,
+                                     gld, dev)
+
+
+def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t, logs, gsum, gld, dev):
+    """Second half of vstep_backward: grouped weight gradients, LayerNorm sums, Conv1x1 / ActNorm parameter chain."""
+    f, pp, st = _hip.f32, _hip.p, _hip.stream()
     Bp = nwg * 4
     R4, P8, PD, DIM = 4 * Bp, 8 * Bp, C, 2 * C
     o = [0]
@@ -263,10 +276,10 @@ def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None):
     _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
     gNN, gt, glogs = torch.empty(C, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
     _hip.call("cf_step_param_grads", pp(gWp.contiguous()), pp(gbp.contiguous()), pp(Wm), pp(t), pp(logs), pp(winv), pp(f(gsum)),
-              xv.shape[2] * xv.shape[3], pp(gNN), pp(gt), pp(glogs), C, st)
+              HW, pp(gNN), pp(gt), pp(glogs), C, st)
     grads[conv.NN] = gNN.view_as(conv.NN)
     grads[act.NN_t], grads[act.NN_logs] = gt.view_as(act.NN_t), glogs.view_as(act.NN_logs)
-    return gx, grads
+    return grads
 
 
 # ------------------------------------------------------------------------------------------------ the Function
@@ -324,8 +337,12 @@ class FlowLogProb(torch.autograd.Function):
                     add(gp)
             elif kind == "vstep":
                 _, xin, conv, act, cpl, ws_rs, xtape = rec
-                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape)
-                add(gp)
+                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape, side, keep)
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        add(gp)
+                else:
+                    add(gp)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)
             elif kind == "pre":
