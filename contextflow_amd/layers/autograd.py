@@ -22,7 +22,7 @@ from .squeeze import squeeze_op
 
 
 # ------------------------------------------------------------------------------------------------ GMM prior
-def gmm_backward(x, dist, prepared, g, gcol=None):
+def gmm_backward(x, dist, prepared, g, gcol=None, side=None, keep=None):
     """x: (B, D...) possibly a channel slice; g: (B, M) upstream; gcol: its column sums (M,) if the caller has them (the
     priors of one backward pass share g).  Returns (gx like x, {param: grad})."""
     a, nm, cst, M, K, D = prepared
@@ -46,6 +46,20 @@ def gmm_backward(x, dist, prepared, g, gcol=None):
     _hip.call("cf_gmm_bwd_gx", pp(xv), pp(G1), pp(G2), pp(gx), B, D, xbs, st)
     # parameter sums over the batch: S1 = r^T x, S2 = r^T x^2 (MK x D) and S0 = column sums of r, as split-K MFMA GEMMs
     # over the samples (cf_linear_wgrad: the bias-gradient column gives S0; x is squared while it is staged for S2)
+    # (small batches: on the side stream - the chain to the previous layer needs gx only)
+    import contextlib
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(dev))
+        keep.append((xv, r, a, nm, gcol))
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        return gx.view(xv.shape), _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev)
+
+
+def _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev):
+    """Second half of gmm_backward: the parameter sums and the gradients of mG / sG / wG."""
+    st, pp = _hip.stream(), _hip.p
+    MK = M * K
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
     S0, S1, S2 = new(MK), new(MK, D), new(MK, D)
     L = _hip.lib()
     if L.cf_gmm_bwd_sums_supported(MK, D) and xbs < (1 << 20):
@@ -65,8 +79,7 @@ def gmm_backward(x, dist, prepared, g, gcol=None):
     wG = _hip.f32(dist.wG.detach()).reshape(M, K)
     _hip.call("cf_gmm_bwd_params_w", pp(a), pp(nm), pp(sG), pp(S0), pp(S1), pp(S2), pp(wG), pp(_hip.f32(gcol)), pp(g_mu), pp(g_sigma),
               pp(g_w), M, K, D, st)
-    grads = {dist.mG: g_mu.view_as(dist.mG), dist.sG: g_sigma.view_as(dist.sG), dist.wG: g_w.view_as(dist.wG)}
-    return gx.view(xv.shape), grads
+    return {dist.mG: g_mu.view_as(dist.mG), dist.sG: g_sigma.view_as(dist.sG), dist.wG: g_w.view_as(dist.wG)}
 
 
 # ------------------------------------------------------------------------------------------------ flow step
@@ -314,18 +327,25 @@ class FlowLogProb(torch.autograd.Function):
         dev = glogp.device
         side = flow._side_stream(dev) if (glogp.is_cuda and B0 <= WGRAD_SIDE_MAX_BATCH) else None
         keep = []
+
+        def add_on(d):               # parameter gradients produced on the side stream are accumulated there
+            if side is not None:
+                with torch.cuda.stream(side):
+                    add(d)
+            else:
+                add(d)
         gz = None
         for rec in reversed(tape):
             kind = rec[0]
             if kind == "prior":
                 _, xin, dist, prep = rec
-                gz, gp = gmm_backward(xin, dist, prep, glogp, gcol)
-                add(gp)
+                gz, gp = gmm_backward(xin, dist, prep, glogp, gcol, side, keep)
+                add_on(gp)
             elif kind == "split":
                 _, xin, dist, prep = rec                      # xin: full tensor before the split
                 c = xin.shape[1] // 2
-                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp, gcol)
-                add(gp)
+                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp, gcol, side, keep)
+                add_on(gp)
                 gz = torch.cat([gz, g2], dim=1)
             elif kind == "step":
                 _, xin, sq, conv, act, cpl, shape, ws, winv, planes = rec
