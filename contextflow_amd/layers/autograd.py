@@ -86,7 +86,7 @@ def _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev):
 WGRAD_SIDE_MAX_BATCH = 1024      # below: the weight gradients of a step run on a side stream, next to the data-gradient chain
 
 
-def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None, side=None, keep=None):
+def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None, side=None, keep=None, wsb=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
     planes: the step tape (y0, h1, h2, aux) written by cf_flow_step_fwd_taped, or None = rebuild it from x with the same kernel.
     gsum: 1-element tensor sum(gld) (the same for every step of a backward pass), or None.
@@ -103,9 +103,10 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
     f, pp, st = _hip.f32, _hip.p, _hip.stream()
     c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
     Wm, t, logs = f(conv.NN.detach()), f(act.NN_t.detach()), f(act.NN_logs.detach())
-    wsb = torch.empty(L.cf_flow_step_bwd_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
-    _hip.call("cf_flow_step_bwd_prepare", pp(Wm), pp(logs), pp(f(c1.weight.detach())), pp(f(c2.weight.detach())),
-              pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
+    if wsb is None:                  # (the training forward packs the backward kernel's fragments on its side stream)
+        wsb = torch.empty(L.cf_flow_step_bwd_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+        _hip.call("cf_flow_step_bwd_prepare", pp(Wm), pp(logs), pp(f(c1.weight.detach())), pp(f(c2.weight.detach())),
+                  pp(f(c3.weight.detach())), pp(wsb), C, H, W, st)
     new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
     # with a Squeeze in front of the step, dL/dx leaves the kernel in the un-squeezed layout of x (index map folded into its stores)
     gx = torch.empty((B, C // 4, 2 * H, 2 * W) if squeeze else (B, C, H, W), device=dev, dtype=torch.float32)
@@ -348,8 +349,8 @@ class FlowLogProb(torch.autograd.Function):
                 add_on(gp)
                 gz = torch.cat([gz, g2], dim=1)
             elif kind == "step":
-                _, xin, sq, conv, act, cpl, shape, ws, winv, planes = rec
-                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, side, keep)
+                _, xin, sq, conv, act, cpl, shape, ws, winv, planes, wsb = rec
+                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, side, keep, wsb)
                 if side is not None:
                     with torch.cuda.stream(side):
                         add(gp)

@@ -289,7 +289,14 @@ class FlowSequential(nn.Module):
                         if tape is not None:     # training: W^-1 for d(log|det W|)/dW from the prepare step's factorisation
                             Cc = op[4][0]
                             winv = torch.empty(Cc, Cc, device=dev, dtype=torch.float32)
-                            buf = (self._prepare_step(op[1], op[2], op[3], op[4], dev, winv), winv)
+                            # ... and the transposed weight fragments of the backward kernel: packed here, on the side stream,
+                            # they are off the chain of the backward pass (at a batch of 256 twelve 18 us launches)
+                            wsb = torch.empty(_hip.lib().cf_flow_step_bwd_ws_bytes(*op[4]), device=dev, dtype=torch.uint8)
+                            c1_, c2_, c3_ = op[3].NN[0], op[3].NN[2], op[3].NN[4]
+                            _hip.call("cf_flow_step_bwd_prepare", _hip.p(_hip.f32(op[1].NN.detach())), _hip.p(_hip.f32(op[2].NN_logs.detach())),
+                                      _hip.p(_hip.f32(c1_.weight.detach())), _hip.p(_hip.f32(c2_.weight.detach())),
+                                      _hip.p(_hip.f32(c3_.weight.detach())), _hip.p(wsb), op[4][0], op[4][1], op[4][2], _hip.stream())
+                            buf = (self._prepare_step(op[1], op[2], op[3], op[4], dev, winv), winv, wsb)
                         else:
                             buf = self._prepare_step(op[1], op[2], op[3], op[4], dev)
                     elif op[0] == "vstep":
@@ -357,7 +364,7 @@ class FlowSequential(nn.Module):
                 if ev is not None:
                     main.wait_event(ev)
                 if tape is not None:
-                    ws, winv = ws
+                    ws, winv, wsb = ws
                     # training: the taping forward kernel writes the step tape and the backward kernel reads it.  If the
                     # planes of this step would take more than 1/64 of the device memory (huge batches), or with
                     # TAPE_PLANES = False, the tape is NOT kept (4.5x less memory per step): the backward then re-runs this
@@ -365,7 +372,7 @@ class FlowSequential(nn.Module):
                     # backward uses are bit for bit those of the forward that produced the loss.
                     keep = TAPE_PLANES and 18 * B * C * H * W <= torch.cuda.get_device_properties(dev).total_memory // 64
                     planes = step_tape(B, C, H, W, dev)
-                    tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws, winv, planes if keep else None))
+                    tape.append(("step", x, sq, conv, act, cpl, (C, H, W), ws, winv, planes if keep else None, wsb))
                     x, xbs = _hip.bview(x)
                     z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
                     _hip.call("cf_flow_step_fwd_taped", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.p(ws), _hip.p(planes[0]),
