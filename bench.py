@@ -33,7 +33,7 @@ LABEL = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap":
 VIT_FLOP_PER_SAMPLE = {"smap": 2 * (26 * 26 * 8 + 454688 + 12288)}
 # what k_vit_step's MFMAs execute per sample (2 148 v_mfma_f32_32x32x2_f32 of 4 096 flop per wave of 8 samples)
 VIT_MFMA_FLOP_PER_SAMPLE = {"smap": 2148 * 4096 // 8}
-TRAFFIC_JSON = {"cifar10": "r3_prof1_traffic.json", "mnist": "r2_mnist3_traffic.json", "smap": "r3_smap1_traffic.json"}
+TRAFFIC_JSON = {"cifar10": "r3_prof2_traffic.json", "mnist": "r2_mnist3_traffic.json", "smap": "r3_smap1_traffic.json"}
 
 
 def step_flop(C, HW):
