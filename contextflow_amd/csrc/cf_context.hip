@@ -269,7 +269,10 @@ __global__ __launch_bounds__(256) void k_affine_ctx(const float* __restrict__ x,
 //   SQ: i = 4 q + 2 dy + dx with q = 4 g + kk, e = 2 dy + dx - the four k-steps of a lane are the four phases of ONE channel
 //     of the un-squeezed tensor: rows 2 y, 2 y + 1, 8 (2) consecutive floats each.
 // tril / exp(diag) / + NN - I are applied to the A fragments in registers; t_b, logs_b come as float4 per (row tile, kk).
-template <int C, int W, bool SQ>
+// BLK: m1 holds only the 16 x 16 blocks on and below the diagonal of the per-sample matrix, block (rt, g <= rt) at
+// (rt (rt + 1) / 2 + g) * 256, row-major inside (the caller permutes the rows of Conv1x1.CN accordingly): the blocks above the
+// diagonal are never needed, and a fragment load is 1 KB of contiguous memory instead of 16 runs of 64 bytes.
+template <int C, int W, bool SQ, bool BLK>
 __global__ __launch_bounds__(256) void k_affine_ctx_wave(const float* __restrict__ x, const float* __restrict__ m1,
                                                          const float* __restrict__ Wm, const float* __restrict__ m2,
                                                          const float* __restrict__ t, const float* __restrict__ logs,
@@ -280,7 +283,8 @@ __global__ __launch_bounds__(256) void k_affine_ctx_wave(const float* __restrict
     const int lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;                                // a whole wave: the kernel has no barrier
-    const float* mb = m1 + (int64_t)b * C * C;
+    constexpr int NBLK = (C / 16) * (C / 16 + 1) / 2;
+    const float* mb = m1 + (int64_t)b * (BLK ? NBLK * 256 : C * C);
     const float* xb = x + (int64_t)b * xbs;
     // ---- A fragments.  W_b is block lower triangular on the 16 x 16 grid of fragments: blocks above the diagonal hold NN alone
     // (never read from m1), blocks below m1 + NN, the diagonal blocks the element-wise tril / exp(diag) / - I.
@@ -289,7 +293,9 @@ __global__ __launch_bounds__(256) void k_affine_ctx_wave(const float* __restrict
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            a[rt][g] = g <= rt ? *reinterpret_cast<const float4*>(mb + (16 * rt + n) * C + 16 * g + 4 * kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[rt][g] = g <= rt ? *reinterpret_cast<const float4*>(BLK ? mb + (rt * (rt + 1) / 2 + g) * 256 + n * 16 + 4 * kk
+                                                                        : mb + (16 * rt + n) * C + 16 * g + 4 * kk)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -974,10 +980,17 @@ int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, fl
     return 0;
 }
 
+// number of floats per sample of the blocked form of m1 (cf_affine_ctx_fwd, m1_blocked != 0), 0 where it is not offered
+int cf_affine_ctx_blocked_floats(int C, int H, int W) {
+    const bool wave = H == W && ((C == 16 && W == 16) || (C == 32 && W == 8) || (C == 64 && W == 4));
+    return wave ? (C / 16) * (C / 16 + 1) / 2 * 256 : 0;
+}
+
 int cf_affine_ctx_fwd(const float* x, const float* m1, const float* Wm, const float* m2, const float* t, const float* logs,
                       const float* lad, float cadd, float* z, float* ldj, int B, int C, int H, int W, int64_t x_bstride,
-                      int in_squeeze, int accumulate, cf_stream_t stream) {
+                      int in_squeeze, int accumulate, int m1_blocked, cf_stream_t stream) {
     if (B == 0) return 0;
+    CF_REQUIRE(!m1_blocked || cf_affine_ctx_blocked_floats(C, H, W) > 0);
     CF_REQUIRE(x && m1 && m2 && z && ldj && B >= 0 && C > 0 && C <= 256 && H > 0 && W > 0 && ((t == nullptr) == (logs == nullptr)) &&
                x_bstride >= (int64_t)C * H * W && (!in_squeeze || C % 4 == 0));
     // the image flows' three levels: one wave per sample on the matrix pipe, operands straight from global memory
@@ -986,13 +999,16 @@ int cf_affine_ctx_fwd(const float* x, const float* m1, const float* Wm, const fl
                       reinterpret_cast<uintptr_t>(logs)) & 15) == 0 && x_bstride % 4 == 0;
     if (al && H == W && ((C == 16 && W == 16) || (C == 32 && W == 8) || (C == 64 && W == 4))) {
         const dim3 grid((B + 3) / 4), blk(256);
-#define CF_AFF(CC, WW) do { if (in_squeeze) k_affine_ctx_wave<CC, WW, true><<<grid, blk, 0, cf_s(stream)>>>(x, m1, Wm, m2, t, logs, lad, cadd, z, ldj, B, x_bstride, accumulate); \
-                            else k_affine_ctx_wave<CC, WW, false><<<grid, blk, 0, cf_s(stream)>>>(x, m1, Wm, m2, t, logs, lad, cadd, z, ldj, B, x_bstride, accumulate); } while (0)
+#define CF_AFF2(CC, WW, SQV, BLV) k_affine_ctx_wave<CC, WW, SQV, BLV><<<grid, blk, 0, cf_s(stream)>>>(x, m1, Wm, m2, t, logs, lad, cadd, z, ldj, B, x_bstride, accumulate)
+#define CF_AFF(CC, WW) do { if (in_squeeze) { if (m1_blocked) CF_AFF2(CC, WW, true, true); else CF_AFF2(CC, WW, true, false); } \
+                            else { if (m1_blocked) CF_AFF2(CC, WW, false, true); else CF_AFF2(CC, WW, false, false); } } while (0)
         if (C == 16) CF_AFF(16, 16); else if (C == 32) CF_AFF(32, 8); else CF_AFF(64, 4);
 #undef CF_AFF
+#undef CF_AFF2
         CF_LAUNCH_CHECK();
         return 0;
     }
+    CF_REQUIRE(!m1_blocked);                             // (the blocked form exists for the wave kernel's shapes and needs their alignment)
     const size_t lds = (size_t)(C * conv1x1_ctx_cp(C) + C * H * W + 4 + 2 * C + C * C) * sizeof(float);
     if (lds > 160 * 1024) { cf_set_error("cf_affine_ctx_fwd: C=%d, H*W=%d need %zu B of LDS", C, H * W, lds); return CF_ERR_UNSUPPORTED; }
     if (lds > 64 * 1024) {

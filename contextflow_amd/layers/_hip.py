@@ -137,7 +137,8 @@ SIGNATURES = {
     "cf_cond_gauss_sample": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_p]),
     "cf_activation": (_c_int, [_c_p] * 3 + [_c_i64, _c_int, _c_int, _c_f, _c_f, _c_p, _c_int, _c_p]),
     "cf_sigmoid_ldj": (_c_int, [_c_p] * 3 + [_c_int, _c_int, _c_p]),
-    "cf_affine_ctx_fwd": (_c_int, [_c_p] * 7 + [ctypes.c_float] + [_c_p] * 2 + [_c_int] * 4 + [_c_i64, _c_int, _c_int, _c_p]),
+    "cf_affine_ctx_blocked_floats": (_c_int, [_c_int] * 3),
+    "cf_affine_ctx_fwd": (_c_int, [_c_p] * 7 + [ctypes.c_float] + [_c_p] * 2 + [_c_int] * 4 + [_c_i64, _c_int, _c_int, _c_int, _c_p]),
     "cf_ctx_encode": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),
     "cf_conv1x1_ctx": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
     "cf_actnorm_ctx": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_i64, _c_p]),

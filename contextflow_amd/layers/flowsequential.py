@@ -89,8 +89,9 @@ class FlowSequential(nn.Module):
         `.to()` are noticed without it."""
         self._prep.clear()
         self._graphs.clear()
-        self.__dict__.pop("_spec_ws", None)          # layers/specialist.py: packed coupling tables, log|det NN| of frozen Conv1x1
-        self.__dict__.pop("_spec_lad", None)
+        self.__dict__.pop("_spec_ws", None)          # layers/specialist.py: packed coupling tables, log|det NN| of frozen Conv1x1,
+        self.__dict__.pop("_spec_lad", None)         # Conv1x1.CN in blocked row order
+        self.__dict__.pop("_spec_cnb", None)
         for m in self.modules():
             if hasattr(m, "_tab_cache"):
                 m._tab_cache = None
@@ -101,6 +102,7 @@ class FlowSequential(nn.Module):
         self._prep, self._graphs, self._plans, self._tensors = {}, {}, {}, None
         self.__dict__.pop("_spec_ws", None)
         self.__dict__.pop("_spec_lad", None)
+        self.__dict__.pop("_spec_cnb", None)
         return super()._apply(fn, *a, **k)
 
     def _versions(self):

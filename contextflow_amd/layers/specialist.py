@@ -103,6 +103,32 @@ def _lad(flow, conv, dev):
     return lad
 
 
+def blocked_rows(C):
+    """Row order of Conv1x1.CN for the blocked form of the per-sample matrix (cf_affine_ctx_fwd, m1_blocked): the 16 x 16
+    blocks (rt, g <= rt) on and below the diagonal, row-major inside - entry (16 rt + n, 16 g + c) of the (C, C) matrix."""
+    idx = []
+    for rt in range(C // 16):
+        for g in range(rt + 1):
+            for n in range(16):
+                idx.extend((16 * rt + n) * C + 16 * g + c for c in range(16))
+    return idx
+
+
+def _cn_blocked(flow, conv, C, dev):
+    """Conv1x1.CN with its rows in blocked order (weight (Nc, width), bias (Nc)), kept while the CN parameters are unchanged:
+    the blocks above the diagonal of the per-sample matrix are never computed, written or read."""
+    cache = flow.__dict__.setdefault("_spec_cnb", {})
+    w, b = conv.CN.weight, conv.CN.bias
+    ver = (w._version, b._version, w.data_ptr(), b.data_ptr(), str(dev))
+    hit = cache.get(id(conv))
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    idx = torch.tensor(blocked_rows(C), device=dev, dtype=torch.long)
+    wp, bp = _hip.f32(w.detach())[idx].contiguous(), _hip.f32(b.detach())[idx].contiguous()
+    cache[id(conv)] = (ver, wp, bp)
+    return wp, bp
+
+
 def supported(flow):
     """True when the plan below has something to fuse: a specialist model with at least one Conv1x1(c) -> ActNorm(c') pair."""
     mods = flow.sequence_modules
@@ -153,7 +179,16 @@ def forward_eval(flow, x, context):
             xv, xbs = _hip.bview(x)
             c1, lp1 = conv.context_net(context)
             c2, lp2 = act.context_net(context)
-            m1 = _linear(f(c1), conv.CN)                       # (B, C*C)
+            nblk = _hip.lib().cf_affine_ctx_blocked_floats(C, H, W) if xbs % 4 == 0 and xv.data_ptr() % 16 == 0 else 0
+            if nblk and nblk < C * C:                          # (B, 10/16 C*C) at C = 64, 3/4 at C = 32: lower blocks only
+                wp, bp = _cn_blocked(flow, conv, C, dev)
+                c1f = f(c1)
+                m1 = torch.empty(B, nblk, device=dev, dtype=torch.float32)
+                _hip.call("cf_linear", pp(c1f), pp(wp), pp(bp), None, pp(m1), B, c1f.shape[1], nblk, 0, st)
+                blocked = 1
+            else:
+                m1 = _linear(f(c1), conv.CN)                   # (B, C*C)
+                blocked = 0
             m2 = _linear(f(c2), act.CN)                        # (B, 2C)
             cadd = 0.0
             for net, lp in ((conv.context_net, lp1), (act.context_net, lp2)):
@@ -169,7 +204,7 @@ def forward_eval(flow, x, context):
             z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
             buf, accum = acc.buffer()
             _hip.call("cf_affine_ctx_fwd", pp(xv), pp(m1), pp(Wm), pp(m2), pp(t), pp(logs), pp(lad), cadd, pp(z), pp(buf), B, C, H, W,
-                      xbs, int(sq), accum, st)
+                      xbs, int(sq), accum, blocked, st)
             x = z
             i = j + 2
             continue

@@ -460,10 +460,15 @@ int cf_conv1x1_ctx(const float* x, const float* m, const float* Wm, float* z, fl
  *   z[b] = (W_b x[b] - t_b) exp(-logs_b);   ldj[b] (+)= H W (sum diag m1[b] + lad[0]) + sum_c logs_b + cadd
  * (the two layers' own log-dets, reference quirks included: H W log|det NN| for Conv1x1, no H W factor for ActNorm).
  * lad: device scalar log|det NN| or NULL; cadd: a host constant (the encoders' constant log-densities).
- * in_squeeze != 0: x is the un-squeezed (B, C/4, 2H, 2W) tensor, Squeeze((2,2)) folded into the reads.                */
+ * in_squeeze != 0: x is the un-squeezed (B, C/4, 2H, 2W) tensor, Squeeze((2,2)) folded into the reads.                
+ * m1_blocked != 0 (offered where cf_affine_ctx_blocked_floats(C, H, W) > 0: the image flows' three levels): m1 is
+ * (B, cf_affine_ctx_blocked_floats) - only the 16 x 16 blocks on and below the diagonal of the per-sample matrix, block
+ * (rt, g <= rt) at (rt (rt + 1) / 2 + g) * 256, row-major inside; the caller evaluates Conv1x1.CN with its rows permuted
+ * to that order (layers/specialist.py::_cn_blocked): 10 / 16 of the bytes at C = 64, every fragment load contiguous.  */
+int cf_affine_ctx_blocked_floats(int C, int H, int W);
 int cf_affine_ctx_fwd(const float* x, const float* m1, const float* Wm, const float* m2, const float* t, const float* logs,
                       const float* lad, float cadd, float* z, float* ldj, int B, int C, int H, int W, int64_t x_bstride,
-                      int in_squeeze, int accumulate, cf_stream_t stream);
+                      int in_squeeze, int accumulate, int m1_blocked, cf_stream_t stream);
 /* ActNorm with a context net (actnorm.py:40-60): m (B, 2C) = CN(c) = [t_b | logs_b] (+ t, logs when non-NULL:
  * contextflow); z = (x - t_b) exp(-logs_b); ldj[b] = sum_c logs_b.                                             */
 int cf_actnorm_ctx(const float* x, const float* m, const float* t, const float* logs, float* z, float* ldj, int B, int C,

@@ -279,9 +279,23 @@ def test_fused_specialist_affine_equals_its_two_layers(L, C, H, W, B, cf, sq):
         z = torch.full((B, C, H, W), float("nan"), device=DEV)
         ldj = torch.full((B,), 2.5, device=DEV)
         _hip.call("cf_affine_ctx_fwd", P(xv), P(d(m1)), P(d(Wm)), P(d(m2)), P(d(t)), P(d(logs)), P(d(lad)), cadd, P(z), P(ldj), B, C, H, W,
-                  wide.stride(0), int(sq), accumulate, st)
+                  wide.stride(0), int(sq), accumulate, 0, st)
         assert (z - z2).abs().max().item() <= 2e-5 * max(1.0, z2.abs().max().item())
         assert (ldj - (want_l + (2.5 if accumulate else 0.0))).abs().max().item() <= 2e-5 * max(1.0, want_l.abs().max().item())
+    # blocked form of m1 (the 16 x 16 blocks on and below the diagonal only): same bits as the dense form
+    nblk = _hip.lib().cf_affine_ctx_blocked_floats(C, H, W)
+    assert (nblk > 0) == ((C, H, W) in ((16, 16, 16), (32, 8, 8), (64, 4, 4)))
+    if nblk:
+        from contextflow_amd.layers.specialist import blocked_rows
+        idx = torch.tensor(blocked_rows(C))
+        assert idx.numel() == nblk
+        zb, lb_ = torch.full((B, C, H, W), float("nan"), device=DEV), torch.empty(B, device=DEV)
+        _hip.call("cf_affine_ctx_fwd", P(xv), P(d(m1[:, idx])), P(d(Wm)), P(d(m2)), P(d(t)), P(d(logs)), P(d(lad)), cadd, P(zb), P(lb_), B, C,
+                  H, W, wide.stride(0), int(sq), 0, 1, st)
+        zd, ld_ = torch.empty_like(zb), torch.empty(B, device=DEV)
+        _hip.call("cf_affine_ctx_fwd", P(xv), P(d(m1)), P(d(Wm)), P(d(m2)), P(d(t)), P(d(logs)), P(d(lad)), cadd, P(zd), P(ld_), B, C, H, W,
+                  wide.stride(0), int(sq), 0, 0, st)
+        assert torch.equal(zb, zd) and torch.equal(lb_, ld_)
     # fp64 formula
     xd = (squeeze_op(xv, (2, 2), False) if sq else xv).double().cpu().reshape(B, C, HW)
     M1 = m1.double().view(B, C, C)
