@@ -89,7 +89,11 @@ class UniformCatDequantization(nn.Module):
         An out-of-range code gives an all-zero one-hot block (torch's one_hot would raise)."""
         dev = self.qbins.device
         B, width = context.shape[0], self.D
-        u = self.fixed_noise if self.fixed_noise is not None else torch.rand((B, width), device=dev, dtype=torch.float32)
+        u = self.fixed_noise
+        if u is None:
+            u = self.__dict__.pop("_noise_once", None)          # a slice of one draw for all encoders of a forward (specialist.py)
+            if u is None or u.shape != (B, width):
+                u = torch.rand((B, width), device=dev, dtype=torch.float32)
         z = torch.empty(B, width, device=dev, dtype=torch.float32)
         code = context.to(device=dev, dtype=torch.int64).contiguous()
         _hip.call("cf_ctx_encode", _hip.p(code), _hip.p(_hip.f32(u)), _hip.p(self.qbins), _hip.p(card), _hip.p(z), B,
