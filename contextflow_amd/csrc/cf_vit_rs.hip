@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float
             }
         }
     };
-    dump(0);
+    // (boundary 0, the embedding output, is rebuilt by the backward kernel together with the statistics it needs: not taped)
     // ================= transformer                                                 (simple_vit.py:56-88)
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
                 }
         }
     };
-    dump(0);
+    // (boundary 0, the embedding output, is rebuilt by the backward kernel together with the statistics it needs: not taped)
     // ================= transformer                                                 (simple_vit.py:56-88)
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {

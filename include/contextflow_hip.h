@@ -396,7 +396,7 @@ int cf_vit_step_bwd(const float* x, const float* gz, const float* gld, float* gx
 
 /* Taped pair for saturating batches (the register-resident forward): cf_vit_step_fwd_taped = cf_vit_step_fwd that also writes
  * the residual stream of the conditioner at its depth + 1 layer boundaries to xtape - cf_vit_step_tape_floats(B, C, depth)
- * floats, feature-major [boundary][2C][T], T = cf_vit_step_tape_tokens(B) = 4 x (B rounded up to 32), token = 4 sample + n
+ * floats, feature-major [boundary][2C][T] (slot 0, the embedding output, is left unwritten: the backward rebuilds it), T = cf_vit_step_tape_tokens(B) = 4 x (B rounded up to 32), token = 4 sample + n
  * (5.8 KB per sample at C = 26, depth 6).  cf_vit_step_bwd_taped = cf_vit_step_bwd that starts from that tape: the Conv1x1 /
  * ActNorm / patch embedding are re-run (their statistics are needed on the way back), the transformer layers are not - a
  * quarter of the kernel's work.  Same outputs to fp32 rounding.                                                          */
