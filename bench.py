@@ -29,12 +29,15 @@ LABEL = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap":
 # Algorithmic flop of ONE launch of the dominant kernel per sample (counted on the reference with hooks):
 #  conv flows: k_flow_step = Conv1x1 (C^2 HW MAC) + coupling net (C/2*2C + 9*2C*2C + 2C*C = 39 C^2 MAC per pixel)
 #              = 2 * 40 C^2 HW flop  (cifar10: 5 242 880 at every level; mnist: 1 310 720 at C = 8, 5 242 880 at C = 32);
-#  smap: k_vit_step = Conv1x1 26x26x8 + SimpleViT linears 454 688 + attention QK^T / PV 12 288 MAC = 944 768 flop.
-VIT_FLOP_PER_SAMPLE = {"smap": 2 * (26 * 26 * 8 + 454688 + 12288)}
-# what k_vit_step's MFMAs execute per sample (2 148 v_mfma_f32_32x32x2_f32 of 4 096 flop per wave of 8 samples)
-VIT_MFMA_FLOP_PER_SAMPLE = {"smap": 2148 * 4096 // 8}
-TRAFFIC_JSON = {"cifar10": "r3_prof2_traffic.json", "mnist": "r2_mnist3_traffic.json", "smap": "r3_smap1_traffic.json"}
+#  smap: k_vit_step = Conv1x1 26x26x8 + SimpleViT linears 454 688 + attention QK^T / PV 12 288 MAC = 944 768 flop (the
+#        library reports it, and what its MFMAs execute: cf_vit_step_macs).
+VIT_STEP = {"smap": (26, 6)}                                              # (C, depth) of the one-kernel transformer step
+TRAFFIC_JSON = {"cifar10": "r3_prof2_traffic.json", "mnist": "r4_mnist1_traffic.json", "smap": "r4_smap1_traffic.json"}
 
+
+def vit_flop_per_sample(name, what):
+    from contextflow_amd.layers import _hip
+    return 2 * _hip.lib().cf_vit_step_macs(VIT_STEP[name][0], VIT_STEP[name][1], what)
 
 def step_flop(C, HW):
     return 80 * C * C * HW
@@ -138,7 +141,7 @@ def kernel_events(model, name):
     """Turn on the HIP-event probes around the dominant kernel of this workload; returns the list they fill."""
     from contextflow_amd.layers import coupling
     ev = []
-    if name in VIT_FLOP_PER_SAMPLE:
+    if name in VIT_STEP:
         coupling.VIT_EVENTS = ev
     else:
         model.step_events = ev
@@ -147,20 +150,24 @@ def kernel_events(model, name):
 
 def roofline(events, name, dt):
     """Roofline of the dominant kernel (fp32 MFMA) from the HIP events around its launches.  `achieved` / `frac` count the
-    multiply-adds the matrix pipe EXECUTED (the library reports them per launch: cf_flow_step_macs - the Winograd
-    F(2x2,3x3) form of the 3x3 runs 16 of its 36 C^2 HW), so frac <= 1 by construction; `algorithmic_tflops` is the
-    reference's direct-convolution flop over the same time and `algorithmic_speedup` their ratio."""
+    USEFUL multiply-adds the matrix pipe executed, so frac <= 1 by construction: for the conv step kernels what the library
+    reports per launch (cf_flow_step_macs - the Winograd F(2x2,3x3) form of the 3x3 runs 16 of its 36 C^2 HW; those kernels
+    have no padding rows), for the transformer step cf_vit_step_macs(.., 2) - its fused 52 x 52 products WITHOUT the padding
+    rows of the 32-row tiles (the padding-inclusive rate is `executed_incl_padding_tflops`).  `algorithmic_tflops` is the
+    reference's flop count over the same time, `algorithmic_frac` that over the peak (it may exceed 1: both
+    kernels run fewer multiplications than the reference's formulation) and `algorithmic_speedup` = algorithmic / useful."""
     if not events:
         return None
     from contextflow_amd.layers import _hip
     L = _hip.lib()
-    vit = name in VIT_FLOP_PER_SAMPLE
+    vit = name in VIT_STEP
     ms = sum(e[0].elapsed_time(e[1]) for e in events)
-    alg = lambda e: e[2] * (VIT_FLOP_PER_SAMPLE[name] if vit else step_flop(e[3], e[4]))
     hw = lambda e: int(round(math.sqrt(e[4])))
-    exe = lambda e: e[2] * (VIT_MFMA_FLOP_PER_SAMPLE[name] if vit else 2 * L.cf_flow_step_macs(e[2], e[3], hw(e), hw(e), 0))
-    flop, flop_exec = sum(alg(e) for e in events), sum(exe(e) for e in events)
-    ach, ach_exec = flop / (ms * 1e-3) / 1e12, flop_exec / (ms * 1e-3) / 1e12
+    alg = lambda e: e[2] * (vit_flop_per_sample(name, 0) if vit else step_flop(e[3], e[4]))
+    exe = lambda e: e[2] * (vit_flop_per_sample(name, 2) if vit else 2 * L.cf_flow_step_macs(e[2], e[3], hw(e), hw(e), 0))
+    pad = lambda e: e[2] * (vit_flop_per_sample(name, 1) if vit else 2 * L.cf_flow_step_macs(e[2], e[3], hw(e), hw(e), 0))
+    flop, flop_exec, flop_pad = sum(alg(e) for e in events), sum(exe(e) for e in events), sum(pad(e) for e in events)
+    ach, ach_exec, ach_pad = (f / (ms * 1e-3) / 1e12 for f in (flop, flop_exec, flop_pad))
     per = {}
     for e in events:
         k = "vit" if vit else "C%d" % e[3]
@@ -174,19 +181,24 @@ def roofline(events, name, dt):
         tj = json.load(open(tp))
         avg_b = sum(e[2] for e in events) / len(events)
         traffic = int(tj["k_flow_step_bytes_per_launch"] / tj["batch_per_launch"] * avg_b)
-    return {"bound": "mfma", "achieved": round(ach_exec, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach_exec / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "basis": "multiply-adds executed by the matrix pipe (x2) / HIP-event time of the launches",
-            "algorithmic_tflops": round(ach, 2), "algorithmic_speedup": round(ach / ach_exec, 3),
-            "algorithm": ("as the reference computes it" if abs(ach_exec - ach) < 1e-9 * ach else
-                          "Winograd F(2x2,3x3) for the 3x3 of the coupling nets where dispatched (fp32; 20 of 40 C^2 HW multiply-adds per sample-step executed)")
-                         if not vit else "52-wide features in 64-row MFMA tiles, K 52 -> 56 (executed > algorithmic: padding)",
-            "kernel": "k_vit_step (Conv1x1+ActNorm+TransCoupling fused, v_mfma_f32_32x32x2_f32)" if vit else
-                      "k_flow_step / k_flow_step_small (Conv1x1+ActNorm+Coupling fused; v_mfma_f32_32x32x2_f32 / 16x16x4_f32, the 3x3 in Winograd F(2x2,3x3) form on 16x16x4 tiles)",
-            "launches": len(events), "avg_launch_ms": round(ms / len(events), 4),
-            "per_level_executed_tflops": {k: round(v[2] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
-            "per_level_algorithmic_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
-            "kernel_time_share": round(ms * 1e-3 / dt, 3)}
+    out = {"bound": "mfma", "achieved": round(ach_exec, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(ach_exec / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+           "basis": "useful multiply-adds executed by the matrix pipe (x2) / HIP-event time of the launches",
+           "algorithmic_tflops": round(ach, 2), "algorithmic_frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+           "algorithmic_speedup": round(ach / ach_exec, 3),
+           "algorithm": ("q.k through Wq^T Wk and value / output through Wout Wv (two 52 x 52 products per attention block instead of "
+                         "52 -> 192 and 64 -> 52; fp64-folded once per parameter version), LayerNorm affine folded into the next Linear") if vit else
+                        ("as the reference computes it" if abs(ach_exec - ach) < 1e-9 * ach else
+                         "Winograd F(2x2,3x3) for the 3x3 of the coupling nets where dispatched (fp32; 20 of 40 C^2 HW multiply-adds per sample-step executed)"),
+           "kernel": "k_vit_step (Conv1x1+ActNorm+TransCoupling fused, v_mfma_f32_32x32x2_f32)" if vit else
+                     "k_flow_step / k_flow_step_small (Conv1x1+ActNorm+Coupling fused; v_mfma_f32_32x32x2_f32 / 16x16x4_f32, the 3x3 in Winograd F(2x2,3x3) form on 16x16x4 tiles)",
+           "launches": len(events), "avg_launch_ms": round(ms / len(events), 4),
+           "per_level_executed_tflops": {k: round(v[2] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
+           "per_level_algorithmic_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
+           "kernel_time_share": round(ms * 1e-3 / dt, 3)}
+    if vit:
+        out["executed_incl_padding_tflops"] = round(ach_pad, 2)
+    return out
 
 
 def total_flop_per_sample(name):
@@ -256,7 +268,7 @@ def train_flop_per_sample(name, B):
     conditioner on top of that; not counted)."""
     from contextflow_amd.layers import _hip
     L = _hip.lib()
-    if name in VIT_FLOP_PER_SAMPLE:
+    if name in VIT_STEP:
         f = 3 * total_flop_per_sample(name)
         return f, f
     levels = {"cifar10": [(16, 16, 4), (32, 8, 4), (64, 4, 4)], "mnist": [(8, 16, 2), (32, 8, 2)]}[name]
@@ -342,11 +354,88 @@ def secondary_training(name, dev, B, iters, graph, cpu=False):
            "roofline": {"bound": "mfma", "achieved": round(tf_exe, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf_exe / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                         "algorithmic_tflops": round(tf_alg, 2), "algorithmic_speedup": round(tf_alg / tf_exe, 3),
-                        "basis": "whole step: dense multiply-adds executed by the matrix pipe (forward, data gradients, weight gradients) / wall time"}}
+                        "basis": ("whole step, ALGORITHMIC: 3 x the reference's forward flop (forward, data gradients, weight gradients; the conditioner "
+                                  "re-run of the backward kernel is not counted) / wall time") if name in VIT_STEP else
+                                 "whole step: dense multiply-adds executed by the matrix pipe (forward, data gradients, weight gradients) / wall time"}}
     if cpu:
         out["cpu_baseline"] = cpu_train_baseline(name)
         out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     del model, x, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_sampling_baseline(name, B=256, iters=5, warmups=1):
+    """The oracle's sampling direction on the host cores (flowsequential.py:32-39: prior draw, every layer's reverse from last
+    to first; mnist topology - the only one whose `sample` runs in the reference)."""
+    from oracle import flow_oracle as fo, params as op
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    ops, prior, M = fo.program(name)
+    params = op.gen_params(op.param_spec(ops, prior, M), seed=0)
+    g = torch.Generator().manual_seed(0)
+    C, H, W = fo.CONFIGS[name][0]
+    x = torch.randint(0, 256, (B, C, H, W), generator=g).float()
+    aug = [i for i, o in enumerate(ops) if o[0] == "augment"][0]
+    times = []
+    with torch.no_grad():
+        fo.flow_forward(ops, params, x, torch.rand(B, C, H, W, generator=g), [torch.randn(B, 1, H, W, generator=g)], init_actnorm=True)
+        mG, sG, wG = params["dist.mG"], params["dist.sG"], params["dist.wG"]
+        for i in range(warmups + iters):
+            t0 = time.perf_counter()
+            k = torch.multinomial(torch.softmax(wG[1], -1), B, replacement=True, generator=g)              # gaussian.py:163-169
+            z = mG[1][k] + torch.nn.functional.softplus(sG[1][k]) * torch.randn(B, *mG.shape[2:], generator=g)
+            h = fo.flow_inverse_layers(ops[aug + 1:], params, z)
+            h = fo.flow_inverse_layers(ops[:aug], params, h[:, :C])                                         # Augment.reverse drops the noise channel
+            if i >= warmups:
+                times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(B / med, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "median of %d sampling passes (oracle/flow_oracle.py: prior draw + reverse chain) of %d %s-shaped samples after %d warm-up, "
+                      "torch %d threads" % (iters, B, name, warmups, cores)}
+
+
+def secondary_sampling(name, dev, B, iters, cpu):
+    """north_star: "forward+inverse".  `flow.sample(B)` (flowsequential.py:32-39): mixture draw, then Coupling^-1, ActNorm^-1,
+    Conv1x1^-1 of every step as ONE kernel (k_flow_step_inv), Squeeze^-1, Augment / pre-processing reverses."""
+    from contextflow_amd.layers import _hip
+    L = _hip.lib()
+    model, cfg = build(name, dev)
+    with torch.no_grad():
+        for _ in range(2):
+            model.sample(B)
+        model.inv_events = ev = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            smp = model.sample(B)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    model.inv_events = None
+    ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+    hw = lambda e: int(round(math.sqrt(e[4])))
+    exe = sum(2 * e[2] * L.cf_flow_step_macs(e[2], e[3], hw(e), hw(e), 3) for e in ev)
+    alg = sum(e[2] * step_flop(e[3], e[4]) for e in ev)
+    per = {}
+    for e in ev:
+        v = per.setdefault("C%d" % e[3], [0.0, 0.0])
+        v[0] += e[0].elapsed_time(e[1])
+        v[1] += 2 * e[2] * L.cf_flow_step_macs(e[2], e[3], hw(e), hw(e), 3)
+    out = {"metric": "samples/s sampling (prior draw + inverse flow), %s" % LABEL[name], "value": round(B / dt, 1), "unit": "samples/s",
+           "config": {"workload": "%s --coupling %s, flow.sample" % (name, cfg["coupling"]), "batch": B, "iters": iters},
+           "ms_per_step": round(dt * 1e3, 3), "finite": bool(torch.isfinite(smp).all()),
+           "roofline": {"bound": "mfma", "achieved": round(exe / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(exe / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "algorithmic_tflops": round(alg / (ms * 1e-3) / 1e12, 2),
+                        "basis": "multiply-adds executed by the matrix pipe (x2) / HIP-event time of the k_flow_step_inv launches",
+                        "kernel": "k_flow_step_inv (Coupling^-1, ActNorm^-1, Conv1x1^-1 fused; conditioner as in the forward)",
+                        "launches": len(ev), "avg_launch_ms": round(ms / max(len(ev), 1), 4),
+                        "per_level_executed_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 2) for k, v in per.items()},
+                        "kernel_time_share": round(ms * 1e-3 / (dt * iters), 3)}}
+    if cpu:
+        out["cpu_baseline"] = cpu_sampling_baseline(name)
+        out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    del model
     torch.cuda.empty_cache()
     return out
 
@@ -474,6 +563,11 @@ def main():
     import torch.distributed as dist
 
     t_start = time.perf_counter()
+    # ONE JSON line on stdout: everything else any library writes there (RCCL prints a version banner when its first
+    # communicator comes up) goes to stderr - file descriptor 1 points at stderr until the line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank, local_rank, world = cdist.env_world()
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
@@ -484,7 +578,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cdist.init_process_group("gloo" if rehearsal else "nccl")
+    # N = 1: the headline line goes through a real RCCL communicator of ONE rank (CF_DIST_SINGLE_RANK=1: dist._active), so the
+    # driver's single-GPU run exercises the collectives of the data-parallel path - flat parameter broadcast, fp64 NLL
+    # all-reduce - exactly as an N-rank run does.  BENCH_NO_SINGLE_RANK_PG=1 skips it (A/B of its cost: none measurable).
+    single_pg = world == 1 and not rehearsal and os.environ.get("BENCH_NO_SINGLE_RANK_PG") != "1"
+    if single_pg:
+        os.environ["CF_DIST_SINGLE_RANK"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    else:
+        cdist.init_process_group("gloo" if rehearsal else "nccl")
     _hip.lib()
     name = a.workload
 
@@ -558,7 +662,7 @@ def main():
             "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
             "visible_devices": torch.cuda.device_count(),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
-            "rehearsal_gloo_on_one_device": rehearsal,
+            "rehearsal_gloo_on_one_device": rehearsal, "single_rank_communicator": single_pg,
             "wall_s_min_max": [min(walls), max(walls)], "kernel_s_min_max": [min(kerns), max(kerns)],
             "allreduce_s_min_max": [min(ars), max(ars)], "allreduce_share_of_step": round(max(ars) / dt, 5),
             "per_rank": per_rank}
@@ -595,10 +699,13 @@ def main():
                 secondary_training("smap", dev, 32768, 10, graph=True, cpu=cpu),       # BASELINE config 4's training step
                 secondary_training("smap", dev, 256, 50, graph=True),                  # ... at the reference's batch (config.py:10)
                 secondary_specialist("cifar10", dev, 32768, 5, cpu),                   # --contextflow specialist forward
+                secondary_sampling("mnist", dev, 16384, 10, cpu),                      # SURVEY 8(f)3 / north_star "forward+inverse": flow.sample
+                secondary_sampling("cifar10", dev, 16384, 10, cpu=False),              # (SplitPrior.reverse by specification: no reference / oracle chain)
             ]
         out["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1364,14 +1364,16 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
 }
 
 // Multiply-adds per sample the matrix pipe EXECUTES for one step at this batch size (bench.py's executed-flop roofline):
-// pass 0 = cf_flow_step_fwd, 1 = cf_flow_step_fwd_taped, 2 = cf_flow_step_bwd_taped (direct transposed 3x3).  The direct
+// pass 0 = cf_flow_step_fwd, 1 = cf_flow_step_fwd_taped, 2 = cf_flow_step_bwd_taped (direct transposed 3x3), 3 = cf_flow_step_inv
+// (the forward's conditioner + W^-1 instead of W: the same count; Winograd form except at mnist's C = 8 level).  The direct
 // form runs C^2 (Conv1x1) + C^2 + 36 C^2 + 2 C^2 = 40 C^2 per pixel; the Winograd form of the 3x3 runs 16 instead of 36
 // C^2.  The conditions below restate the dispatch of the two entry points above / below - change them together.
 int64_t cf_flow_step_macs(int B, int C, int H, int W, int pass) {
     const int sid = shape_id(C, H, W);
-    if (sid < 0 || pass < 0 || pass > 2) return 0;
+    if (sid < 0 || pass < 0 || pass > 3) return 0;
     const int64_t direct = 40ll * C * C * H * W, wino = 20ll * C * C * H * W;
     if (pass == 2 || direct_conv_only()) return direct;
+    if (pass == 3) return sid == 0 ? direct : wino;
     bool w;
     if (sid == 0) w = pass == 0;                                  // mnist's C = 8 level: evaluation only
     else if (sid == 1) w = true;                                  // 16x16, C = 16: every batch size

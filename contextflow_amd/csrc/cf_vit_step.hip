@@ -9,12 +9,25 @@
 //    the FEATURES in the 16 accumulator registers - and a following product that sums over those features can take the
 //    accumulator registers AS its B operand, with no lane movement and no LDS: k-step s of the next Linear is simply
 //    "register s", i.e. lane half 0 supplies feature row(s, 0) and lane half 1 feature row(s, 1) of its own token; the
-//    packed weights are stored in that k order (k_vit_step_pack).  The residual stream, LayerNorm outputs, q / k / v, the
-//    attention output and the MLP hidden layer never leave the register file;
-//  * LayerNorm is lane-local over the registers (+ one exchange between the two lane halves that share a token), GELU is
-//    elementwise on the accumulators (erf by Abramowitz-Stegun 7.1.26 on the hardware exp / rcp: |err| <= 2e-7);
-//  * a sample's 4 tokens sit in 4 consecutive lanes: q.k^T and p.v use DPP quad permutations fused into the FMAs, the
-//    softmax over 4 scores is exact (no online rescaling);
+//    packed weights are stored in that k order (k_vit_step_pack).  The residual stream, LayerNorm outputs, attention
+//    operands and the MLP hidden layer never leave the register file;
+//  * round 4 - the kernel was bound by its MFMA count (with every vector instruction removed it ran 14 % faster, not 40 %),
+//    so the count went down, 2 144 -> 1 326 per wave:
+//      - a single head of 64 on a width of 52 makes q.k and the value / output pair factor through the 52-wide stream:
+//        q_i.k_j = u_i^T (Wq^T Wk) u_j and to_out(sum_j p_ij Wv u_j) = (Wout Wv) sum_j p_ij u_j.  The two 52 x 52 matrices
+//        are formed once per parameter version in fp64 (k_vit_step_pack) and an attention block is TWO 52 x 52 products
+//        instead of 52 -> 192 and 64 -> 52 (18 720 -> 10 816 multiply-adds per token and layer);
+//      - every LayerNorm that feeds a Linear leaves its affine part in that Linear's packed weights and bias (fp64), and
+//        with u_j = g (.) n_j + b the score terms that do not depend on the key j drop out of the softmax exactly:
+//        s_ij = (A1 n_i + c1) . n_j;
+//      - the 2C features of a tile pair sit on the physical rows {0 .. 24, 28} of each 32-row tile: both lane halves hold
+//        C/2 = 13 valid registers per tile, so a product over the stream has 26 k-steps (it had 28: rows 28 / 29 of one
+//        half were padding) and no loop depends on the lane half;
+//  * LayerNorm statistics are lane-local over the registers + one v_permlane32_swap between the two lane halves that share
+//    a token (no LDS round trip), GELU is elementwise on the accumulators (erf by Abramowitz-Stegun 7.1.26 on the
+//    hardware exp / rcp: the resulting GELU is as close to the exact one as torch's, 1.0e-7 rms over [-8, 8]);
+//  * a sample's 4 tokens sit in 4 consecutive lanes: the scores and the probability-weighted sum use DPP quad
+//    permutations, the softmax over 4 scores is exact (no online rescaling);
 //  * Conv1x1 + ActNorm run as a first product with rows (position-in-patch, channel): its two result tiles ARE the
 //    patchified conditioner input x0 (tile 0) and the half that gets transformed, x1 (tile 1).  The model's 2C features
 //    are laid out so that t (tile 0) and raw log-scale (tile 1) of one (position, channel) share lane AND register index
@@ -31,45 +44,54 @@ extern "C" int cf_slogdet_inverse(const float* W, int C, float* logabsdet, float
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
+// accumulator register r of lane half lk <-> row of a 32-row result tile (v_mfma_f32_32x32x2_f32)
 __host__ __device__ constexpr int trow(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+__host__ __device__ constexpr int reg_of_row(int q) { return (q & 3) + 4 * (q >> 3); }
 __host__ __device__ constexpr int ngrp(int ks) { return (ks + 3) / 4; }
 
 // ---- compile-time geometry ------------------------------------------------------------------------------------
 template <int C_> struct VS {
-    static constexpr int C = C_, CIN = C / 2, HW = 8, NTOK = 4, DIM = 2 * C;
-    // registers of a residual tile that can hold a valid row: rows trow(r, lk) < C.  r < KPT for some lane half
-    static constexpr int KPT = C > 28 ? 16 : (C > 24 ? 14 : (C > 20 ? 12 : (C > 16 ? 10 : 8)));
+    static constexpr int C = C_, CIN = C / 2, HW = 8, NTOK = 4, DIM = 2 * C, HEAD = 64;
+    static constexpr int KPT = C / 2;                 // valid registers per tile and lane: rows trow(r, lk), r < KPT, BOTH halves
     static constexpr int KS_RES = 2 * KPT;            // k-steps when the B operand is the two residual tiles
     static constexpr int KS_IN = KPT;                 // ... tile 0 only (patch features)
     static constexpr int KS0 = C;                     // Conv1x1: one k-step per input channel (lane half = position in patch)
-    static constexpr int KS_HEAD = 32;                // attention output: 64 features, all registers
-    // workspace (floats).  "vec" = 64 floats in register order [lk][tile][r]
+    // workspace (floats).  "vec" = 64 floats in register order [lk][tile][r]; "mat" = A fragments of a 2-tile product
+    static constexpr int MAT_RES = ngrp(KS_RES) * 2 * 256;
     static constexpr int OFF_B0 = 4, OFF_A0 = OFF_B0 + 64;
-    static constexpr int OFF_LN0 = OFF_A0 + ngrp(KS0) * 2 * 256;              // [w | b]
-    static constexpr int OFF_WE = OFF_LN0 + 128, OFF_BE = OFF_WE + ngrp(KS_IN) * 2 * 256;
-    static constexpr int OFF_LN1 = OFF_BE + 64, OFF_POS = OFF_LN1 + 128, OFF_LAYER = OFF_POS + NTOK * 64;
-    // per layer
-    static constexpr int L_LNA = 0, L_WQKV = 128, L_WOUT = L_WQKV + ngrp(KS_RES) * 6 * 256;
-    static constexpr int L_LNF = L_WOUT + ngrp(KS_HEAD) * 2 * 256, L_W1 = L_LNF + 128;
-    static constexpr int L_B1 = L_W1 + ngrp(KS_RES) * 2 * 256, L_W2 = L_B1 + 64, L_B2 = L_W2 + ngrp(KS_RES) * 2 * 256;
+    static constexpr int OFF_WE = OFF_A0 + ngrp(KS0) * 2 * 256, OFF_BE = OFF_WE + ngrp(KS_IN) * 2 * 256;
+    static constexpr int OFF_LN1 = OFF_BE + 64;                                // [w | b + pos_0 | .. | b + pos_3]
+    static constexpr int OFF_LAYER = OFF_LN1 + 64 + NTOK * 64;
+    // per layer: s = (A1 n + c1) . n, x += A2 (sum_j p_j n_j) + c2, x += W2 gelu(W1 n' + b1) + b2
+    static constexpr int L_A1 = 0, L_C1 = L_A1 + MAT_RES, L_A2 = L_C1 + 64, L_C2 = L_A2 + MAT_RES;
+    static constexpr int L_W1 = L_C2 + 64, L_B1 = L_W1 + MAT_RES, L_W2 = L_B1 + 64, L_B2 = L_W2 + MAT_RES;
     static constexpr int L_STRIDE = L_B2 + 64;
     static_assert(C % 2 == 0 && C >= 4 && C <= 32, "C even, <= 32");
 };
 template <class V> __host__ __device__ constexpr int off_lno(int depth) { return V::OFF_LAYER + depth * V::L_STRIDE; }
 template <class V> __host__ __device__ constexpr int ws_floats(int depth) { return off_lno<V>(depth) + 128; }
 
+// row q (0..31) of a tile -> logical index j in [0, C) (the valid rows in increasing order), or -1 for padding.  A row is
+// valid when its register index is below KPT; for C = 26 these are the rows 0 .. 24 and 28.
+template <class V> __host__ __device__ constexpr int logical_of_row(int q) {
+    if (reg_of_row(q) >= V::KPT) return -1;
+    int j = 0;
+    for (int p = 0; p < q; ++p) j += reg_of_row(p) < V::KPT ? 1 : 0;
+    return j;
+}
 // physical row p (0..63: tile = p >> 5) of the residual layout -> model feature f = ii * C + ch, or -1 for padding.
-// tile 0 holds channels ch < C/2 (t after the last LayerNorm), tile 1 channels ch >= C/2 (raw log-scale), both at row
-// ii * C/2 + c: the same (lane, register) in the two tiles belongs to one (position ii, channel c).
-template <class V> __host__ __device__ inline int feat_of_phys(int p) {
-    const int q = p & 31;
-    if (q >= V::C) return -1;
-    return (q / V::CIN) * V::C + (q % V::CIN) + V::CIN * (p >> 5);
+// tile 0 holds channels ch < C/2 (t after the last LayerNorm), tile 1 channels ch >= C/2 (raw log-scale), both at logical
+// index ii * C/2 + c: the same (lane, register) in the two tiles belongs to one (position ii, channel c).
+template <class V> __host__ __device__ constexpr int feat_of_phys(int p) {
+    const int j = logical_of_row<V>(p & 31);
+    if (j < 0) return -1;
+    return (j / V::CIN) * V::C + (j % V::CIN) + V::CIN * (p >> 5);
 }
 // k-step s of a product whose B operand is the residual tile pair -> physical row supplied by lane half lk
-template <class V> __host__ __device__ inline int phys_of_kstep(int s, int lk) { return trow(s % V::KPT, lk) + 32 * (s / V::KPT); }
+template <class V> __host__ __device__ constexpr int phys_of_kstep(int s, int lk) { return trow(s % V::KPT, lk) + 32 * (s / V::KPT); }
 
 // ---- packing (cf_vit_step_prepare) ----------------------------------------------------------------------------------
 // fragment element ((g * RT + rt) * 64 + lane) * 4 + e = A[row = rt * 32 + (lane & 31)][k-step 4 g + e, lane half]
@@ -77,32 +99,31 @@ template <class V>
 __global__ __launch_bounds__(256) void k_vit_step_pack(const float* __restrict__ Wm, const float* __restrict__ t,
                                                        const float* __restrict__ logs, const float* __restrict__ flat,
                                                        const float* __restrict__ pos, float* __restrict__ ws, int depth) {
-    constexpr int C = V::C, CIN = V::CIN, DIM = V::DIM;
+    constexpr int C = V::C, CIN = V::CIN, DIM = V::DIM, HEAD = V::HEAD;
+    __shared__ double tq[HEAD], tv[HEAD];
     const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
-    auto vec = [&](float* dst, const float* src, bool tile0_only) {          // register-order vector of a residual-feature vector
+    // register-order vector of a per-feature quantity val(f), f = model feature of the residual layout
+    auto vec = [&](float* dst, auto val) {
         for (int i = gtid; i < 64; i += gsz) {
             const int lk = i >> 5, rt = (i >> 4) & 1, r = i & 15;
-            const int p = trow(r, lk) + 32 * rt;
-            int f = tile0_only ? ((rt == 0 && (p & 31) < C) ? (p & 31) : -1) : feat_of_phys<V>(p);
-            dst[i] = f >= 0 ? src[f] : 0.f;
+            const int f = feat_of_phys<V>(trow(r, lk) + 32 * rt);
+            dst[i] = f >= 0 ? (float)val(f) : 0.f;
         }
     };
-    // A fragments of a Linear.  out_tiles x 32 physical output rows -> model rows through rowmap; k-steps through kmap
-    auto frags = [&](float* dst, const float* W, int K, int out_tiles, int nks, auto rowmap, auto kmap) {
-        const int n = ngrp(nks) * out_tiles * 256;
+    // A fragments of a 2-tile product: physical output rows -> model rows through rowmap; k-steps through kmap; val(row, k)
+    auto frags = [&](float* dst, int nks, auto rowmap, auto kmap, auto val) {
+        const int n = ngrp(nks) * 2 * 256;
         for (int i = gtid; i < n; i += gsz) {
-            const int e = i & 3, lane = (i >> 2) & 63, q = i >> 8, rt = q % out_tiles, g = q / out_tiles;
+            const int e = i & 3, lane = (i >> 2) & 63, q = i >> 8, rt = q % 2, g = q / 2;
             const int s = 4 * g + e;
             const int row = rowmap(rt * 32 + (lane & 31));
             const int k = s < nks ? kmap(s, lane >> 5) : -1;
-            dst[i] = (row >= 0 && k >= 0) ? W[row * K + k] : 0.f;
+            dst[i] = (row >= 0 && k >= 0) ? (float)val(row, k) : 0.f;
         }
     };
     auto res_row = [](int p) { return feat_of_phys<V>(p); };
-    auto nat_row = [](int p) { return p; };
     auto res_k = [](int s, int lk) { return feat_of_phys<V>(phys_of_kstep<V>(s, lk)); };
-    auto in_k = [](int s, int lk) { const int p = trow(s, lk); return p < C ? p : -1; };        // patch feature = tile-0 row
-    auto head_k = [](int s, int lk) { return trow(s & 15, lk) + 32 * (s >> 4); };               // 64 head features, natural
+    auto in_k = [](int s, int lk) { return logical_of_row<V>(trow(s, lk)); };                   // patch feature = logical tile-0 row
 
     if (gtid == 0) {       // ldj_const = H*W*log|det Wm| + sum_c logs  (ws[1] holds log|det| from cf_slogdet_inverse)
         float s = 0.f;
@@ -112,33 +133,66 @@ __global__ __launch_bounds__(256) void k_vit_step_pack(const float* __restrict__
     // Conv1x1 + ActNorm as a product over (position-in-patch, channel): rows = physical rows, k-step s = input channel s,
     // lane half = position ii'; block diagonal in the position
     for (int i = gtid; i < 64; i += gsz) {
-        const int lk = i >> 5, rt = (i >> 4) & 1, r = i & 15, p = trow(r, lk) + 32 * rt, q = p & 31;
-        const int ch = q < C ? (q % CIN) + CIN * rt : -1;
-        ws[V::OFF_B0 + i] = ch >= 0 ? -t[ch] * expf(-logs[ch]) : 0.f;        // (x - t) e^{-logs}
+        const int lk = i >> 5, rt = (i >> 4) & 1, r = i & 15, j = logical_of_row<V>(trow(r, lk));
+        const int ch = j >= 0 ? (j % CIN) + CIN * rt : -1;
+        ws[V::OFF_B0 + i] = ch >= 0 ? (float)(-(double)t[ch] * exp(-(double)logs[ch])) : 0.f;        // (x - t) e^{-logs}
     }
     for (int i = gtid; i < ngrp(V::KS0) * 2 * 256; i += gsz) {
         const int e = i & 3, lane = (i >> 2) & 63, qq = i >> 8, rt = qq % 2, g = qq / 2, s = 4 * g + e;
-        const int q = lane & 31, ii = q / CIN, ch = q < C ? (q % CIN) + CIN * rt : -1;
-        ws[V::OFF_A0 + i] = (ch >= 0 && s < C && ii == (lane >> 5)) ? expf(-logs[ch]) * Wm[ch * C + s] : 0.f;
+        const int j = logical_of_row<V>(lane & 31), ii = j >= 0 ? j / CIN : -1, ch = j >= 0 ? (j % CIN) + CIN * rt : -1;
+        ws[V::OFF_A0 + i] = (ch >= 0 && s < C && ii == (lane >> 5)) ? (float)(exp(-(double)logs[ch]) * (double)Wm[ch * C + s]) : 0.f;
     }
     const float* p = flat;       // order of TransCoupling._flat_params(): see cf_vit_fused.hip
-    vec(ws + V::OFF_LN0, p, true); vec(ws + V::OFF_LN0 + 64, p + C, true); p += 2 * C;          // to_patch_embedding.1 (pd = C)
-    frags(ws + V::OFF_WE, p, C, 2, V::KS_IN, res_row, in_k); p += DIM * C;
-    vec(ws + V::OFF_BE, p, false); p += DIM;
-    vec(ws + V::OFF_LN1, p, false); vec(ws + V::OFF_LN1 + 64, p + DIM, false); p += 2 * DIM;
-    for (int n = 0; n < V::NTOK; ++n) vec(ws + V::OFF_POS + 64 * n, pos + n * DIM, false);
+    {   // to_patch_embedding: LN(pd = C) -> Linear(C, DIM) -> LN(DIM); the first LayerNorm's affine part folded into the Linear
+        const float *g0 = p, *b0 = p + C, *We = p + 2 * C, *be = We + DIM * C, *g1 = be + DIM, *b1 = g1 + DIM;
+        frags(ws + V::OFF_WE, V::KS_IN, res_row, in_k, [&](int f, int k) { return (double)We[f * C + k] * (double)g0[k]; });
+        vec(ws + V::OFF_BE, [&](int f) { double a = be[f]; for (int k = 0; k < C; ++k) a += (double)We[f * C + k] * (double)b0[k]; return a; });
+        vec(ws + V::OFF_LN1, [&](int f) { return g1[f]; });
+        for (int n = 0; n < V::NTOK; ++n) vec(ws + V::OFF_LN1 + 64 * (1 + n), [&](int f) { return b1[f] + pos[n * DIM + f]; });
+        p = b1 + DIM;
+    }
     for (int l = 0; l < depth; ++l) {
         float* w = ws + V::OFF_LAYER + l * V::L_STRIDE;
-        vec(w + V::L_LNA, p, false); vec(w + V::L_LNA + 64, p + DIM, false); p += 2 * DIM;
-        frags(w + V::L_WQKV, p, DIM, 6, V::KS_RES, nat_row, res_k); p += 192 * DIM;
-        frags(w + V::L_WOUT, p, 64, 2, V::KS_HEAD, res_row, head_k); p += DIM * 64;
-        vec(w + V::L_LNF, p, false); vec(w + V::L_LNF + 64, p + DIM, false); p += 2 * DIM;
-        frags(w + V::L_W1, p, DIM, 2, V::KS_RES, res_row, res_k); p += DIM * DIM;
-        vec(w + V::L_B1, p, false); p += DIM;
-        frags(w + V::L_W2, p, DIM, 2, V::KS_RES, res_row, res_k); p += DIM * DIM;
-        vec(w + V::L_B2, p, false); p += DIM;
+        const float *ga = p, *ba = p + DIM, *Wq = p + 2 * DIM, *Wk = Wq + HEAD * DIM, *Wv = Wk + HEAD * DIM, *Wo = Wv + HEAD * DIM;
+        const float *gf = Wo + DIM * HEAD, *bf = gf + DIM, *W1 = bf + DIM, *b1 = W1 + DIM * DIM, *W2 = b1 + DIM, *b2 = W2 + DIM * DIM;
+        __syncthreads();
+        if (threadIdx.x < 2 * HEAD) {                                    // Wq b and Wv b (b = the LayerNorm's bias), every block its own copy
+            const int h = threadIdx.x % HEAD;
+            const float* W = threadIdx.x < HEAD ? Wq : Wv;
+            double a = 0.0;
+            for (int k = 0; k < DIM; ++k) a += (double)W[h * DIM + k] * (double)ba[k];
+            (threadIdx.x < HEAD ? tq : tv)[h] = a;
+        }
+        __syncthreads();
+        // scores (simple_vit.py:60-64): q_i.k_j / 8 = u_i^T G u_j / 8 with G = Wq^T Wk, u = ga (.) n + ba.  The terms without n_j
+        // are the same for the four keys of a query and leave the softmax: s_ij = (A1 n_i + c1) . n_j,
+        // A1 = diag(ga) G^T diag(ga) / 8, c1 = diag(ga) G^T ba / 8
+        frags(w + V::L_A1, V::KS_RES, res_row, res_k, [&](int a, int b) {
+            double s = 0.0;
+            for (int h = 0; h < HEAD; ++h) s += (double)Wk[h * DIM + a] * (double)Wq[h * DIM + b];
+            return 0.125 * s * (double)ga[a] * (double)ga[b]; });
+        vec(w + V::L_C1, [&](int a) {
+            double s = 0.0;
+            for (int h = 0; h < HEAD; ++h) s += (double)Wk[h * DIM + a] * tq[h];
+            return 0.125 * s * (double)ga[a]; });
+        // to_out(sum_j p_ij v_j) = Wout Wv (ga (.) sum_j p_ij n_j + ba)   (simple_vit.py:65-68; sum_j p_ij = 1)
+        frags(w + V::L_A2, V::KS_RES, res_row, res_k, [&](int f, int b) {
+            double s = 0.0;
+            for (int h = 0; h < HEAD; ++h) s += (double)Wo[f * HEAD + h] * (double)Wv[h * DIM + b];
+            return s * (double)ga[b]; });
+        vec(w + V::L_C2, [&](int f) {
+            double s = 0.0;
+            for (int h = 0; h < HEAD; ++h) s += (double)Wo[f * HEAD + h] * tv[h];
+            return s; });
+        // FeedForward (simple_vit.py:30-40): LayerNorm affine folded into the first Linear
+        frags(w + V::L_W1, V::KS_RES, res_row, res_k, [&](int f, int b) { return (double)W1[f * DIM + b] * (double)gf[b]; });
+        vec(w + V::L_B1, [&](int f) { double a = b1[f]; for (int k = 0; k < DIM; ++k) a += (double)W1[f * DIM + k] * (double)bf[k]; return a; });
+        frags(w + V::L_W2, V::KS_RES, res_row, res_k, [&](int f, int b) { return (double)W2[f * DIM + b]; });
+        vec(w + V::L_B2, [&](int f) { return b2[f]; });
+        p = b2 + DIM;
     }
-    vec(ws + off_lno<V>(depth), p, false); vec(ws + off_lno<V>(depth) + 64, p + DIM, false);
+    vec(ws + off_lno<V>(depth), [&](int f) { return p[f]; });
+    vec(ws + off_lno<V>(depth) + 64, [&](int f) { return p[DIM + f]; });
 }
 
 // ---- device helpers ----------------------------------------------------------------------------------------------------
@@ -146,6 +200,9 @@ __device__ __forceinline__ rsrc_t make_rsrc(const float* ws, int floats) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws), 0, floats * 4, 0x00020000);
 }
 __device__ __forceinline__ float4 frag(rsrc_t rs, int lane, int foff) {
+#ifdef CF_ABL_VS_NOFRAG
+    return make_float4(1e-3f * lane, 2e-3f, 3e-3f * foff, 1e-3f);
+#endif
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
     const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, foff * 4, 0);
     return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
@@ -169,14 +226,23 @@ __device__ __forceinline__ void load_vec(f32x16 (&v)[2], const float* __restrict
 template <int RT, int NKS, bool ZERO = false, class BOP>
 __device__ __forceinline__ void gemm_regs(f32x16 (&acc)[RT], rsrc_t rs, int lane, int foff, BOP bop) {
     constexpr int NG = (NKS + 3) / 4;
-    float4 a[2][RT];
+    // fragment groups in flight ahead of the MFMAs (a group = 4 k-steps = 8 MFMAs of 64 cycles).  Measured at 524 288 samples:
+    // 1 group ahead 3 380 us, 2 groups 3 545, 3 groups 3 700 - more requests in flight only raise the L2 traffic's share of the
+    // power budget (the shader clock falls from 2.39 GHz without the loads to 2.26 with them: tools/dev/vit_clock.py)
+#ifndef CF_VS_AHEAD
+#define CF_VS_AHEAD 1
+#endif
+    constexpr int AH = CF_VS_AHEAD, NR = AH + 1;
+    float4 a[NR][RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[0][rt] = frag(rs, lane, foff + rt * 256);
+    for (int g = 0; g < AH && g < NG; ++g)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[g][rt] = frag(rs, lane, foff + (g * RT + rt) * 256);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) {
+        if (g + AH < NG) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) a[(g + 1) & 1][rt] = frag(rs, lane, foff + ((g + 1) * RT + rt) * 256);
+            for (int rt = 0; rt < RT; ++rt) a[(g + AH) % NR][rt] = frag(rs, lane, foff + ((g + AH) * RT + rt) * 256);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -187,77 +253,131 @@ __device__ __forceinline__ void gemm_regs(f32x16 (&acc)[RT], rsrc_t rs, int lane
                 for (int rt = 0; rt < RT; ++rt) {
                     if (ZERO && g == 0 && e == 0) {
                         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[g & 1][rt], e), b, zero, 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[g % NR][rt], e), b, zero, 0, 0, 0);
                     } else {
-                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[g & 1][rt], e), b, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[g % NR][rt], e), b, acc[rt], 0, 0, 0);
                     }
                 }
             }
     }
 }
 
-// LayerNorm of the token over its valid features (NT tiles of C valid rows each; the two lane halves hold different rows
-// of the same token): y = (x - mean) rstd w + b (+ extra).  Biased variance, eps 1e-5 (torch.nn.LayerNorm).
-template <class V, int NT>
-__device__ __forceinline__ void layernorm(const f32x16 (&x)[2], f32x16 (&y)[2], const float* __restrict__ ln, int lk,
-                                          const float* __restrict__ extra) {
-    constexpr int C = V::C;
-    const float m12 = (trow(12, 1) < C || lk == 0) ? 1.f : 0.f;      // registers 12..15: rows 24..27 (lk 0) / 28..31 (lk 1)
-    auto valid = [&](int r) -> float {                               // compile-time for every r except the lk-dependent ones
-        if (trow(r, 1) < C) return 1.f;                              // valid in both halves
-        if (trow(r, 0) >= C) return 0.f;                             // valid in neither
-        return m12;                                                  // valid for lk = 0 only
-    };
-    float s = 0.f;
-#pragma unroll
-    for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (trow(r, 0) < C) s += x[rt][r];                       // padded rows hold exact zeros
-    s += __shfl_xor(s, 32, 64);
-    const float mean = s * (1.0f / (float)(NT * C));
-    float v = 0.f;
-    f32x16 d[2];
-#pragma unroll
-    for (int rt = 0; rt < NT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (trow(r, 0) < C) {
-                d[rt][r] = (x[rt][r] - mean) * valid(r);
-                v = fmaf(d[rt][r], d[rt][r], v);
-            }
-    v += __shfl_xor(v, 32, 64);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / (float)(NT * C)) + 1e-5f);
-    f32x16 w[2], b[2];
-    load_vec(w, ln, lk);
-    load_vec(b, ln + 64, lk);
-    f32x16 ex[2];
-    if (extra) load_vec(ex, extra, lk);
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (rt < NT && trow(r, 0) < C) {
-                float o = fmaf(d[rt][r] * rstd, w[rt][r], b[rt][r]);
-                if (extra) o += ex[rt][r];
-                y[rt][r] = o;
-            } else {
-                y[rt][r] = 0.f;
-            }
-        }
+// sum of a per-lane partial over the two lane halves that share a token (v_permlane32_swap: no LDS round trip); both
+// halves receive lo + hi in that order, i.e. the same bits
+__device__ __forceinline__ float half_sum(float s) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// exact GELU 0.5 v (1 + erf(v / sqrt 2)), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7)
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float x = v * 0.70710678118654752f, ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __expf(-ax * ax);
-    const float er = copysignf(fmaf(-p * t, e, 1.0f), x);
-    return 0.5f * v * (1.0f + er);
+// Packed fp32 (v_pk_add / v_pk_mul / v_pk_fma_f32: two elements per instruction).  The fp32 matrix pipe shares its lanes with
+// the vector ALU (tools/micro/mfma_issue.hip: no overlap), so every vector instruction of this kernel is time taken from the
+// MFMA stream: the elementwise stages work on the aligned register pairs (2i, 2i + 1) of a tile - registers 0 .. 11 of the
+// KPT = 13 valid ones - and treat register 12 on its own.  (Left to itself hipcc pairs registers of different tiles and pays
+// for it in v_mov: 103 of them per transformer layer.)
+#define CF_PAIR(v, i) (f32x2{(v)[2 * (i)], (v)[2 * (i) + 1]})
+__device__ __forceinline__ void set_pair(f32x16& v, int i, f32x2 p) { v[2 * i] = p.x; v[2 * i + 1] = p.y; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+
+// the token's features minus their mean, times 1 / sqrt(biased variance + 1e-5) (torch.nn.LayerNorm without its affine part:
+// that sits in the packed weights of the Linear behind it, or is applied by layernorm_affine).  NT tiles of KPT valid
+// registers per lane; the two lane halves hold different features of the same token.
+template <class V, int NT>
+__device__ __forceinline__ void normalize(const f32x16 (&x)[2], f32x16 (&y)[2]) {
+    constexpr int K = V::KPT, NP = K / 2;
+    static_assert(K % 2 == 1, "an odd number of valid registers per tile: pairs + one single");
+#ifdef CF_ABL_VS_NOLN
+    y[0] = x[0]; y[1] = x[1]; return;
+#endif
+    f32x2 s2[2] = {splat(0.f), splat(0.f)};
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) s2[i & 1] += CF_PAIR(x[rt], i);
+    s2[0] += s2[1];
+    float s = s2[0].x + s2[0].y;
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) s += x[rt][K - 1];
+    const float mean = half_sum(s) * (1.0f / (float)(NT * V::C));
+    const f32x2 nm = splat(-mean);
+    f32x2 v2[2] = {splat(0.f), splat(0.f)};
+    float v = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const f32x2 d = CF_PAIR(x[rt], i) + nm;
+            set_pair(y[rt], i, d);
+            v2[i & 1] = pk_fma(d, d, v2[i & 1]);
+        }
+        const float d = x[rt][K - 1] - mean;
+        y[rt][K - 1] = d;
+        v = fmaf(d, d, v);
+    }
+    v2[0] += v2[1];
+    const float var = half_sum(v + (v2[0].x + v2[0].y)) * (1.0f / (float)(NT * V::C)) + 1e-5f;
+    float rstd = __builtin_amdgcn_rsqf(var);
+    rstd = rstd * fmaf(-0.5f * var * rstd, rstd, 1.5f);            // one Newton step: 1 ulp -> rounding level
+    const f32x2 r2 = splat(rstd);
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) set_pair(y[rt], i, CF_PAIR(y[rt], i) * r2);
+        y[rt][K - 1] *= rstd;
+    }
+}
+
+// full LayerNorm of the two tiles: normalize, then y = y w + b (w, b: register-order vectors)
+template <class V>
+__device__ __forceinline__ void layernorm_affine(const f32x16 (&x)[2], f32x16 (&y)[2], const float* __restrict__ w,
+                                                 const float* __restrict__ b, int lk) {
+    f32x16 wv[2], bv[2];
+    load_vec(wv, w, lk);
+    load_vec(bv, b, lk);
+    normalize<V, 2>(x, y);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+        for (int i = 0; i < V::KPT / 2; ++i) set_pair(y[rt], i, pk_fma(CF_PAIR(y[rt], i), CF_PAIR(wv[rt], i), CF_PAIR(bv[rt], i)));
+        y[rt][V::KPT - 1] = fmaf(y[rt][V::KPT - 1], wv[rt][V::KPT - 1], bv[rt][V::KPT - 1]);
+    }
+}
+
+// exact GELU v Phi(v), Phi(v) = (1 + erf(v / sqrt 2)) / 2 with erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7) on the hardware
+// rcp / exp2: with q = P(t) e^{-v^2 / 2} / 2, t = 1 / (1 + p |v| / sqrt 2), Phi(v) = 1 - q for v >= 0 and q for v < 0, i.e.
+// gelu(v) = max(v, 0) - |v| q.  Against the exact GELU: 1.0e-7 rms over [-8, 8], the same as torch's erf-based one.
+__device__ __forceinline__ float abs_bits(float v) { return __int_as_float(__float_as_int(v) & 0x7fffffff); }
+__device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }   // one integer max (fmaxf: two VALU here)
+__device__ __forceinline__ f32x2 gelu2(f32x2 v) {
+#ifdef CF_ABL_VS_NOGELU
+    return v;
+#endif
+    const f32x2 av = {abs_bits(v.x), abs_bits(v.y)};
+    f32x2 t = pk_fma(av, splat(0.3275911f * 0.70710678118654752f), splat(1.0f));
+    t = f32x2{__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
+    f32x2 p = pk_fma(t, splat(0.5f * 1.061405429f), splat(0.5f * -1.453152027f));
+    p = pk_fma(p, t, splat(0.5f * 1.421413741f));
+    p = pk_fma(p, t, splat(0.5f * -0.284496736f));
+    p = pk_fma(p, t, splat(0.5f * 0.254829592f));
+    f32x2 e = (v * v) * splat(-0.72134752044448170f);              // -v^2 / 2 * log2(e)
+    e = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    const f32x2 q = (p * t) * e;
+    return pk_fma(-av, q, f32x2{relu_bits(v.x), relu_bits(v.y)});
+}
+__device__ __forceinline__ float gelu_erf(float v) { return gelu2(f32x2{v, v}).x; }
+
+#ifdef CF_ABL_VS_NOBIAS
+#define CF_BIAS(v, ptr) do { v[0] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; v[1] = v[0]; } while (0)
+#else
+#define CF_BIAS(v, ptr) load_vec(v, ptr, lk)
+#endif
+template <int K> __device__ __forceinline__ void add_tiles(f32x16 (&X)[2], const f32x16 (&a)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < K / 2; ++i) set_pair(X[t], i, CF_PAIR(X[t], i) + CF_PAIR(a[t], i));
+        X[t][K - 1] += a[t][K - 1];
+    }
 }
 
 template <int CTRL> __device__ __forceinline__ float quad(float v) {          // DPP quad permutation of the 4 tokens of a sample
@@ -281,13 +401,20 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
                                                      float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
                                                      int64_t xbs, int depth, float* __restrict__ hout,
                                                      float* __restrict__ xtape = nullptr, int64_t T = 0) {
-    constexpr int C = V::C, CIN = V::CIN, HW = V::HW;
+    constexpr int C = V::C, CIN = V::CIN, HW = V::HW, K = V::KPT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lk = lane >> 5;
     const int n = li & 3;                                   // token of the sample: positions 2n, 2n + 1
     const int smp = (blockIdx.x * 4 + wave) * 8 + (li >> 2);
     const bool live = smp < B;
     const float* xb = x + (int64_t)min(smp, B - 1) * xbs;
     const rsrc_t rs = make_rsrc(ws, ws_floats<V>(depth));
+#ifdef CF_VS_TICKS
+    const uint64_t tick0 = __builtin_readcyclecounter(), real0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // register r of this lane -> (position in the patch ii, channel c) of both tiles
+    // (r is a constant after unrolling: both candidates fold at compile time, the lane half selects)
+    auto pos_of = [&](int r) { const int j0 = logical_of_row<V>(trow(r, 0)), j1 = logical_of_row<V>(trow(r, 1)); return lk ? j1 / CIN : j0 / CIN; };
+    auto chan_of = [&](int r) { const int j0 = logical_of_row<V>(trow(r, 0)), j1 = logical_of_row<V>(trow(r, 1)); return lk ? j1 % CIN : j0 % CIN; };
 
     // ================= Conv1x1 + ActNorm: [x0' | x1'] rows (ii, c), one k-step per input channel, lane half = position
     f32x16 y[2];
@@ -301,19 +428,16 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
     float* zb = z + (int64_t)smp * C * HW;
     if (live) {                                             // first half passes through (coupling.py:154)
 #pragma unroll
-        for (int r = 0; r < V::KPT; ++r) {
-            const int p = trow(r, lk), ii = p / CIN, c = p - ii * CIN;
-            if (p < C) zb[c * HW + 2 * n + ii] = y[0][r];
-        }
+        for (int r = 0; r < K; ++r) zb[chan_of(r) * HW + 2 * n + pos_of(r)] = y[0][r];
     }
     // ================= patch embedding: LN(pd) -> Linear -> LN(dim) + pos        (simple_vit.py:100-105,122)
     f32x16 X[2];
     {
         f32x16 u[2];
-        layernorm<V, 1>(y, u, ws + V::OFF_LN0, lk, nullptr);
+        normalize<V, 1>(y, u);
         load_vec(X, ws + V::OFF_BE, lk);
         gemm_regs<2, V::KS_IN>(X, rs, lane, V::OFF_WE, [&](int s) { return u[0][s]; });
-        layernorm<V, 2>(X, X, ws + V::OFF_LN1, lk, ws + V::OFF_POS + 64 * n);
+        layernorm_affine<V>(X, X, ws + V::OFF_LN1, ws + V::OFF_LN1 + 64 * (1 + n), lk);
     }
     auto dump = [&](int bnd) {
         if constexpr (DUMP) {
@@ -321,106 +445,118 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < V::KPT; ++r) {
-                    const int f = feat_of_phys<V>(trow(r, lk) + 32 * t);
-                    if (f >= 0) tb[(int64_t)f * T] = X[t][r];
-                }
+                for (int r = 0; r < K; ++r) tb[(int64_t)(pos_of(r) * C + chan_of(r) + CIN * t) * T] = X[t][r];
         }
     };
+    auto bop2 = [](const f32x16 (&u)[2], int s) { return u[s / K][s % K]; };
     // (boundary 0, the embedding output, is rebuilt by the backward kernel together with the statistics it needs: not taped)
     // ================= transformer                                                 (simple_vit.py:56-88)
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
         const int wl = V::OFF_LAYER + l * V::L_STRIDE;
-        f32x16 o[2];
         {
-            f32x16 u[2];
-            layernorm<V, 2>(X, u, ws + wl + V::L_LNA, lk, nullptr);
-            f32x16 qkv[6];
-            gemm_regs<6, V::KS_RES, true>(qkv, rs, lane, wl + V::L_WQKV, [&](int s) { return u[s / V::KPT][s % V::KPT]; });
-            // scores of this token against the 4 tokens of its sample (partner = token ^ m), exact softmax
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            f32x16 u[2], g[2], m[2];
+            normalize<V, 2>(X, u);
+            CF_BIAS(g, ws + wl + V::L_C1);
+            gemm_regs<2, V::KS_RES>(g, rs, lane, wl + V::L_A1, [&](int s) { return bop2(u, s); });
+            // scores of this token (query) against the 4 tokens of its sample (key = token ^ m), exact softmax; the 1 / 8 of
+            // dim_head ** -0.5 sits in A1 / c1
+            // (packed: the DPP-permuted copies of a register pair serve both the scores and the probability-weighted sum)
+#ifdef CF_ABL_VS_NOATT
+            m[0] = u[0] + g[0]; m[1] = u[1] + g[1];
+            if (false) {
+#else
+            {
+#endif
+            f32x2 d0 = splat(0.f), d1 = splat(0.f), d2 = splat(0.f), d3 = splat(0.f);
+            f32x2 k1[2][K / 2], k2[2][K / 2], k3[2][K / 2];
+            float e1[2], e2[2], e3[2], s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float q = qkv[t][r], k = qkv[2 + t][r];
-                    d0 = fmaf(q, k, d0);
-                    d1 = fmaf(q, tok_xor<1>(k), d1);
-                    d2 = fmaf(q, tok_xor<2>(k), d2);
-                    d3 = fmaf(q, tok_xor<3>(k), d3);
+                for (int i = 0; i < K / 2; ++i) {
+                    const f32x2 q = CF_PAIR(g[t], i), k = CF_PAIR(u[t], i);
+                    k1[t][i] = f32x2{tok_xor<1>(k.x), tok_xor<1>(k.y)};
+                    k2[t][i] = f32x2{tok_xor<2>(k.x), tok_xor<2>(k.y)};
+                    k3[t][i] = f32x2{tok_xor<3>(k.x), tok_xor<3>(k.y)};
+                    d0 = pk_fma(q, k, d0); d1 = pk_fma(q, k1[t][i], d1); d2 = pk_fma(q, k2[t][i], d2); d3 = pk_fma(q, k3[t][i], d3);
                 }
-            d0 += __shfl_xor(d0, 32, 64); d1 += __shfl_xor(d1, 32, 64);           // the lane halves hold different features
-            d2 += __shfl_xor(d2, 32, 64); d3 += __shfl_xor(d3, 32, 64);
-            const float scale = 0.125f;                                            // dim_head ** -0.5, dim_head = 64
-            d0 *= scale; d1 *= scale; d2 *= scale; d3 *= scale;
-            const float mx = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
-            float p0 = __expf(d0 - mx), p1 = __expf(d1 - mx), p2 = __expf(d2 - mx), p3 = __expf(d3 - mx);
+                const float q = g[t][K - 1], k = u[t][K - 1];
+                e1[t] = tok_xor<1>(k); e2[t] = tok_xor<2>(k); e3[t] = tok_xor<3>(k);
+                s0 = fmaf(q, k, s0); s1 = fmaf(q, e1[t], s1); s2 = fmaf(q, e2[t], s2); s3 = fmaf(q, e3[t], s3);
+            }
+            s0 = half_sum(s0 + (d0.x + d0.y)); s1 = half_sum(s1 + (d1.x + d1.y));          // the lane halves hold different features
+            s2 = half_sum(s2 + (d2.x + d2.y)); s3 = half_sum(s3 + (d3.x + d3.y));
+            const float mx = fmaxf(fmaxf(s0, s1), fmaxf(s2, s3));
+            float p0 = __expf(s0 - mx), p1 = __expf(s1 - mx), p2 = __expf(s2 - mx), p3 = __expf(s3 - mx);
             const float inv = 1.0f / ((p0 + p1) + (p2 + p3));
             p0 *= inv; p1 *= inv; p2 *= inv; p3 *= inv;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = qkv[4 + t][r];
-                    o[t][r] = fmaf(p3, tok_xor<3>(v), fmaf(p2, tok_xor<2>(v), fmaf(p1, tok_xor<1>(v), p0 * v)));
-                }
-        }
-        {
-            // the product is summed on its own and meets the residual stream in ONE addition per element, as in the
-            // reference (x = to_out(...) + x, simple_vit.py:84).  Accumulating the k-steps on top of X rounds every partial
-            // sum at the magnitude of the residual stream (|X| ~ 5 against |product| < 1): 56-64 roundings of ulp(X) per
-            // element and block, which was 2-3x the reference's own fp32 error on the layer's output and - amplified by
-            // 1 / sigma of a fitted prior - the whole distance of the SMAP "extreme" fixtures (tools/attribute_vit.py)
+                for (int i = 0; i < K / 2; ++i)
+                    set_pair(m[t], i, pk_fma(splat(p3), k3[t][i], pk_fma(splat(p2), k2[t][i], pk_fma(splat(p1), k1[t][i], splat(p0) * CF_PAIR(u[t], i)))));
+                m[t][K - 1] = fmaf(p3, e3[t], fmaf(p2, e2[t], fmaf(p1, e1[t], p0 * u[t][K - 1])));
+            }
+            }
+            // the block's output is summed on its own (bias + 26 k-steps) and meets the residual stream in ONE addition per
+            // element, as in the reference (x = to_out(...) + x, simple_vit.py:84): accumulating the k-steps on top of X
+            // would round every partial sum at the magnitude of the residual stream (tools/attribute_vit.py)
             f32x16 a[2];
-            gemm_regs<2, V::KS_HEAD, true>(a, rs, lane, wl + V::L_WOUT, [&](int s) { return o[s >> 4][s & 15]; });
-#pragma unroll
-            for (int t = 0; t < 2; ++t) X[t] += a[t];
+            CF_BIAS(a, ws + wl + V::L_C2);
+            gemm_regs<2, V::KS_RES>(a, rs, lane, wl + V::L_A2, [&](int s) { return bop2(m, s); });
+            add_tiles<K>(X, a);
         }
         {
             f32x16 u[2], h[2];
-            layernorm<V, 2>(X, u, ws + wl + V::L_LNF, lk, nullptr);
-            load_vec(h, ws + wl + V::L_B1, lk);
-            gemm_regs<2, V::KS_RES>(h, rs, lane, wl + V::L_W1, [&](int s) { return u[s / V::KPT][s % V::KPT]; });
+            normalize<V, 2>(X, u);
+            CF_BIAS(h, ws + wl + V::L_B1);
+            gemm_regs<2, V::KS_RES>(h, rs, lane, wl + V::L_W1, [&](int s) { return bop2(u, s); });
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h[t][r] = (r < V::KPT) ? gelu_erf(h[t][r]) : 0.f;     // gelu(0) = 0 on padded rows anyway
+            for (int i = 0; i < K / 2; ++i) { set_pair(h[0], i, gelu2(CF_PAIR(h[0], i))); set_pair(h[1], i, gelu2(CF_PAIR(h[1], i))); }
+            {
+                const f32x2 last = gelu2(f32x2{h[0][K - 1], h[1][K - 1]});
+                h[0][K - 1] = last.x; h[1][K - 1] = last.y;
+            }
             f32x16 a[2];
-            load_vec(a, ws + wl + V::L_B2, lk);                                   // W2 h + b2 on its own, then one add into the residual
-            gemm_regs<2, V::KS_RES>(a, rs, lane, wl + V::L_W2, [&](int s) { return h[s / V::KPT][s % V::KPT]; });
-#pragma unroll
-            for (int t = 0; t < 2; ++t) X[t] += a[t];
+            CF_BIAS(a, ws + wl + V::L_B2);                                   // W2 h + b2 on its own, then one add into the residual
+            gemm_regs<2, V::KS_RES>(a, rs, lane, wl + V::L_W2, [&](int s) { return bop2(h, s); });
+            add_tiles<K>(X, a);
         }
         dump(l + 1);
     }
     f32x16 hn[2];
-    layernorm<V, 2>(X, hn, ws + off_lno<V>(depth), lk, nullptr);                  // transformer.norm: tile 0 = t, tile 1 = raw
+    layernorm_affine<V>(X, hn, ws + off_lno<V>(depth), ws + off_lno<V>(depth) + 64, lk);     // transformer.norm: tile 0 = t, tile 1 = raw
 
     // ================= affine map, log-det, stores                                 (coupling.py:139-155)
     float lsum = 0.f;
 #pragma unroll
-    for (int r = 0; r < V::KPT; ++r) {
-        const int p = trow(r, lk);                           // physical row of both tiles -> (position ii, channel c)
-        const int ii = p / CIN, c = p - ii * CIN;
-        if (p < C) {
-            const float ls = 2.0f * tanhf(0.5f * hn[1][r]);
-            const float z1 = fmaf(y[1][r], expf(ls), hn[0][r]);
-            lsum += ls;
-            if (live) {
-                zb[(CIN + c) * HW + 2 * n + ii] = z1;
-                if (hout) {
-                    float* hb = hout + (int64_t)smp * C * HW;
-                    hb[c * HW + 2 * n + ii] = hn[0][r];
-                    hb[(CIN + c) * HW + 2 * n + ii] = hn[1][r];
-                }
+    for (int r = 0; r < K; ++r) {
+        const int ii = pos_of(r), c = chan_of(r);            // register of both tiles -> (position ii, channel c)
+        const float ls = 2.0f * tanhf(0.5f * hn[1][r]);
+        const float z1 = fmaf(y[1][r], expf(ls), hn[0][r]);
+        lsum += ls;
+        if (live) {
+            zb[(CIN + c) * HW + 2 * n + ii] = z1;
+#ifndef CF_VS_TICKS
+            if (hout) {
+                float* hb = hout + (int64_t)smp * C * HW;
+                hb[c * HW + 2 * n + ii] = hn[0][r];
+                hb[(CIN + c) * HW + 2 * n + ii] = hn[1][r];
             }
+#endif
         }
     }
     lsum += tok_xor<1>(lsum);
     lsum += tok_xor<2>(lsum);
-    lsum += __shfl_xor(lsum, 32, 64);
+    lsum = half_sum(lsum);
     if (live && lk == 0 && n == 0) ldj_acc[smp] += ws[0] + lsum;
+#ifdef CF_VS_TICKS          // probe build (tools/dev/vit_clock.py): shader cycles and 100 MHz reference ticks this wave was alive
+    if (hout && lane == 0) {
+        float* o = hout + (int64_t)(blockIdx.x * 4 + wave) * 2;
+        o[0] = (float)(__builtin_readcyclecounter() - tick0); o[1] = (float)(__builtin_amdgcn_s_memrealtime() - real0);
+    }
+#endif
 }
 
 using VS26 = VS<26>;
@@ -460,6 +596,17 @@ int cf_vit_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, fl
                                                                                     x_bstride, depth, h_out);
     CF_LAUNCH_CHECK();
     return 0;
+}
+
+int64_t cf_vit_step_macs(int C, int depth, int what) {
+    if (C != 26 || depth < 0) return 0;
+    using V = VS26;
+    const int64_t tok = V::NTOK, D = V::DIM, HD = V::HEAD;
+    if (what == 0)           // the reference: Conv1x1, patch Linear, per layer qkv + out + the two MLP Linears, q.k^T and p.v (4 x 4 x 64 each)
+        return (int64_t)C * C * V::HW + tok * (D * C + depth * (3 * HD * D + D * HD + 2 * D * D)) + depth * 2 * tok * tok * HD;
+    if (what == 1)           // MFMAs of a wave (8 samples): 2 tiles x k-steps per product, 2 048 multiply-adds each
+        return (int64_t)(2 * V::KS0 + 2 * V::KS_IN + depth * 4 * 2 * V::KS_RES) * 2048 / 8;
+    return (int64_t)C * C * V::HW + tok * (D * C + depth * 4 * D * D);
 }
 
 // training forward at saturating batches: cf_vit_step_fwd that also writes the residual stream at the layer boundaries -

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CONTEXTFLOW_HIP_LIB: developer override (A/B builds, probe builds of tools/dev); the default is the in-tree library
 LIB_PATH = os.environ.get("CONTEXTFLOW_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libcontextflow_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -95,6 +95,7 @@ SIGNATURES = {
     "cf_vit_step_ws_bytes": (_c_i64, [_c_int] * 2),
     "cf_vit_step_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 2 + [_c_p]),
     "cf_vit_step_fwd": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
+    "cf_vit_step_macs": (_c_i64, [_c_int] * 3),
     "cf_vit_step_rs_supported": (_c_int, [_c_int] * 8),
     "cf_vit_step_rs_ws_bytes": (_c_i64, [_c_int] * 2),
     "cf_vit_step_rs_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 2 + [_c_p]),

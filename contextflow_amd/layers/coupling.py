@@ -270,7 +270,7 @@ class TransCoupling(_AffineCoupling):
 
     # batches up to this size take the row-split step kernel (cf_vit_step_rs_fwd: 4 samples per workgroup, an eighth of the
     # serial chain); larger ones the one-wave-per-8-samples kernel (cf_vit_step_fwd)
-    STEP_RS_MAX_BATCH = 4096          # measured cross-over (tools/dev/vit_variants.py): 77 vs 89 us at 4096, 132 vs 91 at 8192
+    STEP_RS_MAX_BATCH = 3072          # measured cross-over (tools/dev/vit_variants.py, round 4): 43 vs 56 us at 2048, 56.0 vs 56.5 at 3072, 76 vs 56 at 4096
 
     def step_variant(self, B):
         """'rs' | 'wave': which one-kernel form of the step a batch of B samples takes (FlowSequential keys its packed

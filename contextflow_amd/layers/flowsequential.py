@@ -61,6 +61,7 @@ class FlowSequential(nn.Module):
         self.sequence_modules = modules
         self.fused = True
         self.step_events = None      # bench.py: list collecting (start, end, batch, C, H*W) HIP events per step-kernel launch
+        self.inv_events = None       # ... per inverse-step launch (sampling)
         self._plans = {}             # input (C,H,W) -> op list
         self._side = {}              # device index -> side stream for the parameter transforms
         # evaluation (no_grad): the packed step workspaces / GMM tables are kept between calls and rebuilt only when a
@@ -79,7 +80,7 @@ class FlowSequential(nn.Module):
 
     def __getstate__(self):              # streams / cached plans are per-process runtime state
         d = self.__dict__.copy()
-        d["_plans"], d["_side"], d["step_events"] = {}, {}, None
+        d["_plans"], d["_side"], d["step_events"], d["inv_events"] = {}, {}, None, None
         d["_prep"], d["_graphs"], d["_graph_policy"], d["_tensors"] = {}, {}, {}, None
         return d
 
@@ -592,7 +593,14 @@ class FlowSequential(nn.Module):
         _hip.call("cf_flow_step_inv_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
                   pp(wsi), C, H, W, st)
         x = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+        events = self.inv_events
+        if events is not None:               # HIP events on the launch stream, bracketing exactly this kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
         _hip.call("cf_flow_step_inv", pp(z), pp(x), pp(ws), pp(wsi), B, C, H, W, zbs, st)
+        if events is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            events.append((e0, e1, B, C, H * W))
         return x
 
     def inverse(self, z, context=None):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 5
+#define CF_ABI_VERSION 6
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -241,7 +241,7 @@ int cf_flow_step_bwd_prepare(const float* Wm, const float* logs, const float* w1
 
 /* Multiply-adds per sample that the matrix pipe EXECUTES for one step at batch size B (the dispatch picks the Winograd
  * form of the 3x3 - 16 instead of 36 C^2 HW - by shape and batch size): pass 0 = cf_flow_step_fwd, 1 = cf_flow_step_fwd_taped,
- * 2 = cf_flow_step_bwd_taped; cf_step_wgrads_macs: the four weight gradients of cf_step_wgrads.  The ALGORITHMIC count
+ * 2 = cf_flow_step_bwd_taped, 3 = cf_flow_step_inv; cf_step_wgrads_macs: the four weight gradients of cf_step_wgrads.  The ALGORITHMIC count
  * (the reference's direct convolutions) is 40 C^2 HW for each of them.  Host-only, no stream.           */
 int64_t cf_flow_step_macs(int B, int C, int H, int W, int pass);
 int64_t cf_step_wgrads_macs(int B, int C, int H, int W);
@@ -361,6 +361,12 @@ int cf_vit_step_prepare(const float* Wm, const float* t, const float* logs, cons
                         void* ws, int C, int depth, cf_stream_t stream);
 int cf_vit_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, float* h_out, int B, int C, int depth,
                     int64_t x_bstride, cf_stream_t stream);
+/* Multiply-adds PER SAMPLE of one cf_vit_step_fwd launch: what = 0 the reference's count (Conv1x1 + every Linear of the
+ * SimpleViT + q.k^T / p.v, SURVEY.md 8d: 472 384 for C = 26, depth 6); 1 = what the matrix pipe executes, padding rows of
+ * its 32-row tiles included (1 326 v_mfma_f32_32x32x2_f32 per wave of 8 samples); 2 = the useful part of that (the fused
+ * 52 x 52 products of the round-4 kernel: q.k through Wq^T Wk, value / output through Wout Wv).  Host-only, no stream. */
+int64_t cf_vit_step_macs(int C, int depth, int what);
+
 
 /* The same step for SMALL batches (the reference's operating point is 256 samples, config.py:10), row-split: the four waves
  * of a workgroup share 16 token columns (4 samples) and split the output rows of every Linear (v_mfma_f32_16x16x4_f32,

@@ -400,6 +400,48 @@ def end_to_end_stress(name, tag="stress", seed=7):
           % (logs.min(), logs.max(), min(conds), max(conds), fo.bits_per_dim(logp, D).min(), fo.bits_per_dim(logp, D).max(), floor))
 
 
+def end_to_end_wide(name="smap", B=512, seed=11):
+    """Wide fixture: the reference's fp32 and fp64 answers on B fresh samples with the parameters of e2e_<name>.npz (post
+    ActNorm init).  Only inputs, captured augment noise and logp are stored.  Its purpose is statistics: the one-kernel
+    transformer step the benchmark runs (cf_vit_step_fwd, batches > TransCoupling.STEP_RS_MAX_BATCH) is compared per sample
+    with the reference on hundreds of distinct samples, tiled past the dispatch threshold."""
+    from tests.helpers import load_e2e
+    ops, prior_size, M, params, _ = load_e2e(name)
+    flow, nctx = build_reference(name)
+    flow.load_state_dict(params, strict=True)
+    x = synth_input(name, B, seed)
+    ctx = torch.zeros(B, nctx, dtype=torch.long)
+    with torch.no_grad():
+        torch.manual_seed(99 + seed)
+        h, logdet, noise_eps = x, torch.zeros(B, M), []
+        for i, m in enumerate(flow.sequence_modules):
+            out, ldj = m(h, ctx)
+            assert ops[i][0] != "dequant"
+            if ops[i][0] == "augment":
+                noise_eps.append(out[:, h.shape[1]:].clone())
+            logdet += ldj if ldj.dim() == 2 else ldj.unsqueeze(-1)
+            h = out
+        logp = flow.dist.log_prob(h, ctx) + logdet
+        flow64 = flow.double()
+        h, logdet, eps_iter = x.double(), torch.zeros(B, M, dtype=torch.float64), iter(noise_eps)
+        for i, m in enumerate(flow64.sequence_modules):
+            if ops[i][0] == "augment":
+                e = next(eps_iter).double()
+                out, ldj = torch.cat([h, e], 1), -m.distribution.log_prob(e)
+            else:
+                out, ldj = m(h, ctx)
+            logdet += ldj if ldj.dim() == 2 else ldj.unsqueeze(-1)
+            h = out
+        logp64 = flow64.dist.log_prob(h, ctx) + logdet
+    D = int(np.prod(fo.CONFIGS[name][0]))
+    d = (fo.bits_per_dim(logp, D) - fo.bits_per_dim(logp64, D)).abs()
+    fx = dict(x=x.numpy(), logp=logp.numpy(), logp_f64=logp64.numpy(), seed=np.int64(seed), floor_bpd=np.float64(d.max().item()))
+    for j, e in enumerate(noise_eps):
+        fx["eps%d" % j] = e.numpy()
+    np.savez(os.path.join(HERE, "e2e_%s_wide.npz" % name), **fx)
+    print("wide %s B %d: fp32 reference vs its fp64 run: max %.2e rms %.2e bits/dim" % (name, B, d.max().item(), d.pow(2).mean().sqrt().item()))
+
+
 if __name__ == "__main__":
     for name in ("mnist", "cifar10", "smap"):
         end_to_end(name)
@@ -407,6 +449,7 @@ if __name__ == "__main__":
     for tag in ("stress", "extreme"):
         for name in ("mnist", "cifar10", "smap"):
             end_to_end_stress(name, tag)
+    end_to_end_wide("smap")
     sample_inverse_mnist()
     unit_layers()
     for f in sorted(os.listdir(HERE)):

@@ -1,10 +1,12 @@
 """CPU: the oracle (oracle/flow_oracle.py) against the reference's own outputs (tests/golden)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import flow_oracle as fo
-from tests.helpers import load_e2e, pre_init_params, e2e_inputs, unit, bpd, stress_tolerance
+from tests.helpers import load_e2e, pre_init_params, e2e_inputs, unit, bpd, stress_tolerance, GOLDEN
 
 BPD_TOL = 1e-5     # BASELINE.json: bits/dim within 1e-5 of the reference
 Z_TOL = 1e-5
@@ -87,6 +89,21 @@ def test_e2e_stress_regimes(name, tag):
         if k.endswith(("NN_t", "NN_logs")):
             assert torch.allclose(pre[k], params[k], rtol=1e-4, atol=5e-5), k
     assert (bpd(logp_first, name) - bpd(ref, name)).abs().max() < tol
+
+
+def test_wide_smap_fixture():
+    """512 distinct SMAP samples (tests/golden/e2e_smap_wide.npz, make_golden.end_to_end_wide): the oracle in fp32 within the
+    bits/dim bar of the reference's fp32 answer, in fp64 equal to the reference's fp64 run."""
+    ops, _, M, params, _ = load_e2e("smap")
+    fx = dict(np.load(os.path.join(GOLDEN, "e2e_smap_wide.npz")))
+    x, eps = torch.from_numpy(fx["x"]), [torch.from_numpy(fx["eps0"])]
+    _, logp = fo.flow_forward(ops, params, x, None, eps)
+    ref, ref64 = torch.from_numpy(fx["logp"]), torch.from_numpy(fx["logp_f64"])
+    assert (bpd(logp, "smap") - bpd(ref, "smap")).abs().max() < BPD_TOL
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
+    _, logp64 = fo.flow_forward(ops, p64, x.double(), None, [e.double() for e in eps])
+    assert (bpd(logp64, "smap") - bpd(ref64, "smap")).abs().max() < 1e-9
+    assert (bpd(ref, "smap") - bpd(ref64, "smap")).abs().max().item() < 8e-6          # the reference's own fp32-vs-fp64 distance
 
 
 def test_inverse_mnist():

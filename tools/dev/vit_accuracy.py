@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Which of the transformer-step forms is closest to the fp64 oracle?  4096 random SMAP samples through the fixture's
-model: one-kernel step 'wave' (cf_vit_step_fwd), 'rs' (cf_vit_step_rs_fwd), layer mode (cf_vit_coupling); the fp64 and fp32
-oracles on the 64 samples where the forms disagree most.  Prints max |d logp| in nats and bits/dim."""
+"""Which of the transformer-step forms is closest to the fp64 oracle?  N random SMAP samples through the fixture's model
+(random init, and the "stress" parameter set): one-kernel step 'wave' (cf_vit_step_fwd), 'rs' (cf_vit_step_rs_fwd), layer
+mode (cf_vit_coupling), and the fp32 oracle (= the reference's arithmetic) - each against the fp64 oracle on ALL samples:
+max and rms |d bits/dim|.  usage: vit_accuracy.py [N=4096]"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,31 +12,31 @@ import oracle.flow_oracle as fo
 from contextflow_amd.layers.coupling import TransCoupling
 
 DEV = "cuda:0"
-ops, _, M, params, fx = load_e2e("smap")
-B = 4096
-g = torch.Generator().manual_seed(5)
-x = torch.rand(B, 25, 8, 1, generator=g)
-eps = [torch.randn(B, 1, 8, 1, generator=g)]
-model = build_model("smap", params)
-set_noise(model, None, eps)
-out = {}
-with torch.no_grad():
-    model.auto_graph = False
-    for tag, thr, fused in (("wave", 0, True), ("rs", 1 << 30, True), ("layer", 0, False)):
-        TransCoupling.STEP_RS_MAX_BATCH = thr
-        model.fused = fused
-        out[tag] = model(x.to(DEV))[1].double().cpu()
-d = (out["wave"] - out["layer"]).abs().flatten() + (out["rs"] - out["layer"]).abs().flatten()
-idx = torch.topk(d, 64).indices
-p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
-_, ref64 = fo.flow_forward(ops, p64, x[idx].double(), None, [eps[0][idx].double()])
-_, ref32 = fo.flow_forward(ops, params, x[idx], None, [eps[0][idx]])
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 D = 200 * math.log(2)
-for tag in ("wave", "rs", "layer"):
-    e = (out[tag][idx] - ref64).abs().max().item()
-    print("%-6s max |logp - fp64 oracle| over the 64 most-disagreeing samples: %.2e nats = %.2e bits/dim" % (tag, e, e / D))
-e = (ref32.double() - ref64).abs().max().item()
-print("fp32 oracle (= reference arithmetic): %.2e nats = %.2e bits/dim" % (e, e / D))
-for a, b in (("wave", "layer"), ("rs", "layer"), ("wave", "rs")):
-    e = (out[a] - out[b]).abs().max().item()
-    print("%s vs %s over all %d samples: %.2e nats = %.2e bits/dim" % (a, b, B, e, e / D))
+print("library:", os.environ.get("CONTEXTFLOW_HIP_LIB", "product"))
+for tag in (None, "stress"):
+    ops, _, M, params, fx = load_e2e("smap", tag)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 25, 8, 1, generator=g)
+    eps = [torch.randn(B, 1, 8, 1, generator=g)]
+    model = build_model("smap", params)
+    set_noise(model, None, eps)
+    out = {}
+    with torch.no_grad():
+        model.auto_graph = False
+        for form, thr, fused in (("wave", 0, True), ("rs", 1 << 40, True), ("layer", 0, False)):
+            TransCoupling.STEP_RS_MAX_BATCH = thr
+            model.fused = fused
+            out[form] = model(x.to(DEV))[1].double().cpu()
+    p64 = {k: (v.double() if v.is_floating_point() else v) for k, v in params.items()}
+    _, ref64 = fo.flow_forward(ops, p64, x.double(), None, [eps[0].double()])
+    _, ref32 = fo.flow_forward(ops, params, x, None, [eps[0]])
+    out["fp32 oracle"] = ref32.double()
+    print("parameters: %s, %d samples, |logp| up to %.0f nats" % (tag or "random init", B, ref64.abs().max()))
+    for form in ("wave", "rs", "layer", "fp32 oracle"):
+        e = (out[form] - ref64).abs().flatten() / D
+        print("  %-12s vs fp64 oracle: max %.2e  rms %.2e  99.9%% %.2e bits/dim" % (form, e.max(), e.pow(2).mean().sqrt(), e.quantile(0.999)))
+    for a, b in (("wave", "fp32 oracle"), ("rs", "fp32 oracle"), ("wave", "rs"), ("wave", "layer")):
+        e = (out[a] - out[b]).abs().flatten() / D
+        print("  %-5s vs %-12s max %.2e  rms %.2e bits/dim" % (a, b, e.max(), e.pow(2).mean().sqrt()))
