@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--chunk", type=int, default=262144, help="samples per kernel launch sequence on one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the mnist / smap / small-batch lines (N = 1 only)")
+    ap.add_argument("--train", action="store_true", help="time the data-parallel TRAINING step (SURVEY 8(f)1) instead of the forward: "
+                    "one captured HIP graph per rank with the gradient all-reduces inside, weak scaling")
+    ap.add_argument("--train-batch", type=int, default=16384, help="samples per rank and training step (--train)")
     return ap.parse_args()
 
 
@@ -555,6 +558,75 @@ def secondary_small_batch(name, dev, B, cpu, iters=300):
     return out
 
 
+def train_main(a, model, cfg, name, dev, rank, local_rank, world, rehearsal, single_pg, t_start, real_stdout):
+    """--train: the data-parallel training step (experiment_cl.py:123-136 on N ranks).  Every rank owns --train-batch samples
+    (weak scaling) and replays ONE captured HIP graph per step: forward, the reference's loss, hand-written backward whose
+    gradient kernels write into the flat bucket that p.grad views, one RCCL all-reduce per bucket segment enqueued as soon as
+    the segment is complete (it overlaps the backward of the levels below), fused AdamW behind the last of them."""
+    import torch.distributed as dist
+    B = a.train_batch
+    x = synth(name, B, dev, seed=4000 + rank)
+    M = model.mixtures
+    gt = torch.randint(0, M, (B,), device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
+    loss_fn = reference_loss(name)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True)
+    if rehearsal:                    # gloo moves CUDA tensors through the host: not capturable - the rehearsal runs the same step eagerly
+        model.data_parallel = True
+
+        def step(xb, yb):
+            opt.zero_grad(set_to_none=True)
+            l = loss_fn(model.log_prob(xb), yb)
+            l.backward()
+            opt.step()
+            return l.detach()
+    else:
+        step = model.capture_train_step(x, loss_fn, opt)
+    for _ in range(max(a.warmup, 2)):
+        step(x, gt)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(x, gt)
+    fence()
+    dt = time.perf_counter() - t0
+    table = torch.zeros(world, 3, dtype=torch.float64, device=dev)
+    table[rank] = torch.tensor([dt, float(loss), float(local_rank)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        alg, exe = train_flop_per_sample(name, B)
+        tf_exe, tf_alg = exe * B * world * a.steps / dt / 1e12 / world, alg * B * world * a.steps / dt / 1e12 / world
+        bucket = model._grad_bucket
+        out = {"metric": "samples/s training step (fwd + bwd + gradient all-reduce + AdamW), %s" % LABEL[name],
+               "value": round(B * world * a.steps / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": max(a.warmup, 2),
+               "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s --coupling %s, training step %s" % (name, cfg["coupling"], "launched eagerly (gloo rehearsal)" if rehearsal else "as one captured HIP graph per rank"),
+                          "global_batch": B * world, "per_gpu_batch": B, "parallelism": "dp%d" % world,
+                          "collective": "all_reduce(gradient bucket segment) x %d per step, fp32, inside the graph" % (len(bucket.segments) if bucket else 0),
+                          "loss": "experiment_ad.py:207" if M == 1 else "experiment_cl.py:128-133"},
+               "roofline": {"bound": "mfma", "achieved": round(tf_exe, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf_exe / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "algorithmic_tflops": round(tf_alg, 2),
+                            "basis": "per GPU, whole step: dense multiply-adds (forward, data gradients, weight gradients) / wall time"},
+               "comm": {"backend": dist.get_backend() if dist.is_initialized() else None, "world_size": world,
+                        "data_parallel": bool(model.data_parallel), "single_rank_communicator": single_pg, "rehearsal_gloo_on_one_device": rehearsal,
+                        "gradient_messages_bytes": bucket.message_bytes() if bucket else [],
+                        "per_rank": [{"rank": r, "local_rank": int(v[2]), "wall_s": round(float(v[0]), 4), "last_loss": round(float(v[1]), 5)}
+                                     for r, v in enumerate(table.cpu())]},
+               "bench_wall_s": round(time.perf_counter() - t_start, 1)}
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
 def main():
     a = parse()
     import contextflow_amd as cfa
@@ -595,6 +667,12 @@ def main():
     # model: reference init under a fixed seed; rank 0 runs the ActNorm data-dependent init, then ONE flat broadcast
     model, cfg = build(name, dev, rank)
     cdist.broadcast_parameters(model, src=0)
+
+    if a.train:
+        train_main(a, model, cfg, name, dev, rank, local_rank, world, rehearsal, single_pg, t_start, real_stdout)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     G = a.global_batch
     lo, hi = cdist.shard_bounds(G, rank, world)

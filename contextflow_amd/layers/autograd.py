@@ -22,7 +22,7 @@ from .squeeze import squeeze_op
 
 
 # ------------------------------------------------------------------------------------------------ GMM prior
-def gmm_backward(x, dist, prepared, g, gcol=None, side=None, keep=None):
+def gmm_backward(x, dist, prepared, g, gcol=None, side=None, keep=None, sink=None):
     """x: (B, D...) possibly a channel slice; g: (B, M) upstream; gcol: its column sums (M,) if the caller has them (the
     priors of one backward pass share g).  Returns (gx like x, {param: grad})."""
     a, nm, cst, M, K, D = prepared
@@ -52,10 +52,17 @@ def gmm_backward(x, dist, prepared, g, gcol=None, side=None, keep=None):
         side.wait_stream(torch.cuda.current_stream(dev))
         keep.append((xv, r, a, nm, gcol))
     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        return gx.view(xv.shape), _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev)
+        return gx.view(xv.shape), _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev, sink)
 
 
-def _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev):
+def _out(sink, p, shape, dev):
+    """Gradient buffer of parameter p with the kernel's own shape: the parameter's slice of the data-parallel bucket
+    (dist.GradBucket) when one is active - the kernel then writes p.grad's storage directly - or a fresh tensor."""
+    v = sink(p) if sink is not None else None
+    return v.view(shape) if v is not None else torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+def _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev, sink=None):
     """Second half of gmm_backward: the parameter sums and the gradients of mG / sG / wG."""
     st, pp = _hip.stream(), _hip.p
     MK = M * K
@@ -71,11 +78,11 @@ def _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev):
         wsw = torch.empty(L.cf_linear_wgrad_ws_bytes(B, D, MK), device=dev, dtype=torch.uint8)
         _hip.call("cf_linear_wgrad", pp(xf), pp(r), pp(S1), pp(S0), pp(wsw), B, D, MK, st)
         _hip.call("cf_linear_wgrad_x2", pp(xf), pp(r), pp(S2), pp(wsw), B, D, MK, st)
-    g_mu, g_sigma = new(MK, D), new(MK, D)
+    g_mu, g_sigma = _out(sink, dist.mG, (MK, D), dev), _out(sink, dist.sG, (MK, D), dev)
     sG = _hip.f32(dist.sG.detach()).reshape(MK, D)
     if gcol is None:
         gcol = _hip.f32(g).sum(0)
-    g_w = new(M, K)
+    g_w = _out(sink, dist.wG, (M, K), dev)
     wG = _hip.f32(dist.wG.detach()).reshape(M, K)
     _hip.call("cf_gmm_bwd_params_w", pp(a), pp(nm), pp(sG), pp(S0), pp(S1), pp(S2), pp(wG), pp(_hip.f32(gcol)), pp(g_mu), pp(g_sigma),
               pp(g_w), M, K, D, st)
@@ -86,7 +93,8 @@ def _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev):
 WGRAD_SIDE_MAX_BATCH = 1024      # below: the weight gradients of a step run on a side stream, next to the data-gradient chain
 
 
-def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None, side=None, keep=None, wsb=None):
+def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None, side=None, keep=None, wsb=None,
+                  sink=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
     planes: the step tape (y0, h1, h2, aux) written by cf_flow_step_fwd_taped, or None = rebuild it from x with the same kernel.
     gsum: 1-element tensor sum(gld) (the same for every step of a backward pass), or None.
@@ -136,11 +144,11 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
         keep.append((s_gh, s_gh2, s_gh1, s_gy, planes, xv, wsb, gzc, winv, gsum))
     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         return gx, _step_param_part(conv, act, cpl, (C, H, W), xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1, s_y0,
-                                    Wm, t, logs, winv, gsum, gld, B, dev)
+                                    Wm, t, logs, winv, gsum, gld, B, dev, sink)
 
 
 def _step_param_part(conv, act, cpl, shape, xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1, s_y0, Wm, t, logs, winv, gsum,
-                     gld, B, dev):
+                     gld, B, dev, sink=None):
     """Second half of step_backward: the four weight gradients of the step and the Conv1x1 / ActNorm parameter chain."""
     C, H, W = shape
     HW, HALF, HID = H * W, C // 2, 2 * C
@@ -148,8 +156,9 @@ def _step_param_part(conv, act, cpl, shape, xv, xbs, squeeze, s_gh, s_gh2, s_gh1
     f, pp, st = _hip.f32, _hip.p, _hip.stream()
     c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
     e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
-    gw3, gb3, gw2, gb2 = e(1, C, HID), e(C), e(HID, HID, 3, 3), e(HID)
-    gw1, gb1, gWp, gbp = e(1, HID, HALF), e(HID), e(1, C, C), e(C)
+    o = lambda p, *sh: _out(sink, p, sh, dev)
+    gw3, gb3, gw2, gb2 = o(c3.weight, 1, C, HID), o(c3.bias, C), o(c2.weight, HID, HID, 3, 3), o(c2.bias, HID)
+    gw1, gb1, gWp, gbp = o(c1.weight, 1, HID, HALF), o(c1.bias, HID), e(1, C, C), e(C)
     # the step input is read in place by the Conv1x1 weight gradient: through its batch stride (a channel slice after a
     # SplitPrior) and, behind a Squeeze, through the squeeze index map - no squeezed / contiguous copy
     wsw = torch.empty(L.cf_step_wgrads_ws_bytes(B, C, H, W), device=dev, dtype=torch.uint8)
@@ -163,9 +172,7 @@ def _step_param_part(conv, act, cpl, shape, xv, xbs, squeeze, s_gh, s_gh2, s_gh1
         lad = torch.empty(1, device=dev, dtype=torch.float32)
         winv = torch.empty(C, C, device=dev, dtype=torch.float32)
         _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
-    gNN = torch.empty(C, C, device=dev, dtype=torch.float32)
-    gt = torch.empty(C, device=dev, dtype=torch.float32)
-    glogs = torch.empty(C, device=dev, dtype=torch.float32)
+    gNN, gt, glogs = o(conv.NN, C, C), o(act.NN_t, C), o(act.NN_logs, C)
     gWpc = gWp.contiguous()
     _hip.call("cf_step_param_grads", pp(gWpc), pp(gbp), pp(Wm), pp(t), pp(logs), pp(f(winv)), pp(f(gsum)), HW, pp(gNN), pp(gt),
               pp(glogs), C, st)
@@ -318,9 +325,32 @@ class FlowLogProb(torch.autograd.Function):
         gcol = glogp.sum(0)                                 # ... and by the mixture-weight gradients of all priors
         acc = {}
 
+        # data-parallel training (FlowSequential.data_parallel): gradients are written straight into the flat bucket that
+        # p.grad views (dist.GradBucket); each segment is all-reduced as soon as its last gradient kernel has been launched
+        bucket = _bucket_for(flow, tape, params) if getattr(flow, "data_parallel", False) else None
+        sink = bucket.view if bucket is not None else None
+        pending, written = ([], []), set()
+
         def add(d):
             for p, g in d.items():
-                acc[p] = g if p not in acc else acc[p] + g
+                v = sink(p) if sink is not None else None
+                if v is None:
+                    acc[p] = g if p not in acc else acc[p] + g
+                elif p in written:
+                    v.add_(g.view_as(v))
+                else:
+                    written.add(p)
+                    if g.data_ptr() != v.data_ptr():         # produced elsewhere (transformer steps, layer-by-layer records)
+                        pending[0].append(v)
+                        pending[1].append(g.reshape(v.shape))
+
+        def flush(seg_done):
+            """copy what did not land in the bucket by itself (one multi-tensor launch), then start the collectives"""
+            if pending[0]:
+                torch._foreach_copy_(pending[0], pending[1])
+                del pending[0][:], pending[1][:]
+            for i in seg_done:
+                bucket.reduce(i)
 
         # small batches: the kernels of a step fill a fraction of the chip, and the weight gradients of step k are off the chain
         # that leads to step k - 1 - they run on the flow's side stream and meet the main stream once, at the end
@@ -329,41 +359,34 @@ class FlowLogProb(torch.autograd.Function):
         side = flow._side_stream(dev) if (glogp.is_cuda and B0 <= WGRAD_SIDE_MAX_BATCH) else None
         keep = []
 
-        def add_on(d):               # parameter gradients produced on the side stream are accumulated there
-            if side is not None:
-                with torch.cuda.stream(side):
-                    add(d)
-            else:
+        def add_on(d, ri):           # parameter gradients produced on the side stream are accumulated there
+            import contextlib
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 add(d)
+                if bucket is not None:
+                    flush(bucket.closes.get(ri, ()))
         gz = None
-        for rec in reversed(tape):
+        for ri in range(len(tape) - 1, -1, -1):
+            rec = tape[ri]
             kind = rec[0]
             if kind == "prior":
                 _, xin, dist, prep = rec
-                gz, gp = gmm_backward(xin, dist, prep, glogp, gcol, side, keep)
-                add_on(gp)
+                gz, gp = gmm_backward(xin, dist, prep, glogp, gcol, side, keep, sink)
+                add_on(gp, ri)
             elif kind == "split":
                 _, xin, dist, prep = rec                      # xin: full tensor before the split
                 c = xin.shape[1] // 2
-                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp, gcol, side, keep)
-                add_on(gp)
+                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp, gcol, side, keep, sink)
+                add_on(gp, ri)
                 gz = torch.cat([gz, g2], dim=1)
             elif kind == "step":
                 _, xin, sq, conv, act, cpl, shape, ws, winv, planes, wsb = rec
-                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, side, keep, wsb)
-                if side is not None:
-                    with torch.cuda.stream(side):
-                        add(gp)
-                else:
-                    add(gp)
+                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, side, keep, wsb, sink)
+                add_on(gp, ri)
             elif kind == "vstep":
                 _, xin, conv, act, cpl, ws_rs, xtape = rec
                 gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape, side, keep)
-                if side is not None:
-                    with torch.cuda.stream(side):
-                        add(gp)
-                else:
-                    add(gp)
+                add_on(gp, ri)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)
             elif kind == "pre":
@@ -372,6 +395,8 @@ class FlowLogProb(torch.autograd.Function):
                 _, mod, xin = rec
                 gz, gp = layer_backward(mod, xin, gz, gld)
                 add(gp)
+                if bucket is not None:
+                    flush(bucket.closes.get(ri, ()))
             else:
                 raise NotImplementedError("no backward for tape record %r" % (kind,))
         if side is not None:
@@ -380,4 +405,68 @@ class FlowLogProb(torch.autograd.Function):
             for g in acc.values():
                 g.record_stream(main)
             del keep
+        if bucket is not None:
+            bucket.finish()                                  # this stream (the optimizer's) waits for the collectives
+            for p in params:
+                v = bucket.view(p)
+                if v is not None:
+                    p.grad = v                               # (assigned, not accumulated: one backward per optimizer step)
         return (None, None) + tuple(acc.get(p) for p in params)
+
+
+SEGMENT_MIN_BYTES = 1 << 20      # data-parallel bucket: a segment is closed at the first record boundary past this size, and at every SplitPrior
+
+
+def _record_params(rec):
+    """trainable tensors of a tape record, in the order the backward lists them"""
+    kind = rec[0]
+    if kind in ("prior", "split"):
+        d = rec[2]
+        return [d.mG, d.sG, d.wG]
+    if kind == "step":
+        conv, act, cpl = rec[3], rec[4], rec[5]
+        c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
+        return [conv.NN, act.NN_t, act.NN_logs, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias]
+    if kind == "vstep":
+        return [p for m in rec[2:5] for p in m.parameters()]
+    if kind == "layer":
+        return list(rec[1].parameters())
+    return []
+
+
+def _bucket_for(flow, tape, params):
+    """The flow's gradient bucket for this tape (built on the first backward of a parameter set, then kept: its storage is
+    what p.grad views, also across replays of a captured step).  Segments follow the backward: the final prior and the
+    steps of the last level first; a segment closes at a SplitPrior (= a resolution level is done) or once it holds
+    SEGMENT_MIN_BYTES; bucket.closes[record index] = segments whose last gradient that record produces."""
+    from .. import dist as cdist
+    want = {id(p) for p in params if p.requires_grad}
+    groups, closes, cur, size = [], {}, [], 0
+    for ri in range(len(tape) - 1, -1, -1):
+        rec = tape[ri]
+        if rec[0] == "pre":
+            break
+        if rec[0] == "split" and cur:                        # the level above is complete
+            closes.setdefault(last, []).append(len(groups))
+            groups.append(cur)
+            cur, size = [], 0
+        ps = [p for p in _record_params(rec) if id(p) in want]
+        if not ps:
+            continue
+        cur += ps
+        size += 4 * sum(p.numel() for p in ps)
+        last = ri
+        if size >= SEGMENT_MIN_BYTES:
+            closes.setdefault(ri, []).append(len(groups))
+            groups.append(cur)
+            cur, size = [], 0
+    if cur:
+        closes.setdefault(last, []).append(len(groups))
+        groups.append(cur)
+    key = tuple(id(p) for g in groups for p in g)
+    b = getattr(flow, "_grad_bucket", None)
+    dev = params[0].device if params else torch.device("cpu")
+    if b is None or b.key != key or b.flat.device != dev:
+        b = flow._grad_bucket = cdist.GradBucket(groups, dev)
+    b.closes = closes
+    return b

@@ -258,7 +258,11 @@ class TransCoupling(_AffineCoupling):
         if att is None:
             return False
         C, H, W = shape
-        return bool(_hip.lib().cf_vit_step_supported(C, H, W, self.p_sz[0], self.p_sz[1], vit.dim, att.dim_head, att.heads))
+        L = _hip.lib()
+        a = (C, H, W, self.p_sz[0], self.p_sz[1], vit.dim, att.dim_head, att.heads)
+        # both one-kernel forms must cover the geometry (the dispatch picks by batch size, the training step runs the
+        # row-split backward kernel, depth <= STEP_MAX_DEPTH); anything else keeps the layer path
+        return bool(L.cf_vit_step_supported(*a)) and bool(L.cf_vit_step_rs_supported(*a)) and len(vit.transformer.layers) <= self.STEP_MAX_DEPTH
 
     def step_sources(self):
         """Parameters the packed step workspace derives from (cache key of FlowSequential).  The tuple is built once: walking
@@ -271,6 +275,8 @@ class TransCoupling(_AffineCoupling):
     # batches up to this size take the row-split step kernel (cf_vit_step_rs_fwd: 4 samples per workgroup, an eighth of the
     # serial chain); larger ones the one-wave-per-8-samples kernel (cf_vit_step_fwd)
     STEP_RS_MAX_BATCH = 3072          # measured cross-over (tools/dev/vit_variants.py, round 4): 43 vs 56 us at 2048, 56.0 vs 56.5 at 3072, 76 vs 56 at 4096
+
+    STEP_MAX_DEPTH = 6                # cf_vit_step_bwd parks the residual stream of <= 6 layer boundaries in LDS
 
     def step_variant(self, B):
         """'rs' | 'wave': which one-kernel form of the step a batch of B samples takes (FlowSequential keys its packed

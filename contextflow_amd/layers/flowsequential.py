@@ -41,6 +41,21 @@ TAPE_PLANES = True
 
 VSTEP_TAPE = True        # transformer steps in training: keep the residual-stream tape (False: the backward kernel recomputes it)
 
+# Parameter OBJECTS can be replaced behind a flow's back (`load_state_dict(assign=True)`, `m.weight = nn.Parameter(...)`,
+# parametrizations): the new tensor starts at version 0 again, so the version-counter keys of the evaluation caches would
+# match stale packed tables.  Every parameter registration in the process bumps this counter (a global torch hook: one integer
+# compare per forward, where walking 580 data_ptr()s would cost more than a replayed SMAP forward); a flow that sees a new
+# value drops everything it derived from parameters.  Writes through `param.data` (in-place or by assignment) move neither
+# the version counter nor this one: call FlowSequential.invalidate_caches() after them.
+_PARAM_GENERATION = [0]
+
+
+def _on_parameter_registration(module, name, param):
+    _PARAM_GENERATION[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_on_parameter_registration)
+
 
 def step_tape(B, C, H, W, dev):
     """Buffers of one step's training tape (cf_flow_step_fwd_taped): y0 (B, C/2, HW), h1, h2 (B, 2C, HW) - the operands of
@@ -74,6 +89,11 @@ class FlowSequential(nn.Module):
         self._graph_policy = {}      # (shape, device) -> replaying beat eager launches when it was measured (else: stay eager)
         self._tensors = None         # parameters + buffers, collected once (_versions)
         self._rng_key = 0            # Philox key of the in-kernel noise (rank folded in); the stream position is drawn per call
+        # data-parallel training (dist.GradBucket, layers/autograd.py): the backward writes the gradients into one flat
+        # bucket that p.grad views and all-reduces it segment by segment while it is still running
+        self.data_parallel = False
+        self._grad_bucket = None
+        self._gen = _PARAM_GENERATION[0]
 
     def __iter__(self):
         yield from self.sequence_modules
@@ -82,6 +102,7 @@ class FlowSequential(nn.Module):
         d = self.__dict__.copy()
         d["_plans"], d["_side"], d["step_events"], d["inv_events"] = {}, {}, None, None
         d["_prep"], d["_graphs"], d["_graph_policy"], d["_tensors"] = {}, {}, {}, None
+        d["_grad_bucket"] = None
         return d
 
     def invalidate_caches(self):
@@ -90,6 +111,8 @@ class FlowSequential(nn.Module):
         `.to()` are noticed without it."""
         self._prep.clear()
         self._graphs.clear()
+        self._graph_policy.clear()                   # the replay-vs-eager verdicts are measured again
+        self._tensors = None                         # a Parameter OBJECT may have been replaced (load_state_dict(assign=True), m.w = nn.Parameter(..))
         self.__dict__.pop("_spec_ws", None)          # layers/specialist.py: packed coupling tables, log|det NN| of frozen Conv1x1,
         self.__dict__.pop("_spec_lad", None)         # Conv1x1.CN in blocked row order
         self.__dict__.pop("_spec_cnb", None)
@@ -98,9 +121,12 @@ class FlowSequential(nn.Module):
                 m._tab_cache = None
             if hasattr(m, "_flat_cache"):
                 m._flat_cache = None
+            if hasattr(m, "_step_src"):
+                m._step_src = None
 
     def _apply(self, fn, *a, **k):         # .to() / .cuda() / .float(): new storages, same version counters
         self._prep, self._graphs, self._plans, self._tensors = {}, {}, {}, None
+        self._grad_bucket = None
         self.__dict__.pop("_spec_ws", None)
         self.__dict__.pop("_spec_lad", None)
         self.__dict__.pop("_spec_cnb", None)
@@ -264,6 +290,11 @@ class FlowSequential(nn.Module):
         # a capturing stream must not wait on an event recorded outside the capture - and need not: torch.cuda.graph
         # synchronises the device before the capture begins, so cached tables are complete by then
         capturing = torch.cuda.is_current_stream_capturing()
+        # tables built DURING a capture live in the graph's private pool and their events belong to the capture: they must not
+        # outlive it as cache entries (a later eager call would wait on a captured event and read buffers that only exist
+        # after a replay).  GraphedFlow warms the cache up before it captures; a user-side capture with a cold cache simply
+        # rebuilds the tables inside its graph.
+        store_ok = cache_ok and not capturing
         for k, op in enumerate(plan):
             if op[0] == "step":
                 srcs = (op[1].NN, op[2].NN_t, op[2].NN_logs) + tuple(p for c in (op[3].NN[0], op[3].NN[2], op[3].NN[4]) for p in (c.weight, c.bias))
@@ -310,14 +341,14 @@ class FlowSequential(nn.Module):
                     ev.record(side)
                     prepared[k] = (buf, ev)
                     fresh.add(k)
-                    if cache_ok:
+                    if store_ok:
                         self._prep[(key, k, vkey.get(k))] = (ver, buf, ev)
                 if prior is None:
                     prior = self.dist.prepared()
                     ev_prior = torch.cuda.Event()
                     ev_prior.record(side)
                     fresh.add("prior")
-                    if cache_ok:
+                    if store_ok:
                         self._prep[(key, "prior")] = (pver, prior, ev_prior)
 
         # running log-dets: per-sample scalar terms / per-mixture terms (priors).  The first writer ASSIGNS (no zero-fill
@@ -475,6 +506,9 @@ class FlowSequential(nn.Module):
     # ------------------------------------------------------------------ reference API
     def forward(self, input, context=None):
         _hip.require_device(input)
+        if self._gen != _PARAM_GENERATION[0]:            # a Parameter object was (re)registered somewhere: see _PARAM_GENERATION
+            self._gen = _PARAM_GENERATION[0]
+            self.invalidate_caches()
         if torch.is_grad_enabled() and self._specialist():
             from .autograd_ctx import trainable as _trainable
             params = [p for p in self.parameters() if p.requires_grad]
@@ -544,34 +578,50 @@ class FlowSequential(nn.Module):
                     return None
         return st[2]
 
-    def _replay_wins(self, g, x, n=3):
+    def _replay_wins(self, g, x, n=5, rounds=2, margin=0.97):
         """A replayed node costs ~7-12 us whatever its kernel does, eager launches are queued ahead of the running kernel:
-        with kernels longer than that (the transformer steps: ~90 us each at a batch of 256) the eager forward is the faster
-        one.  Measured once per input shape (the answer does not depend on parameter values): n eager forwards against n
-        replays, wall time; the generator is handed back as it was, so the noise sequence does not see the probe."""
-        import time
+        with kernels longer than that (the transformer steps: ~30 us each at a batch of 256) the eager forward can be the
+        faster one.  Measured once per input shape (the answer does not depend on parameter values; invalidate_caches()
+        forgets it): n eager forwards against n replays between HIP events on the launch stream, best of `rounds` each -
+        device time, so that a busy host core (bench.py's CPU-baseline threads) cannot pin the verdict - and the graph is
+        only rejected when eager is faster by more than 3 %.  The generator is handed back as it was, so the noise
+        sequence does not see the probe."""
         dev = x.device
         gen = torch.cuda.default_generators[dev.index]
         gstate = gen.get_state()
-        t = []
+        stream = torch.cuda.current_stream(dev)
+        best = []
         for run in (lambda: self._forward_fused(x, None), lambda: g(x)):
             run()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for _ in range(n):
-                run()
-            torch.cuda.synchronize(dev)
-            t.append(time.perf_counter() - t0)
+            t = []
+            for _ in range(rounds):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(n):
+                    run()
+                e1.record(stream)
+                e1.synchronize()
+                t.append(e0.elapsed_time(e1))
+            best.append(min(t))
         gen.set_state(gstate)
-        return t[1] < t[0]
+        return best[1] * margin < best[0]
 
-    def capture_train_step(self, example_input, loss_fn, optimizer, warmup=1):
+    def capture_train_step(self, example_input, loss_fn, optimizer, warmup=1, data_parallel=None):
         """One whole training step - forward, loss, hand-written backward, optimizer update - captured into ONE HIP graph
         (at the reference's batch of 256 a step is ~330 launches of a few microseconds each: launch-bound).  Returns
         `step(x, *loss_args) -> loss` that copies its arguments into static buffers and replays; `loss_fn(logp, *loss_args)`
         maps the (B, M) log-densities to a scalar.  The optimizer must be capturable (`torch.optim.AdamW(..., capturable=
         True)`); ActNorm layers must be initialised (run one forward first).  The first call runs `warmup` eager steps
-        (real updates; default 1) and captures; see GraphedTrainStep."""
+        (real updates; default 1) and captures; see GraphedTrainStep.
+        data_parallel (default: whether a process group of more than one rank exists): every rank steps on ITS shard of the
+        batch and the gradients are averaged over the ranks inside the step - written by the backward kernels into one flat
+        bucket that `p.grad` views, all-reduced (RCCL) segment by segment while the backward of the lower levels still runs,
+        the optimizer waits for the last one; the collectives are captured with the step (`self.data_parallel`,
+        dist.GradBucket)."""
+        if data_parallel is None:
+            from .. import dist as cdist
+            data_parallel = cdist._active()
+        self.data_parallel = bool(data_parallel)
         return GraphedTrainStep(self, example_input, loss_fn, optimizer, warmup)
 
     def log_prob(self, input, context=None):

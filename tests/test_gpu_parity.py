@@ -1264,6 +1264,65 @@ def test_auto_graph_replay_and_cache_invalidation(L):
     assert abs(float(bs.mean() - b[0].mean())) > 0.1                    # the shift is visible
 
 
+def test_replaced_parameter_objects_drop_the_caches(L):
+    """A Parameter OBJECT replaced after the caches were filled - `m.NN = nn.Parameter(...)`, `load_state_dict(assign=True)` -
+    starts at version 0 again, which would match the version-counter keys of the stale packed tables and captured graphs:
+    the process-wide parameter-registration hook (flowsequential._PARAM_GENERATION) makes the flow drop them.  Checked with
+    fixed noise (deterministic log-densities): after each replacement the result equals that of a freshly built model with
+    the same parameters, and differs from the stale one."""
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e("mnist")
+    x, u, eps = e2e_inputs("mnist", fx)
+    model = build_model("mnist", params)
+    set_noise(model, u, eps)
+    with torch.no_grad():
+        base = [model.log_prob(x.to(DEV)) for _ in range(3)][-1]          # caches filled
+        conv = next(m for m in model.sequence_modules if isinstance(m, L.Conv1x1))
+        conv.NN = torch.nn.Parameter(conv.NN.detach().clone() * 1.25)      # fresh object, version 0, other values
+        p2 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        got = model.log_prob(x.to(DEV))
+        fresh = build_model("mnist", p2)
+        set_noise(fresh, u, eps)
+        assert torch.equal(got, fresh.log_prob(x.to(DEV))) and not torch.equal(got, base)
+        p3 = {k: (v * 0.5 if k == "dist.mG" else v.clone()) for k, v in p2.items()}
+        model.load_state_dict({k: v.to(DEV) for k, v in p3.items()}, assign=True)
+        got3 = model.log_prob(x.to(DEV))
+        fresh3 = build_model("mnist", p3)
+        set_noise(fresh3, u, eps)
+        assert torch.equal(got3, fresh3.log_prob(x.to(DEV))) and not torch.equal(got3, got)
+
+
+def test_user_side_capture_with_a_cold_cache_leaves_no_stale_entries(L):
+    """torch.cuda.graph around an evaluation forward whose table cache is cold: the tables are built inside the capture (graph
+    pool, captured events) and must NOT be kept as cache entries - the next eager call rebuilds its own and gives the eager
+    result."""
+    from tests.gpu_util import build_model, set_noise
+    ops, _, M, params, fx = load_e2e("mnist")
+    x, u, eps = e2e_inputs("mnist", fx)
+    xd = x.to(DEV)
+    ref_model = build_model("mnist", params)
+    set_noise(ref_model, u, eps)
+    model = build_model("mnist", params)
+    set_noise(model, u, eps)
+    model.auto_graph = False
+    with torch.no_grad():
+        ref = ref_model.log_prob(xd)
+        model._plans[tuple(xd.shape[1:])] = model._build_plan(tuple(xd.shape[1:]))
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            torch.zeros(1, device=DEV)                                  # (allocator / lazy-init warm-up on the side stream)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            _, captured = model._forward_fused(xd, None)
+        assert not model._prep                                          # nothing from inside the capture was cached
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(captured, ref)
+        assert torch.equal(model.log_prob(xd), ref)                     # eager call afterwards: own tables, same numbers
+
+
 def test_auto_graph_keeps_eager_where_replay_loses(L):
     """The replay-or-eager decision is measured once per input shape and kept across parameter updates; a shape whose probe
     said "eager" is never captured again, and the probe leaves torch's generator where it was (same noise either way)."""
@@ -2113,6 +2172,131 @@ def test_rccl_communicator_runs_every_collective_of_the_data_parallel_path(tmp_p
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["CF_ROOT"])
+import torch, torch.distributed as dist
+import contextflow_amd as cfa
+from contextflow_amd import dist as cdist
+torch.cuda.set_device(0)
+rank, world, backend = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), os.environ["DP_BACKEND"]
+dist.init_process_group(backend, rank=rank, world_size=world)
+dev = torch.device("cuda", 0)
+name = os.environ.get("DP_FLOW", "cifar10")
+cfg, ds, M = cfa.preset_config(name)
+B = 64 * world                                                   # global batch; every rank owns a contiguous 64
+g = torch.Generator().manual_seed(1)
+xg = (torch.rand(B, *ds, generator=g) if name == "smap" else torch.randint(0, 256, (B, *ds), generator=g).float()).to(dev)
+ug = torch.rand(B, *ds, generator=g).to(dev)
+eg = torch.randn(B, 1, ds[1], ds[2], generator=g).to(dev)
+yg = torch.randint(0, M, (B,), generator=g).to(dev)
+inv = 1.0 / xg[0].numel()
+loss_fn = lambda lp, y: torch.nn.functional.cross_entropy(lp * inv, y) if M > 1 else -(lp * inv).mean()
+
+def set_noise(m, lo, hi):                                        # the same noise on every path: rows lo..hi of the global draw
+    for q in m.sequence_modules:
+        if isinstance(q, cfa.layers.Dequantization):
+            q.dist.fixed_noise = ug[lo:hi]
+        if isinstance(q, cfa.layers.Augment):
+            q.distribution.fixed_noise = eg[lo:hi]
+
+def build(lo, hi):
+    torch.manual_seed(0)
+    m = cfa.create_model(cfg, ds, M).to(dev)
+    set_noise(m, 0, B)
+    with torch.no_grad():
+        m(xg)                                                    # ActNorm init on the GLOBAL batch, identical on every rank
+    set_noise(m, lo, hi)
+    return m.train()
+
+lo, hi = cdist.shard_bounds(B, rank, world)
+mode = os.environ["DP_MODE"]
+if mode == "two_rank_eager":
+    # every rank: one eager data-parallel step on ITS shard; gradients = the one-process gradients on the whole batch
+    os.environ["CF_DIST_SINGLE_RANK"] = "0"
+    dp = build(lo, hi)
+    dp.data_parallel = True
+    loss = loss_fn(dp.log_prob(xg[lo:hi]), yg[lo:hi])
+    loss.backward()
+    bucket = dp._grad_bucket
+    assert bucket is not None and len(bucket.segments) >= 2
+    for p in dp.parameters():
+        assert p.grad is not None and p.grad.data_ptr() == bucket.view(p).data_ptr()      # views of the flat bucket, no copies
+    ref = build(0, B)                                            # one process, concatenated batch, no collectives
+    loss_fn(ref.log_prob(xg), yg).backward()
+    worst = 0.0
+    for (k, a), (_, b) in zip(dp.named_parameters(), ref.named_parameters()):
+        d = (a.grad - b.grad).abs().max().item() / max(b.grad.abs().max().item(), 1e-30)
+        worst = max(worst, d)
+        assert d < 2e-6, (k, d)
+    print("rank %d: worst relative gradient difference %.2e over %d tensors, %d messages of %s bytes"
+          % (rank, worst, len(list(dp.parameters())), len(bucket.segments), bucket.message_bytes()))
+else:
+    # one rank, RCCL: the captured data-parallel step (collectives inside the graph) against the eager loop without collectives
+    assert backend == "nccl" and world == 1
+    os.environ["CF_DIST_SINGLE_RANK"] = "0"
+    eager = build(0, B)
+    opt_e = torch.optim.AdamW(eager.parameters(), lr=1e-3, fused=True, capturable=True)
+    losses_e = []
+    for _ in range(4):
+        opt_e.zero_grad(set_to_none=True)
+        l = loss_fn(eager.log_prob(xg), yg)
+        l.backward()
+        opt_e.step()
+        losses_e.append(float(l.detach()))
+    os.environ["CF_DIST_SINGLE_RANK"] = "1"                     # a one-rank RCCL communicator carries the collectives
+    cap = build(0, B)
+    opt_c = torch.optim.AdamW(cap.parameters(), lr=1e-3, fused=True, capturable=True)
+    step = cap.capture_train_step(xg, loss_fn, opt_c)            # data_parallel defaults to "a communicator is active"
+    assert cap.data_parallel
+    losses_c = [float(step(xg, yg).detach()) for _ in range(4)]
+    for p in cap.parameters():
+        assert p.grad.data_ptr() == cap._grad_bucket.view(p).data_ptr()
+    for a, b in zip(losses_e, losses_c):
+        assert abs(a - b) < 2e-6 * max(1.0, abs(a)), (losses_e, losses_c)
+    for (k, a), (_, b) in zip(eager.named_parameters(), cap.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), k           # same kernels, same order: the bucket only changes where gradients live
+    print("captured data-parallel step == eager loop, losses", losses_c)
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("DP_OK")
+'''
+
+
+def _run_dp_workers(tmp_path, world, backend, mode, flow, port):
+    import subprocess
+    import sys
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, CF_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", DP_BACKEND=backend, DP_MODE=mode, DP_FLOW=flow)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 and "DP_OK" in o for p, o in zip(procs, outs)), "\n".join(o[-3000:] for o in outs)
+    print(outs[0][-600:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flow", ["cifar10", "smap"])
+def test_data_parallel_step_of_two_ranks_equals_one_process_on_the_whole_batch(tmp_path, flow):
+    """SURVEY.md 8(f)1 "+ gradient all-reduce" (experiment_cl.py:130-136 on N ranks): two processes (both on device 0, gloo
+    transport - a one-GPU box), each with its contiguous half of a batch of 128, run ONE eager data-parallel step
+    (FlowSequential.data_parallel: gradients written into the flat bucket, all-reduced segment by segment during the
+    backward, averaged); every gradient tensor equals the one a single process computes on the whole batch to 2e-6 of its
+    largest entry (two split-K halves averaged against one sum: rounding only)."""
+    _run_dp_workers(tmp_path, 2, "gloo", "two_rank_eager", flow, 29551 if flow == "cifar10" else 29553)
+
+
+@pytest.mark.gpu
+def test_captured_data_parallel_step_through_rccl_equals_the_eager_loop(tmp_path):
+    """The data-parallel training step as ONE HIP graph with its collectives captured inside, through a real RCCL
+    communicator (of one rank: a one-GPU box): four updates give bit for bit the parameters of the eager loop without any
+    collective, and p.grad are views of the flat bucket (no concatenation, no copy back)."""
+    _run_dp_workers(tmp_path, 1, "nccl", "one_rank_captured", "cifar10", 29555)
 
 
 # ------------------------------------------------------------------------------------------ Winograd form of the 3x3

@@ -281,6 +281,98 @@ def test_two_rank_sharded_actnorm_init_and_bucketed_broadcast_gloo(tmp_path):
     assert "OK" in outs[0]
 
 
+BUCKET_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from contextflow_amd.dist import init_process_group, GradBucket
+rank, _, world = init_process_group("gloo")
+torch.manual_seed(0)
+ps = [torch.nn.Parameter(torch.zeros(*sh)) for sh in ((3, 5), (7,), (2, 2, 3, 3), (1,), (6, 1))]
+b = GradBucket([ps[:2], ps[2:4], ps[4:]], torch.device("cpu"))
+assert len(b.segments) == 3 and b.flat.numel() == 16 + 8 + 36 + 4 + 8
+for i, p in enumerate(ps):                                 # the "gradient kernels" write the views; p.grad IS the view
+    b.view(p).fill_(float((rank + 1) * (i + 1)))
+    p.grad = b.view(p)
+    assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * b.slots[p][0] and p.grad.shape == p.shape
+for i in range(len(b.segments)):
+    b.reduce(i)                                            # one message per segment, enqueued as soon as it is complete
+b.finish()
+for i, p in enumerate(ps):
+    assert torch.equal(p.grad, torch.full_like(p, 1.5 * (i + 1))), (rank, i, p.grad.flatten()[:3])      # mean over the two ranks
+assert b.message_bytes() == [96, 160, 32]
+dist.barrier()
+if rank == 0: print("OK")
+'''
+
+
+def test_two_rank_gradient_bucket_gloo(tmp_path):
+    """dist.GradBucket: p.grad are views of ONE flat tensor, every segment is reduced in place (no cat / copy back), the
+    result is the mean over the ranks."""
+    script = tmp_path / "bworker.py"
+    script.write_text(BUCKET_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0]
+
+
+@pytest.mark.parametrize("name", ["cifar10", "mnist", "smap"])
+def test_gradient_bucket_follows_the_backward(built, name):
+    """layers/autograd.py::_bucket_for on the tape the fused plan of a flow would leave (built on the CPU from the plan:
+    records carry modules only): every trainable tensor has exactly one slot, slots appear in the order the backward
+    produces the gradients (final prior and last level first), a segment closes at every SplitPrior and once it holds
+    1 MB, and `closes` names the record after which each segment is complete."""
+    import contextflow_amd as cfa
+    from contextflow_amd.layers import autograd as ag
+    cfg, ds, M = cfa.preset_config(name)
+    flow = cfa.create_model(cfg, ds, M)
+    for m in flow.modules():
+        if hasattr(m, "initialized"):
+            m.initialized.fill_(1)
+            m._init_done = True
+    plan = flow._build_plan(tuple(ds))
+    tape = []
+    for op in plan:
+        if op[0] == "pre":
+            tape.append(("pre",))
+        elif op[0] == "step":
+            tape.append(("step", None, op[5], op[1], op[2], op[3], op[4], None, None, None, None))
+        elif op[0] == "vstep":
+            tape.append(("vstep", None, op[1], op[2], op[3], None, None))
+        elif op[0] == "split":
+            tape.append(("split", None, op[1].dist, None))
+        elif op[0] == "squeeze":
+            tape.append(("squeeze", tuple(op[1].p)))
+        else:
+            tape.append(("layer", op[1], None))
+    tape.append(("prior", None, flow.dist, None))
+    params = [p for p in flow.parameters() if p.requires_grad]
+    b = ag._bucket_for(flow, tape, params)
+    assert set(b.slots) == set(params) and len(b.slots) == len(params)
+    lo_prev = -1
+    order = [p for ri in range(len(tape) - 1, -1, -1) for p in ag._record_params(tape[ri])]
+    for p in order:                                         # backward order, 16-byte aligned, disjoint
+        lo, n = b.slots[p]
+        assert lo > lo_prev and lo % 4 == 0 and n == p.numel()
+        lo_prev = lo + n - 1
+    assert b.segments[0][0] == 0 and all(a[1] == c[0] for a, c in zip(b.segments, b.segments[1:])) and b.segments[-1][1] == b.flat.numel()
+    assert b.segment_of(flow.dist.mG) == 0                 # the final prior leads the first message
+    nsplit = sum(1 for r in tape if r[0] == "split")
+    assert len(b.segments) >= nsplit + 1
+    closed = sorted(i for v in b.closes.values() for i in v)
+    assert closed == list(range(len(b.segments)))
+    for ri, segs in b.closes.items():                       # the closing record owns the last slot of its segments
+        last = max(b.slots[p][0] for p in ag._record_params(tape[ri]))
+        assert b.segments[segs[-1]][0] <= last < b.segments[segs[-1]][1]
+    if name == "cifar10":
+        mb = [v / 2 ** 20 for v in b.message_bytes()]
+        assert abs(sum(mb) - 1518896 * 4 / 2 ** 20) < 0.01 and max(mb) < 2.6, mb
+    assert ag._bucket_for(flow, tape, params) is b          # kept: p.grad keeps viewing the same storage
+
+
 def test_calls_run_on_the_device_that_owns_the_tensors(built, monkeypatch):
     """`_hip.call` launches on the device the tensor arguments live on, on that device's current stream - the reference
     picks `cuda:N` without torch.cuda.set_device (model.py:170).  Host-side check of the selection logic with stand-in
