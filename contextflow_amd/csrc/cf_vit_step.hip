@@ -283,11 +283,27 @@ __device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
 // that sits in the packed weights of the Linear behind it, or is applied by layernorm_affine).  NT tiles of KPT valid
 // registers per lane; the two lane halves hold different features of the same token.
 template <class V, int NT>
+__device__ __forceinline__ float normalize_stats(const f32x16 (&x)[2], f32x16 (&y)[2]);
+template <class V, int NT>
 __device__ __forceinline__ void normalize(const f32x16 (&x)[2], f32x16 (&y)[2]) {
+    constexpr int K = V::KPT;
+    const float rstd = normalize_stats<V, NT>(x, y);
+    const f32x2 r2 = splat(rstd);
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) {
+#pragma unroll
+        for (int i = 0; i < K / 2; ++i) set_pair(y[rt], i, CF_PAIR(y[rt], i) * r2);
+        y[rt][K - 1] *= rstd;
+    }
+}
+// first half of normalize: y = x - mean, returns 1 / sqrt(var + eps) - the scaling is left to the caller (the products that
+// consume the normalised features multiply each one right before the k-step that needs it, in the shadow of the MFMAs)
+template <class V, int NT>
+__device__ __forceinline__ float normalize_stats(const f32x16 (&x)[2], f32x16 (&y)[2]) {
     constexpr int K = V::KPT, NP = K / 2;
     static_assert(K % 2 == 1, "an odd number of valid registers per tile: pairs + one single");
 #ifdef CF_ABL_VS_NOLN
-    y[0] = x[0]; y[1] = x[1]; return;
+    y[0] = x[0]; y[1] = x[1]; return 1.0f;
 #endif
     f32x2 s2[2] = {splat(0.f), splat(0.f)};
 #pragma unroll
@@ -318,13 +334,7 @@ __device__ __forceinline__ void normalize(const f32x16 (&x)[2], f32x16 (&y)[2]) 
     const float var = half_sum(v + (v2[0].x + v2[0].y)) * (1.0f / (float)(NT * V::C)) + 1e-5f;
     float rstd = __builtin_amdgcn_rsqf(var);
     rstd = rstd * fmaf(-0.5f * var * rstd, rstd, 1.5f);            // one Newton step: 1 ulp -> rounding level
-    const f32x2 r2 = splat(rstd);
-#pragma unroll
-    for (int rt = 0; rt < NT; ++rt) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) set_pair(y[rt], i, CF_PAIR(y[rt], i) * r2);
-        y[rt][K - 1] *= rstd;
-    }
+    return rstd;
 }
 
 // full LayerNorm of the two tiles: normalize, then y = y w + b (w, b: register-order vectors)
@@ -348,23 +358,19 @@ __device__ __forceinline__ void layernorm_affine(const f32x16 (&x)[2], f32x16 (&
 // gelu(v) = max(v, 0) - |v| q.  Against the exact GELU: 1.0e-7 rms over [-8, 8], the same as torch's erf-based one.
 __device__ __forceinline__ float abs_bits(float v) { return __int_as_float(__float_as_int(v) & 0x7fffffff); }
 __device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }   // one integer max (fmaxf: two VALU here)
-__device__ __forceinline__ f32x2 gelu2(f32x2 v) {
+__device__ __forceinline__ float gelu1(float v) {
 #ifdef CF_ABL_VS_NOGELU
     return v;
 #endif
-    const f32x2 av = {abs_bits(v.x), abs_bits(v.y)};
-    f32x2 t = pk_fma(av, splat(0.3275911f * 0.70710678118654752f), splat(1.0f));
-    t = f32x2{__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y)};
-    f32x2 p = pk_fma(t, splat(0.5f * 1.061405429f), splat(0.5f * -1.453152027f));
-    p = pk_fma(p, t, splat(0.5f * 1.421413741f));
-    p = pk_fma(p, t, splat(0.5f * -0.284496736f));
-    p = pk_fma(p, t, splat(0.5f * 0.254829592f));
-    f32x2 e = (v * v) * splat(-0.72134752044448170f);              // -v^2 / 2 * log2(e)
-    e = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-    const f32x2 q = (p * t) * e;
-    return pk_fma(-av, q, f32x2{relu_bits(v.x), relu_bits(v.y)});
+    const float av = abs_bits(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(av, 0.3275911f * 0.70710678118654752f, 1.0f));
+    float p = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f((v * v) * -0.72134752044448170f);
+    return fmaf(-av, (p * t) * e, relu_bits(v));
 }
-__device__ __forceinline__ float gelu_erf(float v) { return gelu2(f32x2{v, v}).x; }
 
 #ifdef CF_ABL_VS_NOBIAS
 #define CF_BIAS(v, ptr) do { v[0] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; v[1] = v[0]; } while (0)
@@ -396,8 +402,11 @@ template <int M> __device__ __forceinline__ float tok_xor(float v) {
 // DUMP (training forward at saturating batches): the residual stream at the depth + 1 layer boundaries goes to `xtape`,
 // feature-major [boundary][feature < DIM][token < T] (token = 4 sample + n: 128 contiguous bytes per feature and half wave) -
 // cf_vit_step_bwd_taped then walks back from these instead of running the six layers again.
+#ifndef CF_VS_MINW
+#define CF_VS_MINW 2          // waves per SIMD the register budget allows for (measured: 3 - with the DPP copies formed twice, 145 VGPRs - 3 899 us
+#endif                        // per 524 288 samples against 3 385, 4 with spills 4 615: more resident waves only fight over the L1 / L2 weight traffic)
 template <class V, bool DUMP = false>
-__global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x, float* __restrict__ z,
+__global__ __launch_bounds__(256, CF_VS_MINW) void k_vit_step(const float* __restrict__ x, float* __restrict__ z,
                                                      float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
                                                      int64_t xbs, int depth, float* __restrict__ hout,
                                                      float* __restrict__ xtape = nullptr, int64_t T = 0) {
@@ -448,26 +457,21 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
                 for (int r = 0; r < K; ++r) tb[(int64_t)(pos_of(r) * C + chan_of(r) + CIN * t) * T] = X[t][r];
         }
     };
-    auto bop2 = [](const f32x16 (&u)[2], int s) { return u[s / K][s % K]; };
     // (boundary 0, the embedding output, is rebuilt by the backward kernel together with the statistics it needs: not taped)
     // ================= transformer                                                 (simple_vit.py:56-88)
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
         const int wl = V::OFF_LAYER + l * V::L_STRIDE;
         {
-            f32x16 u[2], g[2], m[2];
-            normalize<V, 2>(X, u);
+            f32x16 u[2], g[2];
+            // operands formed right before the k-step that consumes them: the vector instructions sit between the MFMAs of the
+            // product (in their shadow) instead of in a block of their own in front of it
+            const float rstd = normalize_stats<V, 2>(X, u);
             CF_BIAS(g, ws + wl + V::L_C1);
-            gemm_regs<2, V::KS_RES>(g, rs, lane, wl + V::L_A1, [&](int s) { return bop2(u, s); });
+            gemm_regs<2, V::KS_RES>(g, rs, lane, wl + V::L_A1, [&](int s) { return u[s / K][s % K] *= rstd; });
             // scores of this token (query) against the 4 tokens of its sample (key = token ^ m), exact softmax; the 1 / 8 of
             // dim_head ** -0.5 sits in A1 / c1
             // (packed: the DPP-permuted copies of a register pair serve both the scores and the probability-weighted sum)
-#ifdef CF_ABL_VS_NOATT
-            m[0] = u[0] + g[0]; m[1] = u[1] + g[1];
-            if (false) {
-#else
-            {
-#endif
             f32x2 d0 = splat(0.f), d1 = splat(0.f), d2 = splat(0.f), d3 = splat(0.f);
             f32x2 k1[2][K / 2], k2[2][K / 2], k3[2][K / 2];
             float e1[2], e2[2], e3[2], s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -491,36 +495,26 @@ __global__ __launch_bounds__(256, 2) void k_vit_step(const float* __restrict__ x
             float p0 = __expf(s0 - mx), p1 = __expf(s1 - mx), p2 = __expf(s2 - mx), p3 = __expf(s3 - mx);
             const float inv = 1.0f / ((p0 + p1) + (p2 + p3));
             p0 *= inv; p1 *= inv; p2 *= inv; p3 *= inv;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int i = 0; i < K / 2; ++i)
-                    set_pair(m[t], i, pk_fma(splat(p3), k3[t][i], pk_fma(splat(p2), k2[t][i], pk_fma(splat(p1), k1[t][i], splat(p0) * CF_PAIR(u[t], i)))));
-                m[t][K - 1] = fmaf(p3, e3[t], fmaf(p2, e2[t], fmaf(p1, e1[t], p0 * u[t][K - 1])));
-            }
-            }
             // the block's output is summed on its own (bias + 26 k-steps) and meets the residual stream in ONE addition per
             // element, as in the reference (x = to_out(...) + x, simple_vit.py:84): accumulating the k-steps on top of X
             // would round every partial sum at the magnitude of the residual stream (tools/attribute_vit.py)
             f32x16 a[2];
             CF_BIAS(a, ws + wl + V::L_C2);
-            gemm_regs<2, V::KS_RES>(a, rs, lane, wl + V::L_A2, [&](int s) { return bop2(m, s); });
+            gemm_regs<2, V::KS_RES>(a, rs, lane, wl + V::L_A2, [&](int s) {
+                const int t = s / K, r = s % K;
+                if (r == K - 1) return fmaf(p3, e3[t], fmaf(p2, e2[t], fmaf(p1, e1[t], p0 * u[t][r])));
+                const f32x2 c1 = k1[t][r / 2], c2 = k2[t][r / 2], c3 = k3[t][r / 2];
+                return fmaf(p3, r & 1 ? c3.y : c3.x, fmaf(p2, r & 1 ? c2.y : c2.x, fmaf(p1, r & 1 ? c1.y : c1.x, p0 * u[t][r]))); });
             add_tiles<K>(X, a);
         }
         {
             f32x16 u[2], h[2];
-            normalize<V, 2>(X, u);
+            const float rstd = normalize_stats<V, 2>(X, u);
             CF_BIAS(h, ws + wl + V::L_B1);
-            gemm_regs<2, V::KS_RES>(h, rs, lane, wl + V::L_W1, [&](int s) { return bop2(u, s); });
-#pragma unroll
-            for (int i = 0; i < K / 2; ++i) { set_pair(h[0], i, gelu2(CF_PAIR(h[0], i))); set_pair(h[1], i, gelu2(CF_PAIR(h[1], i))); }
-            {
-                const f32x2 last = gelu2(f32x2{h[0][K - 1], h[1][K - 1]});
-                h[0][K - 1] = last.x; h[1][K - 1] = last.y;
-            }
+            gemm_regs<2, V::KS_RES>(h, rs, lane, wl + V::L_W1, [&](int s) { return u[s / K][s % K] * rstd; });
             f32x16 a[2];
             CF_BIAS(a, ws + wl + V::L_B2);                                   // W2 h + b2 on its own, then one add into the residual
-            gemm_regs<2, V::KS_RES>(a, rs, lane, wl + V::L_W2, [&](int s) { return bop2(h, s); });
+            gemm_regs<2, V::KS_RES>(a, rs, lane, wl + V::L_W2, [&](int s) { return gelu1(h[s / K][s % K]); });
             add_tiles<K>(X, a);
         }
         dump(l + 1);

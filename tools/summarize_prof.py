@@ -8,6 +8,9 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+# samples per launch of the PMC passes: tools/profile.sh runs them at --global-batch 16384 --chunk 16384 unless the caller
+# overrides the chunk (PROF_PMC_BATCH=<chunk>, e.g. 524288 for --workload smap --chunk 524288)
+PMC_BATCH = int(os.environ.get("PROF_PMC_BATCH", "16384"))
 
 
 def short(name):
@@ -36,7 +39,7 @@ if stats:
         print("| `%s` | %d | %.3f | %.1f | %.2f |" % (k, c, t / 1e6, t / c / 1e3, 100 * t / tot))
     print("\ntotal GPU kernel time: %.2f ms\n" % (tot / 1e6))
 
-print("## PMC (per-launch averages; bench.py --steps 1 --warmup 1 --global-batch 16384)\n")
+print("## PMC (per-launch averages; bench.py --steps 1 --warmup 1, %d samples per launch)\n" % PMC_BATCH)
 for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
     if not os.path.isdir(d):
         continue
@@ -85,17 +88,17 @@ levels, tot_b, tot_n = {}, 0.0, 0
 for k in fetch:
     if k.startswith("k_vit_step<") and k in write:
         byt = (2.0 * fetch[k] + write[k]) * 1024.0
-        levels[k] = {"hbm_bytes_per_launch": round(byt), "algorithmic_bytes_per_launch": 16384 * 2 * 26 * 8 * 4, "launches": nf[k]}
+        levels[k] = {"hbm_bytes_per_launch": round(byt), "algorithmic_bytes_per_launch": PMC_BATCH * 2 * 26 * 8 * 4, "launches": nf[k]}
         tot_b += byt * nf[k]; tot_n += nf[k]
     if k.startswith("k_flow_step") and k in write:
         m = re.search(r"Geo<(\d+), (\d+), (\d+)", k)
         C, H, W = (int(v) for v in m.groups())
         byt = (2.0 * fetch[k] + write[k]) * 1024.0
-        alg = 16384 * 2 * C * H * W * 4
+        alg = PMC_BATCH * 2 * C * H * W * 4
         levels[k] = {"hbm_bytes_per_launch": round(byt), "algorithmic_bytes_per_launch": alg, "launches": nf[k]}
         tot_b += byt * nf[k]; tot_n += nf[k]
 if tot_n:
-    tj = {"k_flow_step_bytes_per_launch": round(tot_b / tot_n), "batch_per_launch": 16384,
+    tj = {"k_flow_step_bytes_per_launch": round(tot_b / tot_n), "batch_per_launch": PMC_BATCH,
           "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes (gfx950: FETCH_SIZE reads 1/2 on 16-B/lane streams)",
           "algorithmic_bytes_per_launch_avg": round(sum(v["algorithmic_bytes_per_launch"] * v["launches"] for v in levels.values()) / tot_n),
           "per_kernel": levels}
