@@ -55,16 +55,12 @@ __global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float
     const rsrc_t rs = make_rsrc(ws, ws_floats<V>(depth));
 
     // weight fragments of the first layer and of the front end: requested before anything else
-    float4 fqkv[3][V::NG_D], fout[V::NG_H], ffc1[V::NG_D], ffc2[V::NG_D], fconv[V::NG_C], femb[V::NG_PD];
+    float4 fa1[V::NG_D], fa2[V::NG_D], ffc1[V::NG_D], ffc2[V::NG_D], fconv[V::NG_C], femb[V::NG_PD];
     load_frags(fconv, rs, lane, V::OFF_A0 + (w & 1) * V::NG_C * 256);
     load_frags(femb, rs, lane, V::OFF_WE + w * V::NG_PD * 256);
-    auto load_layer_qkv = [&](int l) {
-        const int wl = V::OFF_LAYER + l * V::L_STRIDE;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) load_frags(fqkv[t], rs, lane, wl + V::L_WQKV + (4 * t + w) * V::NG_D * 256);
-    };
-    load_layer_qkv(0);
-    load_frags(fout, rs, lane, V::OFF_LAYER + V::L_WOUT + w * V::NG_H * 256);
+    const int wf0 = off_fused<V>(depth);
+    load_frags(fa1, rs, lane, wf0 + V::F_A1 + w * V::NG_D * 256);
+    load_frags(fa2, rs, lane, wf0 + V::F_A2 + w * V::NG_D * 256);
     load_frags(ffc1, rs, lane, V::OFF_LAYER + V::L_W1 + w * V::NG_D * 256);
     load_frags(ffc2, rs, lane, V::OFF_LAYER + V::L_W2 + w * V::NG_D * 256);
 
@@ -126,34 +122,34 @@ __global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float
 #pragma unroll 1
     for (int l = 0; l < depth; ++l) {
         const int wl = V::OFF_LAYER + l * V::L_STRIDE, ln = (l + 1 < depth ? l + 1 : l), wn = V::OFF_LAYER + ln * V::L_STRIDE;
+        const int wf = wf0 + l * V::F_STRIDE, wfn = wf0 + ln * V::F_STRIDE;
         float mean, rstd;
-        f32x4 o;
-        {
+        {   // attention through the fused tables: s_ij = (A1 n_i + c1) . n_j, x += A2 (sum_j p_ij n_j) + c2   (simple_vit.py:56-68,84)
             float xv[V::KS_D];
 #pragma unroll
             for (int i = 0; i < V::KS_D; ++i) xv[i] = XA[(g + 4 * i) * TOK + col];
             token_stats(xv, DIM, g, mean, rstd);
             const float mr = -mean * rstd;
-            f32x4 q = vec4(ws + wl + V::L_CQKV, w, g), k = vec4(ws + wl + V::L_CQKV + 64, w, g), v = vec4(ws + wl + V::L_CQKV + 128, w, g);
+            const f32x4 gq = gemm1<V::KS_D>(vec4(ws + wf + V::F_C1, w, g), fa1, [&](int s) { return (g + 4 * s < DIM) ? fmaf(xv[s], rstd, mr) : 0.f; });
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(fa1, rs, lane, wfn + V::F_A1 + w * V::NG_D * 256);         // next layer's fragments: a whole layer of lead time
+            __builtin_amdgcn_sched_barrier(0);
+            // this wave's rows f = 16 w + 4 g + r of the normalised stream (own token; the partners' by DPP), masked beyond DIM
+            f32x4 nv;
 #pragma unroll
-            for (int s = 0; s < V::KS_D; ++s) {
-                const float b = (g + 4 * s < DIM) ? fmaf(xv[s], rstd, mr) : 0.f;
-                q = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(fqkv[0][s >> 2], s & 3), b, q, 0, 0, 0);
-                k = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(fqkv[1][s >> 2], s & 3), b, k, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(fqkv[2][s >> 2], s & 3), b, v, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                const int f = 16 * w + 4 * g + r;
+                nv[r] = f < DIM ? fmaf(XA[f * TOK + col], rstd, mr) : 0.f;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            load_layer_qkv(ln);                                                // next layer's fragments: a whole layer of lead time
-            __builtin_amdgcn_sched_barrier(0);
-            // scores of this token against the 4 tokens of its sample (partner = token ^ m): own 16 head features, then the
-            // lane groups, then the four waves
+            // scores of this token against the 4 tokens of its sample (partner = token ^ m): own 16 features, then the lane
+            // groups, then the four waves
             float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                d0 = fmaf(q[r], k[r], d0);
-                d1 = fmaf(q[r], tok_xor<1>(k[r]), d1);
-                d2 = fmaf(q[r], tok_xor<2>(k[r]), d2);
-                d3 = fmaf(q[r], tok_xor<3>(k[r]), d3);
+                d0 = fmaf(gq[r], nv[r], d0);
+                d1 = fmaf(gq[r], tok_xor<1>(nv[r]), d1);
+                d2 = fmaf(gq[r], tok_xor<2>(nv[r]), d2);
+                d3 = fmaf(gq[r], tok_xor<3>(nv[r]), d3);
             }
             d0 = group_sum(d0); d1 = group_sum(d1); d2 = group_sum(d2); d3 = group_sum(d3);
             if (g == 0) {
@@ -161,25 +157,23 @@ __global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float
                 SC[(w * 4 + 2) * TOK + col] = d2; SC[(w * 4 + 3) * TOK + col] = d3;
             }
             __syncthreads();
-            auto score = [&](int m) {
-                return ((SC[(0 * 4 + m) * TOK + col] + SC[(1 * 4 + m) * TOK + col]) + (SC[(2 * 4 + m) * TOK + col] + SC[(3 * 4 + m) * TOK + col])) * 0.125f;
-            };                                                                 // dim_head ** -0.5, dim_head = 64
+            auto score = [&](int m) {                                          // (dim_head ** -0.5 sits in A1 / c1)
+                return (SC[(0 * 4 + m) * TOK + col] + SC[(1 * 4 + m) * TOK + col]) + (SC[(2 * 4 + m) * TOK + col] + SC[(3 * 4 + m) * TOK + col]);
+            };
             d0 = score(0); d1 = score(1); d2 = score(2); d3 = score(3);
             const float mx = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
             float p0 = expf(d0 - mx), p1 = expf(d1 - mx), p2 = expf(d2 - mx), p3 = expf(d3 - mx);
             const float inv = 1.0f / ((p0 + p1) + (p2 + p3));
             p0 *= inv; p1 *= inv; p2 *= inv; p3 *= inv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[r] = fmaf(p3, tok_xor<3>(v[r]), fmaf(p2, tok_xor<2>(v[r]), fmaf(p1, tok_xor<1>(v[r]), p0 * v[r])));
-                OP[(16 * w + 4 * g + r) * TOK + col] = o[r];
-            }
+            for (int r = 0; r < 4; ++r)
+                OP[(16 * w + 4 * g + r) * TOK + col] = fmaf(p3, tok_xor<3>(nv[r]), fmaf(p2, tok_xor<2>(nv[r]), fmaf(p1, tok_xor<1>(nv[r]), p0 * nv[r])));
         }
         __syncthreads();
-        {   // x = to_out(attention) + x                                              (simple_vit.py:66-68,84)
-            const f32x4 a = gemm1<V::KS_H>(f32x4{0.f, 0.f, 0.f, 0.f}, fout, [&](int s) { return OP[(4 * s + g) * TOK + col]; });
+        {
+            const f32x4 a = gemm1<V::KS_D>(vec4(ws + wf + V::F_C2, w, g), fa2, [&](int s) { return OP[(4 * s + g) * TOK + col]; });
             __builtin_amdgcn_sched_barrier(0);
-            load_frags(fout, rs, lane, wn + V::L_WOUT + w * V::NG_H * 256);
+            load_frags(fa2, rs, lane, wfn + V::F_A2 + w * V::NG_D * 256);
             __builtin_amdgcn_sched_barrier(0);
             X += a;
 #pragma unroll

@@ -24,6 +24,10 @@ template <int C_> struct RS {
     static constexpr int L_WQKV = 0, L_CQKV = L_WQKV + 12 * NG_D * 256, L_WOUT = L_CQKV + 192;
     static constexpr int L_W1 = L_WOUT + 4 * NG_H * 256, L_B1 = L_W1 + 4 * NG_D * 256, L_W2 = L_B1 + 64, L_B2 = L_W2 + 4 * NG_D * 256;
     static constexpr int L_STRIDE = L_B2 + 64;
+    // fused attention tables of the FORWARD kernel (round 4, as in cf_vit_step.hip): per layer A1 = diag(g) Wk^T Wq diag(g) / 8,
+    // c1 = diag(g) Wk^T Wq b / 8 (scores s_ij = (A1 n_i + c1) . n_j) and A2 = Wout Wv diag(g), c2 = Wout Wv b (value / output pair),
+    // g / b = the attention pre-norm's affine part; they sit BEHIND the tables above, which the backward kernel keeps using
+    static constexpr int F_A1 = 0, F_C1 = F_A1 + 4 * NG_D * 256, F_A2 = F_C1 + 64, F_C2 = F_A2 + 4 * NG_D * 256, F_STRIDE = F_C2 + 64;
     // LDS planes (floats)
     static constexpr int P_XIN = 0, P_Y = P_XIN + 4 * KS_C * POSC, P_X0 = P_Y + 32 * POSC, P_X1 = P_X0 + 64 * TOK;
     static constexpr int P_O = P_X1 + 64 * TOK, P_H = P_O + 64 * TOK, P_SC = P_H + 64 * TOK, P_LS = P_SC + 4 * 4 * TOK;
@@ -31,7 +35,8 @@ template <int C_> struct RS {
     static_assert(C % 2 == 0 && C <= 32 && DIM <= 64 && KS_D <= 16, "C even, <= 32");
 };
 template <class V> __host__ __device__ constexpr int off_lno(int depth) { return V::OFF_LAYER + depth * V::L_STRIDE; }
-template <class V> __host__ __device__ constexpr int ws_floats(int depth) { return off_lno<V>(depth) + 128; }
+template <class V> __host__ __device__ constexpr int off_fused(int depth) { return off_lno<V>(depth) + 128; }
+template <class V> __host__ __device__ constexpr int ws_floats(int depth) { return off_fused<V>(depth) + depth * V::F_STRIDE; }
 
 // ---- packing ----------------------------------------------------------------------------------------------------------
 // 16x16x4 A fragments of a Linear W (N x K, row-major): element ((rt * NG + gi) * 64 + lane) * 4 + e =
@@ -40,8 +45,16 @@ template <class V>
 __global__ __launch_bounds__(256) void k_vit_rs_pack(const float* __restrict__ Wm, const float* __restrict__ t,
                                                      const float* __restrict__ logs, const float* __restrict__ flat,
                                                      const float* __restrict__ pos, float* __restrict__ ws, int depth) {
-    constexpr int C = V::C, DIM = V::DIM, PD = V::PD;
+    constexpr int C = V::C, DIM = V::DIM, PD = V::PD, HEAD = V::HEAD;
+    __shared__ double tq[HEAD], tv[HEAD];
     const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    auto frags_fn = [&](float* dst, int N, int K, int tiles, int ng, auto val) {             // as frags, element (row, k) = val(row, k), fp64
+        for (int i = gtid; i < tiles * ng * 256; i += gsz) {
+            const int e = i & 3, lane = (i >> 2) & 63, q = i >> 8, gi = q % ng, rt = q / ng;
+            const int row = 16 * rt + (lane & 15), k = 4 * (4 * gi + e) + (lane >> 4);
+            dst[i] = (row < N && k < K) ? (float)val(row, k) : 0.f;
+        }
+    };
     auto frags = [&](float* dst, const float* W, int N, int K, int tiles, int ng, const float* gamma) {
         for (int i = gtid; i < tiles * ng * 256; i += gsz) {
             const int e = i & 3, lane = (i >> 2) & 63, q = i >> 8, gi = q % ng, rt = q / ng;
@@ -85,6 +98,34 @@ __global__ __launch_bounds__(256) void k_vit_rs_pack(const float* __restrict__ W
     for (int l = 0; l < depth; ++l) {
         float* w = ws + V::OFF_LAYER + l * V::L_STRIDE;
         const float *ga = p, *ba = p + DIM; p += 2 * DIM;                                    // attention pre-norm
+        {   // fused attention tables of the forward kernel (simple_vit.py:56-68; derivation: cf_vit_step.hip, k_vit_step_pack)
+            float* wf = ws + off_fused<V>(depth) + l * V::F_STRIDE;
+            const float *Wq = p, *Wk = p + HEAD * DIM, *Wv = Wk + HEAD * DIM, *Wo = Wv + HEAD * DIM;
+            __syncthreads();
+            if (threadIdx.x < 2 * HEAD) {                                     // Wq b and Wv b, every block its own copy
+                const int h = threadIdx.x % HEAD;
+                const float* W = threadIdx.x < HEAD ? Wq : Wv;
+                double a = 0.0;
+                for (int k = 0; k < DIM; ++k) a += (double)W[h * DIM + k] * (double)ba[k];
+                (threadIdx.x < HEAD ? tq : tv)[h] = a;
+            }
+            __syncthreads();
+            frags_fn(wf + V::F_A1, DIM, DIM, 4, V::NG_D, [&](int a, int b) {
+                double s = 0.0;
+                for (int h = 0; h < HEAD; ++h) s += (double)Wk[h * DIM + a] * (double)Wq[h * DIM + b];
+                return 0.125 * s * (double)ga[a] * (double)ga[b]; });
+            frags_fn(wf + V::F_A2, DIM, DIM, 4, V::NG_D, [&](int f, int b) {
+                double s = 0.0;
+                for (int h = 0; h < HEAD; ++h) s += (double)Wo[f * HEAD + h] * (double)Wv[h * DIM + b];
+                return s * (double)ga[b]; });
+            for (int r = gtid; r < 64; r += gsz) {
+                double s1 = 0.0, s2 = 0.0;
+                if (r < DIM)
+                    for (int h = 0; h < HEAD; ++h) { s1 += (double)Wk[h * DIM + r] * tq[h]; s2 += (double)Wo[r * HEAD + h] * tv[h]; }
+                wf[V::F_C1 + r] = r < DIM ? (float)(0.125 * s1 * (double)ga[r]) : 0.f;
+                wf[V::F_C2 + r] = (float)s2;
+            }
+        }
         frags(w + V::L_WQKV, p, 192, DIM, 12, V::NG_D, ga);
         fold_bias(w + V::L_CQKV, p, nullptr, ba, 192, DIM, 192); p += 192 * DIM;
         frags(w + V::L_WOUT, p, DIM, 64, 4, V::NG_H, nullptr); p += DIM * 64;

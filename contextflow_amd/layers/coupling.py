@@ -274,7 +274,7 @@ class TransCoupling(_AffineCoupling):
 
     # batches up to this size take the row-split step kernel (cf_vit_step_rs_fwd: 4 samples per workgroup, an eighth of the
     # serial chain); larger ones the one-wave-per-8-samples kernel (cf_vit_step_fwd)
-    STEP_RS_MAX_BATCH = 3072          # measured cross-over (tools/dev/vit_variants.py, round 4): 43 vs 56 us at 2048, 56.0 vs 56.5 at 3072, 76 vs 56 at 4096
+    STEP_RS_MAX_BATCH = 3584          # measured cross-over (tools/dev/vit_variants.py, round 4, both forms with the fused attention tables): 36 vs 61 us at 2048, 46 vs 61 at 3072, 64 vs 61 at 4096
 
     STEP_MAX_DEPTH = 6                # cf_vit_step_bwd parks the residual stream of <= 6 layer boundaries in LDS
 

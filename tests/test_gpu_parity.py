@@ -527,14 +527,25 @@ def test_e2e_stress_regimes(L, name, fused, tag):
     assert d32 < tol and d64 < tol, (d32, d64, tol)
     zr = torch.from_numpy(fx["z"])
     assert (z.cpu() - zr).abs().max().item() <= 2e-4 * max(1.0, zr.abs().max().item())
-    # first call on un-initialised ActNorms (init on ill-conditioned Conv1x1 outputs), then the fused plan
-    model = build_model(name, pre_init_params(name, fx))
+    # first call on un-initialised ActNorms (init on ill-conditioned Conv1x1 outputs), then the fused plan.  The exact answer
+    # for THIS call is the fp64 oracle initialising from the same batch: the build's statistics are fp64 sums, the reference's
+    # are fp32 `mean` / `std`, and in these regimes that difference alone moves the log-density (d_init below: the fp64 oracle
+    # with its own init against the fp64 reference run with the reference's init - 3.9e-6 bits/dim on cifar10 and 3.0e-6 on smap "extreme").
+    # So: within the bar of the exact first-call answer, and within bar + d_init of the reference's fp32 first call.
+    pre = pre_init_params(name, fx)
+    pre64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in pre.items()}
+    _, lp64_first = fo.flow_forward(ops, pre64, x.double(), None if u is None else u.double(), [e.double() for e in eps], init_actnorm=True)
+    d_init = (bpd(lp64_first, name) - bpd(ref64, name)).abs().max().item()
+    model = build_model(name, pre)
     model.fused = fused
     set_noise(model, u, eps)
-    _, logp1 = model(x.to(DEV))
-    assert (bpd(logp1.cpu(), name) - bpd(ref, name)).abs().max().item() < tol
-    _, logp2 = model(x.to(DEV))
-    assert (bpd(logp2.cpu(), name) - bpd(ref, name)).abs().max().item() < tol
+    for call in ("first (initialising)", "second (fused plan)"):
+        _, lp = model(x.to(DEV))
+        e64 = (bpd(lp.cpu(), name) - bpd(lp64_first, name)).abs().max().item()
+        e32 = (bpd(lp.cpu(), name) - bpd(ref, name)).abs().max().item()
+        print("%s %s fused=%s %s call: %.2e from the exact first-call answer, %.2e from the reference's fp32 (its init moves it by %.2e)"
+              % (name, tag, fused, call, e64, e32, d_init))
+        assert e64 < tol and e32 < tol + d_init, (call, e64, e32, d_init, tol)
 
 
 @pytest.mark.parametrize("name", ["mnist", "cifar10", "smap", "atm"])
