@@ -32,7 +32,7 @@ LABEL = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap":
 #  smap: k_vit_step = Conv1x1 26x26x8 + SimpleViT linears 454 688 + attention QK^T / PV 12 288 MAC = 944 768 flop (the
 #        library reports it, and what its MFMAs execute: cf_vit_step_macs).
 VIT_STEP = {"smap": (26, 6)}                                              # (C, depth) of the one-kernel transformer step
-TRAFFIC_JSON = {"cifar10": "r3_prof2_traffic.json", "mnist": "r4_mnist1_traffic.json", "smap": "r4_smap2_traffic.json"}
+TRAFFIC_JSON = {"cifar10": "r4_prof1_traffic.json", "mnist": "r4_mnist1_traffic.json", "smap": "r4_smap2_traffic.json"}
 
 
 def vit_flop_per_sample(name, what):
@@ -329,7 +329,7 @@ def secondary_training(name, dev, B, iters, graph, cpu=False):
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True) if graph and os.environ.get("CF_BENCH_FOREACH_ADAMW") != "1" \
         else torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=graph)
     if graph:
-        step = model.capture_train_step(x, loss_fn, opt)
+        step = model.capture_train_step(x, loss_fn, opt, data_parallel=False)     # single-GPU line; `bench.py --train` is the data-parallel step
         run = lambda: step(x, gt)
     else:
         def run():

@@ -276,6 +276,8 @@ int cf_vit_step_rs_prepare(const float* Wm, const float* t, const float* logs, c
     float* w = (float*)ws;
     int rc = cf_slogdet_inverse(Wm, C, w + 1, nullptr, stream);
     if (rc) return rc;
+    k_vit_fuse<RS26::DIM, RS26::HEAD><<<dim3(depth, 2, FUSE_SPLIT), dim3(256), 0, cf_s(stream)>>>(
+        flat_vit_params + 2 * RS26::PD + RS26::DIM * RS26::PD + RS26::DIM + 2 * RS26::DIM, w + off_fuse_scratch<RS26>(depth));
     k_vit_rs_pack<RS26><<<dim3(64), dim3(256), 0, cf_s(stream)>>>(Wm, t, logs, flat_vit_params, pos, w, depth);
     CF_LAUNCH_CHECK();
     return 0;

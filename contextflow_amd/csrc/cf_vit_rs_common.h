@@ -3,6 +3,7 @@
 // statistics.  Everything lives in an anonymous namespace of the including translation unit.
 #pragma once
 #include "cf_common.h"
+#include "cf_vit_fuse.h"
 #include <math.h>
 
 namespace {
@@ -36,7 +37,8 @@ template <int C_> struct RS {
 };
 template <class V> __host__ __device__ constexpr int off_lno(int depth) { return V::OFF_LAYER + depth * V::L_STRIDE; }
 template <class V> __host__ __device__ constexpr int off_fused(int depth) { return off_lno<V>(depth) + 128; }
-template <class V> __host__ __device__ constexpr int ws_floats(int depth) { return off_fused<V>(depth) + depth * V::F_STRIDE; }
+template <class V> __host__ __device__ constexpr int off_fuse_scratch(int depth) { return off_fused<V>(depth) + depth * V::F_STRIDE; }     // k_vit_fuse output
+template <class V> __host__ __device__ constexpr int ws_floats(int depth) { return off_fuse_scratch<V>(depth) + depth * VitFuse<V::DIM, V::HEAD>::LAYER_FLOATS; }
 
 // ---- packing ----------------------------------------------------------------------------------------------------------
 // 16x16x4 A fragments of a Linear W (N x K, row-major): element ((rt * NG + gi) * 64 + lane) * 4 + e =
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void k_vit_rs_pack(const float* __restrict__ W
                                                      const float* __restrict__ logs, const float* __restrict__ flat,
                                                      const float* __restrict__ pos, float* __restrict__ ws, int depth) {
     constexpr int C = V::C, DIM = V::DIM, PD = V::PD, HEAD = V::HEAD;
-    __shared__ double tq[HEAD], tv[HEAD];
+    using F = VitFuse<DIM, HEAD>;
     const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
     auto frags_fn = [&](float* dst, int N, int K, int tiles, int ng, auto val) {             // as frags, element (row, k) = val(row, k), fp64
         for (int i = gtid; i < tiles * ng * 256; i += gsz) {
@@ -98,32 +100,14 @@ __global__ __launch_bounds__(256) void k_vit_rs_pack(const float* __restrict__ W
     for (int l = 0; l < depth; ++l) {
         float* w = ws + V::OFF_LAYER + l * V::L_STRIDE;
         const float *ga = p, *ba = p + DIM; p += 2 * DIM;                                    // attention pre-norm
-        {   // fused attention tables of the forward kernel (simple_vit.py:56-68; derivation: cf_vit_step.hip, k_vit_step_pack)
+        {   // fused attention tables of the forward kernel (cf_vit_fuse.h: k_vit_fuse has formed the matrices in fp64)
             float* wf = ws + off_fused<V>(depth) + l * V::F_STRIDE;
-            const float *Wq = p, *Wk = p + HEAD * DIM, *Wv = Wk + HEAD * DIM, *Wo = Wv + HEAD * DIM;
-            __syncthreads();
-            if (threadIdx.x < 2 * HEAD) {                                     // Wq b and Wv b, every block its own copy
-                const int h = threadIdx.x % HEAD;
-                const float* W = threadIdx.x < HEAD ? Wq : Wv;
-                double a = 0.0;
-                for (int k = 0; k < DIM; ++k) a += (double)W[h * DIM + k] * (double)ba[k];
-                (threadIdx.x < HEAD ? tq : tv)[h] = a;
-            }
-            __syncthreads();
-            frags_fn(wf + V::F_A1, DIM, DIM, 4, V::NG_D, [&](int a, int b) {
-                double s = 0.0;
-                for (int h = 0; h < HEAD; ++h) s += (double)Wk[h * DIM + a] * (double)Wq[h * DIM + b];
-                return 0.125 * s * (double)ga[a] * (double)ga[b]; });
-            frags_fn(wf + V::F_A2, DIM, DIM, 4, V::NG_D, [&](int f, int b) {
-                double s = 0.0;
-                for (int h = 0; h < HEAD; ++h) s += (double)Wo[f * HEAD + h] * (double)Wv[h * DIM + b];
-                return s * (double)ga[b]; });
+            const float* fz = ws + off_fuse_scratch<V>(depth) + l * F::LAYER_FLOATS;
+            frags_fn(wf + V::F_A1, DIM, DIM, 4, V::NG_D, [&](int a, int b) { return fz[F::M1 + a * DIM + b]; });
+            frags_fn(wf + V::F_A2, DIM, DIM, 4, V::NG_D, [&](int f, int b) { return fz[F::M2 + f * DIM + b]; });
             for (int r = gtid; r < 64; r += gsz) {
-                double s1 = 0.0, s2 = 0.0;
-                if (r < DIM)
-                    for (int h = 0; h < HEAD; ++h) { s1 += (double)Wk[h * DIM + r] * tq[h]; s2 += (double)Wo[r * HEAD + h] * tv[h]; }
-                wf[V::F_C1 + r] = r < DIM ? (float)(0.125 * s1 * (double)ga[r]) : 0.f;
-                wf[V::F_C2 + r] = (float)s2;
+                wf[V::F_C1 + r] = r < DIM ? fz[F::C1 + r] : 0.f;
+                wf[V::F_C2 + r] = r < DIM ? fz[F::C2 + r] : 0.f;
             }
         }
         frags(w + V::L_WQKV, p, 192, DIM, 12, V::NG_D, ga);

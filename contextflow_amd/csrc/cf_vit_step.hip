@@ -37,6 +37,7 @@
 // Geometry covered: C even, C <= 32 (SMAP: 26), H = 8, W = 1, patch (2, 1), dim = 2C, 1 head x 64, any depth.  Other
 // transformer couplings keep the LDS-plane kernel (cf_vit_fused.hip) or the layer-by-layer kernels (cf_vit.hip).
 #include "cf_common.h"
+#include "cf_vit_fuse.h"
 #include <math.h>
 
 extern "C" int cf_slogdet_inverse(const float* W, int C, float* logabsdet, float* Winv, cf_stream_t stream);
@@ -72,7 +73,8 @@ template <int C_> struct VS {
     static_assert(C % 2 == 0 && C >= 4 && C <= 32, "C even, <= 32");
 };
 template <class V> __host__ __device__ constexpr int off_lno(int depth) { return V::OFF_LAYER + depth * V::L_STRIDE; }
-template <class V> __host__ __device__ constexpr int ws_floats(int depth) { return off_lno<V>(depth) + 128; }
+template <class V> __host__ __device__ constexpr int off_fuse(int depth) { return off_lno<V>(depth) + 128; }      // k_vit_fuse scratch
+template <class V> __host__ __device__ constexpr int ws_floats(int depth) { return off_fuse<V>(depth) + depth * VitFuse<V::DIM, V::HEAD>::LAYER_FLOATS; }
 
 // row q (0..31) of a tile -> logical index j in [0, C) (the valid rows in increasing order), or -1 for padding.  A row is
 // valid when its register index is below KPT; for C = 26 these are the rows 0 .. 24 and 28.
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void k_vit_step_pack(const float* __restrict__
                                                        const float* __restrict__ logs, const float* __restrict__ flat,
                                                        const float* __restrict__ pos, float* __restrict__ ws, int depth) {
     constexpr int C = V::C, CIN = V::CIN, DIM = V::DIM, HEAD = V::HEAD;
-    __shared__ double tq[HEAD], tv[HEAD];
+    using F = VitFuse<DIM, HEAD>;
     const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
     // register-order vector of a per-feature quantity val(f), f = model feature of the residual layout
     auto vec = [&](float* dst, auto val) {
@@ -153,37 +155,15 @@ __global__ __launch_bounds__(256) void k_vit_step_pack(const float* __restrict__
     }
     for (int l = 0; l < depth; ++l) {
         float* w = ws + V::OFF_LAYER + l * V::L_STRIDE;
-        const float *ga = p, *ba = p + DIM, *Wq = p + 2 * DIM, *Wk = Wq + HEAD * DIM, *Wv = Wk + HEAD * DIM, *Wo = Wv + HEAD * DIM;
+        const float* Wo = p + 2 * DIM + 3 * HEAD * DIM;
         const float *gf = Wo + DIM * HEAD, *bf = gf + DIM, *W1 = bf + DIM, *b1 = W1 + DIM * DIM, *W2 = b1 + DIM, *b2 = W2 + DIM * DIM;
-        __syncthreads();
-        if (threadIdx.x < 2 * HEAD) {                                    // Wq b and Wv b (b = the LayerNorm's bias), every block its own copy
-            const int h = threadIdx.x % HEAD;
-            const float* W = threadIdx.x < HEAD ? Wq : Wv;
-            double a = 0.0;
-            for (int k = 0; k < DIM; ++k) a += (double)W[h * DIM + k] * (double)ba[k];
-            (threadIdx.x < HEAD ? tq : tv)[h] = a;
-        }
-        __syncthreads();
-        // scores (simple_vit.py:60-64): q_i.k_j / 8 = u_i^T G u_j / 8 with G = Wq^T Wk, u = ga (.) n + ba.  The terms without n_j
-        // are the same for the four keys of a query and leave the softmax: s_ij = (A1 n_i + c1) . n_j,
-        // A1 = diag(ga) G^T diag(ga) / 8, c1 = diag(ga) G^T ba / 8
-        frags(w + V::L_A1, V::KS_RES, res_row, res_k, [&](int a, int b) {
-            double s = 0.0;
-            for (int h = 0; h < HEAD; ++h) s += (double)Wk[h * DIM + a] * (double)Wq[h * DIM + b];
-            return 0.125 * s * (double)ga[a] * (double)ga[b]; });
-        vec(w + V::L_C1, [&](int a) {
-            double s = 0.0;
-            for (int h = 0; h < HEAD; ++h) s += (double)Wk[h * DIM + a] * tq[h];
-            return 0.125 * s * (double)ga[a]; });
-        // to_out(sum_j p_ij v_j) = Wout Wv (ga (.) sum_j p_ij n_j + ba)   (simple_vit.py:65-68; sum_j p_ij = 1)
-        frags(w + V::L_A2, V::KS_RES, res_row, res_k, [&](int f, int b) {
-            double s = 0.0;
-            for (int h = 0; h < HEAD; ++h) s += (double)Wo[f * HEAD + h] * (double)Wv[h * DIM + b];
-            return s * (double)ga[b]; });
-        vec(w + V::L_C2, [&](int f) {
-            double s = 0.0;
-            for (int h = 0; h < HEAD; ++h) s += (double)Wo[f * HEAD + h] * tv[h];
-            return s; });
+        // attention through the fused matrices (cf_vit_fuse.h: k_vit_fuse has formed them in fp64):  s_ij = (A1 n_i + c1) . n_j,
+        // x += A2 (sum_j p_ij n_j) + c2
+        const float* fz = ws + off_fuse<V>(depth) + l * F::LAYER_FLOATS;
+        frags(w + V::L_A1, V::KS_RES, res_row, res_k, [&](int a, int b) { return fz[F::M1 + a * DIM + b]; });
+        vec(w + V::L_C1, [&](int a) { return fz[F::C1 + a]; });
+        frags(w + V::L_A2, V::KS_RES, res_row, res_k, [&](int f, int b) { return fz[F::M2 + f * DIM + b]; });
+        vec(w + V::L_C2, [&](int f) { return fz[F::C2 + f]; });
         // FeedForward (simple_vit.py:30-40): LayerNorm affine folded into the first Linear
         frags(w + V::L_W1, V::KS_RES, res_row, res_k, [&](int f, int b) { return (double)W1[f * DIM + b] * (double)gf[b]; });
         vec(w + V::L_B1, [&](int f) { double a = b1[f]; for (int k = 0; k < DIM; ++k) a += (double)W1[f * DIM + k] * (double)bf[k]; return a; });
@@ -576,6 +556,9 @@ int cf_vit_step_prepare(const float* Wm, const float* t, const float* logs, cons
     float* w = (float*)ws;
     int rc = cf_slogdet_inverse(Wm, C, w + 1, nullptr, stream);
     if (rc) return rc;
+    if (depth > 0)
+        k_vit_fuse<VS26::DIM, VS26::HEAD><<<dim3(depth, 2, FUSE_SPLIT), dim3(256), 0, cf_s(stream)>>>(
+            flat_vit_params + 2 * C + VS26::DIM * C + VS26::DIM + 2 * VS26::DIM, w + off_fuse<VS26>(depth));
     k_vit_step_pack<VS26><<<dim3(64), dim3(256), 0, cf_s(stream)>>>(Wm, t, logs, flat_vit_params, pos, w, depth);
     CF_LAUNCH_CHECK();
     return 0;

@@ -186,9 +186,10 @@ def _step_param_part(conv, act, cpl, shape, xv, xbs, squeeze, s_gh, s_gh2, s_gh1
 
 
 # ------------------------------------------------------------------------------------------------ transformer flow step
-def wgrad_group(members, dev):
+def wgrad_group(members, dev, dests=None):
     """members: [(x (rows, K), gy (rows, N), has_bias)], all dense fp32 on `dev`.  One cf_linear_wgrad_group launch pair;
-    returns [(gW (N, K), gb (N,) | None)]."""
+    returns [(gW (N, K), gb (N,) | None)].  dests (data-parallel bucket): per member (gW | None, gb | None) - tensors the kernel
+    writes instead of slices of a fresh buffer."""
     import ctypes
     L = _hip.lib()
     n = len(members)
@@ -198,11 +199,12 @@ def wgrad_group(members, dev):
     tot = sum(N * K + (N if m[2] else 0) for m, K, N in zip(members, Ks, Ns))
     out = torch.empty(tot, device=dev, dtype=torch.float32)
     res, o = [], 0
-    for m, K, N in zip(members, Ks, Ns):
-        gW = out[o:o + N * K].view(N, K); o += N * K
+    for i, (m, K, N) in enumerate(zip(members, Ks, Ns)):
+        dW, db = dests[i] if dests is not None else (None, None)
+        gW = out[o:o + N * K].view(N, K) if dW is None else dW.view(N, K); o += N * K
         gb = None
         if m[2]:
-            gb = out[o:o + N]; o += N
+            gb = out[o:o + N] if db is None else db.view(N); o += N
         res.append((gW, gb))
     iarr = lambda v: (ctypes.c_int * n)(*v)
     parr = lambda ts: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts])
@@ -214,7 +216,7 @@ def wgrad_group(members, dev):
     return res
 
 
-def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, side=None, keep=None):
+def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, side=None, keep=None, sink=None):
     """Conv1x1 -> ActNorm -> TransCoupling (one fused step of the transformer flows) backwards: ONE kernel re-runs the step
     from its input and walks back (cf_vit_step_bwd), ONE grouped launch contracts the 26 weight-gradient operand pairs it
     leaves (cf_linear_wgrad_group), the LayerNorm gradients are column sums of its per-workgroup partials, and the Conv1x1 /
@@ -250,10 +252,10 @@ def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, s
         keep.append((planes, lnp, xv, ws, wsb, gsum))
     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         return gx, _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, xv.shape[2] * xv.shape[3], Wm, t, logs, gsum,
-                                     gld, dev)
+                                     gld, dev, sink)
 
 
-def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t, logs, gsum, gld, dev):
+def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t, logs, gsum, gld, dev, sink=None):
     """Second half of vstep_backward: grouped weight gradients, LayerNorm sums, Conv1x1 / ActNorm parameter chain."""
     f, pp, st = _hip.f32, _hip.p, _hip.stream()
     Bp = nwg * 4
@@ -270,10 +272,16 @@ def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t
         u1, gqkv, oo, gxm, u2, ghp, h, gxo = (take(R4, DIM), take(R4, 192), take(R4, 64), take(R4, DIM), take(R4, DIM), take(R4, DIM),
                                                take(R4, DIM), take(R4, DIM))
         members += [(u1, gqkv, False), (oo, gxm, False), (u2, ghp, True), (h, gxo, True)]
-    wg = wgrad_group(members, dev)
+    tpe = vit.to_patch_embedding
+    dests = None
+    if sink is not None:             # data-parallel bucket: the grouped kernel writes the Linear gradients into p.grad's storage
+        dests = [(None, None), (sink(tpe[2].weight), sink(tpe[2].bias))]
+        for attn, ff in vit.transformer.layers:
+            dests += [(sink(attn.to_qkv.weight), None), (sink(attn.to_out.weight), None), (sink(ff.net[1].weight), sink(ff.net[1].bias)),
+                      (sink(ff.net[3].weight), sink(ff.net[3].bias))]
+    wg = wgrad_group(members, dev, dests)
     ln = lnp.sum(0)                                       # fixed-order column sums of the per-workgroup partials
     grads = {}
-    tpe = vit.to_patch_embedding
     grads[tpe[1].weight], grads[tpe[1].bias] = ln[0:PD], ln[32:32 + PD]
     grads[tpe[2].weight], grads[tpe[2].bias] = wg[1]
     grads[tpe[3].weight], grads[tpe[3].bias] = ln[64:64 + DIM], ln[128:128 + DIM]
@@ -295,7 +303,7 @@ def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t
     lad = torch.empty(1, device=dev, dtype=torch.float32)
     winv = torch.empty(C, C, device=dev, dtype=torch.float32)
     _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
-    gNN, gt, glogs = torch.empty(C, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    gNN, gt, glogs = _out(sink, conv.NN, (C, C), dev), _out(sink, act.NN_t, (C,), dev), _out(sink, act.NN_logs, (C,), dev)
     _hip.call("cf_step_param_grads", pp(gWp.contiguous()), pp(gbp.contiguous()), pp(Wm), pp(t), pp(logs), pp(winv), pp(f(gsum)),
               HW, pp(gNN), pp(gt), pp(glogs), C, st)
     grads[conv.NN] = gNN.view_as(conv.NN)
@@ -385,7 +393,7 @@ class FlowLogProb(torch.autograd.Function):
                 add_on(gp, ri)
             elif kind == "vstep":
                 _, xin, conv, act, cpl, ws_rs, xtape = rec
-                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape, side, keep)
+                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape, side, keep, sink)
                 add_on(gp, ri)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)

@@ -103,6 +103,7 @@ class FlowSequential(nn.Module):
         d["_plans"], d["_side"], d["step_events"], d["inv_events"] = {}, {}, None, None
         d["_prep"], d["_graphs"], d["_graph_policy"], d["_tensors"] = {}, {}, {}, None
         d["_grad_bucket"] = None
+        d.pop("_cache_holders", None)
         return d
 
     def invalidate_caches(self):
@@ -116,13 +117,19 @@ class FlowSequential(nn.Module):
         self.__dict__.pop("_spec_ws", None)          # layers/specialist.py: packed coupling tables, log|det NN| of frozen Conv1x1,
         self.__dict__.pop("_spec_lad", None)         # Conv1x1.CN in blocked row order
         self.__dict__.pop("_spec_cnb", None)
-        for m in self.modules():
-            if hasattr(m, "_tab_cache"):
-                m._tab_cache = None
-            if hasattr(m, "_flat_cache"):
-                m._flat_cache = None
-            if hasattr(m, "_step_src"):
-                m._step_src = None
+        # the modules that keep parameter-derived state of their own: collected once per module tree (`hasattr` on 636 modules
+        # cost 1-4 ms of host time per call - a captured SMAP training step at a batch of 256 takes 2 ms and ends with this call)
+        holders = self.__dict__.get("_cache_holders")
+        if holders is None:
+            holders = self.__dict__["_cache_holders"] = [m for m in self.modules() if isinstance(m, (TransCoupling, GaussianMixtureDistribution))]
+        for m in holders:
+            d = m.__dict__
+            if "_tab_cache" in d:
+                d["_tab_cache"] = None
+            if "_flat_cache" in d:
+                d["_flat_cache"] = None
+            if "_step_src" in d:
+                d["_step_src"] = None
 
     def _apply(self, fn, *a, **k):         # .to() / .cuda() / .float(): new storages, same version counters
         self._prep, self._graphs, self._plans, self._tensors = {}, {}, {}, None
@@ -316,9 +323,13 @@ class FlowSequential(nn.Module):
         prior, ev_prior = (hit[1], None if capturing else hit[2]) if (hit is not None and hit[0] == pver) else (None, None)
         fresh = set()                # entries built by THIS call (their buffers get a record_stream below)
         if todo or prior is None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                for k, op, ver in todo:
+            # (one side stream: spreading the tables of the flow steps over 2 / 4 streams was measured on the captured training
+            # step at a batch of 256 - smap 2.10 -> 2.16 ms, cifar10 2.49 -> 2.48 ms: tools/dev/prep_streams_ab.py - and dropped)
+            sides = [self._side_stream(dev)]
+            sides[0].wait_stream(main)
+            for j, (k, op, ver) in enumerate(todo):
+                side = sides[j % len(sides)]
+                with torch.cuda.stream(side):
                     if op[0] == "step":
                         if tape is not None:     # training: W^-1 for d(log|det W|)/dW from the prepare step's factorisation
                             Cc = op[4][0]
@@ -343,7 +354,9 @@ class FlowSequential(nn.Module):
                     fresh.add(k)
                     if store_ok:
                         self._prep[(key, k, vkey.get(k))] = (ver, buf, ev)
-                if prior is None:
+            if prior is None:
+                side = sides[len(todo) % len(sides)]
+                with torch.cuda.stream(side):
                     prior = self.dist.prepared()
                     ev_prior = torch.cuda.Event()
                     ev_prior.record(side)
@@ -508,6 +521,7 @@ class FlowSequential(nn.Module):
         _hip.require_device(input)
         if self._gen != _PARAM_GENERATION[0]:            # a Parameter object was (re)registered somewhere: see _PARAM_GENERATION
             self._gen = _PARAM_GENERATION[0]
+            self.__dict__.pop("_cache_holders", None)
             self.invalidate_caches()
         if torch.is_grad_enabled() and self._specialist():
             from .autograd_ctx import trainable as _trainable
