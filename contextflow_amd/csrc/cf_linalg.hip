@@ -101,9 +101,20 @@ __device__ __forceinline__ void lu_steps(LuState<CMAX / 4>& s, double* colbuf, i
     }
 }
 
+// One workgroup per matrix; blockIdx.y picks the matrix of a batch (cf_slogdet_inverse_batch: the Conv1x1 weights of all flow
+// steps of a resolution level factorise side by side - at a batch of 256 the twelve serial 15-68 us launches of a cifar10
+// training step were 0.4 ms of its 2.5).
+constexpr int kMaxBatch = 16;
+struct SlogdetBatch {
+    const float* Wm[kMaxBatch];
+    float* lad[kMaxBatch];
+    float* inv[kMaxBatch];
+};
 template <int CMAX, bool INV>
-__global__ __launch_bounds__(256) void k_slogdet(const float* __restrict__ Wm, int C, float* __restrict__ logabsdet,
-                                                 float* __restrict__ inv) {
+__global__ __launch_bounds__(256) void k_slogdet(const SlogdetBatch bt, int C) {
+    const float* __restrict__ Wm = bt.Wm[blockIdx.y];
+    float* __restrict__ logabsdet = bt.lad[blockIdx.y];
+    float* __restrict__ inv = bt.inv[blockIdx.y];
     constexpr int NJ = CMAX / 4;
     __shared__ double colbuf[2 * kMaxLU];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -195,9 +206,9 @@ __global__ __launch_bounds__(256) void k_slogdet128(const float* __restrict__ Wm
 }
 
 template <int CMAX>
-void launch_slogdet(const float* Wm, int C, float* lad, float* inv, hipStream_t st) {
-    if (inv == nullptr) k_slogdet<CMAX, false><<<dim3(1), dim3(256), 0, st>>>(Wm, C, lad, nullptr);
-    else k_slogdet<CMAX, true><<<dim3(1), dim3(256), 0, st>>>(Wm, C, lad, inv);
+void launch_slogdet(const SlogdetBatch& bt, int n, int C, bool with_inverse, hipStream_t st) {
+    if (!with_inverse) k_slogdet<CMAX, false><<<dim3(1, n), dim3(256), 0, st>>>(bt, C);
+    else k_slogdet<CMAX, true><<<dim3(1, n), dim3(256), 0, st>>>(bt, C);
 }
 
 // Inverse for 64 < C <= 128 (ATM: 76-channel Conv1x1, training only: d log|det W| / dW = W^-T) and log|det| + inverse
@@ -306,11 +317,32 @@ int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_
         CF_LAUNCH_CHECK();
         return 0;
     }
-    if (C <= 8) launch_slogdet<8>(Wm, C, logabsdet, inv, cf_s(stream));
-    else if (C <= 16) launch_slogdet<16>(Wm, C, logabsdet, inv, cf_s(stream));
-    else if (C <= 32) launch_slogdet<32>(Wm, C, logabsdet, inv, cf_s(stream));
-    else launch_slogdet<64>(Wm, C, logabsdet, inv, cf_s(stream));
-    CF_LAUNCH_CHECK();
+    const float* wm1[1] = {Wm};
+    float* lad1[1] = {logabsdet};
+    float* inv1[1] = {inv};
+    return cf_slogdet_inverse_batch(1, wm1, C, lad1, inv ? inv1 : nullptr, stream);
+}
+
+int cf_slogdet_inverse_batch(int n, const float* const* Wm, int C, float* const* logabsdet, float* const* inv, cf_stream_t stream) {
+    CF_REQUIRE(n >= 0 && Wm && logabsdet && C > 0);
+    if (C > kMaxLU) {                            // wide matrices: one at a time
+        for (int i = 0; i < n; ++i)
+            if (int rc = cf_slogdet_inverse(Wm[i], C, logabsdet[i], inv ? inv[i] : nullptr, stream)) return rc;
+        return 0;
+    }
+    for (int i0 = 0; i0 < n; i0 += kMaxBatch) {
+        const int m = n - i0 < kMaxBatch ? n - i0 : kMaxBatch;
+        SlogdetBatch bt{};
+        for (int i = 0; i < m; ++i) {
+            CF_REQUIRE(Wm[i0 + i] && logabsdet[i0 + i] && (!inv || inv[i0 + i]));
+            bt.Wm[i] = Wm[i0 + i]; bt.lad[i] = logabsdet[i0 + i]; bt.inv[i] = inv ? inv[i0 + i] : nullptr;
+        }
+        if (C <= 8) launch_slogdet<8>(bt, m, C, inv != nullptr, cf_s(stream));
+        else if (C <= 16) launch_slogdet<16>(bt, m, C, inv != nullptr, cf_s(stream));
+        else if (C <= 32) launch_slogdet<32>(bt, m, C, inv != nullptr, cf_s(stream));
+        else launch_slogdet<64>(bt, m, C, inv != nullptr, cf_s(stream));
+        CF_LAUNCH_CHECK();
+    }
     return 0;
 }
 

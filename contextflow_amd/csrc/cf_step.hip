@@ -29,12 +29,20 @@ namespace {
 // ---- weight packing (cf_flow_step_prepare) ---------------------------------------------------------
 // A fragment of k-step s, row tile rt, lane l: A[row = rt*32 + (l&31)][k = 2s + (l>>5)]; 4 k-steps
 // per float4: element ((g*RT + rt)*64 + l)*4 + e holds k-step 4g+e.
+// blockIdx.y = flow step of a batch (cf_flow_step_prepare_batch: the steps of one resolution level pack side by side)
+constexpr int kPrepBatch = 16;
+struct StepPackBatch {
+    const float *Wm[kPrepBatch], *t[kPrepBatch], *logs[kPrepBatch], *w1[kPrepBatch], *b1[kPrepBatch], *w2[kPrepBatch], *b2[kPrepBatch],
+        *w3[kPrepBatch], *b3[kPrepBatch];
+    float* ws[kPrepBatch];
+};
 template <class G>
-__global__ __launch_bounds__(256) void k_step_pack(const float* __restrict__ Wm, const float* __restrict__ t,
-                                                   const float* __restrict__ logs, const float* __restrict__ w1,
-                                                   const float* __restrict__ b1, const float* __restrict__ w2,
-                                                   const float* __restrict__ b2, const float* __restrict__ w3,
-                                                   const float* __restrict__ b3, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void k_step_pack(const StepPackBatch pb) {
+    const int bi = blockIdx.y;
+    const float* __restrict__ Wm = pb.Wm[bi]; const float* __restrict__ t = pb.t[bi]; const float* __restrict__ logs = pb.logs[bi];
+    const float* __restrict__ w1 = pb.w1[bi]; const float* __restrict__ b1 = pb.b1[bi]; const float* __restrict__ w2 = pb.w2[bi];
+    const float* __restrict__ b2 = pb.b2[bi]; const float* __restrict__ w3 = pb.w3[bi]; const float* __restrict__ b3 = pb.b3[bi];
+    float* __restrict__ ws = pb.ws[bi];
     const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
     if (gtid == 0) {       // ldj_const = H*W*log|det Wm| + sum_c logs  (ws[1] holds log|det| from k_slogdet)
         float s = 0.f;
@@ -1005,16 +1013,19 @@ __global__ __launch_bounds__(256) void k_flow_step_rs16(const float* __restrict_
     if (tid == 0) ldj_acc[b] += ws[0] + lsum;
 }
 
-static thread_local float* g_prepare_winv = nullptr;          // cf_flow_step_prepare_train: also write Wm^-1 here
+extern "C" int cf_slogdet_inverse_batch(int n, const float* const* Wm, int C, float* const* logabsdet, float* const* inv, cf_stream_t stream);
 
+// n <= kPrepBatch steps of one shape: ONE factorisation launch (log|det Wm| into ws[1]; winv: also Wm^-1, training) and ONE
+// packing launch
 template <class G>
-int launch_prepare(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
-                   const float* w2, const float* b2, const float* w3, const float* b3, float* ws, hipStream_t s) {
-    int rc = cf_slogdet_inverse(Wm, G::C, ws + 1, g_prepare_winv, (cf_stream_t)s);       // training: W^-1 from the same factorisation
+int launch_prepare(const StepPackBatch& pb, int n, float* const* winv, hipStream_t s) {
+    float* lad[kPrepBatch];
+    for (int i = 0; i < n; ++i) lad[i] = pb.ws[i] + 1;
+    int rc = cf_slogdet_inverse_batch(n, pb.Wm, G::C, lad, winv, (cf_stream_t)s);
     if (rc) return rc;
     int blocks = (G::WS_FLOATS + 255) / 256;
     if (blocks > 512) blocks = 512;
-    k_step_pack<G><<<dim3(blocks), dim3(256), 0, s>>>(Wm, t, logs, w1, b1, w2, b2, w3, b3, ws);
+    k_step_pack<G><<<dim3(blocks, n), dim3(256), 0, s>>>(pb);
     return 0;
 }
 
@@ -1177,34 +1188,47 @@ int64_t cf_flow_step_ws_bytes(int C, int H, int W) {
     return 0;
 }
 
-int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
-                         const float* w2, const float* b2, const float* w3, const float* b3, void* ws, int C, int H,
-                         int W, cf_stream_t stream) {
-    CF_REQUIRE(Wm && t && logs && w1 && b1 && w2 && b2 && w3 && b3 && ws);
-    CF_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0);
-    int rc;
-    float* w = (float*)ws;
-    switch (shape_id(C, H, W)) {
-        case 0: rc = launch_prepare<G8>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
-        case 1: rc = launch_prepare<G16>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
-        case 2: rc = launch_prepare<G32>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
-        case 3: rc = launch_prepare<G64>(Wm, t, logs, w1, b1, w2, b2, w3, b3, w, cf_s(stream)); break;
-        default: cf_set_error("cf_flow_step_prepare: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
+int cf_flow_step_prepare_batch(int n, const float* const* Wm, const float* const* t, const float* const* logs, const float* const* w1,
+                               const float* const* b1, const float* const* w2, const float* const* b2, const float* const* w3,
+                               const float* const* b3, void* const* ws, float* const* winv, int C, int H, int W, cf_stream_t stream) {
+    CF_REQUIRE(n >= 0 && Wm && t && logs && w1 && b1 && w2 && b2 && w3 && b3 && ws);
+    const int sid = shape_id(C, H, W);
+    if (sid < 0) { cf_set_error("cf_flow_step_prepare: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED; }
+    for (int i0 = 0; i0 < n; i0 += kPrepBatch) {
+        const int m = n - i0 < kPrepBatch ? n - i0 : kPrepBatch;
+        StepPackBatch pb{};
+        for (int i = 0; i < m; ++i) {
+            const int j = i0 + i;
+            CF_REQUIRE(Wm[j] && t[j] && logs[j] && w1[j] && b1[j] && w2[j] && b2[j] && w3[j] && b3[j] && ws[j] &&
+                       (reinterpret_cast<uintptr_t>(ws[j]) & 15) == 0 && (!winv || winv[j]));
+            pb.Wm[i] = Wm[j]; pb.t[i] = t[j]; pb.logs[i] = logs[j]; pb.w1[i] = w1[j]; pb.b1[i] = b1[j]; pb.w2[i] = w2[j]; pb.b2[i] = b2[j];
+            pb.w3[i] = w3[j]; pb.b3[i] = b3[j]; pb.ws[i] = (float*)ws[j];
+        }
+        int rc = 0;
+        switch (sid) {
+            case 0: rc = launch_prepare<G8>(pb, m, winv ? winv + i0 : nullptr, cf_s(stream)); break;
+            case 1: rc = launch_prepare<G16>(pb, m, winv ? winv + i0 : nullptr, cf_s(stream)); break;
+            case 2: rc = launch_prepare<G32>(pb, m, winv ? winv + i0 : nullptr, cf_s(stream)); break;
+            default: rc = launch_prepare<G64>(pb, m, winv ? winv + i0 : nullptr, cf_s(stream)); break;
+        }
+        if (rc) return rc;
+        CF_LAUNCH_CHECK();
     }
-    if (rc) return rc;
-    CF_LAUNCH_CHECK();
     return 0;
 }
 
-// training: the same packing + Wm^-1 (C, C) for d log|det Wm| / d Wm = Wm^-T, from the ONE factorisation of the prepare step
+int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
+                         const float* w2, const float* b2, const float* w3, const float* b3, void* ws, int C, int H, int W,
+                         cf_stream_t stream) {
+    CF_REQUIRE(Wm && t && logs && w1 && b1 && w2 && b2 && w3 && b3 && ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+    return cf_flow_step_prepare_batch(1, &Wm, &t, &logs, &w1, &b1, &w2, &b2, &w3, &b3, &ws, nullptr, C, H, W, stream);
+}
+
 int cf_flow_step_prepare_train(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
                                const float* w2, const float* b2, const float* w3, const float* b3, void* ws, float* winv,
                                int C, int H, int W, cf_stream_t stream) {
-    CF_REQUIRE(winv);
-    g_prepare_winv = winv;
-    const int rc = cf_flow_step_prepare(Wm, t, logs, w1, b1, w2, b2, w3, b3, ws, C, H, W, stream);
-    g_prepare_winv = nullptr;
-    return rc;
+    CF_REQUIRE(Wm && t && logs && w1 && b1 && w2 && b2 && w3 && b3 && ws && winv && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
+    return cf_flow_step_prepare_batch(1, &Wm, &t, &logs, &w1, &b1, &w2, &b2, &w3, &b3, &ws, &winv, C, H, W, stream);
 }
 
 int64_t cf_flow_step_inv_ws_bytes(int C, int H, int W) {

@@ -29,10 +29,18 @@ template <class G> struct GeoBwd {
     static constexpr int WS_FLOATS = OFF_A0T + G::NG0 * RTI * 256;
 };
 
+// blockIdx.y = flow step of a batch (cf_flow_step_bwd_prepare_batch)
+constexpr int kPrepBatchBwd = 16;
+struct StepPackBwdBatch {
+    const float *Wm[kPrepBatchBwd], *logs[kPrepBatchBwd], *w1[kPrepBatchBwd], *w2[kPrepBatchBwd], *w3[kPrepBatchBwd];
+    float* wsb[kPrepBatchBwd];
+};
 template <class G>
-__global__ __launch_bounds__(256) void k_step_pack_bwd(const float* __restrict__ Wm, const float* __restrict__ logs,
-                                                       const float* __restrict__ w1, const float* __restrict__ w2,
-                                                       const float* __restrict__ w3, float* __restrict__ wsb) {
+__global__ __launch_bounds__(256) void k_step_pack_bwd(const StepPackBwdBatch pb) {
+    const int bi = blockIdx.y;
+    const float* __restrict__ Wm = pb.Wm[bi]; const float* __restrict__ logs = pb.logs[bi]; const float* __restrict__ w1 = pb.w1[bi];
+    const float* __restrict__ w2 = pb.w2[bi]; const float* __restrict__ w3 = pb.w3[bi];
+    float* __restrict__ wsb = pb.wsb[bi];
     using Bw = GeoBwd<G>;
     const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
     auto split = [](int e, int RT, int& g, int& rt, int& lane, int& j) {
@@ -593,11 +601,10 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
 }
 
 template <class G>
-int launch_prepare_bwd(const float* Wm, const float* logs, const float* w1, const float* w2, const float* w3, float* wsb,
-                       hipStream_t s) {
+int launch_prepare_bwd(const StepPackBwdBatch& pb, int n, hipStream_t s) {
     int blocks = (GeoBwd<G>::WS_FLOATS + 255) / 256;
     if (blocks > 512) blocks = 512;
-    k_step_pack_bwd<G><<<dim3(blocks), dim3(256), 0, s>>>(Wm, logs, w1, w2, w3, wsb);
+    k_step_pack_bwd<G><<<dim3(blocks, n), dim3(256), 0, s>>>(pb);
     return 0;
 }
 
@@ -636,19 +643,35 @@ int64_t cf_flow_step_bwd_ws_bytes(int C, int H, int W) {
     return 0;
 }
 
+int cf_flow_step_bwd_prepare_batch(int n, const float* const* Wm, const float* const* logs, const float* const* w1,
+                                   const float* const* w2, const float* const* w3, void* const* wsb, int C, int H, int W,
+                                   cf_stream_t stream) {
+    CF_REQUIRE(n >= 0 && Wm && logs && w1 && w2 && w3 && wsb);
+    const int sid = shape_id(C, H, W);
+    if (sid < 0) { cf_set_error("cf_flow_step_bwd_prepare: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED; }
+    for (int i0 = 0; i0 < n; i0 += kPrepBatchBwd) {
+        const int m = n - i0 < kPrepBatchBwd ? n - i0 : kPrepBatchBwd;
+        StepPackBwdBatch pb{};
+        for (int i = 0; i < m; ++i) {
+            const int j = i0 + i;
+            CF_REQUIRE(Wm[j] && logs[j] && w1[j] && w2[j] && w3[j] && wsb[j] && (reinterpret_cast<uintptr_t>(wsb[j]) & 15) == 0);
+            pb.Wm[i] = Wm[j]; pb.logs[i] = logs[j]; pb.w1[i] = w1[j]; pb.w2[i] = w2[j]; pb.w3[i] = w3[j]; pb.wsb[i] = (float*)wsb[j];
+        }
+        switch (sid) {
+            case 0: launch_prepare_bwd<B8>(pb, m, cf_s(stream)); break;
+            case 1: launch_prepare_bwd<B16>(pb, m, cf_s(stream)); break;
+            case 2: launch_prepare_bwd<B32>(pb, m, cf_s(stream)); break;
+            default: launch_prepare_bwd<B64>(pb, m, cf_s(stream)); break;
+        }
+        CF_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int cf_flow_step_bwd_prepare(const float* Wm, const float* logs, const float* w1, const float* w2, const float* w3,
                              void* wsb, int C, int H, int W, cf_stream_t stream) {
     CF_REQUIRE(Wm && logs && w1 && w2 && w3 && wsb && (reinterpret_cast<uintptr_t>(wsb) & 15) == 0);
-    float* w = (float*)wsb;
-    switch (shape_id(C, H, W)) {
-        case 0: launch_prepare_bwd<B8>(Wm, logs, w1, w2, w3, w, cf_s(stream)); break;
-        case 1: launch_prepare_bwd<B16>(Wm, logs, w1, w2, w3, w, cf_s(stream)); break;
-        case 2: launch_prepare_bwd<B32>(Wm, logs, w1, w2, w3, w, cf_s(stream)); break;
-        case 3: launch_prepare_bwd<B64>(Wm, logs, w1, w2, w3, w, cf_s(stream)); break;
-        default: cf_set_error("cf_flow_step_bwd_prepare: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
-    }
-    CF_LAUNCH_CHECK();
-    return 0;
+    return cf_flow_step_bwd_prepare_batch(1, &Wm, &logs, &w1, &w2, &w3, &wsb, C, H, W, stream);
 }
 
 // backward of a step whose forward was cf_flow_step_fwd_taped: the kernel reads ls / y1 / the two ReLU masks from the

@@ -25,13 +25,20 @@ template <int DIM, int HEAD> struct VitFuse {
 // go through LDS first (coalesced loads; the 64-term fp64 chains then read LDS: straight from global memory, on 12 workgroups, the
 // kernel took 98 us - more than the backward kernel of a flow step at a batch of 256).  `layers` = the flat parameters at layer 0.
 constexpr int FUSE_SPLIT = 4;
+constexpr int kVitPrepBatch = 16;
+struct VitFuseBatch {                                          // per flow step of a batch: its layers' flat parameters, its scratch
+    const float* layers[kVitPrepBatch];
+    float* scratch[kVitPrepBatch];
+};
+// blockIdx.x = layer + depth * (flow step of the batch)
 template <int DIM, int HEAD>
-__global__ __launch_bounds__(256) void k_vit_fuse(const float* __restrict__ layers, float* __restrict__ scratch) {
+__global__ __launch_bounds__(256) void k_vit_fuse(const VitFuseBatch fb, int depth) {
     using F = VitFuse<DIM, HEAD>;
     __shared__ float sA[HEAD * DIM], sB[HEAD * DIM];          // out[r][b] = sum_h sA[h][r] sB[h][b]
     __shared__ double tb[HEAD];
-    const float* p = layers + (size_t)blockIdx.x * F::P_STRIDE;
-    float* out = scratch + (size_t)blockIdx.x * F::LAYER_FLOATS;
+    const int bi = blockIdx.x / depth, layer = blockIdx.x - bi * depth;
+    const float* p = fb.layers[bi] + (size_t)layer * F::P_STRIDE;
+    float* out = fb.scratch[bi] + (size_t)layer * F::LAYER_FLOATS;
     const float *ga = p + F::P_GA, *ba = p + F::P_BA;
     const bool scores = blockIdx.y == 0;
     for (int i = threadIdx.x; i < HEAD * DIM; i += 256) {

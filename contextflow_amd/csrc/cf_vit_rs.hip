@@ -23,6 +23,9 @@
 #include "cf_vit_rs_common.h"
 
 extern "C" int cf_slogdet_inverse(const float* W, int C, float* logabsdet, float* Winv, cf_stream_t stream);
+extern "C" int cf_slogdet_inverse_batch(int n, const float* const* Wm, int C, float* const* logabsdet, float* const* inv, cf_stream_t stream);
+extern "C" int cf_vit_step_bwd_prepare_batch(int n, const float* const* Wm, const float* const* logs, const float* const* flat, void* const* wsb,
+                                             int C, int depth, cf_stream_t stream);
 
 namespace {
 
@@ -269,18 +272,43 @@ int cf_vit_step_rs_supported(int C, int H, int W, int p1, int p2, int dim, int d
 
 int64_t cf_vit_step_rs_ws_bytes(int C, int depth) { return C == 26 ? (int64_t)ws_floats<RS26>(depth) * 4 : 0; }
 
+// The row-split tables of n flow steps in ONE factorisation launch, ONE k_vit_fuse launch and ONE packing launch (a training
+// step at a batch of 256 packs all 8 steps of the SMAP flow per update: 24 serial launches of 14-27 us before).  HOST arrays
+// of device pointers.  winv (NULL or n): also Wm^-1 (the Conv1x1 log-det gradient); wsb (NULL or n): also the backward
+// kernel's transposed fragments (cf_vit_step_bwd_prepare).
+int cf_vit_step_rs_prepare_batch(int n, const float* const* Wm, const float* const* t, const float* const* logs,
+                                 const float* const* flat_vit_params, const float* pos, void* const* ws, float* const* winv,
+                                 void* const* wsb, int C, int depth, cf_stream_t stream) {
+    CF_REQUIRE(n >= 0 && Wm && t && logs && flat_vit_params && pos && ws && depth >= 1);
+    if (C != 26) { cf_set_error("cf_vit_step_rs_prepare: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
+    for (int i0 = 0; i0 < n; i0 += kVitPrepBatch) {
+        const int m = n - i0 < kVitPrepBatch ? n - i0 : kVitPrepBatch;
+        VitRsPackBatch pb{};
+        VitFuseBatch fb{};
+        float* lad[kVitPrepBatch];
+        for (int i = 0; i < m; ++i) {
+            const int j = i0 + i;
+            CF_REQUIRE(Wm[j] && t[j] && logs[j] && flat_vit_params[j] && ws[j] && (reinterpret_cast<uintptr_t>(ws[j]) & 15) == 0);
+            float* w = (float*)ws[j];
+            pb.Wm[i] = Wm[j]; pb.t[i] = t[j]; pb.logs[i] = logs[j]; pb.flat[i] = flat_vit_params[j]; pb.ws[i] = w;
+            fb.layers[i] = flat_vit_params[j] + 2 * RS26::PD + RS26::DIM * RS26::PD + RS26::DIM + 2 * RS26::DIM;
+            fb.scratch[i] = w + off_fuse_scratch<RS26>(depth);
+            lad[i] = w + 1;
+        }
+        int rc = cf_slogdet_inverse_batch(m, pb.Wm, C, lad, winv ? winv + i0 : nullptr, stream);
+        if (rc) return rc;
+        k_vit_fuse<RS26::DIM, RS26::HEAD><<<dim3(depth * m, 2, FUSE_SPLIT), dim3(256), 0, cf_s(stream)>>>(fb, depth);
+        k_vit_rs_pack<RS26><<<dim3(64, m), dim3(256), 0, cf_s(stream)>>>(pb, pos, depth);
+        CF_LAUNCH_CHECK();
+    }
+    if (wsb) return cf_vit_step_bwd_prepare_batch(n, Wm, logs, flat_vit_params, wsb, C, depth, stream);
+    return 0;
+}
+
 int cf_vit_step_rs_prepare(const float* Wm, const float* t, const float* logs, const float* flat_vit_params, const float* pos,
                            void* ws, int C, int depth, cf_stream_t stream) {
     CF_REQUIRE(Wm && t && logs && flat_vit_params && pos && ws && depth >= 1 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0);
-    if (C != 26) { cf_set_error("cf_vit_step_rs_prepare: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
-    float* w = (float*)ws;
-    int rc = cf_slogdet_inverse(Wm, C, w + 1, nullptr, stream);
-    if (rc) return rc;
-    k_vit_fuse<RS26::DIM, RS26::HEAD><<<dim3(depth, 2, FUSE_SPLIT), dim3(256), 0, cf_s(stream)>>>(
-        flat_vit_params + 2 * RS26::PD + RS26::DIM * RS26::PD + RS26::DIM + 2 * RS26::DIM, w + off_fuse_scratch<RS26>(depth));
-    k_vit_rs_pack<RS26><<<dim3(64), dim3(256), 0, cf_s(stream)>>>(Wm, t, logs, flat_vit_params, pos, w, depth);
-    CF_LAUNCH_CHECK();
-    return 0;
+    return cf_vit_step_rs_prepare_batch(1, &Wm, &t, &logs, &flat_vit_params, pos, &ws, nullptr, nullptr, C, depth, stream);
 }
 
 int cf_vit_step_rs_fwd(const float* x, float* z, float* ldj_acc, const void* ws, float* h_out, int B, int C, int depth,

@@ -55,9 +55,15 @@ template <class V> __host__ __device__ constexpr int wsb_floats(int depth) { ret
 
 // transposed 16x16x4 A fragments: element ((rt * NG + gi) * 64 + lane) * 4 + e = W[n][k] with k = 16 rt + (lane & 15)
 // (output row of the transposed product) and n = 4 (4 gi + e) + (lane >> 4) (its contraction index)
+struct VitRsPackBwdBatch {                                    // per flow step of a batch (blockIdx.y)
+    const float *Wm[kVitPrepBatch], *logs[kVitPrepBatch], *flat[kVitPrepBatch];
+    float* wsb[kVitPrepBatch];
+};
 template <class V>
-__global__ __launch_bounds__(256) void k_vit_rs_pack_bwd(const float* __restrict__ Wm, const float* __restrict__ logs,
-                                                         const float* __restrict__ flat, float* __restrict__ wsb, int depth) {
+__global__ __launch_bounds__(256) void k_vit_rs_pack_bwd(const VitRsPackBwdBatch pb, int depth) {
+    const float* __restrict__ Wm = pb.Wm[blockIdx.y]; const float* __restrict__ logs = pb.logs[blockIdx.y];
+    const float* __restrict__ flat = pb.flat[blockIdx.y];
+    float* __restrict__ wsb = pb.wsb[blockIdx.y];
     using R = RSB<V>;
     constexpr int C = V::C, DIM = V::DIM, PD = V::PD;
     const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
@@ -649,13 +655,28 @@ int64_t cf_vit_step_bwd_plane_floats(int B, int C, int depth) {
 }
 int64_t cf_vit_step_bwd_ln_floats(int B, int C, int depth) { return C == 26 ? (int64_t)((B + 3) / 4) * RB26::ln_floats(depth) : 0; }
 
+int cf_vit_step_bwd_prepare_batch(int n, const float* const* Wm, const float* const* logs, const float* const* flat_vit_params,
+                                  void* const* wsb, int C, int depth, cf_stream_t stream) {
+    CF_REQUIRE(n >= 0 && Wm && logs && flat_vit_params && wsb && depth >= 1 && depth <= RB26::MAXD);
+    if (C != 26) { cf_set_error("cf_vit_step_bwd_prepare: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
+    for (int i0 = 0; i0 < n; i0 += kVitPrepBatch) {
+        const int m = n - i0 < kVitPrepBatch ? n - i0 : kVitPrepBatch;
+        VitRsPackBwdBatch pb{};
+        for (int i = 0; i < m; ++i) {
+            const int j = i0 + i;
+            CF_REQUIRE(Wm[j] && logs[j] && flat_vit_params[j] && wsb[j] && (reinterpret_cast<uintptr_t>(wsb[j]) & 15) == 0);
+            pb.Wm[i] = Wm[j]; pb.logs[i] = logs[j]; pb.flat[i] = flat_vit_params[j]; pb.wsb[i] = (float*)wsb[j];
+        }
+        k_vit_rs_pack_bwd<RS26><<<dim3(64, m), dim3(256), 0, cf_s(stream)>>>(pb, depth);
+        CF_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 int cf_vit_step_bwd_prepare(const float* Wm, const float* logs, const float* flat_vit_params, void* wsb, int C, int depth,
                             cf_stream_t stream) {
-    CF_REQUIRE(Wm && logs && flat_vit_params && wsb && depth >= 1 && depth <= RB26::MAXD && (reinterpret_cast<uintptr_t>(wsb) & 15) == 0);
-    if (C != 26) { cf_set_error("cf_vit_step_bwd_prepare: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
-    k_vit_rs_pack_bwd<RS26><<<dim3(64), dim3(256), 0, cf_s(stream)>>>(Wm, logs, flat_vit_params, (float*)wsb, depth);
-    CF_LAUNCH_CHECK();
-    return 0;
+    CF_REQUIRE(Wm && logs && flat_vit_params && wsb && (reinterpret_cast<uintptr_t>(wsb) & 15) == 0);
+    return cf_vit_step_bwd_prepare_batch(1, &Wm, &logs, &flat_vit_params, &wsb, C, depth, stream);
 }
 
 int cf_vit_step_bwd(const float* x, const float* gz, const float* gld, float* gx, const void* ws, const void* wsb, float* planes,

@@ -43,10 +43,15 @@ template <class V> __host__ __device__ constexpr int ws_floats(int depth) { retu
 // ---- packing ----------------------------------------------------------------------------------------------------------
 // 16x16x4 A fragments of a Linear W (N x K, row-major): element ((rt * NG + gi) * 64 + lane) * 4 + e =
 // W[16 rt + (lane & 15)][4 (4 gi + e) + (lane >> 4)] * gamma[k]   (gamma: the preceding LayerNorm's weight, or none)
+struct VitRsPackBatch {                                       // per flow step of a batch (blockIdx.y)
+    const float *Wm[kVitPrepBatch], *t[kVitPrepBatch], *logs[kVitPrepBatch], *flat[kVitPrepBatch];
+    float* ws[kVitPrepBatch];
+};
 template <class V>
-__global__ __launch_bounds__(256) void k_vit_rs_pack(const float* __restrict__ Wm, const float* __restrict__ t,
-                                                     const float* __restrict__ logs, const float* __restrict__ flat,
-                                                     const float* __restrict__ pos, float* __restrict__ ws, int depth) {
+__global__ __launch_bounds__(256) void k_vit_rs_pack(const VitRsPackBatch pb, const float* __restrict__ pos, int depth) {
+    const float* __restrict__ Wm = pb.Wm[blockIdx.y]; const float* __restrict__ t = pb.t[blockIdx.y];
+    const float* __restrict__ logs = pb.logs[blockIdx.y]; const float* __restrict__ flat = pb.flat[blockIdx.y];
+    float* __restrict__ ws = pb.ws[blockIdx.y];
     constexpr int C = V::C, DIM = V::DIM, PD = V::PD, HEAD = V::HEAD;
     using F = VitFuse<DIM, HEAD>;
     const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;

@@ -556,9 +556,12 @@ int cf_vit_step_prepare(const float* Wm, const float* t, const float* logs, cons
     float* w = (float*)ws;
     int rc = cf_slogdet_inverse(Wm, C, w + 1, nullptr, stream);
     if (rc) return rc;
-    if (depth > 0)
-        k_vit_fuse<VS26::DIM, VS26::HEAD><<<dim3(depth, 2, FUSE_SPLIT), dim3(256), 0, cf_s(stream)>>>(
-            flat_vit_params + 2 * C + VS26::DIM * C + VS26::DIM + 2 * VS26::DIM, w + off_fuse<VS26>(depth));
+    if (depth > 0) {
+        VitFuseBatch fb{};
+        fb.layers[0] = flat_vit_params + 2 * C + VS26::DIM * C + VS26::DIM + 2 * VS26::DIM;
+        fb.scratch[0] = w + off_fuse<VS26>(depth);
+        k_vit_fuse<VS26::DIM, VS26::HEAD><<<dim3(depth, 2, FUSE_SPLIT), dim3(256), 0, cf_s(stream)>>>(fb, depth);
+    }
     k_vit_step_pack<VS26><<<dim3(64), dim3(256), 0, cf_s(stream)>>>(Wm, t, logs, flat_vit_params, pos, w, depth);
     CF_LAUNCH_CHECK();
     return 0;

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CONTEXTFLOW_HIP_LIB: developer override (A/B builds, probe builds of tools/dev); the default is the in-tree library
 LIB_PATH = os.environ.get("CONTEXTFLOW_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libcontextflow_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -31,6 +31,7 @@ SIGNATURES = {
     "cf_squeeze": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_int, _c_p]),
     "cf_conv1x1_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_p]),
     "cf_slogdet_inverse": (_c_int, [_c_p, _c_int, _c_p, _c_p, _c_p]),
+    "cf_slogdet_inverse_batch": (_c_int, [_c_int, _c_p, _c_int, _c_p, _c_p, _c_p]),
     "cf_actnorm_stats_ws_bytes": (_c_i64, [_c_int]),
     "cf_actnorm_stats": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_p]),
     "cf_actnorm_sums": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_int, _c_i64, _c_p]),
@@ -55,6 +56,8 @@ SIGNATURES = {
     "cf_flow_step_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_prepare": (_c_int, [_c_p] * 10 + [_c_int] * 3 + [_c_p]),
     "cf_flow_step_prepare_train": (_c_int, [_c_p] * 11 + [_c_int] * 3 + [_c_p]),
+    "cf_flow_step_prepare_batch": (_c_int, [_c_int] + [_c_p] * 11 + [_c_int] * 3 + [_c_p]),
+    "cf_flow_step_bwd_prepare_batch": (_c_int, [_c_int] + [_c_p] * 6 + [_c_int] * 3 + [_c_p]),
     "cf_flow_step_fwd": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_flow_step_inv_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_inv_prepare": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_p]),
@@ -96,6 +99,8 @@ SIGNATURES = {
     "cf_vit_step_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 2 + [_c_p]),
     "cf_vit_step_fwd": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
     "cf_vit_step_macs": (_c_i64, [_c_int] * 3),
+    "cf_vit_step_rs_prepare_batch": (_c_int, [_c_int] + [_c_p] * 8 + [_c_int] * 2 + [_c_p]),
+    "cf_vit_step_bwd_prepare_batch": (_c_int, [_c_int] + [_c_p] * 4 + [_c_int] * 2 + [_c_p]),
     "cf_vit_step_rs_supported": (_c_int, [_c_int] * 8),
     "cf_vit_step_rs_ws_bytes": (_c_i64, [_c_int] * 2),
     "cf_vit_step_rs_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 2 + [_c_p]),
@@ -169,6 +174,23 @@ def lib():
             raise RuntimeError("contextflow_amd: ABI version %d != expected %d" % (got, ABI_VERSION))
         _lib = handle
     return _lib
+
+
+class _PtrArray(ctypes.c_void_p):
+    """void* to a HOST array of device pointers; keeps the array and its tensors alive (as _Ptr does for one tensor)."""
+    _keep = None
+    _all = None
+
+
+def ptr_array(tensors):
+    """HOST array of the tensors' device pointers: the `*_batch` entry points take their per-item operands this way (the
+    array travels inside the kernel arguments, so it only has to live until the call returns).  `call` launches on the
+    device of the first tensor."""
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    out = _PtrArray(ctypes.addressof(arr))
+    out._keep = tensors[0]
+    out._all = (arr, list(tensors))
+    return out
 
 
 def check(rc, what=""):

@@ -216,7 +216,7 @@ def wgrad_group(members, dev, dests=None):
     return res
 
 
-def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, side=None, keep=None, sink=None):
+def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, side=None, keep=None, sink=None, winv=None, wsb=None):
     """Conv1x1 -> ActNorm -> TransCoupling (one fused step of the transformer flows) backwards: ONE kernel re-runs the step
     from its input and walks back (cf_vit_step_bwd), ONE grouped launch contracts the 26 weight-gradient operand pairs it
     leaves (cf_linear_wgrad_group), the LayerNorm gradients are column sums of its per-workgroup partials, and the Conv1x1 /
@@ -231,9 +231,10 @@ def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, s
     Wm, t, logs = f(conv.NN.detach()), f(act.NN_t.detach()), f(act.NN_logs.detach())
     if ws is None:                                        # the forward ran the wave form: pack the row-split table now
         ws = cpl.step_prepare(conv.NN, act.NN_t, act.NN_logs, dev, "rs")
-    flat = cpl._flat_params()
-    wsb = torch.empty(L.cf_vit_step_bwd_ws_bytes(C, depth), device=dev, dtype=torch.uint8)
-    _hip.call("cf_vit_step_bwd_prepare", pp(Wm), pp(logs), pp(flat), pp(wsb), C, depth, st)
+    if wsb is None:              # (the training forward at small batches packs these with its own tables: cf_vit_step_rs_prepare_batch)
+        flat = cpl._flat_params()
+        wsb = torch.empty(L.cf_vit_step_bwd_ws_bytes(C, depth), device=dev, dtype=torch.uint8)
+        _hip.call("cf_vit_step_bwd_prepare", pp(Wm), pp(logs), pp(flat), pp(wsb), C, depth, st)
     nwg = (B + 3) // 4
     planes = torch.empty(L.cf_vit_step_bwd_plane_floats(B, C, depth), device=dev, dtype=torch.float32)
     lnp = torch.empty(nwg, L.cf_vit_step_bwd_ln_floats(B, C, depth) // nwg, device=dev, dtype=torch.float32)
@@ -249,13 +250,13 @@ def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, s
     import contextlib
     if side is not None:
         side.wait_stream(torch.cuda.current_stream(dev))
-        keep.append((planes, lnp, xv, ws, wsb, gsum))
+        keep.append((planes, lnp, xv, ws, wsb, gsum, winv))
     with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         return gx, _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, xv.shape[2] * xv.shape[3], Wm, t, logs, gsum,
-                                     gld, dev, sink)
+                                     gld, dev, sink, winv)
 
 
-def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t, logs, gsum, gld, dev, sink=None):
+def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t, logs, gsum, gld, dev, sink=None, winv=None):
     """Second half of vstep_backward: grouped weight gradients, LayerNorm sums, Conv1x1 / ActNorm parameter chain."""
     f, pp, st = _hip.f32, _hip.p, _hip.stream()
     Bp = nwg * 4
@@ -300,9 +301,10 @@ def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t
     gWp, gbp = wg[0]
     if gsum is None:
         gsum = gld.sum().reshape(1)
-    lad = torch.empty(1, device=dev, dtype=torch.float32)
-    winv = torch.empty(C, C, device=dev, dtype=torch.float32)
-    _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
+    if winv is None:
+        lad = torch.empty(1, device=dev, dtype=torch.float32)
+        winv = torch.empty(C, C, device=dev, dtype=torch.float32)
+        _hip.call("cf_slogdet_inverse", pp(Wm), C, pp(lad), pp(winv), st)
     gNN, gt, glogs = _out(sink, conv.NN, (C, C), dev), _out(sink, act.NN_t, (C,), dev), _out(sink, act.NN_logs, (C,), dev)
     _hip.call("cf_step_param_grads", pp(gWp.contiguous()), pp(gbp.contiguous()), pp(Wm), pp(t), pp(logs), pp(winv), pp(f(gsum)),
               HW, pp(gNN), pp(gt), pp(glogs), C, st)
@@ -392,8 +394,9 @@ class FlowLogProb(torch.autograd.Function):
                 gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, side, keep, wsb, sink)
                 add_on(gp, ri)
             elif kind == "vstep":
-                _, xin, conv, act, cpl, ws_rs, xtape = rec
-                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape, side, keep, sink)
+                _, xin, conv, act, cpl, ws_rs, xtape = rec[:7]
+                winv_v, wsb_v = rec[7:9] if len(rec) >= 9 else (None, None)
+                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape, side, keep, sink, winv_v, wsb_v)
                 add_on(gp, ri)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)

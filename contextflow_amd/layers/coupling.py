@@ -297,6 +297,27 @@ class TransCoupling(_AffineCoupling):
                   _hip.p(_hip.f32(logs.detach())), _hip.p(flat), _hip.p(_hip.f32(vit.pos_embedding)), _hip.p(ws), C, depth, _hip.stream())
         return ws
 
+    @staticmethod
+    def step_prepare_rs_batch(items, dev, train=False):
+        """The row-split tables of SEVERAL steps - items: [(coupling, Wm, t, logs)] - in one factorisation, one fuse and one
+        packing launch (cf_vit_step_rs_prepare_batch).  train: also Wm^-1 and the backward kernel's tables per step.  Returns
+        [ws] or [(ws, winv, wsb)]."""
+        L = _hip.lib()
+        cpl0 = items[0][0]
+        vit = cpl0.NN[0]
+        C, depth, n = cpl0.in_sz[0], len(vit.transformer.layers), len(items)
+        if vit.pos_embedding.device != dev:
+            vit.pos_embedding = vit.pos_embedding.to(dev).contiguous()
+        f, A = _hip.f32, _hip.ptr_array
+        ws = [torch.empty(L.cf_vit_step_rs_ws_bytes(C, depth), device=dev, dtype=torch.uint8) for _ in range(n)]
+        Wm, t, logs = [f(i[1].detach()) for i in items], [f(i[2].detach()) for i in items], [f(i[3].detach()) for i in items]
+        flat = [i[0]._flat_params() for i in items]
+        winv = [torch.empty(C, C, device=dev, dtype=torch.float32) for _ in range(n)] if train else None
+        wsb = [torch.empty(L.cf_vit_step_bwd_ws_bytes(C, depth), device=dev, dtype=torch.uint8) for _ in range(n)] if train else None
+        _hip.call("cf_vit_step_rs_prepare_batch", n, A(Wm), A(t), A(logs), A(flat), _hip.p(_hip.f32(vit.pos_embedding)), A(ws),
+                  A(winv) if train else None, A(wsb) if train else None, C, depth, _hip.stream())
+        return list(zip(ws, winv, wsb)) if train else ws
+
     def step_forward(self, x, ws, ld1, h_out=None, variant="wave", xtape=None):
         """z = TransCoupling(ActNorm(Conv1x1(x))) and ld1 += the step's log-det, one launch.  xtape (training, wave form):
         receives the residual stream at the layer boundaries (cf_vit_step_fwd_taped) for cf_vit_step_bwd_taped."""

@@ -279,6 +279,30 @@ class FlowSequential(nn.Module):
             _hip.call("cf_flow_step_prepare_train", *args, pp(winv), C, H, W, _hip.stream())
         return ws
 
+    @staticmethod
+    def _prepare_steps(steps, shape, dev, train=False):
+        """Packed tables of SEVERAL flow steps of one shape - steps: [(conv, act, cpl)] - in one factorisation launch and one
+        packing launch (cf_flow_step_prepare_batch).  train: also Wm^-1 per step (d log|det W| / dW) and the transposed
+        fragments of the backward kernel (cf_flow_step_bwd_prepare_batch).  Returns [ws] or [(ws, winv, wsb)]."""
+        C, H, W = shape
+        L = _hip.lib()
+        f, n = _hip.f32, len(steps)
+        wsz = L.cf_flow_step_ws_bytes(C, H, W)
+        ws = [torch.empty(wsz, device=dev, dtype=torch.uint8) for _ in range(n)]
+        cols = ([f(s[0].NN.detach()) for s in steps], [f(s[1].NN_t.detach()) for s in steps], [f(s[1].NN_logs.detach()) for s in steps],
+                [f(s[2].NN[0].weight.detach()) for s in steps], [f(s[2].NN[0].bias.detach()) for s in steps],
+                [f(s[2].NN[2].weight.detach()) for s in steps], [f(s[2].NN[2].bias.detach()) for s in steps],
+                [f(s[2].NN[4].weight.detach()) for s in steps], [f(s[2].NN[4].bias.detach()) for s in steps])
+        A = _hip.ptr_array
+        winv = [torch.empty(C, C, device=dev, dtype=torch.float32) for _ in range(n)] if train else None
+        _hip.call("cf_flow_step_prepare_batch", n, *[A(c) for c in cols], A(ws), A(winv) if train else None, C, H, W, _hip.stream())
+        if not train:
+            return ws
+        bsz = L.cf_flow_step_bwd_ws_bytes(C, H, W)
+        wsb = [torch.empty(bsz, device=dev, dtype=torch.uint8) for _ in range(n)]
+        _hip.call("cf_flow_step_bwd_prepare_batch", n, A(cols[0]), A(cols[2]), A(cols[3]), A(cols[5]), A(cols[7]), A(wsb), C, H, W, _hip.stream())
+        return list(zip(ws, winv, wsb))
+
     def _forward_fused(self, x, context, tape=None):
         B, M, dev = x.shape[0], self.mixtures, x.device
         key = tuple(x.shape[1:])
@@ -327,23 +351,30 @@ class FlowSequential(nn.Module):
             # step at a batch of 256 - smap 2.10 -> 2.16 ms, cifar10 2.49 -> 2.48 ms: tools/dev/prep_streams_ab.py - and dropped)
             sides = [self._side_stream(dev)]
             sides[0].wait_stream(main)
-            for j, (k, op, ver) in enumerate(todo):
-                side = sides[j % len(sides)]
-                with torch.cuda.stream(side):
+            side = sides[0]
+            with torch.cuda.stream(side):
+                # conv steps: the tables of all steps of one shape in ONE factorisation + ONE packing launch (+ one for the
+                # backward kernel's fragments when training) - cf_flow_step_prepare_batch
+                groups = {}
+                for k, op, ver in todo:
                     if op[0] == "step":
-                        if tape is not None:     # training: W^-1 for d(log|det W|)/dW from the prepare step's factorisation
-                            Cc = op[4][0]
-                            winv = torch.empty(Cc, Cc, device=dev, dtype=torch.float32)
-                            # ... and the transposed weight fragments of the backward kernel: packed here, on the side stream,
-                            # they are off the chain of the backward pass (at a batch of 256 twelve 18 us launches)
-                            wsb = torch.empty(_hip.lib().cf_flow_step_bwd_ws_bytes(*op[4]), device=dev, dtype=torch.uint8)
-                            c1_, c2_, c3_ = op[3].NN[0], op[3].NN[2], op[3].NN[4]
-                            _hip.call("cf_flow_step_bwd_prepare", _hip.p(_hip.f32(op[1].NN.detach())), _hip.p(_hip.f32(op[2].NN_logs.detach())),
-                                      _hip.p(_hip.f32(c1_.weight.detach())), _hip.p(_hip.f32(c2_.weight.detach())),
-                                      _hip.p(_hip.f32(c3_.weight.detach())), _hip.p(wsb), op[4][0], op[4][1], op[4][2], _hip.stream())
-                            buf = (self._prepare_step(op[1], op[2], op[3], op[4], dev, winv), winv, wsb)
-                        else:
-                            buf = self._prepare_step(op[1], op[2], op[3], op[4], dev)
+                        groups.setdefault(tuple(op[4]), []).append((k, op, ver))
+                done = {}
+                for shape, items in groups.items():
+                    bufs = self._prepare_steps([(it[1][1], it[1][2], it[1][3]) for it in items], shape, dev, train=tape is not None)
+                    for (k, op, ver), buf in zip(items, bufs):
+                        done[k] = buf
+                # transformer steps at small batches: the row-split tables of all steps in one launch triple (training: with
+                # Wm^-1 and the backward kernel's tables) - cf_vit_step_rs_prepare_batch
+                vitems = [(k, op, ver) for k, op, ver in todo if op[0] == "vstep" and vkey[k] == "rs"]
+                if vitems:
+                    bufs = TransCoupling.step_prepare_rs_batch([(it[1][3], it[1][1].NN, it[1][2].NN_t, it[1][2].NN_logs) for it in vitems], dev,
+                                                               train=tape is not None)
+                    for (k, op, ver), buf in zip(vitems, bufs):
+                        done[k] = buf
+                for k, op, ver in todo:
+                    if k in done:
+                        buf = done[k]
                     elif op[0] == "vstep":
                         buf = op[3].step_prepare(op[1].NN, op[2].NN_t, op[2].NN_logs, dev, vkey[k])
                     else:
@@ -355,7 +386,6 @@ class FlowSequential(nn.Module):
                     if store_ok:
                         self._prep[(key, k, vkey.get(k))] = (ver, buf, ev)
             if prior is None:
-                side = sides[len(todo) % len(sides)]
                 with torch.cuda.stream(side):
                     prior = self.dist.prepared()
                     ev_prior = torch.cuda.Event()
@@ -440,6 +470,9 @@ class FlowSequential(nn.Module):
                 x = z
             elif kind == "vstep":
                 ws, ev = prepared[k]
+                winv_v = wsb_v = None
+                if isinstance(ws, tuple):    # training, row-split form: (tables, Wm^-1, backward tables) from the batched prepare
+                    ws, winv_v, wsb_v = ws
                 if tape is not None:         # training: the same one-kernel forward; the backward re-runs the step from its input
                     #                          (and reuses the packed forward table when it is the row-split one)
                     # the residual stream at the layer boundaries goes to a tape (5.8 KB per sample and step) and the backward
@@ -448,7 +481,7 @@ class FlowSequential(nn.Module):
                     if VSTEP_TAPE:
                         depth = len(op[3].NN[0].transformer.layers)
                         xt = torch.empty(_hip.lib().cf_vit_step_tape_floats(B, x.shape[1], depth), device=dev, dtype=torch.float32)
-                    tape.append(("vstep", x, op[1], op[2], op[3], ws if vkey[k] == "rs" else None, xt))
+                    tape.append(("vstep", x, op[1], op[2], op[3], ws if vkey[k] == "rs" else None, xt, winv_v, wsb_v))
                     if ev is not None:
                         main.wait_event(ev)
                     x = op[3].step_forward(x, ws, ld1, variant=vkey[k], xtape=xt)
@@ -746,6 +779,20 @@ class GraphedTrainStep:
         self.warmup = warmup
         self.updates = 0             # optimizer updates performed through this object
 
+    @staticmethod
+    def _drain_collectives(dev):
+        """Before a capture that contains RCCL collectives: let the process group's watchdog thread retire the EAGER
+        collectives of the warm-up step.  It polls their completion events (hipEventQuery) every 100 ms; once the capture has
+        pulled RCCL's internal stream into capture mode, HIP answers such a query with hipErrorCapturedEvent ("event last
+        recorded in a capturing stream" - for an event recorded BEFORE the capture, on a stream that is capturing NOW), and
+        the watchdog aborts the process.  Seen once in four captures with a warm-up step right in front.  The device is idle
+        after the synchronize, so every pending work is complete and the next poll (or the one after) drops it."""
+        import time
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_backend() == "nccl":
+            torch.cuda.synchronize(dev)
+            time.sleep(0.35)
+
     def _step(self):
         # grads start as None: the autograd engine then TAKES the gradient buffers the backward returns (allocated from
         # the graph's private pool during capture, so their addresses are the ones every replay writes and the
@@ -769,6 +816,8 @@ class GraphedTrainStep:
                     first = self._step().detach().clone()
             torch.cuda.current_stream(dev).wait_stream(s)
             self.updates += self.warmup
+            if self.flow.data_parallel:
+                self._drain_collectives(dev)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.static_loss = self._step()

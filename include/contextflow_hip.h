@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 6
+#define CF_ABI_VERSION 7
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -76,6 +76,9 @@ int cf_conv1x1_fwd(const float* x, const float* Wm, const float* bias, float* z,
 /* logabsdet[0] = log|det Wm| (LU with partial pivoting; fp64 in registers up to C = 128, an fp32 LDS copy with
  * fp64 accumulation of log|pivot| up to 192); if inv != NULL also Wm^-1 (C x C).                          */
 int cf_slogdet_inverse(const float* Wm, int C, float* logabsdet, float* inv, cf_stream_t stream);
+/* ... of n matrices of one width in ONE launch (C <= 64; wider ones run one at a time).  The pointer arrays are HOST arrays of
+ * device pointers (they travel as kernel arguments); inv may be NULL (no inverses) or hold n pointers.                     */
+int cf_slogdet_inverse_batch(int n, const float* const* Wm, int C, float* const* logabsdet, float* const* inv, cf_stream_t stream);
 
 /* ---- ActNorm (layers/actnorm.py:28-35,53-60,78) ------------------------------------------------- */
 /* data-dependent init: t[c] = mean, logs[c] = log(unbiased_std + 1e-8) over (B,H,W).
@@ -204,6 +207,17 @@ int cf_flow_step_prepare(const float* Wm, const float* t, const float* logs,
 int cf_flow_step_prepare_train(const float* Wm, const float* t, const float* logs, const float* w1, const float* b1,
                                const float* w2, const float* b2, const float* w3, const float* b3, void* ws, float* winv,
                                int C, int H, int W, cf_stream_t stream);
+/* The tables of n flow steps of ONE shape (e.g. the four steps of a resolution level) in one factorisation launch + one packing
+ * launch instead of 2 n (batches of 256: a training step re-packs every step's tables per update, and 36 serial launches of
+ * 15-68 us were a fifth of a cifar10 step).  HOST arrays of n device pointers each; winv NULL or n pointers (training).
+ * cf_flow_step_bwd_prepare_batch: the same for the backward kernel's transposed fragments.                                 */
+int cf_flow_step_prepare_batch(int n, const float* const* Wm, const float* const* t, const float* const* logs, const float* const* w1,
+                               const float* const* b1, const float* const* w2, const float* const* b2, const float* const* w3,
+                               const float* const* b3, void* const* ws, float* const* winv, int C, int H, int W, cf_stream_t stream);
+int cf_flow_step_bwd_prepare_batch(int n, const float* const* Wm, const float* const* logs, const float* const* w1,
+                                   const float* const* w2, const float* const* w3, void* const* wsb, int C, int H, int W,
+                                   cf_stream_t stream);
+
 /* z = step(x); ldj_acc[b] += ldj_const + sum log_s   (ldj_acc is the running per-sample log-det).
  * in_squeeze != 0: x is the UN-squeezed (B, C/4, 2H, 2W) tensor and Squeeze((2,2)) (squeeze.py:10-11)
  * is folded into the kernel's operand addressing (no separate index kernel, no extra HBM pass).
@@ -376,6 +390,15 @@ int cf_vit_step_rs_supported(int C, int H, int W, int p1, int p2, int dim, int d
 int64_t cf_vit_step_rs_ws_bytes(int C, int depth);
 int cf_vit_step_rs_prepare(const float* Wm, const float* t, const float* logs, const float* flat_vit_params, const float* pos,
                            void* ws, int C, int depth, cf_stream_t stream);
+/* The row-split tables of n flow steps in one factorisation, one fuse and one packing launch (HOST arrays of n device
+ * pointers; pos is shared).  winv: NULL or n (C, C) outputs for Wm^-1; wsb: NULL or n backward workspaces
+ * (cf_vit_step_bwd_ws_bytes) that also receive the backward kernel's tables (cf_vit_step_bwd_prepare_batch).            */
+int cf_vit_step_rs_prepare_batch(int n, const float* const* Wm, const float* const* t, const float* const* logs,
+                                 const float* const* flat_vit_params, const float* pos, void* const* ws, float* const* winv,
+                                 void* const* wsb, int C, int depth, cf_stream_t stream);
+int cf_vit_step_bwd_prepare_batch(int n, const float* const* Wm, const float* const* logs, const float* const* flat_vit_params,
+                                  void* const* wsb, int C, int depth, cf_stream_t stream);
+
 int cf_vit_step_rs_fwd(const float* x, float* z, float* ldj_acc, const void* ws, float* h_out, int B, int C, int depth,
                        int64_t x_bstride, cf_stream_t stream);
 
