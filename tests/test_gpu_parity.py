@@ -2197,7 +2197,7 @@ dist.init_process_group(backend, rank=rank, world_size=world)
 dev = torch.device("cuda", 0)
 name = os.environ.get("DP_FLOW", "cifar10")
 cfg, ds, M = cfa.preset_config(name)
-B = 64 * world                                                   # global batch; every rank owns a contiguous 64
+B = int(os.environ.get("DP_BATCH", "64")) * world                # global batch; every rank owns a contiguous share
 g = torch.Generator().manual_seed(1)
 xg = (torch.rand(B, *ds, generator=g) if name == "smap" else torch.randint(0, 256, (B, *ds), generator=g).float()).to(dev)
 ug = torch.rand(B, *ds, generator=g).to(dev)
@@ -2277,13 +2277,13 @@ print("DP_OK")
 '''
 
 
-def _run_dp_workers(tmp_path, world, backend, mode, flow, port):
+def _run_dp_workers(tmp_path, world, backend, mode, flow, port, batch=64):
     import subprocess
     import sys
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
     env = dict(os.environ, CF_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", DP_BACKEND=backend, DP_MODE=mode, DP_FLOW=flow)
+               WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", DP_BACKEND=backend, DP_MODE=mode, DP_FLOW=flow, DP_BATCH=str(batch))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
@@ -2303,11 +2303,13 @@ def test_data_parallel_step_of_two_ranks_equals_one_process_on_the_whole_batch(t
 
 
 @pytest.mark.gpu
-def test_captured_data_parallel_step_through_rccl_equals_the_eager_loop(tmp_path):
+@pytest.mark.parametrize("batch", [64, 1100])
+def test_captured_data_parallel_step_through_rccl_equals_the_eager_loop(tmp_path, batch):
     """The data-parallel training step as ONE HIP graph with its collectives captured inside, through a real RCCL
     communicator (of one rank: a one-GPU box): four updates give bit for bit the parameters of the eager loop without any
-    collective, and p.grad are views of the flat bucket (no concatenation, no copy back)."""
-    _run_dp_workers(tmp_path, 1, "nccl", "one_rank_captured", "cifar10", 29555)
+    collective, and p.grad are views of the flat bucket (no concatenation, no copy back).  64 samples: the weight gradients and
+    the collectives are issued on the flow's side stream (autograd.WGRAD_SIDE_MAX_BATCH); 1100: on the main stream."""
+    _run_dp_workers(tmp_path, 1, "nccl", "one_rank_captured", "cifar10", 29555 + (batch > 64), batch)
 
 
 # ------------------------------------------------------------------------------------------ Winograd form of the 3x3
