@@ -1073,9 +1073,12 @@ __global__ __launch_bounds__(256) void k_step_pack_inv(const float* __restrict__
 }
 
 template <class G>
-__global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__ z, float* __restrict__ x,
+#ifndef CF_INV16_MINW
+#define CF_INV16_MINW 3          // (4 waves per SIMD: 12 spilled registers, 6.55 vs 6.49 ms per cifar10 sample(16384))
+#endif
+__global__ __launch_bounds__(256, (G::WINO && G::C == 16) ? CF_INV16_MINW : G::MINW) void k_flow_step_inv(const float* __restrict__ z, float* __restrict__ x,
                                                        const float* __restrict__ ws, const float* __restrict__ wsi, int B,
-                                                       int64_t zbs) {
+                                                       int64_t zbs, int x_unsq) {
     using I = GeoInv<G>;
     constexpr int C = G::C, HW = G::HW, PIX = G::PIX, HALF = G::HALF;
     constexpr int PTW = G::PTW, RT03 = G::RT03, NR = (HALF <= 16 ? 8 : 16);
@@ -1089,26 +1092,33 @@ __global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__
 #pragma unroll
     for (int q = 0; q < PTW; ++q) { pix[q] = (wave * PTW + q) * 32 + li; pin[q] = pix[q] % HW; }
 
-    float4 zr[XI];
-    x_load<G, false>(zr, z, zbs, tile, B, wave, lane);
-    x_to_lds<G, false>(zr, H1, wave, lane);                      // z plane: rows [0,HALF) = z0, [HALF,C) = z1
-    cf_wave_sync();
-    float z0[PTW][NR], z1[PTW][NR];
+    {   // conditioner input: the first half of z, this wave's columns, straight into the Y0 plane (16-byte accesses)
+        float4 zr[XI];
+        x_load<G, false>(zr, z, zbs, tile, B, wave, lane);
+        x_to_lds<G, false>(zr, H1, wave, lane);                  // z plane: rows [0,HALF) = z0, [HALF,C) = z1
+        cf_wave_sync();
 #pragma unroll
-    for (int q = 0; q < PTW; ++q)
+        for (int q = 0; q < PTW; ++q)
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int idx = tile_row(r, lk);
-            const bool ok = idx < HALF;
-            z0[q][r] = ok ? H1[idx * PIX + pix[q]] : 0.f;
-            z1[q][r] = ok ? H1[(HALF + idx) * PIX + pix[q]] : 0.f;
-            if (ok) Y0[idx * PIX + pix[q]] = z0[q][r];           // conditioner input
-        }
-    cf_wave_sync();
+            for (int r = 0; r < NR; ++r) {
+                const int idx = tile_row(r, lk);
+                if (idx < HALF) Y0[idx * PIX + pix[q]] = H1[idx * PIX + pix[q]];
+            }
+        cf_wave_sync();
+    }
     f32x16 acc3[RT03][PTW];
     conditioner_net<G>(acc3, lds, ws, pix, pin, lane, tid, nullptr, 0, tile);
     cf_wave_sync();                      // phase 3 has read h2: its words are reused for the y plane
-    // y = [z0 | (z1 - t) e^{-log_s}] as the operand plane of the last phase (this wave's columns of the H region)
+    // y = [z0 | (z1 - t) e^{-log_s}] as the operand plane of the last phase (this wave's columns of the H region).  z is read a
+    // SECOND time here (L2-resident: this workgroup read it a few microseconds ago) instead of being carried in registers
+    // across the conditioner: 2 NR PTW registers per lane had cost the Winograd geometries half of their occupancy
+    // (140 / 256 / 256 VGPRs at C = 16 / 32 / 64: 2 / 1 / 1 waves per SIMD where the forward kernels run 4 / 2 / 2).
+    {
+        float4 zr[XI];
+        x_load<G, false>(zr, z, zbs, tile, B, wave, lane);
+        x_to_lds<G, false>(zr, H1, wave, lane);
+        cf_wave_sync();
+    }
 #pragma unroll
     for (int q = 0; q < PTW; ++q)
 #pragma unroll
@@ -1118,8 +1128,8 @@ __global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__
                 const float tt = acc3[0][q][r];
                 const float raw = (HALF <= 16) ? acc3[0][q][r + 8] : acc3[RT03 - 1][q][r];
                 const float ls = cf_log_scale(raw);
-                H1[idx * PIX + pix[q]] = z0[q][r];
-                H1[(HALF + idx) * PIX + pix[q]] = (z1[q][r] - tt) * __expf(-ls);
+                float* y1 = &H1[(HALF + idx) * PIX + pix[q]];
+                *y1 = (*y1 - tt) * __expf(-ls);
             }
         }
     cf_wave_sync();
@@ -1141,7 +1151,9 @@ __global__ __launch_bounds__(256) void k_flow_step_inv(const float* __restrict__
                 if (row < C) Xp[row * PIX + pix[q]] = acc[rt][q][r];
             }
     cf_wave_sync();
-    rows_store<G, C>(x, Xp, b0, 0, B, wave, lane);
+    // x_unsq: the step sits behind a Squeeze((2,2)) in the flow - its inverse is an index map of these stores (squeeze.py:13-14)
+    if (x_unsq) rows_store_unsq<G>(x, Xp, b0, B, wave, lane);
+    else rows_store<G, C>(x, Xp, b0, 0, B, wave, lane);
 }
 
 template <class G>
@@ -1154,13 +1166,13 @@ int launch_prepare_inv(const float* Wm, const float* t, const float* logs, float
 }
 
 template <class G>
-int launch_step_inv(const float* z, float* x, const float* ws, const float* wsi, int B, int64_t zbs, hipStream_t s) {
+int launch_step_inv(const float* z, float* x, const float* ws, const float* wsi, int B, int64_t zbs, int x_unsq, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
     if (lds_bytes > 64 * 1024) {
         static std::atomic<uint64_t> raised{0};
         if (int rc_ = cf_raise_dynamic_lds((const void*)k_flow_step_inv<G>, 160 * 1024, raised, __func__)) return rc_;
     }
-    k_flow_step_inv<G><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(z, x, ws, wsi, B, zbs);
+    k_flow_step_inv<G><<<dim3((B + G::SPW - 1) / G::SPW), dim3(256), lds_bytes, s>>>(z, x, ws, wsi, B, zbs, x_unsq);
     return 0;
 }
 
@@ -1259,7 +1271,7 @@ int cf_flow_step_inv_prepare(const float* Wm, const float* t, const float* logs,
 }
 
 int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, int B, int C, int H, int W,
-                     int64_t z_bstride, cf_stream_t stream) {
+                     int64_t z_bstride, int x_unsqueezed, cf_stream_t stream) {
     if (B == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(z && x && ws && wsi && B >= 0 && z_bstride >= (int64_t)C * H * W && z_bstride % 4 == 0);
     CF_REQUIRE((reinterpret_cast<uintptr_t>(z) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
@@ -1267,14 +1279,14 @@ int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, 
     const float* w = (const float*)ws;
     const float* wi = (const float*)wsi;
     switch (shape_id(C, H, W)) {
-        case 0: rc = launch_step_inv<G8>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        case 0: rc = launch_step_inv<G8>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream)); break;
         // the conditioner is the forward's: Winograd form of its 3x3 unless CONTEXTFLOW_DIRECT_CONV=1
-        case 1: rc = direct_conv_only() ? launch_step_inv<G16>(z, x, w, wi, B, z_bstride, cf_s(stream))
-                                        : launch_step_inv<G16w>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
-        case 2: rc = direct_conv_only() ? launch_step_inv<G32>(z, x, w, wi, B, z_bstride, cf_s(stream))
-                                        : launch_step_inv<G32w>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
-        case 3: rc = direct_conv_only() ? launch_step_inv<G64>(z, x, w, wi, B, z_bstride, cf_s(stream))
-                                        : launch_step_inv<G64w2>(z, x, w, wi, B, z_bstride, cf_s(stream)); break;
+        case 1: rc = direct_conv_only() ? launch_step_inv<G16>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream))
+                                        : launch_step_inv<G16w>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream)); break;
+        case 2: rc = direct_conv_only() ? launch_step_inv<G32>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream))
+                                        : launch_step_inv<G32w>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream)); break;
+        case 3: rc = direct_conv_only() ? launch_step_inv<G64>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream))
+                                        : launch_step_inv<G64w2>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream)); break;
         default: cf_set_error("cf_flow_step_inv: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
     if (rc) return rc;

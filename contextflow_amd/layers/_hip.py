@@ -61,7 +61,7 @@ SIGNATURES = {
     "cf_flow_step_fwd": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_flow_step_inv_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_inv_prepare": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_p]),
-    "cf_flow_step_inv": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_p]),
+    "cf_flow_step_inv": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_gmm_bwd_coeffs": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_int, _c_p]),
     "cf_gmm_bwd_gx": (_c_int, [_c_p] * 4 + [_c_int, _c_int, _c_i64, _c_p]),
     "cf_gmm_bwd_params": (_c_int, [_c_p] * 8 + [_c_int, _c_int, _c_p]),

@@ -321,7 +321,7 @@ class GaussianMixtureDistribution(nn.Module):
             return self._log_prob_ctx(input, context)
         return gmm_logprob(input, self.prepared())
 
-    def sample(self, n_samples, context=None):
+    def sample(self, n_samples, context=None, need_log_prob=True):
         """gaussian.py:163-169: draw from the mixture of class-mixture index 1 (the reference hard-codes `x[:, 1]`;
         with a single mixture, where the reference raises, index 0 is used) and return (x, log_prob(x))."""
         _hip.require_device(self.mG)
@@ -335,4 +335,4 @@ class GaussianMixtureDistribution(nn.Module):
         x = torch.empty(n_samples, *self.mG.shape[2:], device=dev, dtype=torch.float32)
         _hip.call("cf_gmm_sample", _hip.p(_hip.f32(self.mG.detach())), _hip.p(_hip.f32(self.sG.detach())), _hip.p(rows),
                   _hip.p(eps), _hip.p(x), n_samples, D, _hip.stream())
-        return x, self.log_prob(x, context)
+        return x, (self.log_prob(x, context) if need_log_prob else None)

@@ -679,8 +679,9 @@ class FlowSequential(nn.Module):
         `g(x) -> (z, logp)` (static output buffers, overwritten by the next replay)."""
         return GraphedFlow(self, example_input)
 
-    def _inverse_step(self, z, conv, act, cpl):
-        """Conv1x1^-1 o ActNorm^-1 o Coupling^-1 in one MFMA kernel (cf_flow_step_inv)."""
+    def _inverse_step(self, z, conv, act, cpl, unsqueeze=False):
+        """Conv1x1^-1 o ActNorm^-1 o Coupling^-1 in one MFMA kernel (cf_flow_step_inv); unsqueeze: the Squeeze((2,2)) in front of
+        the step is inverted by the kernel's stores."""
         z, zbs = _hip.bview(z)
         B, C, H, W = z.shape
         dev = z.device
@@ -689,12 +690,12 @@ class FlowSequential(nn.Module):
         f, pp, st = _hip.f32, _hip.p, _hip.stream()
         _hip.call("cf_flow_step_inv_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
                   pp(wsi), C, H, W, st)
-        x = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
+        x = torch.empty((B, C // 4, 2 * H, 2 * W) if unsqueeze else (B, C, H, W), device=dev, dtype=torch.float32)
         events = self.inv_events
         if events is not None:               # HIP events on the launch stream, bracketing exactly this kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-        _hip.call("cf_flow_step_inv", pp(z), pp(x), pp(ws), pp(wsi), B, C, H, W, zbs, st)
+        _hip.call("cf_flow_step_inv", pp(z), pp(x), pp(ws), pp(wsi), B, C, H, W, zbs, int(unsqueeze), st)
         if events is not None:
             e1.record(torch.cuda.current_stream(dev))
             events.append((e0, e1, B, C, H * W))
@@ -712,15 +713,17 @@ class FlowSequential(nn.Module):
                 if (self.fused and i >= 2 and z.dim() == 4 and isinstance(mods[i - 1], ActNorm)
                         and mods[i - 1].is_initialized()
                         and self._step_supported(mods[i - 2], mods[i - 1], m, tuple(z.shape[1:]))):
-                    z = self._inverse_step(z, mods[i - 2], mods[i - 1], m)
-                    i -= 3
+                    sq = i >= 3 and isinstance(mods[i - 3], Squeeze) and tuple(mods[i - 3].p) == (2, 2)
+                    z = self._inverse_step(z, mods[i - 2], mods[i - 1], m, unsqueeze=sq)
+                    i -= 4 if sq else 3
                 else:
                     z = m.reverse(z, context)
                     i -= 1
         return z
 
     def sample(self, n_samples, context=None):
-        z, _ = self.dist.sample(n_samples, context)
+        z = self.dist.sample(n_samples, context, need_log_prob=False)[0] if isinstance(self.dist, GaussianMixtureDistribution) \
+            else self.dist.sample(n_samples, context)[0]           # (the reference's sample() also returns log p(z): not needed here)
         return self.inverse(z, context)
 
 

@@ -19,7 +19,7 @@ class SplitPrior(FlowLayer):
         """Inverse by specification: the reference's own line (splitprior.py:18, `self.dist.sample(self.C, ...)`)
         reads an attribute that is never set; the evident intent — resample the split-off half from its prior, one
         draw per batch element, and concatenate — is what runs here."""
-        z2, _ = self.dist.sample(z.shape[0], context)
+        z2 = (self.dist.sample(z.shape[0], context, need_log_prob=False) if hasattr(self.dist, "mG") else self.dist.sample(z.shape[0], context))[0]
         return torch.cat([z, z2], dim=1)
 
     def logdet(self, input, context=None):

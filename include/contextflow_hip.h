@@ -241,8 +241,10 @@ int cf_flow_step_fwd_ctx(const float* x, float* z, float* ldj_acc, const void* w
 int64_t cf_flow_step_inv_ws_bytes(int C, int H, int W);
 int cf_flow_step_inv_prepare(const float* Wm, const float* t, const float* logs, void* wsi, int C, int H, int W,
                              cf_stream_t stream);
+/* x_unsqueezed != 0 (ABI 7): the step sits behind a Squeeze((2,2)) in the flow; x is written in the (B, C/4, 2H, 2W) layout of the
+ * tensor BEFORE that Squeeze (squeeze.py:13-14), i.e. Squeeze.reverse is folded into the kernel's stores.                 */
 int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, int B, int C, int H, int W,
-                     int64_t z_bstride, cf_stream_t stream);
+                     int64_t z_bstride, int x_unsqueezed, cf_stream_t stream);
 
 /* ---- backward of the fused step (training: experiment_cl.py:130-136) ------------------------------
  * cf_flow_step_bwd_prepare packs the TRANSPOSED weight fragments of the data-gradient chain (workspace of

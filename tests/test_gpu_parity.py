@@ -733,6 +733,13 @@ def test_fused_inverse_step(L, C, H, W, B):
     for m in flow.sequence_modules:
         zz, _ = m(zz)
     close(zz, z, tol=5e-5)
+    # a Squeeze((2,2)) in front of the step: its reverse is folded into the inverse kernel's stores (x_unsqueezed) - the very
+    # same numbers as the layer-by-layer inverse, in the layout of the tensor before the Squeeze
+    if C % 4 == 0:
+        flow2 = cfa.layers.FlowSequential(flow.dist, L.Squeeze((2, 2)), conv, act, cpl).to(DEV)
+        xs = flow2.inverse(z.to(DEV))
+        assert tuple(xs.shape) == (B, C // 4, 2 * H, 2 * W)
+        assert torch.equal(xs, L.Squeeze((2, 2)).reverse(x))
 
 
 # ------------------------------------------------------------------------------------------ sampling direction
