@@ -345,11 +345,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 // CTX: per-sample bias of the specialist coupling (see conditioner_net): 1 sb (B, C) on the conditioner output, 2 sb (B, 2C)
 // before the first ReLU.
+// (x and z carry no __restrict__: the chained form below runs steps 2.. IN PLACE on the z of the step before)
 template <class G, bool SQ, bool DBG = false, bool DUMP = false, int CTX = 0>
-__global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
-                                                                  float* __restrict__ ldj_acc, const float* __restrict__ ws,
-                                                                  int B, int64_t xbs, float* __restrict__ dbg, StepTape tp,
-                                                                  const float* __restrict__ sb = nullptr) {
+__device__ __forceinline__ void flow_step_small_body(const float* x, float* z, float* __restrict__ ldj_acc, const float* __restrict__ ws,
+                                                     int B, int64_t xbs, float* __restrict__ dbg, StepTape tp,
+                                                     const float* __restrict__ sb = nullptr) {
     static_assert(G::SMALL, "16x16 images, one sample per workgroup, C <= 16");
     static_assert(CTX == 0 || !G::HID16, "the per-sample bias is wired into the 32-row conditioner phases (C = 16)");
     constexpr int C = G::C, W = 16, H = 16, PIX = 256, HALF = G::HALF, HID = G::HID, PTW = G::PTW;
@@ -560,6 +560,33 @@ __global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16
     __syncthreads();
     if (tid == 0 && tile < B) ldj_acc[tile] += ws[0] + ((Y0[0] + Y0[64]) + (Y0[128] + Y0[192]));
 }
+template <class G, bool SQ, bool DBG = false, bool DUMP = false, int CTX = 0>
+__global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
+                                                                  float* __restrict__ ldj_acc, const float* __restrict__ ws,
+                                                                  int B, int64_t xbs, float* __restrict__ dbg, StepTape tp,
+                                                                  const float* __restrict__ sb = nullptr) {
+    flow_step_small_body<G, SQ, DBG, DUMP, CTX>(x, z, ldj_acc, ws, B, xbs, dbg, tp, sb);
+}
+// Chained form for small batches (cf_flow_step_fwd_chain): the n <= kChain consecutive flow steps of one resolution level in ONE
+// launch.  A workgroup owns whole samples end to end, so step k + 1 can read what step k wrote as soon as the workgroup has passed
+// a barrier; steps 2.. run in place on z.  At a batch of 256 a forward is ~20 launches of 10-35 us that a replayed graph issues
+// at 7-12 us per node whatever they do: 12 step launches become 3.
+constexpr int kChain = 4;
+struct WsChain { const float* ws[kChain]; };
+template <class G, bool SQ>
+__global__ __launch_bounds__(256, (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small_chain(const float* x, float* z, float* __restrict__ ldj_acc,
+                                                                                   const WsChain wc, int nsteps, int B, int64_t xbs) {
+    flow_step_small_body<G, SQ>(x, z, ldj_acc, wc.ws[0], B, xbs, nullptr, kNoTape);
+    for (int st = 1; st < nsteps; ++st) {
+        __syncthreads();                 // this workgroup's z of the step before is complete and visible to all of its waves
+        flow_step_small_body<G, false>(z, z, ldj_acc, wc.ws[st], B, (int64_t)G::C * G::HW, nullptr, kNoTape);
+    }
+}
+template <class G, bool SQ>
+int launch_step_small_chain(const float* x, float* z, float* ldj, const WsChain& wc, int n, int B, int64_t xbs, hipStream_t s) {
+    k_flow_step_small_chain<G, SQ><<<dim3(B), dim3(256), (size_t)G::LDS_FLOATS * sizeof(float), s>>>(x, z, ldj, wc, n, B, xbs);
+    return 0;
+}
 
 template <class G, bool SQ, bool DBG = false, bool DUMP = false, int CTX = 0>
 int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s,
@@ -596,9 +623,8 @@ int launch_step_small(const float* x, float* z, float* ldj, const float* ws, int
 #define RS_TICK_DUMP
 #endif
 template <class G, int NPT, bool SQ, bool DUMP = false, int KS = 2>
-__global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restrict__ x, float* __restrict__ z,
-                                                      float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                      int64_t xbs, StepTape tp = kNoTape) {
+__device__ __forceinline__ void flow_step_rs_body(const float* x, float* z, float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                  int64_t xbs, StepTape tp = kNoTape) {
     constexpr int C = G::C, HW = G::HW, W = G::W, H = G::H, HALF = G::HALF, HID = G::HID, HP = G::HP;
     constexpr int PIXR = 32 * NPT, SPWR = PIXR / HW, RT1 = G::RT1, RT03 = G::RT03;
     static_assert(RT1 * NPT == 4 && RT03 * NPT == 2 && HP == HALF && PIXR % HW == 0, "row-split geometry");
@@ -842,6 +868,28 @@ __global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restri
     RS_TICK_DUMP
 }
 
+template <class G, int NPT, bool SQ, bool DUMP = false, int KS = 2>
+__global__ __launch_bounds__(256 * KS) void k_flow_step_rs(const float* __restrict__ x, float* __restrict__ z,
+                                                      float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                      int64_t xbs, StepTape tp = kNoTape) {
+    flow_step_rs_body<G, NPT, SQ, DUMP, KS>(x, z, ldj_acc, ws, B, xbs, tp);
+}
+template <class G, int NPT, bool SQ, int KS = 2>
+__global__ __launch_bounds__(256 * KS) void k_flow_step_rs_chain(const float* x, float* z, float* __restrict__ ldj_acc, const WsChain wc,
+                                                            int nsteps, int B, int64_t xbs) {
+    flow_step_rs_body<G, NPT, SQ, false, KS>(x, z, ldj_acc, wc.ws[0], B, xbs);
+    for (int st = 1; st < nsteps; ++st) {
+        __syncthreads();
+        flow_step_rs_body<G, NPT, false, false, KS>(z, z, ldj_acc, wc.ws[st], B, (int64_t)G::C * G::HW);
+    }
+}
+template <class G, int NPT, bool SQ>
+int launch_step_rs_chain(const float* x, float* z, float* ldj, const WsChain& wc, int n, int B, int64_t xbs, hipStream_t s) {
+    constexpr int SPWR = 32 * NPT / G::HW;
+    k_flow_step_rs_chain<G, NPT, SQ, 2><<<dim3((B + SPWR - 1) / SPWR), dim3(512), 0, s>>>(x, z, ldj, wc, n, B, xbs);
+    return 0;
+}
+
 template <class G, int NPT, bool SQ, bool DUMP = false>
 int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B, int64_t xbs, hipStream_t s, StepTape tp = kNoTape) {
     constexpr int SPWR = 32 * NPT / G::HW;
@@ -865,9 +913,8 @@ int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B,
 // order (t / raw / y1 of a channel meet in the LDS epilogue), the fragments of the three small products requested at
 // kernel start, those of the 3x3 through a ring of four groups.
 template <class G, bool SQ>
-__global__ __launch_bounds__(256) void k_flow_step_rs16(const float* __restrict__ x, float* __restrict__ z,
-                                                        float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                        int64_t xbs) {
+__device__ __forceinline__ void flow_step_rs16_body(const float* x, float* z, float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                    int64_t xbs) {
     static_assert(G::RS16, "C = 64 on 4x4 images");
     constexpr int C = G::C, HW = 16, W = 4, H = 4, HALF = G::HALF, HID = G::HID, P = 16;
     constexpr int NG0 = C / 16, NG1 = HALF / 16, NGT = HID / 16, NG3 = HID / 16;            // groups of 4 k-steps: per product / per tap
@@ -1011,6 +1058,21 @@ __global__ __launch_bounds__(256) void k_flow_step_rs16(const float* __restrict_
     }
     lsum = cf_block_sum<4>(lsum, red);
     if (tid == 0) ldj_acc[b] += ws[0] + lsum;
+}
+template <class G, bool SQ>
+__global__ __launch_bounds__(256) void k_flow_step_rs16(const float* __restrict__ x, float* __restrict__ z,
+                                                        float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                        int64_t xbs) {
+    flow_step_rs16_body<G, SQ>(x, z, ldj_acc, ws, B, xbs);
+}
+template <class G, bool SQ>
+__global__ __launch_bounds__(256) void k_flow_step_rs16_chain(const float* x, float* z, float* __restrict__ ldj_acc, const WsChain wc,
+                                                              int nsteps, int B, int64_t xbs) {
+    flow_step_rs16_body<G, SQ>(x, z, ldj_acc, wc.ws[0], B, xbs);
+    for (int st = 1; st < nsteps; ++st) {
+        __syncthreads();
+        flow_step_rs16_body<G, false>(z, z, ldj_acc, wc.ws[st], B, (int64_t)G::C * G::HW);
+    }
 }
 
 extern "C" int cf_slogdet_inverse_batch(int n, const float* const* Wm, int C, float* const* logabsdet, float* const* inv, cf_stream_t stream);
@@ -1361,6 +1423,47 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
     }
 #undef CF_STEP
     if (rc) return rc;
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// n <= 4 consecutive flow steps of one shape in ONE launch, for the batch sizes at which a step is one of the small-batch
+// kernels anyway (cf_flow_step_chain_max_batch: 16x16 images up to 1 024 samples, 8x8 up to 512, 4x4 up to 1 024); ws: HOST array
+// of the n packed tables; in_squeeze applies to the first step.  z receives the output of the LAST step (the intermediate
+// activations live in z too: the steps after the first run in place).  Same numbers as n calls of cf_flow_step_fwd, bit for bit.
+int cf_flow_step_chain_max_batch(int C, int H, int W) {
+    switch (shape_id(C, H, W)) {
+        case 0: case 1: return direct_conv_only() ? 0 : 1024;
+        case 2: return 512;                                // k_flow_step_rs's range in cf_flow_step_fwd
+        case 3: return CF_RS16_MAXB < CF_RS_MAXB_C64 ? CF_RS16_MAXB : CF_RS_MAXB_C64;
+    }
+    return 0;
+}
+
+int cf_flow_step_fwd_chain(const float* x, float* z, float* ldj_acc, const void* const* ws, int n, int B, int C, int H, int W,
+                           int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
+    if (B == 0 || n == 0) return 0;
+    CF_REQUIRE(x && z && ldj_acc && ws && n >= 1 && n <= kChain && B > 0 && x_bstride >= (int64_t)C * H * W);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && x_bstride % 4 == 0);
+    const int sid = shape_id(C, H, W);
+    if (sid < 0 || B > cf_flow_step_chain_max_batch(C, H, W)) {
+        cf_set_error("cf_flow_step_fwd_chain: shape (%d,%d,%d) at a batch of %d is not a chained case", C, H, W, B);
+        return CF_ERR_UNSUPPORTED;
+    }
+    WsChain wc{};
+    for (int i = 0; i < n; ++i) { CF_REQUIRE(ws[i]); wc.ws[i] = (const float*)ws[i]; }
+    hipStream_t s = cf_s(stream);
+    switch (sid) {
+        case 0: in_squeeze ? launch_step_small_chain<G8w, true>(x, z, ldj_acc, wc, n, B, x_bstride, s)
+                           : launch_step_small_chain<G8w, false>(x, z, ldj_acc, wc, n, B, x_bstride, s); break;
+        case 1: in_squeeze ? launch_step_small_chain<G16w, true>(x, z, ldj_acc, wc, n, B, x_bstride, s)
+                           : launch_step_small_chain<G16w, false>(x, z, ldj_acc, wc, n, B, x_bstride, s); break;
+        case 2: in_squeeze ? launch_step_rs_chain<G32, 2, true>(x, z, ldj_acc, wc, n, B, x_bstride, s)
+                           : launch_step_rs_chain<G32, 2, false>(x, z, ldj_acc, wc, n, B, x_bstride, s); break;
+        default:
+            if (in_squeeze) k_flow_step_rs16_chain<G64, true><<<dim3(B), dim3(256), 0, s>>>(x, z, ldj_acc, wc, n, B, x_bstride);
+            else k_flow_step_rs16_chain<G64, false><<<dim3(B), dim3(256), 0, s>>>(x, z, ldj_acc, wc, n, B, x_bstride);
+    }
     CF_LAUNCH_CHECK();
     return 0;
 }

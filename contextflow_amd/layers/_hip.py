@@ -72,6 +72,8 @@ SIGNATURES = {
     "cf_flow_step_bwd_ws_bytes": (_c_i64, [_c_int] * 3),
     "cf_flow_step_bwd_prepare": (_c_int, [_c_p] * 6 + [_c_int] * 3 + [_c_p]),
     "cf_flow_step_macs": (_c_i64, [_c_int] * 5),
+    "cf_flow_step_chain_max_batch": (_c_int, [_c_int] * 3),
+    "cf_flow_step_fwd_chain": (_c_int, [_c_p] * 4 + [_c_int] * 5 + [_c_i64, _c_int, _c_p]),
     "cf_step_wgrads_macs": (_c_i64, [_c_int] * 4),
     "cf_flow_step_tape_aux_bytes": (_c_i64, [_c_int] * 4),
     "cf_flow_step_bwd_taped": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_p]),

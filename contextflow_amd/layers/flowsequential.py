@@ -279,6 +279,20 @@ class FlowSequential(nn.Module):
             _hip.call("cf_flow_step_prepare_train", *args, pp(winv), C, H, W, _hip.stream())
         return ws
 
+    _chain_cache = {}
+
+    @classmethod
+    def _chain_max(cls, C, H, W):
+        """largest batch at which cf_flow_step_fwd_chain covers this shape (0: never)"""
+        if not cls.CHAIN_STEPS:
+            return 0
+        v = cls._chain_cache.get((C, H, W))
+        if v is None:
+            v = cls._chain_cache[(C, H, W)] = int(_hip.lib().cf_flow_step_chain_max_batch(C, H, W))
+        return v
+
+    CHAIN_STEPS = True               # False: every flow step its own launch at every batch size (A/B, tests)
+
     @staticmethod
     def _prepare_steps(steps, shape, dev, train=False):
         """Packed tables of SEVERAL flow steps of one shape - steps: [(conv, act, cpl)] - in one factorisation launch and one
@@ -401,8 +415,11 @@ class FlowSequential(nn.Module):
         ldM_set = False
         levels = [] if tape is None and B <= GMM_LEVELS_MAX_BATCH else None
         st = _hip.stream()
+        chained = set()              # plan indices that ran as the tail of a chained launch
         for k, op in enumerate(plan):
             kind = op[0]
+            if k in chained:
+                continue
             if kind == "pre":
                 if tape is not None:
                     tape.append(("pre",))
@@ -460,6 +477,24 @@ class FlowSequential(nn.Module):
                 x, xbs = _hip.bview(x)
                 z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
                 events = self.step_events
+                if events is None and 0 < B <= self._chain_max(C, H, W):
+                    # small batch: this step and the following steps of the same shape (a resolution level) in ONE launch
+                    run = [k]
+                    while (len(run) < 4 and run[-1] + 1 < len(plan) and plan[run[-1] + 1][0] == "step"
+                           and tuple(plan[run[-1] + 1][4]) == (C, H, W) and not plan[run[-1] + 1][5]):
+                        run.append(run[-1] + 1)
+                    if len(run) > 1:
+                        tabs = [ws]
+                        for j in run[1:]:
+                            wj, evj = prepared[j]
+                            if evj is not None:
+                                main.wait_event(evj)
+                            tabs.append(wj)
+                        _hip.call("cf_flow_step_fwd_chain", _hip.p(x), _hip.p(z), _hip.p(ld1), _hip.ptr_array(tabs), len(run), B, C, H, W, xbs,
+                                  int(sq), st)
+                        chained.update(run[1:])
+                        x = z
+                        continue
                 if events is not None:       # HIP events on the launch stream, bracketing exactly this kernel
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(main)

@@ -227,6 +227,15 @@ int cf_flow_step_bwd_prepare_batch(int n, const float* const* Wm, const float* c
  * the direct form everywhere.  The same holds for _fwd_taped, _fwd_ctx and _inv below.                 */
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                      int64_t x_bstride, int in_squeeze, cf_stream_t stream);
+/* Chained form for small batches (ABI 7): n <= 4 consecutive flow steps of ONE shape in ONE launch - a workgroup owns whole samples
+ * end to end, so the steps after the first run in place on z behind a workgroup barrier.  ws: HOST array of the n packed tables
+ * (cf_flow_step_prepare); in_squeeze applies to the first step; z holds the output of the last step.  Only for batches at which
+ * cf_flow_step_fwd takes its small-batch kernels (B <= cf_flow_step_chain_max_batch(C, H, W); 0 = never): the numbers are bit for
+ * bit those of n single calls.  At a batch of 256 a forward is launch-bound: 12 step launches become 3.                      */
+int cf_flow_step_chain_max_batch(int C, int H, int W);
+int cf_flow_step_fwd_chain(const float* x, float* z, float* ldj_acc, const void* const* ws, int n, int B, int C, int H, int W,
+                           int64_t x_bstride, int in_squeeze, cf_stream_t stream);
+
 
 /* the fused step with a per-sample bias from the specialist coupling's CN net (coupling.py:39-47):
  * mode 1: sbias (B,C) added to the conditioner output (contextflow); mode 2: sbias (B,2C) added before the

@@ -1282,6 +1282,53 @@ def test_auto_graph_replay_and_cache_invalidation(L):
     assert abs(float(bs.mean() - b[0].mean())) > 0.1                    # the shift is visible
 
 
+@pytest.mark.parametrize("name,B", [("cifar10", 256), ("cifar10", 37), ("mnist", 64), ("cifar10", 700)])
+def test_chained_flow_steps_equal_single_launches(L, name, B):
+    """Small batches: the flow steps of a resolution level run as ONE launch (cf_flow_step_fwd_chain: a workgroup owns whole
+    samples, steps 2.. run in place on z behind a workgroup barrier).  Bit for bit the log-densities and latents of the same
+    plan with one launch per step - at 700 samples only the levels whose small-batch kernels reach that far are chained."""
+    from tests.gpu_util import build_model, set_noise
+    from contextflow_amd.layers.flowsequential import FlowSequential
+    ops, _, M, params, fx = load_e2e(name)
+    C, H, W = fo.CONFIGS[name][0]
+    g = torch.Generator().manual_seed(B)
+    x = torch.randint(0, 256, (B, C, H, W), generator=g).float()
+    u, eps = torch.rand(B, C, H, W, generator=g), [torch.randn(B, 1, H, W, generator=g)]
+    model = build_model(name, params)
+    set_noise(model, u, eps)
+    model.auto_graph = False
+    launches = []
+    orig = _hip_call_counter(launches)
+    try:
+        with torch.no_grad():
+            FlowSequential.CHAIN_STEPS = False
+            z0, lp0 = model(x.to(DEV))
+            n_single = sum(1 for n in launches if n.startswith("cf_flow_step_fwd"))
+            del launches[:]
+            FlowSequential.CHAIN_STEPS = True
+            z1, lp1 = model(x.to(DEV))
+            n_chain = sum(1 for n in launches if n.startswith("cf_flow_step_fwd"))
+    finally:
+        FlowSequential.CHAIN_STEPS = True
+        orig()
+    assert torch.equal(lp0, lp1) and torch.equal(z0, z1)
+    assert n_chain < n_single, (n_chain, n_single)
+    _, ref = fo.flow_forward(ops, params, x[:16], u[:16], [eps[0][:16]])
+    assert (bpd(lp1[:16].cpu(), name) - bpd(ref, name)).abs().max() < BPD_TOL
+
+
+def _hip_call_counter(log):
+    """records the entry-point names that go through _hip.call; returns the undo function"""
+    from contextflow_amd.layers import _hip
+    real = _hip.call
+
+    def counting(name, *a):
+        log.append(name)
+        return real(name, *a)
+    _hip.call = counting
+    return lambda: setattr(_hip, "call", real)
+
+
 def test_replaced_parameter_objects_drop_the_caches(L):
     """A Parameter OBJECT replaced after the caches were filled - `m.NN = nn.Parameter(...)`, `load_state_dict(assign=True)` -
     starts at version 0 again, which would match the version-counter keys of the stale packed tables and captured graphs:
