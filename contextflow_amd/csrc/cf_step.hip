@@ -912,9 +912,11 @@ int launch_step_rs(const float* x, float* z, float* ldj, const float* ws, int B,
 // (16-row tiles: 1 / 2 / 2 / 1 per wave in the four products), planes [channel][16 pixels] in LDS (20 KB), natural row
 // order (t / raw / y1 of a channel meet in the LDS epilogue), the fragments of the three small products requested at
 // kernel start, those of the 3x3 through a ring of four groups.
-template <class G, bool SQ>
+// DUMP (training): the tape of cf_flow_step_fwd_taped - the planes are the LDS planes themselves (whole 16-byte rows), a mask
+// word of the 32x32x2 layout is put together from the four 4-bit groups two lanes (g, g + 2) hold of it.
+template <class G, bool SQ, bool DUMP = false>
 __device__ __forceinline__ void flow_step_rs16_body(const float* x, float* z, float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                    int64_t xbs) {
+                                                    int64_t xbs, StepTape tp = kNoTape) {
     static_assert(G::RS16, "C = 64 on 4x4 images");
     constexpr int C = G::C, HW = 16, W = 4, H = 4, HALF = G::HALF, HID = G::HID, P = 16;
     constexpr int NG0 = C / 16, NG1 = HALF / 16, NGT = HID / 16, NG3 = HID / 16;            // groups of 4 k-steps: per product / per tap
@@ -979,7 +981,23 @@ __device__ __forceinline__ void flow_step_rs16_body(const float* x, float* z, fl
     for (int i = 0; i < HALF * P / 256; ++i) {                                 // first half of the output = y0 (coupling.py:65)
         const int e = tid + 256 * i;
         z[(int64_t)b * C * HW + e] = YP[e];
+        if constexpr (DUMP) tp.y0[(int64_t)b * HALF * HW + e] = YP[e];
     }
+    // tape helpers: this lane's bits of the mask word of 32-row tile w (rows 16 t + 4 g + r -> bit 4 (2 t + g / 2) + r of the
+    // word of lane (g & 1) * 32 + column), and the copy of a [HID][16] plane to its (B, HID, 16) place
+    auto mask_word = [&](unsigned* __restrict__ m, const f32x4 (&a)[2]) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bits |= (a[t][r] > 0.f ? 1u : 0u) << (4 * (2 * t + (g >> 1)) + r);
+        bits |= (unsigned)__shfl_xor((int)bits, 32);
+        if (g < 2) m[((int64_t)(b >> 1) * G::RT1 + w) * 64 + g * 32 + (b & 1) * 16 + col] = bits;
+    };
+    auto plane_dump = [&](float* __restrict__ dst) {
+        for (int e = 4 * tid; e < HID * P; e += 1024)
+            *reinterpret_cast<float4*>(dst + (int64_t)b * HID * HW + e) = *reinterpret_cast<const float4*>(H1 + e);
+    };
     // ---- phase 1: h1 = relu(NN.0 y0 + b), row tiles 2 w, 2 w + 1
     {
         f32x4 a[2] = {bias4(G::OFF_RB1, 2 * w), bias4(G::OFF_RB1, 2 * w + 1)};
@@ -993,8 +1011,10 @@ __device__ __forceinline__ void flow_step_rs16_body(const float* x, float* z, fl
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) H1[(16 * (2 * w + t) + 4 * g + r) * P + col] = cf_relu(a[t][r]);
+        if constexpr (DUMP) mask_word(tp.m1, a);
     }
     __syncthreads();
+    if constexpr (DUMP) plane_dump(tp.h1);
     // ---- phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3 with reflect padding: 9 taps x HID channels
     f32x4 a2[2] = {bias4(G::OFF_RB2, 2 * w), bias4(G::OFF_RB2, 2 * w + 1)};
     {
@@ -1033,7 +1053,9 @@ __device__ __forceinline__ void flow_step_rs16_body(const float* x, float* z, fl
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) H1[(16 * (2 * w + t) + 4 * g + r) * P + col] = cf_relu(a2[t][r]);
+    if constexpr (DUMP) mask_word(tp.m2, a2);
     __syncthreads();
+    if constexpr (DUMP) plane_dump(tp.h2);
     // ---- phase 3: [t | raw] = NN.4 h2 + b, rows 16 w ..
     {
         f32x4 a0 = bias4(G::OFF_RB3, w), a1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1054,16 +1076,17 @@ __device__ __forceinline__ void flow_step_rs16_body(const float* x, float* z, fl
         const int e = tid + 256 * i;
         const float ls = cf_log_scale(TP[HALF * P + e]);
         z[(int64_t)b * C * HW + HALF * HW + e] = fmaf(YP[HALF * P + e], __expf(ls), TP[e]);
+        if constexpr (DUMP) { tp.ls[(int64_t)b * HALF * HW + e] = ls; tp.y1[(int64_t)b * HALF * HW + e] = YP[HALF * P + e]; }
         lsum += ls;
     }
     lsum = cf_block_sum<4>(lsum, red);
     if (tid == 0) ldj_acc[b] += ws[0] + lsum;
 }
-template <class G, bool SQ>
+template <class G, bool SQ, bool DUMP = false>
 __global__ __launch_bounds__(256) void k_flow_step_rs16(const float* __restrict__ x, float* __restrict__ z,
                                                         float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                        int64_t xbs) {
-    flow_step_rs16_body<G, SQ>(x, z, ldj_acc, ws, B, xbs);
+                                                        int64_t xbs, StepTape tp) {
+    flow_step_rs16_body<G, SQ, DUMP>(x, z, ldj_acc, ws, B, xbs, tp);
 }
 template <class G, bool SQ>
 __global__ __launch_bounds__(256) void k_flow_step_rs16_chain(const float* x, float* z, float* __restrict__ ldj_acc, const WsChain wc,
@@ -1487,8 +1510,8 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
         if (B == 0) return 0;
         const float* w = (const float*)ws;
         if (sid == 3 && B <= CF_RS16_MAXB) {   // 4x4: one sample per workgroup on 16-column tiles (twice the workgroups of the row-split kernel)
-            if (in_squeeze) k_flow_step_rs16<G64, true><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, w, B, x_bstride);
-            else k_flow_step_rs16<G64, false><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, w, B, x_bstride);
+            if (in_squeeze) k_flow_step_rs16<G64, true><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, w, B, x_bstride, kNoTape);
+            else k_flow_step_rs16<G64, false><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, w, B, x_bstride, kNoTape);
             CF_LAUNCH_CHECK();
             return 0;
         }
@@ -1556,8 +1579,10 @@ int cf_flow_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void*
         case 2: if (B <= 512) rc = in_squeeze ? launch_step_rs<G32, 2, true, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), tp)
                                               : launch_step_rs<G32, 2, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), tp);
                 else if (B < 256 * G32::SPW) CF_STEPT(G32v2); else if (direct_only) CF_STEPT(G32); else CF_STEPT(G32w); break;
-        case 3: if (B <= 1024) rc = in_squeeze ? launch_step_rs<G64, 1, true, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), tp)
-                                               : launch_step_rs<G64, 1, false, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream), tp);
+        case 3: if (B <= CF_RS16_MAXB) {    // one sample per workgroup, as the evaluation forward
+                    if (in_squeeze) k_flow_step_rs16<G64, true, true><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, w, B, x_bstride, tp);
+                    else k_flow_step_rs16<G64, false, true><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, w, B, x_bstride, tp);
+                }
                 else if (!direct_only && B >= 256 * G64w2::SPW) CF_STEPT(G64w2); else if (B < 256 * G64::SPW) CF_STEPT(G64v2); else CF_STEPT(G64); break;
         default: cf_set_error("cf_flow_step_fwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }

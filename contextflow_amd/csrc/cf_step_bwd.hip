@@ -26,7 +26,15 @@ template <class G> struct GeoBwd {
     static constexpr int OFF_A2T = OFF_A3T + G::NG0 * G::RT1 * 256;   // per tap: rows ci, K = co
     static constexpr int OFF_A1T = OFF_A2T + G::NG2 * G::RT1 * 256;   // rows HALF (1 tile), K = HID
     static constexpr int OFF_A0T = OFF_A1T + G::NG3 * 1 * 256;        // rows C, K = C          g_x = W'^T g_y
-    static constexpr int WS_FLOATS = OFF_A0T + G::NG0 * RTI * 256;
+    static constexpr int WS32_END = OFF_A0T + G::NG0 * RTI * 256;
+    // one-sample-per-workgroup form of the 4x4 level for small batches (k_flow_step_bwd_rs16): the same four transposed
+    // matrices as 16x16x4 A fragments in NATURAL row / k order, [row tile][group of 4 k-steps][lane][4]
+    static constexpr int OFF_R3T = WS32_END;                                                        // rows HID, K = C
+    static constexpr int OFF_R2T = OFF_R3T + (G::HID / 16) * (G::C / 16) * 256;                     // rows ci, group = tap * HID/16 + co group
+    static constexpr int OFF_R1T = OFF_R2T + (G::HID / 16) * 9 * (G::HID / 16) * 256;               // rows HALF, K = HID
+    static constexpr int OFF_R0T = OFF_R1T + (G::HALF / 16) * (G::HID / 16) * 256;                  // rows C (k_in), K = C: [g_y0 ; g_y1]
+    static constexpr int R16_END = OFF_R0T + (G::C / 16) * (G::C / 16) * 256;
+    static constexpr int WS_FLOATS = G::RS16 ? R16_END : WS32_END;
 };
 
 // blockIdx.y = flow step of a batch (cf_flow_step_bwd_prepare_batch)
@@ -68,6 +76,32 @@ __global__ __launch_bounds__(256) void k_step_pack_bwd(const StepPackBwdBatch pb
         const int row = rt * 32 + (lane & 31), kk = 2 * (4 * g + j) + (lane >> 5);
         const int k = kk < G::HALF ? kk + G::HALF : kk - G::HALF;          // the g_y plane sits in LDS as [g_y1 ; g_y0]
         wsb[Bw::OFF_A0T + e] = (row < G::C && kk < G::C) ? expf(-logs[k]) * Wm[k * G::C + row] : 0.f;
+    }
+    if constexpr (G::RS16) {
+        // element ((rt * NG + gi) * 64 + lane) * 4 + j = A[16 rt + (lane & 15)][4 (4 gi + j) + (lane >> 4)]
+        constexpr int C = G::C, HID = G::HID, HALF = G::HALF;
+        // NG groups per row tile, the k index runs over the KG = NG / taps groups of one tap
+        auto split16 = [](int e, int NG, int KG, int& gi, int& row, int& k) {
+            const int jj = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+            gi = q % NG; row = 16 * (q / NG) + (ln & 15); k = 4 * (4 * (gi % KG) + jj) + (ln >> 4);
+        };
+        int gi, row, k;
+        for (int e = gtid; e < (HID / 16) * (C / 16) * 256; e += gsz) {                  // A3T[hid][c] = w3[c][hid]
+            split16(e, C / 16, C / 16, gi, row, k);
+            wsb[Bw::OFF_R3T + e] = w3[k * HID + row];
+        }
+        for (int e = gtid; e < (HID / 16) * 9 * (HID / 16) * 256; e += gsz) {            // A2T[tap][ci][co] = w2[co][ci][tap]
+            split16(e, 9 * (HID / 16), HID / 16, gi, row, k);
+            wsb[Bw::OFF_R2T + e] = w2[(k * HID + row) * 9 + gi / (HID / 16)];
+        }
+        for (int e = gtid; e < (HALF / 16) * (HID / 16) * 256; e += gsz) {               // A1T[c][hid] = w1[hid][c]
+            split16(e, HID / 16, HID / 16, gi, row, k);
+            wsb[Bw::OFF_R1T + e] = w1[k * HALF + row];
+        }
+        for (int e = gtid; e < (C / 16) * (C / 16) * 256; e += gsz) {                    // A0T[k_in][c] = e^{-logs[c]} Wm[c][k_in]
+            split16(e, C / 16, C / 16, gi, row, k);
+            wsb[Bw::OFF_R0T + e] = expf(-logs[k]) * Wm[k * C + row];
+        }
     }
 }
 
@@ -600,6 +634,206 @@ __global__ __launch_bounds__(256, (G::C <= 16 ? 3 : 2)) void k_flow_step_bwd(
     }
 }
 
+
+// ---- the 4x4 level at small batches: ONE sample per workgroup on 16-column tiles ------------------------------------------------
+// The backward's analogue of k_flow_step_rs16 (cf_step.hip).  k_flow_step_bwd<B64> puts 8 samples into a workgroup: 32
+// workgroups at the reference's batch of 256, every wave running all four 32-row tiles of its two samples - 86 us per step,
+// 15 % of the captured training step.  Here a workgroup is one sample = the 16 columns of v_mfma_f32_16x16x4_f32 tiles, the
+// four waves split the OUTPUT rows (16-row tiles: 2 / 2 / 1 (half of K) / 1 per wave in the four products), planes
+// [channel][16 pixels] in LDS in natural row order.  The adjoint of the reflect-padded gather is taken on the OPERAND: per tap
+// row dy the three planes  GA[dx][co][s] = sum over { p : reflect(p + d) = s } of g_h2[co][p]  are formed once (two row reads,
+// one fold of a float4 per dx), after which a tap is a plain product.  TAPED form only (log-scale, y1 and the ReLU mask words
+// of the tape in the layout of the 32x32x2 kernels: one word holds the four rows of a lane's accumulator).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class G>
+__global__ __launch_bounds__(256) void k_flow_step_bwd_rs16(const float* __restrict__ gz, const float* __restrict__ gld,
+                                                            const float* __restrict__ wsb, float* __restrict__ gx,
+                                                            float* __restrict__ s_gh, float* __restrict__ s_gh2,
+                                                            float* __restrict__ s_gh1, float* __restrict__ s_gy, int B,
+                                                            StepTape tp, int gx_unsq) {
+    static_assert(G::RS16, "C = 64 on 4x4 images");
+    using Bw = GeoBwd<G>;
+    constexpr int C = G::C, HW = 16, W = 4, HALF = G::HALF, HID = G::HID, P = 16, RT1 = G::RT1;
+    constexpr int NGA = C / 16, NGT = HID / 16, NGC = HID / 32, NGD = C / 16;      // groups of 4 k-steps per product (C: half of K)
+    __shared__ __align__(16) float lds[(C + C + HID + 3 * HID) * P];
+    float* GH = lds;                 // [C][16]      g_t | g_raw
+    float* GY = GH + C * P;          // [C][16]      g_y0 | g_y1
+    float* H2 = GY + C * P;          // [HID][16]    g_h2, then g_h1, then g_x
+    float* GA = H2 + HID * P;        // [3][HID][16] the gathered planes of one tap row; then the two K-halves of g_y0
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const ws_rsrc_t rs = ws_rsrc(wsb, Bw::WS_FLOATS);
+    // fragments of the three small products, requested before anything else; the 3x3 through a ring of four groups
+    float4 fa[2][NGA], fc[NGC], fd[NGD];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int gi = 0; gi < NGA; ++gi) fa[t][gi] = ws_frag(rs, lane, Bw::OFF_R3T + ((2 * w + t) * NGA + gi) * 256);
+#pragma unroll
+    for (int gi = 0; gi < NGC; ++gi) fc[gi] = ws_frag(rs, lane, Bw::OFF_R1T + ((w & 1) * NGT + (w >> 1) * NGC + gi) * 256);
+#pragma unroll
+    for (int gi = 0; gi < NGD; ++gi) fd[gi] = ws_frag(rs, lane, Bw::OFF_R0T + (w * NGD + gi) * 256);
+    auto frag2 = [&](int j, float4 (&o)[2]) {
+        const int jj = j < 9 * NGT ? j : 9 * NGT - 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o[t] = ws_frag(rs, lane, Bw::OFF_R2T + ((2 * w + t) * 9 * NGT + jj) * 256);
+    };
+    float4 ring[4][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) frag2(j, ring[j]);
+    // the mask words of this lane's rows (16-row tile 2 w + t = half t of the 32-row tile w; bits 4 (2 t + g / 2) + i)
+    unsigned mw1[2], mw2[2];
+    {
+        const int64_t wi = ((int64_t)(b >> 1) * RT1 + w) * 64 + (g & 1) * 32 + (b & 1) * 16 + col;
+        const unsigned a1 = tp.m1[wi], a2 = tp.m2[wi];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { mw1[t] = a1 >> (4 * (2 * t + (g >> 1))); mw2[t] = a2 >> (4 * (2 * t + (g >> 1))); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto mma = [](float a, float bv, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc, 0, 0, 0); };
+    const float* gzb = gz + (int64_t)b * C * HW;
+    // ---- affine map + log-det: g_h = [g_z1, (g_z1 y1 e^{ls} + g_ld) (1 - (ls/2)^2)], g_y1 = g_z1 e^{ls}; two elements per thread
+    float gz0[HALF * P / 256];
+    {
+        const float gl = gld[b];
+#pragma unroll
+        for (int i = 0; i < HALF * P / 256; ++i) {
+            const int e = tid + 256 * i;
+            const float g1 = gzb[HALF * HW + e], ls = tp.ls[(int64_t)b * HALF * HW + e], y1 = tp.y1[(int64_t)b * HALF * HW + e];
+            gz0[i] = gzb[e];
+            const float ex = __expf(ls);
+            GY[HALF * P + e] = g1 * ex;
+            const float gls = g1 * y1 * ex + gl;
+            GH[e] = g1;
+            GH[HALF * P + e] = gls * (1.0f - 0.25f * ls * ls);
+        }
+    }
+    __syncthreads();
+    // weight-gradient operand planes leave as whole 16-byte rows: (B, rows, 16) is the LDS plane itself
+    auto plane_out = [&](float* __restrict__ dst, const float* __restrict__ src, int floats) {
+        for (int e = 4 * tid; e < floats; e += 1024) *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(src + e);
+    };
+    plane_out(s_gh + (int64_t)b * C * HW, GH, C * P);
+    plane_out(s_gy + (int64_t)b * C * HW + HALF * HW, GY + HALF * P, HALF * P);
+    // ---- g_h2 = (NN.4^T g_h) * [h2 > 0]: row tiles 2 w, 2 w + 1
+    {
+        f32x4 a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 4 * NGA; ++s) {
+            const float bv = GH[(4 * s + g) * P + col];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = mma(f4e(fa[t][s >> 2], s & 3), bv, a[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H2[(16 * (2 * w + t) + 4 * g + r) * P + col] = ((mw2[t] >> r) & 1u) ? a[t][r] : 0.f;
+    }
+    __syncthreads();
+    plane_out(s_gh2 + (int64_t)b * HID * HW, H2, HID * P);
+    // ---- g_h1 = (NN.2^T (*) g_h2) * [h1 > 0]
+    f32x4 a2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+    for (int dyi = 0; dyi < 3; ++dyi) {
+        if (dyi) __syncthreads();                                  // the previous tap row's planes have been consumed
+        // rows py with reflect(py + dy) = sy:  dy = -1: {1}, {0, 2}, {3}, {};  dy = 0: {sy};  dy = +1: {}, {0}, {1, 3}, {2}
+#pragma unroll
+        for (int i = 0; i < HID * 4 / 256; ++i) {
+            const int it = tid + 256 * i, k = it >> 2, sy = it & 3;
+            int p0, p1;
+            if (dyi == 1) { p0 = sy; p1 = -1; }
+            else if (dyi == 0) { p0 = sy == 0 ? 1 : sy == 1 ? 0 : sy == 2 ? 3 : -1; p1 = sy == 1 ? 2 : -1; }
+            else { p0 = sy == 0 ? -1 : sy == 1 ? 0 : sy == 2 ? 1 : 2; p1 = sy == 2 ? 3 : -1; }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 >= 0) v = *reinterpret_cast<const float4*>(&H2[k * P + 4 * p0]);
+            if (p1 >= 0) {
+                const float4 u = *reinterpret_cast<const float4*>(&H2[k * P + 4 * p1]);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            // columns px with reflect(px + dx) = sx, the same sets along x
+            *reinterpret_cast<float4*>(&GA[(0 * HID + k) * P + 4 * sy]) = make_float4(v.y, v.x + v.z, v.w, 0.f);     // dx = -1
+            *reinterpret_cast<float4*>(&GA[(1 * HID + k) * P + 4 * sy]) = v;                                         // dx = 0
+            *reinterpret_cast<float4*>(&GA[(2 * HID + k) * P + 4 * sy]) = make_float4(0.f, v.x, v.y + v.w, v.z);     // dx = +1
+        }
+        __syncthreads();
+        float bv[2][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[0][e] = GA[(4 * e + g) * P + col];
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+            const int tap = 3 * dyi + dxi;
+            const float* cur = GA + dxi * HID * P + g * P + col;
+            const float* nxt = GA + (dxi < 2 ? dxi + 1 : 2) * HID * P + g * P + col;
+#pragma unroll
+            for (int c = 0; c < NGT; ++c) {                            // NGT = 8: static ring slots
+                frag2(tap * NGT + c + 3, ring[(c + 3) & 3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    bv[(c + 1) & 1][e] = (c + 1 < NGT) ? cur[(16 * (c + 1) + 4 * e) * P] : nxt[4 * e * P];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) a2[t] = mma(f4e(ring[c & 3][t], e), bv[c & 1][e], a2[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // g_h2 was last read when the third tap row's planes were formed (a barrier ago): its region takes g_h1
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H2[(16 * (2 * w + t) + 4 * g + r) * P + col] = ((mw1[t] >> r) & 1u) ? a2[t][r] : 0.f;
+    __syncthreads();
+    plane_out(s_gh1 + (int64_t)b * HID * HW, H2, HID * P);
+    // ---- g_y0 = NN.0^T g_h1 + g_z0: row tile w & 1, K half w >> 1; the halves meet in the (dead) gathered planes
+    {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kh = w >> 1, rc = w & 1;
+#pragma unroll
+        for (int s = 0; s < 4 * NGC; ++s) a = mma(f4e(fc[s >> 2], s & 3), H2[(4 * (4 * NGC * kh + s) + g) * P + col], a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) GA[(kh * HALF + 16 * rc + 4 * g + r) * P + col] = a[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < HALF * P / 256; ++i) {
+        const int e = tid + 256 * i;
+        const float v = GA[e] + GA[HALF * P + e] + gz0[i];
+        GY[e] = v;
+        s_gy[(int64_t)b * C * HW + e] = v;
+    }
+    __syncthreads();
+    // ---- g_x = (e^{-logs} Wm)^T g_y: row tile w
+    {
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int s = 0; s < 4 * NGD; ++s) {
+            const float bv = GY[(4 * s + g) * P + col];
+            if (s & 1) a1 = mma(f4e(fd[s >> 2], s & 3), bv, a1); else a0 = mma(f4e(fd[s >> 2], s & 3), bv, a0);
+        }
+        a0 += a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) H2[(16 * w + 4 * g + r) * P + col] = a0[r];      // g_h1 is dead (two barriers ago)
+    }
+    __syncthreads();
+    float* gxb = gx + (int64_t)b * C * HW;
+    if (!gx_unsq) plane_out(gxb, H2, C * P);
+    else if (tid < (C / 2) * 4) {        // d/dx in the layout of the tensor BEFORE Squeeze((2,2)) (rows_store_unsq)
+        const int j = tid >> 2, yy = tid & 3;
+        const float4 p = *reinterpret_cast<const float4*>(&H2[(2 * j) * P + 4 * yy]);
+        const float4 q = *reinterpret_cast<const float4*>(&H2[(2 * j + 1) * P + 4 * yy]);
+        float* d = gxb + (j >> 1) * 4 * HW + (2 * yy + (j & 1)) * 2 * W;
+        *reinterpret_cast<float4*>(d) = make_float4(p.x, q.x, p.y, q.y);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(p.z, q.z, p.w, q.w);
+    }
+}
+
+#ifndef CF_BWD_RS16_MAXB
+#define CF_BWD_RS16_MAXB 1536       // tools/bwd_bench.py: 17 / 30 / 54 / 100 us at 256 / 512 / 1024 / 2048 samples against 86 / 87 / 88 / 95
+#endif
+
 template <class G>
 int launch_prepare_bwd(const StepPackBwdBatch& pb, int n, hipStream_t s) {
     int blocks = (GeoBwd<G>::WS_FLOATS + 255) / 256;
@@ -693,7 +927,12 @@ int cf_flow_step_bwd_taped(const float* gz, const float* gld, const void* wsb, c
         case 0: CF_BWDT(B8); break;
         case 1: CF_BWDT(B16); break;
         case 2: CF_BWDT(B32); break;
-        case 3: CF_BWDT(B64); break;
+        case 3:
+            if (B <= CF_BWD_RS16_MAXB)      // one sample per workgroup: B workgroups instead of B / 8
+                k_flow_step_bwd_rs16<B64><<<dim3(B), dim3(256), 0, cf_s(stream)>>>(gz, gld, wb, gx, s_gh, s_gh2, s_gh1, s_gy, B, tp,
+                                                                                  gx_unsqueezed != 0);
+            else CF_BWDT(B64);
+            break;
         default: cf_set_error("cf_flow_step_bwd_taped: shape (%d,%d,%d) unsupported", C, H, W); return CF_ERR_UNSUPPORTED;
     }
 #undef CF_BWDT

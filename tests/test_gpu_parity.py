@@ -1612,6 +1612,50 @@ def test_step_backward_writes_the_unsqueezed_gradient(L, C, H, B):
     assert torch.equal(res[1].view_as(want), want)
 
 
+def test_one_sample_backward_of_the_4x4_level_equals_the_tile_form(L):
+    """cf_flow_step_bwd_taped at the 4x4 level runs one sample per workgroup (k_flow_step_bwd_rs16: 16x16x4 tiles, natural
+    row order, adjoint of the reflect gather on the operand; its tape comes from the one-sample forward k_flow_step_rs16) up
+    to 1536 samples and the 8-samples-per-workgroup kernel above: the same samples through both (a batch of 512, and the
+    first 512 of a batch of 1600 - tape from the tile-form forward) agree to the rounding of two accumulation orders in
+    dL/dx and in all four weight-gradient operand planes, for both layouts of dL/dx."""
+    from contextflow_amd.layers import _hip
+    from contextflow_amd.layers.flowsequential import step_tape
+    lib = _hip.lib()
+    C, H = 64, 4
+    g = torch.Generator().manual_seed(41)
+    HID, HALF, HW = 2 * C, C // 2, H * H
+    r = lambda *sh: torch.randn(*sh, generator=g).to(DEV)
+    Wm = torch.linalg.qr(torch.randn(C, C, generator=g))[0].contiguous().to(DEV)
+    t, logs = 0.1 * r(C), 0.1 * r(C)
+    w1, b1, w2, b2, w3, b3 = 0.2 * r(HID, HALF, 1, 1), 0.1 * r(HID), 0.05 * r(HID, HID, 3, 3), 0.1 * r(HID), 0.05 * r(C, HID, 1, 1), 0.1 * r(C)
+    P, st = _hip.p, _hip.stream()
+    ws = torch.empty(lib.cf_flow_step_ws_bytes(C, H, H), device=DEV, dtype=torch.uint8)
+    _hip.call("cf_flow_step_prepare", P(Wm), P(t), P(logs), P(w1), P(b1), P(w2), P(b2), P(w3), P(b3), P(ws), C, H, H, st)
+    wsb = torch.empty(lib.cf_flow_step_bwd_ws_bytes(C, H, H), device=DEV, dtype=torch.uint8)
+    _hip.call("cf_flow_step_bwd_prepare", P(Wm), P(logs), P(w1), P(w2), P(w3), P(wsb), C, H, H, st)
+    xa, gza, glda = r(1600, C, H, H), r(1600, C, H, H), r(1600)
+
+    def run(B, unsq):
+        x, gz, gld = xa[:B].contiguous(), gza[:B].contiguous(), glda[:B].contiguous()
+        z, ld = torch.empty_like(x), torch.zeros(B, device=DEV)
+        planes = step_tape(B, C, H, H, DEV)
+        _hip.call("cf_flow_step_fwd_taped", P(x), P(z), P(ld), P(ws), P(planes[0]), P(planes[1]), P(planes[2]), P(planes[3]), B, C, H, H,
+                  C * HW, 0, st)
+        gx = torch.full((B, C, H, H), float("nan"), device=DEV)
+        pl = [torch.full((B, rows, HW), float("nan"), device=DEV) for rows in (C, HID, HID, C)]
+        _hip.call("cf_flow_step_bwd_taped", P(gz), P(gld), P(wsb), P(planes[3]), P(gx), *[P(p_) for p_ in pl], B, C, H, H, unsq, st)
+        return [gx] + pl
+
+    for unsq in (0, 1):
+        one, tile = run(512, unsq), run(1600, unsq)
+        for name, a, b in zip(("gx", "g_h", "g_h2", "g_h1", "g_y"), one, tile):
+            assert torch.isfinite(a).all(), name
+            err = (a.double() - b[:512].double()).abs().max().item()
+            assert err <= 2e-6 * b.abs().max().item(), (name, unsq, err)
+        # the ReLU masks are the tape's in both forms: exact zeros at the same places
+        assert torch.equal(one[2] == 0, tile[2][:512] == 0) and torch.equal(one[3] == 0, tile[3][:512] == 0)
+
+
 @pytest.mark.parametrize("C,H", [(16, 16), (32, 8), (64, 4)])
 def test_prepare_train_equals_prepare_plus_inverse(L, C, H):
     """cf_flow_step_prepare_train: the packed tables are bitwise those of cf_flow_step_prepare, and the W^-1 it writes from
