@@ -91,6 +91,7 @@ def _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev, sink=None
 
 # ------------------------------------------------------------------------------------------------ flow step
 WGRAD_SIDE_MAX_BATCH = 1024      # below: the weight gradients of a step run on a side stream, next to the data-gradient chain
+WGRAD_SIDE_STREAMS = int(__import__("os").environ.get("CONTEXTFLOW_WGRAD_STREAMS", "4"))
 
 
 def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None, side=None, keep=None, wsb=None,
@@ -366,19 +367,40 @@ class FlowLogProb(torch.autograd.Function):
         # that leads to step k - 1 - they run on the flow's side stream and meet the main stream once, at the end
         B0 = glogp.shape[0]
         dev = glogp.device
-        side = flow._side_stream(dev) if (glogp.is_cuda and B0 <= WGRAD_SIDE_MAX_BATCH) else None
+        # (WGRAD_SIDE_STREAMS of them, taken in turn by the records: the parameter work of one step is a chain of 6 - 8 small
+        # launches, longer than the step's backward kernel, so a single side stream becomes the critical path)
+        sides = ([flow._side_stream(dev, k) for k in range(WGRAD_SIDE_STREAMS)]
+                 if (glogp.is_cuda and B0 <= WGRAD_SIDE_MAX_BATCH) else [])
+        side, owner = None, {}
         keep = []
 
-        def add_on(d, ri):           # parameter gradients produced on the side stream are accumulated there
+        def add_on(d, ri):           # parameter gradients produced on a side stream are accumulated there
             import contextlib
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if side is not None:
+                    for p in d:                                  # a parameter shared by two records: behind its first producer
+                        o = owner.setdefault(p, side)
+                        if o is not side:
+                            side.wait_stream(o)
                 add(d)
                 if bucket is not None:
-                    flush(bucket.closes.get(ri, ()))
-        gz = None
+                    flush(())
+            seg_done = bucket.closes.get(ri, ()) if bucket is not None else ()
+            if seg_done:
+                # the collectives of all segments are issued from ONE stream (the first side stream, behind the others: the
+                # segment's gradients came from all of them) - RCCL's own stream then follows a single launching stream
+                red = sides[0] if sides else None
+                with (torch.cuda.stream(red) if red is not None else contextlib.nullcontext()):
+                    for s_ in sides[1:]:
+                        red.wait_stream(s_)
+                    flush(seg_done)
+        gz, turn = None, -1
         for ri in range(len(tape) - 1, -1, -1):
             rec = tape[ri]
             kind = rec[0]
+            if sides and kind in ("prior", "split", "step", "vstep"):
+                turn += 1
+                side = sides[turn % len(sides)]
             if kind == "prior":
                 _, xin, dist, prep = rec
                 gz, gp = gmm_backward(xin, dist, prep, glogp, gcol, side, keep, sink)
@@ -410,9 +432,10 @@ class FlowLogProb(torch.autograd.Function):
                     flush(bucket.closes.get(ri, ()))
             else:
                 raise NotImplementedError("no backward for tape record %r" % (kind,))
-        if side is not None:
+        if sides:
             main = torch.cuda.current_stream(dev)
-            main.wait_stream(side)
+            for s_ in sides:
+                main.wait_stream(s_)
             for g in acc.values():
                 g.record_stream(main)
             del keep

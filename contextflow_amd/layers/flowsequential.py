@@ -257,10 +257,10 @@ class FlowSequential(nn.Module):
         self._rng_key = (0x243F6A8885A308D3 ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
         return torch.empty(1, device=dev, dtype=torch.int64).random_()
 
-    def _side_stream(self, dev):
-        s = self._side.get(dev.index)
+    def _side_stream(self, dev, k=0):
+        s = self._side.get((dev.index, k))
         if s is None:
-            s = self._side[dev.index] = torch.cuda.Stream(device=dev)
+            s = self._side[(dev.index, k)] = torch.cuda.Stream(device=dev)
         return s
 
     @staticmethod
