@@ -251,11 +251,17 @@ __global__ __launch_bounds__(256) void k_channel_sums_finish(const float* __rest
 //   gt[o]      = -s[o] gbp[o]
 //   glogs[o]   = -sum_i gWp[o][i] s[o] Wm[o][i] + gbp[o] t[o] s[o] + G      (reference quirk: ldj = +sum logs)
 // One workgroup (C <= 128): replaces ~15 parameter-sized torch kernels per flow step of a training step.
-__global__ __launch_bounds__(256) void k_step_param_grads(const float* __restrict__ gWp, const float* __restrict__ gbp,
-                                                          const float* __restrict__ Wm, const float* __restrict__ t,
-                                                          const float* __restrict__ logs, const float* __restrict__ winv,
-                                                          const float* __restrict__ Gsum, float hw, float* __restrict__ gNN,
-                                                          float* __restrict__ gt, float* __restrict__ glogs, int C) {
+// blockIdx.x = flow step of a batch (cf_step_param_grads_batch)
+constexpr int kParamBatch = 8;
+struct StepParamBatch {
+    const float *gWp[kParamBatch], *gbp[kParamBatch], *Wm[kParamBatch], *t[kParamBatch], *logs[kParamBatch], *winv[kParamBatch];
+    float *gNN[kParamBatch], *gt[kParamBatch], *glogs[kParamBatch];
+};
+__global__ __launch_bounds__(256) void k_step_param_grads(const StepParamBatch pb, const float* __restrict__ Gsum, float hw, int C) {
+    const int bi = blockIdx.x;
+    const float* __restrict__ gWp = pb.gWp[bi]; const float* __restrict__ gbp = pb.gbp[bi]; const float* __restrict__ Wm = pb.Wm[bi];
+    const float* __restrict__ t = pb.t[bi]; const float* __restrict__ logs = pb.logs[bi]; const float* __restrict__ winv = pb.winv[bi];
+    float* __restrict__ gNN = pb.gNN[bi]; float* __restrict__ gt = pb.gt[bi]; float* __restrict__ glogs = pb.glogs[bi];
     const float G = Gsum[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int e = tid; e < C * C; e += 256) {
@@ -338,12 +344,34 @@ int cf_channel_sums(const float* a, const float* b2, float* out, void* ws, int B
     return 0;
 }
 
+int cf_step_param_grads_batch(int n, const float* const* gWp, const float* const* gbp, const float* const* Wm, const float* const* t,
+                              const float* const* logs, const float* const* winv, const float* gld_sum, int HW, float* const* gNN,
+                              float* const* gt, float* const* glogs, int C, cf_stream_t stream);
+
 int cf_step_param_grads(const float* gWp, const float* gbp, const float* Wm, const float* t, const float* logs,
                         const float* winv, const float* gld_sum, int HW, float* gNN, float* gt, float* glogs, int C,
                         cf_stream_t stream) {
     CF_REQUIRE(gWp && gbp && Wm && t && logs && winv && gld_sum && gNN && gt && glogs && C > 0 && HW > 0);
-    k_step_param_grads<<<dim3(1), dim3(256), 0, cf_s(stream)>>>(gWp, gbp, Wm, t, logs, winv, gld_sum, (float)HW, gNN, gt, glogs, C);
-    CF_LAUNCH_CHECK();
+    return cf_step_param_grads_batch(1, &gWp, &gbp, &Wm, &t, &logs, &winv, gld_sum, HW, &gNN, &gt, &glogs, C, stream);
+}
+
+// the parameter chains of n flow steps of one width in one launch (workgroup = step); gld_sum is shared by the steps
+int cf_step_param_grads_batch(int n, const float* const* gWp, const float* const* gbp, const float* const* Wm, const float* const* t,
+                              const float* const* logs, const float* const* winv, const float* gld_sum, int HW, float* const* gNN,
+                              float* const* gt, float* const* glogs, int C, cf_stream_t stream) {
+    CF_REQUIRE(n >= 0 && gWp && gbp && Wm && t && logs && winv && gld_sum && gNN && gt && glogs && C > 0 && HW > 0);
+    for (int i0 = 0; i0 < n; i0 += kParamBatch) {
+        const int m = n - i0 < kParamBatch ? n - i0 : kParamBatch;
+        StepParamBatch pb{};
+        for (int i = 0; i < m; ++i) {
+            const int j = i0 + i;
+            CF_REQUIRE(gWp[j] && gbp[j] && Wm[j] && t[j] && logs[j] && winv[j] && gNN[j] && gt[j] && glogs[j]);
+            pb.gWp[i] = gWp[j]; pb.gbp[i] = gbp[j]; pb.Wm[i] = Wm[j]; pb.t[i] = t[j]; pb.logs[i] = logs[j]; pb.winv[i] = winv[j];
+            pb.gNN[i] = gNN[j]; pb.gt[i] = gt[j]; pb.glogs[i] = glogs[j];
+        }
+        k_step_param_grads<<<dim3(m), dim3(256), 0, cf_s(stream)>>>(pb, gld_sum, (float)HW, C);
+        CF_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -247,9 +247,14 @@ __device__ __forceinline__ void ww_output(const float (&m)[16], float (&o)[9]) {
 }
 
 // NT = 32-column tiles of Bm (1, 2 or 4); the 4 waves split (column tile) x (K quarter): KW = 4 / NT
+// blockIdx.z = flow step of a batch (cf_step_wgrads_batch: the steps of one resolution level in one launch per product)
+constexpr int kWgBatch = 8;
+struct WgBatch { const float* A[kWgBatch]; const float* Bm[kWgBatch]; float* part[kWgBatch]; };
+
 template <int H, int W, int TAPS, int NT, bool WINO = false>
-__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, const float* __restrict__ Bm,
-                                               float* __restrict__ part, int B, int MR, int NR, int64_t bsB, int sqB) {
+__global__ __launch_bounds__(256) void k_wgrad(const WgBatch wb, int B, int MR, int NR, int64_t bsB, int sqB) {
+    const float* __restrict__ A = wb.A[blockIdx.z]; const float* __restrict__ Bm = wb.Bm[blockIdx.z];
+    float* __restrict__ part = wb.part[blockIdx.z];
     constexpr int HW = H * W;
     constexpr int KC = HW >= 64 ? HW : 64;            // pixels per chunk (whole samples)
     constexpr int SPC = KC / HW;                      // samples per chunk
@@ -493,9 +498,10 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, cons
 __device__ __forceinline__ float wg_f4e(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 template <int RT, int CT, bool SQB, int NF>
-__global__ __launch_bounds__(256) void k_wgrad1x1(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                  float* __restrict__ part, int MR, int NR, int HW, int W, int64_t bsB,
+__global__ __launch_bounds__(256) void k_wgrad1x1(const WgBatch wb, int MR, int NR, int HW, int W, int64_t bsB,
                                                   int Q, int qper, int nsplit) {
+    const float* __restrict__ A = wb.A[blockIdx.z]; const float* __restrict__ Bm = wb.Bm[blockIdx.z];
+    float* __restrict__ part = wb.part[blockIdx.z];
     // NF = float4 per lane, row and unit: a unit is 16 NF pixels, of which lane group kk takes the 4 NF consecutive ones from
     // 4 NF kk - with NF = 2 the four lane groups of a row read 128 contiguous bytes (whole cache lines; 16x16 / 8x8 images)
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -656,8 +662,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 // the same sum for up to four problems in one launch (blockIdx.y = problem): the four weight gradients of a flow step
 struct WgReduce4 { const float* part[4]; float* out0[4]; float* out1[4]; int n0[4], n[4], S[4], taps[4]; };   // taps > 1: out0 as [m][n][tap]
-__global__ __launch_bounds__(256) void k_wgrad_reduce4(WgReduce4 d) {
+struct WgReduce4B { WgReduce4 d[kWgBatch]; };         // blockIdx.z = flow step
+__global__ __launch_bounds__(256) void k_wgrad_reduce4(const WgReduce4B db) {
     __shared__ float red[4][64];
+    const WgReduce4& d = db.d[blockIdx.z];
     const int q = blockIdx.y;
     const float* __restrict__ part = d.part[q];
     const int n = d.n[q], n0 = d.n0[q], S = d.S[q];
@@ -693,6 +701,16 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4(WgReduce4 d) {
 // cf_step_wgrads: the k_wgrad launches leave their partials in place and report their split count; one reduce follows
 static thread_local bool g_wgrad_defer = false;
 static thread_local int g_wgrad_last_S = 0;
+// cf_step_wgrads_batch: the launch covers g_wgrad_nb steps whose operands are g_wgrad_batch's (the pointer arguments of the
+// launchers are step 0's then)
+static thread_local const WgBatch* g_wgrad_batch = nullptr;
+static thread_local int g_wgrad_nb = 1;
+inline WgBatch wg_batch(const float* A, const float* Bm, float* part) {
+    if (g_wgrad_batch) return *g_wgrad_batch;
+    WgBatch wb{};
+    wb.A[0] = A; wb.Bm[0] = Bm; wb.part[0] = part;
+    return wb;
+}
 
 // wgs = workgroups to aim for: 512 (two per CU in flight) for the direct forms; the Winograd form runs one workgroup per
 // CU (512 registers per lane), so 256 - one round, one epilogue per CU
@@ -724,10 +742,11 @@ inline bool wgrad1x1_ok(int MR, int NR, int HW) {
 template <int RT, int CT, int NF>
 int launch_wgrad1x1(const float* A, const float* Bm, float* ws, int MR, int NR, int HW, int W, int64_t bsB, int sqB, int Q,
                     int qper, int nsplit, hipStream_t s) {
-    const dim3 grid(nsplit), blk(256);
+    const dim3 grid(nsplit, 1, g_wgrad_nb), blk(256);
     const size_t lds = (size_t)(RT * CT * 4 + RT) * 64 * sizeof(float);          // <= 33 KB
-    if (sqB) k_wgrad1x1<RT, CT, true, NF><<<grid, blk, lds, s>>>(A, Bm, ws, MR, NR, HW, W, bsB, Q, qper, nsplit);
-    else k_wgrad1x1<RT, CT, false, NF><<<grid, blk, lds, s>>>(A, Bm, ws, MR, NR, HW, W, bsB, Q, qper, nsplit);
+    const WgBatch wb = wg_batch(A, Bm, ws);
+    if (sqB) k_wgrad1x1<RT, CT, true, NF><<<grid, blk, lds, s>>>(wb, MR, NR, HW, W, bsB, Q, qper, nsplit);
+    else k_wgrad1x1<RT, CT, false, NF><<<grid, blk, lds, s>>>(wb, MR, NR, HW, W, bsB, Q, qper, nsplit);
     return 0;
 }
 
@@ -746,7 +765,7 @@ int launch_wgrad(const float* A, const float* Bm, float* gw, float* gbias, float
     const int splits = wgrad_splits(B, MR, HW, WINO ? 256 : 512);
     const int S = splits, nw = TAPS * MR * NR;
     // partials: [S][TAPS*MR*NR + MR] (weights | bias of one split contiguous: ONE reduce launch)
-    k_wgrad<H, W, TAPS, NT, WINO><<<dim3(mtiles, splits), dim3(256), lds, s>>>(A, Bm, ws, B, MR, NR, bsB, sqB);
+    k_wgrad<H, W, TAPS, NT, WINO><<<dim3(mtiles, splits, g_wgrad_nb), dim3(256), lds, s>>>(wg_batch(A, Bm, ws), B, MR, NR, bsB, sqB);
     g_wgrad_last_S = S;
     if (!g_wgrad_defer) k_wgrad_reduce<<<dim3((nw + MR + 63) / 64), dim3(256), 0, s>>>(ws, gw, gbias, nw, nw + MR, S);
     return 0;
@@ -848,36 +867,86 @@ int64_t cf_step_wgrads_ws_bytes(int B, int C, int H, int W) {
            cf_wgrad_ws_bytes(B, HID, HALF, H, W, 1) + cf_wgrad_ws_bytes(B, C, C, H, W, 1);
 }
 
+// n steps of one shape: per product ONE launch over all steps (blockIdx.z) - the Conv1x1 product once per (stride, layout) of
+// the step inputs: the first step of a level reads the tensor in front of its Squeeze - and ONE reduce launch.  Each step's
+// workspace is laid out as cf_step_wgrads' (cf_step_wgrads_ws_bytes); results bit for bit those of n cf_step_wgrads calls.
+static int step_wgrads_impl(int n, const float* const* s_gh, const float* const* s_gh2, const float* const* s_gh1,
+                            const float* const* s_gy, const float* const* t_h2, const float* const* t_h1, const float* const* t_y0,
+                            const float* const* xs, float* const* gw3, float* const* gb3, float* const* gw2, float* const* gb2,
+                            float* const* gw1, float* const* gb1, float* const* gwp, float* const* gbp, void* const* ws, int B, int C,
+                            int H, int W, const int64_t* xs_bstride, const int* xs_unsqueezed, cf_stream_t stream) {
+    if (B == 0 || n == 0) return 0;
+    CF_REQUIRE(n > 0 && n <= kWgBatch && C >= 2 && C % 2 == 0 && 2 * C <= 128);
+    const int HID = 2 * C, HALF = C / 2;
+    const float* const* As[4] = {s_gh, s_gh2, s_gh1, s_gy};
+    const float* const* Bs[4] = {t_h2, t_h1, t_y0, xs};
+    float* const* gws[4] = {gw3, gw2, gw1, gwp};
+    float* const* gbs[4] = {gb3, gb2, gb1, gbp};
+    const int MRs[4] = {C, HID, HID, C}, NRs[4] = {HID, HID, HALF, C}, tps[4] = {1, 9, 1, 1};
+    for (int i = 0; i < n; ++i)
+        for (int q = 0; q < 4; ++q) CF_REQUIRE(As[q][i] && Bs[q][i] && gws[q][i] && gbs[q][i] && ws[i]);
+    WgReduce4B db{};
+    int64_t woff = 0;
+    int nmax = 0;
+    for (int q = 0; q < 4; ++q) {
+        // steps that share the operand layout of this product go into one launch
+        bool done[kWgBatch] = {};
+        for (int i0 = 0; i0 < n; ++i0) {
+            if (done[i0]) continue;
+            WgBatch wb{};
+            int idx[kWgBatch], m = 0;
+            for (int i = i0; i < n; ++i) {
+                if (done[i] || (q == 3 && (xs_bstride[i] != xs_bstride[i0] || (xs_unsqueezed[i] != 0) != (xs_unsqueezed[i0] != 0)))) continue;
+                // (alignment decides the kernel inside wgrad_impl: only steps whose operands agree with the leader's share a launch)
+                if ((((reinterpret_cast<uintptr_t>(As[q][i]) | reinterpret_cast<uintptr_t>(Bs[q][i])) & 15) == 0) !=
+                    (((reinterpret_cast<uintptr_t>(As[q][i0]) | reinterpret_cast<uintptr_t>(Bs[q][i0])) & 15) == 0)) continue;
+                done[i] = true; idx[m] = i;
+                wb.A[m] = As[q][i]; wb.Bm[m] = Bs[q][i]; wb.part[m] = (float*)((char*)ws[i] + woff);
+                ++m;
+            }
+            g_wgrad_defer = true; g_wgrad_batch = &wb; g_wgrad_nb = m;
+            const int rc = wgrad_impl(wb.A[0], wb.Bm[0], gws[q][idx[0]], gbs[q][idx[0]], wb.part[0], B, MRs[q], NRs[q], H, W, tps[q],
+                                      q == 3 ? xs_bstride[i0] : (int64_t)NRs[q] * H * W, q == 3 && xs_unsqueezed[i0] != 0, stream);
+            g_wgrad_defer = false; g_wgrad_batch = nullptr; g_wgrad_nb = 1;
+            if (rc) return rc;
+            const int nw = tps[q] * MRs[q] * NRs[q];
+            for (int j = 0; j < m; ++j) {
+                WgReduce4& d = db.d[idx[j]];
+                d.part[q] = wb.part[j]; d.out0[q] = gws[q][idx[j]]; d.out1[q] = gbs[q][idx[j]];
+                d.n0[q] = nw; d.n[q] = nw + MRs[q]; d.S[q] = g_wgrad_last_S; d.taps[q] = tps[q];
+            }
+            nmax = nw + MRs[q] > nmax ? nw + MRs[q] : nmax;
+        }
+        woff += cf_wgrad_ws_bytes(B, MRs[q], NRs[q], H, W, tps[q]);
+    }
+    k_wgrad_reduce4<<<dim3((nmax + 63) / 64, 4, n), dim3(256), 0, cf_s(stream)>>>(db);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
 int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, const float* s_gy, const float* t_h2,
                    const float* t_h1, const float* t_y0, const float* xs, float* gw3, float* gb3, float* gw2, float* gb2,
                    float* gw1, float* gb1, float* gwp, float* gbp, void* ws, int B, int C, int H, int W, int64_t xs_bstride,
                    int xs_unsqueezed, cf_stream_t stream) {
     if (B == 0) return 0;
     CF_REQUIRE(s_gh && s_gh2 && s_gh1 && s_gy && t_h2 && t_h1 && t_y0 && xs && gw3 && gb3 && gw2 && gb2 && gw1 && gb1 && gwp && gbp && ws);
-    CF_REQUIRE(C >= 2 && C % 2 == 0 && 2 * C <= 128);
-    const int HID = 2 * C, HALF = C / 2;
-    const float* As[4] = {s_gh, s_gh2, s_gh1, s_gy};
-    const float* Bs[4] = {t_h2, t_h1, t_y0, xs};
-    float* gws[4] = {gw3, gw2, gw1, gwp};
-    float* gbs[4] = {gb3, gb2, gb1, gbp};
-    const int MRs[4] = {C, HID, HID, C}, NRs[4] = {HID, HID, HALF, C}, tps[4] = {1, 9, 1, 1};
-    WgReduce4 d;
-    char* w = (char*)ws;
-    int nmax = 0;
-    for (int q = 0; q < 4; ++q) {
-        g_wgrad_defer = true;
-        const int rc = q == 3 ? wgrad_impl(As[q], Bs[q], gws[q], gbs[q], w, B, MRs[q], NRs[q], H, W, tps[q], xs_bstride, xs_unsqueezed != 0, stream)
-                              : cf_wgrad(As[q], Bs[q], gws[q], gbs[q], w, B, MRs[q], NRs[q], H, W, tps[q], stream);
-        g_wgrad_defer = false;
-        if (rc) return rc;
-        const int nw = tps[q] * MRs[q] * NRs[q];
-        d.part[q] = (const float*)w; d.out0[q] = gws[q]; d.out1[q] = gbs[q];
-        d.n0[q] = nw; d.n[q] = nw + MRs[q]; d.S[q] = g_wgrad_last_S; d.taps[q] = tps[q];
-        nmax = nw + MRs[q] > nmax ? nw + MRs[q] : nmax;
-        w += cf_wgrad_ws_bytes(B, MRs[q], NRs[q], H, W, tps[q]);
+    return step_wgrads_impl(1, &s_gh, &s_gh2, &s_gh1, &s_gy, &t_h2, &t_h1, &t_y0, &xs, &gw3, &gb3, &gw2, &gb2, &gw1, &gb1, &gwp, &gbp,
+                            &ws, B, C, H, W, &xs_bstride, &xs_unsqueezed, stream);
+}
+
+int cf_step_wgrads_batch(int n, const float* const* s_gh, const float* const* s_gh2, const float* const* s_gh1,
+                         const float* const* s_gy, const float* const* t_h2, const float* const* t_h1, const float* const* t_y0,
+                         const float* const* xs, float* const* gw3, float* const* gb3, float* const* gw2, float* const* gb2,
+                         float* const* gw1, float* const* gb1, float* const* gwp, float* const* gbp, void* const* ws, int B, int C,
+                         int H, int W, const int64_t* xs_bstride, const int* xs_unsqueezed, cf_stream_t stream) {
+    CF_REQUIRE(n >= 0 && s_gh && s_gh2 && s_gh1 && s_gy && t_h2 && t_h1 && t_y0 && xs && gw3 && gb3 && gw2 && gb2 && gw1 && gb1 && gwp &&
+               gbp && ws && xs_bstride && xs_unsqueezed);
+    for (int i0 = 0; i0 < n; i0 += kWgBatch) {
+        const int m = n - i0 < kWgBatch ? n - i0 : kWgBatch;
+        if (int rc = step_wgrads_impl(m, s_gh + i0, s_gh2 + i0, s_gh1 + i0, s_gy + i0, t_h2 + i0, t_h1 + i0, t_y0 + i0, xs + i0, gw3 + i0,
+                                      gb3 + i0, gw2 + i0, gb2 + i0, gw1 + i0, gb1 + i0, gwp + i0, gbp + i0, ws + i0, B, C, H, W,
+                                      xs_bstride + i0, xs_unsqueezed + i0, stream)) return rc;
     }
-    k_wgrad_reduce4<<<dim3((nmax + 63) / 64, 4), dim3(256), 0, cf_s(stream)>>>(d);
-    CF_LAUNCH_CHECK();
     return 0;
 }
 

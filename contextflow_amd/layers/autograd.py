@@ -21,8 +21,36 @@ from .autograd_layers import layer_backward
 from .squeeze import squeeze_op
 
 
+
+def _param_part_on(side, keep, alive, fn, defer, dev):
+    """Run fn() - the parameter half of a record's backward - on the stream `side`, behind what the current stream has been
+    given so far; `alive` (what it reads) goes to `keep`.  With `defer` (a list) the launch is POSTPONED: a thunk that does it
+    is appended and None returned - the caller runs the thunk once it has issued the next record's kernels on the main
+    stream.  (A captured HIP graph runs its nodes on a few hardware queues in creation order, and a node that waits for a node of
+    another queue waits for everything created on that queue before the waiter: created right behind its backward kernel, a
+    step's weight-gradient chain held up the NEXT step's backward kernel - tools/dev/step_timeline.py.)"""
+    import contextlib
+    if side is None:
+        return fn()
+    main = torch.cuda.current_stream(dev)
+    keep.append(alive)
+    if defer is None:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            return fn()
+    ev = torch.cuda.Event()
+    ev.record(main)
+
+    def thunk():
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            return fn()
+    defer.append(thunk)
+    return None
+
+
 # ------------------------------------------------------------------------------------------------ GMM prior
-def gmm_backward(x, dist, prepared, g, gcol=None, side=None, keep=None, sink=None):
+def gmm_backward(x, dist, prepared, g, gcol=None, side=None, keep=None, sink=None, defer=None):
     """x: (B, D...) possibly a channel slice; g: (B, M) upstream; gcol: its column sums (M,) if the caller has them (the
     priors of one backward pass share g).  Returns (gx like x, {param: grad})."""
     a, nm, cst, M, K, D = prepared
@@ -47,12 +75,8 @@ def gmm_backward(x, dist, prepared, g, gcol=None, side=None, keep=None, sink=Non
     # parameter sums over the batch: S1 = r^T x, S2 = r^T x^2 (MK x D) and S0 = column sums of r, as split-K MFMA GEMMs
     # over the samples (cf_linear_wgrad: the bias-gradient column gives S0; x is squared while it is staged for S2)
     # (small batches: on the side stream - the chain to the previous layer needs gx only)
-    import contextlib
-    if side is not None:
-        side.wait_stream(torch.cuda.current_stream(dev))
-        keep.append((xv, r, a, nm, gcol))
-    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        return gx.view(xv.shape), _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev, sink)
+    return gx.view(xv.shape), _param_part_on(side, keep, (xv, r, a, nm, gcol),
+                                             lambda: _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev, sink), defer, dev)
 
 
 def _out(sink, p, shape, dev):
@@ -92,10 +116,12 @@ def _gmm_param_part(xv, xbs, r, dist, a, nm, g, gcol, B, M, K, D, dev, sink=None
 # ------------------------------------------------------------------------------------------------ flow step
 WGRAD_SIDE_MAX_BATCH = 1024      # below: the weight gradients of a step run on a side stream, next to the data-gradient chain
 WGRAD_SIDE_STREAMS = int(__import__("os").environ.get("CONTEXTFLOW_WGRAD_STREAMS", "4"))
+WGRAD_DEFER = __import__("os").environ.get("CONTEXTFLOW_WGRAD_DEFER", "0") == "1"    # see _param_part_on (measured: slower)
+WGRAD_BATCH = __import__("os").environ.get("CONTEXTFLOW_WGRAD_BATCH", "1") == "1"    # see _step_param_part_batch
 
 
 def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, planes=None, gsum=None, side=None, keep=None, wsb=None,
-                  sink=None):
+                  sink=None, defer=None, collect=None):
     """x: saved step input (un-squeezed when `squeeze`), gz: dL/dz (B,C,H,W), gld: dL/d(ld1) (B,).
     planes: the step tape (y0, h1, h2, aux) written by cf_flow_step_fwd_taped, or None = rebuild it from x with the same kernel.
     gsum: 1-element tensor sum(gld) (the same for every step of a backward pass), or None.
@@ -139,13 +165,15 @@ def step_backward(x, squeeze, conv, act, cpl, shape, ws, gz, gld, winv=None, pla
               pp(s_gy), B, C, H, W, int(bool(squeeze)), st)
     # ---- weight gradients: split-K MFMA GEMMs over (batch, pixel) with the 3x3 tap shifts, the four of a step in one call
     # (cf_step_wgrads: four k_wgrad launches, ONE reduce launch)
-    import contextlib
-    if side is not None:
-        side.wait_stream(torch.cuda.current_stream(dev))
-        keep.append((s_gh, s_gh2, s_gh1, s_gy, planes, xv, wsb, gzc, winv, gsum))
-    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        return gx, _step_param_part(conv, act, cpl, (C, H, W), xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1, s_y0,
-                                    Wm, t, logs, winv, gsum, gld, B, dev, sink)
+    if collect is not None:
+        # small batches: the parameter halves of the steps of a resolution level are launched TOGETHER once the level's
+        # backward kernels are in the queue (_step_param_part_batch); what they read travels in `collect`
+        collect.append((conv, act, cpl, (C, H, W), xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1, s_y0, Wm, t, logs, winv,
+                        (planes, wsb, gzc)))
+        return gx, None
+    return gx, _param_part_on(side, keep, (s_gh, s_gh2, s_gh1, s_gy, planes, xv, wsb, gzc, winv, gsum),
+                              lambda: _step_param_part(conv, act, cpl, (C, H, W), xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1,
+                                                       s_y0, Wm, t, logs, winv, gsum, gld, B, dev, sink), defer, dev)
 
 
 def _step_param_part(conv, act, cpl, shape, xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1, s_y0, Wm, t, logs, winv, gsum,
@@ -186,6 +214,59 @@ def _step_param_part(conv, act, cpl, shape, xv, xbs, squeeze, s_gh, s_gh2, s_gh1
     return grads
 
 
+
+def _step_param_part_batch(items, gsum, gld, B, dev, sink=None):
+    """_step_param_part for the n steps of one shape in 6 - 7 launches instead of 6 n (cf_step_wgrads_batch: one launch per
+    product over all steps + one reduce; cf_step_param_grads_batch: one workgroup per step): at the reference's batch of 256
+    the parameter work of a backward pass is latency, not arithmetic.  Same kernels on the same operands: bitwise equal.
+    items: what step_backward collected.  Returns one {param: grad} per item."""
+    import ctypes
+    L = _hip.lib()
+    f, pp, st, A = _hip.f32, _hip.p, _hip.stream(), _hip.ptr_array
+    C, H, W = items[0][3]
+    HW, HALF, HID = H * W, C // 2, 2 * C
+    e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)
+    o = lambda p, *sh: _out(sink, p, sh, dev)
+    n = len(items)
+    outs = []
+    for (conv, act, cpl, _, xv, xbs, squeeze, s_gh, s_gh2, s_gh1, s_gy, s_h2, s_h1, s_y0, Wm, t, logs, winv, _alive) in items:
+        c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
+        outs.append(dict(gw3=o(c3.weight, 1, C, HID), gb3=o(c3.bias, C), gw2=o(c2.weight, HID, HID, 3, 3), gb2=o(c2.bias, HID),
+                         gw1=o(c1.weight, 1, HID, HALF), gb1=o(c1.bias, HID), gWp=e(1, C, C), gbp=e(C),
+                         gNN=o(conv.NN, C, C), gt=o(act.NN_t, C), glogs=o(act.NN_logs, C),
+                         wsw=torch.empty(L.cf_step_wgrads_ws_bytes(B, C, H, W), device=dev, dtype=torch.uint8)))
+    col = lambda k: [it[k] for it in items]
+    oc = lambda k: [d[k] for d in outs]
+    xbs_arr = (ctypes.c_int64 * n)(*[int(it[5]) for it in items])
+    sq_arr = (ctypes.c_int * n)(*[int(bool(it[6])) for it in items])
+    _hip.call("cf_step_wgrads_batch", n, A(col(7)), A(col(8)), A(col(9)), A(col(10)), A(col(11)), A(col(12)), A(col(13)), A(col(4)),
+              A(oc("gw3")), A(oc("gb3")), A(oc("gw2")), A(oc("gb2")), A(oc("gw1")), A(oc("gb1")), A(oc("gWp")), A(oc("gbp")),
+              A(oc("wsw")), B, C, H, W, ctypes.cast(xbs_arr, ctypes.c_void_p), ctypes.cast(sq_arr, ctypes.c_void_p), st)
+    if gsum is None:
+        gsum = gld.sum().reshape(1)
+    winvs = []
+    for it in items:
+        winv = it[17]
+        if winv is None:
+            lad = torch.empty(1, device=dev, dtype=torch.float32)
+            winv = torch.empty(C, C, device=dev, dtype=torch.float32)
+            _hip.call("cf_slogdet_inverse", pp(it[14]), C, pp(lad), pp(winv), st)
+        winvs.append(f(winv))
+    _hip.call("cf_step_param_grads_batch", n, A(oc("gWp")), A(oc("gbp")), A(col(14)), A(col(15)), A(col(16)), A(winvs), pp(f(gsum)), HW,
+              A(oc("gNN")), A(oc("gt")), A(oc("glogs")), C, st)
+    res = []
+    for it, d in zip(items, outs):
+        conv, act, cpl = it[0], it[1], it[2]
+        c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
+        res.append({
+            conv.NN: d["gNN"].view_as(conv.NN), act.NN_t: d["gt"].view_as(act.NN_t), act.NN_logs: d["glogs"].view_as(act.NN_logs),
+            c1.weight: d["gw1"][0].reshape(c1.weight.shape), c1.bias: d["gb1"],
+            c2.weight: d["gw2"], c2.bias: d["gb2"],
+            c3.weight: d["gw3"][0].reshape(c3.weight.shape), c3.bias: d["gb3"],
+        })
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ transformer flow step
 def wgrad_group(members, dev, dests=None):
     """members: [(x (rows, K), gy (rows, N), has_bias)], all dense fp32 on `dev`.  One cf_linear_wgrad_group launch pair;
@@ -217,7 +298,8 @@ def wgrad_group(members, dev, dests=None):
     return res
 
 
-def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, side=None, keep=None, sink=None, winv=None, wsb=None):
+def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, side=None, keep=None, sink=None, winv=None, wsb=None,
+                   defer=None):
     """Conv1x1 -> ActNorm -> TransCoupling (one fused step of the transformer flows) backwards: ONE kernel re-runs the step
     from its input and walks back (cf_vit_step_bwd), ONE grouped launch contracts the 26 weight-gradient operand pairs it
     leaves (cf_linear_wgrad_group), the LayerNorm gradients are column sums of its per-workgroup partials, and the Conv1x1 /
@@ -248,13 +330,10 @@ def vstep_backward(x, conv, act, cpl, gz, gld, gsum=None, ws=None, xtape=None, s
                   depth, xbs, st)
     # ---- weight gradients: the planes as (rows, width) matrices (layout: include/contextflow_hip.h, cf_vit_step_bwd)
     # (small batches: on the side stream, as in step_backward)
-    import contextlib
-    if side is not None:
-        side.wait_stream(torch.cuda.current_stream(dev))
-        keep.append((planes, lnp, xv, ws, wsb, gsum, winv))
-    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        return gx, _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, xv.shape[2] * xv.shape[3], Wm, t, logs, gsum,
-                                     gld, dev, sink, winv)
+    HWv = xv.shape[2] * xv.shape[3]
+    return gx, _param_part_on(side, keep, (planes, lnp, xv, ws, wsb, gsum, winv),
+                              lambda: _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HWv, Wm, t, logs, gsum, gld, dev,
+                                                        sink, winv), defer, dev)
 
 
 def _vstep_param_part(conv, act, cpl, vit, depth, planes, lnp, nwg, C, HW, Wm, t, logs, gsum, gld, dev, sink=None, winv=None):
@@ -374,7 +453,7 @@ class FlowLogProb(torch.autograd.Function):
         side, owner = None, {}
         keep = []
 
-        def add_on(d, ri):           # parameter gradients produced on a side stream are accumulated there
+        def add_on(d, ri, side):     # parameter gradients produced on a side stream are accumulated there
             import contextlib
             with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
                 if side is not None:
@@ -395,31 +474,65 @@ class FlowLogProb(torch.autograd.Function):
                         red.wait_stream(s_)
                     flush(seg_done)
         gz, turn = None, -1
+        held = []                    # [(thunk, record index, side)]: the previous record's parameter half, not launched yet
+        group, group_ri, group_side = [], [], None      # the steps of the current resolution level (WGRAD_BATCH)
+
+        def run_pending():
+            while held:
+                thunk, ri_p, side_p = held.pop(0)
+                add_on(thunk(), ri_p, side_p)
+
+        def finish(gp, ri, defer):
+            """this record's kernels of the data-gradient chain are in the queue: launch the previous record's parameter half,
+            then hold this one's back in turn (WGRAD_DEFER) or account for its gradients at once"""
+            run_pending()
+            if defer:
+                held.append((defer[0], ri, side))
+            else:
+                add_on(gp, ri, side)
         for ri in range(len(tape) - 1, -1, -1):
             rec = tape[ri]
             kind = rec[0]
             if sides and kind in ("prior", "split", "step", "vstep"):
                 turn += 1
                 side = sides[turn % len(sides)]
+            defer = [] if (sides and WGRAD_DEFER) else None
             if kind == "prior":
                 _, xin, dist, prep = rec
-                gz, gp = gmm_backward(xin, dist, prep, glogp, gcol, side, keep, sink)
-                add_on(gp, ri)
+                gz, gp = gmm_backward(xin, dist, prep, glogp, gcol, side, keep, sink, defer)
+                finish(gp, ri, defer)
             elif kind == "split":
                 _, xin, dist, prep = rec                      # xin: full tensor before the split
                 c = xin.shape[1] // 2
-                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp, gcol, side, keep, sink)
-                add_on(gp, ri)
+                g2, gp = gmm_backward(xin[:, c:], dist, prep, glogp, gcol, side, keep, sink, defer)
                 gz = torch.cat([gz, g2], dim=1)
+                finish(gp, ri, defer)
             elif kind == "step":
                 _, xin, sq, conv, act, cpl, shape, ws, winv, planes, wsb = rec
-                gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, side, keep, wsb, sink)
-                add_on(gp, ri)
+                if sides and WGRAD_BATCH:
+                    # the level's steps share ONE side stream and ONE set of batched launches, issued behind its last backward kernel
+                    if not group:
+                        group_side = side
+                    gz, _ = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, None, None, wsb, sink,
+                                          None, group)
+                    group_ri.append(ri)
+                    nxt = tape[ri - 1] if ri > 0 else None
+                    if nxt is None or nxt[0] != "step" or tuple(nxt[6]) != tuple(shape):
+                        run_pending()
+                        items, ris = list(group), list(group_ri)
+                        del group[:], group_ri[:]
+                        gps = _param_part_on(group_side, keep, items, lambda: _step_param_part_batch(items, gsum, gld, B0, dev, sink),
+                                             None, dev)
+                        for gp_i, ri_i in zip(gps, ris):
+                            add_on(gp_i, ri_i, group_side)
+                else:
+                    gz, gp = step_backward(xin, sq, conv, act, cpl, shape, ws, gz, gld, winv, planes, gsum, side, keep, wsb, sink, defer)
+                    finish(gp, ri, defer)
             elif kind == "vstep":
                 _, xin, conv, act, cpl, ws_rs, xtape = rec[:7]
                 winv_v, wsb_v = rec[7:9] if len(rec) >= 9 else (None, None)
-                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape, side, keep, sink, winv_v, wsb_v)
-                add_on(gp, ri)
+                gz, gp = vstep_backward(xin, conv, act, cpl, gz, gld, gsum, ws_rs, xtape, side, keep, sink, winv_v, wsb_v, defer)
+                finish(gp, ri, defer)
             elif kind == "squeeze":
                 gz = squeeze_op(gz, rec[1], True)
             elif kind == "pre":
@@ -427,11 +540,13 @@ class FlowLogProb(torch.autograd.Function):
             elif kind == "layer":
                 _, mod, xin = rec
                 gz, gp = layer_backward(mod, xin, gz, gld)
+                run_pending()
                 add(gp)
                 if bucket is not None:
                     flush(bucket.closes.get(ri, ()))
             else:
                 raise NotImplementedError("no backward for tape record %r" % (kind,))
+        run_pending()
         if sides:
             main = torch.cuda.current_stream(dev)
             for s_ in sides:

@@ -373,28 +373,37 @@ class FlowSequential(nn.Module):
                 for k, op, ver in todo:
                     if op[0] == "step":
                         groups.setdefault(tuple(op[4]), []).append((k, op, ver))
-                done = {}
+                # (one event per group, recorded right behind its launches: the first level's steps start as soon as THEIR
+                # tables exist - the 64-channel factorisation alone takes 50 us - instead of behind every table of the flow)
+                done, done_ev = {}, {}
                 for shape, items in groups.items():
                     bufs = self._prepare_steps([(it[1][1], it[1][2], it[1][3]) for it in items], shape, dev, train=tape is not None)
+                    gev = torch.cuda.Event()
+                    gev.record(side)
                     for (k, op, ver), buf in zip(items, bufs):
                         done[k] = buf
+                        done_ev[k] = gev
                 # transformer steps at small batches: the row-split tables of all steps in one launch triple (training: with
                 # Wm^-1 and the backward kernel's tables) - cf_vit_step_rs_prepare_batch
                 vitems = [(k, op, ver) for k, op, ver in todo if op[0] == "vstep" and vkey[k] == "rs"]
                 if vitems:
                     bufs = TransCoupling.step_prepare_rs_batch([(it[1][3], it[1][1].NN, it[1][2].NN_t, it[1][2].NN_logs) for it in vitems], dev,
                                                                train=tape is not None)
+                    gev = torch.cuda.Event()
+                    gev.record(side)
                     for (k, op, ver), buf in zip(vitems, bufs):
                         done[k] = buf
+                        done_ev[k] = gev
                 for k, op, ver in todo:
                     if k in done:
-                        buf = done[k]
-                    elif op[0] == "vstep":
-                        buf = op[3].step_prepare(op[1].NN, op[2].NN_t, op[2].NN_logs, dev, vkey[k])
+                        buf, ev = done[k], done_ev[k]
                     else:
-                        buf = op[1].dist.prepared()
-                    ev = torch.cuda.Event()
-                    ev.record(side)
+                        if op[0] == "vstep":
+                            buf = op[3].step_prepare(op[1].NN, op[2].NN_t, op[2].NN_logs, dev, vkey[k])
+                        else:
+                            buf = op[1].dist.prepared()
+                        ev = torch.cuda.Event()
+                        ev.record(side)
                     prepared[k] = (buf, ev)
                     fresh.add(k)
                     if store_ok:

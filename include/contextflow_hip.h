@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 7
+#define CF_ABI_VERSION 8
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -299,6 +299,12 @@ int cf_flow_step_bwd_taped(const float* gz, const float* gld, const void* wsb, c
 int cf_step_param_grads(const float* gWp, const float* gbp, const float* Wm, const float* t, const float* logs,
                         const float* winv, const float* gld_sum, int HW, float* gNN, float* gt, float* glogs, int C,
                         cf_stream_t stream);
+/* n flow steps of one width (the steps of a resolution level) in ONE launch: every operand is a host array of n device pointers,
+ * gld_sum is shared (small batches: the parameter work of a backward pass is a chain of launches of a few microseconds
+ * each - layers/autograd.py::_step_param_part_batch).  Bitwise equal to n cf_step_param_grads calls.                        */
+int cf_step_param_grads_batch(int n, const float* const* gWp, const float* const* gbp, const float* const* Wm, const float* const* t,
+                              const float* const* logs, const float* const* winv, const float* gld_sum, int HW, float* const* gNN,
+                              float* const* gt, float* const* glogs, int C, cf_stream_t stream);
 
 /* weight gradient as a split-K MFMA GEMM over (sample, pixel):
  *   gw[t][m][n] = sum_{b,p} A[b][m][p] * Bm[b][n][src_t(p)],  t < taps (1, or 9 = 3x3 reflect-shifted pixels)
@@ -323,6 +329,15 @@ int cf_step_wgrads(const float* s_gh, const float* s_gh2, const float* s_gh1, co
                    const float* t_h1, const float* t_y0, const float* xs, float* gw3, float* gb3, float* gw2, float* gb2,
                    float* gw1, float* gb1, float* gwp, float* gbp, void* ws, int B, int C, int H, int W, int64_t xs_bstride,
                    int xs_unsqueezed, cf_stream_t stream);
+/* The same for n flow steps of one shape (host arrays of n device pointers / strides / flags; ws[i]: cf_step_wgrads_ws_bytes
+ * each): per product ONE launch over all steps (the Conv1x1 product once per distinct (xs_bstride, xs_unsqueezed): the first
+ * step of a level reads the tensor in front of its Squeeze) and ONE reduce launch - 5 or 6 launches instead of 5 n.  Bitwise
+ * equal to n cf_step_wgrads calls.                                                                                          */
+int cf_step_wgrads_batch(int n, const float* const* s_gh, const float* const* s_gh2, const float* const* s_gh1,
+                         const float* const* s_gy, const float* const* t_h2, const float* const* t_h1, const float* const* t_y0,
+                         const float* const* xs, float* const* gw3, float* const* gb3, float* const* gw2, float* const* gb2,
+                         float* const* gw1, float* const* gb1, float* const* gwp, float* const* gbp, void* const* ws, int B, int C,
+                         int H, int W, const int64_t* xs_bstride, const int* xs_unsqueezed, cf_stream_t stream);
 
 /* ---- SimpleViT conditioner of TransCoupling (layers/simple_vit.py:18-127, coupling.py:100-159) --- */
 /* y[r,n] = act(sum_k x[r,k] Wt[n,k] + bias[n]) + res[r,n]; fp32 MFMA; bias/res may be NULL; any K, N.

@@ -1440,6 +1440,43 @@ def test_training_steps_reduce_the_loss(L):
     assert losses[-1] < losses[0] - 1e-3, losses
 
 
+@pytest.mark.parametrize("name,data_parallel", [("cifar10", False), ("mnist", False), ("cifar10", True)])
+def test_batched_parameter_work_of_a_level_equals_the_per_step_launches(L, name, data_parallel, monkeypatch):
+    """At small batches the weight gradients and parameter chains of the steps of a resolution level go out in one set of
+    launches (cf_step_wgrads_batch / cf_step_param_grads_batch, blockIdx.z = step) on a side stream, behind the level's last
+    backward kernel: the gradients of every parameter equal those of the per-step launches bit for bit - with the
+    data-parallel bucket as their destination as well."""
+    import contextflow_amd as cfa
+    from contextflow_amd.layers import autograd as ag
+    cfg, ds, M = cfa.preset_config(name)
+    g = torch.Generator().manual_seed(5)
+    B = 48
+    x = torch.randint(0, 256, (B, *ds), generator=g).float().to(DEV)
+    y = torch.randint(0, M, (B,), generator=g).to(DEV)
+    inv = 1.0 / x[0].numel()
+    got = {}
+    for batch in (True, False):
+        monkeypatch.setattr(ag, "WGRAD_BATCH", batch)
+        torch.manual_seed(0)
+        m = cfa.create_model(cfg, ds, M).to(DEV)
+        for q in m.sequence_modules:
+            if isinstance(q, cfa.layers.Dequantization):
+                q.dist.fixed_noise = torch.rand(B, *ds, generator=torch.Generator().manual_seed(9)).to(DEV)
+            if isinstance(q, cfa.layers.Augment):
+                q.distribution.fixed_noise = torch.randn(B, 1, ds[1], ds[2], generator=torch.Generator().manual_seed(10)).to(DEV)
+        with torch.no_grad():
+            m(x)
+        m.train()
+        m.data_parallel = data_parallel
+        torch.nn.functional.cross_entropy(m.log_prob(x) * inv, y).backward()
+        torch.cuda.synchronize()
+        got[batch] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert len(got[True]) == len(got[False]) > 20
+    for k, a in got[True].items():
+        assert torch.isfinite(a).all(), k
+        assert torch.equal(a, got[False][k]), k
+
+
 @pytest.mark.parametrize("name,coupling", [("mnist", "maf"), ("smap", "conv"), ("smap", "maf")])
 def test_training_with_generic_conv_couplings(L, name, coupling):
     """`--coupling maf` (MaskedCoupling, ar.py) and `--coupling conv` on a time-series topology ((3,1) kernels, model.py:114):
