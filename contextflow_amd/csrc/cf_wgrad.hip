@@ -718,6 +718,12 @@ inline int wgrad_splits(int B, int MR, int HW, int wgs = 512) {
     const int KC = HW >= 64 ? HW : 64, SPC = KC / HW;
     const int mtiles = (MR + 31) / 32, nchunks = (B + SPC - 1) / SPC;
     int splits = wgs / mtiles;
+    // small batches: at least CF_WGRAD_MIN_CHUNKS chunks per workgroup - a split costs a whole epilogue and a row of the reduce
+    // (batch of 256 at 4x4: 64 splits of ONE chunk each; with 16, the captured cifar10 training step 1.51 -> 1.43 ms)
+#ifndef CF_WGRAD_MIN_CHUNKS
+#define CF_WGRAD_MIN_CHUNKS 4
+#endif
+    if (splits > nchunks / CF_WGRAD_MIN_CHUNKS) splits = nchunks / CF_WGRAD_MIN_CHUNKS;
     if (splits > nchunks) splits = nchunks;
     return splits < 1 ? 1 : splits;
 }
@@ -731,7 +737,10 @@ inline void wgrad1x1_split(int B, int MR, int NR, int HW, int& Q, int& qper, int
     const int waves = rt * ct <= 2 ? 4096 : 2048;
     Q = B * (HW / (16 * wgrad1x1_nf(HW)));
     qper = (Q + waves - 1) / waves;                    // (small batches: one unit per wave - the units are what fills the chip)
-    if (qper < 1) qper = 1;
+#ifndef CF_W1_MIN_UNITS
+#define CF_W1_MIN_UNITS 1
+#endif
+    if (qper < CF_W1_MIN_UNITS) qper = CF_W1_MIN_UNITS;
     nsplit = ((Q + qper - 1) / qper + 3) / 4;
 }
 inline bool wgrad1x1_ok(int MR, int NR, int HW) {
