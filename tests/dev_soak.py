@@ -17,7 +17,7 @@ for name in ("cifar10", "mnist", "smap"):
     mk = (lambda B: torch.rand(B, *ds, device=dev)) if M == 1 else (lambda B: torch.randint(0, 256, (B, *ds), device=dev).float())
     with torch.no_grad():
         model(mk(256))
-    for B in (300, 4100, 16384):
+    for B in (300, 1100, 4100, 16384):
         x = mk(B)
         gt = torch.randint(0, max(M, 2), (B,), device=dev) % M
         ref = None
