@@ -1613,7 +1613,67 @@ def test_step_wgrads_equals_four_wgrad_calls(L, C, H, B):
     assert not torch.equal(outs[0][6], out[6])               # (another input: the comparison above is not vacuous)
 
 
-@pytest.mark.parametrize("C,H,B", [(16, 16, 5), (32, 8, 37), (64, 4, 300), (8, 16, 3)])
+@pytest.mark.parametrize("C,H,B", [(16, 16, 21), (32, 8, 130), (64, 4, 257)])
+def test_batched_step_wgrads_equal_the_single_calls(L, C, H, B):
+    """cf_step_wgrads_batch / cf_step_param_grads_batch over n = 10 steps (more than one launch's worth of 8; the first and
+    the sixth read their input through a Squeeze index map and a wider batch stride, as the first step of a level does):
+    every output bitwise equal to the per-step entry points."""
+    import ctypes
+    from contextflow_amd.layers import _hip
+    lib, P, A = _hip.lib(), _hip.p, _hip.ptr_array
+    HID, HALF, HW, n = 2 * C, C // 2, H * H, 10
+    g = torch.Generator().manual_seed(C + B)
+    r = lambda *sh: torch.randn(*sh, generator=g).to(DEV)
+    steps = []
+    for i in range(n):
+        planes = [r(B, rows, HW) for rows in (C, HID, HID, C, HID, HID, HALF)]
+        if i % 5 == 0:
+            wide = r(B, C // 2, 2 * H, 2 * H)
+            xs, bst, unsq = wide[:, : C // 4], wide.stride(0), 1
+        else:
+            xs, bst, unsq = r(B, C, HW), C * HW, 0
+        steps.append((planes, xs, bst, unsq, wide if i % 5 == 0 else None))
+    shapes = [(1, C, HID), (C,), (HID, HID, 3, 3), (HID,), (1, HID, HALF), (HID,), (1, C, C), (C,)]
+    wsb = lib.cf_step_wgrads_ws_bytes(B, C, H, H)
+    single, batched = [], []
+    for planes, xs, bst, unsq, _ in steps:
+        o = [torch.full(sh, float("nan"), device=DEV) for sh in shapes]
+        ws = torch.empty(wsb, device=DEV, dtype=torch.uint8)
+        _hip.call("cf_step_wgrads", *[P(t) for t in planes], P(xs), *[P(t) for t in o], P(ws), B, C, H, H, bst, unsq, _hip.stream())
+        single.append(o)
+        batched.append([torch.full(sh, float("nan"), device=DEV) for sh in shapes])
+    wss = [torch.empty(wsb, device=DEV, dtype=torch.uint8) for _ in range(n)]
+    bst_arr = (ctypes.c_int64 * n)(*[st[2] for st in steps])
+    sq_arr = (ctypes.c_int * n)(*[st[3] for st in steps])
+    _hip.call("cf_step_wgrads_batch", n, *[A([st[0][k] for st in steps]) for k in range(7)], A([st[1] for st in steps]),
+              *[A([o[k] for o in batched]) for k in range(8)], A(wss), B, C, H, H, ctypes.cast(bst_arr, ctypes.c_void_p),
+              ctypes.cast(sq_arr, ctypes.c_void_p), _hip.stream())
+    for i in range(n):
+        for a, b in zip(single[i], batched[i]):
+            assert torch.isfinite(a).all() and torch.equal(a, b), i
+    # the parameter chains behind them
+    Wm = [torch.linalg.qr(torch.randn(C, C, generator=g))[0].contiguous().to(DEV) for _ in range(n)]
+    t, logs, winv = [0.1 * r(C) for _ in range(n)], [0.1 * r(C) for _ in range(n)], [r(C, C) for _ in range(n)]
+    gsum = r(1)
+    outs = {}
+    for mode in ("single", "batch"):
+        gNN, gt, gl = ([torch.full((C, C), float("nan"), device=DEV) for _ in range(n)], [torch.full((C,), float("nan"), device=DEV) for _ in range(n)],
+                       [torch.full((C,), float("nan"), device=DEV) for _ in range(n)])
+        gWp = [o[6][0].contiguous() for o in single]
+        gbp = [o[7] for o in single]
+        if mode == "single":
+            for i in range(n):
+                _hip.call("cf_step_param_grads", P(gWp[i]), P(gbp[i]), P(Wm[i]), P(t[i]), P(logs[i]), P(winv[i]), P(gsum), HW, P(gNN[i]), P(gt[i]),
+                          P(gl[i]), C, _hip.stream())
+        else:
+            _hip.call("cf_step_param_grads_batch", n, A(gWp), A(gbp), A(Wm), A(t), A(logs), A(winv), P(gsum), HW, A(gNN), A(gt), A(gl), C,
+                      _hip.stream())
+        outs[mode] = gNN + gt + gl
+    for a, b in zip(outs["single"], outs["batch"]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,H,B", [(16, 16, 5), (32, 8, 37), (64, 4, 300), (64, 4, 1), (64, 4, 3), (64, 4, 1700), (8, 16, 3)])
 def test_step_backward_writes_the_unsqueezed_gradient(L, C, H, B):
     """cf_flow_step_bwd_taped with gx_unsqueezed: dL/dx in the layout of the tensor in front of the step's Squeeze((2,2)) =
     squeeze_op(inverse) of the squeezed-layout result, bit for bit (ragged last workgroup included)."""
