@@ -2,6 +2,7 @@
 // MFMA operand pipeline, wave-local staging, the conditioner (phases 1-3).  Included by cf_step.hip and
 // cf_step_bwd.hip; everything lives in an anonymous namespace of the including translation unit.
 #pragma once
+#include <type_traits>
 #include "cf_common.h"
 #include <math.h>
 
@@ -414,6 +415,9 @@ template <class G> __device__ __forceinline__ int wino_pix(int sHW, int y, int x
 }
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
+#ifndef CF_WINO_PEEL
+#define CF_WINO_PEEL 1
+#endif
 
 // Loop form: the 16 positions run as a RUNTIME loop over xi (row of B^T / A^T on the vertical axis) around the four nu,
 // unrolled.  (All 16 unrolled was measured first: 4x the code, and hipcc spilled 50-150 registers at 2-3 workgroups / CU:
@@ -528,8 +532,9 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
         int r1[NT], r2[NT], r1n[NT], r2n[NT];
         rows_of(0, r1, r2);
         load(0, r1, r2, 0, fa[0], raw[0]);
-#pragma unroll 1
-        for (int xi = 0; xi < 4; ++xi) {
+        // the vertical coefficients A^T[0][xi] = (1, 1, 1, 0) and A^T[1][xi] = (0, 1, -1, -1): xi = 0 and xi = 3 are peeled so that
+        // their zero halves of the output transform are not executed (CF_WINO_PEEL; the loop keeps xi = 1, 2)
+        auto xi_body = [&](const int xi, auto has0, auto has1) {
             const int xn = xi < 3 ? xi + 1 : 3;
             rows_of(xn, r1n, r2n);
             const float sigma = xi == 1 ? 1.f : -1.f;
@@ -586,14 +591,23 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
                             for (int rt = 0; rt < RTW; ++rt) {
-                                Y[ct][0][j][rt] += k0 * M[ct][rt];
-                                Y[ct][1][j][rt] += k1 * M[ct][rt];
+                                if constexpr (decltype(has0)::value) Y[ct][0][j][rt] += k0 * M[ct][rt];
+                                if constexpr (decltype(has1)::value) Y[ct][1][j][rt] += k1 * M[ct][rt];
                             }
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) { r1[ct] = r1n[ct]; r2[ct] = r2n[ct]; }
+        };
+        if constexpr (CF_WINO_PEEL) {
+            xi_body(0, std::true_type{}, std::false_type{});
+#pragma unroll 1
+            for (int xi = 1; xi < 3; ++xi) xi_body(xi, std::true_type{}, std::true_type{});
+            xi_body(3, std::false_type{}, std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int xi = 0; xi < 4; ++xi) xi_body(xi, std::true_type{}, std::true_type{});
         }
     } else {
 #pragma unroll 1
@@ -630,8 +644,7 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
         int r1[NT], r2[NT], r1n[NT], r2n[NT];
         rows_of(0, r1, r2);
         load(0, r1, r2, 0, fa[0], pd[0]);
-#pragma unroll 1
-        for (int xi = 0; xi < 4; ++xi) {
+        auto xi_body = [&](const int xi, auto has0, auto has1) {          // xi = 0 / 3 peeled, as in the column-shared form
             const int xn = xi < 3 ? xi + 1 : 3;
             rows_of(xn, r1n, r2n);
             const float sigma = xi == 1 ? 1.f : -1.f;
@@ -678,14 +691,23 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
                             for (int rt = 0; rt < RTW; ++rt) {
-                                Y[ct][0][j][rt] += k0 * M[ct][rt];
-                                Y[ct][1][j][rt] += k1 * M[ct][rt];
+                                if constexpr (decltype(has0)::value) Y[ct][0][j][rt] += k0 * M[ct][rt];
+                                if constexpr (decltype(has1)::value) Y[ct][1][j][rt] += k1 * M[ct][rt];
                             }
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) { r1[ct] = r1n[ct]; r2[ct] = r2n[ct]; }
+        };
+        if constexpr (CF_WINO_PEEL) {
+            xi_body(0, std::true_type{}, std::false_type{});
+#pragma unroll 1
+            for (int xi = 1; xi < 3; ++xi) xi_body(xi, std::true_type{}, std::true_type{});
+            xi_body(3, std::false_type{}, std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int xi = 0; xi < 4; ++xi) xi_body(xi, std::true_type{}, std::true_type{});
         }
     }
     }       // per-position form
