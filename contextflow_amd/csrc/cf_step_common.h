@@ -600,7 +600,12 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) { r1[ct] = r1n[ct]; r2[ct] = r2n[ct]; }
         };
-        if constexpr (CF_WINO_PEEL) {
+        if constexpr (CF_WINO_PEEL == 2) {      // all four bodies (measured: see DESIGN)
+            xi_body(0, std::true_type{}, std::false_type{});
+            xi_body(1, std::true_type{}, std::true_type{});
+            xi_body(2, std::true_type{}, std::true_type{});
+            xi_body(3, std::false_type{}, std::true_type{});
+        } else if constexpr (CF_WINO_PEEL) {
             xi_body(0, std::true_type{}, std::false_type{});
 #pragma unroll 1
             for (int xi = 1; xi < 3; ++xi) xi_body(xi, std::true_type{}, std::true_type{});
@@ -700,7 +705,12 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) { r1[ct] = r1n[ct]; r2[ct] = r2n[ct]; }
         };
-        if constexpr (CF_WINO_PEEL) {
+        if constexpr (CF_WINO_PEEL == 2) {      // all four bodies (measured: see DESIGN)
+            xi_body(0, std::true_type{}, std::false_type{});
+            xi_body(1, std::true_type{}, std::true_type{});
+            xi_body(2, std::true_type{}, std::true_type{});
+            xi_body(3, std::false_type{}, std::true_type{});
+        } else if constexpr (CF_WINO_PEEL) {
             xi_body(0, std::true_type{}, std::false_type{});
 #pragma unroll 1
             for (int xi = 1; xi < 3; ++xi) xi_body(xi, std::true_type{}, std::true_type{});
