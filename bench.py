@@ -314,7 +314,7 @@ def cpu_train_baseline(name, B=256, iters=5, warmups=1):
                       "%d %s-shaped samples after %d warm-up, torch %d threads" % (iters, B, name, warmups, cores)}
 
 
-def secondary_training(name, dev, B, iters, graph, cpu=False):
+def secondary_training(name, dev, B, iters, graph, cpu=False, own_adamw=False):
     """SURVEY.md 8(f)1, the caller right after the path (experiment_cl.py:123-136 / experiment_ad.py:199-213): one
     optimisation step = forward, the reference's loss, hand-written backward, AdamW - as ONE captured HIP graph
     (FlowSequential.capture_train_step) at a saturating batch and at the reference's batch of 256, and eagerly launched
@@ -326,8 +326,15 @@ def secondary_training(name, dev, B, iters, graph, cpu=False):
     loss_fn = reference_loss(name)
     # the reference's optimizer (model.py:289: AdamW(params, lr)); under capture its fused implementation: ONE multi-tensor
     # kernel per step (the foreach form falls back to two launches per parameter on the 0-dim step tensors of capturable mode)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True) if graph and os.environ.get("CF_BENCH_FOREACH_ADAMW") != "1" \
-        else torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=graph)
+    if own_adamw:
+        # the same update through contextflow_amd.optim.FusedAdamW: the whole parameter table in one or two launches (torch's fused
+        # multi-tensor kernel: 4 launches of 43 us for cifar10's 135 tensors, 16 of 15 us for smap's 571)
+        import contextflow_amd as cfa
+        opt = cfa.optim.FusedAdamW(model.parameters(), lr=1e-4)
+    elif graph and os.environ.get("CF_BENCH_FOREACH_ADAMW") != "1":
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=graph)
     if graph:
         step = model.capture_train_step(x, loss_fn, opt, data_parallel=False)     # single-GPU line; `bench.py --train` is the data-parallel step
         run = lambda: step(x, gt)
@@ -351,6 +358,7 @@ def secondary_training(name, dev, B, iters, graph, cpu=False):
     out = {"metric": "samples/s training step (fwd + bwd + AdamW), %s" % LABEL[name], "value": round(B / dt, 1), "unit": "samples/s",
            "config": {"workload": "%s --coupling %s" % (name, cfg["coupling"]), "batch": B, "iters": iters,
                       "launch": "one captured HIP graph" if graph else "eager",
+                      "optimizer": "contextflow_amd.optim.FusedAdamW" if own_adamw else "torch.optim.AdamW(fused=True)" if graph else "torch.optim.AdamW",
                       "loss": "experiment_ad.py:207 (1e2 * -logsigmoid(logp / D), NaN scrubbed)" if M == 1 else
                               "experiment_cl.py:128-133 (NaN scrub, CE + 1e-3 * -logsigmoid(logsumexp))"},
            "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss), 5),
@@ -774,8 +782,10 @@ def main():
                 secondary_training("cifar10", dev, 16384, 10, graph=False),            # (before the leg that ends with the CPU baseline:
                 secondary_training("cifar10", dev, 16384, 10, graph=True, cpu=cpu),    #  its idle worker threads slow an eager launcher down)
                 secondary_training("cifar10", dev, 256, 50, graph=True),
+                secondary_training("cifar10", dev, 256, 50, graph=True, own_adamw=True),
                 secondary_training("smap", dev, 32768, 10, graph=True, cpu=cpu),       # BASELINE config 4's training step
                 secondary_training("smap", dev, 256, 50, graph=True),                  # ... at the reference's batch (config.py:10)
+                secondary_training("smap", dev, 256, 50, graph=True, own_adamw=True),
                 secondary_specialist("cifar10", dev, 32768, 5, cpu),                   # --contextflow specialist forward
                 secondary_sampling("mnist", dev, 16384, 10, cpu),                      # SURVEY 8(f)3 / north_star "forward+inverse": flow.sample
                 secondary_sampling("cifar10", dev, 16384, 10, cpu=False),              # (SplitPrior.reverse by specification: no reference / oracle chain)

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CONTEXTFLOW_HIP_LIB: developer override (A/B builds, probe builds of tools/dev); the default is the in-tree library
 LIB_PATH = os.environ.get("CONTEXTFLOW_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libcontextflow_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -79,6 +79,7 @@ SIGNATURES = {
     "cf_flow_step_bwd_taped": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_p]),
     "cf_flow_step_fwd_taped": (_c_int, [_c_p] * 8 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_step_param_grads": (_c_int, [_c_p] * 7 + [_c_int] + [_c_p] * 3 + [_c_int, _c_p]),
+    "cf_adamw_step_batch": (_c_int, [_c_int] + [_c_p] * 6 + [ctypes.c_double] * 5 + [_c_int, _c_p]),
     "cf_step_param_grads_batch": (_c_int, [_c_int] + [_c_p] * 7 + [_c_int] + [_c_p] * 3 + [_c_int, _c_p]),
     "cf_wgrad_ws_bytes": (_c_i64, [_c_int] * 6),
     "cf_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 6 + [_c_p]),

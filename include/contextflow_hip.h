@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 8
+#define CF_ABI_VERSION 9
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -604,6 +604,15 @@ int cf_add_repeat(float* h, const float* x, int B, int C2, int C, int HW, cf_str
 int cf_logdet_combine(const float* ldM, const float* ld1, float* out, int B, int M, cf_stream_t stream);
 /* acc[0] += sum_b logsumexp_m logp[b,m] (fp64 accumulator; the scalar each rank all-reduces)         */
 int cf_nll_sum(const float* logp, double* acc, int B, int M, cf_stream_t stream);
+
+/* ---- optimizer update of the training step (model.py:289 optim.AdamW; experiment_cl.py:136, experiment_ad.py:213) ---------- */
+/* torch.optim.AdamW's update (decoupled weight decay, lerp form of the first moment, bias-corrected; amsgrad off) of n tensors
+ * in ceil(n / 72) launches: host arrays of n device pointers (p, g, exp_avg m, exp_avg_sq v) and element counts; `step` = device
+ * scalar holding the update count t >= 1 of THIS update (the caller increments it: the call is capturable).  fp32 tensors;
+ * the hyper-parameters arrive as doubles and 1 - beta, 1 - lr weight_decay are formed in double, as torch forms them.        */
+int cf_adamw_step_batch(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
+                        const float* step, double lr, double beta1, double beta2, double eps, double weight_decay, int maximize,
+                        cf_stream_t stream);
 
 #ifdef __cplusplus
 }

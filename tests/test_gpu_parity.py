@@ -1477,6 +1477,81 @@ def test_batched_parameter_work_of_a_level_equals_the_per_step_launches(L, name,
         assert torch.equal(a, got[False][k]), k
 
 
+@pytest.mark.parametrize("wd,maximize", [(1e-2, False), (0.0, False), (0.3, True)])
+def test_fused_adamw_equals_torch_adamw(L, wd, maximize):
+    """contextflow_amd.optim.FusedAdamW (one cf_adamw_step_batch launch per 72 tensors) against torch.optim.AdamW: the same
+    parameters and moments after six updates on 150 tensors of awkward sizes (1 ... 100 003 elements), to fp32 rounding of the
+    same formulas; the state_dict has torch's layout and survives a round trip."""
+    import contextflow_amd as cfa
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 2, 3, 5, 9, 64, 255, 1024, 1025, 4097, 100003] + [int(torch.randint(1, 3000, (1,), generator=g)) for _ in range(139)]
+    base = [torch.randn(n, generator=g) for n in sizes]
+    grads = [[torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-3, 2, (1,), generator=g))) for n in sizes] for _ in range(6)]
+    pa = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    pb = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    kw = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd, maximize=maximize)
+    oa, ob = torch.optim.AdamW(pa, **kw), cfa.optim.FusedAdamW(pb, **kw)
+    for it, gr in enumerate(grads):
+        for p, q, gg in zip(pa, pb, gr):
+            p.grad = gg.to(DEV)
+            q.grad = gg.to(DEV)
+        oa.step()
+        ob.step()
+        if it == 2:                  # save / load in the middle: torch's layout, moments and step count carried over
+            sd = ob.state_dict()
+            assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and "_flat" not in sd["param_groups"][0]
+            ob2 = cfa.optim.FusedAdamW(pb, **kw)
+            ob2.load_state_dict(sd)
+            ob = ob2
+    for p, q in zip(pa, pb):
+        assert torch.isfinite(q).all()
+        assert (p - q).abs().max().item() <= 2e-6 * max(1.0, p.abs().max().item())
+        sa, sb = oa.state[p], ob.state[q]
+        assert (sa["exp_avg"] - sb["exp_avg"]).abs().max().item() <= 1e-6 * max(1e-3, sa["exp_avg"].abs().max().item())
+        assert (sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max().item() <= 1e-6 * max(1e-6, sa["exp_avg_sq"].abs().max().item())
+        assert float(sb["step"]) == 6.0
+
+
+def test_captured_training_step_with_fused_adamw_equals_the_eager_loop(L):
+    """FlowSequential.capture_train_step with FusedAdamW (its update count lives on the device): four replayed steps give the
+    parameters of four eager steps, bit for bit."""
+    import contextflow_amd as cfa
+    cfg, ds, M = cfa.preset_config("mnist")
+    g = torch.Generator().manual_seed(8)
+    B = 64
+    x = torch.randint(0, 256, (B, *ds), generator=g).float().to(DEV)
+    y = torch.randint(0, M, (B,), generator=g).to(DEV)
+    inv = 1.0 / x[0].numel()
+    loss_fn = lambda lp, yy: torch.nn.functional.cross_entropy(lp * inv, yy)
+    res = []
+    for captured in (False, True):
+        torch.manual_seed(0)
+        m = cfa.create_model(cfg, ds, M).to(DEV)
+        for q in m.sequence_modules:
+            if isinstance(q, cfa.layers.Dequantization):
+                q.dist.fixed_noise = torch.rand(B, *ds, generator=torch.Generator().manual_seed(9)).to(DEV)
+        with torch.no_grad():
+            m(x)
+        m.train()
+        opt = cfa.optim.FusedAdamW(m.parameters(), lr=1e-3)
+        if captured:
+            step = m.capture_train_step(x, loss_fn, opt, data_parallel=False)
+            losses = [float(step(x, y).detach()) for _ in range(4)]
+        else:
+            losses = []
+            for _ in range(4):
+                opt.zero_grad(set_to_none=True)
+                l = loss_fn(m.log_prob(x), y)
+                l.backward()
+                opt.step()
+                losses.append(float(l.detach()))
+        res.append((losses, [p.detach().clone() for p in m.parameters()]))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    assert res[0][0][-1] < res[0][0][0]
+
+
 @pytest.mark.parametrize("name,coupling", [("mnist", "maf"), ("smap", "conv"), ("smap", "maf")])
 def test_training_with_generic_conv_couplings(L, name, coupling):
     """`--coupling maf` (MaskedCoupling, ar.py) and `--coupling conv` on a time-series topology ((3,1) kernels, model.py:114):

@@ -17,7 +17,8 @@ x = torch.rand(B, *ds, device=dev) if M == 1 else torch.randint(0, 256, (B, *ds)
 gt = torch.randint(0, M, (B,), device=dev)
 with torch.no_grad():
     model(x[:256])
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=True, fused=True)      # one multi-tensor kernel per step
+opt = (cfa.optim.FusedAdamW(model.parameters(), lr=1e-4) if os.environ.get("CF_OWN_ADAMW") == "1"      # CF_OWN_ADAMW=1: contextflow_amd.optim
+       else torch.optim.AdamW(model.parameters(), lr=1e-4, capturable=True, fused=True))      # one multi-tensor kernel per step
 dim_inv = 1.0 / (ds[0] * ds[1] * ds[2])
 
 
