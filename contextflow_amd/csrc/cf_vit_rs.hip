@@ -37,11 +37,11 @@ namespace {
 #endif
 // DUMP (training forward): the residual stream at the depth + 1 layer boundaries also goes to xtape ([boundary][DIM][T],
 // as cf_vit_step_fwd_taped writes it) - the owner's tile, 64 contiguous bytes per feature row.
+// (x and z may be the same buffer: a workgroup reads its four samples before it writes them - the chained form below)
 template <class V, bool DUMP = false>
-__global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float* __restrict__ x, float* __restrict__ z,
-                                                     float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
-                                                     int64_t xbs, int depth, float* __restrict__ hout,
-                                                     float* __restrict__ xtape = nullptr, int64_t T = 0) {
+__device__ __forceinline__ void vit_step_rs_body(const float* x, float* z, float* __restrict__ ldj_acc, const float* __restrict__ ws,
+                                                 int B, int64_t xbs, int depth, float* __restrict__ hout,
+                                                 float* __restrict__ xtape = nullptr, int64_t T = 0) {
     constexpr int C = V::C, CIN = V::CIN, HW = V::HW, DIM = V::DIM, PD = V::PD, TOK = V::TOK, POSC = V::POSC;
     __shared__ __align__(16) float lds[V::LDS_FLOATS];
     float* XIN = lds + V::P_XIN;     // [4 KS_C][32 positions]   step input, channel-major
@@ -256,6 +256,29 @@ __global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float
     }
 }
 
+template <class V, bool DUMP = false>
+__global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs(const float* __restrict__ x, float* __restrict__ z,
+                                                     float* __restrict__ ldj_acc, const float* __restrict__ ws, int B,
+                                                     int64_t xbs, int depth, float* __restrict__ hout,
+                                                     float* __restrict__ xtape = nullptr, int64_t T = 0) {
+    vit_step_rs_body<V, DUMP>(x, z, ldj_acc, ws, B, xbs, depth, hout, xtape, T);
+}
+
+// Consecutive transformer flow steps in ONE launch (evaluation at small batches: a step is latency - 28 us on 64 workgroups at a
+// batch of 256 - and so is the gap between two launches): a workgroup owns its four samples end to end, steps 2.. run in place
+// on z behind a workgroup barrier.  Same code per step: bit for bit the per-step launches.
+constexpr int kVitChain = 8;
+struct VitWsChain { const float* ws[kVitChain]; };
+template <class V>
+__global__ __launch_bounds__(256, CF_VIT_RS_MINW) void k_vit_step_rs_chain(const float* x, float* z, float* __restrict__ ldj_acc,
+                                                                           const VitWsChain wc, int nsteps, int B, int64_t xbs, int depth) {
+    vit_step_rs_body<V>(x, z, ldj_acc, wc.ws[0], B, xbs, depth, nullptr);
+    for (int st = 1; st < nsteps; ++st) {
+        __syncthreads();
+        vit_step_rs_body<V>(z, z, ldj_acc, wc.ws[st], B, (int64_t)V::C * V::HW, depth, nullptr);
+    }
+}
+
 using RS26 = RS<26>;
 
 bool rs_ok(int C, int H, int W, int p1, int p2, int dim, int dim_head, int heads) {
@@ -318,6 +341,21 @@ int cf_vit_step_rs_fwd(const float* x, float* z, float* ldj_acc, const void* ws,
     if (C != 26) { cf_set_error("cf_vit_step_rs_fwd: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
     k_vit_step_rs<RS26><<<dim3((unsigned)((B + 3) / 4)), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, (const float*)ws, B,
                                                                                    x_bstride, depth, h_out);
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_vit_step_rs_chain_max_steps(void) { return kVitChain; }
+
+// n <= cf_vit_step_rs_chain_max_steps() consecutive steps (ws: host array of their packed tables); z may not alias x
+int cf_vit_step_rs_fwd_chain(const float* x, float* z, float* ldj_acc, const void* const* ws, int n, int B, int C, int depth,
+                             int64_t x_bstride, cf_stream_t stream) {
+    if (B == 0 || n == 0) return 0;
+    CF_REQUIRE(x && z && ldj_acc && ws && n >= 1 && n <= kVitChain && B > 0 && depth >= 1 && x_bstride >= (int64_t)C * 8 && (const float*)z != x);
+    if (C != 26) { cf_set_error("cf_vit_step_rs_fwd_chain: C=%d unsupported", C); return CF_ERR_UNSUPPORTED; }
+    VitWsChain wc{};
+    for (int i = 0; i < n; ++i) { CF_REQUIRE(ws[i]); wc.ws[i] = (const float*)ws[i]; }
+    k_vit_step_rs_chain<RS26><<<dim3((unsigned)((B + 3) / 4)), dim3(256), 0, cf_s(stream)>>>(x, z, ldj_acc, wc, n, B, x_bstride, depth);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CONTEXTFLOW_HIP_LIB: developer override (A/B builds, probe builds of tools/dev); the default is the in-tree library
 LIB_PATH = os.environ.get("CONTEXTFLOW_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libcontextflow_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -119,6 +119,8 @@ SIGNATURES = {
     "cf_vit_step_tape_tokens": (_c_i64, [_c_int]),
     "cf_vit_step_tape_floats": (_c_i64, [_c_int] * 3),
     "cf_vit_step_fwd_taped": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
+    "cf_vit_step_rs_chain_max_steps": (_c_int, []),
+    "cf_vit_step_rs_fwd_chain": (_c_int, [_c_p] * 4 + [_c_int] * 4 + [_c_i64, _c_p]),
     "cf_vit_step_rs_fwd_taped": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_i64, _c_p]),
     "cf_linear_wgrad_group_ws_bytes": (_c_i64, [_c_p] * 3 + [_c_int]),
     "cf_linear_wgrad_group": (_c_int, [_c_p] * 7 + [_c_int, _c_p, _c_p]),

@@ -22,6 +22,7 @@ from . import _hip
 from .actnorm import ActNorm
 from .augment import Augment
 from .conv1x1 import Conv1x1
+from . import coupling as _cpl
 from .coupling import Coupling, TransCoupling
 from .dequantize import Dequantization
 from .distributions.gaussian import (GaussianMixtureDistribution, StandardNormal, gmm_logprob, gmm_levels_ok,
@@ -532,6 +533,28 @@ class FlowSequential(nn.Module):
                     continue
                 if ev is not None:
                     main.wait_event(ev)
+                if self.CHAIN_STEPS and vkey[k] == "rs" and _cpl.VIT_EVENTS is None:
+                    # small batch (row-split form): this step and the transformer steps that follow it in ONE launch
+                    run = [k]
+                    nmax = int(_hip.lib().cf_vit_step_rs_chain_max_steps())
+                    depth = len(op[3].NN[0].transformer.layers)
+                    while (len(run) < nmax and run[-1] + 1 < len(plan) and plan[run[-1] + 1][0] == "vstep" and vkey.get(run[-1] + 1) == "rs"
+                           and len(plan[run[-1] + 1][3].NN[0].transformer.layers) == depth):
+                        run.append(run[-1] + 1)
+                    if len(run) > 1:
+                        tabs = [ws]
+                        for j in run[1:]:
+                            wj, evj = prepared[j]
+                            if evj is not None:
+                                main.wait_event(evj)
+                            tabs.append(wj)
+                        xv, xbs = _hip.bview(x)
+                        z = torch.empty(B, xv.shape[1], xv.shape[2], xv.shape[3], device=dev, dtype=torch.float32)
+                        _hip.call("cf_vit_step_rs_fwd_chain", _hip.p(xv), _hip.p(z), _hip.p(ld1), _hip.ptr_array(tabs), len(run), B, xv.shape[1],
+                                  depth, xbs, st)
+                        chained.update(run[1:])
+                        x = z
+                        continue
                 x = op[3].step_forward(x, ws, ld1, variant=vkey[k])
             elif kind == "squeeze":
                 if tape is not None:

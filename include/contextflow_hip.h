@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 9
+#define CF_ABI_VERSION 10
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -460,6 +460,12 @@ int64_t cf_vit_step_tape_floats(int B, int C, int depth);
 int cf_vit_step_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* xtape, int B, int C, int depth,
                           int64_t x_bstride, cf_stream_t stream);
 int cf_vit_step_rs_fwd_taped(const float* x, float* z, float* ldj_acc, const void* ws, float* xtape, int B, int C, int depth,
+                             int64_t x_bstride, cf_stream_t stream);
+/* n <= cf_vit_step_rs_chain_max_steps() CONSECUTIVE transformer flow steps in one launch (evaluation at small batches; ws: host
+ * array of n packed tables; a workgroup owns its samples end to end, steps 2.. run in place on z).  Bitwise equal to n
+ * cf_vit_step_rs_fwd calls.                                                                                                  */
+int cf_vit_step_rs_chain_max_steps(void);
+int cf_vit_step_rs_fwd_chain(const float* x, float* z, float* ldj_acc, const void* const* ws, int n, int B, int C, int depth,
                              int64_t x_bstride, cf_stream_t stream);       /* the row-split (small-batch) forward, same tape */
 int cf_vit_step_bwd_taped(const float* x, const float* gz, const float* gld, float* gx, const void* ws, const void* wsb,
                           float* planes, float* ln_partials, const float* xtape, int B, int C, int depth, int64_t x_bstride,

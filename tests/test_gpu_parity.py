@@ -1552,6 +1552,36 @@ def test_captured_training_step_with_fused_adamw_equals_the_eager_loop(L):
     assert res[0][0][-1] < res[0][0][0]
 
 
+def test_chained_transformer_steps_equal_single_launches(L, monkeypatch):
+    """Evaluation of the SMAP flow at small batches: its eight transformer flow steps in ONE launch (cf_vit_step_rs_fwd_chain:
+    a workgroup owns its four samples end to end, steps 2.. in place on z) - z and logp of the per-step launches bit for bit,
+    at a ragged batch as well."""
+    import contextflow_amd as cfa
+    from contextflow_amd.layers.flowsequential import FlowSequential
+    cfg, ds, M = cfa.preset_config("smap")
+    torch.manual_seed(0)
+    m = cfa.create_model(cfg, ds, M).to(DEV).eval()
+    m.auto_graph = False
+    g = torch.Generator().manual_seed(2)
+    with torch.no_grad():
+        m(torch.rand(256, *ds, generator=g).to(DEV))
+        for B in (256, 61, 3):
+            x = torch.rand(B, *ds, generator=g).to(DEV)
+            for q in m.sequence_modules:             # the same noise in both passes
+                if isinstance(q, cfa.layers.Dequantization):
+                    q.dist.fixed_noise = torch.rand(B, *ds, generator=g).to(DEV)
+                if isinstance(q, cfa.layers.Augment):
+                    q.distribution.fixed_noise = torch.randn(B, q.aug_size, ds[1], ds[2], generator=g).to(DEV)
+            outs = []
+            for chain in (True, False):
+                monkeypatch.setattr(FlowSequential, "CHAIN_STEPS", chain)
+                m.invalidate_caches()
+                z, lp = m(x)
+                outs.append((z.clone(), lp.clone()))
+            assert torch.isfinite(outs[0][1]).all()
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), B
+
+
 @pytest.mark.parametrize("name,coupling", [("mnist", "maf"), ("smap", "conv"), ("smap", "maf")])
 def test_training_with_generic_conv_couplings(L, name, coupling):
     """`--coupling maf` (MaskedCoupling, ar.py) and `--coupling conv` on a time-series topology ((3,1) kernels, model.py:114):

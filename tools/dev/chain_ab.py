@@ -7,7 +7,7 @@ import torch
 import bench
 from contextflow_amd.layers.flowsequential import FlowSequential
 dev = torch.device("cuda", 0)
-for name, B in (("cifar10", 64), ("cifar10", 256), ("cifar10", 512), ("mnist", 64), ("mnist", 256)):
+for name, B in (("cifar10", 64), ("cifar10", 256), ("cifar10", 512), ("mnist", 64), ("mnist", 256), ("smap", 64), ("smap", 256), ("smap", 1024)):
     out = []
     for chain in (False, True):
         FlowSequential.CHAIN_STEPS = chain
