@@ -455,8 +455,9 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
             int yy = 2 * ty[ct] - 1 + a, xx = 2 * tx[ct] - 1 + a;
             yy = yy < 0 ? -yy : (yy >= H ? 2 * (H - 1) - yy : yy);
             xx = xx < 0 ? -xx : (xx >= W ? 2 * (W - 1) - xx : xx);
-            rpart[ct][a] = HALF * PIX + lg * PIX + wino_pix<G>(smp[ct] * HW, yy, 0);
-            cpart[ct][a] = (((xx ^ lg) & 1) * (W / 2)) + (xx >> 1);
+            // BYTE offsets: an operand address is then one addition (row part + column part) in front of the ds_read's immediate
+            rpart[ct][a] = 4 * (HALF * PIX + lg * PIX + wino_pix<G>(smp[ct] * HW, yy, 0));
+            cpart[ct][a] = 4 * ((((xx ^ lg) & 1) * (W / 2)) + (xx >> 1));
         }
     }
     f32x4w Y[NT][2][2][RTW];
@@ -521,10 +522,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                         const int o1 = r1[ct] + cpart[ct][c], o2 = r2[ct] + cpart[ct][c];
 #pragma unroll
                         for (int e2 = 0; e2 < 2; ++e2) {
-                            const float* q0 = base + (16 * kk + 8 * e2) * PIX;
-                            const float* q1 = q0 + 4 * PIX;
-                            o.d[ct][sl][0][e2] = f32x2w{q0[o1], q1[o1]};
-                            o.d[ct][sl][1][e2] = f32x2w{q0[o2], q1[o2]};
+                            const char* q0 = reinterpret_cast<const char*>(base + (16 * kk + 8 * e2) * PIX);
+                            const char* q1 = q0 + 4 * PIX * 4;
+                            auto at = [](const char* q, int ob) { return *reinterpret_cast<const float*>(q + ob); };
+                            o.d[ct][sl][0][e2] = f32x2w{at(q0, o1), at(q1, o1)};
+                            o.d[ct][sl][1][e2] = f32x2w{at(q0, o2), at(q1, o2)};
                         }
                     }
         };
@@ -639,10 +641,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                 const int o21 = r2[ct] + cpart[ct][B1[nu]], o22 = r2[ct] + cpart[ct][B2[nu]];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
-                    const float* q0 = base + (16 * kk + 8 * e2) * PIX;
-                    const float* q1 = q0 + 4 * PIX;
-                    o.d[ct][e2][0] = f32x2w{q0[o11], q1[o11]}; o.d[ct][e2][1] = f32x2w{q0[o12], q1[o12]};
-                    o.d[ct][e2][2] = f32x2w{q0[o21], q1[o21]}; o.d[ct][e2][3] = f32x2w{q0[o22], q1[o22]};
+                    const char* q0 = reinterpret_cast<const char*>(base + (16 * kk + 8 * e2) * PIX);
+                    const char* q1 = q0 + 4 * PIX * 4;
+                    auto at = [](const char* q, int ob) { return *reinterpret_cast<const float*>(q + ob); };
+                    o.d[ct][e2][0] = f32x2w{at(q0, o11), at(q1, o11)}; o.d[ct][e2][1] = f32x2w{at(q0, o12), at(q1, o12)};
+                    o.d[ct][e2][2] = f32x2w{at(q0, o21), at(q1, o21)}; o.d[ct][e2][3] = f32x2w{at(q0, o22), at(q1, o22)};
                 }
             }
         };
