@@ -5,7 +5,7 @@ import csv, glob, os, re, sys, collections
 if sys.argv[1] == "sum":
     f = glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True)[0]
     rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
-    marks = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "fused_adam" in r[2].lower()]
+    marks = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "fused_adam" in r[2].lower() or "k_adamw" in r[2]]
     # one step = between the first fused-Adam launch of consecutive steps
     firsts = [m for j, m in enumerate(marks) if j == 0 or marks[j] - marks[j - 1] > 8]
     a, b = firsts[-2], firsts[-1]
@@ -33,7 +33,8 @@ with torch.no_grad():
     model(x)
 inv = 1.0 / (ds[0] * ds[1] * ds[2])
 loss_fn = (lambda lp, y: -(lp * inv).mean()) if M == 1 else (lambda lp, y: torch.nn.functional.cross_entropy(lp * inv, y))
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True)
+opt = (cfa.optim.FusedAdamW(model.parameters(), lr=1e-4) if os.environ.get("CF_OWN_ADAMW") == "1"
+       else torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True))
 step = model.capture_train_step(x, loss_fn, opt)
 for _ in range(8):
     step(x, gt)

@@ -8,7 +8,7 @@ rd = list(csv.DictReader(open(f)))
 qk = "Queue_Id" if "Queue_Id" in rd[0] else None
 sk = "Stream_Id" if "Stream_Id" in rd[0] else None
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get(qk, "?") if qk else "?", r.get(sk, "?") if sk else "?") for r in rd))
-marks = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "fused_adam" in r[2].lower()]
+marks = [i for i, r in enumerate(rows) if "FusedAdam" in r[2] or "fused_adam" in r[2].lower() or "k_adamw" in r[2]]
 firsts = [m for j, m in enumerate(marks) if j == 0 or marks[j] - marks[j - 1] > 8]
 a, b = firsts[-2], firsts[-1]
 win = rows[a:b]
