@@ -346,6 +346,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // CTX: per-sample bias of the specialist coupling (see conditioner_net): 1 sb (B, C) on the conditioner output, 2 sb (B, 2C)
 // before the first ReLU.
 // (x and z carry no __restrict__: the chained form below runs steps 2.. IN PLACE on the z of the step before)
+// timing-only probe (-DCF_ABL_NOCONF): the B-operand reads of the 16-row phases without their bank conflict (rows 4s + lg of a
+// 256-float plane share a bank): the lane group shifts the COLUMN instead - wrong data, conflict-free
+#ifdef CF_ABL_NOCONF
+#define CF_ROWIDX(r, lg) ((r) * PIX + ((lg) * 16 & 63))
+#else
+#define CF_ROWIDX(r, lg) (((r) + (lg)) * PIX)
+#endif
 template <class G, bool SQ, bool DBG = false, bool DUMP = false, int CTX = 0>
 __device__ __forceinline__ void flow_step_small_body(const float* x, float* z, float* __restrict__ ldj_acc, const float* __restrict__ ws,
                                                      int B, int64_t xbs, float* __restrict__ dbg, StepTape tp,
@@ -381,7 +388,7 @@ __device__ __forceinline__ void flow_step_small_body(const float* x, float* z, f
                 if (4 * (4 * g + e) < C) {
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
-                        acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), H1[(4 * (4 * g + e) + lg) * PIX + colb + 16 * ct],
+                        acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), H1[CF_ROWIDX(4 * (4 * g + e), lg) + colb + 16 * ct],
                                                                         acc0[ct], 0, 0, 0);
                 }
         }
@@ -517,7 +524,7 @@ __device__ __forceinline__ void flow_step_small_body(const float* x, float* z, f
                 if (4 * (4 * g + e) < HID) {
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
-                        acc3[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), H1[(4 * (4 * g + e) + lg) * PIX + colb + 16 * ct],
+                        acc3[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(a, e), H1[CF_ROWIDX(4 * (4 * g + e), lg) + colb + 16 * ct],
                                                                         acc3[ct], 0, 0, 0);
                 }
         }
