@@ -96,6 +96,29 @@ __global__ __launch_bounds__(256) void k_step_pack(const StepPackBatch pb) {
                 for (int b = 0; b < 3; ++b) u += Gm[xi][a] * Gm[nu][b] * (double)wk[a * 3 + b];
             ws[G::OFF_AW + e] = (float)u;
         }
+        if constexpr (G::KB32 > 0) {
+            // the same values as three bf16 pieces each (truncation split: exact, u = p0 + p1 + p2), in the operand layout of
+            // v_mfma_f32_16x16x32_bf16 with k index (lane >> 4, j) = channel 4 j + (lane >> 4) of a 32-channel block
+            unsigned short* wb = reinterpret_cast<unsigned short*>(ws + G::OFF_AWB);
+            for (int e = gtid; e < 16 * G::RT16 * G::KB32 * 64 * 8; e += gsz) {
+                const int j = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+                const int kb = q % G::KB32, rt16 = (q / G::KB32) % G::RT16, pos = q / (G::KB32 * G::RT16);
+                const int co = rt16 * 16 + (ln & 15), ci = 32 * kb + 4 * j + (ln >> 4), xi = pos >> 2, nu = pos & 3;
+                const float* wk = w2 + ((int64_t)co * HID + ci) * 9;
+                double u = 0.0;
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) u += Gm[xi][a] * Gm[nu][b] * (double)wk[a * 3 + b];
+                const float uf = (float)u;
+                const unsigned u0 = __float_as_uint(uf) & 0xffff0000u;
+                const float r1 = uf - __uint_as_float(u0);
+                const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(u1);
+                const unsigned pc[3] = {u0, u1, __float_as_uint(r2)};
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz)
+                    wb[((((int64_t)(pos * G::RT16 + rt16) * G::KB32 + kb) * 3 + pz) * 64 + ln) * 8 + j] = (unsigned short)(pc[pz] >> 16);
+            }
+        }
     }
     if constexpr (G::RS16) {
         // k_flow_step_rs16: natural row order, element ((rt * NG + gi) * 64 + lane) * 4 + j = A[16 rt + (lane & 15)][4 (4 gi + j) + (lane >> 4)]
@@ -567,8 +590,11 @@ __device__ __forceinline__ void flow_step_small_body(const float* x, float* z, f
     __syncthreads();
     if (tid == 0 && tile < B) ldj_acc[tile] += ws[0] + ((Y0[0] + Y0[64]) + (Y0[128] + Y0[192]));
 }
+#ifndef CF_G16WB_MINW
+#define CF_G16WB_MINW 3
+#endif
 template <class G, bool SQ, bool DBG = false, bool DUMP = false, int CTX = 0>
-__global__ __launch_bounds__(256, (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
+__global__ __launch_bounds__(256, G::BF16S ? CF_G16WB_MINW : (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
                                                                   float* __restrict__ ldj_acc, const float* __restrict__ ws,
                                                                   int B, int64_t xbs, float* __restrict__ dbg, StepTape tp,
                                                                   const float* __restrict__ sb = nullptr) {
@@ -1444,6 +1470,8 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
         case 27: CF_STEP(G64v3); break;
         case 4: rc = in_squeeze ? launch_step_small<G8w, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))           // variant 4 at C = 8
                                : launch_step_small<G8w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
+        case 14: rc = in_squeeze ? launch_step_small<G16wb, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))        // variant 6: bf16-piece form of variant 4
+                                 : launch_step_small<G16wb, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
         case 12: rc = in_squeeze ? launch_step_small<G16w, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))         // variant 4:
                                 : launch_step_small<G16w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;  // Winograd form of the 3x3
         case 20: CF_STEP(G32w); break;
@@ -1498,6 +1526,11 @@ int cf_flow_step_fwd_chain(const float* x, float* z, float* ldj_acc, const void*
     return 0;
 }
 
+static bool bf16_split_enabled() {
+    static const bool v = [] { const char* e = getenv("CONTEXTFLOW_BF16_SPLIT"); return e && e[0] == '1'; }();
+    return v;
+}
+
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
                      int64_t x_bstride, int in_squeeze, cf_stream_t stream) {
     // Small batches are latency-bound by the serial work of ONE workgroup (a launch of < 256 workgroups leaves CUs
@@ -1511,6 +1544,8 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     const bool direct_only = direct_conv_only();
     if (!direct_only && (sid == 0 || sid == 1 || (sid == 2 && B >= 256 * G32::SPW))) flags = 4 << 16;
     if (!direct_only && sid == 3 && B >= 256 * G64w2::SPW) flags = 5 << 16;      // 4x4: 8 samples per workgroup, rows split over wave pairs
+    // CONTEXTFLOW_BF16_SPLIT=1 (off by default): the 16x16 level's Winograd-domain products as bf16-piece MFMAs (G16wb)
+    if (!direct_only && sid == 1 && bf16_split_enabled()) flags = 6 << 16;
     // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
     if ((sid == 2 && B <= 512) || (sid == 3 && B <= CF_RS_MAXB_C64)) {
         CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);

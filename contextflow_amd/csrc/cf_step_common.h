@@ -60,7 +60,10 @@ struct Geo {
     static constexpr int OFF_SA2 = OFF_SA1 + (HID16 ? SG1 * 256 : 0);
     // Winograd F(2x2,3x3) form of the 3x3 (PIPE == 3, winograd_phase2 below): U = G w G^T for the 16 positions, packed as
     // 16x16x4 A fragments: [position][16-row tile][group of 4 k-steps][lane][4]
-    static constexpr bool WINO = (PIPE_ == 3);
+    static constexpr bool WINO = (PIPE_ == 3 || PIPE_ == 4);
+    // PIPE == 4: the Winograd-domain products on the bf16 matrix cores - every fp32 operand as three bf16 pieces, the six piece
+    // products with i + j <= 2 accumulated in fp32 (winograd_phase2; tools/micro/bf16_split_gemm.hip: the error of the f32 MFMA)
+    static constexpr bool BF16S = (PIPE_ == 4);
     static constexpr int RT16 = HID / 16, KG4 = HID / 16;         // row tiles / k-step groups of the 16x16x4 products over HID
     static constexpr int OFF_AW = OFF_SA2 + (HID16 ? 9 * 256 : 0);
     // one-sample-per-workgroup form of the 4x4 level for small batches (k_flow_step_rs16, cf_step.hip): 16x16x4 A fragments
@@ -70,7 +73,13 @@ struct Geo {
     static constexpr int OFF_RA0 = OFF_RB3 + C, OFF_RA1 = OFF_RA0 + (C / 16) * (C / 16) * 256;
     static constexpr int OFF_RA2 = OFF_RA1 + (HID / 16) * (HALF / 16) * 256, OFF_RA3 = OFF_RA2 + (HID / 16) * 9 * (HID / 16) * 256;
     static constexpr int R16_END = OFF_RA3 + (C / 16) * (HID / 16) * 256;
-    static constexpr int WS_FLOATS = RS16 ? R16_END : OFF_AW + 16 * HID * HID;
+    static constexpr int WS_END0 = RS16 ? R16_END : OFF_AW + 16 * HID * HID;
+    // bf16 pieces of the Winograd-domain weights (BF16S): [position][16-row tile][32-channel block][piece][lane] 16 bytes =
+    // 8 bf16: element j of lane l = piece of U[pos][16 rt + (l & 15)][32 kb + 4 j + (l >> 4)] (the hardware's k index (l >> 4, j)
+    // stands for channel 4 j + (l >> 4): the eight values a lane of winograd_phase2 forms over eight consecutive k-steps)
+    static constexpr int KB32 = HID / 32;
+    static constexpr int OFF_AWB = WS_END0;
+    static constexpr int WS_FLOATS = WS_END0 + 16 * RT16 * KB32 * 3 * 256;
     static constexpr int PP = 2 * W + 2 * H + 4;      // fold slots per sample: 2 patched rows, 2 patched columns, 4 corners
     static constexpr int RS = PATCH ? ((PIX + SPW * PP + 1 + 3) & ~3) : PIX;
     static constexpr int LDS_FLOATS = (HALF + HID) * RS;
@@ -510,8 +519,10 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
         auto load = [&](int xi, const int (&r1)[NT], const int (&r2)[NT], int g, WFrag& fo, WRaw& o) {
             const int nu = g / KGC, kk = g % KGC;
             const int fr = frc + ((xi * 4 + nu) * RT16 * KG4 + kk) * 256;
+            if constexpr (!G::BF16S) {
 #pragma unroll
-            for (int rt = 0; rt < RTW; ++rt) fo.a[rt] = ws_frag(rs, lane, fr + (rt0 + rt) * KG4 * 256);
+                for (int rt = 0; rt < RTW; ++rt) fo.a[rt] = ws_frag(rs, lane, fr + (rt0 + rt) * KG4 * 256);
+            }
             constexpr int NC[4] = {2, 1, 0, 1}, C0[4] = {0, 1, 0, 3}, C1[4] = {2, 0, 0, 0};
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct)
@@ -531,6 +542,9 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                     }
         };
         f32x2w A1[KGC][NT][2], A2[KGC][NT][2];
+        float4 wp[RTW][3];                 // BF16S: the weight pieces of the current 32-channel block
+        f32x2w vb[2][NT][2];               // BF16S: the Winograd-domain values of its two k-groups
+        static_assert(!G::BF16S || KGC % 2 == 0, "32-channel blocks");
         int r1[NT], r2[NT], r1n[NT], r2n[NT];
         rows_of(0, r1, r2);
         load(0, r1, r2, 0, fa[0], raw[0]);
@@ -575,13 +589,63 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                                 v[ct][e2] = A1[kk][ct][e2] - a3;
                             }
                         }
+                    if constexpr (!G::BF16S) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int rt = 0; rt < RTW; ++rt)
+                            for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
-                            for (int ct = 0; ct < NT; ++ct)
-                                M[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[ct][e >> 1][e & 1], M[ct][rt], 0, 0, 0);
+                                for (int ct = 0; ct < NT; ++ct)
+                                    M[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4e(oa.a[rt], e), v[ct][e >> 1][e & 1], M[ct][rt], 0, 0, 0);
+                    } else {
+                        // two k-groups = one 32-channel block: the lane's eight Winograd-domain values (channel 4 j + lg, j = 4 (kk & 1)
+                        // + 2 e2 + h) are split into three bf16 pieces each and meet the pre-split weight pieces in six MFMAs per tile
+                        (void)oa;
+                        if (!(kk & 1)) {        // the block's weight pieces, requested one k-group ahead of their use
+#pragma unroll
+                            for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+                                for (int pz = 0; pz < 3; ++pz)
+                                    wp[rt][pz] = ws_frag(rs, lane, G::OFF_AWB + ((((xi * 4 + nu) * RT16 + rt0 + rt) * G::KB32 + (kk >> 1)) * 3 + pz) * 256);
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                            for (int e2 = 0; e2 < 2; ++e2) vb[kk & 1][ct][e2] = v[ct][e2];
+                        if (kk & 1) {
+                            typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+                            float4 bp[NT][3];
+#pragma unroll
+                            for (int ct = 0; ct < NT; ++ct) {
+                                unsigned p0[8], p1[8], p2[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {             // (scalar on purpose: packed subtractions measured 1.7 % slower)
+                                    const float xv = vb[j >> 2][ct][(j >> 1) & 1][j & 1];
+                                    const unsigned u0 = __float_as_uint(xv) & 0xffff0000u;
+                                    const float r1 = xv - __uint_as_float(u0);
+                                    const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+                                    const float r2 = r1 - __uint_as_float(u1);
+                                    p0[j] = u0; p1[j] = u1; p2[j] = __float_as_uint(r2);
+                                }
+                                auto pack = [](const unsigned (&p)[8]) {   // element j in bits 16 (j & 1) .. of dword j / 2
+                                    return make_float4(__uint_as_float(__builtin_amdgcn_perm(p[1], p[0], 0x07060302u)),
+                                                       __uint_as_float(__builtin_amdgcn_perm(p[3], p[2], 0x07060302u)),
+                                                       __uint_as_float(__builtin_amdgcn_perm(p[5], p[4], 0x07060302u)),
+                                                       __uint_as_float(__builtin_amdgcn_perm(p[7], p[6], 0x07060302u)));
+                                };
+                                bp[ct][0] = pack(p0); bp[ct][1] = pack(p1); bp[ct][2] = pack(p2);
+                            }
+                            constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // small terms first
+#pragma unroll
+                            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                                for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+                                    for (int ct = 0; ct < NT; ++ct)
+                                        M[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, wp[rt][order[t][0]]),
+                                                                                            __builtin_bit_cast(bf16x8w, bp[ct][order[t][1]]), M[ct][rt], 0, 0, 0);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // Y[i][j] += A^T[i][xi] A^T[j][nu] M
@@ -1050,6 +1114,7 @@ using G64v1 = Geo<64, 4, 4, 16, 1, 1>;
 using G64v2 = Geo<64, 4, 4, 8, 1>;
 using G64v3 = Geo<64, 4, 4, 16, 0>;
 using G8w = Geo<8, 16, 16, 1, 3>;
+using G16wb = Geo<16, 16, 16, 1, 4>;     // ... with the Winograd-domain products as bf16-piece MFMAs (CONTEXTFLOW_BF16_SPLIT=1)
 using G16w = Geo<16, 16, 16, 1, 3>;      // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2); 16x16: in k_flow_step_small
 using G32w = Geo<32, 8, 8, 4, 3>;
 using G64w = Geo<64, 4, 4, 16, 3>;

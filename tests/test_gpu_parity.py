@@ -1582,6 +1582,51 @@ def test_chained_transformer_steps_equal_single_launches(L, monkeypatch):
             assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), B
 
 
+@pytest.mark.parametrize("B,squeeze", [(777, False), (64, True)])
+def test_bf16_piece_form_of_the_16x16_step_equals_the_fp32_forms(L, B, squeeze):
+    """CONTEXTFLOW_BF16_SPLIT=1 (off by default) runs the 16x16 level's Winograd-domain products on the bf16 matrix cores:
+    every fp32 operand as three bf16 pieces (exact), the six piece products with i + j <= 2 accumulated in fp32.  Through the
+    debug entry (variant 6) on trained-like weights: z and the log-det agree with the fp32 Winograd kernel (variant 4) as
+    closely as that one agrees with the direct form - the dropped pairs are below 2^-24 of a product."""
+    import ctypes
+    import contextflow_amd as cfa
+    from contextflow_amd.layers import _hip
+    Lr = cfa.layers
+    lib = _hip.lib()
+    fn = lib.cf_flow_step_fwd_debug
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    C, H, W = 16, 16, 16
+    torch.manual_seed(5)
+    conv, act, cpl = Lr.Conv1x1((C, H, W)).to(DEV), Lr.ActNorm((C, H, W)).to(DEV), Lr.Coupling(C, (3, 3), (1, 1)).to(DEV)
+    with torch.no_grad():
+        for p in cpl.parameters():
+            p.normal_(0, 0.1)
+        act.NN_t.normal_(0, 0.2)
+        act.NN_logs.normal_(0, 0.2)
+    x = torch.randn(B, C // 4, 2 * H, 2 * W, device=DEV) if squeeze else torch.randn(B, C, H, W, device=DEV)
+    ws = torch.empty(lib.cf_flow_step_ws_bytes(C, H, W), device=DEV, dtype=torch.uint8)
+    f, pp = _hip.f32, _hip.p
+    c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
+    _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
+              pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
+              pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, _hip.stream())
+    out = {}
+    for var in (3, 4, 6):
+        z = torch.full((B, C, H, W), float("nan"), device=DEV)
+        ldj = torch.zeros(B, device=DEV)
+        _hip.check(fn(pp(x), pp(z), pp(ldj), pp(ws), B, C, H, W, C * H * W, int(squeeze), None, var << 16, _hip.stream()), "debug step")
+        out[var] = (z, ldj)
+    zs = out[3][0].abs().max().item()
+    d46 = (out[4][0] - out[6][0]).abs().max().item()
+    d43 = (out[4][0] - out[3][0]).abs().max().item()
+    assert torch.isfinite(out[6][0]).all() and torch.isfinite(out[6][1]).all()
+    assert d46 <= max(2.0 * d43, 4e-7 * zs), (d46, d43, zs)
+    l46 = (out[4][1] - out[6][1]).abs().max().item()
+    l43 = (out[4][1] - out[3][1]).abs().max().item()
+    assert l46 <= max(2.0 * l43, 2e-5), (l46, l43)
+
+
 @pytest.mark.parametrize("name,coupling", [("mnist", "maf"), ("smap", "conv"), ("smap", "maf")])
 def test_training_with_generic_conv_couplings(L, name, coupling):
     """`--coupling maf` (MaskedCoupling, ar.py) and `--coupling conv` on a time-series topology ((3,1) kernels, model.py:114):
