@@ -35,6 +35,7 @@ struct StepPackBatch {
     const float *Wm[kPrepBatch], *t[kPrepBatch], *logs[kPrepBatch], *w1[kPrepBatch], *b1[kPrepBatch], *w2[kPrepBatch], *b2[kPrepBatch],
         *w3[kPrepBatch], *b3[kPrepBatch];
     float* ws[kPrepBatch];
+    int pieces;                          // also the bf16 pieces of the Winograd-domain weights (CONTEXTFLOW_BF16_SPLIT=1)
 };
 template <class G>
 __global__ __launch_bounds__(256) void k_step_pack(const StepPackBatch pb) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void k_step_pack(const StepPackBatch pb) {
                 for (int b = 0; b < 3; ++b) u += Gm[xi][a] * Gm[nu][b] * (double)wk[a * 3 + b];
             ws[G::OFF_AW + e] = (float)u;
         }
-        if constexpr (G::KB32 > 0) {
+        if (G::KB32 > 0 && G::HID == 32 && pb.pieces) {     // (the 16x16 level is the only consumer so far)
             // the same values as three bf16 pieces each (truncation split: exact, u = p0 + p1 + p2), in the operand layout of
             // v_mfma_f32_16x16x32_bf16 with k index (lane >> 4, j) = channel 4 j + (lane >> 4) of a 32-channel block
             unsigned short* wb = reinterpret_cast<unsigned short*>(ws + G::OFF_AWB);
@@ -1283,6 +1284,12 @@ int launch_prepare_inv(const float* Wm, const float* t, const float* logs, float
     return 0;
 }
 
+static int g_bf16_split = -1;             // -1: the environment decides (CONTEXTFLOW_BF16_SPLIT=1); 0 / 1: set by cf_bf16_split
+static bool bf16_split_enabled() {
+    static const bool v = [] { const char* e = getenv("CONTEXTFLOW_BF16_SPLIT"); return e && e[0] == '1'; }();
+    return g_bf16_split < 0 ? v : g_bf16_split != 0;
+}
+
 template <class G>
 int launch_step_inv(const float* z, float* x, const float* ws, const float* wsi, int B, int64_t zbs, int x_unsq, hipStream_t s) {
     constexpr size_t lds_bytes = (size_t)G::LDS_FLOATS * sizeof(float);
@@ -1327,6 +1334,7 @@ int cf_flow_step_prepare_batch(int n, const float* const* Wm, const float* const
     for (int i0 = 0; i0 < n; i0 += kPrepBatch) {
         const int m = n - i0 < kPrepBatch ? n - i0 : kPrepBatch;
         StepPackBatch pb{};
+        pb.pieces = bf16_split_enabled() ? 1 : 0;
         for (int i = 0; i < m; ++i) {
             const int j = i0 + i;
             CF_REQUIRE(Wm[j] && t[j] && logs[j] && w1[j] && b1[j] && w2[j] && b2[j] && w3[j] && b3[j] && ws[j] &&
@@ -1526,9 +1534,11 @@ int cf_flow_step_fwd_chain(const float* x, float* z, float* ldj_acc, const void*
     return 0;
 }
 
-static bool bf16_split_enabled() {
-    static const bool v = [] { const char* e = getenv("CONTEXTFLOW_BF16_SPLIT"); return e && e[0] == '1'; }();
-    return v;
+// on = 0 / 1: switch the bf16-piece form of the 16x16 level off / on for the tables packed and the steps launched from now on
+// (overrides CONTEXTFLOW_BF16_SPLIT); on < 0: query.  Returns the setting in force.
+int cf_bf16_split(int on) {
+    if (on >= 0) g_bf16_split = on ? 1 : 0;
+    return bf16_split_enabled() ? 1 : 0;
 }
 
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "cf_flow_step_bwd_taped": (_c_int, [_c_p] * 9 + [_c_int] * 5 + [_c_p]),
     "cf_flow_step_fwd_taped": (_c_int, [_c_p] * 8 + [_c_int] * 4 + [_c_i64, _c_int, _c_p]),
     "cf_step_param_grads": (_c_int, [_c_p] * 7 + [_c_int] + [_c_p] * 3 + [_c_int, _c_p]),
+    "cf_bf16_split": (_c_int, [_c_int]),
     "cf_adamw_step_batch": (_c_int, [_c_int] + [_c_p] * 6 + [ctypes.c_double] * 5 + [_c_int, _c_p]),
     "cf_step_param_grads_batch": (_c_int, [_c_int] + [_c_p] * 7 + [_c_int] + [_c_p] * 3 + [_c_int, _c_p]),
     "cf_wgrad_ws_bytes": (_c_i64, [_c_int] * 6),

@@ -218,6 +218,11 @@ int cf_flow_step_bwd_prepare_batch(int n, const float* const* Wm, const float* c
                                    const float* const* w2, const float* const* w3, void* const* wsb, int C, int H, int W,
                                    cf_stream_t stream);
 
+/* The 16x16 level's Winograd-domain products as exact bf16-piece MFMAs (default: the environment variable
+ * CONTEXTFLOW_BF16_SPLIT=1, else off).  on = 0 / 1 sets it for the tables packed and the steps launched from now on, on < 0 queries;
+ * returns the setting in force.  Tables packed while it was off do not hold the weight pieces: prepare again after switching on. */
+int cf_bf16_split(int on);
+
 /* z = step(x); ldj_acc[b] += ldj_const + sum log_s   (ldj_acc is the running per-sample log-det).
  * in_squeeze != 0: x is the UN-squeezed (B, C/4, 2H, 2W) tensor and Squeeze((2,2)) (squeeze.py:10-11)
  * is folded into the kernel's operand addressing (no separate index kernel, no extra HBM pass).

@@ -1608,9 +1608,14 @@ def test_bf16_piece_form_of_the_16x16_step_equals_the_fp32_forms(L, B, squeeze):
     ws = torch.empty(lib.cf_flow_step_ws_bytes(C, H, W), device=DEV, dtype=torch.uint8)
     f, pp = _hip.f32, _hip.p
     c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
-    _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
-              pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
-              pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, _hip.stream())
+    was = lib.cf_bf16_split(-1)
+    lib.cf_bf16_split(1)                 # the tables get the weight pieces
+    try:
+        _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
+                  pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
+                  pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, _hip.stream())
+    finally:
+        lib.cf_bf16_split(was)
     out = {}
     for var in (3, 4, 6):
         z = torch.full((B, C, H, W), float("nan"), device=DEV)

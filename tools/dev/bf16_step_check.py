@@ -23,6 +23,7 @@ with torch.no_grad():
     act.NN_t.normal_(0, 0.1); act.NN_logs.normal_(0, 0.1)
 x = torch.randn(B, C, H, W, device=dev)
 ws = torch.empty(lib.cf_flow_step_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+lib.cf_bf16_split(1)
 f, pp = _hip.f32, _hip.p
 c1, c2, c3 = cpl.NN[0], cpl.NN[2], cpl.NN[4]
 _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach())), pp(f(act.NN_logs.detach())),
