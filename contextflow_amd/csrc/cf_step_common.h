@@ -542,7 +542,16 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                     }
         };
         f32x2w A1[KGC][NT][2], A2[KGC][NT][2];
-        float4 wp[RTW][3];                 // BF16S: the weight pieces of the current 32-channel block
+        float4 wpb[2][RTW][3];             // BF16S: the weight pieces of the current and of the next 32-channel block
+        auto wp_load = [&](float4 (&dst)[RTW][3], int xi_, int nu_, int kb_) {
+#pragma unroll
+            for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz)
+                    dst[rt][pz] = ws_frag(rs, lane, G::OFF_AWB + ((((xi_ * 4 + nu_) * RT16 + rt0 + rt) * G::KB32 + kb_) * 3 + pz) * 256);
+        };
+        if constexpr (G::BF16S) wp_load(wpb[0], 0, 0, 0);
+        static_assert(!G::BF16S || (4 * G::KB32) % 2 == 0, "static ping-pong of the weight pieces across xi");
         f32x2w vb[2][NT][2];               // BF16S: the Winograd-domain values of its two k-groups
         static_assert(!G::BF16S || KGC % 2 == 0, "32-channel blocks");
         int r1[NT], r2[NT], r1n[NT], r2n[NT];
@@ -601,13 +610,15 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                         // two k-groups = one 32-channel block: the lane's eight Winograd-domain values (channel 4 j + lg, j = 4 (kk & 1)
                         // + 2 e2 + h) are split into three bf16 pieces each and meet the pre-split weight pieces in six MFMAs per tile
                         (void)oa;
-                        if (!(kk & 1)) {        // the block's weight pieces, requested one k-group ahead of their use
-#pragma unroll
-                            for (int rt = 0; rt < RTW; ++rt)
-#pragma unroll
-                                for (int pz = 0; pz < 3; ++pz)
-                                    wp[rt][pz] = ws_frag(rs, lane, G::OFF_AWB + ((((xi * 4 + nu) * RT16 + rt0 + rt) * G::KB32 + (kk >> 1)) * 3 + pz) * 256);
+                        // the weight pieces of a 32-channel block are requested one BLOCK ahead of their use (double buffer: an L2
+                        // round trip is longer than a block's vector work); block index q counts (nu, kb) within xi, then the next xi
+                        constexpr int NBX = 4 * G::KB32;                        // blocks per xi
+                        const int q = nu * G::KB32 + (kk >> 1);
+                        if (!(kk & 1)) {
+                            const int qn = q + 1 < NBX ? q + 1 : 0, xq = q + 1 < NBX ? xi : xn;
+                            wp_load(wpb[(q + 1) & 1], xq, qn / G::KB32, qn % G::KB32);
                         }
+                        auto& wp = wpb[q & 1];
 #pragma unroll
                         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
