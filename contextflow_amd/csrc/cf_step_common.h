@@ -518,7 +518,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
         WRaw raw[2];
         auto load = [&](int xi, const int (&r1)[NT], const int (&r2)[NT], int g, WFrag& fo, WRaw& o) {
             const int nu = g / KGC, kk = g % KGC;
+#ifdef CF_ABL_FIXEDW                       // timing-only probe: every group reads the SAME fragments (L1-resident; wrong results)
+            const int fr = frc + (0 * xi * nu * kk) * 256;
+#else
             const int fr = frc + ((xi * 4 + nu) * RT16 * KG4 + kk) * 256;
+#endif
             if constexpr (!G::BF16S) {
 #pragma unroll
                 for (int rt = 0; rt < RTW; ++rt) fo.a[rt] = ws_frag(rs, lane, fr + (rt0 + rt) * KG4 * 256);
@@ -548,7 +552,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
             for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
                 for (int pz = 0; pz < 3; ++pz)
+#ifdef CF_ABL_FIXEDW
+                    dst[rt][pz] = ws_frag(rs, lane, G::OFF_AWB + ((((0 * xi_ * nu_ * kb_) * RT16 + rt0 + rt) * G::KB32) * 3 + pz) * 256);
+#else
                     dst[rt][pz] = ws_frag(rs, lane, G::OFF_AWB + ((((xi_ * 4 + nu_) * RT16 + rt0 + rt) * G::KB32 + kb_) * 3 + pz) * 256);
+#endif
         };
         if constexpr (G::BF16S) wp_load(wpb[0], 0, 0, 0);
         static_assert(!G::BF16S || (4 * G::KB32) % 2 == 0, "static ping-pong of the weight pieces across xi");
@@ -632,6 +640,10 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) {             // (scalar on purpose: packed subtractions measured 1.7 % slower)
                                     const float xv = vb[j >> 2][ct][(j >> 1) & 1][j & 1];
+#ifdef CF_ABL_NOSPLIT                                                     // timing-only probe: no split arithmetic (wrong results)
+                                    p0[j] = p1[j] = p2[j] = __float_as_uint(xv);
+                                    continue;
+#endif
                                     const unsigned u0 = __float_as_uint(xv) & 0xffff0000u;
                                     const float r1 = xv - __uint_as_float(u0);
                                     const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
@@ -647,8 +659,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
                                 bp[ct][0] = pack(p0); bp[ct][1] = pack(p1); bp[ct][2] = pack(p2);
                             }
                             constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // small terms first
+#ifndef CF_ABL_NPAIRS
+#define CF_ABL_NPAIRS 6                                                     // timing-only probe: fewer piece pairs (wrong results)
+#endif
 #pragma unroll
-                            for (int t = 0; t < 6; ++t)
+                            for (int t = 6 - CF_ABL_NPAIRS; t < 6; ++t)
 #pragma unroll
                                 for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
