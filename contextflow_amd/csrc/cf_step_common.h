@@ -201,6 +201,35 @@ __device__ __forceinline__ void dense_phase(f32x16 (&acc)[RT][G::PTW], ws_rsrc_t
     dense_phase_impl<G, KS, NG, RT>(acc, [&](int i) { return ws_frag(rs, lane, foff + i * 256); }, plane, pix, lane);
 }
 
+// Streaming accesses of the step kernels (x is read once, z written once per step): non-temporal, so that they do not displace
+// the weight fragments every workgroup re-reads from L1 / L2 (-DCF_STREAM_NT=0: plain accesses, A/B)
+#ifndef CF_STREAM_NT
+#define CF_STREAM_NT 1
+#endif
+typedef float cf_f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 cf_ld_stream(const float4* p) {
+#if CF_STREAM_NT
+    const cf_f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const cf_f32x4v*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float cf_ldf_stream(const float* p) {
+#if CF_STREAM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void cf_st_stream(float4* p, const float4 v) {
+#if CF_STREAM_NT
+    __builtin_nontemporal_store(cf_f32x4v{v.x, v.y, v.z, v.w}, reinterpret_cast<cf_f32x4v*>(p));
+#else
+    *p = v;
+#endif
+}
+
 // ---- wave-local staging of activations with 16-byte global accesses ---------------------------------
 // A wave owns WPX = 32*PTW pixel columns.  Item n = i*64 + lane enumerates its C x WPX block of x.
 template <class G, bool SQ>
@@ -214,13 +243,13 @@ __device__ __forceinline__ void x_load(float4 (&xr)[G::C * G::PTW / 8], const fl
         if constexpr (!SQ) {
             const int ch = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
             const int b = min(tb0 + col / HW, B - 1);
-            xr[i] = *reinterpret_cast<const float4*>(x + (int64_t)b * xbs + ch * HW + col % HW);
+            xr[i] = cf_ld_stream(reinterpret_cast<const float4*>(x + (int64_t)b * xbs + ch * HW + col % HW));
         } else {
             // un-squeezed row (2y+i1), 4 consecutive floats = channels (4c'+2i1, +1) of squeezed pixels (x, x+1)
             const int cp = n / (WPX / 2), col = wave * WPX + 2 * (n % (WPX / 2));
             const int b = min(tb0 + col / HW, B - 1);
             const int p = col % HW, yy = p / W, xx = p % W;
-            xr[i] = *reinterpret_cast<const float4*>(x + (int64_t)b * xbs + (cp >> 1) * 4 * HW + (2 * yy + (cp & 1)) * 2 * W + 2 * xx);
+            xr[i] = cf_ld_stream(reinterpret_cast<const float4*>(x + (int64_t)b * xbs + (cp >> 1) * 4 * HW + (2 * yy + (cp & 1)) * 2 * W + 2 * xx));
         }
     }
 }
@@ -256,8 +285,8 @@ __device__ __forceinline__ void rows_store(float* __restrict__ z, const float* _
         const int idx = n / (WPX / 4), col = wave * WPX + 4 * (n % (WPX / 4));
         const int b = tb0 + col / HW;
         if (idx < NROWS && b < B)
-            *reinterpret_cast<float4*>(z + (int64_t)b * C * HW + (int64_t)(ch0 + idx) * HW + col % HW) =
-                *reinterpret_cast<const float4*>(&plane[idx * PIX + col]);
+            cf_st_stream(reinterpret_cast<float4*>(z + (int64_t)b * C * HW + (int64_t)(ch0 + idx) * HW + col % HW),
+                         *reinterpret_cast<const float4*>(&plane[idx * PIX + col]));
     }
     cf_wave_sync();                      // ... read back before anyone reuses the words
 }
@@ -291,7 +320,11 @@ __device__ __forceinline__ cf_i32x4 tile_rsrc_words(const float* base, int bytes
 __device__ __forceinline__ void tile_store_b128(const cf_i32x4 rs, int voff, int soff, const float4 v) {
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const f32x4s d = {v.x, v.y, v.z, v.w};
+#if CF_STREAM_NT      // planes of the tape / gradient planes: written once, read by another kernel - non-temporal, as the z rows
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" : : "v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
+#else
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(d), "v"(voff), "s"(rs), "s"(soff) : "memory");
+#endif
 }
 
 template <class G, int NROWS, int CT>
