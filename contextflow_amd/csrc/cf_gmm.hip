@@ -117,6 +117,14 @@ __device__ __forceinline__ void gmm_logprob_body(const float* __restrict__ x, co
         for (int q = 0; q < XITEMS; ++q) {
             const int e = q * 256 + tid, row = e >> 3, c4 = (e & 7) * 4;
             const float* rp = x + (int64_t)(KEYED ? rows[min(row, nvalid - 1)] : min(b0 + row, B - 1)) * xbs;
+#ifndef CF_GMM_NT
+#define CF_GMM_NT 1                  // x is read once per component block: non-temporal, the parameter rows every workgroup re-reads stay cached
+#endif
+            if (CF_GMM_NT && full) {
+                typedef float f32x4nt __attribute__((ext_vector_type(4)));
+                const f32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(rp + d0 + c4));
+                px[q] = make_float4(v[0], v[1], v[2], v[3]);
+            } else
             px[q] = full ? *reinterpret_cast<const float4*>(rp + d0 + c4) : ld4_tail<VEC>(rp, d0 + c4, dhi);
         }
 #pragma unroll
