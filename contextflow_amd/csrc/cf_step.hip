@@ -396,6 +396,14 @@ __device__ __forceinline__ void flow_step_small_body(const float* x, float* z, f
     x_load<G, SQ>(xr, x, xbs, tile, B, wave, lane);
     const ws_rsrc_t rs = ws_rsrc(ws, G::WS_FLOATS);
     x_to_lds<G, SQ>(xr, H1, wave, lane);
+    if constexpr (G::LDS_W > 0) {
+        // the Winograd-domain weights of the 3x3 into LDS (16 KB, fragment order as packed): read by every wave of phase 2,
+        // two workgroup barriers from here
+        float* WL = lds + (HALF + HID) * PIX;
+#pragma unroll
+        for (int i = 0; i < G::LDS_W / 1024; ++i)
+            *reinterpret_cast<float4*>(WL + (i * 256 + tid) * 4) = ws_frag(rs, tid, G::OFF_AW + i * 1024);
+    }
     cf_wave_sync();
 
     // ================= phase 0: [y0 | y1] = (e^{-logs} Wm) x - t e^{-logs}   (conv1x1.py:54 + actnorm.py:59)

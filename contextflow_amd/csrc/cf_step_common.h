@@ -82,7 +82,14 @@ struct Geo {
     static constexpr int WS_FLOATS = WS_END0 + 16 * RT16 * KB32 * 3 * 256;
     static constexpr int PP = 2 * W + 2 * H + 4;      // fold slots per sample: 2 patched rows, 2 patched columns, 4 corners
     static constexpr int RS = PATCH ? ((PIX + SPW * PP + 1 + 3) & ~3) : PIX;
-    static constexpr int LDS_FLOATS = (HALF + HID) * RS;
+    // C = 8 (HID = 16) in the Winograd form: all 16 Winograd-domain weight matrices are 16 KB - staged into LDS once per workgroup
+    // (LDS_W floats behind the planes) instead of streamed per wave through L1 (that delivery costs 6.7 % of the level:
+    // -DCF_ABL_FIXEDW); the larger levels fill their LDS with planes
+#ifndef CF_WINO_LDSW
+#define CF_WINO_LDSW 1
+#endif
+    static constexpr int LDS_W = (CF_WINO_LDSW && PIPE_ == 3 && HID == 16 && H == 16 && W == 16 && SPW == 1) ? 16 * HID * HID : 0;
+    static constexpr int LDS_FLOATS = (HALF + HID) * RS + LDS_W;
     // waves per SIMD the register allocator must leave room for = workgroups per CU the LDS footprint admits
     static constexpr int MINW = (160 * 1024) / (LDS_FLOATS * 4) >= 4 ? 4 : ((160 * 1024) / (LDS_FLOATS * 4) >= 2 ? 2 : 1);
     static_assert(PIX % 128 == 0 && PTW >= 1, "workgroup must own a multiple of 128 pixels");
@@ -556,7 +563,11 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
 #else
             const int fr = frc + ((xi * 4 + nu) * RT16 * KG4 + kk) * 256;
 #endif
-            if constexpr (!G::BF16S) {
+            if constexpr (G::LDS_W > 0) {            // staged by the kernel (k_flow_step_small) behind the planes, same fragment order
+#pragma unroll
+                for (int rt = 0; rt < RTW; ++rt)
+                    fo.a[rt] = *reinterpret_cast<const float4*>(lds + (HALF + HID) * G::RS + (fr - frc) + (rt0 + rt) * KG4 * 256 + lane * 4);
+            } else if constexpr (!G::BF16S) {
 #pragma unroll
                 for (int rt = 0; rt < RTW; ++rt) fo.a[rt] = ws_frag(rs, lane, fr + (rt0 + rt) * KG4 * 256);
             }
