@@ -120,6 +120,25 @@ __global__ __launch_bounds__(256) void k_step_pack(const StepPackBatch pb) {
                     wb[((((int64_t)(pos * G::RT16 + rt16) * G::KB32 + kb) * 3 + pz) * 64 + ln) * 8 + j] = (unsigned short)(pc[pz] >> 16);
             }
         }
+        if (G::KB32 > 0 && G::HID == 32 && pb.pieces) {
+            // the taps of NN.2 themselves as three bf16 pieces each, operand layout of v_mfma_f32_16x16x32_bf16 in the hardware's own k
+            // order (direct_bf16_phases): element j of lane l = NN.2[16 rt + (l & 15)][32 kb + 8 (l >> 4) + j][tap]
+            unsigned short* wb = reinterpret_cast<unsigned short*>(ws + G::OFF_ADB);
+            for (int e = gtid; e < 9 * G::RT16 * G::KB32 * 64 * 8; e += gsz) {
+                const int j = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+                const int kb = q % G::KB32, rt16 = (q / G::KB32) % G::RT16, tap = q / (G::KB32 * G::RT16);
+                const int co = rt16 * 16 + (ln & 15), ci = 32 * kb + 8 * (ln >> 4) + j;
+                const float uf = w2[((int64_t)co * HID + ci) * 9 + tap];
+                const unsigned u0 = __float_as_uint(uf) & 0xffff0000u;
+                const float r1 = uf - __uint_as_float(u0);
+                const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(u1);
+                const unsigned pc[3] = {u0, u1, __float_as_uint(r2)};
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz)
+                    wb[((((int64_t)(tap * G::RT16 + rt16) * G::KB32 + kb) * 3 + pz) * 64 + ln) * 8 + j] = (unsigned short)(pc[pz] >> 16);
+            }
+        }
     }
     if constexpr (G::RS16) {
         // k_flow_step_rs16: natural row order, element ((rt * NG + gi) * 64 + lane) * 4 + j = A[16 rt + (lane & 15)][4 (4 gi + j) + (lane >> 4)]
@@ -456,7 +475,10 @@ __device__ __forceinline__ void flow_step_small_body(const float* x, float* z, f
     (void)plane_mask_store;
 
     // ================= phases 1, 2: h2 = relu(NN.2 (*) relu(NN.0 y0 + b) + b)   (coupling.py:26-27)
-    if constexpr (!G::HID16) {
+    if constexpr (G::DBF) {
+        static_assert(!DUMP && !DBG && CTX != 2, "evaluation form only");
+        direct_bf16_phases<G>(lds, ws, rs, lane, wave);
+    } else if constexpr (!G::HID16) {
         const int li = lane & 31;
         int pix[PTW], pin[PTW];
 #pragma unroll
@@ -602,8 +624,11 @@ __device__ __forceinline__ void flow_step_small_body(const float* x, float* z, f
 #ifndef CF_G16WB_MINW
 #define CF_G16WB_MINW 3
 #endif
+#ifndef CF_G16DB_MINW
+#define CF_G16DB_MINW 3
+#endif
 template <class G, bool SQ, bool DBG = false, bool DUMP = false, int CTX = 0>
-__global__ __launch_bounds__(256, G::BF16S ? CF_G16WB_MINW : (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
+__global__ __launch_bounds__(256, G::DBF ? CF_G16DB_MINW : G::BF16S ? CF_G16WB_MINW : (G::WINO && DUMP) ? 3 : (G::WINO && G::C == 16) ? CF_G16W_MINW : G::MINW) void k_flow_step_small(const float* __restrict__ x, float* __restrict__ z,
                                                                   float* __restrict__ ldj_acc, const float* __restrict__ ws,
                                                                   int B, int64_t xbs, float* __restrict__ dbg, StepTape tp,
                                                                   const float* __restrict__ sb = nullptr) {
@@ -1292,11 +1317,12 @@ int launch_prepare_inv(const float* Wm, const float* t, const float* logs, float
     return 0;
 }
 
-static int g_bf16_split = -1;             // -1: the environment decides (CONTEXTFLOW_BF16_SPLIT=1); 0 / 1: set by cf_bf16_split
-static bool bf16_split_enabled() {
-    static const bool v = [] { const char* e = getenv("CONTEXTFLOW_BF16_SPLIT"); return e && e[0] == '1'; }();
-    return g_bf16_split < 0 ? v : g_bf16_split != 0;
+static int g_bf16_split = -1;             // -1: the environment decides (CONTEXTFLOW_BF16_SPLIT=1|2); 0 / 1 / 2: set by cf_bf16_split
+static int bf16_split_mode() {            // 0 off, 1 Winograd-domain products as bf16 pieces (G16wb), 2 direct 3x3 on bf16 pieces (G16db)
+    static const int v = [] { const char* e = getenv("CONTEXTFLOW_BF16_SPLIT"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+    return g_bf16_split < 0 ? v : g_bf16_split;
 }
+static bool bf16_split_enabled() { return bf16_split_mode() != 0; }
 
 template <class G>
 int launch_step_inv(const float* z, float* x, const float* ws, const float* wsi, int B, int64_t zbs, int x_unsq, hipStream_t s) {
@@ -1488,6 +1514,8 @@ int cf_flow_step_fwd_debug(const float* x, float* z, float* ldj_acc, const void*
                                : launch_step_small<G8w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
         case 14: rc = in_squeeze ? launch_step_small<G16wb, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))        // variant 6: bf16-piece form of variant 4
                                  : launch_step_small<G16wb, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
+        case 15: rc = in_squeeze ? launch_step_small<G16db, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))        // variant 7: direct 3x3 on bf16 pieces
+                                 : launch_step_small<G16db, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;
         case 12: rc = in_squeeze ? launch_step_small<G16w, true>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream))         // variant 4:
                                 : launch_step_small<G16w, false>(x, z, ldj_acc, w, B, x_bstride, cf_s(stream)); break;  // Winograd form of the 3x3
         case 20: CF_STEP(G32w); break;
@@ -1545,8 +1573,8 @@ int cf_flow_step_fwd_chain(const float* x, float* z, float* ldj_acc, const void*
 // on = 0 / 1: switch the bf16-piece form of the 16x16 level off / on for the tables packed and the steps launched from now on
 // (overrides CONTEXTFLOW_BF16_SPLIT); on < 0: query.  Returns the setting in force.
 int cf_bf16_split(int on) {
-    if (on >= 0) g_bf16_split = on ? 1 : 0;
-    return bf16_split_enabled() ? 1 : 0;
+    if (on >= 0) g_bf16_split = on > 2 ? 1 : on;
+    return bf16_split_mode();
 }
 
 int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, int B, int C, int H, int W,
@@ -1563,7 +1591,9 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
     if (!direct_only && (sid == 0 || sid == 1 || (sid == 2 && B >= 256 * G32::SPW))) flags = 4 << 16;
     if (!direct_only && sid == 3 && B >= 256 * G64w2::SPW) flags = 5 << 16;      // 4x4: 8 samples per workgroup, rows split over wave pairs
     // CONTEXTFLOW_BF16_SPLIT=1 (off by default): the 16x16 level's Winograd-domain products as bf16-piece MFMAs (G16wb)
-    if (!direct_only && sid == 1 && bf16_split_enabled()) flags = 6 << 16;
+    // (mode 2, the direct bf16-piece form: from 1024 samples per launch - below that the chained launches of the fp32 form run)
+    if (!direct_only && sid == 1 && bf16_split_mode() == 1) flags = 6 << 16;
+    if (!direct_only && sid == 1 && bf16_split_mode() == 2 && B >= 1024) flags = 7 << 16;
     // very small batches: the row-split kernel (a quarter of the serial chain per workgroup, 4x the workgroups)
     if ((sid == 2 && B <= 512) || (sid == 3 && B <= CF_RS_MAXB_C64)) {
         CF_REQUIRE(x && z && ldj_acc && ws && B >= 0 && x_bstride >= (int64_t)C * H * W);

@@ -64,6 +64,10 @@ struct Geo {
     // PIPE == 4: the Winograd-domain products on the bf16 matrix cores - every fp32 operand as three bf16 pieces, the six piece
     // products with i + j <= 2 accumulated in fp32 (winograd_phase2; tools/micro/bf16_split_gemm.hip: the error of the f32 MFMA)
     static constexpr bool BF16S = (PIPE_ == 4);
+    // PIPE == 5: the DIRECT 3x3 on the bf16 matrix cores (direct_bf16_phases, below): h1 is split once, by its producer, into three
+    // bf16 planes [pixel][channel] in LDS; a tap's B operand is one 16-byte read per piece and feeds 6 MFMAs per 16-row tile; no
+    // transform arithmetic at all, and the matrix pipe of v_mfma_f32_16x16x32_bf16 runs beside the vector pipe
+    static constexpr bool DBF = (PIPE_ == 5);
     static constexpr int RT16 = HID / 16, KG4 = HID / 16;         // row tiles / k-step groups of the 16x16x4 products over HID
     static constexpr int OFF_AW = OFF_SA2 + (HID16 ? 9 * 256 : 0);
     // one-sample-per-workgroup form of the 4x4 level for small batches (k_flow_step_rs16, cf_step.hip): 16x16x4 A fragments
@@ -79,7 +83,10 @@ struct Geo {
     // stands for channel 4 j + (l >> 4): the eight values a lane of winograd_phase2 forms over eight consecutive k-steps)
     static constexpr int KB32 = HID / 32;
     static constexpr int OFF_AWB = WS_END0;
-    static constexpr int WS_FLOATS = WS_END0 + 16 * RT16 * KB32 * 3 * 256;
+    // bf16 pieces of the direct 3x3 taps (DBF): [tap][16-row tile][32-channel block][piece][lane] 16 bytes = 8 bf16: element j of
+    // lane l = piece of NN.2[16 rt + (l & 15)][32 kb + 8 (l >> 4) + j][tap] (the hardware's own k order)
+    static constexpr int OFF_ADB = WS_END0 + 16 * RT16 * KB32 * 3 * 256;
+    static constexpr int WS_FLOATS = OFF_ADB + 9 * RT16 * KB32 * 3 * 256;
     static constexpr int PP = 2 * W + 2 * H + 4;      // fold slots per sample: 2 patched rows, 2 patched columns, 4 corners
     static constexpr int RS = PATCH ? ((PIX + SPW * PP + 1 + 3) & ~3) : PIX;
     // C = 8 (HID = 16) in the Winograd form: all 16 Winograd-domain weight matrices are 16 KB - staged into LDS once per workgroup
@@ -89,7 +96,8 @@ struct Geo {
 #define CF_WINO_LDSW 1
 #endif
     static constexpr int LDS_W = (CF_WINO_LDSW && PIPE_ == 3 && HID == 16 && H == 16 && W == 16 && SPW == 1) ? 16 * HID * HID : 0;
-    static constexpr int LDS_FLOATS = (HALF + HID) * RS + LDS_W;
+    static constexpr int DBF_FLOATS = 3 * PIX * HID / 2;        // three bf16 planes [pixel][HID]; they alias the fp32 planes
+    static constexpr int LDS_FLOATS = (DBF && DBF_FLOATS > (HALF + HID) * RS) ? DBF_FLOATS : (HALF + HID) * RS + LDS_W;
     // waves per SIMD the register allocator must leave room for = workgroups per CU the LDS footprint admits
     static constexpr int MINW = (160 * 1024) / (LDS_FLOATS * 4) >= 4 ? 4 : ((160 * 1024) / (LDS_FLOATS * 4) >= 2 ? 2 : 1);
     static_assert(PIX % 128 == 0 && PTW >= 1, "workgroup must own a multiple of 128 pixels");
@@ -878,6 +886,132 @@ __device__ __forceinline__ void winograd_phase2(float* __restrict__ lds, const f
     else cf_wave_sync();
 }
 
+// ---- direct 3x3 on the bf16 matrix cores (phases 1 + 2 of the PIPE == 5 geometry: 16x16 images, HID = 32) -----------------------
+// `v_mfma_f32_*_f32` runs at the vector rate on the pipe the vector instructions use; `v_mfma_f32_16x16x32_bf16` has 16x that
+// rate on a pipe of its own.  An fp32 value is exactly three bf16 pieces (truncation split), piece products are exact in fp32,
+// and the six pairs with i + j <= 2 accumulated in fp32 carry the error of the f32 MFMA (tools/micro/bf16_split_gemm.hip).  The
+// Winograd form would have to split every TRANSFORMED operand at its read (5.5 vector instructions per value: that, not the
+// matrix pipe, bounded the PIPE == 4 kernel); the direct form splits h1 ONCE, where phase 1 produces it, and a tap is pure
+// data movement: 9 taps x 6 piece pairs = 54 bf16 MFMAs of K = 32 per 16-row x 16-pixel tile = 864 cycles, against 16 positions x 8
+// f32 MFMAs = 4096 cycles / 4 tiles = 1024 for the Winograd form - with no transform arithmetic beside them.
+// LDS: plane pz at byte pz * PIX * HID * 2; pixel p = 16 y + x holds its 32 channels in 64 bytes, the 16-byte chunk c (channels
+// 8 c ..) at slot c ^ ((x >> 1) & 2): a tap's B operand (lane = (pixel column l & 15, chunk l >> 4), pixel shifted by the tap with
+// reflection) is then one conflict-free ds_read_b128 for every dx.  The planes alias Y0 / the x plane (barrier before they are
+// written) and h2 (fp32 [row][pixel], natural order, this wave's own columns) overwrites them after a barrier.
+template <class G>
+__device__ __forceinline__ void direct_bf16_phases(float* __restrict__ lds, const float* __restrict__ wsl, ws_rsrc_t rs, int lane, int wave) {
+    static_assert(G::DBF && G::H == 16 && G::W == 16 && G::SPW == 1 && G::HID == 32 && G::PTW == 2, "the 16x16 level at C = 16");
+    constexpr int PIX = G::PIX, HALF = G::HALF, HID = G::HID, PTW = G::PTW, RT16 = G::RT16;
+    constexpr int PLANE = PIX * HID * 2;            // bytes of one bf16 plane
+    typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+    float* Y0 = lds;
+    float* H1 = lds + HALF * PIX;
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const int li = lane & 31, lk = lane >> 5, l15 = lane & 15, lg = lane >> 4;
+    // ================= phase 1: h1 = relu(NN.0 y0 + b) on 32x32x2 tiles (K = 8), this wave's own columns of Y0
+    int pix[PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) pix[q] = (wave * PTW + q) * 32 + li;
+    f32x16 acc1[1][PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) acc1[0][q] = bias_tile(wsl + G::OFF_B1, lk);
+    dense_phase<G, G::KS1, G::NG1, 1>(acc1, rs, G::OFF_A1, Y0, pix, lane);
+    // weight pieces of the first tap: requested before the barrier
+    float4 wp[2][RT16][3];
+    auto wp_load = [&](float4 (&dst)[RT16][3], int tap) {
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) dst[rt][pz] = ws_frag(rs, lane, G::OFF_ADB + ((tap * RT16 + rt) * 3 + pz) * 256);
+    };
+    wp_load(wp[0], 0);
+    __syncthreads();                 // every wave is done with Y0 and the x plane: the bf16 planes alias them
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) {
+        const int xx = pix[q] & 15;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {               // registers 4 a .. 4 a + 3 = channels 8 a + 4 lk + (0..3): half a chunk
+            unsigned p[3][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = cf_relu(acc1[0][q][4 * a + i]);
+#ifdef CF_ABL_DB_NOSPLIT                                                     // timing-only probe: no split arithmetic (wrong results)
+                p[0][i] = p[1][i] = p[2][i] = __float_as_uint(v);
+                continue;
+#endif
+                const unsigned u0 = __float_as_uint(v) & 0xffff0000u;
+                const float r1 = v - __uint_as_float(u0);
+                const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(u1);
+                p[0][i] = u0; p[1][i] = u1; p[2][i] = __float_as_uint(r2);
+            }
+            char* dst = ldsb + pix[q] * (HID * 2) + ((a ^ ((xx >> 1) & 2)) * 16) + lk * 8;
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz)
+                *reinterpret_cast<uint2*>(dst + pz * PLANE) = make_uint2(__builtin_amdgcn_perm(p[pz][1], p[pz][0], 0x07060302u),
+                                                                         __builtin_amdgcn_perm(p[pz][3], p[pz][2], 0x07060302u));
+        }
+    }
+    __syncthreads();                 // h1 pieces complete: the taps read neighbouring waves' image rows
+    // ================= phase 2: h2 = relu(NN.2 (*) h1 + b), 3x3, reflect padding   (coupling.py:27)
+    int colpart[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int xx = l15 + d - 1;
+        xx = xx < 0 ? -xx : (xx >= 16 ? 30 - xx : xx);
+        colpart[d] = xx * (HID * 2) + ((lg ^ ((xx >> 1) & 2)) * 16);
+    }
+    f32x4w acc[4][RT16];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) acc[ct][rt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    constexpr int order[6][2] = {{0, 2}, {2, 0}, {1, 1}, {0, 1}, {1, 0}, {0, 0}};      // (weight piece, h1 piece): small terms first
+    // B operands are requested one (tap, image row) ahead of the 12 MFMAs that consume them, the weight pieces one tap ahead
+    float4 bq[2][3];
+    auto b_load = [&](float4 (&dst)[3], int tap, int ct) {
+        int yy = wave * 4 + ct + tap / 3 - 1;                            // wave-uniform: a column tile is one image row
+        yy = yy < 0 ? -yy : (yy >= 16 ? 30 - yy : yy);
+        const char* src = ldsb + yy * (16 * HID * 2) + colpart[tap % 3];
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) dst[pz] = *reinterpret_cast<const float4*>(src + pz * PLANE);
+    };
+    b_load(bq[0], 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) wp_load(wp[(tap + 1) & 1], tap + 1);
+        auto& w = wp[tap & 1];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int it = tap * 4 + ct;
+            if (it + 1 < 36) b_load(bq[(it + 1) & 1], (it + 1) / 4, (it + 1) % 4);
+            __builtin_amdgcn_sched_barrier(0);
+            auto& b = bq[it & 1];
+#ifndef CF_ABL_DB_NPAIRS
+#define CF_ABL_DB_NPAIRS 6                 // timing-only probe: fewer piece pairs (wrong results)
+#endif
+#pragma unroll
+            for (int t = 6 - CF_ABL_DB_NPAIRS; t < 6; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RT16; ++rt)
+                    acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8w, w[rt][order[t][0]]),
+                                                                          __builtin_bit_cast(bf16x8w, b[order[t][1]]), acc[ct][rt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();                 // every wave has finished reading the h1 pieces: h2 overwrites them
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) {
+        const float4 bv = *reinterpret_cast<const float4*>(wsl + G::OFF_B2 + rt * 16 + 4 * lg);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H1[(rt * 16 + 4 * lg + r) * PIX + wave * 64 + 16 * ct + l15] = cf_relu(acc[ct][rt][r] + bb[r]);
+    }
+    cf_wave_sync();
+}
+
 // ---- the conditioner: phases 1-3 of a step (shared by the forward and the inverse kernel) --------------
 // In: Y0 = y0 plane (this wave's columns).  Out: acc3 = NN.4 output tiles (t rows / raw rows, packed-row
 // layout of chan_of_row).  Uses the H region of LDS for h1 / h2; two workgroup barriers.
@@ -1185,6 +1319,7 @@ using G64v2 = Geo<64, 4, 4, 8, 1>;
 using G64v3 = Geo<64, 4, 4, 16, 0>;
 using G8w = Geo<8, 16, 16, 1, 3>;
 using G16wb = Geo<16, 16, 16, 1, 4>;     // ... with the Winograd-domain products as bf16-piece MFMAs (CONTEXTFLOW_BF16_SPLIT=1)
+using G16db = Geo<16, 16, 16, 1, 5>;     // direct 3x3 on the bf16 matrix cores, h1 split by its producer (CONTEXTFLOW_BF16_SPLIT=2)
 using G16w = Geo<16, 16, 16, 1, 3>;      // Winograd F(2x2,3x3) form of the 3x3 (winograd_phase2); 16x16: in k_flow_step_small
 using G32w = Geo<32, 8, 8, 4, 3>;
 using G64w = Geo<64, 4, 4, 16, 3>;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The bf16-piece form of the 16x16 level's step kernel (G16wb, debug variant 6 / CONTEXTFLOW_BF16_SPLIT=1) against the fp32
-Winograd form (variant 4): z and the log-det of the same step on the same input, and both kernel times.
+"""The bf16-piece forms of the 16x16 level's step kernel (G16wb: Winograd-domain products, debug variant 6 / CONTEXTFLOW_BF16_SPLIT=1;
+G16db: direct 3x3 with h1 split by its producer, variant 7 / CONTEXTFLOW_BF16_SPLIT=2) against the fp32 Winograd form (variant 4): z and the log-det of the same step on the same input, and both kernel times.
 usage: bf16_step_check.py [B]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -30,7 +30,7 @@ _hip.call("cf_flow_step_prepare", pp(f(conv.NN.detach())), pp(f(act.NN_t.detach(
           pp(f(c1.weight.detach())), pp(f(c1.bias.detach())), pp(f(c2.weight.detach())), pp(f(c2.bias.detach())),
           pp(f(c3.weight.detach())), pp(f(c3.bias.detach())), pp(ws), C, H, W, _hip.stream())
 res = {}
-for name, var in (("fp32 MFMA (variant 4)", 4), ("bf16 pieces (variant 6)", 6), ("direct (variant 3)", 3)):
+for name, var in (("fp32 MFMA (variant 4)", 4), ("bf16 pieces (variant 6)", 6), ("direct bf16 (variant 7)", 7), ("direct (variant 3)", 3)):
     z = torch.full_like(x, float("nan"))
     ldj = torch.zeros(B, device=dev)
     flags = var << 16
@@ -49,7 +49,7 @@ for name, var in (("fp32 MFMA (variant 4)", 4), ("bf16 pieces (variant 6)", 6), 
     res[name] = (z.clone(), ldj.clone(), e0.elapsed_time(e1) / 20)
     print("%-26s %.3f ms per %d samples, finite: %s" % (name, res[name][2], B, bool(torch.isfinite(z).all())))
 zr, lr, _ = res["direct (variant 3)"]
-for name in ("fp32 MFMA (variant 4)", "bf16 pieces (variant 6)"):
+for name in ("fp32 MFMA (variant 4)", "bf16 pieces (variant 6)", "direct bf16 (variant 7)"):
     z, l, _ = res[name]
     print("%-26s vs the direct form: max |dz| %.3e (|z| max %.2f), max |d ldj| %.3e, rms d ldj %.3e, bits/dim of the worst sample %.3e"
           % (name, (z - zr).abs().max().item(), zr.abs().max().item(), (l - lr).abs().max().item(), (l - lr).pow(2).mean().sqrt().item(),
