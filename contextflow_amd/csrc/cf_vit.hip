@@ -132,6 +132,130 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ x, con
     }
 }
 
+// ---- grouped Linears over one batch (the CN nets of a specialist flow, layers/specialist.py) ---------------------------------------
+// A specialist flow runs five small Linears and three context encodings per flow step, all functions of the context alone: 36
+// encodings + 60 Linears of 5 - 25 us in the cifar10 flow (profiles/r3_spec_fwd_b32768_kstats_final.txt).  Here blockIdx.z walks up to
+// kLinGroup problems of one launch: y_g = act_g(x_g W_g^T + b_g), the same rows and K for every problem, N / activation per problem
+// (workgroups beyond a problem's N leave at once).  ENC: x_g is not read but FORMED while it is staged - the uniform
+// dequantisation of the integer context (k_ctx_encode's arithmetic: (code + u_g) / qbins_g, one-hot code or the context itself), so
+// the encoder outputs never exist in memory.  Tile, staging and summation order are k_linear's.
+constexpr int kLinGroup = 48;
+struct LinGroup {
+    const float* x[kLinGroup];          // (rows, K) activations; ENC: the encoder's uniforms u (rows, K)
+    const float* q[kLinGroup];          // ENC: qbins (K)
+    const float* W[kLinGroup];          // (N, K)
+    const float* b[kLinGroup];          // (N) or null
+    float* y[kLinGroup];                // (rows, N)
+    int N[kLinGroup];
+    int act[kLinGroup];                 // 0 none, 2 ReLU
+};
+template <bool VEC, bool ENC>
+__global__ __launch_bounds__(256) void k_linear_group(const LinGroup pg, const int64_t* __restrict__ ctx, const int64_t* __restrict__ card,
+                                                      int nctx, int onehot, int rows, int K) {
+    constexpr int NTL = 3, LIN_COLS = 32 * NTL;
+    const int g = blockIdx.z, N = pg.N[g];
+    const int r0 = blockIdx.x * LIN_ROWS, n0 = blockIdx.y * LIN_COLS;
+    if (n0 >= N) return;
+    __shared__ float xs[LIN_ROWS * LIN_KP];
+    __shared__ float ws[LIN_COLS * LIN_KP];
+    const float* __restrict__ x = pg.x[g];
+    const float* __restrict__ qb = pg.q[g];
+    const float* __restrict__ Wt = pg.W[g];
+    const float* __restrict__ bias = pg.b[g];
+    float* __restrict__ y = pg.y[g];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int EPL = VEC ? 4 : 1;
+    constexpr int RSTEP = 256 * EPL / LIN_KC;
+    constexpr int NXI = LIN_ROWS / RSTEP, NWI = (LIN_COLS + RSTEP - 1) / RSTEP;
+    const int sk = (tid % (LIN_KC / EPL)) * EPL, sr = tid / (LIN_KC / EPL);
+    const float* __restrict__ xb = x + (int64_t)r0 * K;
+    const float* __restrict__ wbp = Wt + (int64_t)n0 * K;
+    const int rmax = rows - 1 - r0, nmax = N - 1 - n0;
+    int xo[NXI], wo[NWI];
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) xo[i] = min(sr + RSTEP * i, rmax) * K;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) wo[i] = min(sr + RSTEP * i, nmax) * K;
+    float xr[NXI][EPL], wr[NWI][EPL];
+    auto fetch = [&](int k0) {
+        const int kc = min(k0 + sk, K - EPL);
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            if constexpr (VEC) { const float4 v = *reinterpret_cast<const float4*>(xb + xo[i] + kc); xr[i][0] = v.x; xr[i][1] = v.y; xr[i][2] = v.z; xr[i][3] = v.w; }
+            else xr[i][0] = xb[xo[i] + kc];
+            if constexpr (ENC) {          // (code + u) / qbins, dequantize.py:55-64 - the arithmetic of k_ctx_encode
+                const int64_t* __restrict__ crow = ctx + (int64_t)(r0 + min(sr + RSTEP * i, rmax)) * nctx;
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const int k = kc + j;
+                    float code;
+                    if (onehot) {
+                        int v = 0, off = 0;
+                        while (v < nctx - 1 && k >= off + (int)card[v]) { off += (int)card[v]; ++v; }
+                        code = (crow[v] == (int64_t)(k - off)) ? 1.f : 0.f;
+                    } else {
+                        code = (float)crow[k];
+                    }
+                    xr[i][j] = (code + xr[i][j]) / qb[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            if constexpr (VEC) { const float4 v = *reinterpret_cast<const float4*>(wbp + wo[i] + kc); wr[i][0] = v.x; wr[i][1] = v.y; wr[i][2] = v.z; wr[i][3] = v.w; }
+            else wr[i][0] = wbp[wo[i] + kc];
+        }
+    };
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const int li = lane & 31, lk = lane >> 5;
+    const float* xa = xs + (wave * 32 + li) * LIN_KP + lk;
+    const float* wb = ws + li * LIN_KP + lk;
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += LIN_KC) {
+        const bool kin = k0 + sk < K;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i)
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) xs[(sr + RSTEP * i) * LIN_KP + sk + j] = (kin && sr + RSTEP * i <= rmax) ? xr[i][j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NWI; ++i)
+#pragma unroll
+            for (int j = 0; j < EPL; ++j)
+                if (sr + RSTEP * i < LIN_COLS) ws[(sr + RSTEP * i) * LIN_KP + sk + j] = (kin && sr + RSTEP * i <= nmax) ? wr[i][j] : 0.f;
+        __syncthreads();
+        if (k0 + LIN_KC < K) fetch(k0 + LIN_KC);
+#pragma unroll
+        for (int kk = 0; kk < LIN_KC; kk += 2) {
+            const float a = xa[kk];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                const float b = wb[t * 32 * LIN_KP + kk];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const bool relu = pg.act[g] == 2;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int n = n0 + t * 32 + li;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row >= rows) continue;
+            float v = acc[t][r] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            y[(int64_t)row * N + n] = v;
+        }
+    }
+}
+
 // Weight / bias gradient of a Linear over row-major activations (backward of k_linear; simple_vit.py's nn.Linear):
 //   gW[n][k] = sum_r gy[r][n] x[r][k],   gb[n] = sum_r gy[r][n]        (rows = samples x tokens: 1e5 .. 1e6)
 // A split-K GEMM whose reduction dimension is the ROW index: both MFMA operands come straight from row-major LDS tiles
@@ -498,6 +622,41 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
 #undef CF_LIN_A
 #undef CF_LIN
     CF_LAUNCH_CHECK();
+    return 0;
+}
+
+// n Linears over the same rows in one launch (k_linear_group): y_g = act_g(x_g W_g^T + b_g), x_g (rows, K), W_g (N_g, K), b_g (N_g) or
+// null, act_g 0 | 2 (ReLU).  With ctx != null the inputs are FORMED from the integer context (rows, nctx) instead of read:
+// x_g[r, k] = (code(ctx[r], k) + u_g[r, k]) / qbins_g[k] - x[] then holds the uniforms u_g and q[] the encoders' qbins; onehot != 0:
+// code = the concatenated one-hot code with cardinalities card (device int64, nctx entries), else the context itself (K == nctx).
+int cf_linear_group(int n, const float* const* x, const float* const* q, const float* const* W, const float* const* b, float* const* y,
+                    const int* N, const int* act, const int64_t* ctx, const int64_t* card, int nctx, int onehot, int rows, int K,
+                    cf_stream_t stream) {
+    if (n == 0 || rows == 0) return 0;
+    CF_REQUIRE(n > 0 && x && W && b && y && N && act && rows > 0 && K > 0 && (!ctx || (q && nctx > 0 && (onehot ? card != nullptr : K == nctx))));
+    hipStream_t st = cf_s(stream);
+    for (int i0 = 0; i0 < n; i0 += kLinGroup) {
+        const int m = n - i0 < kLinGroup ? n - i0 : kLinGroup;
+        LinGroup pg{};
+        int nmax = 0;
+        bool vec = K % 4 == 0;
+        for (int i = 0; i < m; ++i) {
+            const int j = i0 + i;
+            CF_REQUIRE(x[j] && W[j] && y[j] && N[j] > 0 && (act[j] == 0 || act[j] == 2) && (!ctx || q[j]));
+            pg.x[i] = x[j]; pg.q[i] = ctx ? q[j] : nullptr; pg.W[i] = W[j]; pg.b[i] = b[j]; pg.y[i] = y[j]; pg.N[i] = N[j]; pg.act[i] = act[j];
+            nmax = N[j] > nmax ? N[j] : nmax;
+            vec = vec && ((reinterpret_cast<uintptr_t>(x[j]) | reinterpret_cast<uintptr_t>(W[j])) & 15) == 0;
+        }
+        dim3 grid((rows + LIN_ROWS - 1) / LIN_ROWS, (nmax + 95) / 96, m);
+        if (ctx) {
+            if (vec) k_linear_group<true, true><<<grid, dim3(256), 0, st>>>(pg, ctx, card, nctx, onehot, rows, K);
+            else k_linear_group<false, true><<<grid, dim3(256), 0, st>>>(pg, ctx, card, nctx, onehot, rows, K);
+        } else {
+            if (vec) k_linear_group<true, false><<<grid, dim3(256), 0, st>>>(pg, nullptr, nullptr, 0, 0, rows, K);
+            else k_linear_group<false, false><<<grid, dim3(256), 0, st>>>(pg, nullptr, nullptr, 0, 0, rows, K);
+        }
+        CF_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -14,6 +14,7 @@ and the per-sample log-dets accumulate in ONE (B,) buffer inside the kernels ins
 Evaluation only (no tape); `FlowSequential.forward` uses it under no_grad and falls back to the layer loop when a
 model does not have this shape."""
 import math
+import os
 
 import torch
 
@@ -154,6 +155,101 @@ def _draw_encoder_noise(flow, B, dev):
         e.__dict__["_noise_once"] = u[i] if e.D == width else u[i, :, :e.D].contiguous()
 
 
+FRONT_END = os.environ.get("CONTEXTFLOW_SPEC_FRONT", "1") != "0"      # A/B switch of _front_end (tools/specialist_bench.py)
+
+
+def _uniform_encoder(net):
+    """(encoder, card, onehot) when `net` is a ContextEncoder whose code is the uniform dequantisation of the one-hot code / of the
+    context itself (the form cf_linear_group can build while it stages its input), else None."""
+    from .context import ContextEncoder, EyeEncoder, OneHotEncoder, UniformCatDequantization
+    if not isinstance(net, ContextEncoder) or not isinstance(net[1], UniformCatDequantization):
+        return None
+    if isinstance(net[0], OneHotEncoder):
+        return net[1], net[0].cardinalities, 1
+    if isinstance(net[0], EyeEncoder):
+        return net[1], None, 0
+    return None
+
+
+def _front_end(flow, context, B, dev):
+    """Everything a specialist flow computes from the CONTEXT ALONE, ahead of the data path and in three launches instead of ~96:
+    the code of every uniform context encoder is formed inside the first Linear that consumes it (Conv1x1.CN, ActNorm.CN,
+    Coupling.CN[0]: one grouped launch, cf_linear_group with ctx), then the second and third Linears of the coupling CN nets
+    (one grouped launch each).  Returns {id(layer): tensor}: Conv1x1 -> (m1, blocked), ActNorm -> m2, Coupling -> CN(c)."""
+    import ctypes
+    mods, n = flow.sequence_modules, len(flow.sequence_modules)
+    if context is None or context.dim() != 2 or not FRONT_END:
+        return {}
+    f = _hip.f32
+    first, second, third, out = [], [], [], {}
+    enc0 = None
+    for i, m in enumerate(mods):
+        net = getattr(m, "context_net", None)
+        ue = _uniform_encoder(net) if net else None
+        if ue is None:
+            continue
+        enc, card, onehot = ue
+        key = (enc.D, onehot, None if card is None else card.shape[0])
+        if enc0 is None:
+            enc0 = (key, enc, card, onehot)
+        if key != enc0[0]:
+            continue                                       # a different code layout: that layer keeps its own path
+        u = enc.fixed_noise
+        if u is None:
+            u = enc.__dict__.pop("_noise_once", None)
+            if u is None or u.shape != (B, enc.D):
+                u = torch.rand((B, enc.D), device=dev, dtype=torch.float32)
+        u = f(u)
+        if isinstance(m, Conv1x1):
+            C = m.D
+            nblk = _hip.lib().cf_affine_ctx_blocked_floats(C, m.H, m.W)
+            if nblk and nblk < C * C:
+                w, b = _cn_blocked(flow, m, C, dev)
+                blocked = 1
+            else:
+                w, b, blocked = f(m.CN.weight.detach()), f(m.CN.bias.detach()), 0
+            y = torch.empty(B, w.shape[0], device=dev, dtype=torch.float32)
+            first.append((u, enc.qbins, w, b, y, 0))
+            out[id(m)] = (y, blocked)
+        elif isinstance(m, ActNorm):
+            w, b = f(m.CN.weight.detach()), f(m.CN.bias.detach())
+            y = torch.empty(B, w.shape[0], device=dev, dtype=torch.float32)
+            first.append((u, enc.qbins, w, b, y, 0))
+            out[id(m)] = y
+        elif type(m) is Coupling and m.contextflow:
+            l0, l1, l2 = m.CN[0], m.CN[2], m.CN[4]
+            a1 = torch.empty(B, l0.weight.shape[0], device=dev, dtype=torch.float32)
+            a2 = torch.empty(B, l1.weight.shape[0], device=dev, dtype=torch.float32)
+            cn = torch.empty(B, l2.weight.shape[0], device=dev, dtype=torch.float32)
+            first.append((u, enc.qbins, f(l0.weight.detach()), f(l0.bias.detach()), a1, 2))
+            second.append((a1, None, f(l1.weight.detach()), f(l1.bias.detach()), a2, 2))
+            third.append((a2, None, f(l2.weight.detach()), f(l2.bias.detach()), cn, 0))
+            out[id(m)] = cn
+    if not first:
+        return {}
+    _, enc, card, onehot = enc0
+    ctx = context.to(device=dev, dtype=torch.int64).contiguous()
+    st = _hip.stream()
+
+    def launch(probs, K, with_ctx):
+        # problems of one launch share K; the coupling nets of different levels have different hidden widths: one launch per K
+        byk = {}
+        for pr in probs:
+            byk.setdefault(pr[2].shape[1], []).append(pr)
+        for k, ps in byk.items():
+            nn_ = len(ps)
+            arr = lambda j: (ctypes.c_void_p * nn_)(*[(pr[j].data_ptr() if pr[j] is not None else None) for pr in ps])
+            Ns = (ctypes.c_int * nn_)(*[pr[2].shape[0] for pr in ps])
+            acts = (ctypes.c_int * nn_)(*[pr[5] for pr in ps])
+            _hip.call("cf_linear_group", nn_, arr(0), arr(1), arr(2), arr(3), arr(4), Ns, acts,
+                      _hip.p(ctx) if with_ctx else None, _hip.p(card) if (with_ctx and card is not None) else None,
+                      ctx.shape[1] if with_ctx else 0, onehot if with_ctx else 0, B, k, st)
+    launch(first, enc.D, True)
+    launch(second, 0, False)
+    launch(third, 0, False)
+    return out
+
+
 def forward_eval(flow, x, context):
     """(z, logp (B, M)) of a specialist flow, evaluation.  Same results as FlowSequential._forward_layers to fp32 rounding
     (the per-sample log-dets are summed in another order)."""
@@ -161,6 +257,7 @@ def forward_eval(flow, x, context):
     mods, n = flow.sequence_modules, len(flow.sequence_modules)
     B, dev = x.shape[0], x.device
     _draw_encoder_noise(flow, B, dev)
+    pre = _front_end(flow, context, B, dev)
     acc = _Acc(B, dev)
     st, pp, f = _hip.stream(), _hip.p, _hip.f32
     i = 0
@@ -196,19 +293,27 @@ def forward_eval(flow, x, context):
             conv, act = mods[j], mods[j + 1]
             C, H, W = sshape
             xv, xbs = _hip.bview(x)
-            c1, lp1 = conv.context_net(context)
-            c2, lp2 = act.context_net(context)
-            nblk = _hip.lib().cf_affine_ctx_blocked_floats(C, H, W) if xbs % 4 == 0 and xv.data_ptr() % 16 == 0 else 0
-            if nblk and nblk < C * C:                          # (B, 10/16 C*C) at C = 64, 3/4 at C = 32: lower blocks only
-                wp, bp = _cn_blocked(flow, conv, C, dev)
-                c1f = f(c1)
-                m1 = torch.empty(B, nblk, device=dev, dtype=torch.float32)
-                _hip.call("cf_linear", pp(c1f), pp(wp), pp(bp), None, pp(m1), B, c1f.shape[1], nblk, 0, st)
-                blocked = 1
+            aligned = xbs % 4 == 0 and xv.data_ptr() % 16 == 0
+            lp1 = lp2 = None
+            if id(conv) in pre and (aligned or not pre[id(conv)][1]):      # formed by the front end (grouped launch)
+                m1, blocked = pre[id(conv)]
             else:
-                m1 = _linear(f(c1), conv.CN)                   # (B, C*C)
-                blocked = 0
-            m2 = _linear(f(c2), act.CN)                        # (B, 2C)
+                c1, lp1 = conv.context_net(context)
+                nblk = _hip.lib().cf_affine_ctx_blocked_floats(C, H, W) if aligned else 0
+                if nblk and nblk < C * C:                          # (B, 10/16 C*C) at C = 64, 3/4 at C = 32: lower blocks only
+                    wp, bp = _cn_blocked(flow, conv, C, dev)
+                    c1f = f(c1)
+                    m1 = torch.empty(B, nblk, device=dev, dtype=torch.float32)
+                    _hip.call("cf_linear", pp(c1f), pp(wp), pp(bp), None, pp(m1), B, c1f.shape[1], nblk, 0, st)
+                    blocked = 1
+                else:
+                    m1 = _linear(f(c1), conv.CN)                   # (B, C*C)
+                    blocked = 0
+            if id(act) in pre:
+                m2 = pre[id(act)]
+            else:
+                c2, lp2 = act.context_net(context)
+                m2 = _linear(f(c2), act.CN)                        # (B, 2C)
             cadd = 0.0
             for net, lp in ((conv.context_net, lp1), (act.context_net, lp2)):
                 k = _const_logp(net)
@@ -230,10 +335,14 @@ def forward_eval(flow, x, context):
         # ---- Coupling(c''): the fused step kernel, CN bias on the conditioner output (contextflow)
         if (type(m) is Coupling and m.context_net and m.contextflow and len(shape) == 3 and m._fused_ctx_ok(x)):
             C, H, W = shape
-            c, lp = m.context_net(context)
-            a1 = _linear(f(c), m.CN[0], act=2)
-            a2 = _linear(a1, m.CN[2], act=2)
-            cn = _linear(a2, m.CN[4])
+            lp = None
+            if id(m) in pre:
+                cn = pre[id(m)]
+            else:
+                c, lp = m.context_net(context)
+                a1 = _linear(f(c), m.CN[0], act=2)
+                a2 = _linear(a1, m.CN[2], act=2)
+                cn = _linear(a2, m.CN[4])
             xv, xbs = _hip.bview(x)
             ws = _coupling_ws(flow, m, C, H, W, dev)
             z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)

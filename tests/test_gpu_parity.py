@@ -246,6 +246,49 @@ def test_gmm_backward_sums_kernel(L, B, D, wide):
         assert (got.cpu().double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()) * max(1.0, (B / 1000) ** 0.5)
 
 
+@pytest.mark.parametrize("onehot,K", [(1, 20), (0, 3), (1, 7)])
+def test_grouped_linears_with_the_context_code_formed_in_the_kernel(L, onehot, K):
+    """cf_linear_group: the first Linears of the CN nets of a specialist flow in one launch, the uniform dequantisation of the
+    context (model.py:30-90, dequantize.py:55-64) formed while the input is staged; and plain grouped Linears.  Bitwise equal to
+    cf_ctx_encode + cf_linear per problem (same tile, same summation order); ragged N, an empty and a 1-row batch."""
+    from contextflow_amd.layers import _hip
+    torch.manual_seed(3)
+    for B in (0, 1, 301):
+        cards = [15, 5] if K == 20 else ([3, 4] if onehot else [9, 4, 6])
+        assert (sum(cards) if onehot else len(cards)) == K
+        ctx = torch.stack([torch.randint(0, c, (B,)) for c in cards], 1).to(DEV)
+        card = torch.tensor(cards, device=DEV)
+        Ns, acts = [7, 96, 200, 33], [0, 2, 0, 2]
+        n = len(Ns)
+        us = [torch.rand(B, K, device=DEV) for _ in Ns]
+        qs = [torch.rand(K, device=DEV) + 0.5 for _ in Ns]
+        Ws = [torch.randn(N, K, device=DEV) for N in Ns]
+        bs = [torch.randn(N, device=DEV) for N in Ns]
+        ys = [torch.full((B, N), float("nan"), device=DEV) for N in Ns]
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts])
+        iarr = lambda v: (ctypes.c_int * n)(*v)
+        pp, st = _hip.p, _hip.stream()
+        _hip.call("cf_linear_group", n, arr(us), arr(qs), arr(Ws), arr(bs), arr(ys), iarr(Ns), iarr(acts), pp(ctx), pp(card) if onehot else None,
+                  len(cards), onehot, B, K, st)
+        xs = []
+        for g in range(n):
+            c = torch.empty(B, K, device=DEV)
+            if B:
+                _hip.call("cf_ctx_encode", pp(ctx), pp(us[g]), pp(qs[g]), pp(card) if onehot else None, pp(c), B, len(cards), K, onehot, st)
+            want = torch.empty(B, Ns[g], device=DEV)
+            _hip.call("cf_linear", pp(c), pp(Ws[g]), pp(bs[g]), None, pp(want), B, K, Ns[g], acts[g], st)
+            assert torch.equal(ys[g], want), (B, g)
+            xs.append(c)
+        # plain grouped Linears (no context), one problem without a bias
+        ys2 = [torch.full((B, N), float("nan"), device=DEV) for N in Ns]
+        bs2 = [bs[0], None, bs[2], bs[3]]
+        _hip.call("cf_linear_group", n, arr(xs), None, arr(Ws), arr(bs2), arr(ys2), iarr(Ns), iarr(acts), None, None, 0, 0, B, K, st)
+        for g in range(n):
+            want = torch.empty(B, Ns[g], device=DEV)
+            _hip.call("cf_linear", pp(xs[g]), pp(Ws[g]), pp(bs2[g]), None, pp(want), B, K, Ns[g], acts[g], st)
+            assert torch.equal(ys2[g], want), (B, g)
+
+
 @pytest.mark.parametrize("C,H,W,B,cf,sq", [(16, 16, 16, 5, True, False), (16, 16, 16, 3, True, True), (32, 8, 8, 37, False, False),
                                             (32, 8, 8, 9, True, True), (64, 4, 4, 130, True, False), (64, 4, 4, 6, False, True),
                                             (8, 6, 6, 7, True, False), (12, 4, 4, 5, False, True)])
