@@ -218,9 +218,11 @@ int cf_flow_step_bwd_prepare_batch(int n, const float* const* Wm, const float* c
                                    const float* const* w2, const float* const* w3, void* const* wsb, int C, int H, int W,
                                    cf_stream_t stream);
 
-/* The 16x16 level's Winograd-domain products as exact bf16-piece MFMAs (default: the environment variable
- * CONTEXTFLOW_BF16_SPLIT=1, else off).  on = 0 / 1 sets it for the tables packed and the steps launched from now on, on < 0 queries;
- * returns the setting in force.  Tables packed while it was off do not hold the weight pieces: prepare again after switching on. */
+/* The 16x16 level's 3x3 as exact bf16-piece MFMAs (default: the environment variable CONTEXTFLOW_BF16_SPLIT=1|2,
+ * else off): 1 = the Winograd-domain products on bf16 pieces, 2 = the DIRECT 3x3 with h1 split once by its producer (from 1024
+ * samples per launch).  on = 0 / 1 / 2 sets it for the tables packed and the steps launched from now on, on < 0 queries; returns the
+ * setting in force.  Tables packed while it was off do not hold the weight pieces: prepare again after switching on.  Same fp32
+ * results as the default (fp32 Winograd) kernels to their rounding; measured: no gain for a whole flow (power), see DESIGN.md. */
 int cf_bf16_split(int on);
 
 /* z = step(x); ldj_acc[b] += ldj_const + sum log_s   (ldj_acc is the running per-sample log-det).
