@@ -189,17 +189,26 @@ def _front_end(flow, context, B, dev):
         if ue is None:
             continue
         enc, card, onehot = ue
-        key = (enc.D, onehot, None if card is None else card.shape[0])
+        key = (enc.D, onehot, tuple(net.contexts), context.shape[1])   # the code layout: width, kind, cardinalities of the variables
         if enc0 is None:
             enc0 = (key, enc, card, onehot)
-        if key != enc0[0]:
-            continue                                       # a different code layout: that layer keeps its own path
+        if isinstance(m, (Conv1x1, ActNorm)):
+            first_lin = m.CN
+        elif type(m) is Coupling and m.contextflow:
+            first_lin = m.CN[0]
+        else:
+            continue
+        if (key != enc0[0] or enc.qbins.device != dev or first_lin.weight.device != dev or context.shape[1] != len(net.contexts)
+                or first_lin.weight.shape[1] != enc.D or (not onehot and enc.D != context.shape[1])):
+            continue                                       # another code layout / device, or a context of another width: the layer's own path
         u = enc.fixed_noise
+        if u is not None and tuple(u.shape) != (B, enc.D):
+            continue                                       # (the layer's own path reports it)
         if u is None:
             u = enc.__dict__.pop("_noise_once", None)
             if u is None or u.shape != (B, enc.D):
                 u = torch.rand((B, enc.D), device=dev, dtype=torch.float32)
-        u = f(u)
+        u = f(u.to(dev))                                   # raw pointers travel in host arrays below: everything on `dev`, fp32, dense
         if isinstance(m, Conv1x1):
             C = m.D
             nblk = _hip.lib().cf_affine_ctx_blocked_floats(C, m.H, m.W)
