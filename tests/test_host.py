@@ -154,6 +154,33 @@ def test_unbuilt_names_raise_and_specialist_layout():
         assert all(tuple(sd[k].shape) == tuple(spec[k][0]) for k in sd), fxname
 
 
+def test_specialist_front_end_takes_uniform_encoders_only():
+    """layers/specialist.py::_front_end forms a context code inside cf_linear_group only for encoders whose code IS the uniform
+    dequantisation of the one-hot code / of the context itself (model.py:32-49, dequantize.py:26-70); flow-type encoders (vardeq,
+    argmax, probsample: the noise comes from a conditional flow) keep their own path.  Host logic only - no kernel runs here."""
+    import contextflow_amd as cfa
+    from contextflow_amd.layers import specialist
+    from contextflow_amd.layers.context import OneHotEncoder, EyeEncoder
+    cfg, ds, M = cfa.preset_config("mnist")
+    for emb, typ, want in (("onehot", "uniform", 1), ("eye", "uniform", 0), ("onehot", "vardeq", None), ("eye", "argmax", None)):
+        contexts = [4, 6] if typ != "argmax" else [4, 16]
+        cfg.update(generalist=False, enc_emb=emb, enc_type=typ, contextflow=True)
+        flow = cfa.create_model(cfg, ds, M, contexts=contexts)
+        assert specialist.supported(flow)
+        nets = [m.context_net for m in flow.sequence_modules if getattr(m, "context_net", None)]
+        assert nets
+        for net in nets:
+            got = specialist._uniform_encoder(net)
+            if want is None:
+                assert got is None, (emb, typ)
+            else:
+                enc, card, onehot = got
+                assert onehot == want and enc is net[1] and isinstance(net[0], OneHotEncoder if want else EyeEncoder)
+                assert (card is None) == (want == 0) and enc.D == (sum(contexts) if want else len(contexts)) and net.contexts == contexts
+        # without a context (or with the switch off) the front end has nothing to do
+        assert specialist._front_end(flow, None, 4, "cpu") == {}
+
+
 def test_shard_bounds():
     from contextflow_amd.dist import shard_bounds
     for total in (0, 1, 7, 64, 65536 + 3):
