@@ -1248,6 +1248,15 @@ __global__ __launch_bounds__(256, (G::WINO && G::C == 16) ? CF_INV16_MINW : G::M
         float4 zr[XI];
         x_load<G, false>(zr, z, zbs, tile, B, wave, lane);
         x_to_lds<G, false>(zr, H1, wave, lane);                  // z plane: rows [0,HALF) = z0, [HALF,C) = z1
+        if constexpr (G::LDS_W > 0) {
+            // C = 8: the Winograd-domain weights of the 3x3 into LDS behind the planes (winograd_phase2 reads them there; two
+            // workgroup barriers of the conditioner lie between this and their first use)
+            const ws_rsrc_t rsw = ws_rsrc(ws, G::WS_FLOATS);
+            float* WL = lds + (HALF + G::HID) * PIX;
+#pragma unroll
+            for (int i = 0; i < G::LDS_W / 1024; ++i)
+                *reinterpret_cast<float4*>(WL + (i * 256 + tid) * 4) = ws_frag(rsw, tid, G::OFF_AW + i * 1024);
+        }
         cf_wave_sync();
 #pragma unroll
         for (int q = 0; q < PTW; ++q)
@@ -1439,7 +1448,8 @@ int cf_flow_step_inv(const float* z, float* x, const void* ws, const void* wsi, 
     const float* w = (const float*)ws;
     const float* wi = (const float*)wsi;
     switch (shape_id(C, H, W)) {
-        case 0: rc = launch_step_inv<G8>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream)); break;
+        case 0: rc = direct_conv_only() ? launch_step_inv<G8>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream))
+                                        : launch_step_inv<G8w>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream)); break;
         // the conditioner is the forward's: Winograd form of its 3x3 unless CONTEXTFLOW_DIRECT_CONV=1
         case 1: rc = direct_conv_only() ? launch_step_inv<G16>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream))
                                         : launch_step_inv<G16w>(z, x, w, wi, B, z_bstride, x_unsqueezed, cf_s(stream)); break;
@@ -1617,7 +1627,7 @@ int cf_flow_step_fwd(const float* x, float* z, float* ldj_acc, const void* ws, i
 
 // Multiply-adds per sample the matrix pipe EXECUTES for one step at this batch size (bench.py's executed-flop roofline):
 // pass 0 = cf_flow_step_fwd, 1 = cf_flow_step_fwd_taped, 2 = cf_flow_step_bwd_taped (direct transposed 3x3), 3 = cf_flow_step_inv
-// (the forward's conditioner + W^-1 instead of W: the same count; Winograd form except at mnist's C = 8 level).  The direct
+// (the forward's conditioner + W^-1 instead of W: the same count; Winograd form at every level).  The direct
 // form runs C^2 (Conv1x1) + C^2 + 36 C^2 + 2 C^2 = 40 C^2 per pixel; the Winograd form of the 3x3 runs 16 instead of 36
 // C^2.  The conditions below restate the dispatch of the two entry points above / below - change them together.
 int64_t cf_flow_step_macs(int B, int C, int H, int W, int pass) {
@@ -1625,7 +1635,7 @@ int64_t cf_flow_step_macs(int B, int C, int H, int W, int pass) {
     if (sid < 0 || pass < 0 || pass > 3) return 0;
     const int64_t direct = 40ll * C * C * H * W, wino = 20ll * C * C * H * W;
     if (pass == 2 || direct_conv_only()) return direct;
-    if (pass == 3) return sid == 0 ? direct : wino;
+    if (pass == 3) return wino;
     bool w;
     if (sid == 0) w = pass == 0;                                  // mnist's C = 8 level: evaluation only
     else if (sid == 1) w = true;                                  // 16x16, C = 16: every batch size
