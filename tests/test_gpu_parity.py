@@ -807,6 +807,38 @@ def test_inverse_chain_mnist_golden(L):
         assert (h.cpu() - ref).abs().max() <= 1.0 and (h.cpu() != ref).float().mean() < 2e-3, fused
 
 
+def test_inverse_step_tables_follow_the_parameters(L):
+    """`inverse` keeps the packed tables of its fused steps (forward fragments of the conditioner, W^-1, inverse ActNorm) between
+    calls while their source tensors are unchanged: a second call is bitwise the first; an in-place update of a Conv1x1 weight, of
+    an ActNorm shift and of a conditioner weight each changes the result exactly as a fresh packing does; `invalidate_caches()`
+    covers writes through `.data`."""
+    from tests.gpu_util import build_model
+    ops, _, M, params, fx = load_e2e("mnist")
+    model = build_model("mnist", params)
+    torch.manual_seed(1)
+    z = model.dist.sample(9)[0]
+    a, b = model.inverse(z), model.inverse(z)
+    assert torch.equal(a, b) and len(model.__dict__["_inv_ws"]) >= 2
+    from contextflow_amd.layers import ActNorm, Conv1x1, Coupling
+    mods = list(model.sequence_modules)
+    conv = next(m for m in mods if isinstance(m, Conv1x1))
+    act = next(m for m in mods if isinstance(m, ActNorm))
+    cpl = [m for m in mods if isinstance(m, Coupling)][-1]
+    with torch.no_grad():
+        conv.NN.mul_(1.03)
+        act.NN_t.add_(0.05)
+        cpl.NN[2].weight.mul_(0.9)
+    c = model.inverse(z)                       # the version counters moved: the three steps concerned are packed again
+    model.__dict__.pop("_inv_ws")
+    d = model.inverse(z)                       # everything packed from scratch
+    assert torch.equal(c, d) and not torch.equal(a, c)
+    conv.NN.data.mul_(0.5)                     # a write the version counter does not see
+    model.invalidate_caches()
+    e = model.inverse(z)
+    model.__dict__.pop("_inv_ws")
+    assert torch.equal(e, model.inverse(z)) and not torch.equal(e, c)
+
+
 @pytest.mark.parametrize("name", ["mnist", "cifar10"])
 def test_sample_shapes_and_prior_consistency(L, name):
     """`sample` runs end to end (SplitPrior.reverse resamples the split halves) and the prior sampler is
