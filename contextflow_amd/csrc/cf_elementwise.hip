@@ -396,6 +396,29 @@ __global__ __launch_bounds__(256) void k_activation(const float* __restrict__ x,
     }
 }
 
+// The tail of `inverse` / `sample` in one pass: [Augment.reverse] -> LogitTransform.reverse -> Normalization.reverse x 2 ->
+// Dequantization.reverse = x[b, i] = floor(((sigmoid(z[b, i]) - t2) * s2 - t1) * s1) for the first n_keep elements of every sample
+// (z_bstride > n_keep drops the augmented channels).  The same operations in the same order as the four k_flat launches + the copy
+// of the channel slice it replaces - subtraction and multiplication kept apart (no fma contraction), so the results are bitwise equal.
+template <int V>
+__global__ __launch_bounds__(256) void k_postprocess_inv(const float* __restrict__ z, float* __restrict__ x, int64_t n_items, int per_sample,
+                                                         int64_t zbs, float t2, float s2, float t1, float s1) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / per_sample;
+        const int j = (int)(i - b * per_sample);
+        float r[V];
+        vload<V>(z + b * zbs + (int64_t)j * V, r);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float v = 1.0f / (1.0f + expf(-r[e]));               // OP_SIGMOID
+            v = __fmul_rn(__fsub_rn(v, t2), s2);                 // OP_AFFINE_INV, Normalization 2
+            v = __fmul_rn(__fsub_rn(v, t1), s1);                 // OP_AFFINE_INV, Normalization 1
+            r[e] = floorf(v);                                    // OP_FLOOR
+        }
+        vstore<V>(x + i * V, r);
+    }
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -424,6 +447,21 @@ int cf_sigmoid(const float* x, float* y, int64_t n, cf_stream_t stream) {
     if (n == 0) return 0;                       // empty batch: nothing to do (pointers may be null)
     CF_REQUIRE(x && y && n >= 0);
     launch_flat<OP_SIGMOID>(x, nullptr, y, n, 0.f, 0.f, cf_s(stream));
+    CF_LAUNCH_CHECK();
+    return 0;
+}
+
+int cf_postprocess_inv(const float* z, float* x, int B, int n_keep, int64_t z_bstride, float t2, float s2, float t1, float s1,
+                       cf_stream_t stream) {
+    if (B == 0 || n_keep == 0) return 0;
+    CF_REQUIRE(z && x && B > 0 && n_keep > 0 && z_bstride >= n_keep);
+    const bool vec = n_keep % 4 == 0 && z_bstride % 4 == 0 && aligned16(z) && aligned16(x);
+    const int per = vec ? n_keep / 4 : n_keep;
+    const int64_t items = (int64_t)B * per;
+    int64_t blocks = (items + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (vec) k_postprocess_inv<4><<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(z, x, items, per, z_bstride, t2, s2, t1, s1);
+    else k_postprocess_inv<1><<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(z, x, items, per, z_bstride, t2, s2, t1, s1);
     CF_LAUNCH_CHECK();
     return 0;
 }

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CONTEXTFLOW_HIP_LIB: developer override (A/B builds, probe builds of tools/dev); the default is the in-tree library
 LIB_PATH = os.environ.get("CONTEXTFLOW_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libcontextflow_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -25,6 +25,7 @@ SIGNATURES = {
     "cf_logit_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_int, _c_int, _c_p]),
     "cf_sigmoid": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "cf_floor": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
+    "cf_postprocess_inv": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_i64] + [_c_f] * 4 + [_c_p]),
     "cf_preprocess_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_int, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_p]),
     "cf_preprocess_rng_fwd": (_c_int, [_c_p] * 4 + [ctypes.c_uint64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int, _c_p]),
     "cf_std_normal_nll": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_i64, _c_p]),

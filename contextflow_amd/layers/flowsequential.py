@@ -802,10 +802,32 @@ class FlowSequential(nn.Module):
                     sq = i >= 3 and isinstance(mods[i - 3], Squeeze) and tuple(mods[i - 3].p) == (2, 2)
                     z = self._inverse_step(z, mods[i - 2], mods[i - 1], m, unsqueeze=sq)
                     i -= 4 if sq else 3
+                elif self.fused and self._tail_fusable(i, z):
+                    z = self._inverse_tail(z, i)
+                    i = -1
                 else:
                     z = m.reverse(z, context)
                     i -= 1
         return z
+
+    def _tail_fusable(self, i, z):
+        """mods[:i + 1] is the pre-processing of the image flows - Dequantization, Normalization x 2, LogitTransform [, Augment over
+        the channels] - whose reverse chain cf_postprocess_inv runs in one pass."""
+        mods = self.sequence_modules
+        if z.dim() != 4 or i not in (3, 4) or not (isinstance(mods[0], Dequantization) and isinstance(mods[1], Normalization)
+                                                   and isinstance(mods[2], Normalization) and isinstance(mods[3], LogitTransform)):
+            return False
+        return i == 3 or (isinstance(mods[4], Augment) and mods[4].split_dim == 1 and 0 < mods[4].aug_size < z.shape[1])
+
+    def _inverse_tail(self, z, i):
+        mods = self.sequence_modules
+        z, zbs = _hip.bview(z)
+        B, C, H, W = z.shape
+        keep = C - (mods[4].aug_size if i == 4 else 0)
+        x = torch.empty(B, keep, H, W, device=z.device, dtype=torch.float32)
+        n1, n2 = mods[1], mods[2]
+        _hip.call("cf_postprocess_inv", _hip.p(z), _hip.p(x), B, keep * H * W, zbs, n2._t, n2._s, n1._t, n1._s, _hip.stream())
+        return x
 
     def sample(self, n_samples, context=None):
         z = self.dist.sample(n_samples, context, need_log_prob=False)[0] if isinstance(self.dist, GaussianMixtureDistribution) \

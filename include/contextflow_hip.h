@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 11
+#define CF_ABI_VERSION 12
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -46,6 +46,12 @@ int cf_logit_fwd(const float* x, float* y, float* ldj, int B, int N, cf_stream_t
 int cf_sigmoid(const float* x, float* y, int64_t n, cf_stream_t stream);
 /* y = floor(x)                                                  Dequantization.reverse           */
 int cf_floor(const float* x, float* y, int64_t n, cf_stream_t stream);
+/* the tail of FlowSequential.sample / inverse (flowsequential.py:32-39) in one pass: [Augment.reverse, augment.py] ->
+ * LogitTransform.reverse -> Normalization.reverse x 2 (normalize.py:40) -> Dequantization.reverse:
+ * x[b,i] = floor(((sigmoid(z[b,i]) - t2) * s2 - t1) * s1), i < n_keep; z_bstride > n_keep drops the augmented channels.
+ * Bitwise the result of the single calls (cf_sigmoid, cf_affine inverse x 2, cf_floor). */
+int cf_postprocess_inv(const float* z, float* x, int B, int n_keep, int64_t z_bstride, float t2, float s2, float t1, float s1,
+                       cf_stream_t stream);
 /* Fused layers 0-3 of the image flows (model.py:97-100): v = ((x+u)/s1 + t1)/s2 + t2,
  * y = logit(v) written with batch stride y_bstride, ldj[b] = ldj_const + sum(-log v - log(1-v)).   */
 int cf_preprocess_fwd(const float* x, const float* u, float* y, float* ldj, int B, int N, int64_t y_bstride,

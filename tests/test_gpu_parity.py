@@ -807,6 +807,28 @@ def test_inverse_chain_mnist_golden(L):
         assert (h.cpu() - ref).abs().max() <= 1.0 and (h.cpu() != ref).float().mean() < 2e-3, fused
 
 
+@pytest.mark.parametrize("B,C,aug,H,W", [(5, 3, 1, 32, 32), (3, 1, 1, 32, 32), (4, 3, 0, 8, 8), (2, 3, 1, 5, 3), (0, 3, 1, 32, 32)])
+def test_fused_tail_of_the_inverse_equals_the_layer_chain(L, B, C, aug, H, W):
+    """cf_postprocess_inv = [Augment.reverse] -> LogitTransform.reverse -> Normalization.reverse x 2 -> Dequantization.reverse
+    (flowsequential.py:32-39 walks them one by one), bitwise: same operations, same order, no fma contraction."""
+    from contextflow_amd.layers import _hip
+    torch.manual_seed(11)
+    z = (torch.randn(B, C + aug, H, W, device=DEV) * 3.0)
+    layers = [L.Dequantization(L.UniformDistribution(size=(C, H, W))), L.Normalization(translation=0, scale=256),
+              L.Normalization(translation=-1e-6, scale=1 / (1 - 2 * 1e-6)), L.LogitTransform()]
+    layers = [m.to(DEV) for m in layers]
+    want = z[:, :C] if aug else z
+    for m in reversed(layers):
+        want = m.reverse(want)
+    zz, zbs = _hip.bview(z)
+    got = torch.full((B, C, H, W), float("nan"), device=DEV)
+    n1, n2 = layers[1], layers[2]
+    _hip.call("cf_postprocess_inv", _hip.p(zz), _hip.p(got), B, C * H * W, zbs, n2._t, n2._s, n1._t, n1._s, _hip.stream())
+    assert torch.equal(got, want)
+    if B:
+        assert torch.equal(got, got.floor()) and got.min() >= -1 and got.max() <= 256
+
+
 def test_inverse_step_tables_follow_the_parameters(L):
     """`inverse` keeps the packed tables of its fused steps (forward fragments of the conditioner, W^-1, inverse ActNorm) between
     calls while their source tensors are unchanged: a second call is bitwise the first; an in-place update of a Conv1x1 weight, of
