@@ -115,6 +115,7 @@ def gmm_logprob_levels(levels, ldM=None, ld1=None):
 
 KEYED_MIN_PER_KEY = 16             # cf_gmm_logprob_keyed from 16 samples per (mean key, scale key) value on average
 _bucket_cache = [None, None]
+_key_cache = []                    # [(context tensor, signature, key)]: GaussianMixtureDistribution._scale_tables
 
 
 def _key_buckets(context, key_s, key_m, Us, Um, tag=None, TB=128):
@@ -249,10 +250,20 @@ class GaussianMixtureDistribution(nn.Module):
         ctx = context.to(device=dev, dtype=torch.long)
 
         def key_of(rel, strides):
+            # the mixtures of all levels of a flow see the same context and, with model.py's embedding widths, form the same keys:
+            # kept with the context tensor they were made from (the object itself: its storage cannot be recycled under the cache;
+            # in-place writes bump its version) - 11 tiny launches per mixture and call otherwise
+            sig = (context._version, tuple(rel), tuple(sorted(strides.items())), tuple(embs[i].num_embeddings for i in rel), str(dev))
+            for ent in _key_cache:
+                if ent[0] is context and ent[1] == sig:
+                    return ent[2]
             key = torch.zeros(ctx.shape[0], dtype=torch.long, device=dev)
             for i in rel:        # clamped: an out-of-range code must not index past the tables (the lookup would raise)
                 key += ctx[:, i].clamp(0, embs[i].num_embeddings - 1) * strides[i]
-            return key.to(torch.int32)
+            key = key.to(torch.int32)
+            _key_cache.append((context, sig, key))
+            del _key_cache[:-4]               # the two keys of the current context (+ those of the one before)
+            return key
         return (key_of(rel_s, st_s),) + cache[1:4] + (key_of(rel_m, st_m), cache[4])
 
     def _keyed_tables(self, tab, logw):
