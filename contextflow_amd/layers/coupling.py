@@ -132,12 +132,26 @@ class Coupling(_AffineCoupling):
             sbias = torch.empty(B, wc.shape[0], device=dev, dtype=torch.float32)
             _hip.call("cf_linear", pp(cn), pp(wc), None, None, pp(sbias), B, wc.shape[1], wc.shape[0], 0, st)
             mode, w1 = 2, w1[:, :D].contiguous()
-        eye = torch.eye(C, device=dev, dtype=torch.float32)
-        zero = torch.zeros(C, device=dev, dtype=torch.float32)
-        ws = torch.empty(_hip.lib().cf_flow_step_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
-        _hip.call("cf_flow_step_prepare", pp(eye), pp(zero), pp(zero), pp(w1), pp(f(c1.bias.detach())),
-                  pp(f(c2.weight.detach())), pp(f(c2.bias.detach())), pp(f(c3.weight.detach())), pp(f(c3.bias.detach())),
-                  pp(ws), C, H, W, st)
+        # packed tables of the step: kept while the conditioner is unchanged (version counter + storage of its six tensors) - under
+        # contextflow it is frozen, and a training step otherwise factorises an identity and packs the same tables for every coupling
+        srcs = (c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias)
+        key = (mode, C, H, W, str(dev)) + tuple((t._version, t.data_ptr()) for t in srcs)
+        hit = self.__dict__.get("_ctx_ws")
+        capturing = torch.cuda.is_current_stream_capturing()
+        if hit is not None and hit[0] == key and not capturing:
+            ws = hit[1]
+            torch.cuda.current_stream(dev).wait_event(hit[2])
+        else:
+            eye = torch.eye(C, device=dev, dtype=torch.float32)
+            zero = torch.zeros(C, device=dev, dtype=torch.float32)
+            ws = torch.empty(_hip.lib().cf_flow_step_ws_bytes(C, H, W), device=dev, dtype=torch.uint8)
+            _hip.call("cf_flow_step_prepare", pp(eye), pp(zero), pp(zero), pp(w1), pp(f(c1.bias.detach())),
+                      pp(f(c2.weight.detach())), pp(f(c2.bias.detach())), pp(f(c3.weight.detach())), pp(f(c3.bias.detach())),
+                      pp(ws), C, H, W, st)
+            if not capturing:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                self.__dict__["_ctx_ws"] = (key, ws, ev)
         z = torch.empty(B, C, H, W, device=dev, dtype=torch.float32)
         ldj = torch.zeros(B, device=dev, dtype=torch.float32)
         planes = None
