@@ -175,11 +175,20 @@ def _embedding_grads(emb, context, gc, grads):
         o += d
 
 
-def _linear_bwd(x_in, lin, gy, grads):
+def _linear_bwd(x_in, lin, gy, grads, need_gx=True):
     """nn.Linear of a CN net: weight / bias gradients and the data gradient through cf_linear_wgrad / cf_linear."""
-    gx, gW, gb = _dense_bwd(_hip.f32(x_in), _hip.f32(lin.weight.detach()), _hip.f32(gy))
+    gx, gW, gb = _dense_bwd(_hip.f32(x_in), _hip.f32(lin.weight.detach()), _hip.f32(gy), need_gx)
     grads[lin.weight], grads[lin.bias] = gW, gb
     return gx
+
+
+def _encoder_needs_gc(enc):
+    """False when nothing behind the encoder's output trains (uniform dequantisation / pass-through of a code that is not an
+    embedding lookup): the data gradient of the first CN Linear - a (B, N) x (N, width) product and a transposed copy of its
+    weight per layer and step - is then never read (_encoder_backward returns at once)."""
+    if isinstance(enc[1], (UniformCatDequantization, EyeSampling)):
+        return isinstance(enc[0], CatEmbeddings)
+    return True
 
 
 def _relu_bwd(act, gy):
@@ -197,8 +206,10 @@ def conv1x1_ctx_backward(m, rec, context, gz, gld, grads):
     Wm = _hip.f32(m.NN.detach()) if m.contextflow else None
     _hip.call("cf_conv1x1_ctx_bwd", _hip.p(x), _hip.p(rec["m"]), _hip.p(Wm), _hip.p(gzv), _hip.p(gld), _hip.p(gx), _hip.p(gm),
               B, C, H * W, xbs, gzbs, _hip.stream())
-    gc = _linear_bwd(rec["c"], m.CN, gm, grads)
-    _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W), rec.get("eps"))   # ldj += H W logp_c
+    need = _encoder_needs_gc(m.context_net)
+    gc = _linear_bwd(rec["c"], m.CN, gm, grads, need)
+    if need:
+        _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W), rec.get("eps"))   # ldj += H W logp_c
     return gx
 
 
@@ -212,8 +223,10 @@ def actnorm_ctx_backward(m, rec, context, gz, gld, grads):
     logs = _hip.f32(m.NN_logs.detach()) if m.contextflow else None
     _hip.call("cf_actnorm_ctx_bwd", _hip.p(x), _hip.p(rec["m"]), _hip.p(t), _hip.p(logs), _hip.p(gzv), _hip.p(gld), _hip.p(gx),
               _hip.p(gm), B, C, H * W, xbs, gzbs, _hip.stream())
-    gc = _linear_bwd(rec["c"], m.CN, gm, grads)
-    _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W), rec.get("eps"))   # ldj += H W logp_c
+    need = _encoder_needs_gc(m.context_net)
+    gc = _linear_bwd(rec["c"], m.CN, gm, grads, need)
+    if need:
+        _encoder_backward(m.context_net, context, gc, grads, _hip.f32(gld) * float(H * W), rec.get("eps"))   # ldj += H W logp_c
     return gx
 
 
@@ -222,8 +235,10 @@ def _cn_chain_backward(m, rec, context, gcn, grads, glq):
     encoder's log-density term of the layer's log-det."""
     ga2 = _relu_bwd(rec["a2"], _linear_bwd(rec["a2"], m.CN[4], gcn, grads))
     ga1 = _relu_bwd(rec["a1"], _linear_bwd(rec["a1"], m.CN[2], ga2, grads))
-    gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads)
-    _encoder_backward(m.context_net, context, gc, grads, glq, rec.get("eps"))
+    need = _encoder_needs_gc(m.context_net)
+    gc = _linear_bwd(rec["c"], m.CN[0], ga1, grads, need)
+    if need:
+        _encoder_backward(m.context_net, context, gc, grads, glq() if callable(glq) else glq, rec.get("eps"))
 
 
 def coupling_ctx_backward(m, rec, context, gz, gld, grads):
@@ -264,7 +279,7 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
                   None, None, pp(s_gh), None, None, None, B, C, H, W, xbs, st)
         gcn = _new(B, C, like=x)
         _hip.call("cf_sample_channel_sums", pp(s_gh), pp(gcn), B, C, HW, st)
-        _cn_chain_backward(m, rec, context, gcn, grads, f(gld) * float(HW))      # ldj += H W logp_c (coupling.py:43)
+        _cn_chain_backward(m, rec, context, gcn, grads, lambda: f(gld) * float(HW))      # ldj += H W logp_c (coupling.py:43)
         return gx
     new = lambda rows: torch.empty(B, rows, HW, device=dev, dtype=torch.float32)
     y0, h1, h2, aux = rec["planes"]
@@ -294,7 +309,7 @@ def coupling_ctx_backward(m, rec, context, gz, gld, grads):
     grads[c3.weight], grads[c3.bias] = gw3[0].reshape(c3.weight.shape), gb3
     gcn = _new(B, wc.shape[1], like=x)
     _hip.call("cf_linear", pp(s1), pp(wc.t().contiguous()), None, None, pp(gcn), B, HID, wc.shape[1], 0, st)   # s1 wc
-    _cn_chain_backward(m, rec, context, gcn, grads, f(gld) * float(HW))
+    _cn_chain_backward(m, rec, context, gcn, grads, lambda: f(gld) * float(HW))
     return gx
 
 
