@@ -55,8 +55,15 @@ class Conv1x1(FlowLayer):
         ldj = torch.empty(B, device=x.device, dtype=torch.float32)
         _hip.call("cf_conv1x1_ctx", _hip.p(x), _hip.p(m), _hip.p(Wm), _hip.p(z), _hip.p(ldj), B, C, H * W, xbs, _hip.stream())
         if self.contextflow:
-            lad, _ = slogdet_inverse(Wm, False)
-            ldj = ldj + lad * float(H * W)
+            # H W log|det NN| of the frozen shared matrix: kept while NN is unchanged (one factorisation per layer and call otherwise)
+            key = (self.NN._version, self.NN.data_ptr(), H * W, str(x.device))
+            hit = self.__dict__.get("_lad_cache")
+            if hit is None or hit[0] != key or torch.cuda.is_current_stream_capturing():
+                lad, _ = slogdet_inverse(Wm, False)
+                hit = (key, lad * float(H * W))
+                if not torch.cuda.is_current_stream_capturing():
+                    self.__dict__["_lad_cache"] = hit
+            ldj = ldj + hit[1]
         if tape is not None:
             tape.append(dict(x=x, c=_hip.f32(c), m=m, eps=encoder_noise(self.context_net)))
         return z, ldj + logp_c * float(H * W)

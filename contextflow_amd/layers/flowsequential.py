@@ -123,9 +123,10 @@ class FlowSequential(nn.Module):
         # cost 1-4 ms of host time per call - a captured SMAP training step at a batch of 256 takes 2 ms and ends with this call)
         holders = self.__dict__.get("_cache_holders")
         if holders is None:
-            holders = self.__dict__["_cache_holders"] = [m for m in self.modules() if isinstance(m, (TransCoupling, GaussianMixtureDistribution, Coupling))]
+            holders = self.__dict__["_cache_holders"] = [m for m in self.modules() if isinstance(m, (TransCoupling, GaussianMixtureDistribution, Coupling, Conv1x1))]
         for m in holders:
             d = m.__dict__
+            d.pop("_lad_cache", None)                # Conv1x1 with a context net under contextflow: H W log|det NN|
             d.pop("_ctx_ws", None)                   # Coupling with a context net: packed step tables (forward / backward)
             d.pop("_ctx_wsb", None)
             if "_tab_cache" in d:
