@@ -8,6 +8,8 @@ cf_actnorm_ctx_bwd, the fused MFMA step-backward kernel with the per-sample CN(c
 cf_gmm_ctx_bwd) and turns the per-sample parameter gradients into CN / embedding gradients with library GEMMs.
 Built for the conv couplings with the encoders that have no trainable parameters of their own (eye | onehot + uniform)
 and for embedding lookups (embed + eyesample)."""
+import os
+
 import torch
 
 from . import _hip
@@ -175,11 +177,39 @@ def _embedding_grads(emb, context, gc, grads):
         o += d
 
 
+DEFER_LINEAR_WGRADS = os.environ.get("CONTEXTFLOW_SPEC_DEFER_WGRADS", "1") != "0"      # A/B switch (tools/specialist_train_bench.py)
+_DEFER = "_deferred_linear_wgrads"      # key of `grads`: [(x_in, gy, lin)] whose weight gradients are formed at the end of the backward
+
+
 def _linear_bwd(x_in, lin, gy, grads, need_gx=True):
-    """nn.Linear of a CN net: weight / bias gradients and the data gradient through cf_linear_wgrad / cf_linear."""
-    gx, gW, gb = _dense_bwd(_hip.f32(x_in), _hip.f32(lin.weight.detach()), _hip.f32(gy), need_gx)
-    grads[lin.weight], grads[lin.bias] = gW, gb
+    """nn.Linear of a CN net: weight / bias gradients and the data gradient through cf_linear_wgrad / cf_linear.  With a deferral
+    list in `grads` (the specialist backward) only the data gradient is formed here; the weight gradients of all CN Linears of the
+    flow - 60 operand pairs in the cifar10 flow, 420 launches of 7 - 10 us one by one - leave in grouped launches at the end
+    (_flush_linear_wgrads: cf_linear_wgrad_group, the transformer step's LDS-free kernel)."""
+    defer = grads.get(_DEFER)
+    if defer is None:
+        gx, gW, gb = _dense_bwd(_hip.f32(x_in), _hip.f32(lin.weight.detach()), _hip.f32(gy), need_gx)
+        grads[lin.weight], grads[lin.bias] = gW, gb
+        return gx
+    x_in, gy = _hip.f32(x_in).contiguous(), _hip.f32(gy).contiguous()
+    defer.append((x_in, gy, lin))
+    if not need_gx:
+        return None
+    W2d = _hip.f32(lin.weight.detach())
+    gx = _new(x_in.shape[0], W2d.shape[1], like=gy)
+    _hip.call("cf_linear", _hip.p(gy), _hip.p(W2d.t().contiguous()), None, None, _hip.p(gx), x_in.shape[0], W2d.shape[0], W2d.shape[1], 0,
+              _hip.stream())
     return gx
+
+
+def _flush_linear_wgrads(grads, dev):
+    from .autograd import wgrad_group
+    todo = grads.pop(_DEFER, None) or []
+    for i0 in range(0, len(todo), 32):                  # cf_linear_wgrad_group takes up to 32 members per launch pair
+        part = todo[i0:i0 + 32]
+        res = wgrad_group([(x_in, gy, True) for x_in, gy, _ in part], dev)
+        for (_, _, lin), (gW, gb) in zip(part, res):
+            grads[lin.weight], grads[lin.bias] = gW.view_as(lin.weight), gb
 
 
 def _encoder_needs_gc(enc):
@@ -430,7 +460,7 @@ class SpecialistLogProb(torch.autograd.Function):
         flow, tape, params, context = ctx.flow, ctx.tape, ctx.params, ctx.context
         glogp = _hip.f32(glogp)
         gld = glogp.sum(1).contiguous()
-        grads = {}
+        grads = {_DEFER: []} if DEFER_LINEAR_WGRADS else {}
         gz = gmm_ctx_backward(flow.dist, ctx.prior, glogp, grads)
         for mod, rec in reversed(tape):
             if rec is None:
@@ -452,4 +482,5 @@ class SpecialistLogProb(torch.autograd.Function):
                 gz = transcoupling_ctx_backward(mod, rec, context, gz, gld, grads)
             else:
                 gz = coupling_ctx_backward(mod, rec, context, gz, gld, grads)
+        _flush_linear_wgrads(grads, glogp.device)
         return (None, None, None) + tuple(grads.get(p) for p in params)
