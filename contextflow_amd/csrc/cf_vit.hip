@@ -143,6 +143,7 @@ constexpr int kLinGroup = 48;
 struct LinGroup {
     const float* x[kLinGroup];          // (rows, K) activations; ENC: the encoder's uniforms u (rows, K)
     const float* q[kLinGroup];          // ENC: qbins (K)
+    float* c[kLinGroup];                // ENC: where the code itself goes too (rows, K), or null (training keeps it for the backward)
     const float* W[kLinGroup];          // (N, K)
     const float* b[kLinGroup];          // (N) or null
     float* y[kLinGroup];                // (rows, N)
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void k_linear_group(const LinGroup pg, const i
     __shared__ float ws[LIN_COLS * LIN_KP];
     const float* __restrict__ x = pg.x[g];
     const float* __restrict__ qb = pg.q[g];
+    float* __restrict__ cout = pg.c[g];
     const float* __restrict__ Wt = pg.W[g];
     const float* __restrict__ bias = pg.b[g];
     float* __restrict__ y = pg.y[g];
@@ -197,6 +199,13 @@ __global__ __launch_bounds__(256) void k_linear_group(const LinGroup pg, const i
                         code = (float)crow[k];
                     }
                     xr[i][j] = (code + xr[i][j]) / qb[k];
+                }
+                // the code itself, for callers that need it (first column block only; clamped rows / k positions repeat a neighbour's
+                // store with the same values)
+                if (cout != nullptr && n0 == 0) {
+                    float* cp = cout + (int64_t)(r0 + min(sr + RSTEP * i, rmax)) * K + kc;
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) cp[j] = xr[i][j];
                 }
             }
         }
@@ -628,10 +637,11 @@ int cf_linear(const float* x, const float* Wt, const float* bias, const float* r
 // n Linears over the same rows in one launch (k_linear_group): y_g = act_g(x_g W_g^T + b_g), x_g (rows, K), W_g (N_g, K), b_g (N_g) or
 // null, act_g 0 | 2 (ReLU).  With ctx != null the inputs are FORMED from the integer context (rows, nctx) instead of read:
 // x_g[r, k] = (code(ctx[r], k) + u_g[r, k]) / qbins_g[k] - x[] then holds the uniforms u_g and q[] the encoders' qbins; onehot != 0:
-// code = the concatenated one-hot code with cardinalities card (device int64, nctx entries), else the context itself (K == nctx).
+// code = the concatenated one-hot code with cardinalities card (device int64, nctx entries), else the context itself (K == nctx);
+// c_out (or null; entries may be null): the codes x_g themselves are written there as well (rows, K).
 int cf_linear_group(int n, const float* const* x, const float* const* q, const float* const* W, const float* const* b, float* const* y,
-                    const int* N, const int* act, const int64_t* ctx, const int64_t* card, int nctx, int onehot, int rows, int K,
-                    cf_stream_t stream) {
+                    float* const* c_out, const int* N, const int* act, const int64_t* ctx, const int64_t* card, int nctx, int onehot,
+                    int rows, int K, cf_stream_t stream) {
     if (n == 0 || rows == 0) return 0;
     CF_REQUIRE(n > 0 && x && W && b && y && N && act && rows > 0 && K > 0 && (!ctx || (q && nctx > 0 && (onehot ? card != nullptr : K == nctx))));
     hipStream_t st = cf_s(stream);
@@ -643,7 +653,7 @@ int cf_linear_group(int n, const float* const* x, const float* const* q, const f
         for (int i = 0; i < m; ++i) {
             const int j = i0 + i;
             CF_REQUIRE(x[j] && W[j] && y[j] && N[j] > 0 && (act[j] == 0 || act[j] == 2) && (!ctx || q[j]));
-            pg.x[i] = x[j]; pg.q[i] = ctx ? q[j] : nullptr; pg.W[i] = W[j]; pg.b[i] = b[j]; pg.y[i] = y[j]; pg.N[i] = N[j]; pg.act[i] = act[j];
+            pg.x[i] = x[j]; pg.q[i] = ctx ? q[j] : nullptr; pg.c[i] = (ctx && c_out) ? c_out[j] : nullptr; pg.W[i] = W[j]; pg.b[i] = b[j]; pg.y[i] = y[j]; pg.N[i] = N[j]; pg.act[i] = act[j];
             nmax = N[j] > nmax ? N[j] : nmax;
             vec = vec && ((reinterpret_cast<uintptr_t>(x[j]) | reinterpret_cast<uintptr_t>(W[j])) & 15) == 0;
         }

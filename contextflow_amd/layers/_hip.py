@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # CONTEXTFLOW_HIP_LIB: developer override (A/B builds, probe builds of tools/dev); the default is the in-tree library
 LIB_PATH = os.environ.get("CONTEXTFLOW_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libcontextflow_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_int, _c_i64, _c_f, _c_p = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -92,7 +92,7 @@ SIGNATURES = {
     "cf_linear_wgrad": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_p]),
     "cf_linear_wgrad_x2": (_c_int, [_c_p] * 4 + [_c_int] * 3 + [_c_p]),
     "cf_linear": (_c_int, [_c_p] * 5 + [_c_int] * 4 + [_c_p]),
-    "cf_linear_group": (_c_int, [_c_int] + [_c_p] * 9 + [_c_int] * 4 + [_c_p]),
+    "cf_linear_group": (_c_int, [_c_int] + [_c_p] * 10 + [_c_int] * 4 + [_c_p]),
     "cf_linear_tn": (_c_int, [_c_p] * 3 + [_c_int] * 3 + [_c_p]),
     "cf_layernorm": (_c_int, [_c_p] * 5 + [_c_int] * 3 + [_c_f, _c_p]),
     "cf_attention": (_c_int, [_c_p, _c_p, _c_int, _c_int, _c_int, _c_f, _c_p]),

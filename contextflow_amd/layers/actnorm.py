@@ -75,16 +75,19 @@ class ActNorm(FlowLayer):
                   _hip.p(out), _hip.p(s), B, C, HW, int(inverse), _hip.stream())
         return out, s
 
-    def _forward_ctx(self, x, context, tape=None):
+    def _forward_ctx(self, x, context, tape=None, pre=None):
         """actnorm.py:40-60: per-sample shift / log-scale CN(c), added to the shared ones under contextflow (the only
-        branch that runs the data-dependent init)."""
+        branch that runs the data-dependent init).  pre: code, log-density and CN(c) from the grouped front end (specialist.py)."""
         from .simple_vit import _linear
-        c, logp_c = self.context_net(context)
+        if pre is not None:
+            c, logp_c = pre["c"], pre["logp"]
+        else:
+            c, logp_c = self.context_net(context)
         if self.contextflow and not self._init_done:
             self.initialize(x)
         x, xbs = _hip.bview(x)
         B, C, H, W = x.shape
-        m = _linear(_hip.f32(c), self.CN)                   # (B, 2C)
+        m = pre["m"] if pre is not None else _linear(_hip.f32(c), self.CN)      # (B, 2C)
         t = _hip.f32(self.NN_t.detach()) if self.contextflow else None
         logs = _hip.f32(self.NN_logs.detach()) if self.contextflow else None
         z = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)

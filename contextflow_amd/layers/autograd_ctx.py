@@ -422,19 +422,24 @@ class SpecialistLogProb(torch.autograd.Function):
         B, M = x.shape[0], flow.mixtures
         tape = []
         logdet = torch.zeros(B, M, device=x.device, dtype=torch.float32)
+        # everything the CN nets compute from the context alone, for all layers at once (the uniform encoders' codes are formed
+        # inside the first grouped launch and kept for the backward): 36 encodings + 60 Linears one by one otherwise
+        from . import specialist
+        specialist._draw_encoder_noise(flow, B, x.device)
+        pre = specialist._front_end(flow, context, B, x.device, train=True)
         for mod in flow.sequence_modules:
             rec = []
             if isinstance(mod, Conv1x1) and mod.context_net:
                 _check_encoder(mod.context_net)
-                x, ldj = mod._forward_ctx(x, context, rec)
+                x, ldj = mod._forward_ctx(x, context, rec, pre.get(id(mod)))
             elif isinstance(mod, ActNorm) and mod.context_net:
                 _check_encoder(mod.context_net)
-                x, ldj = mod._forward_ctx(x, context, rec)
+                x, ldj = mod._forward_ctx(x, context, rec, pre.get(id(mod)))
             elif type(mod) is Coupling and mod.context_net:
                 _check_encoder(mod.context_net)
                 if not mod._fused_ctx_ok(x):
                     raise NotImplementedError("specialist training needs the fused coupling geometry (3x3, C in 8..64)")
-                x, ldj = mod._fused_ctx(x, context, rec)
+                x, ldj = mod._fused_ctx(x, context, rec, pre.get(id(mod)))
             elif isinstance(mod, TransCoupling) and mod.context_net:
                 _check_encoder(mod.context_net)
                 x, ldj = mod._forward_ctx(x, context, rec)

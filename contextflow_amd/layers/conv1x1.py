@@ -42,14 +42,18 @@ class Conv1x1(FlowLayer):
             if self.contextflow:
                 self.NN.requires_grad_(False)
 
-    def _forward_ctx(self, x, context, tape=None):
+    def _forward_ctx(self, x, context, tape=None, pre=None):
         """conv1x1.py:34-50: per-sample triangular matrix from CN(c).  `tape` (training): receives what the backward
-        needs - the encoder is stochastic, so its output must be kept, not recomputed."""
+        needs - the encoder is stochastic, so its output must be kept, not recomputed.  pre: the code, its log-density and CN(c)
+        already formed by the grouped front end (layers/specialist.py::_front_end, train form)."""
         from .simple_vit import _linear
-        c, logp_c = self.context_net(context)
         x, xbs = _hip.bview(x)
         B, C, H, W = x.shape
-        m = _linear(_hip.f32(c), self.CN)                  # (B, C*C)
+        if pre is not None:
+            c, logp_c, m = pre["c"], pre["logp"], pre["m"]
+        else:
+            c, logp_c = self.context_net(context)
+            m = _linear(_hip.f32(c), self.CN)              # (B, C*C)
         Wm = _hip.f32(self.NN.detach()) if self.contextflow else None
         z = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
         ldj = torch.empty(B, device=x.device, dtype=torch.float32)

@@ -109,16 +109,19 @@ class Coupling(_AffineCoupling):
         h = conv2d_reflect(h1, self.NN[2], True)
         return conv2d_reflect(h, self.NN[4], False), logp_c
 
-    def _fused_ctx(self, x, context, tape=None):
+    def _fused_ctx(self, x, context, tape=None, pre=None):
         """The Coupling layer as ONE fp32-MFMA kernel (the fused flow-step kernel with an identity 1x1 / ActNorm in
         front) with the CN(c) term as a per-sample bias: on the conditioner output (contextflow) or before its first
         ReLU (CN(c) concatenated to the conditioner input: W[:, D:] CN(c))."""
         from .simple_vit import _linear
-        c, logp_c = self.context_net(context)
-        c = _hip.f32(c)
-        a1 = _linear(c, self.CN[0], act=2)
-        a2 = _linear(a1, self.CN[2], act=2)
-        cn = _linear(a2, self.CN[4])                                                              # (B, O)
+        if pre is not None:          # code, log-density and the CN chain from the grouped front end (layers/specialist.py, train form)
+            c, logp_c, a1, a2, cn = pre["c"], pre["logp"], pre["a1"], pre["a2"], pre["cn"]
+        else:
+            c, logp_c = self.context_net(context)
+            c = _hip.f32(c)
+            a1 = _linear(c, self.CN[0], act=2)
+            a2 = _linear(a1, self.CN[2], act=2)
+            cn = _linear(a2, self.CN[4])                                                          # (B, O)
         x, xbs = _hip.bview(x)
         B, C, H, W = x.shape
         D = C // 2

@@ -171,11 +171,14 @@ def _uniform_encoder(net):
     return None
 
 
-def _front_end(flow, context, B, dev):
+def _front_end(flow, context, B, dev, train=False):
     """Everything a specialist flow computes from the CONTEXT ALONE, ahead of the data path and in three launches instead of ~96:
     the code of every uniform context encoder is formed inside the first Linear that consumes it (Conv1x1.CN, ActNorm.CN,
     Coupling.CN[0]: one grouped launch, cf_linear_group with ctx), then the second and third Linears of the coupling CN nets
-    (one grouped launch each).  Returns {id(layer): tensor}: Conv1x1 -> (m1, blocked), ActNorm -> m2, Coupling -> CN(c)."""
+    (one grouped launch each).  Returns {id(layer): tensor}: Conv1x1 -> (m1, blocked), ActNorm -> m2, Coupling -> CN(c).
+    train (layers/autograd_ctx.py): the training forward's form - every intermediate the backward needs is kept and returned as
+    {id(layer): dict(c=code, logp=log-density of the code, m=CN(c) | a1=.., a2=.., cn=..)}, the per-sample matrix in full (C, C) form,
+    couplings with and without contextflow."""
     import ctypes
     mods, n = flow.sequence_modules, len(flow.sequence_modules)
     if context is None or context.dim() != 2 or not FRONT_END:
@@ -194,7 +197,7 @@ def _front_end(flow, context, B, dev):
             enc0 = (key, enc, card, onehot)
         if isinstance(m, (Conv1x1, ActNorm)):
             first_lin = m.CN
-        elif type(m) is Coupling and m.contextflow:
+        elif type(m) is Coupling and (m.contextflow or train):
             first_lin = m.CN[0]
         else:
             continue
@@ -209,31 +212,38 @@ def _front_end(flow, context, B, dev):
             if u is None or u.shape != (B, enc.D):
                 u = torch.rand((B, enc.D), device=dev, dtype=torch.float32)
         u = f(u.to(dev))                                   # raw pointers travel in host arrays below: everything on `dev`, fp32, dense
+        cbuf, lc = None, None
+        if train:
+            cbuf = torch.empty(B, enc.D, device=dev, dtype=torch.float32)
+            lc = getattr(enc, "_lc", None)
+            if lc is None or lc.device != dev:
+                lc = enc._lc = (enc.ldj_per_dim * enc.D).sum(-1).reshape(1)             # dequantize.py:62, as UniformCatDequantization.encode
+            lc = lc.expand(B)
         if isinstance(m, Conv1x1):
             C = m.D
-            nblk = _hip.lib().cf_affine_ctx_blocked_floats(C, m.H, m.W)
+            nblk = 0 if train else _hip.lib().cf_affine_ctx_blocked_floats(C, m.H, m.W)
             if nblk and nblk < C * C:
                 w, b = _cn_blocked(flow, m, C, dev)
                 blocked = 1
             else:
                 w, b, blocked = f(m.CN.weight.detach()), f(m.CN.bias.detach()), 0
             y = torch.empty(B, w.shape[0], device=dev, dtype=torch.float32)
-            first.append((u, enc.qbins, w, b, y, 0))
-            out[id(m)] = (y, blocked)
+            first.append((u, enc.qbins, w, b, y, 0, cbuf))
+            out[id(m)] = dict(c=cbuf, logp=lc, m=y) if train else (y, blocked)
         elif isinstance(m, ActNorm):
             w, b = f(m.CN.weight.detach()), f(m.CN.bias.detach())
             y = torch.empty(B, w.shape[0], device=dev, dtype=torch.float32)
-            first.append((u, enc.qbins, w, b, y, 0))
-            out[id(m)] = y
-        elif type(m) is Coupling and m.contextflow:
+            first.append((u, enc.qbins, w, b, y, 0, cbuf))
+            out[id(m)] = dict(c=cbuf, logp=lc, m=y) if train else y
+        elif type(m) is Coupling and (m.contextflow or train):
             l0, l1, l2 = m.CN[0], m.CN[2], m.CN[4]
             a1 = torch.empty(B, l0.weight.shape[0], device=dev, dtype=torch.float32)
             a2 = torch.empty(B, l1.weight.shape[0], device=dev, dtype=torch.float32)
             cn = torch.empty(B, l2.weight.shape[0], device=dev, dtype=torch.float32)
-            first.append((u, enc.qbins, f(l0.weight.detach()), f(l0.bias.detach()), a1, 2))
-            second.append((a1, None, f(l1.weight.detach()), f(l1.bias.detach()), a2, 2))
-            third.append((a2, None, f(l2.weight.detach()), f(l2.bias.detach()), cn, 0))
-            out[id(m)] = cn
+            first.append((u, enc.qbins, f(l0.weight.detach()), f(l0.bias.detach()), a1, 2, cbuf))
+            second.append((a1, None, f(l1.weight.detach()), f(l1.bias.detach()), a2, 2, None))
+            third.append((a2, None, f(l2.weight.detach()), f(l2.bias.detach()), cn, 0, None))
+            out[id(m)] = dict(c=cbuf, logp=lc, a1=a1, a2=a2, cn=cn) if train else cn
     if not first:
         return {}
     _, enc, card, onehot = enc0
@@ -250,7 +260,7 @@ def _front_end(flow, context, B, dev):
             arr = lambda j: (ctypes.c_void_p * nn_)(*[(pr[j].data_ptr() if pr[j] is not None else None) for pr in ps])
             Ns = (ctypes.c_int * nn_)(*[pr[2].shape[0] for pr in ps])
             acts = (ctypes.c_int * nn_)(*[pr[5] for pr in ps])
-            _hip.call("cf_linear_group", nn_, arr(0), arr(1), arr(2), arr(3), arr(4), Ns, acts,
+            _hip.call("cf_linear_group", nn_, arr(0), arr(1), arr(2), arr(3), arr(4), arr(6) if (with_ctx and train) else None, Ns, acts,
                       _hip.p(ctx) if with_ctx else None, _hip.p(card) if (with_ctx and card is not None) else None,
                       ctx.shape[1] if with_ctx else 0, onehot if with_ctx else 0, B, k, st)
     launch(first, enc.D, True)

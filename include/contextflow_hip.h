@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 12
+#define CF_ABI_VERSION 13
 #define CF_ERR_ARG (-1)          /* bad argument (shape, null pointer, unsupported size) */
 #define CF_ERR_UNSUPPORTED (-2)  /* shape not covered by this kernel; caller uses the generic path */
 
@@ -365,10 +365,11 @@ int cf_linear_tn(const float* x, const float* W, float* y, int rows, int K, int 
  * act_g 0 | 2 (ReLU); host arrays of n device pointers / ints.  With ctx != NULL the inputs are formed from the integer context
  * (rows, nctx) while they are staged - the uniform dequantisation of the context encoders (model.py:30-90, dequantize.py:55-64):
  * x_g[r,k] = (code(ctx[r], k) + u_g[r,k]) / qbins_g[k]; x[] then holds the uniforms u_g (rows, K), q[] the qbins (K); onehot != 0: code
- * = concatenated one-hot code with cardinalities card (device int64[nctx]), else the context itself (K == nctx). */
+ * = concatenated one-hot code with cardinalities card (device int64[nctx]), else the context itself (K == nctx).  c_out (NULL, or n
+ * pointers of which any may be NULL): the formed codes x_g (rows, K) are stored there too - the training forward keeps them. */
 int cf_linear_group(int n, const float* const* x, const float* const* q, const float* const* W, const float* const* b, float* const* y,
-                    const int* N, const int* act, const int64_t* ctx, const int64_t* card, int nctx, int onehot, int rows, int K,
-                    cf_stream_t stream);
+                    float* const* c_out, const int* N, const int* act, const int64_t* ctx, const int64_t* card, int nctx, int onehot,
+                    int rows, int K, cf_stream_t stream);
 /* backward of cf_linear w.r.t. its parameters: gW (N,K) = gy^T x, gb (N) = column sums of gy (gb may be NULL); split-K
  * fp32-MFMA GEMM over the rows, partials in ws (cf_linear_wgrad_ws_bytes) summed in a fixed order.  Any K, N (wide
  * problems run as column blocks of at most 128 outputs x 255 inputs).  cf_linear_wgrad_x2: the same with x squared

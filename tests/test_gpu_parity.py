@@ -268,8 +268,9 @@ def test_grouped_linears_with_the_context_code_formed_in_the_kernel(L, onehot, K
         arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in ts])
         iarr = lambda v: (ctypes.c_int * n)(*v)
         pp, st = _hip.p, _hip.stream()
-        _hip.call("cf_linear_group", n, arr(us), arr(qs), arr(Ws), arr(bs), arr(ys), iarr(Ns), iarr(acts), pp(ctx), pp(card) if onehot else None,
-                  len(cards), onehot, B, K, st)
+        cs = [torch.full((B, K), float("nan"), device=DEV) if g != 1 else None for g in range(n)]      # the codes too (one problem without)
+        _hip.call("cf_linear_group", n, arr(us), arr(qs), arr(Ws), arr(bs), arr(ys), arr(cs), iarr(Ns), iarr(acts), pp(ctx),
+                  pp(card) if onehot else None, len(cards), onehot, B, K, st)
         xs = []
         for g in range(n):
             c = torch.empty(B, K, device=DEV)
@@ -278,11 +279,12 @@ def test_grouped_linears_with_the_context_code_formed_in_the_kernel(L, onehot, K
             want = torch.empty(B, Ns[g], device=DEV)
             _hip.call("cf_linear", pp(c), pp(Ws[g]), pp(bs[g]), None, pp(want), B, K, Ns[g], acts[g], st)
             assert torch.equal(ys[g], want), (B, g)
+            assert cs[g] is None or torch.equal(cs[g], c), (B, g)
             xs.append(c)
         # plain grouped Linears (no context), one problem without a bias
         ys2 = [torch.full((B, N), float("nan"), device=DEV) for N in Ns]
         bs2 = [bs[0], None, bs[2], bs[3]]
-        _hip.call("cf_linear_group", n, arr(xs), None, arr(Ws), arr(bs2), arr(ys2), iarr(Ns), iarr(acts), None, None, 0, 0, B, K, st)
+        _hip.call("cf_linear_group", n, arr(xs), None, arr(Ws), arr(bs2), arr(ys2), None, iarr(Ns), iarr(acts), None, None, 0, 0, B, K, st)
         for g in range(n):
             want = torch.empty(B, Ns[g], device=DEV)
             _hip.call("cf_linear", pp(xs[g]), pp(Ws[g]), pp(bs2[g]), None, pp(want), B, K, Ns[g], acts[g], st)

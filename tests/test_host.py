@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
     for s in syms:
         assert hasattr(lib, s), "header declares %s but the library does not export it" % s
     assert sorted(_hip.SIGNATURES) == syms, set(_hip.SIGNATURES) ^ set(syms)
-    assert _hip.lib().cf_abi_version() == _hip.ABI_VERSION == 12
+    assert _hip.lib().cf_abi_version() == _hip.ABI_VERSION == 13
     # pure host-side queries work without a GPU
     assert _hip.lib().cf_flow_step_supported(64, 4, 4, 3, 3) == 1
     assert _hip.lib().cf_flow_step_supported(26, 8, 1, 3, 1) == 0

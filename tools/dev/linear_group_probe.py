@@ -12,7 +12,7 @@ def run(Ns, label):
     Ws = [torch.randn(N, K, device=dev) for N in Ns]; bs = [torch.randn(N, device=dev) for N in Ns]
     ys = [torch.empty(B, N, device=dev) for N in Ns]
     arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts]); iarr = lambda v: (ctypes.c_int * n)(*v)
-    f = lambda: _hip.call("cf_linear_group", n, arr(us), arr(qs), arr(Ws), arr(bs), arr(ys), iarr(Ns), iarr([0] * n), _hip.p(ctx), _hip.p(card), 2, 1, B, K, _hip.stream())
+    f = lambda: _hip.call("cf_linear_group", n, arr(us), arr(qs), arr(Ws), arr(bs), arr(ys), None, iarr(Ns), iarr([0] * n), _hip.p(ctx), _hip.p(card), 2, 1, B, K, _hip.stream())
     for _ in range(3): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,7 +21,7 @@ def run(Ns, label):
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 10
     byt = sum(B * N * 4 for N in Ns)
-    g = lambda: _hip.call("cf_linear_group", n, arr(us), None, arr(Ws), arr(bs), arr(ys), iarr(Ns), iarr([0] * n), None, None, 0, 0, B, K, _hip.stream())
+    g = lambda: _hip.call("cf_linear_group", n, arr(us), None, arr(Ws), arr(bs), arr(ys), None, iarr(Ns), iarr([0] * n), None, None, 0, 0, B, K, _hip.stream())
     g(); torch.cuda.synchronize()
     e0.record()
     for _ in range(10): g()
