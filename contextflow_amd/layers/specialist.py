@@ -181,7 +181,7 @@ def _front_end(flow, context, B, dev, train=False):
     couplings with and without contextflow."""
     import ctypes
     mods, n = flow.sequence_modules, len(flow.sequence_modules)
-    if context is None or context.dim() != 2 or not FRONT_END:
+    if not torch.is_tensor(context) or context.dim() != 2 or not FRONT_END:
         return {}
     f = _hip.f32
     first, second, third, out = [], [], [], {}
