@@ -86,7 +86,16 @@ class Conv1x1(FlowLayer):
         _hip.require_device(z, self.NN)
         if self.context_net:
             raise NotImplementedError("Conv1x1.reverse with a context net (the reference's own is marked 'to update')")
-        _, inv = slogdet_inverse(_hip.f32(self.NN.detach()), True)
+        # W^-1 follows NN's version counter and storage (`sample` inverts every layer's matrix per call otherwise)
+        key = (self.NN._version, self.NN.data_ptr(), str(z.device))
+        hit = self.__dict__.get("_winv_cache")
+        capturing = torch.cuda.is_current_stream_capturing()
+        if hit is None or hit[0] != key or capturing:
+            _, inv = slogdet_inverse(_hip.f32(self.NN.detach()), True)
+            if not capturing:
+                self.__dict__["_winv_cache"] = (key, inv)
+        else:
+            inv = hit[1]
         return conv1x1_apply(z, inv)                       # conv1x1.py:72
 
     def logdet(self, input, context=None):

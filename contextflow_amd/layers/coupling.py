@@ -389,9 +389,21 @@ class TransCoupling(_AffineCoupling):
         L = _hip.lib()
         flat = self._flat_params()
         assert flat.numel() == L.cf_vit_flat_params(pd, dim, depth)
-        ws = torch.empty(L.cf_vit_ws_bytes(pd, dim, depth), device=x.device, dtype=torch.uint8)
         st = _hip.stream()
-        _hip.call("cf_vit_prepare", _hip.p(flat), _hip.p(ws), pd, dim, depth, st)
+        # the packed table follows the flat parameter tensor (rebuilt when a version counter moves): packed once per parameter version,
+        # not once per call (`sample` walks eight such layers per call)
+        hit = self.__dict__.get("_fused_ws")
+        capturing = torch.cuda.is_current_stream_capturing()
+        if hit is not None and hit[0] is flat and hit[1] == (pd, dim, depth, str(x.device)) and not capturing:
+            ws = hit[2]
+            torch.cuda.current_stream(x.device).wait_event(hit[3])
+        else:
+            ws = torch.empty(L.cf_vit_ws_bytes(pd, dim, depth), device=x.device, dtype=torch.uint8)
+            _hip.call("cf_vit_prepare", _hip.p(flat), _hip.p(ws), pd, dim, depth, st)
+            if not capturing:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(x.device))
+                self.__dict__["_fused_ws"] = (flat, (pd, dim, depth, str(x.device)), ws, ev)
         if vit.pos_embedding.device != x.device:
             vit.pos_embedding = vit.pos_embedding.to(x.device).contiguous()
         z = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)

@@ -127,6 +127,8 @@ class FlowSequential(nn.Module):
         for m in holders:
             d = m.__dict__
             d.pop("_lad_cache", None)                # Conv1x1 with a context net under contextflow: H W log|det NN|
+            d.pop("_winv_cache", None)               # Conv1x1.reverse: W^-1
+            d.pop("_fused_ws", None)                 # TransCoupling._fused: packed ViT table
             d.pop("_ctx_ws", None)                   # Coupling with a context net: packed step tables (forward / backward)
             d.pop("_ctx_wsb", None)
             if "_tab_cache" in d:
