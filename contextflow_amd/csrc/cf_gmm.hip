@@ -554,6 +554,23 @@ __global__ __launch_bounds__(256) void k_gmm_sample(const float* __restrict__ mG
     }
 }
 
+// ... 16 bytes per lane, the sample index by a 32-bit division per FOUR elements (the scalar form above spends a 64-bit division per
+// element: 142 us for 16 384 x 2 048 values, 0.95 TB/s)
+__global__ __launch_bounds__(256) void k_gmm_sample4(const float* __restrict__ mG, const float* __restrict__ sG,
+                                                     const int64_t* __restrict__ rows, const float* __restrict__ eps,
+                                                     float* __restrict__ out, int D4, int total4) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+        const int n = i / D4, d4 = i - n * D4;
+        const int64_t r = rows[n] * D4 + d4;
+        const float4 m = reinterpret_cast<const float4*>(mG)[r], sg = reinterpret_cast<const float4*>(sG)[r];
+        const float4 e = reinterpret_cast<const float4*>(eps)[i];
+        float4 o;
+        o.x = fmaf(softplus_ref(sg.x), e.x, m.x); o.y = fmaf(softplus_ref(sg.y), e.y, m.y);
+        o.z = fmaf(softplus_ref(sg.z), e.z, m.z); o.w = fmaf(softplus_ref(sg.w), e.w, m.w);
+        reinterpret_cast<float4*>(out)[i] = o;
+    }
+}
+
 // D-split heuristic: enough workgroups to cover the chip (~2 per CU), chunks stay multiples of DC
 // ---- parameter sums of the mixture backward: S0[mk] = sum_b r[b][mk], S1[mk][d] = sum_b r[b][mk] x[b][d],
 // S2[mk][d] = sum_b r[b][mk] x[b][d]^2 - one (MK x B)(B x D) product with two right-hand sides.  MK = 80 rows are five
@@ -722,7 +739,15 @@ int cf_gmm_sample(const float* mG, const float* sG, const int64_t* rows, const f
     if (total == 0) return 0;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    k_gmm_sample<<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(mG, sG, rows, eps, out, D, total);
+    const bool vec = D % 4 == 0 && total / 4 < (1ll << 31) &&
+                     ((reinterpret_cast<uintptr_t>(mG) | reinterpret_cast<uintptr_t>(sG) | reinterpret_cast<uintptr_t>(eps) |
+                       reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vec) {
+        int64_t b4 = (total / 4 + 255) / 256;
+        if (b4 > 16384) b4 = 16384;
+        k_gmm_sample4<<<dim3((unsigned)b4), dim3(256), 0, cf_s(stream)>>>(mG, sG, rows, eps, out, D / 4, (int)(total / 4));
+    } else
+        k_gmm_sample<<<dim3((unsigned)blocks), dim3(256), 0, cf_s(stream)>>>(mG, sG, rows, eps, out, D, total);
     CF_LAUNCH_CHECK();
     return 0;
 }
