@@ -532,6 +532,47 @@ def secondary_specialist(name, dev, B, iters, cpu):
     return out
 
 
+def secondary_specialist_training(name, dev, B, iters):
+    """SURVEY.md 8(f)2, training: one eager training step of the specialist flow under --contextflow (README: the generalist is frozen,
+    the CN nets train) - forward through the grouped context front end, hand-written backward, torch.optim.AdamW; the loss of
+    experiment_cl.py:128-133's classification term.  No CPU leg (the oracle has no specialist backward)."""
+    import contextflow_amd as cfa
+    ctx = SPECIALIST_CTX[name]
+    torch.manual_seed(0)
+    cfg, ds, M = cfa.preset_config(name)
+    cfg.update(generalist=False, enc_emb=ctx["enc_emb"], enc_type=ctx["enc_type"], contextflow=ctx["contextflow"])
+    model = cfa.create_model(cfg, ds, M, contexts=ctx["contexts"]).to(dev)
+    x = synth(name, B, dev, seed=5100)
+    gt = torch.randint(0, M, (B,), device=dev)
+    context = torch.stack([torch.randint(0, k, (B,), device=dev) for k in ctx["contexts"]], 1)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    dim_inv = 1.0 / (ds[0] * ds[1] * ds[2])
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(dim_inv * model.log_prob(x, context), gt)
+        loss.backward()
+        opt.step()
+        return loss.detach()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    out = {"metric": "samples/s specialist training step (--contextflow: fwd + bwd + AdamW, eager), %s" % LABEL[name], "value": round(B / dt, 1),
+           "unit": "samples/s",
+           "config": {"workload": "%s --coupling %s --contextflow, enc %s + %s, contexts %s" % (name, cfg["coupling"], ctx["enc_emb"], ctx["enc_type"], ctx["contexts"]),
+                      "batch": B, "iters": iters, "trainable_tensors": len(params), "launch": "eager"},
+           "ms_per_step": round(dt * 1e3, 3), "loss": round(float(loss), 5), "finite": bool(torch.isfinite(loss))}
+    del model, x, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary_small_batch(name, dev, B, cpu, iters=300):
     """The reference's operating point (config.py:10: batch 256; BASELINE config 1: 64): latency of ONE eval forward
     through the public API (`flow.log_prob(x)` under no_grad), eagerly launched and - the default once a shape repeats -
@@ -787,6 +828,7 @@ def main():
                 secondary_training("smap", dev, 256, 50, graph=True),                  # ... at the reference's batch (config.py:10)
                 secondary_training("smap", dev, 256, 50, graph=True, own_adamw=True),
                 secondary_specialist("cifar10", dev, 32768, 5, cpu),                   # --contextflow specialist forward
+                secondary_specialist_training("cifar10", dev, 8192, 5),                # ... and its training step
                 secondary_sampling("mnist", dev, 16384, 10, cpu),                      # SURVEY 8(f)3 / north_star "forward+inverse": flow.sample
                 secondary_sampling("cifar10", dev, 16384, 10, cpu=False),              # (SplitPrior.reverse by specification: no reference / oracle chain)
             ]
