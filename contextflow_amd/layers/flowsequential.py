@@ -115,6 +115,8 @@ class FlowSequential(nn.Module):
         self._graphs.clear()
         self._graph_policy.clear()                   # the replay-vs-eager verdicts are measured again
         self._tensors = None                         # a Parameter OBJECT may have been replaced (load_state_dict(assign=True), m.w = nn.Parameter(..))
+        self.__dict__.pop("_fusable_ok", None)       # (an ActNorm may have been reset)
+        self.__dict__.pop("_all_params", None)
         self.__dict__.pop("_spec_ws", None)          # layers/specialist.py: packed coupling tables, log|det NN| of frozen Conv1x1,
         self.__dict__.pop("_spec_lad", None)         # Conv1x1.CN in blocked row order
         self.__dict__.pop("_spec_cnb", None)
@@ -166,6 +168,11 @@ class FlowSequential(nn.Module):
     def _fusable(self):
         if not self.fused or not isinstance(self.dist, GaussianMixtureDistribution):
             return False
+        # a positive answer holds until the module tree changes (`_gen`) or the caches are dropped: the walk below - ~50 layers through
+        # nn.Module.__getattr__ - costs 90 us of host time, per forward call, and an eager training step is host-bound
+        ok = self.__dict__.get("_fusable_ok")
+        if ok is not None and ok[0] == self._gen and all(a._init_done for a in ok[1]):      # (a loaded state_dict may reset an ActNorm)
+            return True
         if getattr(self.dist, "context_net", None):
             return False                     # specialist models run layer by layer (per-sample parameters)
         for m in self.sequence_modules:
@@ -173,7 +180,15 @@ class FlowSequential(nn.Module):
                 return False
             if isinstance(m, ActNorm) and not m.is_initialized():
                 return False
+        self.__dict__["_fusable_ok"] = (self._gen, [m for m in self.sequence_modules if isinstance(m, ActNorm)])
         return True
+
+    def _trainable_params(self):
+        """The parameters with requires_grad, in `parameters()` order; the flat parameter list is kept until the module tree changes."""
+        allp = self.__dict__.get("_all_params")
+        if allp is None or allp[0] != self._gen:
+            allp = self.__dict__["_all_params"] = (self._gen, list(self.parameters()))
+        return [p for p in allp[1] if p.requires_grad]
 
     def _specialist(self):
         return bool(getattr(self.dist, "context_net", None))
@@ -632,7 +647,7 @@ class FlowSequential(nn.Module):
             self.invalidate_caches()
         if torch.is_grad_enabled() and self._specialist():
             from .autograd_ctx import trainable as _trainable
-            params = [p for p in self.parameters() if p.requires_grad]
+            params = self._trainable_params()
             if params and _trainable(self):  # specialist training under contextflow (autograd_ctx.py); other
                                              # specialist models evaluate only: they fall through to the no_grad path
                 if any(isinstance(m, ActNorm) and m.contextflow and not m.is_initialized() for m in self.sequence_modules):
@@ -641,7 +656,7 @@ class FlowSequential(nn.Module):
                 from .autograd_ctx import SpecialistLogProb
                 return SpecialistLogProb.apply(self, input, context, *params)
         if torch.is_grad_enabled():
-            params = [p for p in self.parameters() if p.requires_grad]
+            params = self._trainable_params()
             if params and not self._fusable() and self._needs_only_init():
                 with torch.no_grad():        # first training call: the ActNorm data-dependent init (actnorm.py:28-35)
                     self._forward_layers(input, context)
