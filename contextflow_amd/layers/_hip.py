@@ -213,9 +213,25 @@ class _Stream(ctypes.c_void_p):
     """hipStream_t argument produced by `stream()`: `call` re-derives it from the device of the tensor arguments."""
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # (device index) -> hipStream_t as an integer
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream(device=None):
     """torch's current stream on `device` (default: the current device).  Passed to `call`, it is only a placeholder:
-    `call` substitutes the current stream of the device the tensor arguments live on."""
+    `call` substitutes the current stream of the device the tensor arguments live on.
+    (torch.cuda.current_stream() builds a Stream object through three layers of device-index resolution: 8 us per call, 65 calls
+    per eager training step; the raw query torch itself uses for its compiled kernels returns the same handle in 0.3 us.)"""
+    if _raw_stream is not None and _raw_device is not None:
+        if device is None:
+            idx = _raw_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = torch.device(device).index
+            if idx is None:
+                idx = _raw_device()
+        return _Stream(_raw_stream(idx))
     return _Stream(torch.cuda.current_stream(device).cuda_stream)
 
 

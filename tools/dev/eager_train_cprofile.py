@@ -30,6 +30,7 @@ t0 = time.perf_counter()
 for _ in range(steps): step()
 torch.cuda.synchronize()
 print("eager step %.3f ms" % ((time.perf_counter() - t0) / steps * 1e3))
+torch.autograd.set_multithreading_enabled(False)       # the backward runs in this thread: visible to cProfile
 pr = cProfile.Profile(); pr.enable()
 for _ in range(steps): step()
 torch.cuda.synchronize()
