@@ -240,6 +240,8 @@ def device_of(args):
     different devices in one call are a caller bug and raise."""
     dev = None
     for a in args:
+        if a.__class__ not in _WRAPPED:              # ints, floats, streams, None: nothing to look at (a failing getattr costs more)
+            continue
         t = getattr(a, "_keep", None)
         if t is None:
             continue
@@ -327,3 +329,6 @@ def p(t):
     ptr = _Ptr(t.data_ptr())
     ptr._keep = t
     return ptr
+
+
+_WRAPPED = (_Ptr, _PtrArray)             # the argument wrappers that carry tensors (device_of)
