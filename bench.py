@@ -32,7 +32,7 @@ LABEL = {"cifar10": "CIFAR-10C conv flow", "mnist": "MNIST-R conv flow", "smap":
 #  smap: k_vit_step = Conv1x1 26x26x8 + SimpleViT linears 454 688 + attention QK^T / PV 12 288 MAC = 944 768 flop (the
 #        library reports it, and what its MFMAs execute: cf_vit_step_macs).
 VIT_STEP = {"smap": (26, 6)}                                              # (C, depth) of the one-kernel transformer step
-TRAFFIC_JSON = {"cifar10": "r4_prof3_traffic.json", "mnist": "r4_mnist2_traffic.json", "smap": "r4_smap2_traffic.json"}
+TRAFFIC_JSON = {"cifar10": "r4_prof4_traffic.json", "mnist": "r4_mnist2_traffic.json", "smap": "r4_smap2_traffic.json"}
 
 
 def vit_flop_per_sample(name, what):
